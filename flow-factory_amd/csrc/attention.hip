@@ -1,0 +1,208 @@
+// mi355_flow -- joint text-image attention (ops K7/K10 of SURVEY.md 2.3): non-causal
+// softmax(q k^T / sqrt(64)) v, head_dim 64, flash-style online softmax, for gfx950.
+//
+// Layout in HBM (written by the q/k/v GEMM epilogues):
+//   q, k : [B][H][S_pad][64] bf16 (per-head RMSNorm already applied)
+//   vT   : [B][H][64][S_pad] bf16 (keys contiguous: the PV MFMA A-operand needs 8 consecutive keys)
+//
+// One workgroup = 8 waves = 256 queries of one (b, h); each wave owns 32 queries and keeps
+// everything per-query LANE-LOCAL:
+//   S^T tile = K . Q^T      v_mfma_f32_32x32x16_bf16(A = K rows, B = Q rows): the accumulator lane
+//                           holds ONE query (lane&31) and 16 keys per 32-key block, so row max / row
+//                           sum are in-register reductions + one xor-32 exchange;
+//   O^T     += V^T . P^T    (A = V^T rows (d), B = P): the lane again holds ONE query, so the online
+//                           softmax rescale is a per-lane scalar multiply.
+// K rows are fed to the first MFMA in a permuted order (pi below) chosen so that the 16 S^T
+// registers of a 32-key block, converted to bf16 in register order, ARE the B-operand fragments of
+// the second MFMA (8 consecutive keys per lane): P never touches LDS and needs no cross-lane moves.
+// K / V^T tiles (64 keys) are staged by global_load_lds into a 2-deep LDS ring with the same
+// XOR-swizzled 128-byte rows as the GEMM (conflict-free ds_read_b128).
+#include "kernels.h"
+
+namespace mi355 {
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int KV = 64;          // keys per tile
+constexpr int QW = 32;          // queries per wave
+constexpr int NWAVE = 8;
+constexpr int QB = QW * NWAVE;  // queries per workgroup
+constexpr int TILE_BYTES = KV * 64 * 2;          // 8 KiB (K tile, and V^T tile)
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // K + V^T
+constexpr float SCALE_LOG2E = 0.125f * 1.4426950408889634f;
+
+// MFMA output row i (0..31) -> key offset inside the 32-key block
+__device__ __forceinline__ int key_perm(int i) {
+    const int a = i >> 3, g = (i >> 2) & 1, b = i & 3;
+    return 16 * (a >> 1) + 8 * g + 4 * (a & 1) + b;
+}
+
+__global__ __launch_bounds__(NWAVE * 64) void attn_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, lg = lane >> 5;
+    const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const long bh = (long)b * p.H + h;
+    const bf16_t* Qg = p.q + bh * p.S_pad * 64;
+    const bf16_t* Kg = p.k + bh * p.S_pad * 64;
+    const bf16_t* Vg = p.vT + bh * 64 * p.S_pad;
+
+    // ---- Q fragments (B operand): lane holds Q[q][kk*16 + lg*8 .. +8]
+    const int q_row = qblk * QB + wave * QW + lq;
+    const int q_ld = q_row < p.S ? q_row : p.S - 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(Qg + (long)q_ld * 64 + kk * 16 + lg * 8);
+
+    // ---- staging: a tile is 64 rows x 128 B = 8 glds groups; wave w stages group w of K and of V^T
+    const int srow = wave * 8 + (lane >> 3);
+    const int sc = (lane & 7) ^ ((srow >> 1) & 7);
+    const bf16_t* srcK = Kg + (long)srow * 64 + sc * 8;          // + tile*64*64
+    const bf16_t* srcV = Vg + (long)srow * p.S_pad + sc * 8;     // + tile*64
+    auto stage = [&](int t, int buf) {
+        char* base = smem + buf * STAGE_BYTES + wave * 1024;
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcK + (long)t * KV * 64), (lptr_t)base, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcV + (long)t * KV), (lptr_t)(base + TILE_BYTES), 16, 0, 0);
+    };
+
+    // ---- fragment read offsets
+    // K (A operand of S^T): row = 32*kb + pi(lq), chunk = 2*kk + lg
+    const int krow = key_perm(lq);
+    int offK[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) offK[kk] = krow * 128 + (((2 * kk + lg) ^ ((krow >> 1) & 7)) << 4);
+    // V^T (A operand of O^T): row = 32*db + lq (d), chunk = 4*kb + 2*s + lg
+    int offV[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) offV[c] = TILE_BYTES + lq * 128 + (((2 * c + lg) ^ ((lq >> 1) & 7)) << 4);
+    // (rows +32: (row>>1)&7 unchanged, byte offset +4096)
+
+    f32x16 o[2];
+    o[0] = (f32x16){0}; o[1] = (f32x16){0};
+    float m_run = -1e30f, l_run = 0.f;
+
+    const int nt = (p.S + KV - 1) / KV;
+    stage(0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+        const char* sb = smem + (t & 1) * STAGE_BYTES;
+
+        // ---- S^T = K Q^T : two 32-key blocks
+        f32x16 s[2];
+        s[0] = (f32x16){0}; s[1] = (f32x16){0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const bf16x8 kf = *(const bf16x8*)(sb + offK[kk] + kb * 4096);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
+            }
+        }
+        // register r of block kb <-> key t*64 + 32*kb + 16*(r>>3) + 8*lg + (r&7)
+        if (t == nt - 1) {
+            const int kbase = t * KV + 8 * lg;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kbase + 32 * kb + 16 * (r >> 3) + (r & 7);
+                    if (key >= p.S) s[kb][r] = -1e30f;
+                }
+        }
+        // ---- online softmax (per lane = per query; partner lane^32 holds the other 32 keys)
+        float mx = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * SCALE_LOG2E);
+        const float mb = m_new * SCALE_LOG2E;
+        m_run = m_new;
+        float psum = 0.f;
+        unsigned pk[2][8];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(s[kb][r] * SCALE_LOG2E - mb);
+                const float p1 = __builtin_amdgcn_exp2f(s[kb][r + 1] * SCALE_LOG2E - mb);
+                psum += p0 + p1;
+                pk[kb][r >> 1] = pack_bf16(p0, p1);
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+
+        // ---- O^T += V^T P^T : 4 k-steps of 16 keys (c = 2*kb + s), two 32-row d blocks
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int kb = c >> 1, sh = (c & 1) * 4;
+            bf16x8 pf;
+            {
+                const unsigned u0 = pk[kb][sh + 0], u1 = pk[kb][sh + 1], u2 = pk[kb][sh + 2], u3 = pk[kb][sh + 3];
+                typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+                const u32x4 uu = {u0, u1, u2, u3};
+                pf = __builtin_bit_cast(bf16x8, uu);
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const bf16x8 vf = *(const bf16x8*)(sb + offV[c] + db * 4096);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- finalize: 1/l (both half-wave partial sums), stage O through LDS for full-row stores
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_run;
+    __syncthreads();  // all waves done with the K/V ring
+    // wave region: 32 queries x 64 d bf16 = 4 KiB, row = query (128 B), 16-B chunk XOR-swizzled by (q&7)
+    char* ob = smem + wave * 4096;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            // registers 4a..4a+3 -> d = 32*db + 8*a + 4*lg + (0..3)
+            const int d0 = 32 * db + 8 * a + 4 * lg;
+            uint2 w = {pack_bf16(o[db][4 * a] * inv, o[db][4 * a + 1] * inv),
+                       pack_bf16(o[db][4 * a + 2] * inv, o[db][4 * a + 3] * inv)};
+            const int chunk = (d0 >> 3) ^ (lq & 7);
+            *(uint2*)(ob + lq * 128 + chunk * 16 + (d0 & 7) * 2) = w;
+        }
+    // wave-private region: a wave's LDS operations execute in order, no barrier needed
+    __builtin_amdgcn_wave_barrier();
+    const int n_ctx = p.S - p.n_img;
+    const int D = p.H * 64;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = it * 8 + (lane >> 3), c = lane & 7;      // row (query), logical chunk
+        const uint4 val = *(const uint4*)(ob + r * 128 + ((c ^ (r & 7)) << 4));
+        const int qi = qblk * QB + wave * QW + r;
+        if (qi < p.S) {
+            bf16_t* dst = (qi < p.n_img) ? p.o_img + ((long)b * p.n_img + qi) * D
+                                         : p.o_ctx + ((long)b * n_ctx + (qi - p.n_img)) * D;
+            *(uint4*)(dst + h * 64 + c * 8) = val;
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
+    if (p.S <= 0 || p.S_pad % KV != 0 || p.S_pad < p.S) return hipErrorInvalidValue;
+    dim3 grid((p.S + QB - 1) / QB, p.H, p.B);
+    hipLaunchKernelGGL(attn_kernel, grid, dim3(NWAVE * 64), 2 * STAGE_BYTES, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace mi355

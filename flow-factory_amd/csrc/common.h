@@ -1,0 +1,67 @@
+// mi355_flow -- shared device helpers (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi355 {
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16;  // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16v2;
+typedef __attribute__((ext_vector_type(2))) float f32v2;
+
+enum DType : int { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };
+
+__device__ __forceinline__ float bf2f(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// two floats -> packed bf16x2 (round-to-nearest-even; lowers to v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    f32v2 v = {lo, hi};
+    bf16v2 r = __builtin_convertvector(v, bf16v2);
+    return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf16(f, 0.f) & 0xffffu); }
+__device__ __forceinline__ float round_bf16(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// GELU(tanh approximation), as torch.nn.functional.gelu(approximate="tanh")
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    // tanh(u) = 1 - 2/(exp(2u)+1)
+    float e = __expf(2.0f * u);
+    float t = 1.0f - 2.0f / (e + 1.0f);
+    return 0.5f * x * (1.0f + t);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// storage-dtype load/store of a latent element (fp32 / bf16 / fp16)
+__device__ __forceinline__ float load_as_f32(const void* p, long i, int dt) {
+    if (dt == DT_F32) return ((const float*)p)[i];
+    if (dt == DT_BF16) return bf2f(((const bf16_t*)p)[i]);
+    return (float)(((const _Float16*)p)[i]);
+}
+// value-round an fp32 to the storage dtype (the reference's `.to(dtype).float()`), with the
+// fp16 clamp of cast_latents (reference models/abc.py:172-182)
+__device__ __forceinline__ float round_to_dtype(float v, int dt) {
+    if (dt == DT_F32) return v;
+    if (dt == DT_BF16) return round_bf16(v);
+    v = fminf(fmaxf(v, -65504.0f), 65504.0f);
+    return (float)((_Float16)v);
+}
+__device__ __forceinline__ void store_from_f32(void* p, long i, int dt, float v) {
+    if (dt == DT_F32) ((float*)p)[i] = v;
+    else if (dt == DT_BF16) ((bf16_t*)p)[i] = f2bf(v);
+    else ((_Float16*)p)[i] = (_Float16)fminf(fmaxf(v, -65504.0f), 65504.0f);
+}
+
+}  // namespace mi355

@@ -1,0 +1,167 @@
+// mi355_flow -- HBM-bound helper kernels of the MMDiT forward (ops K0-prologue, K1, K4, K12 of
+// SURVEY.md 2.3): LayerNorm+AdaLN-modulate, patchify (im2col of the k2/s2 conv), pos-embed crop,
+// sinusoidal timestep projection, dtype conversion.  All 16-byte vectorised, one wave per row
+// where a row reduction is needed.
+#include "kernels.h"
+
+namespace mi355 {
+namespace {
+
+// ------------------------------------------------------------------ LayerNorm + modulate
+// One wave per row; the row (D <= 8*64*MAXC) stays in registers: exact two-pass mean/variance.
+constexpr int LN_MAXC = 4;  // 16-byte chunks per lane -> D <= 2048
+
+__global__ __launch_bounds__(256) void ln_mod_kernel(LnModParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const int nchunk = p.D >> 3;  // 8 bf16 per 16-byte chunk
+    float v[LN_MAXC][8];
+    float sum = 0.f;
+    const bf16_t* xr = p.x + (long)row * p.D;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            const uint4 u = *(const uint4*)(xr + ch * 8);
+            v[c][0] = bf_lo(u.x); v[c][1] = bf_hi(u.x); v[c][2] = bf_lo(u.y); v[c][3] = bf_hi(u.y);
+            v[c][4] = bf_lo(u.z); v[c][5] = bf_hi(u.z); v[c][6] = bf_lo(u.w); v[c][7] = bf_hi(u.w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += v[c][e];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)p.D;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
+    const int b = row / p.rows_per_sample;
+    const bf16_t* mod = p.mod + (long)b * p.mod_ld;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            float nv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) nv[e] = (v[c][e] - mean) * rstd;
+            {
+                const uint4 sc = *(const uint4*)(mod + p.scale_off + ch * 8);
+                const uint4 sh = *(const uint4*)(mod + p.shift_off + ch * 8);
+                uint4 o;
+                o.x = pack_bf16(nv[0] * (1.f + bf_lo(sc.x)) + bf_lo(sh.x), nv[1] * (1.f + bf_hi(sc.x)) + bf_hi(sh.x));
+                o.y = pack_bf16(nv[2] * (1.f + bf_lo(sc.y)) + bf_lo(sh.y), nv[3] * (1.f + bf_hi(sc.y)) + bf_hi(sh.y));
+                o.z = pack_bf16(nv[4] * (1.f + bf_lo(sc.z)) + bf_lo(sh.z), nv[5] * (1.f + bf_hi(sc.z)) + bf_hi(sh.z));
+                o.w = pack_bf16(nv[6] * (1.f + bf_lo(sc.w)) + bf_lo(sh.w), nv[7] * (1.f + bf_hi(sc.w)) + bf_hi(sh.w));
+                *(uint4*)(p.out + (long)row * p.D + ch * 8) = o;
+            }
+            if (p.out2) {
+                const uint4 sc = *(const uint4*)(mod + p.scale2_off + ch * 8);
+                const uint4 sh = *(const uint4*)(mod + p.shift2_off + ch * 8);
+                uint4 o;
+                o.x = pack_bf16(nv[0] * (1.f + bf_lo(sc.x)) + bf_lo(sh.x), nv[1] * (1.f + bf_hi(sc.x)) + bf_hi(sh.x));
+                o.y = pack_bf16(nv[2] * (1.f + bf_lo(sc.y)) + bf_lo(sh.y), nv[3] * (1.f + bf_hi(sc.y)) + bf_hi(sh.y));
+                o.z = pack_bf16(nv[4] * (1.f + bf_lo(sc.z)) + bf_lo(sh.z), nv[5] * (1.f + bf_hi(sc.z)) + bf_hi(sh.z));
+                o.w = pack_bf16(nv[6] * (1.f + bf_lo(sc.w)) + bf_lo(sh.w), nv[7] * (1.f + bf_hi(sc.w)) + bf_hi(sh.w));
+                *(uint4*)(p.out2 + (long)row * p.D + ch * 8) = o;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ patchify (im2col, k = c*p*p + py*p + px)
+__global__ void patchify_kernel(const void* lat, int dt, bf16_t* out, int B, int rep, int C, int h, int w, int p) {
+    const int hp = h / p, wp = w / p, K = C * p * p;
+    const long total = (long)B * rep * hp * wp * K;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        const long tok = i / K;
+        const int tx = (int)(tok % wp);
+        const int ty = (int)((tok / wp) % hp);
+        const int bb = (int)(tok / ((long)wp * hp));
+        const int b = bb % B;  // cat([latents, latents]): replica r uses sample bb - r*B
+        const int c = k / (p * p), py = (k / p) % p, px = k % p;
+        const long src = (((long)b * C + c) * h + ty * p + py) * w + tx * p + px;
+        out[i] = f2bf(load_as_f32(lat, src, dt));
+    }
+}
+
+__global__ void pos_crop_kernel(const bf16_t* pos, bf16_t* out, int max_size, int hp, int wp, int D) {
+    const int top = (max_size - hp) / 2, left = (max_size - wp) / 2;
+    const int chunks = D >> 3;
+    const long total = (long)hp * wp * chunks;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % chunks);
+        const long tok = i / chunks;
+        const int tx = (int)(tok % wp), ty = (int)(tok / wp);
+        const long src = ((long)(top + ty) * max_size + left + tx) * D + ch * 8;
+        *(uint4*)(out + tok * D + ch * 8) = *(const uint4*)(pos + src);
+    }
+}
+
+// diffusers get_timestep_embedding(flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
+__global__ void time_proj_kernel(const float* t, int rows, int dim, int t_round_dt, bf16_t* out) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * half) return;
+    const int r = i / half, j = i % half;
+    const float tv = round_to_dtype(t[r], t_round_dt);
+    const float freq = expf(-9.210340371976184f * (float)j / (float)half);  // -ln(10000) * j / half
+    const float a = tv * freq;
+    out[(long)r * dim + j] = f2bf(cosf(a));
+    out[(long)r * dim + half + j] = f2bf(sinf(a));
+}
+
+__global__ void convert_kernel(const void* src, int sdt, void* dst, int ddt, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = load_as_f32(src, i, sdt);
+        store_from_f32(dst, i, ddt, v);  // fp16 destination clamps at +-65504 (cast_latents)
+    }
+}
+
+inline int grid_for(long total, int block) {
+    long g = (total + block - 1) / block;
+    return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+hipError_t launch_ln_mod(const LnModParams& p, hipStream_t stream) {
+    if (p.D % 8 != 0 || p.D > 8 * 64 * LN_MAXC || p.M <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(ln_mod_kernel, dim3((p.M + 3) / 4), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_patchify(const void* lat, int dt, bf16_t* patches, int B, int rep, int C, int h, int w, int p,
+                           hipStream_t stream) {
+    const long total = (long)B * rep * (h / p) * (w / p) * C * p * p;
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, lat, dt, patches, B, rep, C, h,
+                       w, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_pos_crop(const bf16_t* pos, bf16_t* out, int max_size, int hp, int wp, int D, hipStream_t stream) {
+    if (hp > max_size || wp > max_size || D % 8) return hipErrorInvalidValue;
+    const long total = (long)hp * wp * (D >> 3);
+    hipLaunchKernelGGL(pos_crop_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, pos, out, max_size, hp, wp, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_time_proj(const float* t, int rows, int dim, int t_round_dt, bf16_t* out, hipStream_t stream) {
+    const int total = rows * (dim / 2);
+    hipLaunchKernelGGL(time_proj_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, t, rows, dim, t_round_dt, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_convert(const void* src, int src_dt, void* dst, int dst_dt, long n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(convert_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, src, src_dt, dst, dst_dt, n);
+    return hipGetLastError();
+}
+
+}  // namespace mi355

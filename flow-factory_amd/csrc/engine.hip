@@ -1,0 +1,641 @@
+// mi355_flow -- engine / plan / rollout orchestration behind the C ABI (include/mi355_flow.h).
+// Host code only launches kernels on the caller's stream; no device synchronisation anywhere
+// on the rollout path (the reference syncs 3x per step: flow_match_euler_discrete.py:187-194,:344,
+// models/abc.py:177-181).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355_flow.h"
+#include "kernels.h"
+
+using namespace mi355;
+
+static thread_local std::string g_err;
+static int fail(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+#define HIPCHK(x)                                                                          \
+    do {                                                                                   \
+        hipError_t _e = (x);                                                               \
+        if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define CHK(x)                 \
+    do {                       \
+        int _r = (x);          \
+        if (_r) return _r;     \
+    } while (0)
+
+// ------------------------------------------------------------------------------------ engine
+struct Slot {
+    void* dst;      // device destination (bf16_t* or float*)
+    int dst_dt;     // DT_BF16 / DT_F32
+    int64_t numel;  // elements expected
+    bool bound;
+};
+
+struct BlockW {
+    bool dual, last;
+    bf16_t *w_qk, *w_v, *w_o, *w_cqk, *w_cv, *w_co, *w_qk2, *w_v2, *w_o2, *w_ff1, *w_ff2, *w_cff1, *w_cff2;
+    float *b_qk, *b_v, *b_o, *b_cqk, *b_cv, *b_co, *b_qk2, *b_v2, *b_o2, *b_ff1, *b_ff2, *b_cff1, *b_cff2;
+    float *nq, *nk, *ncq, *nck, *nq2, *nk2;
+    int mod_img, mod_ctx;  // column offsets into a mod_all row
+};
+
+struct mi355_engine {
+    mi355_model_cfg cfg;
+    int D, F, L, KP;  // model dim, ff inner, layers, patch K
+    int mod_cols, mod_out;
+    char* arena16 = nullptr;
+    char* arena32 = nullptr;
+    size_t used16 = 0, used32 = 0, cap16 = 0, cap32 = 0;
+    bf16_t *w_patch, *pos_embed, *w_t1, *w_t2, *w_p1, *w_p2, *w_ctx, *w_mod, *w_proj;
+    float *b_patch, *b_t1, *b_t2, *b_p1, *b_p2, *b_ctx, *b_mod, *b_proj;
+    std::vector<BlockW> blk;
+    std::map<std::string, Slot> slots;
+    std::vector<std::string> names;
+
+    bf16_t* a16(int64_t n) {
+        size_t bytes = ((size_t)n * 2 + 255) & ~(size_t)255;
+        char* p = arena16 ? arena16 + used16 : nullptr;
+        used16 += bytes;
+        return (bf16_t*)p;
+    }
+    float* a32(int64_t n) {
+        size_t bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
+        char* p = arena32 ? arena32 + used32 : nullptr;
+        used32 += bytes;
+        return (float*)p;
+    }
+    void reg(const std::string& name, void* dst, int dt, int64_t numel) {
+        if (arena16) {
+            slots[name] = Slot{dst, dt, numel, false};
+            names.push_back(name);
+        }
+    }
+    // linear: weight [out][in] bf16 at w (row offset allowed by caller), bias fp32
+    void lin(const std::string& name, bf16_t* w, float* b, int out_f, int in_f) {
+        reg(name + ".weight", w, DT_BF16, (int64_t)out_f * in_f);
+        reg(name + ".bias", b, DT_F32, out_f);
+    }
+    void layout();  // called twice: sizing pass (arena null), then real pass
+};
+
+void mi355_engine::layout() {
+    used16 = used32 = 0;
+    slots.clear();
+    names.clear();
+    blk.assign(L, BlockW());
+    const int P = cfg.pooled_projection_dim, J = cfg.joint_attention_dim, T = cfg.time_proj_dim;
+    w_patch = a16((int64_t)D * KP); b_patch = a32(D);
+    reg("pos_embed.proj.weight", w_patch, DT_BF16, (int64_t)D * KP);
+    reg("pos_embed.proj.bias", b_patch, DT_F32, D);
+    pos_embed = a16((int64_t)cfg.pos_embed_max_size * cfg.pos_embed_max_size * D);
+    reg("pos_embed.pos_embed", pos_embed, DT_BF16, (int64_t)cfg.pos_embed_max_size * cfg.pos_embed_max_size * D);
+    w_t1 = a16((int64_t)D * T); b_t1 = a32(D); lin("time_text_embed.timestep_embedder.linear_1", w_t1, b_t1, D, T);
+    w_t2 = a16((int64_t)D * D); b_t2 = a32(D); lin("time_text_embed.timestep_embedder.linear_2", w_t2, b_t2, D, D);
+    w_p1 = a16((int64_t)D * P); b_p1 = a32(D); lin("time_text_embed.text_embedder.linear_1", w_p1, b_p1, D, P);
+    w_p2 = a16((int64_t)D * D); b_p2 = a32(D); lin("time_text_embed.text_embedder.linear_2", w_p2, b_p2, D, D);
+    w_ctx = a16((int64_t)D * J); b_ctx = a32(D); lin("context_embedder", w_ctx, b_ctx, D, J);
+    // all AdaLN modulation linears concatenated along the output dim: one GEMM for every block (K3)
+    int cols = 0;
+    for (int i = 0; i < L; ++i) {
+        BlockW& b = blk[i];
+        b.dual = (cfg.dual_layer_mask >> i) & 1;
+        b.last = (i == L - 1);
+        b.mod_img = cols; cols += (b.dual ? 9 : 6) * D;
+        b.mod_ctx = cols; cols += (b.last ? 2 : 6) * D;
+    }
+    mod_out = cols; cols += 2 * D;
+    mod_cols = cols;
+    w_mod = a16((int64_t)mod_cols * D); b_mod = a32(mod_cols);
+    for (int i = 0; i < L; ++i) {
+        BlockW& b = blk[i];
+        const std::string pre = "transformer_blocks." + std::to_string(i);
+        lin(pre + ".norm1.linear", w_mod + (int64_t)b.mod_img * D, b_mod + b.mod_img, (b.dual ? 9 : 6) * D, D);
+        lin(pre + ".norm1_context.linear", w_mod + (int64_t)b.mod_ctx * D, b_mod + b.mod_ctx, (b.last ? 2 : 6) * D, D);
+    }
+    lin("norm_out.linear", w_mod + (int64_t)mod_out * D, b_mod + mod_out, 2 * D, D);
+    const int64_t DD = (int64_t)D * D;
+    for (int i = 0; i < L; ++i) {
+        BlockW& b = blk[i];
+        const std::string pre = "transformer_blocks." + std::to_string(i);
+        b.w_qk = a16(2 * DD); b.b_qk = a32(2 * D);
+        lin(pre + ".attn.to_q", b.w_qk, b.b_qk, D, D);
+        lin(pre + ".attn.to_k", b.w_qk + DD, b.b_qk + D, D, D);
+        b.w_v = a16(DD); b.b_v = a32(D); lin(pre + ".attn.to_v", b.w_v, b.b_v, D, D);
+        b.w_o = a16(DD); b.b_o = a32(D); lin(pre + ".attn.to_out.0", b.w_o, b.b_o, D, D);
+        b.w_cqk = a16(2 * DD); b.b_cqk = a32(2 * D);
+        lin(pre + ".attn.add_q_proj", b.w_cqk, b.b_cqk, D, D);
+        lin(pre + ".attn.add_k_proj", b.w_cqk + DD, b.b_cqk + D, D, D);
+        b.w_cv = a16(DD); b.b_cv = a32(D); lin(pre + ".attn.add_v_proj", b.w_cv, b.b_cv, D, D);
+        if (!b.last) { b.w_co = a16(DD); b.b_co = a32(D); lin(pre + ".attn.to_add_out", b.w_co, b.b_co, D, D); }
+        b.nq = a32(64); b.nk = a32(64); b.ncq = a32(64); b.nck = a32(64);
+        reg(pre + ".attn.norm_q.weight", b.nq, DT_F32, 64);
+        reg(pre + ".attn.norm_k.weight", b.nk, DT_F32, 64);
+        reg(pre + ".attn.norm_added_q.weight", b.ncq, DT_F32, 64);
+        reg(pre + ".attn.norm_added_k.weight", b.nck, DT_F32, 64);
+        if (b.dual) {
+            b.w_qk2 = a16(2 * DD); b.b_qk2 = a32(2 * D);
+            lin(pre + ".attn2.to_q", b.w_qk2, b.b_qk2, D, D);
+            lin(pre + ".attn2.to_k", b.w_qk2 + DD, b.b_qk2 + D, D, D);
+            b.w_v2 = a16(DD); b.b_v2 = a32(D); lin(pre + ".attn2.to_v", b.w_v2, b.b_v2, D, D);
+            b.w_o2 = a16(DD); b.b_o2 = a32(D); lin(pre + ".attn2.to_out.0", b.w_o2, b.b_o2, D, D);
+            b.nq2 = a32(64); b.nk2 = a32(64);
+            reg(pre + ".attn2.norm_q.weight", b.nq2, DT_F32, 64);
+            reg(pre + ".attn2.norm_k.weight", b.nk2, DT_F32, 64);
+        }
+        b.w_ff1 = a16((int64_t)F * D); b.b_ff1 = a32(F); lin(pre + ".ff.net.0.proj", b.w_ff1, b.b_ff1, F, D);
+        b.w_ff2 = a16((int64_t)D * F); b.b_ff2 = a32(D); lin(pre + ".ff.net.2", b.w_ff2, b.b_ff2, D, F);
+        if (!b.last) {
+            b.w_cff1 = a16((int64_t)F * D); b.b_cff1 = a32(F); lin(pre + ".ff_context.net.0.proj", b.w_cff1, b.b_cff1, F, D);
+            b.w_cff2 = a16((int64_t)D * F); b.b_cff2 = a32(D); lin(pre + ".ff_context.net.2", b.w_cff2, b.b_cff2, D, F);
+        }
+    }
+    const int NO = cfg.patch_size * cfg.patch_size * cfg.out_channels;
+    w_proj = a16((int64_t)NO * D); b_proj = a32(NO); lin("proj_out", w_proj, b_proj, NO, D);
+}
+
+extern "C" int mi355_version(void) { return MI355_FLOW_VERSION; }
+extern "C" const char* mi355_last_error(void) { return g_err.c_str(); }
+
+extern "C" int mi355_engine_create(const mi355_model_cfg* cfg, mi355_engine** out) {
+    if (!cfg || !out) return fail("mi355_engine_create: null argument");
+    if (cfg->head_dim != 64) return fail("mi355_engine_create: head_dim must be 64 (got %d)", cfg->head_dim);
+    if (cfg->num_layers < 1 || cfg->num_layers > 64) return fail("mi355_engine_create: num_layers out of range");
+    const int KP = cfg->in_channels * cfg->patch_size * cfg->patch_size;
+    if (KP % 64 || cfg->joint_attention_dim % 64 || cfg->pooled_projection_dim % 64 || cfg->time_proj_dim % 64)
+        return fail("mi355_engine_create: every GEMM K dim must be a multiple of 64");
+    if ((cfg->patch_size * cfg->patch_size * cfg->out_channels) % 4) return fail("proj_out width must be a multiple of 4");
+    mi355_engine* e = new mi355_engine();
+    e->cfg = *cfg;
+    e->D = cfg->num_heads * cfg->head_dim;
+    e->F = cfg->ff_mult * e->D;
+    e->L = cfg->num_layers;
+    e->KP = KP;
+    e->layout();  // sizing pass
+    e->cap16 = e->used16;
+    e->cap32 = e->used32;
+    hipError_t e1 = hipMalloc((void**)&e->arena16, e->cap16);
+    hipError_t e2 = hipMalloc((void**)&e->arena32, e->cap32);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+        int r = fail("mi355_engine_create: hipMalloc of %zu + %zu bytes failed", e->cap16, e->cap32);
+        if (e->arena16) hipFree(e->arena16);
+        if (e->arena32) hipFree(e->arena32);
+        delete e;
+        return r;
+    }
+    e->layout();  // real pass
+    *out = e;
+    return 0;
+}
+
+extern "C" int mi355_engine_destroy(mi355_engine* e) {
+    if (!e) return 0;
+    if (e->arena16) hipFree(e->arena16);
+    if (e->arena32) hipFree(e->arena32);
+    delete e;
+    return 0;
+}
+
+extern "C" int mi355_engine_num_params(mi355_engine* e) { return e ? (int)e->names.size() : 0; }
+extern "C" const char* mi355_engine_param_name(mi355_engine* e, int i) {
+    if (!e || i < 0 || i >= (int)e->names.size()) return nullptr;
+    return e->names[i].c_str();
+}
+
+extern "C" int mi355_engine_bind_weight(mi355_engine* e, const char* name, const void* src, int dtype, int ndim,
+                                        const int64_t* shape, void* stream) {
+    if (!e || !name || !src) return fail("mi355_engine_bind_weight: null argument");
+    auto it = e->slots.find(name);
+    if (it == e->slots.end()) return fail("mi355_engine_bind_weight: unknown parameter '%s'", name);
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    if (n != it->second.numel)
+        return fail("mi355_engine_bind_weight: '%s' has %lld elements, expected %lld", name, (long long)n,
+                    (long long)it->second.numel);
+    if (dtype < 0 || dtype > 2) return fail("mi355_engine_bind_weight: bad dtype %d", dtype);
+    HIPCHK(launch_convert(src, dtype, it->second.dst, it->second.dst_dt, n, (hipStream_t)stream));
+    it->second.bound = true;
+    return 0;
+}
+
+extern "C" int mi355_engine_weights_ready(mi355_engine* e) {
+    if (!e) return fail("null engine");
+    for (auto& kv : e->slots)
+        if (!kv.second.bound) return fail("parameter '%s' has not been bound", kv.first.c_str());
+    return 0;
+}
+
+// -------------------------------------------------------------------------------------- plan
+struct mi355_plan {
+    mi355_engine* e;
+    int B, ncfg, Bp, h, w, hp, wp, Ni, Nt, S, S_pad, Mi, Mc, C, max_steps;
+    int64_t n_lat;  // elements per latent sample
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    bool pos_ready = false;
+    // workspace pointers
+    bf16_t *pe, *patches, *x, *c, *c0, *xn, *xn2, *cn, *q, *k, *vT, *q2, *k2, *vT2, *o_img, *o_ctx, *hid, *chid;
+    bf16_t *tproj, *h1, *p1, *pemb, *semb, *mod_all, *v;
+    float *t_dev, *scal;  // t per (step, sample); scalars [3][max_steps] (sigma, sigma_next, eta)
+    char *lat_a, *lat_b;  // storage-dtype latent ping-pong (fp32-sized)
+    std::vector<float> host_t, host_sc;
+};
+
+extern "C" int mi355_plan_create(mi355_engine* e, int batch, int n_cfg, int latent_h, int latent_w, int n_text,
+                                 int max_steps, mi355_plan** out) {
+    if (!e || !out) return fail("mi355_plan_create: null argument");
+    if (batch < 1 || (n_cfg != 1 && n_cfg != 2) || n_text < 1 || max_steps < 1) return fail("mi355_plan_create: bad shape");
+    const int ps = e->cfg.patch_size;
+    if (latent_h % ps || latent_w % ps) return fail("latent size must be a multiple of patch_size");
+    mi355_plan* p = new mi355_plan();
+    p->e = e;
+    p->B = batch; p->ncfg = n_cfg; p->Bp = batch * n_cfg;
+    p->h = latent_h; p->w = latent_w; p->hp = latent_h / ps; p->wp = latent_w / ps;
+    p->Ni = p->hp * p->wp; p->Nt = n_text; p->S = p->Ni + p->Nt;
+    p->S_pad = (p->S + 63) / 64 * 64;
+    p->Mi = p->Bp * p->Ni; p->Mc = p->Bp * p->Nt;
+    p->C = e->cfg.in_channels; p->max_steps = max_steps;
+    p->n_lat = (int64_t)p->C * latent_h * latent_w;
+    if (p->hp > e->cfg.pos_embed_max_size || p->wp > e->cfg.pos_embed_max_size) {
+        const int hp = p->hp, wp = p->wp;
+        delete p;
+        return fail("latent grid %dx%d exceeds pos_embed_max_size %d", hp, wp, e->cfg.pos_embed_max_size);
+    }
+    const int D = e->D, F = e->F;
+    const int64_t rows_cond = (int64_t)max_steps * p->Bp;
+    size_t off = 0;
+    auto take = [&](int64_t elems, int esz) {
+        size_t o = off;
+        off += (((size_t)elems * esz) + 255) & ~(size_t)255;
+        return o;
+    };
+    const int64_t qk_el = (int64_t)p->Bp * e->cfg.num_heads * p->S_pad * 64;
+    const int Ni_pad = (p->Ni + 63) / 64 * 64;
+    const int64_t qk2_el = (int64_t)p->Bp * e->cfg.num_heads * Ni_pad * 64;
+    size_t o_pe = take((int64_t)p->Ni * D, 2), o_patch = take((int64_t)p->Mi * e->KP, 2);
+    size_t o_x = take((int64_t)p->Mi * D, 2), o_c = take((int64_t)p->Mc * D, 2), o_c0 = take((int64_t)p->Mc * D, 2);
+    size_t o_xn = take((int64_t)p->Mi * D, 2), o_xn2 = take((int64_t)p->Mi * D, 2), o_cn = take((int64_t)p->Mc * D, 2);
+    size_t o_q = take(qk_el, 2), o_k = take(qk_el, 2), o_vT = take(qk_el, 2);
+    size_t o_q2 = take(qk2_el, 2), o_k2 = take(qk2_el, 2), o_vT2 = take(qk2_el, 2);
+    size_t o_oi = take((int64_t)p->Mi * D, 2), o_oc = take((int64_t)p->Mc * D, 2);
+    size_t o_hid = take((int64_t)p->Mi * F, 2), o_chid = take((int64_t)p->Mc * F, 2);
+    size_t o_tp = take(rows_cond * e->cfg.time_proj_dim, 2), o_h1 = take(rows_cond * D, 2);
+    size_t o_p1 = take((int64_t)p->Bp * D, 2), o_pemb = take((int64_t)p->Bp * D, 2), o_semb = take(rows_cond * D, 2);
+    size_t o_mod = take(rows_cond * e->mod_cols, 2), o_v = take((int64_t)p->Bp * p->n_lat, 2);
+    size_t o_t = take(rows_cond, 4), o_sc = take(3 * (int64_t)max_steps, 4);
+    size_t o_la = take((int64_t)p->B * p->n_lat, 4), o_lb = take((int64_t)p->B * p->n_lat, 4);
+    p->ws_bytes = off;
+    if (hipMalloc((void**)&p->ws, off) != hipSuccess) {
+        int r = fail("mi355_plan_create: hipMalloc of %zu bytes failed", off);
+        delete p;
+        return r;
+    }
+    // zero once: the padded key rows / columns of q,k,vT must stay finite (attention masks them)
+    if (hipMemset(p->ws, 0, off) != hipSuccess) {
+        hipFree(p->ws);
+        delete p;
+        return fail("mi355_plan_create: hipMemset failed");
+    }
+    char* w = p->ws;
+    p->pe = (bf16_t*)(w + o_pe); p->patches = (bf16_t*)(w + o_patch);
+    p->x = (bf16_t*)(w + o_x); p->c = (bf16_t*)(w + o_c); p->c0 = (bf16_t*)(w + o_c0);
+    p->xn = (bf16_t*)(w + o_xn); p->xn2 = (bf16_t*)(w + o_xn2); p->cn = (bf16_t*)(w + o_cn);
+    p->q = (bf16_t*)(w + o_q); p->k = (bf16_t*)(w + o_k); p->vT = (bf16_t*)(w + o_vT);
+    p->q2 = (bf16_t*)(w + o_q2); p->k2 = (bf16_t*)(w + o_k2); p->vT2 = (bf16_t*)(w + o_vT2);
+    p->o_img = (bf16_t*)(w + o_oi); p->o_ctx = (bf16_t*)(w + o_oc);
+    p->hid = (bf16_t*)(w + o_hid); p->chid = (bf16_t*)(w + o_chid);
+    p->tproj = (bf16_t*)(w + o_tp); p->h1 = (bf16_t*)(w + o_h1); p->p1 = (bf16_t*)(w + o_p1);
+    p->pemb = (bf16_t*)(w + o_pemb); p->semb = (bf16_t*)(w + o_semb); p->mod_all = (bf16_t*)(w + o_mod);
+    p->v = (bf16_t*)(w + o_v);
+    p->t_dev = (float*)(w + o_t); p->scal = (float*)(w + o_sc);
+    p->lat_a = w + o_la; p->lat_b = w + o_lb;
+    *out = p;
+    return 0;
+}
+
+extern "C" int mi355_plan_destroy(mi355_plan* p) {
+    if (!p) return 0;
+    if (p->ws) hipFree(p->ws);
+    delete p;
+    return 0;
+}
+extern "C" int64_t mi355_plan_workspace_bytes(mi355_plan* p) { return p ? (int64_t)p->ws_bytes : 0; }
+
+// ---------------------------------------------------------------------------------- forward
+static GemmParams gp(const bf16_t* A, long lda, const bf16_t* W, long ldw, int M, int N, int K, int epi,
+                     const float* bias, bf16_t* out, long ldo) {
+    GemmParams g;
+    memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.epi = epi; g.bias = bias;
+    g.out = out; g.ldo = ldo; g.rows_per_sample = M > 0 ? M : 1; g.eps = 1e-6f;
+    return g;
+}
+
+// step-invariant prompt work: context embedder (K2) + pooled-text MLP.  enc_b == NULL => n_cfg 1.
+static int prepare_prompt(mi355_plan* p, hipStream_t st, const void* enc_a, const void* pooled_a, const void* enc_b,
+                          const void* pooled_b) {
+    mi355_engine* e = p->e;
+    const int D = e->D, J = e->cfg.joint_attention_dim, P = e->cfg.pooled_projection_dim;
+    const void* encs[2] = {enc_a, enc_b};
+    const void* pools[2] = {pooled_a, pooled_b};
+    if (p->ncfg == 2 && (!enc_b || !pooled_b)) return fail("n_cfg == 2 needs both prompt halves");
+    if (!enc_a || !pooled_a) return fail("prompt embeddings are NULL");
+    for (int half = 0; half < p->ncfg; ++half) {
+        const int rows = p->B * p->Nt;
+        GemmParams g = gp((const bf16_t*)encs[half], J, e->w_ctx, J, rows, D, J, EPI_BIAS, e->b_ctx,
+                          p->c0 + (int64_t)half * rows * D, D);
+        HIPCHK(launch_gemm(g, st));
+        GemmParams g1 = gp((const bf16_t*)pools[half], P, e->w_p1, P, p->B, D, P, EPI_BIAS_SILU, e->b_p1,
+                           p->p1 + (int64_t)half * p->B * D, D);
+        HIPCHK(launch_gemm(g1, st));
+    }
+    GemmParams g2 = gp(p->p1, D, e->w_p2, D, p->Bp, D, D, EPI_BIAS, e->b_p2, p->pemb, D);
+    HIPCHK(launch_gemm(g2, st));
+    return 0;
+}
+
+// conditioning for `nsteps` steps at once (K1 + K3 hoisted): t_dev holds nsteps*Bp timesteps
+static int prepare_conditioning(mi355_plan* p, hipStream_t st, int nsteps, int t_round_dt) {
+    mi355_engine* e = p->e;
+    const int D = e->D, T = e->cfg.time_proj_dim;
+    const int rows = nsteps * p->Bp;
+    HIPCHK(launch_time_proj(p->t_dev, rows, T, t_round_dt, p->tproj, st));
+    GemmParams g1 = gp(p->tproj, T, e->w_t1, T, rows, D, T, EPI_BIAS_SILU, e->b_t1, p->h1, D);
+    HIPCHK(launch_gemm(g1, st));
+    // semb = silu(bf16(timestep_emb + pooled_emb)): every AdaLN consumes silu(temb)
+    GemmParams g2 = gp(p->h1, D, e->w_t2, D, rows, D, D, EPI_ADDSRC_SILU, e->b_t2, p->semb, D);
+    g2.aux = p->pemb; g2.ld_aux = D; g2.rows_per_sample = p->Bp;
+    HIPCHK(launch_gemm(g2, st));
+    GemmParams g3 = gp(p->semb, D, e->w_mod, D, rows, e->mod_cols, D, EPI_BIAS, e->b_mod, p->mod_all, e->mod_cols);
+    HIPCHK(launch_gemm(g3, st));
+    return 0;
+}
+
+static int ln_mod(mi355_plan* p, hipStream_t st, const bf16_t* x, bf16_t* out, bf16_t* out2, const bf16_t* mod, int M,
+                  int rps, int shift_off, int scale_off, int shift2_off, int scale2_off) {
+    LnModParams l;
+    l.x = x; l.out = out; l.out2 = out2; l.mod = mod; l.mod_ld = p->e->mod_cols;
+    l.shift_off = shift_off; l.scale_off = scale_off; l.shift2_off = shift2_off; l.scale2_off = scale2_off;
+    l.M = M; l.D = p->e->D; l.rows_per_sample = rps; l.eps = p->e->cfg.eps;
+    HIPCHK(launch_ln_mod(l, st));
+    return 0;
+}
+
+// q/k projection with fused bias + per-head RMSNorm + scatter, and V^T projection (operands swapped)
+static int qkv_proj(mi355_plan* p, hipStream_t st, const bf16_t* xin, int M, int rps, const bf16_t* w_qk,
+                    const float* b_qk, const bf16_t* w_v, const float* b_v, const float* nq, const float* nk,
+                    bf16_t* q, bf16_t* k, bf16_t* vT, int S_pad, int s_off) {
+    mi355_engine* e = p->e;
+    const int D = e->D;
+    GemmParams g = gp(xin, D, w_qk, D, M, 2 * D, D, EPI_QK_NORM, b_qk, nullptr, 0);
+    g.q = q; g.k = k; g.nw_q = nq; g.nw_k = nk; g.H = e->cfg.num_heads; g.S_pad = S_pad; g.s_off = s_off;
+    g.rows_per_sample = rps; g.eps = e->cfg.eps;
+    HIPCHK(launch_gemm(g, st));
+    GemmParams gv = gp(w_v, D, xin, D, D, M, D, EPI_VT, b_v, nullptr, 0);
+    gv.q = vT; gv.H = e->cfg.num_heads; gv.S_pad = S_pad; gv.s_off = s_off; gv.rows_per_sample = rps;
+    HIPCHK(launch_gemm(gv, st));
+    return 0;
+}
+
+static int gate_res(mi355_plan* p, hipStream_t st, const bf16_t* A, int K, const bf16_t* W, const float* bias, bf16_t* x,
+                    int M, int rps, const bf16_t* mod, int gate_off) {
+    GemmParams g = gp(A, K, W, K, M, p->e->D, K, EPI_GATE_RES, bias, x, p->e->D);
+    g.aux = mod + gate_off; g.ld_aux = p->e->mod_cols; g.rows_per_sample = rps;
+    HIPCHK(launch_gemm(g, st));
+    return 0;
+}
+
+// One transformer forward.  `mod` = this step's rows of mod_all; c0 / pe / conditioning prepared.
+static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int lat_dt, const bf16_t* mod, bf16_t* v_out) {
+    mi355_engine* e = p->e;
+    const int D = e->D, F = e->F, H = e->cfg.num_heads;
+    const int Mi = p->Mi, Mc = p->Mc, Ni = p->Ni, Nt = p->Nt;
+    const int Ni_pad = (Ni + 63) / 64 * 64;
+    if (!p->pos_ready) {
+        HIPCHK(launch_pos_crop(e->pos_embed, p->pe, e->cfg.pos_embed_max_size, p->hp, p->wp, D, st));
+        p->pos_ready = true;
+    }
+    // K0: patch-embed = im2col + GEMM + bias + pos-embed
+    HIPCHK(launch_patchify(latents, lat_dt, p->patches, p->B, p->ncfg, p->C, p->h, p->w, e->cfg.patch_size, st));
+    {
+        GemmParams g = gp(p->patches, e->KP, e->w_patch, e->KP, Mi, D, e->KP, EPI_POSADD, e->b_patch, p->x, D);
+        g.aux = p->pe; g.ld_aux = D; g.rows_per_sample = Ni;
+        HIPCHK(launch_gemm(g, st));
+    }
+    HIPCHK(hipMemcpyAsync(p->c, p->c0, (size_t)Mc * D * 2, hipMemcpyDeviceToDevice, st));
+    for (int i = 0; i < e->L; ++i) {
+        const BlockW& b = e->blk[i];
+        const int mi = b.mod_img, mc = b.mod_ctx;
+        // AdaLN-Zero chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp[, shift2, scale2, gate2]
+        CHK(ln_mod(p, st, p->x, p->xn, b.dual ? p->xn2 : nullptr, mod, Mi, Ni, mi + 0 * D, mi + 1 * D, mi + 6 * D, mi + 7 * D));
+        if (b.last)  // AdaLayerNormContinuous: scale first, then shift
+            CHK(ln_mod(p, st, p->c, p->cn, nullptr, mod, Mc, Nt, mc + 1 * D, mc + 0 * D, 0, 0));
+        else
+            CHK(ln_mod(p, st, p->c, p->cn, nullptr, mod, Mc, Nt, mc + 0 * D, mc + 1 * D, 0, 0));
+        // joint attention: image tokens first, then text
+        CHK(qkv_proj(p, st, p->xn, Mi, Ni, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk, p->q, p->k, p->vT, p->S_pad, 0));
+        CHK(qkv_proj(p, st, p->cn, Mc, Nt, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck, p->q, p->k, p->vT, p->S_pad, Ni));
+        {
+            AttnParams a{p->q, p->k, p->vT, p->o_img, p->o_ctx, p->Bp, H, p->S, p->S_pad, Ni};
+            HIPCHK(launch_attention(a, st));
+        }
+        CHK(gate_res(p, st, p->o_img, D, b.w_o, b.b_o, p->x, Mi, Ni, mod, mi + 2 * D));
+        if (!b.last) CHK(gate_res(p, st, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
+        if (b.dual) {
+            CHK(qkv_proj(p, st, p->xn2, Mi, Ni, b.w_qk2, b.b_qk2, b.w_v2, b.b_v2, b.nq2, b.nk2, p->q2, p->k2, p->vT2, Ni_pad, 0));
+            AttnParams a{p->q2, p->k2, p->vT2, p->o_img, p->o_ctx, p->Bp, H, Ni, Ni_pad, Ni};
+            HIPCHK(launch_attention(a, st));
+            CHK(gate_res(p, st, p->o_img, D, b.w_o2, b.b_o2, p->x, Mi, Ni, mod, mi + 8 * D));
+        }
+        // MLP (image stream)
+        CHK(ln_mod(p, st, p->x, p->xn, nullptr, mod, Mi, Ni, mi + 3 * D, mi + 4 * D, 0, 0));
+        {
+            GemmParams g = gp(p->xn, D, b.w_ff1, D, Mi, F, D, EPI_BIAS_GELU, b.b_ff1, p->hid, F);
+            HIPCHK(launch_gemm(g, st));
+        }
+        CHK(gate_res(p, st, p->hid, F, b.w_ff2, b.b_ff2, p->x, Mi, Ni, mod, mi + 5 * D));
+        if (!b.last) {
+            CHK(ln_mod(p, st, p->c, p->cn, nullptr, mod, Mc, Nt, mc + 3 * D, mc + 4 * D, 0, 0));
+            GemmParams g = gp(p->cn, D, b.w_cff1, D, Mc, F, D, EPI_BIAS_GELU, b.b_cff1, p->chid, F);
+            HIPCHK(launch_gemm(g, st));
+            CHK(gate_res(p, st, p->chid, F, b.w_cff2, b.b_cff2, p->c, Mc, Nt, mod, mc + 5 * D));
+        }
+    }
+    // norm_out (scale first) + proj_out + unpatchify
+    CHK(ln_mod(p, st, p->x, p->xn, nullptr, mod, Mi, Ni, e->mod_out + 1 * D, e->mod_out + 0 * D, 0, 0));
+    {
+        const int NO = e->cfg.patch_size * e->cfg.patch_size * e->cfg.out_channels;
+        GemmParams g = gp(p->xn, D, e->w_proj, D, Mi, NO, D, EPI_UNPATCH, e->b_proj, v_out, 0);
+        g.hp = p->hp; g.wp = p->wp; g.patch = e->cfg.patch_size; g.out_ch = e->cfg.out_channels;
+        HIPCHK(launch_gemm(g, st));
+    }
+    return 0;
+}
+
+extern "C" int mi355_transformer_forward(mi355_plan* p, void* stream, const void* latents, int lat_dtype, const float* t,
+                                         int t_round_dtype, const void* enc_a, const void* pooled_a, const void* enc_b,
+                                         const void* pooled_b, void* v_out) {
+    if (!p || !latents || !t || !v_out) return fail("mi355_transformer_forward: null argument");
+    CHK(mi355_engine_weights_ready(p->e));
+    hipStream_t st = (hipStream_t)stream;
+    CHK(prepare_prompt(p, st, enc_a, pooled_a, enc_b, pooled_b));
+    HIPCHK(hipMemcpyAsync(p->t_dev, t, (size_t)p->Bp * 4, hipMemcpyDeviceToDevice, st));
+    CHK(prepare_conditioning(p, st, 1, t_round_dtype));
+    return forward_core(p, st, latents, lat_dtype, p->mod_all, (bf16_t*)v_out);
+}
+
+static int sde_call(hipStream_t st, int batch, int64_t n, const void* v_text, const void* v_uncond, float guidance,
+                    const void* latents, int lat_dtype, const float* noise, const void* next_in, int next_in_dtype,
+                    const float* sigma, const float* sigma_next, const float* eta, int scalar_stride, float sigma_max,
+                    int dynamics, int compute_log_prob, void* next_out, float* next_f32, float* mean_out,
+                    float* noise_pred_out, float* log_prob, float* std_dev_t, float* dt) {
+    if (!v_text || !latents || !sigma || !sigma_next || !eta) return fail("mi355_sde_step: null argument");
+    if (!next_in && !noise && dynamics != MI355_ODE) return fail("mi355_sde_step: SDE rollout step needs `noise`");
+    if (dynamics < 0 || dynamics > 3) return fail("mi355_sde_step: unknown dynamics %d", dynamics);
+    if (lat_dtype < 0 || lat_dtype > 2) return fail("mi355_sde_step: bad latent dtype %d", lat_dtype);
+    SdeStepParams s;
+    memset(&s, 0, sizeof(s));
+    s.v_text = (const bf16_t*)v_text; s.v_uncond = (const bf16_t*)v_uncond; s.guidance = guidance;
+    s.latents = latents; s.lat_dt = lat_dtype; s.noise = noise; s.next_in = next_in; s.next_in_dt = next_in_dtype;
+    s.sigma = sigma; s.sigma_next = sigma_next; s.eta = eta; s.scalar_stride = scalar_stride; s.sigma_max = sigma_max;
+    s.dynamics = dynamics; s.compute_log_prob = compute_log_prob; s.B = batch; s.n = n;
+    s.next_out = next_out; s.next_out_dt = lat_dtype; s.next_f32 = next_f32; s.mean_out = mean_out;
+    s.noise_pred_out = noise_pred_out; s.log_prob = log_prob; s.std_dev_t = std_dev_t; s.dt_out = dt;
+    HIPCHK(launch_sde_step(s, st));
+    return 0;
+}
+
+extern "C" int mi355_sde_step(void* stream, int batch, int64_t n, const void* v_text, const void* v_uncond, float guidance,
+                              const void* latents, int lat_dtype, const float* noise, const void* next_in,
+                              int next_in_dtype, const float* sigma, const float* sigma_next, const float* eta,
+                              int scalar_stride, float sigma_max, int dynamics, int compute_log_prob, void* next_out,
+                              float* next_f32, float* mean_out, float* noise_pred_out, float* log_prob, float* std_dev_t,
+                              float* dt) {
+    return sde_call((hipStream_t)stream, batch, n, v_text, v_uncond, guidance, latents, lat_dtype, noise, next_in,
+                    next_in_dtype, sigma, sigma_next, eta, scalar_stride, sigma_max, dynamics, compute_log_prob, next_out,
+                    next_f32, mean_out, noise_pred_out, log_prob, std_dev_t, dt);
+}
+
+extern "C" int mi355_denoise_step(mi355_plan* p, void* stream, const void* latents, int lat_dtype, const float* t,
+                                  const void* enc_a, const void* pooled_a, const void* enc_b, const void* pooled_b,
+                                  float guidance, const float* noise, const void* next_in, int next_in_dtype,
+                                  const float* sigma, const float* sigma_next, const float* eta, int scalar_stride,
+                                  float sigma_max, int dynamics, int compute_log_prob, void* next_out, float* next_f32,
+                                  float* mean_out, float* noise_pred_out, float* log_prob, float* std_dev_t, float* dt) {
+    if (!p) return fail("mi355_denoise_step: null plan");
+    CHK(mi355_transformer_forward(p, stream, latents, lat_dtype, t, lat_dtype, enc_a, pooled_a, enc_b, pooled_b, p->v));
+    const bf16_t* vu = p->ncfg == 2 ? p->v : nullptr;
+    const bf16_t* vt = p->ncfg == 2 ? p->v + (int64_t)p->B * p->n_lat : p->v;
+    return sde_call((hipStream_t)stream, p->B, p->n_lat, vt, vu, guidance, latents, lat_dtype, noise, next_in,
+                    next_in_dtype, sigma, sigma_next, eta, scalar_stride, sigma_max, dynamics, compute_log_prob, next_out,
+                    next_f32, mean_out, noise_pred_out, log_prob, std_dev_t, dt);
+}
+
+static size_t dt_size(int dt) { return dt == MI355_F32 ? 4 : 2; }
+
+extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const float* timesteps_host, const float* sigmas_host,
+                             const float* noise_levels_host, int dynamics, float guidance, const void* init_latents,
+                             int init_dtype, int storage_dtype, const float* step_noise, const void* prompt_embeds,
+                             const void* pooled, const void* neg_embeds, const void* neg_pooled,
+                             const int32_t* keep_slot_host, void* out_latents, float* out_log_probs, void* out_final,
+                             int compute_log_prob) {
+    if (!p || !timesteps_host || !sigmas_host || !noise_levels_host || !init_latents || !prompt_embeds || !pooled)
+        return fail("mi355_rollout: null argument");
+    if (n_steps < 1 || n_steps > p->max_steps) return fail("mi355_rollout: n_steps %d exceeds the plan's max_steps %d", n_steps, p->max_steps);
+    if (storage_dtype < 0 || storage_dtype > 2 || init_dtype < 0 || init_dtype > 2) return fail("mi355_rollout: bad dtype");
+    if (p->ncfg == 2 && (!neg_embeds || !neg_pooled)) return fail("mi355_rollout: plan has n_cfg == 2 but no negative prompt embeddings");
+    if (!step_noise && dynamics != MI355_ODE) return fail("mi355_rollout: step_noise is NULL");
+    CHK(mi355_engine_weights_ready(p->e));
+    hipStream_t st = (hipStream_t)stream;
+    const int Bp = p->Bp;
+    // host-side per-step scalars (the reference computes them with .item() syncs inside the loop)
+    std::vector<float>& tt = p->host_t;   // plan-owned: must outlive the async H2D copies
+    std::vector<float>& sc = p->host_sc;
+    tt.assign((size_t)n_steps * Bp, 0.f);
+    sc.assign(3 * (size_t)p->max_steps, 0.f);
+    for (int i = 0; i < n_steps; ++i) {
+        for (int j = 0; j < Bp; ++j) tt[(size_t)i * Bp + j] = timesteps_host[i];
+        const float t_next = (i + 1 < n_steps) ? timesteps_host[i + 1] : 0.0f;
+        sc[i] = timesteps_host[i] / 1000.0f;                 // sigma      (flow_match_euler_discrete.py:302)
+        sc[p->max_steps + i] = t_next / 1000.0f;             // sigma_next (:303)
+        sc[2 * p->max_steps + i] = noise_levels_host[i];
+    }
+    HIPCHK(hipMemcpyAsync(p->t_dev, tt.data(), tt.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(p->scal, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, st));
+    if (p->ncfg == 2) CHK(prepare_prompt(p, st, neg_embeds, neg_pooled, prompt_embeds, pooled));
+    else CHK(prepare_prompt(p, st, prompt_embeds, pooled, nullptr, nullptr));
+    CHK(prepare_conditioning(p, st, n_steps, storage_dtype));
+    // cast_latents(init) -> storage dtype (sd3_5.py:266-267)
+    const size_t esz = dt_size(storage_dtype);
+    const size_t lat_bytes = (size_t)p->B * p->n_lat * esz;
+    HIPCHK(launch_convert(init_latents, init_dtype, p->lat_a, storage_dtype, (long)p->B * p->n_lat, st));
+    char* cur = p->lat_a;
+    char* nxt = p->lat_b;
+    if (keep_slot_host && keep_slot_host[0] >= 0 && out_latents)
+        HIPCHK(hipMemcpyAsync((char*)out_latents + (size_t)keep_slot_host[0] * lat_bytes, cur, lat_bytes, hipMemcpyDeviceToDevice, st));
+    const float sigma_max = sigmas_host[1];
+    for (int i = 0; i < n_steps; ++i) {
+        const bf16_t* mod = p->mod_all + (int64_t)i * Bp * p->e->mod_cols;
+        CHK(forward_core(p, st, cur, storage_dtype, mod, p->v));
+        const bf16_t* vu = p->ncfg == 2 ? p->v : nullptr;
+        const bf16_t* vt = p->ncfg == 2 ? p->v + (int64_t)p->B * p->n_lat : p->v;
+        const int clp = compute_log_prob && noise_levels_host[i] > 0.f && out_log_probs;
+        CHK(sde_call(st, p->B, p->n_lat, vt, vu, guidance, cur, storage_dtype,
+                     step_noise ? step_noise + (int64_t)i * p->B * p->n_lat : nullptr, nullptr, 0, p->scal + i,
+                     p->scal + p->max_steps + i, p->scal + 2 * p->max_steps + i, 0, sigma_max, dynamics, clp, nxt, nullptr,
+                     nullptr, nullptr, clp ? out_log_probs + (int64_t)i * p->B : nullptr, nullptr, nullptr));
+        if (keep_slot_host && keep_slot_host[i + 1] >= 0 && out_latents)
+            HIPCHK(hipMemcpyAsync((char*)out_latents + (size_t)keep_slot_host[i + 1] * lat_bytes, nxt, lat_bytes, hipMemcpyDeviceToDevice, st));
+        char* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (out_final) HIPCHK(hipMemcpyAsync(out_final, cur, lat_bytes, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// ----------------------------------------------------------------------- operator-level API
+extern "C" int mi355_op_linear(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                               int act) {
+    if (!A || !W || !bias || !out) return fail("mi355_op_linear: null argument");
+    if (K % 64 || N % 4) return fail("mi355_op_linear: K %% 64 and N %% 4 must be 0");
+    GemmParams g = gp((const bf16_t*)A, K, (const bf16_t*)W, K, M, N, K, act == 1 ? EPI_BIAS_SILU : act == 2 ? EPI_BIAS_GELU : EPI_BIAS,
+                      bias, (bf16_t*)out, N);
+    HIPCHK(launch_gemm(g, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int mi355_op_attention(void* stream, const void* q, const void* k, const void* vT, void* o_img, void* o_ctx, int B,
+                                  int H, int S, int S_pad, int n_img) {
+    if (!q || !k || !vT || !o_img) return fail("mi355_op_attention: null argument");
+    if (n_img < S && !o_ctx) return fail("mi355_op_attention: o_ctx is NULL but S > n_img");
+    AttnParams a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vT, (bf16_t*)o_img, (bf16_t*)o_ctx, B, H, S, S_pad, n_img};
+    HIPCHK(launch_attention(a, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int mi355_op_ln_modulate(void* stream, const void* x, const void* shift, const void* scale, void* out, int M, int D,
+                                    int rows_per_sample, float eps) {
+    if (!x || !shift || !scale || !out) return fail("mi355_op_ln_modulate: null argument");
+    LnModParams l;
+    memset(&l, 0, sizeof(l));
+    // shift / scale are separate [nb][D] tensors: address them relative to `shift`
+    l.x = (const bf16_t*)x; l.out = (bf16_t*)out; l.out2 = nullptr; l.mod = (const bf16_t*)shift; l.mod_ld = D;
+    l.shift_off = 0;
+    const long delta = (const bf16_t*)scale - (const bf16_t*)shift;
+    if (delta < -2147483647L || delta > 2147483647L) return fail("mi355_op_ln_modulate: shift/scale too far apart");
+    l.scale_off = (int)delta;
+    l.M = M; l.D = D; l.rows_per_sample = rows_per_sample; l.eps = eps;
+    HIPCHK(launch_ln_mod(l, (hipStream_t)stream));
+    return 0;
+}

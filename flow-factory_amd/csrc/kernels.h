@@ -1,0 +1,101 @@
+// mi355_flow -- host-visible kernel launchers (internal C++ API; the drop-in boundary is
+// include/mi355_flow.h).  Every launcher enqueues on `stream` and never synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+
+namespace mi355 {
+
+// ------------------------------------------------------------------------------------ GEMM
+// C[m][n] = sum_k A[m][k] * W[n][k]   (both operands K-contiguous bf16, fp32 accumulate on
+// v_mfma_f32_16x16x32_bf16); the epilogue decides what is written.  K % 64 == 0.
+enum GemmEpi : int {
+    EPI_BIAS = 0,       // out[m][n] = bf16(acc + bias[n])
+    EPI_BIAS_SILU,      // out = bf16(silu(bf16(acc + bias)))
+    EPI_BIAS_GELU,      // out = bf16(gelu_tanh(acc + bias))
+    EPI_POSADD,         // out = bf16(acc + bias[n] + aux[(m % rows_per_sample)][n])   (patch-embed + pos-embed)
+    EPI_ADDSRC_SILU,    // out = bf16(silu(bf16(acc + bias[n] + aux[m % rows_per_sample][n])))  (temb = t_emb + pooled_emb)
+    EPI_GATE_RES,       // out[m][n] = bf16(out[m][n] + gate[m / rows_per_sample][n] * (acc + bias[n]))  (in place)
+    EPI_QK_NORM,        // per-head RMSNorm of (acc + bias) then scatter to q/k [b][h][s][64]
+    EPI_VT,             // rows = features, cols = tokens: vT[b][h][d][s] = bf16(acc + bias[m])
+    EPI_UNPATCH,        // proj_out: scatter (token, (p,q,c)) -> latent [b][c][y][x] (bf16)
+    EPI_COUNT
+};
+
+struct GemmParams {
+    const bf16_t* A; long lda;
+    const bf16_t* W; long ldw;
+    int M, N, K;
+    int epi;
+    const float* bias;        // [N], or [M] for EPI_VT
+    bf16_t* out; long ldo;
+    const bf16_t* aux; long ld_aux;   // POSADD: table; ADDSRC: src; GATE_RES: gate base (row stride ld_aux per sample)
+    int rows_per_sample;      // tokens per sample of the row (or column, EPI_VT) dimension
+    // EPI_QK_NORM / EPI_VT scatter
+    bf16_t* q; bf16_t* k;     // q,k: [B][H][S_pad][64];  EPI_VT: q = vT [B][H][64][S_pad]
+    const float* nw_q; const float* nw_k;   // RMSNorm weights [64]
+    int H, S_pad, s_off; float eps;
+    // EPI_UNPATCH
+    int hp, wp, patch, out_ch;
+};
+
+hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);
+
+// ------------------------------------------------------------------------------- attention
+// Non-causal softmax(q k^T / 8) v over S keys, head_dim 64.  q,k: [B][H][S_pad][64],
+// vT: [B][H][64][S_pad] (keys >= S must be finite).  Output rows: query s < n_img goes to
+// o_img[(b*n_img + s)][h*64 + d], the rest to o_ctx[(b*(S-n_img) + s-n_img)][h*64 + d].
+struct AttnParams {
+    const bf16_t* q; const bf16_t* k; const bf16_t* vT;
+    bf16_t* o_img; bf16_t* o_ctx;
+    int B, H, S, S_pad, n_img;
+};
+hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
+
+// ------------------------------------------------------------------------------ elementwise
+// LayerNorm(no affine, eps) + AdaLN modulate: out = LN(x)*(1+scale[b]) + shift[b]; optional
+// second modulated copy (dual blocks).  x,out: [M][D] bf16; mod vectors bf16 at
+// mod + b*mod_ld + {shift,scale}_off.
+struct LnModParams {
+    const bf16_t* x; bf16_t* out; bf16_t* out2;
+    const bf16_t* mod; long mod_ld;
+    int shift_off, scale_off, shift2_off, scale2_off;
+    int M, D, rows_per_sample; float eps;
+};
+hipError_t launch_ln_mod(const LnModParams& p, hipStream_t stream);
+
+// latents [B][C][h][w] (storage dtype) -> patches [B*hp*wp][C*p*p] bf16 (k = c*p*p + py*p + px);
+// `rep` > 1 replicates the batch (CFG: latents_input = cat([latents, latents])).
+hipError_t launch_patchify(const void* lat, int dt, bf16_t* patches, int B, int rep, int C, int h, int w, int p,
+                           hipStream_t stream);
+// pos_embed buffer [max*max][D] bf16 -> centre crop [hp*wp][D]
+hipError_t launch_pos_crop(const bf16_t* pos, bf16_t* out, int max_size, int hp, int wp, int D, hipStream_t stream);
+// sinusoidal timestep projection (cos first): out[r][dim] bf16, t rounded to `t_round_dt` first
+hipError_t launch_time_proj(const float* t, int rows, int dim, int t_round_dt, bf16_t* out, hipStream_t stream);
+// generic dtype conversion (weights binding); n elements
+hipError_t launch_convert(const void* src, int src_dt, void* dst, int dst_dt, long n, hipStream_t stream);
+
+// --------------------------------------------------------------------------- SDE step (K15)
+enum Dynamics : int { DYN_ODE = 0, DYN_FLOW_SDE = 1, DYN_DANCE_SDE = 2, DYN_CPS = 3 };
+struct SdeStepParams {
+    const bf16_t* v_text;     // network output (bf16) [B][n]; with CFG: text branch
+    const bf16_t* v_uncond;   // nullptr => no CFG
+    float guidance;
+    const void* latents; int lat_dt;          // x_i, storage dtype
+    const float* noise;                       // eps [B][n] fp32 (ignored when next_in != nullptr)
+    const void* next_in; int next_in_dt;      // replay: provided x_{i+1} (not re-rounded)
+    const float* sigma; const float* sigma_next; const float* eta;   // device scalars
+    int scalar_stride;                        // 0: one value for the whole batch, 1: per sample
+    float sigma_max;
+    int dynamics; int compute_log_prob;
+    int B; long n;                            // elements per sample
+    void* next_out; int next_out_dt;          // x_{i+1} in the storage dtype (may be nullptr)
+    float* next_f32;                          // optional fp32 (value-rounded) copy
+    float* mean_out;                          // optional next_latents_mean fp32
+    float* noise_pred_out;                    // optional CFG-combined noise_pred as fp32
+    float* log_prob; float* std_dev_t; float* dt_out;   // [B] (optional)
+};
+hipError_t launch_sde_step(const SdeStepParams& p, hipStream_t stream);
+
+}  // namespace mi355

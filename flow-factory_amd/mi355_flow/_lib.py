@@ -1,0 +1,86 @@
+"""ctypes binding of libmi355flow.so (C ABI: include/mi355_flow.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C flow-factory_amd/csrc`.
+There is NO fallback: if the shared object is missing or a call fails, this module raises
+(reference error convention: fail fast, never degrade silently -- constraints.md:144-145).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libmi355flow.so")
+
+F32, BF16, F16 = 0, 1, 2
+ODE, FLOW_SDE, DANCE_SDE, CPS = 0, 1, 2, 3
+DYNAMICS = {"ODE": ODE, "Flow-SDE": FLOW_SDE, "Dance-SDE": DANCE_SDE, "CPS": CPS}
+
+
+class ModelCfg(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32), ("out_channels", C.c_int32), ("patch_size", C.c_int32),
+        ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("head_dim", C.c_int32),
+        ("joint_attention_dim", C.c_int32), ("pooled_projection_dim", C.c_int32),
+        ("pos_embed_max_size", C.c_int32), ("time_proj_dim", C.c_int32), ("ff_mult", C.c_int32),
+        ("dual_layer_mask", C.c_uint64), ("eps", C.c_float),
+    ]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_L = C.c_int64
+
+# name -> (restype, argtypes); must list every symbol declared in include/mi355_flow.h
+SIGNATURES = {
+    "mi355_version": (_I, []),
+    "mi355_last_error": (C.c_char_p, []),
+    "mi355_engine_create": (_I, [C.POINTER(ModelCfg), C.POINTER(_P)]),
+    "mi355_engine_destroy": (_I, [_P]),
+    "mi355_engine_bind_weight": (_I, [_P, C.c_char_p, _P, _I, _I, C.POINTER(_L), _P]),
+    "mi355_engine_weights_ready": (_I, [_P]),
+    "mi355_engine_num_params": (_I, [_P]),
+    "mi355_engine_param_name": (C.c_char_p, [_P, _I]),
+    "mi355_plan_create": (_I, [_P, _I, _I, _I, _I, _I, _I, C.POINTER(_P)]),
+    "mi355_plan_destroy": (_I, [_P]),
+    "mi355_plan_workspace_bytes": (_L, [_P]),
+    "mi355_transformer_forward": (_I, [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P]),
+    "mi355_sde_step": (_I, [_P, _I, _L, _P, _P, _F, _P, _I, _P, _P, _I, _P, _P, _P, _I, _F, _I, _I,
+                            _P, _P, _P, _P, _P, _P, _P]),
+    "mi355_denoise_step": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P, _P, _P, _I, _F, _I, _I,
+                                _P, _P, _P, _P, _P, _P, _P]),
+    "mi355_rollout": (_I, [_P, _P, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _I, _F, _P, _I, _I, _P,
+                           _P, _P, _P, _P, C.POINTER(C.c_int32), _P, _P, _P, _I]),
+    "mi355_op_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I]),
+    "mi355_op_attention": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    "mi355_op_ln_modulate": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library (no GPU needed to load; compute calls need one)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"mi355_flow: {LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C flow-factory_amd/csrc`).  There is no CPU / PyTorch fallback for the rollout hot path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().mi355_last_error()
+        raise RuntimeError(f"mi355_flow {what} failed: {msg.decode() if msg else 'unknown error'}")

@@ -1,0 +1,331 @@
+"""Thin torch-facing wrappers over the C ABI: tensors in, tensors out, current HIP stream.
+
+PyTorch is plumbing here (device memory, streams); every computation on the rollout hot path
+runs in libmi355flow.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BF16, DYNAMICS, F16, F32, ModelCfg
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise ValueError(f"mi355_flow: unsupported dtype {dt} (float32 / bfloat16 / float16 only)") from None
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("mi355_flow: expected a tensor on the GPU (there is no CPU fallback)")
+    if not t.is_contiguous():
+        raise ValueError("mi355_flow: tensors passed to the engine must be contiguous")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+@dataclass
+class TransformerConfig:
+    """diffusers SD3Transformer2DModel config fields the engine needs (SD3.5-medium defaults)."""
+    in_channels: int = 16
+    out_channels: int = 16
+    patch_size: int = 2
+    num_layers: int = 24
+    num_heads: int = 24
+    head_dim: int = 64
+    joint_attention_dim: int = 4096
+    pooled_projection_dim: int = 2048
+    pos_embed_max_size: int = 384
+    dual_layers: Tuple[int, ...] = tuple(range(13))
+    time_proj_dim: int = 256
+    ff_mult: int = 4
+    eps: float = 1e-6
+
+    @property
+    def dim(self) -> int:
+        return self.num_heads * self.head_dim
+
+    def to_c(self) -> ModelCfg:
+        mask = 0
+        for i in self.dual_layers:
+            mask |= 1 << int(i)
+        return ModelCfg(self.in_channels, self.out_channels, self.patch_size, self.num_layers, self.num_heads,
+                        self.head_dim, self.joint_attention_dim, self.pooled_projection_dim, self.pos_embed_max_size,
+                        self.time_proj_dim, self.ff_mult, mask, self.eps)
+
+
+class Engine:
+    """Owns the packed bf16 copy of the transformer weights (mi355_engine)."""
+
+    def __init__(self, cfg: TransformerConfig):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        h = C.c_void_p()
+        c = cfg.to_c()
+        _lib.check(self.lib.mi355_engine_create(C.byref(c), C.byref(h)), "engine_create")
+        self._h = h
+        self._plans: Dict[tuple, "Plan"] = {}
+
+    def param_names(self) -> List[str]:
+        n = self.lib.mi355_engine_num_params(self._h)
+        return [self.lib.mi355_engine_param_name(self._h, i).decode() for i in range(n)]
+
+    def bind_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        """Copy / re-pack torch Parameters (HF names) into the engine.  Call again after every
+        optimizer step, EMA swap or LoRA merge: the weights are live during GRPO."""
+        names = self.param_names()
+        missing = [n for n in names if n not in state_dict]
+        if missing and strict:
+            raise KeyError(f"mi355_flow: state dict lacks {len(missing)} parameters, first: {missing[0]}")
+        st = _stream()
+        for n in names:
+            if n not in state_dict:
+                continue
+            t = state_dict[n].detach()
+            if not t.is_cuda:
+                t = t.cuda(non_blocking=True)
+            t = t.contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            _lib.check(self.lib.mi355_engine_bind_weight(self._h, n.encode(), t.data_ptr(), dtype_code(t.dtype),
+                                                         t.dim(), shape, st), f"bind_weight({n})")
+        # conversion kernels read the (possibly temporary) source tensors asynchronously
+        torch.cuda.current_stream().synchronize()
+
+    def ready(self) -> None:
+        _lib.check(self.lib.mi355_engine_weights_ready(self._h), "weights_ready")
+
+    def plan(self, batch: int, n_cfg: int, latent_h: int, latent_w: int, n_text: int, max_steps: int) -> "Plan":
+        key = (batch, n_cfg, latent_h, latent_w, n_text)
+        p = self._plans.get(key)
+        if p is None or p.max_steps < max_steps:
+            if p is not None:
+                p.close()
+            p = Plan(self, batch, n_cfg, latent_h, latent_w, n_text, max_steps)
+            self._plans[key] = p
+        return p
+
+    def close(self) -> None:
+        for p in self._plans.values():
+            p.close()
+        self._plans.clear()
+        if self._h:
+            self.lib.mi355_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan:
+    """Workspace for one (batch, n_cfg, latent_h, latent_w, n_text) shape (mi355_plan)."""
+
+    def __init__(self, engine: Engine, batch: int, n_cfg: int, latent_h: int, latent_w: int, n_text: int, max_steps: int):
+        self.engine, self.lib = engine, engine.lib
+        self.batch, self.n_cfg, self.h, self.w, self.n_text, self.max_steps = batch, n_cfg, latent_h, latent_w, n_text, max_steps
+        self.C = engine.cfg.in_channels
+        h = C.c_void_p()
+        _lib.check(self.lib.mi355_plan_create(engine._h, batch, n_cfg, latent_h, latent_w, n_text, max_steps, C.byref(h)),
+                   "plan_create")
+        self._h = h
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self.lib.mi355_plan_workspace_bytes(self._h))
+
+    def close(self) -> None:
+        if self._h:
+            self.lib.mi355_plan_destroy(self._h)
+            self._h = None
+
+    # ---------------------------------------------------------------- denoiser forward
+    def transformer_forward(self, latents, timestep, enc_a, pooled_a, enc_b=None, pooled_b=None, t_round_dtype=None):
+        B, Bp = self.batch, self.batch * self.n_cfg
+        assert latents.shape == (B, self.C, self.h, self.w), latents.shape
+        t = timestep.to(device=latents.device, dtype=torch.float32).reshape(-1)
+        if t.numel() == 1:
+            t = t.expand(Bp)
+        t = t.contiguous()
+        assert t.numel() == Bp
+        out = torch.empty((Bp, self.C, self.h, self.w), device=latents.device, dtype=torch.bfloat16)
+        rd = dtype_code(t_round_dtype if t_round_dtype is not None else latents.dtype)
+        enc_a, pooled_a = _bf16c(enc_a), _bf16c(pooled_a)
+        enc_b = _bf16c(enc_b) if enc_b is not None else None
+        pooled_b = _bf16c(pooled_b) if pooled_b is not None else None
+        latents = latents.contiguous()
+        _lib.check(self.lib.mi355_transformer_forward(self._h, _stream(), _ptr(latents), dtype_code(latents.dtype), _ptr(t), rd,
+                                                      _ptr(enc_a), _ptr(pooled_a), _ptr(enc_b), _ptr(pooled_b), _ptr(out)),
+                   "transformer_forward")
+        return out
+
+    # ---------------------------------------------------------------- one denoise step (forward + CFG + SDE step)
+    def denoise_step(self, latents, timestep, enc_a, pooled_a, enc_b, pooled_b, guidance, sigma, sigma_next, eta,
+                     sigma_max, dynamics: str, noise=None, next_latents=None, compute_log_prob=True, want=()):
+        B = self.batch
+        dev = latents.device
+        latents = latents.contiguous()
+        n = latents[0].numel()
+        t = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
+        if t.numel() == 1:
+            t = t.expand(B * self.n_cfg)
+        elif t.numel() == B and self.n_cfg == 2:
+            t = t.repeat(2)
+        t = t.contiguous()
+        sig, sig_n, et, stride = _scalars(sigma, sigma_next, eta, B, dev)
+        outs = _StepOutputs(B, latents, want, compute_log_prob)
+        enc_a, pooled_a = _bf16c(enc_a), _bf16c(pooled_a)
+        enc_b = _bf16c(enc_b) if enc_b is not None else None
+        pooled_b = _bf16c(pooled_b) if pooled_b is not None else None
+        noise = noise.contiguous() if noise is not None else None
+        nxt_in = next_latents.contiguous() if next_latents is not None else None
+        _lib.check(self.lib.mi355_denoise_step(
+            self._h, _stream(), _ptr(latents), dtype_code(latents.dtype), _ptr(t), _ptr(enc_a), _ptr(pooled_a),
+            _ptr(enc_b), _ptr(pooled_b), float(guidance), _ptr(noise), _ptr(nxt_in),
+            dtype_code(nxt_in.dtype) if nxt_in is not None else 0, _ptr(sig), _ptr(sig_n), _ptr(et), stride,
+            float(sigma_max), DYNAMICS[dynamics], int(bool(compute_log_prob)), *outs.ptrs()), "denoise_step")
+        return outs
+
+    # ---------------------------------------------------------------- whole rollout
+    def rollout(self, timesteps: Sequence[float], sigmas: Sequence[float], noise_levels: Sequence[float], dynamics: str,
+                guidance: float, init_latents: torch.Tensor, storage_dtype: torch.dtype, step_noise: torch.Tensor,
+                prompt_embeds, pooled, neg_embeds=None, neg_pooled=None, keep_positions: Optional[Sequence[int]] = None,
+                compute_log_prob: bool = True):
+        """Returns (kept_latents [n_kept,B,C,h,w] storage dtype, log_probs [N,B] fp32 (nan where not
+        computed), final_latents [B,C,h,w])."""
+        N, B = len(timesteps), self.batch
+        assert len(sigmas) == N + 1 and len(noise_levels) == N
+        dev = init_latents.device
+        keep = list(range(N + 1)) if keep_positions is None else sorted(set(int(k) for k in keep_positions))
+        slots = [-1] * (N + 1)
+        for s, pos in enumerate(keep):
+            slots[pos] = s
+        shape = (B, self.C, self.h, self.w)
+        out_lat = torch.empty((len(keep),) + shape, device=dev, dtype=storage_dtype)
+        out_lp = torch.full((N, B), float("nan"), device=dev, dtype=torch.float32)
+        out_fin = torch.empty(shape, device=dev, dtype=storage_dtype)
+        fa = C.c_float * N
+        ts_c, nl_c = fa(*[float(t) for t in timesteps]), fa(*[float(e) for e in noise_levels])
+        sg_c = (C.c_float * (N + 1))(*[float(s) for s in sigmas])
+        sl_c = (C.c_int32 * (N + 1))(*slots)
+        init_latents = init_latents.contiguous()
+        step_noise = step_noise.contiguous() if step_noise is not None else None
+        if step_noise is not None:
+            assert step_noise.dtype == torch.float32 and step_noise.shape == (N,) + shape, step_noise.shape
+        pe, pp = _bf16c(prompt_embeds), _bf16c(pooled)
+        ne = _bf16c(neg_embeds) if neg_embeds is not None else None
+        npl = _bf16c(neg_pooled) if neg_pooled is not None else None
+        _lib.check(self.lib.mi355_rollout(
+            self._h, _stream(), N, ts_c, sg_c, nl_c, DYNAMICS[dynamics], float(guidance), _ptr(init_latents),
+            dtype_code(init_latents.dtype), dtype_code(storage_dtype), _ptr(step_noise), _ptr(pe), _ptr(pp), _ptr(ne),
+            _ptr(npl), sl_c, _ptr(out_lat), _ptr(out_lp), _ptr(out_fin), int(bool(compute_log_prob))), "rollout")
+        return out_lat, out_lp, out_fin
+
+
+def _bf16c(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).contiguous()
+
+
+def _scalars(sigma, sigma_next, eta, B, dev):
+    def one(v):
+        if not isinstance(v, torch.Tensor):
+            v = torch.tensor([float(v)], dtype=torch.float32)
+        return v.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+
+    s, sn, e = one(sigma), one(sigma_next), one(eta)
+    per = max(s.numel(), sn.numel(), e.numel())
+    if per == 1:
+        return s, sn, e, 0
+    assert per == B, "per-sample scalars must have one value per sample"
+    ex = lambda v: (v.expand(B) if v.numel() == 1 else v).contiguous()
+    return ex(s), ex(sn), ex(e), 1
+
+
+class _StepOutputs:
+    """Output buffers of one SDE step, allocated by torch (the engine never owns outputs)."""
+
+    FIELDS = ("next_latents", "next_latents_mean", "noise_pred", "log_prob", "std_dev_t", "dt")
+
+    def __init__(self, B: int, latents: torch.Tensor, want: Iterable[str], compute_log_prob: bool):
+        dev, shp = latents.device, latents.shape
+        want = set(want)
+        self.next_storage = torch.empty_like(latents)
+        self.next_latents = torch.empty(shp, device=dev, dtype=torch.float32) if "next_latents" in want else None
+        self.next_latents_mean = torch.empty(shp, device=dev, dtype=torch.float32) if "next_latents_mean" in want else None
+        self.noise_pred = torch.empty(shp, device=dev, dtype=torch.float32) if "noise_pred" in want else None
+        self.log_prob = torch.empty((B,), device=dev, dtype=torch.float32) if compute_log_prob else None
+        self.std_dev_t = torch.empty((B,), device=dev, dtype=torch.float32) if "std_dev_t" in want else None
+        self.dt = torch.empty((B,), device=dev, dtype=torch.float32) if "dt" in want else None
+
+    def ptrs(self):
+        return (_ptr(self.next_storage), _ptr(self.next_latents), _ptr(self.next_latents_mean), _ptr(self.noise_pred),
+                _ptr(self.log_prob), _ptr(self.std_dev_t), _ptr(self.dt))
+
+
+def sde_step(v_text, v_uncond, guidance, latents, sigma, sigma_next, eta, sigma_max, dynamics: str, noise=None,
+             next_latents=None, compute_log_prob=True, want=("next_latents", "next_latents_mean", "noise_pred", "std_dev_t", "dt")):
+    """Standalone fused CFG + SDE/ODE step + log-prob (mi355_sde_step)."""
+    lib = _lib.load()
+    B = latents.shape[0]
+    latents = latents.contiguous()
+    n = latents[0].numel()
+    sig, sig_n, et, stride = _scalars(sigma, sigma_next, eta, B, latents.device)
+    outs = _StepOutputs(B, latents, want, compute_log_prob)
+    v_text = _bf16c(v_text)
+    v_uncond = _bf16c(v_uncond) if v_uncond is not None else None
+    noise = noise.to(torch.float32).contiguous() if noise is not None else None
+    nxt_in = next_latents.contiguous() if next_latents is not None else None
+    _lib.check(lib.mi355_sde_step(
+        _stream(), B, n, _ptr(v_text), _ptr(v_uncond), float(guidance), _ptr(latents), dtype_code(latents.dtype), _ptr(noise),
+        _ptr(nxt_in), dtype_code(nxt_in.dtype) if nxt_in is not None else 0, _ptr(sig), _ptr(sig_n), _ptr(et), stride,
+        float(sigma_max), DYNAMICS[dynamics], int(bool(compute_log_prob)), *outs.ptrs()), "sde_step")
+    return outs
+
+
+# ---------------------------------------------------------------------- operator-level wrappers (tests / profiling)
+def op_linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, act: int = 0) -> torch.Tensor:
+    lib = _lib.load()
+    x, w = _bf16c(x), _bf16c(w)
+    bias = bias.to(torch.float32).contiguous()
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), device=x.device, dtype=torch.bfloat16)
+    _lib.check(lib.mi355_op_linear(_stream(), _ptr(x), _ptr(w), _ptr(bias), _ptr(out), M, N, K, act), "op_linear")
+    return out
+
+
+def op_attention(q: torch.Tensor, k: torch.Tensor, vT: torch.Tensor, S: int, n_img: int):
+    """q,k: [B,H,S_pad,64] bf16; vT: [B,H,64,S_pad] bf16 -> (o_img [B*n_img, H*64], o_ctx [B*(S-n_img), H*64])."""
+    lib = _lib.load()
+    B, H, S_pad, hd = q.shape
+    assert hd == 64 and vT.shape == (B, H, 64, S_pad)
+    o_img = torch.empty((B * n_img, H * 64), device=q.device, dtype=torch.bfloat16)
+    o_ctx = torch.empty((max(B * (S - n_img), 1), H * 64), device=q.device, dtype=torch.bfloat16)
+    _lib.check(lib.mi355_op_attention(_stream(), _ptr(q.contiguous()), _ptr(k.contiguous()), _ptr(vT.contiguous()),
+                                      _ptr(o_img), _ptr(o_ctx), B, H, S, S_pad, n_img), "op_attention")
+    return o_img, o_ctx[: B * (S - n_img)]
+
+
+def op_ln_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, rows_per_sample: int, eps: float = 1e-6):
+    lib = _lib.load()
+    M, D = x.shape
+    mod = torch.stack([_bf16c(shift), _bf16c(scale)], 0).contiguous()  # [2][nb][D]: one allocation
+    out = torch.empty_like(x)
+    _lib.check(lib.mi355_op_ln_modulate(_stream(), _ptr(_bf16c(x)), _ptr(mod[0]), _ptr(mod[1]), _ptr(out), M, D,
+                                        rows_per_sample, eps), "op_ln_modulate")
+    return out

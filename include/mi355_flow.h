@@ -1,0 +1,140 @@
+/* mi355_flow.h -- C ABI of libmi355flow.so, the MI355X-native GRPO rollout engine for
+ * SD3.5-medium (MMDiT-X) that drops in under X-GenGroup/Flow-Factory's adapter API.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero on error; `mi355_last_error()` then holds a
+ *     message (thread-local).  Nothing falls back silently (reference constraints.md:144-145).
+ *   - all `const void*`/`void*` data arguments are DEVICE pointers unless the name ends in
+ *     `_host`; they are borrowed for the duration of the call's stream work and never aliased
+ *     across calls (outputs are written into caller-allocated buffers).
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises.
+ *   - dtypes: MI355_F32 / MI355_BF16 / MI355_F16; activations and weights inside the engine are
+ *     bf16 with fp32 accumulation, the scheduler math is fp32.
+ *
+ * Reference interfaces replaced (X-GenGroup/Flow-Factory @ 2026-05-01, paths under
+ * src/flow_factory/):
+ *   mi355_transformer_forward  <- `self.transformer(hidden_states, timestep, encoder_hidden_states,
+ *                                 pooled_projections, return_dict=False)[0]`
+ *                                 models/stable_diffusion/sd3_5.py:421-428 (diffusers SD3Transformer2DModel)
+ *   mi355_sde_step             <- FlowMatchEulerDiscreteSDEScheduler.step
+ *                                 scheduler/flow_match_euler_discrete.py:243-438 (+ CFG combine
+ *                                 sd3_5.py:431-433, cast_latents models/abc.py:172-182)
+ *   mi355_denoise_step         <- SD3_5Adapter.forward  models/stable_diffusion/sd3_5.py:352-448
+ *   mi355_rollout              <- the N-step loop of SD3_5Adapter.inference  sd3_5.py:258-304
+ *   mi355_engine_bind_weight   <- the torch Parameters of `pipeline.transformer`
+ *                                 (models/abc.py:314-320), HF state-dict names
+ */
+#ifndef MI355_FLOW_H
+#define MI355_FLOW_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355_FLOW_VERSION 1
+
+enum { MI355_F32 = 0, MI355_BF16 = 1, MI355_F16 = 2 };
+enum { MI355_ODE = 0, MI355_FLOW_SDE = 1, MI355_DANCE_SDE = 2, MI355_CPS = 3 };
+
+typedef struct mi355_engine mi355_engine;
+typedef struct mi355_plan mi355_plan;
+
+/* SD3Transformer2DModel config (diffusers `transformer/config.json`).  head_dim must be 64. */
+typedef struct mi355_model_cfg {
+    int32_t in_channels, out_channels, patch_size;
+    int32_t num_layers, num_heads, head_dim;
+    int32_t joint_attention_dim, pooled_projection_dim;
+    int32_t pos_embed_max_size, time_proj_dim, ff_mult;
+    uint64_t dual_layer_mask; /* bit i set: block i carries attn2 (SD3.5-medium: bits 0..12) */
+    float eps;
+} mi355_model_cfg;
+
+int mi355_version(void);
+const char* mi355_last_error(void);
+
+/* ---- engine: owns a packed bf16 copy of the transformer weights --------------------------- */
+int mi355_engine_create(const mi355_model_cfg* cfg, mi355_engine** out);
+int mi355_engine_destroy(mi355_engine* e);
+/* Copy (and convert / re-pack) one named parameter, e.g. "transformer_blocks.3.attn.to_q.weight".
+ * `src` is a contiguous device tensor of dtype `dtype` and shape `shape[ndim]`.  Call again after
+ * an optimizer step / EMA swap / LoRA merge to refresh (weights are live in GRPO). */
+int mi355_engine_bind_weight(mi355_engine* e, const char* name, const void* src, int dtype, int ndim,
+                             const int64_t* shape, void* stream);
+/* 0 if every parameter of the config has been bound at least once, else error listing the first missing. */
+int mi355_engine_weights_ready(mi355_engine* e);
+/* number of parameter tensors the engine expects, and the i-th expected name (for binding loops) */
+int mi355_engine_num_params(mi355_engine* e);
+const char* mi355_engine_param_name(mi355_engine* e, int i);
+
+/* ---- plan: workspace for one (batch, n_cfg, latent_h, latent_w, n_text, max_steps) shape -- */
+int mi355_plan_create(mi355_engine* e, int batch, int n_cfg, int latent_h, int latent_w, int n_text_tokens,
+                      int max_steps, mi355_plan** out);
+int mi355_plan_destroy(mi355_plan* p);
+int64_t mi355_plan_workspace_bytes(mi355_plan* p);
+
+/* ---- denoiser forward (K0-K13) -------------------------------------------------------------
+ * latents : [batch][C][h][w] of `lat_dtype`; with n_cfg == 2 the batch is used twice
+ *           (reference: latents_input = cat([latents, latents]), sd3_5.py:409-413).
+ * t       : [batch*n_cfg] fp32 timesteps in [0,1000]; rounded to `t_round_dtype` before the
+ *           sinusoidal embedding (reference: t.expand(B).to(latents.dtype), sd3_5.py:394).
+ * enc_a/pooled_a : first half of the forward batch (negative prompt when n_cfg == 2, else the prompt)
+ * enc_b/pooled_b : second half (the prompt) when n_cfg == 2, else NULL.  bf16,
+ *           [batch][n_text][joint_attention_dim] and [batch][pooled_projection_dim].
+ * v_out   : [batch*n_cfg][C][h][w] bf16 (order [negative, positive], sd3_5.py:432). */
+int mi355_transformer_forward(mi355_plan* p, void* stream, const void* latents, int lat_dtype, const float* t,
+                              int t_round_dtype, const void* enc_a, const void* pooled_a, const void* enc_b,
+                              const void* pooled_b, void* v_out);
+
+/* ---- fused CFG-combine + SDE/ODE step + log-prob (K14-K17), usable standalone ---------------
+ * v_text/v_uncond : bf16 [batch][n]; v_uncond NULL => no CFG.   latents: storage dtype.
+ * noise           : fp32 eps [batch][n] (rollout) -- ignored when next_in != NULL (replay).
+ * sigma/sigma_next/eta : device fp32, one value (scalar_stride 0) or one per sample (stride 1).
+ * outputs (any may be NULL): next_out (storage dtype `lat_dtype`), next_f32 (value-rounded fp32,
+ * what the reference's step() returns), mean_out fp32, noise_pred_out fp32 (CFG-combined),
+ * log_prob/std_dev_t/dt [batch] fp32. */
+int mi355_sde_step(void* stream, int batch, int64_t n, const void* v_text, const void* v_uncond, float guidance,
+                   const void* latents, int lat_dtype, const float* noise, const void* next_in, int next_in_dtype,
+                   const float* sigma, const float* sigma_next, const float* eta, int scalar_stride, float sigma_max,
+                   int dynamics, int compute_log_prob, void* next_out, float* next_f32, float* mean_out,
+                   float* noise_pred_out, float* log_prob, float* std_dev_t, float* dt);
+
+/* ---- one denoise step = forward + CFG + step (SD3_5Adapter.forward); replay when next_in != NULL */
+int mi355_denoise_step(mi355_plan* p, void* stream, const void* latents, int lat_dtype, const float* t,
+                       const void* enc_a, const void* pooled_a, const void* enc_b, const void* pooled_b,
+                       float guidance, const float* noise, const void* next_in, int next_in_dtype,
+                       const float* sigma, const float* sigma_next, const float* eta, int scalar_stride,
+                       float sigma_max, int dynamics, int compute_log_prob, void* next_out, float* next_f32,
+                       float* mean_out, float* noise_pred_out, float* log_prob, float* std_dev_t, float* dt);
+
+/* ---- whole rollout: N denoise steps with no host sync ----------------------------------------
+ * timesteps_host[N], sigmas_host[N+1] (scheduler.sigmas, last = 0), noise_levels_host[N]: host arrays.
+ * init_latents : [batch][C][h][w] of `init_dtype` (prepare_latents output), cast to `storage_dtype`
+ *                with the fp16 clamp of cast_latents.
+ * step_noise   : fp32 [N][batch][C][h][w], drawn by the caller in the reference's RNG order.
+ * keep_slot_host[N+1] : trajectory position -> slot in out_latents, or -1 (TrajectoryCollector).
+ * out_latents  : [n_kept][batch][C][h][w] storage dtype;  out_log_probs : fp32 [N][batch]
+ *                (written only for steps with noise_level > 0 when compute_log_prob);
+ * out_final    : [batch][C][h][w] storage dtype (x_N). */
+int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const float* timesteps_host, const float* sigmas_host,
+                  const float* noise_levels_host, int dynamics, float guidance, const void* init_latents,
+                  int init_dtype, int storage_dtype, const float* step_noise, const void* prompt_embeds,
+                  const void* pooled, const void* neg_embeds, const void* neg_pooled, const int32_t* keep_slot_host,
+                  void* out_latents, float* out_log_probs, void* out_final, int compute_log_prob);
+
+/* ---- operator-level entry points (unit tests, per-kernel profiling) ------------------------- */
+/* out[M][N] (bf16, ld = N) = A[M][K] . W[N][K]^T + bias[N] (fp32 bias); act: 0 none, 1 silu, 2 gelu-tanh */
+int mi355_op_linear(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                    int act);
+/* q,k : [B][H][S_pad][64] bf16, vT : [B][H][64][S_pad] bf16 -> o_img [B*n_img][H*64], o_ctx [B*(S-n_img)][H*64] */
+int mi355_op_attention(void* stream, const void* q, const void* k, const void* vT, void* o_img, void* o_ctx, int B,
+                       int H, int S, int S_pad, int n_img);
+/* out = LayerNorm(x)*(1+scale[b]) + shift[b]; x,out [M][D] bf16; shift,scale [M/rows_per_sample][D] bf16 */
+int mi355_op_ln_modulate(void* stream, const void* x, const void* shift, const void* scale, void* out, int M, int D,
+                         int rows_per_sample, float eps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355_FLOW_H */
