@@ -53,7 +53,8 @@ __global__ __launch_bounds__(NT) void sde_step_kernel(SdeStepParams p) {
         dance_k = 0.5f * (eta * eta);
         sv = std_dev * sqrtf(-1.0f * dt);
     } else if (dyn == DYN_CPS) {
-        std_dev = sigma_next * sinf(eta * 3.14159274101257324f / 2.0f);
+        // sin through fp64 so the fp32 result is correctly rounded (torch CPU's sinf is <= 1 ulp off that)
+        std_dev = sigma_next * (float)sin((double)(eta * 3.14159274101257324f / 2.0f));
         cps_a = 1.0f - sigma_next;
         cps_b = sqrtf(sigma_next * sigma_next - std_dev * std_dev);
         sv = std_dev;

@@ -1,0 +1,312 @@
+"""`SD3_5NativeAdapter`: the rollout hot path of Flow-Factory's `SD3_5Adapter` on the MI355X engine.
+
+Mirrors `SD3_5Adapter.inference` / `SD3_5Adapter.forward` (reference
+src/flow_factory/models/stable_diffusion/sd3_5.py:176-349, :352-448): the parameter names and
+defaults are the ABI (the trainer filters kwargs by signature, trainers/grpo.py:165,252), the RNG
+draw order, latent storage dtype, CFG batch order and collector semantics are the reference's.
+The N-step loop itself runs inside libmi355flow.so (`mi355_rollout`) with no host sync.
+
+This class is self-contained (no `flow_factory` / `diffusers` import) so it runs and is tested
+here; `mi355_flow.flow_factory_plugin` subclasses the reference's own `SD3_5Adapter` with it when
+Flow-Factory is installed.
+"""
+from __future__ import annotations
+
+import logging
+from typing import Any, Callable, Dict, List, Optional, Union
+
+import torch
+
+from .engine import Engine, TransformerConfig
+from .samples import SD3_5Sample
+from .scheduler import FlowMatchEulerDiscreteSDEScheduler, SDESchedulerOutput, set_scheduler_timesteps
+from .trajectory import (TrajectoryIndicesType, create_callback_collector, create_trajectory_collector, _resolve)
+
+logger = logging.getLogger(__name__)
+
+_DTYPE_MAP = {"fp16": torch.float16, "float16": torch.float16, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
+              "fp32": torch.float32, "float32": torch.float32}
+VAE_SCALE_FACTOR = 8  # SD3 VAE: latent = image / 8
+
+
+class NativeRolloutMixin:
+    """inference()/forward() on the engine.  Host classes provide: `engine` (Engine), `scheduler`
+    (FlowMatchEulerDiscreteSDEScheduler-like), `device`, `transformer_dtype`,
+    `latent_storage_dtype`, `decode_latents(latents, output_type)`."""
+
+    engine: Engine
+    scheduler: FlowMatchEulerDiscreteSDEScheduler
+
+    # -------------------------------------------------------------- latent casting (models/abc.py:172-182)
+    def cast_latents(self, latents: torch.Tensor, default_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        target = self.latent_storage_dtype or default_dtype
+        if target is None or latents.dtype == target:
+            return latents
+        if target == torch.float16:
+            latents = latents.clamp(-65504.0, 65504.0)  # unconditional: no abs().max().item() host sync
+        return latents.to(target)
+
+    # -------------------------------------------------------------- rollout
+    @torch.no_grad()
+    def inference(
+        self,
+        prompt: Union[str, List[str], None] = None,
+        negative_prompt: Optional[Union[str, List[str]]] = None,
+        height: Optional[int] = 1024,
+        width: Optional[int] = 1024,
+        num_inference_steps: Optional[int] = 50,
+        guidance_scale: float = 7.5,
+        generator: Optional[torch.Generator] = None,
+        joint_attention_kwargs: Optional[Dict[str, Any]] = None,
+        prompt_ids: Optional[torch.Tensor] = None,
+        prompt_embeds: Optional[torch.Tensor] = None,
+        pooled_prompt_embeds: Optional[torch.Tensor] = None,
+        negative_prompt_ids: Optional[torch.Tensor] = None,
+        negative_prompt_embeds: Optional[torch.Tensor] = None,
+        negative_pooled_prompt_embeds: Optional[torch.Tensor] = None,
+        compute_log_prob: bool = True,
+        extra_call_back_kwargs: List[str] = [],
+        trajectory_indices: TrajectoryIndicesType = "all",
+    ) -> List[SD3_5Sample]:
+        device = self.device
+        dtype = self.transformer_dtype
+        if joint_attention_kwargs:
+            raise ValueError("mi355_flow: joint_attention_kwargs (LoRA scale, IP-adapter, ...) are not supported by the native engine")
+        do_cfg = guidance_scale > 1.0
+        has_neg = negative_prompt is not None or (negative_prompt_embeds is not None and negative_pooled_prompt_embeds is not None)
+        if do_cfg and not has_neg:
+            logger.warning("No negative prompt/embeds provided, classifier-free-guidance will be disabled.")
+            do_cfg = False
+        if prompt_embeds is None or pooled_prompt_embeds is None:
+            enc = self.encode_prompt(prompt, negative_prompt, guidance_scale=guidance_scale, device=device)
+            prompt_embeds, pooled_prompt_embeds, prompt_ids = enc["prompt_embeds"], enc["pooled_prompt_embeds"], enc["prompt_ids"]
+            if do_cfg:
+                negative_prompt_embeds = enc["negative_prompt_embeds"]
+                negative_prompt_ids = enc["negative_prompt_ids"]
+                negative_pooled_prompt_embeds = enc["negative_pooled_prompt_embeds"]
+        else:
+            prompt_embeds, pooled_prompt_embeds = prompt_embeds.to(device), pooled_prompt_embeds.to(device)
+            if do_cfg:
+                if negative_prompt_embeds is None or negative_pooled_prompt_embeds is None:
+                    raise ValueError("classifier-free guidance with pre-encoded prompts needs negative_prompt_embeds "
+                                     "and negative_pooled_prompt_embeds")
+                negative_prompt_embeds = negative_prompt_embeds.to(device)
+                negative_pooled_prompt_embeds = negative_pooled_prompt_embeds.to(device)
+        B = len(prompt_embeds)
+        C = self.engine.cfg.in_channels
+        h, w = int(height) // VAE_SCALE_FACTOR, int(width) // VAE_SCALE_FACTOR
+        N = int(num_inference_steps)
+
+        # RNG, in the reference's order on `generator` (None = the global device generator):
+        # prepare_latents (transformer dtype), then one fp32 draw per step -- also when noise_level == 0
+        latents = torch.randn((B, C, h, w), generator=generator, device=device, dtype=dtype)
+        step_noise = torch.empty((N, B, C, h, w), device=device, dtype=torch.float32)
+        for i in range(N):
+            step_noise[i] = torch.randn((B, C, h, w), generator=generator, device=device, dtype=torch.float32)
+
+        ps = self.engine.cfg.patch_size
+        timesteps = set_scheduler_timesteps(self.scheduler, N, seq_len=(h // ps) * (w // ps), device=device)
+        ts_host = [float(t) for t in timesteps.tolist()]          # one D2H before the loop, none inside
+        sig_host = [float(s) for s in self.scheduler.sigmas.tolist()]
+        eta_host = self.scheduler.host_noise_levels()
+        storage = self.latent_storage_dtype or dtype
+
+        n_text = prompt_embeds.shape[1]
+        plan = self.engine.plan(B, 2 if do_cfg else 1, h, w, n_text, N)
+        stepwise = any(k != "noise_level" for k in extra_call_back_kwargs)
+        kept = _resolve(trajectory_indices, N + 1)
+        keep_positions = list(range(N + 1)) if kept is None else sorted(kept)
+        if not stepwise:
+            lat_kept, log_probs, final = plan.rollout(
+                ts_host, sig_host, eta_host, self.scheduler.dynamics_type, guidance_scale, latents, storage, step_noise,
+                prompt_embeds, pooled_prompt_embeds, negative_prompt_embeds if do_cfg else None,
+                negative_pooled_prompt_embeds if do_cfg else None, keep_positions=keep_positions,
+                compute_log_prob=compute_log_prob)
+            pos_to_slot = {p: s for s, p in enumerate(keep_positions)}
+            get_lat = lambda pos: lat_kept[pos_to_slot[pos]]
+            step_outputs = None
+        else:
+            all_lat, log_probs, step_outputs = self._rollout_stepwise(
+                plan, ts_host, sig_host, eta_host, guidance_scale, latents, storage, step_noise, prompt_embeds,
+                pooled_prompt_embeds, negative_prompt_embeds if do_cfg else None,
+                negative_pooled_prompt_embeds if do_cfg else None, compute_log_prob, extra_call_back_kwargs)
+            get_lat = lambda pos: all_lat[pos]
+            final = all_lat[N]
+
+        # collectors: exactly the reference's bookkeeping (sd3_5.py:265-304) over the engine outputs
+        latent_collector = create_trajectory_collector(trajectory_indices, N)
+        log_prob_collector = create_trajectory_collector(trajectory_indices, N) if compute_log_prob else None
+        callback_collector = create_callback_collector(trajectory_indices, N)
+        if latent_collector.should_collect(0):
+            latent_collector.collect(get_lat(0), 0)
+        for i in range(N):
+            if latent_collector.should_collect(i + 1):
+                latent_collector.collect(get_lat(i + 1), i + 1)
+            if compute_log_prob and eta_host[i] > 0:
+                log_prob_collector.collect(log_probs[i], i)
+            out_i = step_outputs[i] if step_outputs is not None else None
+            callback_collector.collect_step(step_idx=i, output=out_i, keys=extra_call_back_kwargs,
+                                            capturable={"noise_level": eta_host[i]})
+
+        images = self.decode_latents(latents=final, output_type="pt")
+        cb_res = callback_collector.get_result()
+        cb_map = callback_collector.get_index_map()
+        all_latents = latent_collector.get_result()
+        latent_index_map = latent_collector.get_index_map()
+        all_log_probs = log_prob_collector.get_result() if compute_log_prob else None
+        log_prob_index_map = log_prob_collector.get_index_map() if compute_log_prob else None
+        lat_stack = torch.stack(all_latents, dim=1) if all_latents else None           # (B, P, C, h, w)
+        lp_stack = torch.stack(all_log_probs, dim=1) if all_log_probs else None        # (B, P')
+        samples = []
+        for b in range(B):
+            samples.append(SD3_5Sample(
+                timesteps=timesteps,
+                all_latents=lat_stack[b] if lat_stack is not None else None,
+                log_probs=lp_stack[b] if lp_stack is not None else None,
+                latent_index_map=latent_index_map,
+                log_prob_index_map=log_prob_index_map,
+                prompt=prompt[b] if isinstance(prompt, list) else prompt,
+                prompt_ids=prompt_ids[b] if prompt_ids is not None else None,
+                prompt_embeds=prompt_embeds[b],
+                pooled_prompt_embeds=pooled_prompt_embeds[b],
+                negative_prompt=(negative_prompt[b] if isinstance(negative_prompt, list) else negative_prompt),
+                negative_prompt_ids=negative_prompt_ids[b] if negative_prompt_ids is not None else None,
+                negative_prompt_embeds=negative_prompt_embeds[b] if negative_prompt_embeds is not None else None,
+                negative_pooled_prompt_embeds=negative_pooled_prompt_embeds[b] if negative_pooled_prompt_embeds is not None else None,
+                height=height, width=width,
+                image=images[b] if images is not None else None,
+                extra_kwargs={**{k: v[b] for k, v in cb_res.items()}, "callback_index_map": cb_map},
+            ))
+        return samples
+
+    def _rollout_stepwise(self, plan, ts, sig, eta, guidance, latents, storage, step_noise, pe, pp, ne, npl, compute_log_prob,
+                          extra_keys):
+        """Per-step engine calls (still all-HIP) for rollouts that ask for per-step callback tensors."""
+        N, B = len(ts), latents.shape[0]
+        cur = self.cast_latents(latents, storage)
+        all_lat = [cur]
+        log_probs = torch.full((N, B), float("nan"), device=latents.device)
+        outs = []
+        want = tuple(k for k in extra_keys if k in ("next_latents", "next_latents_mean", "noise_pred", "std_dev_t", "dt"))
+        for i in range(N):
+            t_next = ts[i + 1] if i + 1 < N else 0.0
+            clp = compute_log_prob and eta[i] > 0
+            enc_a, pool_a, enc_b, pool_b = (ne, npl, pe, pp) if ne is not None else (pe, pp, None, None)
+            o = plan.denoise_step(cur, torch.tensor(ts[i]), enc_a, pool_a, enc_b, pool_b, guidance,
+                                  torch.tensor(ts[i]) / 1000, torch.tensor(t_next) / 1000, eta[i], sig[1],
+                                  self.scheduler.dynamics_type, noise=step_noise[i], compute_log_prob=clp, want=want)
+            if clp:
+                log_probs[i] = o.log_prob
+            cur = o.next_storage
+            all_lat.append(cur)
+            outs.append(o)
+        return all_lat, log_probs, outs
+
+    # -------------------------------------------------------------- one step (rollout or replay)
+    def forward(
+        self,
+        t: torch.Tensor,
+        latents: torch.Tensor,
+        prompt_embeds: torch.Tensor,
+        pooled_prompt_embeds: torch.Tensor,
+        negative_prompt_embeds: Optional[torch.Tensor] = None,
+        negative_pooled_prompt_embeds: Optional[torch.Tensor] = None,
+        guidance_scale: float = 7.5,
+        t_next: Optional[torch.Tensor] = None,
+        next_latents: Optional[torch.Tensor] = None,
+        noise_level: Optional[float] = None,
+        joint_attention_kwargs: Optional[Dict[str, Any]] = None,
+        compute_log_prob: bool = True,
+        return_kwargs: List[str] = ["noise_pred", "next_latents", "next_latents_mean", "std_dev_t", "dt", "log_prob"],
+    ) -> SDESchedulerOutput:
+        if joint_attention_kwargs:
+            raise ValueError("mi355_flow: joint_attention_kwargs are not supported by the native engine")
+        if not latents.is_cuda:
+            raise RuntimeError("mi355_flow forward: latents must be on the GPU (no CPU fallback)")
+        B = latents.shape[0]
+        dev = latents.device
+        if guidance_scale > 1.0 and (negative_prompt_embeds is None or negative_pooled_prompt_embeds is None):
+            logger.warning("Passed `guidance_scale` > 1.0, but no `negative_prompt_embeds` or `negative_pooled_prompt_embeds` "
+                           "provided. Classifier-free guidance will be disabled.")
+        do_cfg = negative_prompt_embeds is not None and negative_pooled_prompt_embeds is not None and guidance_scale > 1.0
+        sched = self.scheduler
+        t = torch.as_tensor(t, dtype=torch.float32, device=dev)
+        if t_next is None:
+            idx = [sched.index_for_timestep(x) for x in t.reshape(-1)]
+            t_next = torch.stack([sched.timesteps[i + 1] if i + 1 < len(sched.timesteps) else torch.zeros(()) for i in idx]).to(dev)
+            if t.ndim == 0:
+                t_next = t_next[0]
+        t_next = torch.as_tensor(t_next, dtype=torch.float32, device=dev)
+        dyn = sched.dynamics_type
+        sigma, sigma_next = t / 1000, t_next / 1000
+        if sched.is_eval or dyn == "ODE":
+            noise_level = 0.0
+        elif noise_level is None:
+            noise_level = sched.get_noise_level_for_sigma(sigma.reshape(-1)) if sigma.ndim else sched.get_noise_level_for_sigma(float(sigma))
+        noise = None
+        if next_latents is None and dyn != "ODE":
+            noise = torch.randn(latents.shape, device=dev, dtype=torch.float32)  # same draw as randn_tensor(:352-357)
+        plan = self.engine.plan(B, 2 if do_cfg else 1, latents.shape[2], latents.shape[3], prompt_embeds.shape[1], 1)
+        enc = (negative_prompt_embeds, negative_pooled_prompt_embeds, prompt_embeds, pooled_prompt_embeds) if do_cfg else \
+              (prompt_embeds, pooled_prompt_embeds, None, None)
+        sigma_max = float(sched.sigmas[1])
+        want = tuple(k for k in return_kwargs if k in ("next_latents", "next_latents_mean", "noise_pred", "std_dev_t", "dt"))
+        o = plan.denoise_step(latents, t, enc[0], enc[1], enc[2], enc[3], guidance_scale, sigma, sigma_next, noise_level,
+                              sigma_max, dyn, noise=noise, next_latents=next_latents, compute_log_prob=compute_log_prob, want=want)
+        view = (-1, 1, 1, 1)
+        res = dict(
+            noise_pred=o.noise_pred,
+            next_latents=o.next_latents if next_latents is None else next_latents.float(),
+            next_latents_mean=o.next_latents_mean,
+            std_dev_t=o.std_dev_t.view(view) if o.std_dev_t is not None else None,
+            dt=o.dt.view(view) if o.dt is not None else None,
+            log_prob=o.log_prob if compute_log_prob else None,
+        )
+        return SDESchedulerOutput.from_dict({k: res[k] for k in return_kwargs if k in res})
+
+
+class SD3_5NativeAdapter(NativeRolloutMixin):
+    """Standalone adapter (no Flow-Factory import): engine + scheduler + optional VAE decoder."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[TransformerConfig] = None,
+                 scheduler: Optional[FlowMatchEulerDiscreteSDEScheduler] = None, latent_storage_dtype: Optional[str] = "fp16",
+                 transformer_dtype: torch.dtype = torch.bfloat16, device: Union[str, torch.device] = "cuda",
+                 vae_decode: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("mi355_flow: no GPU visible; the native rollout engine has no CPU path")
+        self.device = torch.device(device)
+        self.transformer_dtype = transformer_dtype
+        self._latent_storage = latent_storage_dtype
+        self.scheduler = scheduler or FlowMatchEulerDiscreteSDEScheduler(shift=3.0, sde_steps=[1, 2, 3], num_sde_steps=1)
+        self.engine = Engine(config or TransformerConfig())
+        self.refresh_weights(state_dict)
+        self._vae_decode = vae_decode
+
+    @property
+    def latent_storage_dtype(self) -> Optional[torch.dtype]:
+        return _DTYPE_MAP.get(self._latent_storage) if self._latent_storage else None
+
+    def refresh_weights(self, state_dict: Dict[str, torch.Tensor]) -> None:
+        """Re-pack the (live) torch parameters: call after optimizer steps / EMA swaps / LoRA merges."""
+        self.engine.bind_state_dict(state_dict)
+        self.engine.ready()
+
+    # mode switches the trainer calls (models/abc.py:351-378)
+    def rollout(self):
+        self.scheduler.rollout()
+
+    def eval(self):
+        self.scheduler.eval()
+
+    def train(self, mode: bool = True):
+        self.scheduler.train(mode)
+
+    def encode_prompt(self, *a, **k):
+        raise RuntimeError("mi355_flow standalone adapter has no text encoders: pass prompt_embeds / pooled_prompt_embeds "
+                           "(the Flow-Factory plugin inherits encode_prompt from SD3_5Adapter)")
+
+    def decode_latents(self, latents: torch.Tensor, output_type: str = "pt"):
+        """VAE decode is outside the first bar: delegated to an attached decoder."""
+        if self._vae_decode is None:
+            return None
+        return self._vae_decode(latents)

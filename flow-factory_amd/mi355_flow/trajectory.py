@@ -1,0 +1,181 @@
+"""Sparse trajectory bookkeeping of a rollout (host side).
+
+Mirrors the public behaviour of the reference's `TrajectoryCollector`, `CallbackCollector` and
+`compute_trajectory_indices` (reference src/flow_factory/utils/trajectory_collector.py:40-180,
+:187-337, :344-388): which trajectory positions are kept, the compact storage order and the dense
+`position -> compact index` maps (-1 = not kept) that `optimize()` uses to find x_i / x_{i+1}.
+The engine consumes the same selection as a `keep_slot` table (see `keep_slots`).
+"""
+from __future__ import annotations
+
+from collections import defaultdict
+from typing import Any, Dict, List, Literal, Optional, Sequence, Set, Union
+
+import torch
+
+TrajectoryIndicesType = Union[Literal["all"], List[int], None]
+
+
+def _resolve(indices: TrajectoryIndicesType, n_positions: int) -> Optional[Set[int]]:
+    """None -> keep everything; empty set -> keep nothing; else the normalised positions."""
+    if indices is None:
+        return set()
+    if isinstance(indices, str):
+        if indices != "all":
+            raise ValueError(f"trajectory indices must be 'all', None or a list of ints, got {indices!r}")
+        return None
+    keep = set()
+    for i in indices:
+        i = int(i)
+        if i < 0:
+            i += n_positions
+        if 0 <= i < n_positions:
+            keep.add(i)
+    return keep
+
+
+class TrajectoryCollector:
+    """Keeps tensors at selected trajectory positions 0..T (T = total_steps)."""
+
+    def __init__(self, indices: TrajectoryIndicesType = "all", total_steps: int = 0):
+        self.indices = indices
+        self.total_steps = total_steps
+        self._keep = _resolve(indices, total_steps + 1)
+        self._values: List[torch.Tensor] = []
+        self._positions: List[int] = []
+
+    @property
+    def is_disabled(self) -> bool:
+        return self._keep is not None and not self._keep
+
+    @property
+    def collect_all(self) -> bool:
+        return self._keep is None
+
+    def should_collect(self, step_idx: int) -> bool:
+        return self._keep is None or step_idx in self._keep
+
+    def collect(self, value: torch.Tensor, step_idx: int) -> None:
+        if self.should_collect(step_idx):
+            self._values.append(value)
+            self._positions.append(step_idx)
+
+    def get_result(self) -> Optional[List[torch.Tensor]]:
+        return None if self.is_disabled else self._values
+
+    @property
+    def collected_indices(self) -> List[int]:
+        return self._positions
+
+    def get_index_map(self) -> Optional[torch.Tensor]:
+        if self.is_disabled:
+            return None
+        n = self.total_steps + 1
+        if self.collect_all:
+            return torch.arange(n, dtype=torch.long)
+        out = torch.full((n,), -1, dtype=torch.long)
+        for slot, pos in enumerate(self._positions):
+            out[pos] = slot
+        return out
+
+    def reset(self) -> None:
+        self._values, self._positions = [], []
+
+    def __len__(self) -> int:
+        return len(self._values)
+
+
+class CallbackCollector:
+    """Collects named per-step values (step indices 0..T-1) with the same gating."""
+
+    def __init__(self, indices: TrajectoryIndicesType = "all", total_steps: int = 0):
+        self._gate = TrajectoryCollector(indices=indices, total_steps=total_steps)
+        self._data: Dict[str, List] = defaultdict(list)
+        self._steps: List[int] = []
+
+    @property
+    def is_disabled(self) -> bool:
+        return self._gate.is_disabled
+
+    def should_collect(self, step_idx: int) -> bool:
+        return self._gate.should_collect(step_idx)
+
+    def collect_step(self, step_idx: int, output: Any, keys: List[str], capturable: Optional[Dict[str, Any]] = None) -> None:
+        if not keys or not self.should_collect(step_idx):
+            return
+        if step_idx not in self._steps:
+            self._steps.append(step_idx)
+        for key in keys:
+            val = None
+            if capturable and capturable.get(key) is not None:
+                val = capturable[key]
+            elif hasattr(output, key):
+                val = getattr(output, key)
+            if val is not None:
+                self._data[key].append(val)
+
+    def get_result(self) -> Dict[str, Any]:
+        out = {}
+        for k, v in self._data.items():
+            out[k] = torch.stack(v, dim=1) if v and isinstance(v[0], torch.Tensor) else v
+        return out
+
+    def get_index_map(self) -> Optional[torch.Tensor]:
+        if self.is_disabled:
+            return None
+        T = self._gate.total_steps
+        if self._gate.collect_all:
+            return torch.arange(T, dtype=torch.long)
+        out = torch.full((T,), -1, dtype=torch.long)
+        for slot, step in enumerate(self._steps):
+            if 0 <= step < T:
+                out[step] = slot
+        return out
+
+    @property
+    def collected_indices(self) -> List[int]:
+        return self._steps
+
+    def reset(self) -> None:
+        self._data = defaultdict(list)
+        self._steps = []
+
+    def __len__(self) -> int:
+        return len(self._steps)
+
+
+def compute_trajectory_indices(train_timestep_indices, num_inference_steps: int, include_initial: bool = False) -> List[int]:
+    """Positions {i, i+1 : i in train steps} (deduplicated, sorted): what GRPO's replay needs."""
+    if isinstance(train_timestep_indices, torch.Tensor):
+        train_timestep_indices = train_timestep_indices.tolist()
+    n = num_inference_steps + 1
+    pos = {0} if include_initial else set()
+    for i in train_timestep_indices:
+        for j in (i, i + 1):
+            if 0 <= j < n:
+                pos.add(int(j))
+    return sorted(pos)
+
+
+def create_trajectory_collector(indices: TrajectoryIndicesType, num_steps: int) -> TrajectoryCollector:
+    return TrajectoryCollector(indices=indices, total_steps=num_steps)
+
+
+def create_callback_collector(indices: TrajectoryIndicesType, num_steps: int) -> CallbackCollector:
+    return CallbackCollector(indices=indices, total_steps=num_steps)
+
+
+def keep_slots(indices: TrajectoryIndicesType, num_steps: int) -> List[int]:
+    """`position -> output slot` table (N+1 entries, -1 = dropped) handed to mi355_rollout; equals
+    TrajectoryCollector(indices, N).get_index_map() for a full rollout."""
+    keep = _resolve(indices, num_steps + 1)
+    if keep is None:
+        return list(range(num_steps + 1))
+    out, slot = [], 0
+    for pos in range(num_steps + 1):
+        if pos in keep:
+            out.append(slot)
+            slot += 1
+        else:
+            out.append(-1)
+    return out

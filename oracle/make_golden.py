@@ -251,6 +251,30 @@ def gen_mmdit_tiny():
                         log_probs=_np(ro["log_probs"]), noise_levels=_np(nl))
 
 
+# ------------------------------------------------------------------ [REF] group-contiguous sampler (DP partitioner)
+def gen_sampler():
+    import importlib.util
+
+    ref_loader.load()
+    pkg = types.ModuleType("flow_factory.data_utils")
+    pkg.__path__ = [os.path.join(ref_loader.REF_PKG, "data_utils")]
+    sys.modules.setdefault("flow_factory.data_utils", pkg)
+    spec = importlib.util.spec_from_file_location("flow_factory.data_utils.sampler",
+                                                  os.path.join(ref_loader.REF_PKG, "data_utils", "sampler.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[spec.name] = mod
+    spec.loader.exec_module(mod)
+    rows = []
+    for (ds, bs, k, m, world, seed) in ((100, 2, 4, 8, 2, 42), (64, 4, 16, 48, 8, 7), (10, 1, 3, 4, 1, 0)):
+        for rank in range(world):
+            smp = mod.GroupContiguousSampler(list(range(ds)), bs, k, m, world, rank, seed)
+            it = iter(smp)
+            batches = [next(it) for _ in range(2 * smp.num_batches_per_epoch)]  # two epochs
+            rows.append(repr(dict(ds=ds, bs=bs, k=k, m=m, world=world, seed=seed, rank=rank,
+                                  nb=smp.num_batches_per_epoch, batches=batches)))
+    np.savez_compressed(os.path.join(OUT, "sampler.npz"), rows=np.array(rows))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ns = ref_loader.load()
@@ -259,6 +283,7 @@ def main():
     gen_collectors(ns)
     gen_advantages()
     gen_mmdit_tiny()
+    gen_sampler()
     print(f"wrote fixtures to {OUT} ({n} scheduler step cases)")
 
 

