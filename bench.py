@@ -1,0 +1,222 @@
+#!/usr/bin/env python
+"""bench.py -- denoise-steps/sec of the SD3.5-medium 1024^2 GRPO rollout on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
+
+One bench "step" = ONE rollout micro-batch through the drop-in API (`SD3_5NativeAdapter.inference`):
+`--batch` samples x 28 SDE/ODE denoise steps at 1024x1024 (latents 16x128x128, 4096 image + 333 text
+tokens), RNG draws + collectors + sample building included, VAE decode / rewards excluded
+(SURVEY.md 8(d)).  value = samples x 28 x K x N / wall-time  [denoise-steps/sec, whole job].
+Synthetic prompts (random prompt embeddings) and random-init weights of the SD3.5-medium
+architecture: no checkpoints / datasets exist in this environment.
+
+Rank 0 prints ONE JSON line; besides the contract keys it carries
+  roofline     : the dominant kernel (attention, v_mfma_f32_32x32x16_bf16) -- algorithmic FLOPs per
+                 launch / mean launch duration from hipEvents recorded on the launch stream over the
+                 timed region, vs the 2.5 PFLOP/s dense bf16 MFMA peak; plus the whole-forward figure
+                 the north star asks for (`forward.frac`, target 0.40) and a per-class breakdown.
+  cpu_baseline : the oracle (fp32 PyTorch restatement of the reference path) timed on this box's
+                 host cores on a bounded sample; a reported baseline, not the optimisation target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "flow-factory_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
+N_TEXT = 333               # 77 CLIP + 256 T5 tokens
+
+
+def forward_flops(cfg, Ni, Nt):
+    """algorithmic matmul FLOPs per transformer forward per sample (2 FLOP/MAC)."""
+    D, F, L, Ld = cfg.dim, cfg.ff_mult * cfg.dim, cfg.num_layers, len(cfg.dual_layers)
+    mac = (L * Ni * (4 * D * D + 2 * D * F) + ((L - 1) * Nt * (4 * D * D + 2 * D * F) + Nt * 3 * D * D)
+           + Ld * Ni * 4 * D * D + L * 2 * (Ni + Nt) ** 2 * D + Ld * 2 * Ni * Ni * D
+           + Nt * cfg.joint_attention_dim * D + 2 * Ni * cfg.patch_size ** 2 * cfg.in_channels * D)
+    return 2.0 * mac
+
+
+def attention_flops(cfg, Ni, Nt):
+    L, Ld, D = cfg.num_layers, len(cfg.dual_layers), cfg.dim
+    return 2.0 * (L * 2 * (Ni + Nt) ** 2 * D + Ld * 2 * Ni * Ni * D), L + Ld  # flops / forward / sample, launches
+
+
+def cpu_baseline(budget_s=30.0):
+    """Oracle on the host cores, bounded: one fp32 MMDiT-X forward at the bench shape if it fits the
+    budget (probed on the 256^2 shape first), else the 256^2 forward scaled by the FLOP ratio."""
+    from oracle import mmditx_ref as M
+    cfg = M.SD35_MEDIUM
+    cores = torch.get_num_threads()
+    # timing only: draw the 2.5 B fp32 weights on the GPU and copy them down (the CPU generator needs ~1 min)
+    from mi355_flow.engine import TransformerConfig
+    from mi355_flow.weights import synthetic_state_dict
+    sd = {k: v.float().cpu() for k, v in synthetic_state_dict(TransformerConfig(), device="cuda", dtype=torch.float32).items()}
+    g = torch.Generator().manual_seed(4321)
+    enc = torch.randn(1, N_TEXT, 4096, generator=g)
+    pooled = torch.randn(1, 2048, generator=g)
+    t = torch.tensor([900.0])
+
+    def run(hw):
+        x = torch.randn(1, 16, hw, hw, generator=g)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            M.mmdit_forward(sd, cfg, x, t, enc, pooled)
+        return time.perf_counter() - t0
+
+    run(32)  # warm the thread pool / allocator
+    t256 = run(32)
+    f256, f1024 = M.forward_flops(cfg, 256, N_TEXT), M.forward_flops(cfg, 4096, N_TEXT)
+    est = t256 * f1024 / f256
+    if est <= budget_s:
+        t1024 = run(128)
+        return dict(value=1.0 / t1024, unit="denoise-steps/sec", cores=cores, kind="port",
+                    sample=f"1 fp32 oracle forward (= 1 denoise step, n_cfg=1) of 1 sample at 1024^2, {t1024:.2f} s measured; "
+                           f"256^2 forward {t256:.2f} s")
+    return dict(value=1.0 / est, unit="denoise-steps/sec", cores=cores, kind="port",
+                sample=f"1 fp32 oracle forward at 256^2 ({t256:.2f} s measured) EXTRAPOLATED x{f1024 / f256:.1f} by FLOPs to 1024^2")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=8, help="samples per rollout micro-batch per GPU")
+    ap.add_argument("--guidance", type=float, default=1.0, help="> 1 enables CFG (2 forwards per denoise step)")
+    ap.add_argument("--size", type=int, default=1024)
+    ap.add_argument("--denoise-steps", type=int, default=28)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the rollout engine has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI; the rollout itself needs no collective
+
+    from mi355_flow import _lib
+    from mi355_flow.adapter import SD3_5NativeAdapter
+    from mi355_flow.engine import TransformerConfig
+    from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
+    from mi355_flow.trajectory import compute_trajectory_indices
+    from mi355_flow.weights import synthetic_state_dict
+
+    cfg = TransformerConfig()  # SD3.5-medium
+    torch.manual_seed(42 + rank)  # reference: set_seed(seed, device_specific=True) (trainers/loader.py:70)
+    sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=1, seed=42,
+                                               dynamics_type="Flow-SDE", shift=3.0)
+    adapter = SD3_5NativeAdapter(synthetic_state_dict(cfg, device=dev, seed=1234), cfg, sched, latent_storage_dtype="fp16",
+                                 device=dev)
+    B, N = args.batch, args.denoise_steps
+    cfg_on = args.guidance > 1.0
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    pe = torch.randn(B, N_TEXT, cfg.joint_attention_dim, device=dev, generator=g).bfloat16()
+    pp = torch.randn(B, cfg.pooled_projection_dim, device=dev, generator=g).bfloat16()
+    ne = torch.randn(B, N_TEXT, cfg.joint_attention_dim, device=dev, generator=g).bfloat16() if cfg_on else None
+    npl = torch.randn(B, cfg.pooled_projection_dim, device=dev, generator=g).bfloat16() if cfg_on else None
+    adapter.rollout()
+    traj = compute_trajectory_indices(sched.train_timesteps, N)
+
+    def one_rollout():
+        return adapter.inference(prompt=None, height=args.size, width=args.size, num_inference_steps=N,
+                                 guidance_scale=args.guidance, prompt_embeds=pe, pooled_prompt_embeds=pp,
+                                 negative_prompt_embeds=ne, negative_pooled_prompt_embeds=npl, compute_log_prob=True,
+                                 trajectory_indices=traj)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        samples = one_rollout()
+    lib = _lib.load()
+    timing = not args.no_kernel_timing
+    fence()
+    if timing:
+        lib.mi355_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        samples = one_rollout()
+    fence()
+    elapsed = time.perf_counter() - t0
+    import ctypes as C
+    ms = (C.c_double * 5)()
+    cnt = (C.c_int64 * 5)()
+    if timing:
+        _lib.check(lib.mi355_profile_collect(ms, cnt), "profile_collect")
+        lib.mi355_profile_enable(0)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert len(samples) == B and samples[0].all_latents.shape[0] == len(traj) and torch.isfinite(samples[0].log_probs).all()
+
+    n_cfg = 2 if cfg_on else 1
+    lat = args.size // 8
+    Ni = (lat // cfg.patch_size) ** 2
+    denoise_steps_total = B * N * args.steps * world
+    value = denoise_steps_total / elapsed
+    F = forward_flops(cfg, Ni, N_TEXT)
+    fwd_tflops = n_cfg * F * (B * N * args.steps) / elapsed / 1e12  # per GPU
+    out = {
+        "metric": "denoise-steps/sec (whole node), SD3.5-medium 1024^2 GRPO rollout", "value": round(value, 3),
+        "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"SD3.5-medium T2I GRPO rollout, {args.size}x{args.size}, {N} denoise steps (Flow-SDE, 1 SDE step, "
+                               f"log-prob fused), batch {B}/GPU, n_cfg={n_cfg}, fp16 latent storage; 1 bench step = 1 rollout micro-batch",
+                   "global_batch": B * world, "tokens_per_sample": Ni + N_TEXT, "n_cfg": n_cfg, "denoise_steps": N,
+                   "parallelism": f"dp{world} (rollout shards by prompt group, no data-path collective)"},
+    }
+    if timing and rank == 0:
+        attn_fl, attn_launches = attention_flops(cfg, Ni, N_TEXT)
+        fwd_per_timed = n_cfg * N * args.steps  # transformer forwards (batch B each) in the timed region on this rank
+        names = ["attention", "gemm", "ln_modulate", "sde_step", "misc"]
+        by_class = {names[i]: {"ms": round(ms[i], 3), "launches": int(cnt[i])} for i in range(5)}
+        a_ms = ms[0] / max(cnt[0], 1)                       # mean duration of one attention launch
+        a_flop = attn_fl * B / attn_launches                # mean algorithmic FLOPs of one attention launch
+        achieved = a_flop / (a_ms * 1e-3) / 1e12 if a_ms > 0 else 0.0
+        gemm_fl = (F - attn_fl) * B * fwd_per_timed
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_attention.json")
+        if os.path.isfile(pmc):
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        out["roofline"] = {
+            "bound": "mfma", "kernel": "attn_kernel (joint S=4429 x24, dual S=4096 x13 per forward)",
+            "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
+            "traffic": traffic, "flops_per_launch": a_flop, "ms_per_launch": round(a_ms, 4),
+            "gemm": {"achieved": round(gemm_fl / (ms[1] * 1e-3) / 1e12, 1) if ms[1] > 0 else None,
+                     "frac": round(gemm_fl / (ms[1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if ms[1] > 0 else None},
+            "forward": {"achieved": round(fwd_tflops, 1), "frac": round(fwd_tflops / PEAK_BF16_TFLOPS, 4),
+                        "flops_per_forward_per_sample": F, "note": "wall-clock of the whole rollout incl. host glue; north-star target 0.40"},
+            "by_class": by_class,
+        }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

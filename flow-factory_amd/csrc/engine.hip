@@ -36,6 +36,72 @@ static int fail(const char* fmt, ...) {
         if (_r) return _r;     \
     } while (0)
 
+// ------------------------------------------------------------------------ kernel-class timing
+// Optional hipEvent brackets around every launch of a kernel class, recorded on the launch stream
+// (bench.py's roofline leg).  Off by default: zero cost on the normal path.
+enum ProfClass : int { PC_ATTN = 0, PC_GEMM, PC_LNMOD, PC_SDE, PC_MISC, PC_COUNT };
+struct ProfState {
+    bool on = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    std::vector<int> cls;
+    size_t used = 0;              // pairs used
+    double ms[PC_COUNT] = {0};
+    long count[PC_COUNT] = {0};
+};
+static ProfState g_prof;
+
+struct ProfScope {
+    hipStream_t st; size_t idx; bool active;
+    ProfScope(int cls, hipStream_t s) : st(s), idx(0), active(g_prof.on) {
+        if (!active) return;
+        if (g_prof.used * 2 + 2 > g_prof.ev.size()) {
+            for (int i = 0; i < 2; ++i) {
+                hipEvent_t e;
+                if (hipEventCreate(&e) != hipSuccess) { active = false; return; }
+                g_prof.ev.push_back(e);
+            }
+            g_prof.cls.push_back(cls);
+        }
+        idx = g_prof.used++;
+        g_prof.cls[idx] = cls;
+        (void)hipEventRecord(g_prof.ev[2 * idx], st);
+    }
+    ~ProfScope() {
+        if (active) (void)hipEventRecord(g_prof.ev[2 * idx + 1], st);
+    }
+};
+
+extern "C" int mi355_profile_enable(int on) {
+    g_prof.on = on != 0;
+    g_prof.used = 0;
+    for (int i = 0; i < PC_COUNT; ++i) { g_prof.ms[i] = 0; g_prof.count[i] = 0; }
+    return 0;
+}
+
+// Waits for the recorded events, accumulates elapsed ms / launch counts per class
+// (order: attention, gemm, ln_modulate, sde_step, misc) and resets the event pool.
+extern "C" int mi355_profile_collect(double* ms_out, int64_t* count_out) {
+    for (size_t i = 0; i < g_prof.used; ++i) {
+        float ms = 0.f;
+        hipError_t e = hipEventSynchronize(g_prof.ev[2 * i + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]);
+        if (e != hipSuccess) return fail("mi355_profile_collect: %s", hipGetErrorString(e));
+        g_prof.ms[g_prof.cls[i]] += ms;
+        g_prof.count[g_prof.cls[i]] += 1;
+    }
+    g_prof.used = 0;
+    for (int i = 0; i < PC_COUNT; ++i) {
+        if (ms_out) ms_out[i] = g_prof.ms[i];
+        if (count_out) count_out[i] = g_prof.count[i];
+    }
+    return 0;
+}
+
+static hipError_t gemm_p(const GemmParams& g, hipStream_t st) { ProfScope ps(PC_GEMM, st); return launch_gemm(g, st); }
+static hipError_t attn_p(const AttnParams& a, hipStream_t st) { ProfScope ps(PC_ATTN, st); return launch_attention(a, st); }
+static hipError_t lnmod_p(const LnModParams& l, hipStream_t st) { ProfScope ps(PC_LNMOD, st); return launch_ln_mod(l, st); }
+static hipError_t sde_p(const SdeStepParams& s, hipStream_t st) { ProfScope ps(PC_SDE, st); return launch_sde_step(s, st); }
+
 // ------------------------------------------------------------------------------------ engine
 struct Slot {
     void* dst;      // device destination (bf16_t* or float*)
@@ -356,13 +422,13 @@ static int prepare_prompt(mi355_plan* p, hipStream_t st, const void* enc_a, cons
         const int rows = p->B * p->Nt;
         GemmParams g = gp((const bf16_t*)encs[half], J, e->w_ctx, J, rows, D, J, EPI_BIAS, e->b_ctx,
                           p->c0 + (int64_t)half * rows * D, D);
-        HIPCHK(launch_gemm(g, st));
+        HIPCHK(gemm_p(g, st));
         GemmParams g1 = gp((const bf16_t*)pools[half], P, e->w_p1, P, p->B, D, P, EPI_BIAS_SILU, e->b_p1,
                            p->p1 + (int64_t)half * p->B * D, D);
-        HIPCHK(launch_gemm(g1, st));
+        HIPCHK(gemm_p(g1, st));
     }
     GemmParams g2 = gp(p->p1, D, e->w_p2, D, p->Bp, D, D, EPI_BIAS, e->b_p2, p->pemb, D);
-    HIPCHK(launch_gemm(g2, st));
+    HIPCHK(gemm_p(g2, st));
     return 0;
 }
 
@@ -373,13 +439,13 @@ static int prepare_conditioning(mi355_plan* p, hipStream_t st, int nsteps, int t
     const int rows = nsteps * p->Bp;
     HIPCHK(launch_time_proj(p->t_dev, rows, T, t_round_dt, p->tproj, st));
     GemmParams g1 = gp(p->tproj, T, e->w_t1, T, rows, D, T, EPI_BIAS_SILU, e->b_t1, p->h1, D);
-    HIPCHK(launch_gemm(g1, st));
+    HIPCHK(gemm_p(g1, st));
     // semb = silu(bf16(timestep_emb + pooled_emb)): every AdaLN consumes silu(temb)
     GemmParams g2 = gp(p->h1, D, e->w_t2, D, rows, D, D, EPI_ADDSRC_SILU, e->b_t2, p->semb, D);
     g2.aux = p->pemb; g2.ld_aux = D; g2.rows_per_sample = p->Bp;
-    HIPCHK(launch_gemm(g2, st));
+    HIPCHK(gemm_p(g2, st));
     GemmParams g3 = gp(p->semb, D, e->w_mod, D, rows, e->mod_cols, D, EPI_BIAS, e->b_mod, p->mod_all, e->mod_cols);
-    HIPCHK(launch_gemm(g3, st));
+    HIPCHK(gemm_p(g3, st));
     return 0;
 }
 
@@ -389,7 +455,7 @@ static int ln_mod(mi355_plan* p, hipStream_t st, const bf16_t* x, bf16_t* out, b
     l.x = x; l.out = out; l.out2 = out2; l.mod = mod; l.mod_ld = p->e->mod_cols;
     l.shift_off = shift_off; l.scale_off = scale_off; l.shift2_off = shift2_off; l.scale2_off = scale2_off;
     l.M = M; l.D = p->e->D; l.rows_per_sample = rps; l.eps = p->e->cfg.eps;
-    HIPCHK(launch_ln_mod(l, st));
+    HIPCHK(lnmod_p(l, st));
     return 0;
 }
 
@@ -402,10 +468,10 @@ static int qkv_proj(mi355_plan* p, hipStream_t st, const bf16_t* xin, int M, int
     GemmParams g = gp(xin, D, w_qk, D, M, 2 * D, D, EPI_QK_NORM, b_qk, nullptr, 0);
     g.q = q; g.k = k; g.nw_q = nq; g.nw_k = nk; g.H = e->cfg.num_heads; g.S_pad = S_pad; g.s_off = s_off;
     g.rows_per_sample = rps; g.eps = e->cfg.eps;
-    HIPCHK(launch_gemm(g, st));
+    HIPCHK(gemm_p(g, st));
     GemmParams gv = gp(w_v, D, xin, D, D, M, D, EPI_VT, b_v, nullptr, 0);
     gv.q = vT; gv.H = e->cfg.num_heads; gv.S_pad = S_pad; gv.s_off = s_off; gv.rows_per_sample = rps;
-    HIPCHK(launch_gemm(gv, st));
+    HIPCHK(gemm_p(gv, st));
     return 0;
 }
 
@@ -413,7 +479,7 @@ static int gate_res(mi355_plan* p, hipStream_t st, const bf16_t* A, int K, const
                     int M, int rps, const bf16_t* mod, int gate_off) {
     GemmParams g = gp(A, K, W, K, M, p->e->D, K, EPI_GATE_RES, bias, x, p->e->D);
     g.aux = mod + gate_off; g.ld_aux = p->e->mod_cols; g.rows_per_sample = rps;
-    HIPCHK(launch_gemm(g, st));
+    HIPCHK(gemm_p(g, st));
     return 0;
 }
 
@@ -432,7 +498,7 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
     {
         GemmParams g = gp(p->patches, e->KP, e->w_patch, e->KP, Mi, D, e->KP, EPI_POSADD, e->b_patch, p->x, D);
         g.aux = p->pe; g.ld_aux = D; g.rows_per_sample = Ni;
-        HIPCHK(launch_gemm(g, st));
+        HIPCHK(gemm_p(g, st));
     }
     HIPCHK(hipMemcpyAsync(p->c, p->c0, (size_t)Mc * D * 2, hipMemcpyDeviceToDevice, st));
     for (int i = 0; i < e->L; ++i) {
@@ -449,27 +515,27 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
         CHK(qkv_proj(p, st, p->cn, Mc, Nt, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck, p->q, p->k, p->vT, p->S_pad, Ni));
         {
             AttnParams a{p->q, p->k, p->vT, p->o_img, p->o_ctx, p->Bp, H, p->S, p->S_pad, Ni};
-            HIPCHK(launch_attention(a, st));
+            HIPCHK(attn_p(a, st));
         }
         CHK(gate_res(p, st, p->o_img, D, b.w_o, b.b_o, p->x, Mi, Ni, mod, mi + 2 * D));
         if (!b.last) CHK(gate_res(p, st, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
         if (b.dual) {
             CHK(qkv_proj(p, st, p->xn2, Mi, Ni, b.w_qk2, b.b_qk2, b.w_v2, b.b_v2, b.nq2, b.nk2, p->q2, p->k2, p->vT2, Ni_pad, 0));
             AttnParams a{p->q2, p->k2, p->vT2, p->o_img, p->o_ctx, p->Bp, H, Ni, Ni_pad, Ni};
-            HIPCHK(launch_attention(a, st));
+            HIPCHK(attn_p(a, st));
             CHK(gate_res(p, st, p->o_img, D, b.w_o2, b.b_o2, p->x, Mi, Ni, mod, mi + 8 * D));
         }
         // MLP (image stream)
         CHK(ln_mod(p, st, p->x, p->xn, nullptr, mod, Mi, Ni, mi + 3 * D, mi + 4 * D, 0, 0));
         {
             GemmParams g = gp(p->xn, D, b.w_ff1, D, Mi, F, D, EPI_BIAS_GELU, b.b_ff1, p->hid, F);
-            HIPCHK(launch_gemm(g, st));
+            HIPCHK(gemm_p(g, st));
         }
         CHK(gate_res(p, st, p->hid, F, b.w_ff2, b.b_ff2, p->x, Mi, Ni, mod, mi + 5 * D));
         if (!b.last) {
             CHK(ln_mod(p, st, p->c, p->cn, nullptr, mod, Mc, Nt, mc + 3 * D, mc + 4 * D, 0, 0));
             GemmParams g = gp(p->cn, D, b.w_cff1, D, Mc, F, D, EPI_BIAS_GELU, b.b_cff1, p->chid, F);
-            HIPCHK(launch_gemm(g, st));
+            HIPCHK(gemm_p(g, st));
             CHK(gate_res(p, st, p->chid, F, b.w_cff2, b.b_cff2, p->c, Mc, Nt, mod, mc + 5 * D));
         }
     }
@@ -479,7 +545,7 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
         const int NO = e->cfg.patch_size * e->cfg.patch_size * e->cfg.out_channels;
         GemmParams g = gp(p->xn, D, e->w_proj, D, Mi, NO, D, EPI_UNPATCH, e->b_proj, v_out, 0);
         g.hp = p->hp; g.wp = p->wp; g.patch = e->cfg.patch_size; g.out_ch = e->cfg.out_channels;
-        HIPCHK(launch_gemm(g, st));
+        HIPCHK(gemm_p(g, st));
     }
     return 0;
 }
@@ -513,7 +579,7 @@ static int sde_call(hipStream_t st, int batch, int64_t n, const void* v_text, co
     s.dynamics = dynamics; s.compute_log_prob = compute_log_prob; s.B = batch; s.n = n;
     s.next_out = next_out; s.next_out_dt = lat_dtype; s.next_f32 = next_f32; s.mean_out = mean_out;
     s.noise_pred_out = noise_pred_out; s.log_prob = log_prob; s.std_dev_t = std_dev_t; s.dt_out = dt;
-    HIPCHK(launch_sde_step(s, st));
+    HIPCHK(sde_p(s, st));
     return 0;
 }
 
@@ -611,7 +677,7 @@ extern "C" int mi355_op_linear(void* stream, const void* A, const void* W, const
     if (K % 64 || N % 4) return fail("mi355_op_linear: K %% 64 and N %% 4 must be 0");
     GemmParams g = gp((const bf16_t*)A, K, (const bf16_t*)W, K, M, N, K, act == 1 ? EPI_BIAS_SILU : act == 2 ? EPI_BIAS_GELU : EPI_BIAS,
                       bias, (bf16_t*)out, N);
-    HIPCHK(launch_gemm(g, (hipStream_t)stream));
+    HIPCHK(gemm_p(g, (hipStream_t)stream));
     return 0;
 }
 
@@ -620,7 +686,7 @@ extern "C" int mi355_op_attention(void* stream, const void* q, const void* k, co
     if (!q || !k || !vT || !o_img) return fail("mi355_op_attention: null argument");
     if (n_img < S && !o_ctx) return fail("mi355_op_attention: o_ctx is NULL but S > n_img");
     AttnParams a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vT, (bf16_t*)o_img, (bf16_t*)o_ctx, B, H, S, S_pad, n_img};
-    HIPCHK(launch_attention(a, (hipStream_t)stream));
+    HIPCHK(attn_p(a, (hipStream_t)stream));
     return 0;
 }
 
@@ -636,6 +702,6 @@ extern "C" int mi355_op_ln_modulate(void* stream, const void* x, const void* shi
     if (delta < -2147483647L || delta > 2147483647L) return fail("mi355_op_ln_modulate: shift/scale too far apart");
     l.scale_off = (int)delta;
     l.M = M; l.D = D; l.rows_per_sample = rows_per_sample; l.eps = eps;
-    HIPCHK(launch_ln_mod(l, (hipStream_t)stream));
+    HIPCHK(lnmod_p(l, (hipStream_t)stream));
     return 0;
 }

@@ -56,6 +56,8 @@ SIGNATURES = {
     "mi355_op_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I]),
     "mi355_op_attention": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "mi355_op_ln_modulate": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F]),
+    "mi355_profile_enable": (_I, [_I]),
+    "mi355_profile_collect": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
 _lib: Optional[C.CDLL] = None

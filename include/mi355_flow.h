@@ -134,6 +134,12 @@ int mi355_op_attention(void* stream, const void* q, const void* k, const void* v
 int mi355_op_ln_modulate(void* stream, const void* x, const void* shift, const void* scale, void* out, int M, int D,
                          int rows_per_sample, float eps);
 
+/* ---- measurement: hipEvent brackets per kernel class, recorded on the launch stream ---------
+ * enable(1) starts recording every launch of {attention, gemm, ln_modulate, sde_step, misc};
+ * collect() waits for the events and returns summed elapsed milliseconds and launch counts (5 each). */
+int mi355_profile_enable(int on);
+int mi355_profile_collect(double* ms_out, int64_t* count_out);
+
 #ifdef __cplusplus
 }
 #endif

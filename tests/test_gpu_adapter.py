@@ -1,0 +1,135 @@
+"""GPU test of the drop-in boundary: `SD3_5NativeAdapter.inference` / `.forward` (the reference's
+adapter API) against the CPU oracle on identical seeds and prompts, plus the invariants the GRPO
+trainer relies on (sample layout, index maps, ratio == 1 on replay)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mi355_flow.adapter import SD3_5NativeAdapter
+    from mi355_flow.engine import TransformerConfig
+    from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
+    from oracle import mmditx_ref as M
+    cfg_o = M.tiny_config(num_layers=3, num_heads=2, dual_layers=(0, 1), joint_attention_dim=128, pooled_projection_dim=128,
+                          pos_embed_max_size=24)
+    sd = {k: v.bfloat16().float() for k, v in M.make_synthetic_state_dict(cfg_o, seed=1234, std=0.08).items()}
+    cfg_e = TransformerConfig(num_layers=3, num_heads=2, joint_attention_dim=128, pooled_projection_dim=128,
+                              pos_embed_max_size=24, dual_layers=(0, 1))
+    sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=2, seed=42,
+                                               dynamics_type="Flow-SDE", shift=3.0)
+    ad = SD3_5NativeAdapter({k: v.cuda() for k, v in sd.items()}, cfg_e, sched, latent_storage_dtype="fp16")
+    ad.rollout()
+    yield ad, sd, cfg_o
+    ad.engine.close()
+
+
+def _prompts(B, Nt, seed):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda *s: torch.randn(*s, generator=g).bfloat16()
+    return mk(B, Nt, 128), mk(B, 128), mk(B, Nt, 128), mk(B, 128)
+
+
+@pytest.mark.parametrize("guidance", [1.0, 4.5])
+def test_inference_matches_oracle(setup, guidance):
+    from mi355_flow.trajectory import compute_trajectory_indices
+    from oracle import rollout_ref as R, scheduler_ref as S
+    ad, sd, cfg_o = setup
+    B, Nt, N, H, W = 2, 13, 6, 128, 128
+    pe, pp, ne, npl = _prompts(B, Nt, 5)
+    cfg_on = guidance > 1
+    traj = compute_trajectory_indices(ad.scheduler.train_timesteps, N)
+    torch.cuda.manual_seed(1234)
+    samples = ad.inference(prompt=["a", "b"], height=H, width=W, num_inference_steps=N, guidance_scale=guidance,
+                           prompt_embeds=pe.cuda(), pooled_prompt_embeds=pp.cuda(),
+                           negative_prompt_embeds=ne.cuda() if cfg_on else None,
+                           negative_pooled_prompt_embeds=npl.cuda() if cfg_on else None, trajectory_indices=traj)
+    # the same draws, in the reference's order, for the oracle
+    torch.cuda.manual_seed(1234)
+    init = torch.randn((B, 16, H // 8, W // 8), device="cuda", dtype=torch.bfloat16).cpu()
+    noise = torch.stack([torch.randn((B, 16, H // 8, W // 8), device="cuda", dtype=torch.float32) for _ in range(N)]).cpu()
+    ts, sig = S.make_schedule(N, shift=3.0)
+    nl = S.noise_levels(N, S.current_sde_steps([1, 2, 3], 2, 42, N), 0.7).tolist()
+    ref = R.rollout(sd, cfg_o, pe, pp, ne if cfg_on else None, npl if cfg_on else None, guidance, init, noise, ts, sig, nl,
+                    torch.float16)
+    assert len(samples) == B
+    s0 = samples[0]
+    assert torch.equal(s0.timesteps.cpu(), ts)
+    assert s0.all_latents.dtype == torch.float16 and s0.all_latents.shape == (len(traj), 16, 16, 16)
+    lm = s0.latent_index_map.tolist()
+    assert [p for p, s in enumerate(lm) if s >= 0] == traj and len(lm) == N + 1
+    sde = sorted(i for i in range(N) if nl[i] > 0)
+    pm = s0.log_prob_index_map.tolist()
+    assert [p for p, s in enumerate(pm) if s >= 0] == sde and s0.log_probs.shape == (len(sde),)
+    for b in range(B):
+        for pos in traj:
+            got = samples[b].all_latents[lm[pos]].float().cpu()
+            want = ref["all_latents"][pos][b].float()
+            assert float((got - want).norm() / want.norm()) < 2e-2, (b, pos)
+        for j, i in enumerate(sde):
+            np.testing.assert_allclose(float(samples[b].log_probs[j]), float(ref["log_probs"][i][b]), rtol=1e-3)
+    assert samples[0].prompt == "a" and samples[1].prompt == "b" and samples[0].image is None
+    assert samples[0].unique_id != samples[1].unique_id
+
+
+def test_fused_rollout_equals_stepwise_and_replay_ratio_is_one(setup):
+    ad, sd, cfg_o = setup
+    B, Nt, N = 2, 13, 6
+    pe, pp, ne, npl = _prompts(B, Nt, 6)
+    kw = dict(prompt=None, height=128, width=128, num_inference_steps=N, guidance_scale=4.5, prompt_embeds=pe.cuda(),
+              pooled_prompt_embeds=pp.cuda(), negative_prompt_embeds=ne.cuda(), negative_pooled_prompt_embeds=npl.cuda())
+    torch.cuda.manual_seed(77)
+    fused = ad.inference(**kw, trajectory_indices="all")
+    torch.cuda.manual_seed(77)
+    step = ad.inference(**kw, trajectory_indices="all", extra_call_back_kwargs=["noise_pred", "noise_level"])
+    for a, b in zip(fused, step):
+        assert torch.equal(a.all_latents, b.all_latents)          # one fused launch sequence == N single steps
+        assert torch.equal(a.log_probs, b.log_probs)
+        assert b.extra_kwargs["noise_pred"].shape == (N, 16, 16, 16)
+    # replay what optimize() does (grpo.py:229-263): stored x_i, x_{i+1}, per-sample t tensor
+    s = fused
+    ts = s[0].timesteps
+    for j, i in enumerate(p for p, v in enumerate(s[0].log_prob_index_map.tolist()) if v >= 0):
+        lat = torch.stack([x.all_latents[i] for x in s])
+        nxt = torch.stack([x.all_latents[i + 1] for x in s])
+        t = ts[i].expand(B)
+        t_next = (ts[i + 1] if i + 1 < N else torch.zeros((), device=ts.device)).expand(B)
+        out = ad.forward(t=t, t_next=t_next, latents=lat, next_latents=nxt, prompt_embeds=pe.cuda(), pooled_prompt_embeds=pp.cuda(),
+                         negative_prompt_embeds=ne.cuda(), negative_pooled_prompt_embeds=npl.cuda(), guidance_scale=4.5,
+                         noise_level=ad.scheduler.noise_level, compute_log_prob=True,
+                         return_kwargs=["log_prob", "next_latents_mean", "std_dev_t", "dt"])
+        old = torch.stack([x.log_probs[j] for x in s])
+        ratio = torch.exp(out.log_prob - old)
+        assert torch.equal(ratio, torch.ones_like(ratio)), ratio   # train/inference consistency invariant
+        assert out.std_dev_t.shape == (B, 1, 1, 1) and out.next_latents_mean.shape == lat.shape
+
+
+def test_scheduler_mirror_step_on_gpu(setup):
+    """The scheduler mirror's step() (reference signature) runs the fused kernel and honours return_kwargs."""
+    from oracle import scheduler_ref as S
+    ad, _, _ = setup
+    sch = ad.scheduler
+    from mi355_flow.scheduler import set_scheduler_timesteps
+    ts = set_scheduler_timesteps(sch, 4, seq_len=64, device="cuda")
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 16, 8, 8, generator=g).half()
+    v = torch.randn(2, 16, 8, 8, generator=g).bfloat16()
+    eps = torch.randn(2, 16, 8, 8, generator=g)
+    o = sch.step(noise_pred=v.cuda(), timestep=ts[1], latents=x.cuda(), timestep_next=ts[2], noise_level=0.7,
+                 variance_noise=eps.cuda(), return_kwargs=["next_latents", "log_prob", "dt"])
+    ref = S.sde_step(v, x, ts[1].cpu() / 1000, ts[2].cpu() / 1000, 0.7, "Flow-SDE", sigma_max=float(sch.sigmas[1]), variance_noise=eps)
+    assert torch.equal(o.next_latents.cpu(), ref["next_latents"]) and o.next_latents_mean is None
+    np.testing.assert_allclose(o.log_prob.cpu().numpy(), ref["log_prob"].numpy(), rtol=1e-5)
+    assert o.dt.shape == (2, 1, 1, 1)
+    # index-based call (timestep_next omitted) resolves sigma from the schedule like the reference
+    o2 = sch.step(noise_pred=v.cuda(), timestep=ts[1], latents=x.cuda(), noise_level=0.7, variance_noise=eps.cuda())
+    assert torch.equal(o2.next_latents, o.next_latents)
+    sch.eval()
+    o3 = sch.step(noise_pred=v.cuda(), timestep=ts[1], latents=x.cuda(), timestep_next=ts[2], compute_log_prob=False)
+    assert o3.log_prob is None and torch.equal(o3.std_dev_t.cpu(), torch.zeros(2, 1, 1, 1))
+    sch.rollout()
