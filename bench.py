@@ -192,9 +192,9 @@ def main():
         names = ["attention", "gemm", "ln_modulate", "sde_step", "misc"]
         by_class = {names[i]: {"ms": round(ms[i], 3), "launches": int(cnt[i])} for i in range(5)}
         a_ms = ms[0] / max(cnt[0], 1)                       # mean duration of one attention launch
-        a_flop = attn_fl * B / attn_launches                # mean algorithmic FLOPs of one attention launch
+        a_flop = attn_fl * B * n_cfg / attn_launches        # mean algorithmic FLOPs of one attention launch (forward batch B*n_cfg)
         achieved = a_flop / (a_ms * 1e-3) / 1e12 if a_ms > 0 else 0.0
-        gemm_fl = (F - attn_fl) * B * fwd_per_timed
+        gemm_fl = (F - attn_fl) * B * fwd_per_timed        # fwd_per_timed already counts the n_cfg forwards
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_attention.json")
         if os.path.isfile(pmc):

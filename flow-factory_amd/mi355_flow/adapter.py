@@ -238,7 +238,9 @@ class NativeRolloutMixin:
                 t_next = t_next[0]
         t_next = torch.as_tensor(t_next, dtype=torch.float32, device=dev)
         dyn = sched.dynamics_type
-        sigma, sigma_next = t / 1000, t_next / 1000
+        # exact fp32 quotient (torch's GPU tensor/scalar division multiplies by a rounded reciprocal: 1 ulp off
+        # the host-side t/1000 the fused rollout uses, which would break the bit-exact ratio == 1 invariant)
+        sigma, sigma_next = (t.double() / 1000).float(), (t_next.double() / 1000).float()
         if sched.is_eval or dyn == "ODE":
             noise_level = 0.0
         elif noise_level is None:

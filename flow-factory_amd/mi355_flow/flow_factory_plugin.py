@@ -1,0 +1,80 @@
+"""The binding a Flow-Factory installation uses:  `model.model_type: mi355_flow.flow_factory_plugin.SD3_5NativeAdapter`.
+
+Flow-Factory resolves an unknown `model_type` as a python path (reference
+src/flow_factory/models/registry.py:69-82) and constructs `cls(config=config, accelerator=accelerator)`
+(models/loader.py:61-64).  The class below IS the reference's `SD3_5Adapter` (pipeline loading, text
+encoders, VAE, LoRA, EMA, checkpoints, device placement all inherited) with the rollout hot path
+(`inference`, no-grad `forward`) routed to libmi355flow.so through `NativeRolloutMixin`.
+
+Importing this module needs `flow_factory` (+ diffusers, peft): it is NOT importable in the build
+container; `mi355_flow.adapter` carries the same code path standalone and is what the tests run.
+"""
+from __future__ import annotations
+
+import torch
+
+try:  # pragma: no cover - exercised only inside a Flow-Factory installation
+    from flow_factory.models.stable_diffusion.sd3_5 import SD3_5Adapter as _RefAdapter
+except Exception as e:  # noqa: BLE001
+    _RefAdapter = None
+    _IMPORT_ERROR = e
+
+from .adapter import NativeRolloutMixin
+from .engine import Engine, TransformerConfig
+
+if _RefAdapter is not None:  # pragma: no cover
+
+    class SD3_5NativeAdapter(NativeRolloutMixin, _RefAdapter):
+        """`SD3_5Adapter` with the GRPO rollout running on the MI355X engine."""
+
+        def __init__(self, config, accelerator):
+            _RefAdapter.__init__(self, config, accelerator)
+            tc = self.pipeline.transformer.config
+            self.engine = Engine(TransformerConfig(
+                in_channels=tc.in_channels, out_channels=tc.out_channels, patch_size=tc.patch_size,
+                num_layers=tc.num_layers, num_heads=tc.num_attention_heads, head_dim=tc.attention_head_dim,
+                joint_attention_dim=tc.joint_attention_dim, pooled_projection_dim=tc.pooled_projection_dim,
+                pos_embed_max_size=tc.pos_embed_max_size, dual_layers=tuple(tc.dual_attention_layers)))
+            self._bound_version = -1
+            self._weights_version = 0
+
+        # the engine computes in bf16 like the reference's autocast run
+        @property
+        def transformer_dtype(self):
+            return self.pipeline.transformer.dtype
+
+        def _sync_weights(self):
+            if self._bound_version != self._weights_version:
+                module = self.accelerator.unwrap_model(self.transformer)
+                self.engine.bind_state_dict(module.state_dict())  # LoRA: merge first (peft `merge_adapter`) or bind merged weights
+                self.engine.ready()
+                self._bound_version = self._weights_version
+
+        # weights are live: every mode switch that can change them invalidates the packed copy
+        def rollout(self, *a, **k):
+            self._weights_version += 1
+            return _RefAdapter.rollout(self, *a, **k)
+
+        def eval(self, *a, **k):
+            self._weights_version += 1
+            return _RefAdapter.eval(self, *a, **k)
+
+        @torch.no_grad()
+        def inference(self, *args, **kwargs):
+            self._sync_weights()
+            return NativeRolloutMixin.inference(self, *args, **kwargs)
+
+        def forward(self, *args, **kwargs):
+            # optimize() (trainers/grpo.py:263) needs autograd through the transformer: that stays on the
+            # reference path until the backward kernels exist.  The rollout is no-grad.
+            if torch.is_grad_enabled():
+                return _RefAdapter.forward(self, *args, **kwargs)
+            self._sync_weights()
+            return NativeRolloutMixin.forward(self, *args, **kwargs)
+
+else:
+
+    class SD3_5NativeAdapter:  # type: ignore[no-redef]
+        def __init__(self, *a, **k):
+            raise ImportError("mi355_flow.flow_factory_plugin needs an importable `flow_factory` (with diffusers/peft): "
+                              f"{_IMPORT_ERROR!r}.  Use mi355_flow.adapter.SD3_5NativeAdapter standalone instead.")

@@ -293,8 +293,9 @@ class FlowMatchEulerDiscreteSDEScheduler:
             sigma = self.sigmas[idxs].to(dev)
             sigma_prev = self.sigmas[[i + 1 for i in idxs]].to(dev)
         else:
-            sigma = torch.as_tensor(timestep, dtype=torch.float32, device=dev) / 1000
-            sigma_prev = torch.as_tensor(timestep_next, dtype=torch.float32, device=dev) / 1000
+            # exact fp32 quotient (GPU tensor/scalar division multiplies by a rounded reciprocal)
+            sigma = (torch.as_tensor(timestep, dtype=torch.float32, device=dev).double() / 1000).float()
+            sigma_prev = (torch.as_tensor(timestep_next, dtype=torch.float32, device=dev).double() / 1000).float()
         dyn = dynamics_type or self.dynamics_type
         if dyn not in ("Flow-SDE", "Dance-SDE", "CPS", "ODE"):
             raise ValueError(f"unknown dynamics_type {dyn!r}")

@@ -1,0 +1,54 @@
+"""Condense rocprofv3 output (kernel stats CSV + counter_collection CSVs) into small text/JSON summaries."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def short(name):
+    for key, tag in (("attn_kernel", "attn_kernel"), ("gemm_kernel", None), ("ln_mod_kernel", "ln_mod_kernel"),
+                     ("sde_step_kernel", "sde_step_kernel"), ("patchify", "patchify_kernel"), ("time_proj", "time_proj_kernel"),
+                     ("convert_kernel", "convert_kernel"), ("pos_crop", "pos_crop_kernel")):
+        if key in name:
+            if tag:
+                return tag
+            # gemm_kernelILi256ELi256ELi2ELi4ELi5EE -> gemm<256,256,epi5>
+            import re
+            m = re.search(r"gemm_kernelILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d+)EE", name)
+            return f"gemm<{m.group(1)}x{m.group(2)},epi{m.group(3)}>" if m else "gemm"
+    return name[:60]
+
+
+stats = glob.glob(os.path.join(out, "prof_stats", "**", "*kernel_stats*.csv"), recursive=True)
+if stats:
+    rows = list(csv.DictReader(open(stats[0])))
+    print("== rocprofv3 --kernel-trace --stats (bench.py --steps 1 --warmup 1):", os.path.basename(stats[0]))
+    print(f"{'kernel':34s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}")
+    for r in rows[:25]:
+        print(f"{short(r['Name']):34s} {int(r['Calls']):7d} {float(r['TotalDurationNs'])/1e6:10.2f} {float(r['AverageNs'])/1e3:10.1f} {float(r['Percentage']):6.2f}")
+
+summary = {}
+for d in sorted(glob.glob(os.path.join(out, "prof_pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    files = glob.glob(os.path.join(d, "**", "*counter_collection*.csv"), recursive=True)
+    if not files:
+        print("no counter csv in", d)
+        continue
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(lambda: defaultdict(int))
+    for r in csv.DictReader(open(files[0])):
+        k = short(r["Kernel_Name"])
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[k][r["Counter_Name"]] += 1
+    print("== PMC", os.path.basename(d))
+    for k in sorted(acc, key=lambda k: -sum(acc[k].values()))[:12]:
+        per = {c: acc[k][c] / cnt[k][c] for c in acc[k]}
+        print(f"  {k:34s} launches={max(cnt[k].values()):6d} per-launch: " + ", ".join(f"{c}={v:.4g}" for c, v in per.items()))
+        summary.setdefault(k, {}).update({c: v for c, v in per.items()})
+        summary[k]["launches"] = max(cnt[k].values())
+json.dump(summary, open(os.path.join(out, "pmc_per_launch.json"), "w"), indent=1)

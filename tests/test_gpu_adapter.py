@@ -94,7 +94,11 @@ def test_fused_rollout_equals_stepwise_and_replay_ratio_is_one(setup):
     # replay what optimize() does (grpo.py:229-263): stored x_i, x_{i+1}, per-sample t tensor
     s = fused
     ts = s[0].timesteps
-    for j, i in enumerate(p for p, v in enumerate(s[0].log_prob_index_map.tolist()) if v >= 0):
+    # with trajectory_indices='all' the index maps are the identity (reference collector semantics), so take
+    # the trained steps from the scheduler, in the order the log-probs were collected (ascending step)
+    sde = [i for i, e in enumerate(ad.scheduler.host_noise_levels()) if e > 0]
+    assert len(sde) == 2 and s[0].log_probs.shape == (2,)
+    for j, i in enumerate(sde):
         lat = torch.stack([x.all_latents[i] for x in s])
         nxt = torch.stack([x.all_latents[i + 1] for x in s])
         t = ts[i].expand(B)
