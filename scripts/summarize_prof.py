@@ -18,8 +18,10 @@ def short(name):
                 return tag
             # gemm_kernelILi256ELi256ELi2ELi4ELi5EE -> gemm<256,256,epi5>
             import re
-            m = re.search(r"gemm_kernelILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d+)EE", name)
-            return f"gemm<{m.group(1)}x{m.group(2)},epi{m.group(3)}>" if m else "gemm"
+            m = re.search(r"gemm_kernelILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d+)EE", name) or \
+                re.search(r"gemm_kernel<(\d+), (\d+), \d+, \d+, (\d+)>", name)
+            epi = ["bias", "bias_silu", "bias_gelu", "posadd", "addsrc_silu", "gate_res", "qk_norm", "vT", "unpatch"]
+            return f"gemm<{m.group(1)}x{m.group(2)},{epi[int(m.group(3))]}>" if m else "gemm"
     return name[:60]
 
 
