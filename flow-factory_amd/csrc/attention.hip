@@ -45,7 +45,18 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_kernel(AttnParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 31, lg = lane >> 5;
-    const int qblk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // XCD-aware work order: workgroup id w runs on XCD (w % 8); give each XCD a contiguous range of
+    // (batch, head, q-block) so that the q-blocks sharing one (b, h)'s K / V^T hit the same private L2.
+    const int nqb = (p.S + QB - 1) / QB;
+    const int nwg = nqb * p.H * p.B;
+    int wid = blockIdx.x;
+    {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = wid & 7;
+        wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (wid >> 3);
+    }
+    const int qblk = wid % nqb;
+    const int bhi = wid / nqb;
+    const int h = bhi % p.H, b = bhi / p.H;
     const long bh = (long)b * p.H + h;
     const bf16_t* Qg = p.q + bh * p.S_pad * 64;
     const bf16_t* Kg = p.k + bh * p.S_pad * 64;
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_kernel(AttnParams p) {
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.S <= 0 || p.S_pad % KV != 0 || p.S_pad < p.S) return hipErrorInvalidValue;
-    dim3 grid((p.S + QB - 1) / QB, p.H, p.B);
+    dim3 grid(((p.S + QB - 1) / QB) * p.H * p.B);
     hipLaunchKernelGGL(attn_kernel, grid, dim3(NWAVE * 64), 2 * STAGE_BYTES, stream, p);
     return hipGetLastError();
 }

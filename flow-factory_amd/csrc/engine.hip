@@ -670,6 +670,12 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
     return 0;
 }
 
+// A/B knob for kernel variants (key 0: GEMM 256x256 schedule, 0 = simple 2-stage, 1 = ping-pong)
+extern "C" int mi355_tune_set(int key, int value) {
+    if (key == 0) { set_gemm_variant(value); return 0; }
+    return fail("mi355_tune_set: unknown key %d", key);
+}
+
 // ----------------------------------------------------------------------- operator-level API
 extern "C" int mi355_op_linear(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                                int act) {
@@ -678,6 +684,15 @@ extern "C" int mi355_op_linear(void* stream, const void* A, const void* W, const
     GemmParams g = gp((const bf16_t*)A, K, (const bf16_t*)W, K, M, N, K, act == 1 ? EPI_BIAS_SILU : act == 2 ? EPI_BIAS_GELU : EPI_BIAS,
                       bias, (bf16_t*)out, N);
     HIPCHK(gemm_p(g, (hipStream_t)stream));
+    return 0;
+}
+
+// debug: same as mi355_op_linear (act 0) with an s_memtime trace buffer (device, >= 256*16*2*4 int64)
+extern "C" int mi355_op_linear_trace(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                                     void* trace) {
+    GemmParams g = gp((const bf16_t*)A, K, (const bf16_t*)W, K, M, N, K, EPI_BIAS, bias, (bf16_t*)out, N);
+    g.trace = (long long*)trace;
+    HIPCHK(launch_gemm(g, (hipStream_t)stream));
     return 0;
 }
 

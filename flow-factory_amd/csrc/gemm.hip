@@ -22,6 +22,7 @@ namespace mi355 {
 namespace {
 
 constexpr int BK = 64;
+int g_gemm_variant = 1;  // 0: simple 2-stage kernel, 1: ping-pong schedule (large grids)
 
 template <int BM, int BN, int WM, int WN>
 struct Cfg {
@@ -56,6 +57,14 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, int m, int n, con
         // m = feature (row bias), n = token
         const float b = p.bias[m];
         const int h = m >> 6, d = m & 63;
+        if (((p.rows_per_sample | p.s_off) & 3) == 0 && n + 3 < p.N) {
+            // 4 consecutive tokens of one sample, 8-byte aligned: one packed store (image stream)
+            const int bi = n / p.rows_per_sample;
+            const int s0 = n - bi * p.rows_per_sample + p.s_off;
+            uint2 o = {pack_bf16(v[0] + b, v[1] + b), pack_bf16(v[2] + b, v[3] + b)};
+            *(uint2*)(p.q + (((long)bi * p.H + h) * 64 + d) * p.S_pad + s0) = o;
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int tok = n + r;
@@ -129,6 +138,164 @@ __device__ __forceinline__ void epi_store(const GemmParams& p, int m, int n, con
                 p.out[(((long)bi * p.out_ch + c) * Himg + ty * p.patch + pp) * Wimg + tx * p.patch + qq] = f2bf(y[r]);
             }
         }
+    }
+}
+
+// ---- LDS-staged epilogue ----------------------------------------------------------------------
+// The MFMA accumulator layout gives a lane 4 consecutive columns of 16 different rows; written to
+// HBM directly that is 32-byte partial-line stores (4 per 128-byte line, store-issue bound: the
+// store tail of a 256x256 tile cost ~19 us of a 52 us K=1536 tile).  Instead each wave transposes its
+// 64x64 half-tile through a private 8 KiB LDS region (bf16, 16-byte chunks XOR-swizzled by row) and
+// writes / read-modify-writes whole 128-byte lines, 16 bytes per lane.
+//   phase 1 (accumulator layout, fp32): + bias, per-head RMSNorm (q/k), SiLU / GELU  -> bf16 -> LDS
+//   phase 2 (row layout, 8 columns per lane): + pos-embed / + src, gated residual, scatter -> HBM
+template <int EPI, bool FULL>
+__device__ __forceinline__ void store_row8(const GemmParams& p, int m, int n, int n_wave, uint4 val) {
+    const bool full = FULL || (n + 8 <= p.N);
+    float y[8] = {bf_lo(val.x), bf_hi(val.x), bf_lo(val.y), bf_hi(val.y), bf_lo(val.z), bf_hi(val.z), bf_lo(val.w), bf_hi(val.w)};
+    if constexpr (EPI == EPI_QK_NORM) {
+        const int D = p.H * 64;
+        const bool is_k = n_wave >= D;
+        const int h = ((is_k ? n_wave - D : n_wave) >> 6);
+        const int bi = m / p.rows_per_sample;
+        const int s = m - bi * p.rows_per_sample + p.s_off;
+        bf16_t* dst = (is_k ? p.k : p.q) + (((long)bi * p.H + h) * p.S_pad + s) * 64 + (n - n_wave);
+        *(uint4*)dst = val;
+        return;
+    } else if constexpr (EPI == EPI_VT) {
+        // m = feature, n.. = 8 tokens
+        const int h = m >> 6, d = m & 63;
+        if (full && ((p.rows_per_sample | p.s_off) & 7) == 0) {
+            const int bi = n / p.rows_per_sample;
+            const int s0 = n - bi * p.rows_per_sample + p.s_off;
+            *(uint4*)(p.q + (((long)bi * p.H + h) * 64 + d) * p.S_pad + s0) = val;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int tok = n + e;
+                if (tok < p.N) {
+                    const int bi = tok / p.rows_per_sample;
+                    const int s = tok - bi * p.rows_per_sample + p.s_off;
+                    p.q[(((long)bi * p.H + h) * 64 + d) * p.S_pad + s] = f2bf(y[e]);
+                }
+            }
+        }
+        return;
+    } else {
+        bf16_t* op = p.out + (long)m * p.ldo + n;
+        const bool vec = FULL || (full && ((p.ldo & 7) == 0));
+        if constexpr (EPI == EPI_POSADD || EPI == EPI_ADDSRC_SILU) {
+            const bf16_t* ap = p.aux + (long)(m % p.rows_per_sample) * p.ld_aux + n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (n + e < p.N) {
+                    y[e] += bf2f(ap[e]);
+                    if constexpr (EPI == EPI_ADDSRC_SILU) y[e] = silu_f(round_bf16(y[e]));
+                }
+        } else if constexpr (EPI == EPI_GATE_RES) {
+            const int bi = m / p.rows_per_sample;
+            const bf16_t* gp = p.aux + (long)bi * p.ld_aux + n;
+            if (vec) {
+                const uint4 g = *(const uint4*)gp;
+                const uint4 x = *(const uint4*)op;
+                y[0] = bf_lo(x.x) + bf_lo(g.x) * y[0]; y[1] = bf_hi(x.x) + bf_hi(g.x) * y[1];
+                y[2] = bf_lo(x.y) + bf_lo(g.y) * y[2]; y[3] = bf_hi(x.y) + bf_hi(g.y) * y[3];
+                y[4] = bf_lo(x.z) + bf_lo(g.z) * y[4]; y[5] = bf_hi(x.z) + bf_hi(g.z) * y[5];
+                y[6] = bf_lo(x.w) + bf_lo(g.w) * y[6]; y[7] = bf_hi(x.w) + bf_hi(g.w) * y[7];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (n + e < p.N) y[e] = bf2f(op[e]) + bf2f(gp[e]) * y[e];
+            }
+        }
+        if (vec) {
+            uint4 o;
+            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_SILU || EPI == EPI_BIAS_GELU) o = val;
+            else o = make_uint4(pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7]));
+            *(uint4*)op = o;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (n + e < p.N) op[e] = f2bf(y[e]);
+        }
+    }
+}
+
+// acc: NR*16 rows x 64 columns of the wave's tile, acc[i][j][e] = C[m_base + 16 i + (lane&15)][n_base + 16 j + 4 (lane>>4) + e];
+// stg: NR*2 KiB of wave-private LDS
+// FULL: the whole 256-wide tile lies inside [0,M) x [0,N) and rows are 16-byte aligned (no guards)
+template <int EPI, int NR, bool FULL = false>
+__device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (&acc)[NR][4], int m_base, int n_base,
+                                              char* stg, int lane) {
+    const int frow = lane & 15, fkg = lane >> 4;
+    float4 bcol[4];
+    float4 nw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n_base + j * 16 + 4 * fkg;
+        bcol[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (EPI != EPI_VT) {
+            if (FULL || n < p.N) bcol[j] = *(const float4*)(p.bias + n);
+        }
+        if constexpr (EPI == EPI_QK_NORM) {
+            const bool is_k = n_base >= p.H * 64;
+            nw[j] = *(const float4*)((is_k ? p.nw_k : p.nw_q) + j * 16 + 4 * fkg);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int r = i * 16 + frow;
+        float y[4][4];
+        float brow = 0.f;
+        if constexpr (EPI == EPI_VT) {
+            const int m = m_base + r;
+            brow = p.bias[m < p.M ? m : p.M - 1];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            y[j][0] = acc[i][j][0] + (EPI == EPI_VT ? brow : bcol[j].x);
+            y[j][1] = acc[i][j][1] + (EPI == EPI_VT ? brow : bcol[j].y);
+            y[j][2] = acc[i][j][2] + (EPI == EPI_VT ? brow : bcol[j].z);
+            y[j][3] = acc[i][j][3] + (EPI == EPI_VT ? brow : bcol[j].w);
+        }
+        if constexpr (EPI == EPI_QK_NORM) {
+            float ss = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ss += y[j][0] * y[j][0] + y[j][1] * y[j][1] + y[j][2] * y[j][2] + y[j][3] * y[j][3];
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float rstd = rsqrtf(ss * (1.0f / 64.0f) + p.eps);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                y[j][0] *= rstd * nw[j].x; y[j][1] *= rstd * nw[j].y; y[j][2] *= rstd * nw[j].z; y[j][3] *= rstd * nw[j].w;
+            }
+        }
+        if constexpr (EPI == EPI_BIAS_SILU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[j][e] = silu_f(round_bf16(y[j][e]));
+        }
+        if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[j][e] = gelu_tanh_f(y[j][e]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int chunk = (j * 2 + (fkg >> 1)) ^ (r & 7);
+            uint2 o = {pack_bf16(y[j][0], y[j][1]), pack_bf16(y[j][2], y[j][3])};
+            *(uint2*)(stg + r * 128 + chunk * 16 + (fkg & 1) * 8) = o;
+        }
+    }
+    // wave-private region: a wave's LDS operations execute in order, no barrier needed
+#pragma unroll
+    for (int it = 0; it < NR * 2; ++it) {
+        const int r = it * 8 + (lane >> 3), c = lane & 7;
+        const uint4 val = *(const uint4*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
+        const int m = m_base + r;
+        if (FULL || m < p.M) store_row8<EPI, FULL>(p, m, n_base + c * 8, n_base, val);
     }
 }
 
@@ -220,34 +387,278 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
         }
     }
 
-    // ---- epilogue.  Lane holds, for row m = .. + (lane&15): columns n = .. + ni*16 + 4*(lane>>4) + r
-    const int mrow = m0 + wm * C::TM + frow;
-    const int ncol = n0 + wn * C::TN + 4 * fkg;
+    // ---- epilogue
+    if constexpr (EPI == EPI_UNPATCH) {
+        // tiny N (64): scalar scatter straight from the accumulator layout
+        const int mrow = m0 + wm * C::TM + frow;
+        const int ncol = n0 + wn * C::TN + 4 * fkg;
 #pragma unroll
-    for (int i = 0; i < C::MI; ++i) {
-        const int m = mrow + i * 16;
-        float rstd = 1.0f;
-        if constexpr (EPI == EPI_QK_NORM) {
-            float ss = 0.f;
+        for (int i = 0; i < C::MI; ++i)
 #pragma unroll
             for (int j = 0; j < C::NI; ++j) {
-                const int n = ncol + j * 16;
-                const int nc = n < p.N ? n : 0;
-                const float4 bb = *(const float4*)(p.bias + nc);
-                const float a0 = acc[i][j][0] + bb.x, a1 = acc[i][j][1] + bb.y, a2 = acc[i][j][2] + bb.z,
-                            a3 = acc[i][j][3] + bb.w;
-                ss += a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3;
+                const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                epi_store<EPI>(p, mrow + i * 16, ncol + j * 16, v, 1.0f);
             }
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
-            rstd = rsqrtf(ss * (1.0f / 64.0f) + p.eps);
-        }
+    } else {
+        __syncthreads();  // every wave is done reading the operand ring: reuse it as epilogue staging
+        char* stg = smem + wave * 8192;
 #pragma unroll
-        for (int j = 0; j < C::NI; ++j) {
-            const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            epi_store<EPI>(p, m, ncol + j * 16, v, rstd);
+        for (int hh = 0; hh < C::MI / 4; ++hh) {
+            f32x4 a4[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a4[i][j] = acc[hh * 4 + i][j];
+            epilogue_part<EPI, 4>(p, a4, m0 + wm * C::TM + hh * 64, n0 + wn * C::TN, stg, lane);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 256x256x64 "ping-pong" kernel (the large-M GEMMs of the image stream).
+//
+// 8 waves = 2 groups of 4 (group g owns tile rows [128g, 128g+128), wave (g, wn) the 128x64 sub-tile
+// at columns 64*wn).  Waves w and w+4 share a SIMD; the two groups run the same 4-phase-per-K-tile
+// schedule staggered by one barrier interval, so that on every SIMD one wave is inside a 16-MFMA
+// cluster (one 64x32 quadrant x K=64, s_setprio 1) while its partner issues the ds_read_b128s of its
+// next quadrant and the global_load_lds prefetches -- matrix beside memory, never matrix beside
+// matrix (MI355X_MICROARCH.md "Two waves per SIMD").  Loads for K-tile t+1 are issued one unit
+// (128 rows x 128 B = 16 KiB, 2 wave-instructions per wave) per phase during K-tile t and retired with
+// COUNTED s_waitcnt vmcnt(4) (never 0 in the main loop): every unit has >= 4 barrier intervals to
+// land, and a unit is first read one phase after the wait + barrier that retires it for BOTH groups.
+//   unit order U0 = A rows of quadrant-row 0 (both groups), U2/U3 = W rows of quadrant-col 0/1, U1 = A
+//   rows of quadrant-row 1;  phase P0: (0,0) reads A0,B0 | P1: (0,1) reads B1 | P2: (1,1) reads A1 |
+//   P3: (1,0) reads nothing;  prefetch order for tile t+1: U0, U2, U3, U1.
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
+    constexpr int BM = 256, BN = 256, TM = 128, TN = 64;
+    constexpr int A_BYTES = BM * BK * 2, STAGE = 2 * A_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wn = wave & 3;
+
+    // ---- persistent tile schedule: the grid is min(#tiles, #CUs) workgroups; workgroup b (XCD b % 8) walks
+    // tiles  chunk(b % 8) + (b / 8) + i * (gridDim / 8): at any time the workgroups of one XCD hold consecutive
+    // tiles (same activation row panel / neighbouring weight panels) in that XCD's private L2.
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    const int nblk = ntm * ntn;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per_xcd = (int)(gridDim.x >> 3);            // gridDim is a multiple of 8 (launcher)
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int chunk_lo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int chunk_n = q8 + (xcd < r8 ? 1 : 0);
+
+    // ---- staging: unit u in {0:A q-row 0, 1:A q-row 1, 2:W q-col 0, 3:W q-col 1}; 16 groups of 8 rows per
+    // unit, wave w stages groups j = w and w + 8 of every unit.  Per-lane source = uniform base (+ k offset,
+    // scalar) + 32-bit byte offset (VGPR): 8 VGPRs of addressing state for the whole kernel.
+    const int srow = lane >> 3, spc = lane & 7;
+    unsigned soff[4][2];   // byte offset of this lane's 16-byte chunk from p.A (u < 2) / p.W (u >= 2)
+    int ldsoff[4][2];
+    int m0 = 0, n0 = 0;
+    auto set_tile = [&](int tile) {
+        const int tm = tile / ntn, tn = tile - tm * ntn;
+        m0 = tm * BM; n0 = tn * BN;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int j = wave + 8 * i;
+                int g8;  // 8-row group index inside the 256-row operand tile
+                if (u == 0) g8 = (j < 8) ? j : 16 + (j - 8);
+                else if (u == 1) g8 = (j < 8) ? 8 + j : 24 + (j - 8);
+                else g8 = (j >> 2) * 8 + (u == 3 ? 4 : 0) + (j & 3);
+                const int row = g8 * 8 + srow;
+                const int c = spc ^ ((row >> 1) & 7);
+                if (u < 2) {
+                    int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;
+                    soff[u][i] = ((unsigned)gm * (unsigned)p.lda + (unsigned)(c * 8)) * 2u;
+                    ldsoff[u][i] = g8 * 1024;
+                } else {
+                    int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+                    soff[u][i] = ((unsigned)gn * (unsigned)p.ldw + (unsigned)(c * 8)) * 2u;
+                    ldsoff[u][i] = A_BYTES + g8 * 1024;
+                }
+            }
+    };
+    auto stage_unit = [&](int u, long ko, char* base) {
+        const char* gb = (u < 2 ? (const char*)p.A : (const char*)p.W) + ko * 2;   // uniform
+        glds16(gb + soff[u][0], base + ldsoff[u][0]);
+        glds16(gb + soff[u][1], base + ldsoff[u][1]);
+    };
+
+    // ---- fragment read offsets inside a stage
+    const int frow = lane & 15, fkg = lane >> 4, fsw = frow >> 1;
+    int offX[2], offW[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int pc = (kk * 4 + fkg) ^ fsw;
+        offX[kk] = (grp * TM + frow) * 128 + pc * 16;
+        offW[kk] = A_BYTES + (wn * TN + frow) * 128 + pc * 16;
+    }
+
+    f32x4 acc[8][4];
+    bf16x8 af[4][2], bfr[2][2][2];
+
+#define PP_BARRIER()                              \
+    do {                                          \
+        __builtin_amdgcn_sched_barrier(0);        \
+        __builtin_amdgcn_s_barrier();             \
+        __builtin_amdgcn_sched_barrier(0);        \
+    } while (0)
+#define PP_READ_A(qm)                                                                                   \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)     \
+        af[mi][kk] = *(const bf16x8*)(sb + offX[kk] + (qm) * 8192 + mi * 2048)
+#define PP_READ_B(qn)                                                                                   \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)     \
+        bfr[qn][ni][kk] = *(const bf16x8*)(sb + offW[kk] + (qn) * 4096 + ni * 2048)
+#define PP_MFMA(qm, qn)                                                                                 \
+    do {                                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        __builtin_amdgcn_s_setprio(1);                                                                  \
+        _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) \
+            _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                             \
+                acc[(qm) * 4 + mi][(qn) * 2 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(              \
+                    bfr[qn][ni][kk], af[mi][kk], acc[(qm) * 4 + mi][(qn) * 2 + ni], 0, 0, 0);            \
+        __builtin_amdgcn_s_setprio(0);                                                                  \
+    } while (0)
+
+    const int nt = p.K / BK;
+    if (slot >= chunk_n) return;  // (only when there are fewer tiles than workgroups)
+    const int my_tiles = (chunk_n - slot + per_xcd - 1) / per_xcd;
+    // K-tile 0 of the first tile completely, then ONE continuous (tile, K-tile) stream: the prefetch of the
+    // step after a tile's last K-tile already belongs to the next tile, so the cold first K-tile of a tile
+    // lands under the previous tile's last MFMA phases and epilogue instead of in front of an idle CU.
+    set_tile(chunk_lo + slot);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) stage_unit(u, 0, smem);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BARRIER();
+    if (grp == 1) PP_BARRIER();  // stagger: group 1 runs one barrier interval behind group 0
+
+    // epilogue staging: 4 KiB per wave in the W half of the stage that was just consumed.  While some wave is
+    // still in its epilogue, the only LDS-DMA that can target that stage is unit U0 of the next-but-one step
+    // (A rows) issued by waves that are already past theirs; W-row units follow a barrier every wave must reach.
+    const int stg_off = A_BYTES + wave * 4096;
+    int cur_m0 = m0, cur_n0 = n0;
+    int tile_i = 0, t = 0, par = 0;
+    long long* trc = nullptr;
+    if (p.trace && (wave == 0 || wave == 4) && lane == 0) trc = p.trace + ((long)blockIdx.x * 16 * 2 + grp) * 4;
+    if (trc) { trc[0] = __builtin_amdgcn_s_memtime(); trc[1] = trc[0]; }
+#define PP_EPILOGUE(SB)                                                                                        \
+    do {                                                                                                          \
+        /* no wave has an LDS read of this stage pending here (P3 reads nothing; every wave's P2 reads were  */  \
+        /* waited for before its P2 MFMAs, which precede the barrier this wave just passed).                 */  \
+        /* Retire this wave's share of the next step's operands NOW (issued >= 2 intervals ago), before the  */  \
+        /* epilogue queues stores behind them: the step after an epilogue then needs no wait in P0 / P1.     */  \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
+        if (trc) trc[2] = __builtin_amdgcn_s_memtime();                                                          \
+        char* stg = (char*)(SB) + stg_off;                                                                        \
+        const bool full_tile = (em0 + BM <= p.M) && (en0 + BN <= p.N) && ((p.ldo & 7) == 0 || EPI == EPI_QK_NORM || EPI == EPI_VT) && \
+                               (EPI != EPI_VT || ((p.rows_per_sample | p.s_off) & 7) == 0);                       \
+        _Pragma("unroll") for (int qq = 0; qq < 4; ++qq) {                                                        \
+            f32x4 a2[2][4];                                                                                       \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j) {          \
+                a2[i][j] = acc[qq * 2 + i][j];                                                                    \
+                acc[qq * 2 + i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                 \
+            }                                                                                                     \
+            if (full_tile) epilogue_part<EPI, 2, true>(p, a2, em0 + grp * TM + qq * 32, en0 + wn * TN, stg, lane); \
+            else epilogue_part<EPI, 2, false>(p, a2, em0 + grp * TM + qq * 32, en0 + wn * TN, stg, lane);          \
+            __builtin_amdgcn_sched_barrier(0);                                                                    \
+        }                                                                                                         \
+        if (trc) {                                                                                                \
+            trc[3] = __builtin_amdgcn_s_memtime();                                                                \
+            trc += 8;                                                                                             \
+            trc[0] = trc[-8 + 3]; trc[1] = trc[0];                                                                \
+        }                                                                                                         \
+    } while (0)
+
+    const int nsteps = my_tiles * nt;
+    bool after_epi = false;  // this step's operands were fully retired by the wait that opens PP_EPILOGUE
+    for (int sidx = 0; sidx < nsteps - 1; ++sidx) {
+        const bool last_k = (t == nt - 1);
+        const char* sb = smem + par * STAGE;
+        char* nb = smem + (par ^ 1) * STAGE;
+        const int em0 = cur_m0, en0 = cur_n0;  // the tile the accumulators belong to
+        long ko = (long)(t + 1) * BK;
+        if (last_k) {
+            ++tile_i;
+            set_tile(chunk_lo + slot + tile_i * per_xcd);
+            ko = 0; cur_m0 = m0; cur_n0 = n0;
+        }
+        // P0: quadrant (0,0)
+        PP_READ_A(0); PP_READ_B(0);
+        stage_unit(0, ko, nb);
+        if (!after_epi) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // retires U3 of this step: first read in P1
+        PP_BARRIER(); PP_MFMA(0, 0); PP_BARRIER();
+        // P1: quadrant (0,1)
+        PP_READ_B(1);
+        stage_unit(2, ko, nb);
+        if (!after_epi) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // retires U1 of this step: first read in P2
+        PP_BARRIER(); PP_MFMA(0, 1); PP_BARRIER();
+        // P2: quadrant (1,1)
+        PP_READ_A(1);
+        stage_unit(3, ko, nb);
+        PP_BARRIER(); PP_MFMA(1, 1); PP_BARRIER();
+        // P3: quadrant (1,0)
+        stage_unit(1, ko, nb);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // retires U0,U2 of the next step (and any epilogue stores)
+        PP_BARRIER(); PP_MFMA(1, 0); PP_BARRIER();
+        after_epi = false;
+        if (last_k) {
+            PP_EPILOGUE(sb);
+            t = 0;
+            after_epi = true;
+        } else {
+            ++t;
+        }
+        par ^= 1;
+    }
+    {   // very last step of this workgroup: nothing left to prefetch
+        const char* sb = smem + par * STAGE;
+        const int em0 = cur_m0, en0 = cur_n0;
+        PP_READ_A(0); PP_READ_B(0);
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        PP_BARRIER(); PP_MFMA(0, 0); PP_BARRIER();
+        PP_READ_B(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_BARRIER(); PP_MFMA(0, 1); PP_BARRIER();
+        PP_READ_A(1);
+        PP_BARRIER(); PP_MFMA(1, 1); PP_BARRIER();
+        PP_BARRIER(); PP_MFMA(1, 0);
+        if (grp == 0) PP_BARRIER();  // pairs with group 1's barrier in front of its last MFMA cluster
+        PP_EPILOGUE(sb);
+    }
+#undef PP_EPILOGUE
+#undef PP_BARRIER
+#undef PP_READ_A
+#undef PP_READ_B
+#undef PP_MFMA
+}
+
+template <int EPI>
+hipError_t launch_pp(const GemmParams& p, hipStream_t stream) {
+    auto kern = gemm_pp_kernel<EPI>;
+    constexpr int smem = 2 * 2 * 256 * BK * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int ntm = (p.M + 255) / 256, ntn = (p.N + 255) / 256;
+    int grid = ntm * ntn;
+    if (grid > 256) grid = 256;            // one 512-thread workgroup (128 KiB LDS) per CU, persistent
+    grid = (grid + 7) / 8 * 8;             // whole XCD rounds (surplus workgroups exit at once)
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, stream, p);
+    return hipGetLastError();
 }
 
 template <int BM, int BN, int WM, int WN, int EPI>
@@ -270,11 +681,13 @@ template <int EPI>
 hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
     // 256x256 tiles (8 waves, 1 block/CU) once they fill the chip, else 128x128 (4 waves, 2 blocks/CU)
     const long big = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    if (big >= 200) return launch_cfg<256, 256, 2, 4, EPI>(p, stream);
+    if (big >= 200) return g_gemm_variant == 0 ? launch_cfg<256, 256, 2, 4, EPI>(p, stream) : launch_pp<EPI>(p, stream);
     return launch_cfg<128, 128, 2, 2, EPI>(p, stream);
 }
 
 }  // namespace
+
+void set_gemm_variant(int v) { g_gemm_variant = v; }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.K % BK != 0 || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;

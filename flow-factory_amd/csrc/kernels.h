@@ -38,9 +38,12 @@ struct GemmParams {
     int H, S_pad, s_off; float eps;
     // EPI_UNPATCH
     int hp, wp, patch, out_ch;
+    // optional s_memtime trace (debug): per workgroup, per tile 4 stamps {tile start, main loop start, main loop end, epilogue end}
+    long long* trace;
 };
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);
+void set_gemm_variant(int v);  // tuning / A-B knob: 0 = simple 2-stage 256x256 kernel, 1 = ping-pong (default)
 
 // ------------------------------------------------------------------------------- attention
 // Non-causal softmax(q k^T / 8) v over S keys, head_dim 64.  q,k: [B][H][S_pad][64],

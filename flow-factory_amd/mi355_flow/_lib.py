@@ -54,9 +54,11 @@ SIGNATURES = {
     "mi355_rollout": (_I, [_P, _P, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _I, _F, _P, _I, _I, _P,
                            _P, _P, _P, _P, C.POINTER(C.c_int32), _P, _P, _P, _I]),
     "mi355_op_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I]),
+    "mi355_op_linear_trace": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "mi355_op_attention": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "mi355_op_ln_modulate": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F]),
     "mi355_profile_enable": (_I, [_I]),
+    "mi355_tune_set": (_I, [_I, _I]),
     "mi355_profile_collect": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 

@@ -127,6 +127,10 @@ int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const float* timeste
 /* out[M][N] (bf16, ld = N) = A[M][K] . W[N][K]^T + bias[N] (fp32 bias); act: 0 none, 1 silu, 2 gelu-tanh */
 int mi355_op_linear(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                     int act);
+/* debug: mi355_op_linear (act 0) that also records s_memtime stamps per workgroup / tile / wave-group:
+ * trace[((wg*16 + tile_iter)*2 + group)*4 + {0: tile start, 1: main loop start, 2: main loop end, 3: stores drained}] */
+int mi355_op_linear_trace(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                          void* trace);
 /* q,k : [B][H][S_pad][64] bf16, vT : [B][H][64][S_pad] bf16 -> o_img [B*n_img][H*64], o_ctx [B*(S-n_img)][H*64] */
 int mi355_op_attention(void* stream, const void* q, const void* k, const void* vT, void* o_img, void* o_ctx, int B,
                        int H, int S, int S_pad, int n_img);
@@ -138,6 +142,8 @@ int mi355_op_ln_modulate(void* stream, const void* x, const void* shift, const v
  * enable(1) starts recording every launch of {attention, gemm, ln_modulate, sde_step, misc};
  * collect() waits for the events and returns summed elapsed milliseconds and launch counts (5 each). */
 int mi355_profile_enable(int on);
+/* A/B knob for kernel variants (key 0 = schedule of the 256x256 GEMM: 0 simple 2-stage, 1 ping-pong (default)). */
+int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);
 
 #ifdef __cplusplus
