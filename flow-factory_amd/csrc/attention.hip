@@ -39,7 +39,10 @@ __device__ __forceinline__ int key_perm(int i) {
     return 16 * (a >> 1) + 8 * g + 4 * (a & 1) + b;
 }
 
-__global__ __launch_bounds__(NWAVE * 64) void attn_kernel(AttnParams p) {
+int g_attn_variant = 1;
+
+template <bool V2>
+__global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {  // 4 waves/SIMD = 2 workgroups per CU
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -68,6 +71,17 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_kernel(AttnParams p) {
     bf16x8 qf[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(Qg + (long)q_ld * 64 + kk * 16 + lg * 8);
+    if (V2 && !p.q_prescaled) {
+        // stand-alone use: fold the softmax scale into q here (one extra bf16 rounding of q)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            u32x4 u = __builtin_bit_cast(u32x4, qf[kk]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = pack_bf16(bf_lo(u[e]) * SCALE_LOG2E, bf_hi(u[e]) * SCALE_LOG2E);
+            qf[kk] = __builtin_bit_cast(bf16x8, u);
+        }
+    }
 
     // ---- staging: a tile is 64 rows x 128 B = 8 glds groups; wave w stages group w of K and of V^T
     const int srow = wave * 8 + (lane >> 3);
@@ -94,10 +108,11 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_kernel(AttnParams p) {
 
     f32x16 o[2];
     o[0] = (f32x16){0}; o[1] = (f32x16){0};
-    float m_run = -1e30f, l_run = 0.f;
-
+    float l_run = 0.f;
     const int nt = (p.S + KV - 1) / KV;
     stage(0, 0);
+    if constexpr (!V2) {
+    float m_run = -1e30f;
     for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -173,6 +188,95 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_kernel(AttnParams p) {
         }
     }
 
+    } else {
+    // ---- deferred-rescale online softmax.  q carries 0.125*log2(e); the running max m (log2 domain) enters the
+    // S^T MFMA chain as its C operand (-m in all 16 accumulator registers), so the tile arrives as s - m and
+    // p = exp2(s - m) needs no subtract.  m is only raised when some score exceeds it by more than THR (P <= 2^THR
+    // otherwise, harmless in fp32 accumulators / bf16 P): the 64-multiply rescale of O and the cross-half-wave
+    // max exchange leave the common path, which is 16 MFMA + 16 v_max3 + 32 v_exp + 32 v_add + 16 v_cvt_pk per tile.
+    constexpr float THR = 6.0f;
+    float m_run = 0.f;
+    f32x16 negm = (f32x16){0};
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+        const char* sb = smem + (t & 1) * STAGE_BYTES;
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const bf16x8 kf = *(const bf16x8*)(sb + offK[0] + kb * 4096);
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], negm, 0, 0, 0);
+        }
+#pragma unroll
+        for (int kk = 1; kk < 4; ++kk) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const bf16x8 kf = *(const bf16x8*)(sb + offK[kk] + kb * 4096);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
+            }
+        }
+        if (t == nt - 1) {
+            const int kbase = t * KV + 8 * lg;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kbase + 32 * kb + 16 * (r >> 3) + (r & 7);
+                    if (key >= p.S) s[kb][r] = -1e30f;
+                }
+        }
+        float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[0][r]), s[0][r + 1]);
+        mx = fmaxf(mx, s[0][15]);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[1][r]), s[1][r + 1]);
+        if (t == 0 || __any(mx > THR)) {
+            // (re)centre: both half-waves of a query must agree on m; the first tile also lowers it
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float delta = (t == 0) ? mx : fmaxf(mx, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            m_run += delta;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        float psum = 0.f;
+        unsigned pk[2][8];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(s[kb][r]);
+                const float p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
+                psum += p0 + p1;
+                pk[kb][r >> 1] = pack_bf16(p0, p1);
+            }
+        l_run += psum;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int kb = c >> 1, sh = (c & 1) * 4;
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            const u32x4 uu = {pk[kb][sh + 0], pk[kb][sh + 1], pk[kb][sh + 2], pk[kb][sh + 3]};
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, uu);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const bf16x8 vf = *(const bf16x8*)(sb + offV[c] + db * 4096);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+            }
+        }
+    }
+    }
+
     // ---- finalize: 1/l (both half-wave partial sums), stage O through LDS for full-row stores
     l_run += __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_run;
@@ -209,10 +313,14 @@ __global__ __launch_bounds__(NWAVE * 64) void attn_kernel(AttnParams p) {
 
 }  // namespace
 
+void set_attn_variant(int v) { g_attn_variant = v; }
+int get_attn_variant() { return g_attn_variant; }
+
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.S <= 0 || p.S_pad % KV != 0 || p.S_pad < p.S) return hipErrorInvalidValue;
     dim3 grid(((p.S + QB - 1) / QB) * p.H * p.B);
-    hipLaunchKernelGGL(attn_kernel, grid, dim3(NWAVE * 64), 2 * STAGE_BYTES, stream, p);
+    if (g_attn_variant == 0) hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(NWAVE * 64), 2 * STAGE_BYTES, stream, p);
+    else hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(NWAVE * 64), 2 * STAGE_BYTES, stream, p);
     return hipGetLastError();
 }
 

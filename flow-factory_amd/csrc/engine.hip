@@ -468,6 +468,8 @@ static int qkv_proj(mi355_plan* p, hipStream_t st, const bf16_t* xin, int M, int
     GemmParams g = gp(xin, D, w_qk, D, M, 2 * D, D, EPI_QK_NORM, b_qk, nullptr, 0);
     g.q = q; g.k = k; g.nw_q = nq; g.nw_k = nk; g.H = e->cfg.num_heads; g.S_pad = S_pad; g.s_off = s_off;
     g.rows_per_sample = rps; g.eps = e->cfg.eps;
+    // deferred-rescale attention consumes q with the softmax scale 0.125*log2(e) folded in (same single bf16 rounding)
+    if (get_attn_variant() == 1) g.q_scale = 0.125f * 1.4426950408889634f;
     HIPCHK(gemm_p(g, st));
     GemmParams gv = gp(w_v, D, xin, D, D, M, D, EPI_VT, b_v, nullptr, 0);
     gv.q = vT; gv.H = e->cfg.num_heads; gv.S_pad = S_pad; gv.s_off = s_off; gv.rows_per_sample = rps;
@@ -514,14 +516,14 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
         CHK(qkv_proj(p, st, p->xn, Mi, Ni, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk, p->q, p->k, p->vT, p->S_pad, 0));
         CHK(qkv_proj(p, st, p->cn, Mc, Nt, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck, p->q, p->k, p->vT, p->S_pad, Ni));
         {
-            AttnParams a{p->q, p->k, p->vT, p->o_img, p->o_ctx, p->Bp, H, p->S, p->S_pad, Ni};
+            AttnParams a{p->q, p->k, p->vT, p->o_img, p->o_ctx, p->Bp, H, p->S, p->S_pad, Ni, get_attn_variant() == 1};
             HIPCHK(attn_p(a, st));
         }
         CHK(gate_res(p, st, p->o_img, D, b.w_o, b.b_o, p->x, Mi, Ni, mod, mi + 2 * D));
         if (!b.last) CHK(gate_res(p, st, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
         if (b.dual) {
             CHK(qkv_proj(p, st, p->xn2, Mi, Ni, b.w_qk2, b.b_qk2, b.w_v2, b.b_v2, b.nq2, b.nk2, p->q2, p->k2, p->vT2, Ni_pad, 0));
-            AttnParams a{p->q2, p->k2, p->vT2, p->o_img, p->o_ctx, p->Bp, H, Ni, Ni_pad, Ni};
+            AttnParams a{p->q2, p->k2, p->vT2, p->o_img, p->o_ctx, p->Bp, H, Ni, Ni_pad, Ni, get_attn_variant() == 1};
             HIPCHK(attn_p(a, st));
             CHK(gate_res(p, st, p->o_img, D, b.w_o2, b.b_o2, p->x, Mi, Ni, mod, mi + 8 * D));
         }
@@ -673,6 +675,7 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
 // A/B knob for kernel variants (key 0: GEMM 256x256 schedule, 0 = simple 2-stage, 1 = ping-pong)
 extern "C" int mi355_tune_set(int key, int value) {
     if (key == 0) { set_gemm_variant(value); return 0; }
+    if (key == 1) { set_attn_variant(value); return 0; }
     return fail("mi355_tune_set: unknown key %d", key);
 }
 
@@ -700,7 +703,7 @@ extern "C" int mi355_op_attention(void* stream, const void* q, const void* k, co
                                   int H, int S, int S_pad, int n_img) {
     if (!q || !k || !vT || !o_img) return fail("mi355_op_attention: null argument");
     if (n_img < S && !o_ctx) return fail("mi355_op_attention: o_ctx is NULL but S > n_img");
-    AttnParams a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vT, (bf16_t*)o_img, (bf16_t*)o_ctx, B, H, S, S_pad, n_img};
+    AttnParams a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vT, (bf16_t*)o_img, (bf16_t*)o_ctx, B, H, S, S_pad, n_img, 0};
     HIPCHK(attn_p(a, (hipStream_t)stream));
     return 0;
 }

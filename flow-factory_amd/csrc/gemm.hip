@@ -240,6 +240,7 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
         if constexpr (EPI == EPI_QK_NORM) {
             const bool is_k = n_base >= p.H * 64;
             nw[j] = *(const float4*)((is_k ? p.nw_k : p.nw_q) + j * 16 + 4 * fkg);
+            if (!is_k && p.q_scale != 0.f) { nw[j].x *= p.q_scale; nw[j].y *= p.q_scale; nw[j].z *= p.q_scale; nw[j].w *= p.q_scale; }
         }
     }
 #pragma unroll

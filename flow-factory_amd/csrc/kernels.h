@@ -36,6 +36,7 @@ struct GemmParams {
     bf16_t* q; bf16_t* k;     // q,k: [B][H][S_pad][64];  EPI_VT: q = vT [B][H][64][S_pad]
     const float* nw_q; const float* nw_k;   // RMSNorm weights [64]
     int H, S_pad, s_off; float eps;
+    float q_scale;            // EPI_QK_NORM: extra factor on the normalised q (softmax scale folded in); 0 = 1.0
     // EPI_UNPATCH
     int hp, wp, patch, out_ch;
     // optional s_memtime trace (debug): per workgroup, per tile 4 stamps {tile start, main loop start, main loop end, epilogue end}
@@ -43,7 +44,9 @@ struct GemmParams {
 };
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);
-void set_gemm_variant(int v);  // tuning / A-B knob: 0 = simple 2-stage 256x256 kernel, 1 = ping-pong (default)
+void set_gemm_variant(int v);
+void set_attn_variant(int v);  // 0 = plain online softmax, 1 = deferred-rescale (default)
+int get_attn_variant();  // tuning / A-B knob: 0 = simple 2-stage 256x256 kernel, 1 = ping-pong (default)
 
 // ------------------------------------------------------------------------------- attention
 // Non-causal softmax(q k^T / 8) v over S keys, head_dim 64.  q,k: [B][H][S_pad][64],
@@ -53,6 +56,7 @@ struct AttnParams {
     const bf16_t* q; const bf16_t* k; const bf16_t* vT;
     bf16_t* o_img; bf16_t* o_ctx;
     int B, H, S, S_pad, n_img;
+    int q_prescaled;   // 1: q already carries the softmax scale 0.125*log2(e) (folded into the q RMSNorm epilogue)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 
