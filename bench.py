@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=28)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--kernel-timing", choices=["attention", "all"], default="attention",
+                    help="hipEvent brackets in the timed region: the dominant kernel only (default) or every class")
+    ap.add_argument("--no-graph", action="store_true", help="launch the rollout eagerly instead of replaying the hipGraph")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -150,8 +153,10 @@ def main():
     lib = _lib.load()
     timing = not args.no_kernel_timing
     fence()
+    if args.no_graph:
+        lib.mi355_tune_set(2, 0)
     if timing:
-        lib.mi355_profile_enable(1)
+        lib.mi355_profile_enable(1 if args.kernel_timing == "all" else 2)  # brackets force eager launches
     t0 = time.perf_counter()
     for _ in range(args.steps):
         samples = one_rollout()

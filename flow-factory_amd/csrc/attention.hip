@@ -27,8 +27,6 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int KV = 64;          // keys per tile
 constexpr int QW = 32;          // queries per wave
-constexpr int NWAVE = 8;
-constexpr int QB = QW * NWAVE;  // queries per workgroup
 constexpr int TILE_BYTES = KV * 64 * 2;          // 8 KiB (K tile, and V^T tile)
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // K + V^T
 constexpr float SCALE_LOG2E = 0.125f * 1.4426950408889634f;
@@ -41,8 +39,13 @@ __device__ __forceinline__ int key_perm(int i) {
 
 int g_attn_variant = 1;
 
-template <bool V2>
-__global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {  // 4 waves/SIMD = 2 workgroups per CU
+// NWAVE waves x 32 queries per workgroup; 4 waves per SIMD in every configuration (2 workgroups of 8 waves or 4 of 4).
+// Smaller workgroups mean more independent barrier domains per CU: the per-tile __syncthreads() keeps a workgroup's
+// waves in lockstep (all in their MFMA burst, then all in their softmax), so waves of DIFFERENT workgroups are what
+// overlap the matrix pipe with the VALU.
+template <bool V2, int NWAVE>
+__global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
+    constexpr int QB = QW * NWAVE;  // queries per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -84,14 +87,24 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {  //
     }
 
     // ---- staging: a tile is 64 rows x 128 B = 8 glds groups; wave w stages group w of K and of V^T
-    const int srow = wave * 8 + (lane >> 3);
-    const int sc = (lane & 7) ^ ((srow >> 1) & 7);
-    const bf16_t* srcK = Kg + (long)srow * 64 + sc * 8;          // + tile*64*64
-    const bf16_t* srcV = Vg + (long)srow * p.S_pad + sc * 8;     // + tile*64
+    // a tile is 64 rows x 128 B = 8 glds groups of 8 rows; wave w stages groups w, w + NWAVE, ... of K and of V^T
+    constexpr int NG = 8 / NWAVE;
+    const bf16_t* srcK[NG];
+    const bf16_t* srcV[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int srow = (wave + i * NWAVE) * 8 + (lane >> 3);
+        const int sc = (lane & 7) ^ ((srow >> 1) & 7);
+        srcK[i] = Kg + (long)srow * 64 + sc * 8;          // + tile*64*64
+        srcV[i] = Vg + (long)srow * p.S_pad + sc * 8;     // + tile*64
+    }
     auto stage = [&](int t, int buf) {
-        char* base = smem + buf * STAGE_BYTES + wave * 1024;
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcK + (long)t * KV * 64), (lptr_t)base, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcV + (long)t * KV), (lptr_t)(base + TILE_BYTES), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            char* base = smem + buf * STAGE_BYTES + (wave + i * NWAVE) * 1024;
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcK[i] + (long)t * KV * 64), (lptr_t)base, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcV[i] + (long)t * KV), (lptr_t)(base + TILE_BYTES), 16, 0, 0);
+        }
     };
 
     // ---- fragment read offsets
@@ -311,6 +324,7 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {  //
     }
 }
 
+
 }  // namespace
 
 void set_attn_variant(int v) { g_attn_variant = v; }
@@ -318,9 +332,13 @@ int get_attn_variant() { return g_attn_variant; }
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.S <= 0 || p.S_pad % KV != 0 || p.S_pad < p.S) return hipErrorInvalidValue;
-    dim3 grid(((p.S + QB - 1) / QB) * p.H * p.B);
-    if (g_attn_variant == 0) hipLaunchKernelGGL(attn_kernel<false>, grid, dim3(NWAVE * 64), 2 * STAGE_BYTES, stream, p);
-    else hipLaunchKernelGGL(attn_kernel<true>, grid, dim3(NWAVE * 64), 2 * STAGE_BYTES, stream, p);
+    if (g_attn_variant == 0) {
+        hipLaunchKernelGGL((attn_kernel<false, 8>), dim3(((p.S + 255) / 256) * p.H * p.B), dim3(512), 2 * STAGE_BYTES, stream, p);
+    } else if (g_attn_variant == 1) {
+        hipLaunchKernelGGL((attn_kernel<true, 8>), dim3(((p.S + 255) / 256) * p.H * p.B), dim3(512), 2 * STAGE_BYTES, stream, p);
+    } else {
+        hipLaunchKernelGGL((attn_kernel<true, 4>), dim3(((p.S + 127) / 128) * p.H * p.B), dim3(256), 2 * STAGE_BYTES, stream, p);
+    }
     return hipGetLastError();
 }
 

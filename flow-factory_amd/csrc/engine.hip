@@ -42,6 +42,7 @@ static int fail(const char* fmt, ...) {
 enum ProfClass : int { PC_ATTN = 0, PC_GEMM, PC_LNMOD, PC_SDE, PC_MISC, PC_COUNT };
 struct ProfState {
     bool on = false;
+    int mask = 0;                 // bit c set: bracket launches of class c
     std::vector<hipEvent_t> ev;   // pairs
     std::vector<int> cls;
     size_t used = 0;              // pairs used
@@ -52,7 +53,7 @@ static ProfState g_prof;
 
 struct ProfScope {
     hipStream_t st; size_t idx; bool active;
-    ProfScope(int cls, hipStream_t s) : st(s), idx(0), active(g_prof.on) {
+    ProfScope(int cls, hipStream_t s) : st(s), idx(0), active(g_prof.on && ((g_prof.mask >> cls) & 1)) {
         if (!active) return;
         if (g_prof.used * 2 + 2 > g_prof.ev.size()) {
             for (int i = 0; i < 2; ++i) {
@@ -71,8 +72,11 @@ struct ProfScope {
     }
 };
 
+// on: 0 = off; 1 = every kernel class; otherwise a bit mask of classes (bit 0 attention, 1 gemm, 2 ln_modulate, 3 sde_step)
+// shifted left by one (e.g. 2 = attention only: ~4 k events per rollout instead of ~31 k).
 extern "C" int mi355_profile_enable(int on) {
     g_prof.on = on != 0;
+    g_prof.mask = on == 1 ? 0x1f : (on >> 1);
     g_prof.used = 0;
     for (int i = 0; i < PC_COUNT; ++i) { g_prof.ms[i] = 0; g_prof.count[i] = 0; }
     return 0;
@@ -315,8 +319,17 @@ struct mi355_plan {
     bf16_t *pe, *patches, *x, *c, *c0, *xn, *xn2, *cn, *q, *k, *vT, *q2, *k2, *vT2, *o_img, *o_ctx, *hid, *chid;
     bf16_t *tproj, *h1, *p1, *pemb, *semb, *mod_all, *v;
     float *t_dev, *scal;  // t per (step, sample); scalars [3][max_steps] (sigma, sigma_next, eta)
-    char *lat_a, *lat_b;  // storage-dtype latent ping-pong (fp32-sized)
+    char *lat_a, *lat_b;  // storage-dtype latent ping-pong (single-step entry points)
+    // rollout I/O staging (fixed addresses: the captured hipGraph bakes pointers in)
+    char *io_init, *io_traj;            // init latents (<= fp32), trajectory [max_steps+1][B][n_lat] storage dtype
+    float *io_noise, *io_lp;            // step noise [max_steps][B][n_lat] fp32, log-probs [max_steps][B]
+    bf16_t *io_pe, *io_pp, *io_ne, *io_np;
     std::vector<float> host_t, host_sc;
+    // hipGraph of the whole N-step loop
+    hipGraphExec_t gexec = nullptr;
+    bool warmed = false;
+    int g_steps = -1, g_dyn = -1, g_storage = -1, g_init = -1, g_clp = -1, g_attn = -1, g_gemm = -1;
+    float g_guidance = 0.f, g_sigma_max = 0.f;
 };
 
 extern "C" int mi355_plan_create(mi355_engine* e, int batch, int n_cfg, int latent_h, int latent_w, int n_text,
@@ -362,6 +375,10 @@ extern "C" int mi355_plan_create(mi355_engine* e, int batch, int n_cfg, int late
     size_t o_mod = take(rows_cond * e->mod_cols, 2), o_v = take((int64_t)p->Bp * p->n_lat, 2);
     size_t o_t = take(rows_cond, 4), o_sc = take(3 * (int64_t)max_steps, 4);
     size_t o_la = take((int64_t)p->B * p->n_lat, 4), o_lb = take((int64_t)p->B * p->n_lat, 4);
+    size_t o_ii = take((int64_t)p->B * p->n_lat, 4), o_it = take((int64_t)(max_steps + 1) * p->B * p->n_lat, 4);
+    size_t o_in = take((int64_t)max_steps * p->B * p->n_lat, 4), o_il = take((int64_t)max_steps * p->B, 4);
+    size_t o_ipe = take((int64_t)p->B * p->Nt * e->cfg.joint_attention_dim, 2), o_ipp = take((int64_t)p->B * e->cfg.pooled_projection_dim, 2);
+    size_t o_ine = take((int64_t)p->B * p->Nt * e->cfg.joint_attention_dim, 2), o_inp = take((int64_t)p->B * e->cfg.pooled_projection_dim, 2);
     p->ws_bytes = off;
     if (hipMalloc((void**)&p->ws, off) != hipSuccess) {
         int r = fail("mi355_plan_create: hipMalloc of %zu bytes failed", off);
@@ -387,13 +404,16 @@ extern "C" int mi355_plan_create(mi355_engine* e, int batch, int n_cfg, int late
     p->v = (bf16_t*)(w + o_v);
     p->t_dev = (float*)(w + o_t); p->scal = (float*)(w + o_sc);
     p->lat_a = w + o_la; p->lat_b = w + o_lb;
+    p->io_init = w + o_ii; p->io_traj = w + o_it; p->io_noise = (float*)(w + o_in); p->io_lp = (float*)(w + o_il);
+    p->io_pe = (bf16_t*)(w + o_ipe); p->io_pp = (bf16_t*)(w + o_ipp); p->io_ne = (bf16_t*)(w + o_ine); p->io_np = (bf16_t*)(w + o_inp);
     *out = p;
     return 0;
 }
 
 extern "C" int mi355_plan_destroy(mi355_plan* p) {
     if (!p) return 0;
-    if (p->ws) hipFree(p->ws);
+    if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
+    if (p->ws) (void)hipFree(p->ws);
     delete p;
     return 0;
 }
@@ -469,7 +489,7 @@ static int qkv_proj(mi355_plan* p, hipStream_t st, const bf16_t* xin, int M, int
     g.q = q; g.k = k; g.nw_q = nq; g.nw_k = nk; g.H = e->cfg.num_heads; g.S_pad = S_pad; g.s_off = s_off;
     g.rows_per_sample = rps; g.eps = e->cfg.eps;
     // deferred-rescale attention consumes q with the softmax scale 0.125*log2(e) folded in (same single bf16 rounding)
-    if (get_attn_variant() == 1) g.q_scale = 0.125f * 1.4426950408889634f;
+    if (get_attn_variant() >= 1) g.q_scale = 0.125f * 1.4426950408889634f;
     HIPCHK(gemm_p(g, st));
     GemmParams gv = gp(w_v, D, xin, D, D, M, D, EPI_VT, b_v, nullptr, 0);
     gv.q = vT; gv.H = e->cfg.num_heads; gv.S_pad = S_pad; gv.s_off = s_off; gv.rows_per_sample = rps;
@@ -516,14 +536,14 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
         CHK(qkv_proj(p, st, p->xn, Mi, Ni, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk, p->q, p->k, p->vT, p->S_pad, 0));
         CHK(qkv_proj(p, st, p->cn, Mc, Nt, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck, p->q, p->k, p->vT, p->S_pad, Ni));
         {
-            AttnParams a{p->q, p->k, p->vT, p->o_img, p->o_ctx, p->Bp, H, p->S, p->S_pad, Ni, get_attn_variant() == 1};
+            AttnParams a{p->q, p->k, p->vT, p->o_img, p->o_ctx, p->Bp, H, p->S, p->S_pad, Ni, get_attn_variant() >= 1};
             HIPCHK(attn_p(a, st));
         }
         CHK(gate_res(p, st, p->o_img, D, b.w_o, b.b_o, p->x, Mi, Ni, mod, mi + 2 * D));
         if (!b.last) CHK(gate_res(p, st, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
         if (b.dual) {
             CHK(qkv_proj(p, st, p->xn2, Mi, Ni, b.w_qk2, b.b_qk2, b.w_v2, b.b_v2, b.nq2, b.nk2, p->q2, p->k2, p->vT2, Ni_pad, 0));
-            AttnParams a{p->q2, p->k2, p->vT2, p->o_img, p->o_ctx, p->Bp, H, Ni, Ni_pad, Ni, get_attn_variant() == 1};
+            AttnParams a{p->q2, p->k2, p->vT2, p->o_img, p->o_ctx, p->Bp, H, Ni, Ni_pad, Ni, get_attn_variant() >= 1};
             HIPCHK(attn_p(a, st));
             CHK(gate_res(p, st, p->o_img, D, b.w_o2, b.b_o2, p->x, Mi, Ni, mod, mi + 8 * D));
         }
@@ -613,6 +633,36 @@ extern "C" int mi355_denoise_step(mi355_plan* p, void* stream, const void* laten
 
 static size_t dt_size(int dt) { return dt == MI355_F32 ? 4 : 2; }
 
+static int g_use_graph = 1;
+
+// The whole rollout on plan-owned buffers only (fixed addresses): this is what gets captured.
+static int rollout_body(mi355_plan* p, hipStream_t st, int n_steps, int dynamics, float guidance, int init_dtype,
+                        int storage_dtype, float sigma_max, int compute_log_prob) {
+    const int Bp = p->Bp;
+    if (p->ncfg == 2) CHK(prepare_prompt(p, st, p->io_ne, p->io_np, p->io_pe, p->io_pp));
+    else CHK(prepare_prompt(p, st, p->io_pe, p->io_pp, nullptr, nullptr));
+    CHK(prepare_conditioning(p, st, n_steps, storage_dtype));
+    const size_t esz = storage_dtype == MI355_F32 ? 4 : 2;
+    const size_t lat_bytes = (size_t)p->B * p->n_lat * esz;
+    // cast_latents(init) -> trajectory position 0 (sd3_5.py:266-267)
+    HIPCHK(launch_convert(p->io_init, init_dtype, p->io_traj, storage_dtype, (long)p->B * p->n_lat, st));
+    for (int i = 0; i < n_steps; ++i) {
+        const bf16_t* mod = p->mod_all + (int64_t)i * Bp * p->e->mod_cols;
+        char* cur = p->io_traj + (size_t)i * lat_bytes;
+        char* nxt = p->io_traj + (size_t)(i + 1) * lat_bytes;
+        CHK(forward_core(p, st, cur, storage_dtype, mod, p->v));
+        const bf16_t* vu = p->ncfg == 2 ? p->v : nullptr;
+        const bf16_t* vt = p->ncfg == 2 ? p->v + (int64_t)p->B * p->n_lat : p->v;
+        // the log-prob of a step is only meaningful (and only read) when its noise level is > 0; the kernel
+        // checks eta on the device so that the launch sequence does not depend on which steps are SDE steps
+        CHK(sde_call(st, p->B, p->n_lat, vt, vu, guidance, cur, storage_dtype, p->io_noise + (int64_t)i * p->B * p->n_lat,
+                     nullptr, 0, p->scal + i, p->scal + p->max_steps + i, p->scal + 2 * p->max_steps + i, 0, sigma_max,
+                     dynamics, compute_log_prob ? 2 : 0, nxt, nullptr, nullptr, nullptr,
+                     compute_log_prob ? p->io_lp + (int64_t)i * p->B : nullptr, nullptr, nullptr));
+    }
+    return 0;
+}
+
 extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const float* timesteps_host, const float* sigmas_host,
                              const float* noise_levels_host, int dynamics, float guidance, const void* init_latents,
                              int init_dtype, int storage_dtype, const float* step_noise, const void* prompt_embeds,
@@ -625,10 +675,11 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
     if (storage_dtype < 0 || storage_dtype > 2 || init_dtype < 0 || init_dtype > 2) return fail("mi355_rollout: bad dtype");
     if (p->ncfg == 2 && (!neg_embeds || !neg_pooled)) return fail("mi355_rollout: plan has n_cfg == 2 but no negative prompt embeddings");
     if (!step_noise && dynamics != MI355_ODE) return fail("mi355_rollout: step_noise is NULL");
+    if (dynamics < 0 || dynamics > 3) return fail("mi355_rollout: unknown dynamics %d", dynamics);
     CHK(mi355_engine_weights_ready(p->e));
     hipStream_t st = (hipStream_t)stream;
     const int Bp = p->Bp;
-    // host-side per-step scalars (the reference computes them with .item() syncs inside the loop)
+    // ---- host-side per-step scalars (the reference computes them with .item() syncs inside the loop)
     std::vector<float>& tt = p->host_t;   // plan-owned: must outlive the async H2D copies
     std::vector<float>& sc = p->host_sc;
     tt.assign((size_t)n_steps * Bp, 0.f);
@@ -642,33 +693,76 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
     }
     HIPCHK(hipMemcpyAsync(p->t_dev, tt.data(), tt.size() * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(p->scal, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, st));
-    if (p->ncfg == 2) CHK(prepare_prompt(p, st, neg_embeds, neg_pooled, prompt_embeds, pooled));
-    else CHK(prepare_prompt(p, st, prompt_embeds, pooled, nullptr, nullptr));
-    CHK(prepare_conditioning(p, st, n_steps, storage_dtype));
-    // cast_latents(init) -> storage dtype (sd3_5.py:266-267)
-    const size_t esz = dt_size(storage_dtype);
-    const size_t lat_bytes = (size_t)p->B * p->n_lat * esz;
-    HIPCHK(launch_convert(init_latents, init_dtype, p->lat_a, storage_dtype, (long)p->B * p->n_lat, st));
-    char* cur = p->lat_a;
-    char* nxt = p->lat_b;
-    if (keep_slot_host && keep_slot_host[0] >= 0 && out_latents)
-        HIPCHK(hipMemcpyAsync((char*)out_latents + (size_t)keep_slot_host[0] * lat_bytes, cur, lat_bytes, hipMemcpyDeviceToDevice, st));
-    const float sigma_max = sigmas_host[1];
-    for (int i = 0; i < n_steps; ++i) {
-        const bf16_t* mod = p->mod_all + (int64_t)i * Bp * p->e->mod_cols;
-        CHK(forward_core(p, st, cur, storage_dtype, mod, p->v));
-        const bf16_t* vu = p->ncfg == 2 ? p->v : nullptr;
-        const bf16_t* vt = p->ncfg == 2 ? p->v + (int64_t)p->B * p->n_lat : p->v;
-        const int clp = compute_log_prob && noise_levels_host[i] > 0.f && out_log_probs;
-        CHK(sde_call(st, p->B, p->n_lat, vt, vu, guidance, cur, storage_dtype,
-                     step_noise ? step_noise + (int64_t)i * p->B * p->n_lat : nullptr, nullptr, 0, p->scal + i,
-                     p->scal + p->max_steps + i, p->scal + 2 * p->max_steps + i, 0, sigma_max, dynamics, clp, nxt, nullptr,
-                     nullptr, nullptr, clp ? out_log_probs + (int64_t)i * p->B : nullptr, nullptr, nullptr));
-        if (keep_slot_host && keep_slot_host[i + 1] >= 0 && out_latents)
-            HIPCHK(hipMemcpyAsync((char*)out_latents + (size_t)keep_slot_host[i + 1] * lat_bytes, nxt, lat_bytes, hipMemcpyDeviceToDevice, st));
-        char* tmp = cur; cur = nxt; nxt = tmp;
+    // ---- inputs -> fixed-address staging (device-to-device, enqueued)
+    const int64_t nl = (int64_t)p->B * p->n_lat;
+    const size_t in_esz = init_dtype == MI355_F32 ? 4 : 2;
+    const size_t emb_bytes = (size_t)p->B * p->Nt * p->e->cfg.joint_attention_dim * 2;
+    const size_t pool_bytes = (size_t)p->B * p->e->cfg.pooled_projection_dim * 2;
+    HIPCHK(hipMemcpyAsync(p->io_init, init_latents, nl * in_esz, hipMemcpyDeviceToDevice, st));
+    if (step_noise) HIPCHK(hipMemcpyAsync(p->io_noise, step_noise, (size_t)n_steps * nl * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(p->io_pe, prompt_embeds, emb_bytes, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(p->io_pp, pooled, pool_bytes, hipMemcpyDeviceToDevice, st));
+    if (p->ncfg == 2) {
+        HIPCHK(hipMemcpyAsync(p->io_ne, neg_embeds, emb_bytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(p->io_np, neg_pooled, pool_bytes, hipMemcpyDeviceToDevice, st));
     }
-    if (out_final) HIPCHK(hipMemcpyAsync(out_final, cur, lat_bytes, hipMemcpyDeviceToDevice, st));
+    const float sigma_max = sigmas_host[1];
+    const int clp = compute_log_prob && out_log_probs;
+    // ---- the N-step loop: one hipGraph launch (captured on the second call of a configuration), else eager
+    bool launched = false;
+    if (g_use_graph && !g_prof.on && p->warmed) {
+        const bool same = p->gexec && p->g_steps == n_steps && p->g_dyn == dynamics && p->g_storage == storage_dtype &&
+                          p->g_init == init_dtype && p->g_clp == clp && p->g_guidance == guidance && p->g_sigma_max == sigma_max &&
+                          p->g_attn == get_attn_variant() && p->g_gemm == get_gemm_variant();
+        if (!same) {
+            if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
+            hipGraph_t graph = nullptr;
+            hipError_t ce = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+            if (ce == hipSuccess) {
+                const int rc = rollout_body(p, st, n_steps, dynamics, guidance, init_dtype, storage_dtype, sigma_max, clp);
+                ce = hipStreamEndCapture(st, &graph);
+                if (rc != 0 || ce != hipSuccess || !graph) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    graph = nullptr;
+                }
+            }
+            if (graph) {
+                ce = hipGraphInstantiate(&p->gexec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (ce != hipSuccess) p->gexec = nullptr;
+            }
+            if (p->gexec) {
+                p->g_steps = n_steps; p->g_dyn = dynamics; p->g_storage = storage_dtype; p->g_init = init_dtype; p->g_clp = clp;
+                p->g_guidance = guidance; p->g_sigma_max = sigma_max; p->g_attn = get_attn_variant(); p->g_gemm = get_gemm_variant();
+            } else {
+                (void)hipGetLastError();
+                g_err = "mi355_rollout: hipGraph capture failed, running the launch sequence eagerly";  // same kernels
+            }
+        }
+        if (p->gexec) {
+            HIPCHK(hipGraphLaunch(p->gexec, st));
+            launched = true;
+        }
+    }
+    if (!launched) {
+        CHK(rollout_body(p, st, n_steps, dynamics, guidance, init_dtype, storage_dtype, sigma_max, clp));
+        p->warmed = true;
+    }
+    // ---- outputs: kept trajectory positions, log-probs of the SDE steps, final latents
+    const size_t esz = storage_dtype == MI355_F32 ? 4 : 2;
+    const size_t lat_bytes = (size_t)nl * esz;
+    if (keep_slot_host && out_latents)
+        for (int i = 0; i <= n_steps; ++i)
+            if (keep_slot_host[i] >= 0)
+                HIPCHK(hipMemcpyAsync((char*)out_latents + (size_t)keep_slot_host[i] * lat_bytes, p->io_traj + (size_t)i * lat_bytes,
+                                      lat_bytes, hipMemcpyDeviceToDevice, st));
+    if (clp)
+        for (int i = 0; i < n_steps; ++i)
+            if (noise_levels_host[i] > 0.f)
+                HIPCHK(hipMemcpyAsync(out_log_probs + (int64_t)i * p->B, p->io_lp + (int64_t)i * p->B, (size_t)p->B * 4,
+                                      hipMemcpyDeviceToDevice, st));
+    if (out_final)
+        HIPCHK(hipMemcpyAsync(out_final, p->io_traj + (size_t)n_steps * lat_bytes, lat_bytes, hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
@@ -676,6 +770,7 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
 extern "C" int mi355_tune_set(int key, int value) {
     if (key == 0) { set_gemm_variant(value); return 0; }
     if (key == 1) { set_attn_variant(value); return 0; }
+    if (key == 2) { g_use_graph = value; return 0; }
     return fail("mi355_tune_set: unknown key %d", key);
 }
 

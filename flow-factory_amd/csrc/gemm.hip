@@ -22,7 +22,9 @@ namespace mi355 {
 namespace {
 
 constexpr int BK = 64;
-int g_gemm_variant = 1;  // 0: simple 2-stage kernel, 1: ping-pong schedule (large grids)
+int g_gemm_variant = 1;  // large grids: 0 simple 2-stage kernel, 1 persistent ping-pong kernel
+// (a 32x32x16-MFMA / 2-phases-per-K-tile ping-pong variant was measured 6-10 % SLOWER than the 16x16x32 / 4-phase one
+//  on every shape of this model and was dropped: profiles/r01_gemm_variants.txt)
 
 template <int BM, int BN, int WM, int WN>
 struct Cfg {
@@ -544,10 +546,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
     PP_BARRIER();
     if (grp == 1) PP_BARRIER();  // stagger: group 1 runs one barrier interval behind group 0
 
-    // epilogue staging: 4 KiB per wave in the W half of the stage that was just consumed.  While some wave is
-    // still in its epilogue, the only LDS-DMA that can target that stage is unit U0 of the next-but-one step
-    // (A rows) issued by waves that are already past theirs; W-row units follow a barrier every wave must reach.
-    const int stg_off = A_BYTES + wave * 4096;
+    // epilogue staging: a dedicated 32 KiB behind the 128 KiB operand ring (the CU has 160 KiB): no interplay with the
+    // LDS-DMA prefetches that waves already past their epilogue issue into either ring stage
+    const int stg_off = wave * 4096;
     int cur_m0 = m0, cur_n0 = n0;
     int tile_i = 0, t = 0, par = 0;
     long long* trc = nullptr;
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
         /* epilogue queues stores behind them: the step after an epilogue then needs no wait in P0 / P1.     */  \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
         if (trc) trc[2] = __builtin_amdgcn_s_memtime();                                                          \
-        char* stg = (char*)(SB) + stg_off;                                                                        \
+        char* stg = smem + 2 * STAGE + stg_off; (void)(SB);                                                       \
         const bool full_tile = (em0 + BM <= p.M) && (en0 + BN <= p.N) && ((p.ldo & 7) == 0 || EPI == EPI_QK_NORM || EPI == EPI_VT) && \
                                (EPI != EPI_VT || ((p.rows_per_sample | p.s_off) & 7) == 0);                       \
         _Pragma("unroll") for (int qq = 0; qq < 4; ++qq) {                                                        \
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
 template <int EPI>
 hipError_t launch_pp(const GemmParams& p, hipStream_t stream) {
     auto kern = gemm_pp_kernel<EPI>;
-    constexpr int smem = 2 * 2 * 256 * BK * 2;
+    constexpr int smem = 2 * 2 * 256 * BK * 2 + 8 * 4096;   // operand ring + epilogue staging = 160 KiB
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -689,6 +690,7 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
 }  // namespace
 
 void set_gemm_variant(int v) { g_gemm_variant = v; }
+int get_gemm_variant() { return g_gemm_variant; }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.K % BK != 0 || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;

@@ -64,6 +64,9 @@ __global__ __launch_bounds__(NT) void sde_step_kernel(SdeStepParams p) {
         log_sv = logf(sv);
     }
 
+    // compute_log_prob == 2: only on steps with noise (decided on the device: keeps a captured rollout's launch
+    // sequence independent of which steps the epoch's seed made SDE steps)
+    const bool do_lp = p.compute_log_prob == 1 || (p.compute_log_prob == 2 && eta > 0.f);
     const long base = (long)b * p.n;
     float lp_sum = 0.f;
     for (long i = tid; i < p.n; i += NT) {
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(NT) void sde_step_kernel(SdeStepParams p) {
         if (p.next_f32) p.next_f32[gi] = nxt;
         if (p.mean_out) p.mean_out[gi] = mean;
         if (p.noise_pred_out) p.noise_pred_out[gi] = v;
-        if (p.compute_log_prob) {
+        if (do_lp) {
             const float d = nxt - mean;
             float lp;
             if (dyn == DYN_CPS) lp = -(d * d);
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(NT) void sde_step_kernel(SdeStepParams p) {
             lp_sum += lp;
         }
     }
-    if (p.compute_log_prob && p.log_prob) {
+    if (do_lp && p.log_prob) {
         lp_sum = wave_sum(lp_sum);
         if ((tid & 63) == 0) red[tid >> 6] = lp_sum;
         __syncthreads();

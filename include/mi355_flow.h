@@ -143,7 +143,8 @@ int mi355_op_ln_modulate(void* stream, const void* x, const void* shift, const v
  * collect() waits for the events and returns summed elapsed milliseconds and launch counts (5 each). */
 int mi355_profile_enable(int on);
 /* A/B knob for kernel variants (key 0 = schedule of the 256x256 GEMM: 0 simple 2-stage, 1 ping-pong (default);
- * key 1 = attention softmax: 0 plain online softmax, 1 deferred rescale (default)). */
+ * key 1 = attention softmax: 0 plain online softmax, 1 deferred rescale (default);
+ * key 2 = hipGraph replay of the rollout loop: 0 eager launches, 1 captured graph (default)). */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);
 
