@@ -195,7 +195,7 @@ def main():
         attn_fl, attn_launches = attention_flops(cfg, Ni, N_TEXT)
         fwd_per_timed = n_cfg * N * args.steps  # transformer forwards (batch B each) in the timed region on this rank
         names = ["attention", "gemm", "ln_modulate", "sde_step", "misc"]
-        by_class = {names[i]: {"ms": round(ms[i], 3), "launches": int(cnt[i])} for i in range(5)}
+        by_class = {names[i]: {"ms": round(ms[i], 3), "launches": int(cnt[i])} for i in range(5) if cnt[i] > 0}
         a_ms = ms[0] / max(cnt[0], 1)                       # mean duration of one attention launch
         a_flop = attn_fl * B * n_cfg / attn_launches        # mean algorithmic FLOPs of one attention launch (forward batch B*n_cfg)
         achieved = a_flop / (a_ms * 1e-3) / 1e12 if a_ms > 0 else 0.0
@@ -208,8 +208,8 @@ def main():
             "bound": "mfma", "kernel": "attn_kernel (joint S=4429 x24, dual S=4096 x13 per forward)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
             "traffic": traffic, "flops_per_launch": a_flop, "ms_per_launch": round(a_ms, 4),
-            "gemm": {"achieved": round(gemm_fl / (ms[1] * 1e-3) / 1e12, 1) if ms[1] > 0 else None,
-                     "frac": round(gemm_fl / (ms[1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if ms[1] > 0 else None},
+            **({"gemm": {"achieved": round(gemm_fl / (ms[1] * 1e-3) / 1e12, 1),
+                         "frac": round(gemm_fl / (ms[1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}} if ms[1] > 0 else {}),
             "forward": {"achieved": round(fwd_tflops, 1), "frac": round(fwd_tflops / PEAK_BF16_TFLOPS, 4),
                         "flops_per_forward_per_sample": F, "note": "wall-clock of the whole rollout incl. host glue; north-star target 0.40"},
             "by_class": by_class,

@@ -10,7 +10,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    for key, tag in (("attn_kernel", "attn_kernel"), ("gemm_kernel", None), ("ln_mod_kernel", "ln_mod_kernel"),
+    for key, tag in (("attn_kernel", "attn_kernel"), ("gemm_pp_kernel", None), ("gemm_kernel", None), ("ln_mod_kernel", "ln_mod_kernel"),
                      ("sde_step_kernel", "sde_step_kernel"), ("patchify", "patchify_kernel"), ("time_proj", "time_proj_kernel"),
                      ("convert_kernel", "convert_kernel"), ("pos_crop", "pos_crop_kernel")):
         if key in name:
@@ -18,9 +18,12 @@ def short(name):
                 return tag
             # gemm_kernelILi256ELi256ELi2ELi4ELi5EE -> gemm<256,256,epi5>
             import re
+            epi = ["bias", "bias_silu", "bias_gelu", "posadd", "addsrc_silu", "gate_res", "qk_norm", "vT", "unpatch"]
+            mp = re.search(r"gemm_pp_kernel<(\d+)>", name)
+            if mp:
+                return f"gemm_pp<256x256,{epi[int(mp.group(1))]}>"
             m = re.search(r"gemm_kernelILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d+)EE", name) or \
                 re.search(r"gemm_kernel<(\d+), (\d+), \d+, \d+, (\d+)>", name)
-            epi = ["bias", "bias_silu", "bias_gelu", "posadd", "addsrc_silu", "gate_res", "qk_norm", "vT", "unpatch"]
             return f"gemm<{m.group(1)}x{m.group(2)},{epi[int(m.group(3))]}>" if m else "gemm"
     return name[:60]
 
