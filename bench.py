@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--kernel-timing", choices=["attention", "all"], default="attention",
                     help="hipEvent brackets in the timed region: the dominant kernel only (default) or every class")
+    ap.add_argument("--pp-min-tiles", type=int, default=None, help="(tuning) smallest 256x256-tile grid that uses the ping-pong GEMM")
     ap.add_argument("--no-graph", action="store_true", help="launch the rollout eagerly instead of replaying the hipGraph")
     args = ap.parse_args()
 
@@ -148,13 +149,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    lib = _lib.load()
+    if args.pp_min_tiles is not None:
+        lib.mi355_tune_set(3, args.pp_min_tiles)
     for _ in range(args.warmup):
         samples = one_rollout()
-    lib = _lib.load()
     timing = not args.no_kernel_timing
     fence()
     if args.no_graph:
         lib.mi355_tune_set(2, 0)
+    if args.pp_min_tiles is not None:
+        lib.mi355_tune_set(3, args.pp_min_tiles)
     if timing:
         lib.mi355_profile_enable(1 if args.kernel_timing == "all" else 2)  # brackets force eager launches
     t0 = time.perf_counter()

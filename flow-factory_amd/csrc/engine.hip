@@ -771,6 +771,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 0) { set_gemm_variant(value); return 0; }
     if (key == 1) { set_attn_variant(value); return 0; }
     if (key == 2) { g_use_graph = value; return 0; }
+    if (key == 3) { set_pp_min_tiles(value); return 0; }
     return fail("mi355_tune_set: unknown key %d", key);
 }
 

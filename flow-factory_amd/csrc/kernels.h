@@ -46,6 +46,7 @@ struct GemmParams {
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);
 void set_gemm_variant(int v);
 int get_gemm_variant();
+void set_pp_min_tiles(int v);
 void set_attn_variant(int v);  // 0 = plain online softmax, 1 = deferred-rescale (default)
 int get_attn_variant();  // tuning / A-B knob: 0 = simple 2-stage 256x256 kernel, 1 = ping-pong (default)
 
