@@ -22,7 +22,7 @@ namespace mi355 {
 namespace {
 
 constexpr int BK = 64;
-int g_pp_min_tiles = 128;  // grids with fewer 256x256 tiles use the 128x128 kernel (2 workgroups per CU)
+int g_pp_min_tiles = 128;     // smallest 256x256-tile grid for gemm_pp_kernel
 int g_gemm_variant = 1;  // large grids: 0 simple 2-stage kernel, 1 persistent ping-pong kernel
 // (a 32x32x16-MFMA / 2-phases-per-K-tile ping-pong variant was measured 6-10 % SLOWER than the 16x16x32 / 4-phase one
 //  on every shape of this model and was dropped: profiles/r01_gemm_variants.txt)
@@ -682,9 +682,15 @@ hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
 
 template <int EPI>
 hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
-    // 256x256 tiles (8 waves, 1 block/CU) once they fill the chip, else 128x128 (4 waves, 2 blocks/CU)
+    // grid-size dispatch: 256x256 persistent ping-pong once >= g_pp_min_tiles of its tiles exist (1 workgroup per CU),
+    // else 128x128 tiles with 2 workgroups per CU (a 128x256 ping-pong variant for mid-size grids measured slower than
+    // this on every text-stream / small-batch shape: profiles/r01_gemm_variants.txt)
     const long big = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-    if (big >= g_pp_min_tiles) return g_gemm_variant == 0 ? launch_cfg<256, 256, 2, 4, EPI>(p, stream) : launch_pp<EPI>(p, stream);
+    if (g_gemm_variant == 0) {
+        if (big >= 200) return launch_cfg<256, 256, 2, 4, EPI>(p, stream);
+        return launch_cfg<128, 128, 2, 2, EPI>(p, stream);
+    }
+    if (big >= g_pp_min_tiles) return launch_pp<EPI>(p, stream);
     return launch_cfg<128, 128, 2, 2, EPI>(p, stream);
 }
 
