@@ -3,6 +3,7 @@
 // on the rollout path (the reference syncs 3x per step: flow_match_euler_discrete.py:187-194,:344,
 // models/abc.py:177-181).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -791,6 +792,7 @@ extern "C" int mi355_op_linear_trace(void* stream, const void* A, const void* W,
                                      void* trace) {
     GemmParams g = gp((const bf16_t*)A, K, (const bf16_t*)W, K, M, N, K, EPI_BIAS, bias, (bf16_t*)out, N);
     g.trace = (long long*)trace;
+    g.dbg_skip_prefetch = getenv("MI355_DBG_SKIP_PREFETCH") != nullptr;
     HIPCHK(launch_gemm(g, (hipStream_t)stream));
     return 0;
 }

@@ -488,6 +488,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
             }
     };
     auto stage_unit = [&](int u, long ko, char* base) {
+        if (p.dbg_skip_prefetch && ko != 0) return;   // (ablation only)
         const char* gb = (u < 2 ? (const char*)p.A : (const char*)p.W) + ko * 2;   // uniform
         glds16(gb + soff[u][0], base + ldsoff[u][0]);
         glds16(gb + soff[u][1], base + ldsoff[u][1]);

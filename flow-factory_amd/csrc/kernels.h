@@ -41,6 +41,7 @@ struct GemmParams {
     int hp, wp, patch, out_ch;
     // optional s_memtime trace (debug): per workgroup, per tile 4 stamps {tile start, main loop start, main loop end, epilogue end}
     long long* trace;
+    int dbg_skip_prefetch;    // debug ablation: the K-loop prefetches are not issued (results are garbage)
 };
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);
