@@ -11,14 +11,19 @@
 // -ffp-contract=off, so mean / x' are bit-identical to torch CPU fp32; only the log-prob
 // reduction order (and logf/sinf last-ulp) differs.
 //
-// HBM-bound and tiny (about 4 MB per 1024^2 sample) next to the 11 TFLOP transformer forward, so
-// the launch shape is one 1024-thread workgroup per sample: deterministic reduction, no atomics.
+// HBM-bound (about 4 MB per 1024^2 sample).  Launch shape: NCHUNK workgroups per sample, 4 consecutive elements per
+// thread and iteration (8/16-byte accesses); the log-prob mean is reduced DETERMINISTICALLY: every workgroup writes its
+// partial sum, the last one to arrive (agent-scope ticket) adds the NCHUNK partials in index order, so the replay of a
+// rollout step reproduces the rollout log-prob bit for bit (ratio == 1 invariant).
 #include "kernels.h"
 
 namespace mi355 {
 namespace {
 
-constexpr int NT = 1024;
+constexpr int NT = 256;
+constexpr int NCHUNK = 64;          // workgroups per sample
+constexpr int SCRATCH_SLOTS = 16;   // launches in flight that may share the scratch ring
+constexpr int MAX_B = 4096;
 
 __device__ __forceinline__ float cfg_bf16(float vu, float vt, float g) {
     const float d = round_bf16(vt - vu);
@@ -26,9 +31,27 @@ __device__ __forceinline__ float cfg_bf16(float vu, float vt, float g) {
     return round_bf16(vu + s);
 }
 
-__global__ __launch_bounds__(NT) void sde_step_kernel(SdeStepParams p) {
+__device__ __forceinline__ void load4(const void* p, long i, int dt, float (&o)[4]) {
+    if (dt == DT_F32) { const float4 v = *(const float4*)((const float*)p + i); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+    else if (dt == DT_BF16) { const uint2 v = *(const uint2*)((const bf16_t*)p + i); o[0] = bf_lo(v.x); o[1] = bf_hi(v.x); o[2] = bf_lo(v.y); o[3] = bf_hi(v.y); }
+    else { typedef __attribute__((ext_vector_type(4))) _Float16 h4; const h4 v = *(const h4*)((const _Float16*)p + i);
+           o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3]; }
+}
+__device__ __forceinline__ void store4(void* p, long i, int dt, const float (&v)[4]) {
+    if (dt == DT_F32) *(float4*)((float*)p + i) = make_float4(v[0], v[1], v[2], v[3]);
+    else if (dt == DT_BF16) *(uint2*)((bf16_t*)p + i) = make_uint2(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]));
+    else { typedef __attribute__((ext_vector_type(4))) _Float16 h4; h4 o;
+#pragma unroll
+           for (int e = 0; e < 4; ++e) o[e] = (_Float16)fminf(fmaxf(v[e], -65504.0f), 65504.0f);
+           *(h4*)((_Float16*)p + i) = o; }
+}
+
+// partial[b][chunk] + ticket[b] live in `scratch` (zeroed once; the last workgroup of a sample resets its ticket)
+__global__ __launch_bounds__(NT) void sde_step_kernel(SdeStepParams p, float* partial, unsigned* ticket) {
     __shared__ float red[NT / 64];
-    const int b = blockIdx.x;
+    __shared__ int is_last;
+    const int b = blockIdx.y;
+    const int chunk = blockIdx.x;
     const int tid = threadIdx.x;
     const float sigma = p.sigma[b * p.scalar_stride];
     const float sigma_next = p.sigma_next[b * p.scalar_stride];
@@ -63,74 +86,129 @@ __global__ __launch_bounds__(NT) void sde_step_kernel(SdeStepParams p) {
         den = 2.0f * (sv * sv);
         log_sv = logf(sv);
     }
-
     // compute_log_prob == 2: only on steps with noise (decided on the device: keeps a captured rollout's launch
     // sequence independent of which steps the epoch's seed made SDE steps)
     const bool do_lp = p.compute_log_prob == 1 || (p.compute_log_prob == 2 && eta > 0.f);
+
     const long base = (long)b * p.n;
+    const long per = ((p.n + NCHUNK - 1) / NCHUNK + 3) & ~3L;   // elements per chunk, multiple of 4
+    const long lo = (long)chunk * per;
+    const long hi = lo + per < p.n ? lo + per : p.n;
     float lp_sum = 0.f;
-    for (long i = tid; i < p.n; i += NT) {
+    for (long i = lo + 4 * tid; i < hi; i += 4 * NT) {
         const long gi = base + i;
-        float v = bf2f(p.v_text[gi]);
-        if (p.v_uncond) v = cfg_bf16(bf2f(p.v_uncond[gi]), v, p.guidance);
-        const float x = load_as_f32(p.latents, gi, p.lat_dt);
-        float mean;
-        if (dyn == DYN_ODE) {
-            mean = x + v * dt;
-        } else if (dyn == DYN_FLOW_SDE) {
-            mean = x * c1 + v * c2 * dt;
-        } else if (dyn == DYN_DANCE_SDE) {
-            const float x0 = x - sigma * v;
-            const float log_term = dance_k * (x - x0 * one_m_sigma) / (sigma * sigma);
-            mean = x + (v + log_term) * dt;
+        const int cnt = hi - i >= 4 ? 4 : (int)(hi - i);
+        float v[4], x[4], nz[4] = {0.f, 0.f, 0.f, 0.f}, nin[4], mean[4], nxt[4];
+        if (cnt == 4 && (p.n & 3) == 0) {
+            load4(p.v_text, gi, DT_BF16, v);
+            if (p.v_uncond) {
+                float u[4];
+                load4(p.v_uncond, gi, DT_BF16, u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = cfg_bf16(u[e], v[e], p.guidance);
+            }
+            load4(p.latents, gi, p.lat_dt, x);
+            if (p.next_in) load4(p.next_in, gi, p.next_in_dt, nin);
+            else if (dyn != DYN_ODE) load4(p.noise, gi, DT_F32, nz);
         } else {
-            const float x0 = x - sigma * v;
-            const float x1 = x + v * one_m_sigma;
-            mean = x0 * cps_a + x1 * cps_b;
+            for (int e = 0; e < 4; ++e) {
+                const long g = gi + (e < cnt ? e : 0);
+                v[e] = bf2f(p.v_text[g]);
+                if (p.v_uncond) v[e] = cfg_bf16(bf2f(p.v_uncond[g]), v[e], p.guidance);
+                x[e] = load_as_f32(p.latents, g, p.lat_dt);
+                nin[e] = p.next_in ? load_as_f32(p.next_in, g, p.next_in_dt) : 0.f;
+                nz[e] = (!p.next_in && dyn != DYN_ODE) ? p.noise[g] : 0.f;
+            }
         }
-        float nxt;
-        if (p.next_in) {
-            nxt = load_as_f32(p.next_in, gi, p.next_in_dt);
-        } else if (dyn == DYN_ODE) {
-            nxt = mean;   // reference returns the unrounded mean; cast_latents rounds on store
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (dyn == DYN_ODE) {
+                mean[e] = x[e] + v[e] * dt;
+            } else if (dyn == DYN_FLOW_SDE) {
+                mean[e] = x[e] * c1 + v[e] * c2 * dt;
+            } else if (dyn == DYN_DANCE_SDE) {
+                const float x0 = x[e] - sigma * v[e];
+                const float log_term = dance_k * (x[e] - x0 * one_m_sigma) / (sigma * sigma);
+                mean[e] = x[e] + (v[e] + log_term) * dt;
+            } else {
+                const float x0 = x[e] - sigma * v[e];
+                const float x1 = x[e] + v[e] * one_m_sigma;
+                mean[e] = x0 * cps_a + x1 * cps_b;
+            }
+            if (p.next_in) nxt[e] = nin[e];
+            else if (dyn == DYN_ODE) nxt[e] = mean[e];   // reference returns the unrounded mean; cast_latents rounds on store
+            else nxt[e] = round_to_dtype(mean[e] + sv * nz[e], p.lat_dt);
+            if (do_lp && e < cnt) {
+                const float d = nxt[e] - mean[e];
+                float lp;
+                if (dyn == DYN_CPS) lp = -(d * d);
+                else if (dyn == DYN_ODE) lp = 0.f;
+                else lp = -(d * d) / den - log_sv - LOG_SQRT_2PI;
+                lp_sum += lp;
+            }
+        }
+        if (cnt == 4 && (p.n & 3) == 0) {
+            if (p.next_out) store4(p.next_out, gi, p.next_out_dt, nxt);
+            if (p.next_f32) store4(p.next_f32, gi, DT_F32, nxt);
+            if (p.mean_out) store4(p.mean_out, gi, DT_F32, mean);
+            if (p.noise_pred_out) store4(p.noise_pred_out, gi, DT_F32, v);
         } else {
-            nxt = mean + sv * p.noise[gi];
-            nxt = round_to_dtype(nxt, p.lat_dt);
-        }
-        if (p.next_out) store_from_f32(p.next_out, gi, p.next_out_dt, nxt);
-        if (p.next_f32) p.next_f32[gi] = nxt;
-        if (p.mean_out) p.mean_out[gi] = mean;
-        if (p.noise_pred_out) p.noise_pred_out[gi] = v;
-        if (do_lp) {
-            const float d = nxt - mean;
-            float lp;
-            if (dyn == DYN_CPS) lp = -(d * d);
-            else if (dyn == DYN_ODE) lp = 0.f;
-            else lp = -(d * d) / den - log_sv - LOG_SQRT_2PI;
-            lp_sum += lp;
+            for (int e = 0; e < cnt; ++e) {
+                if (p.next_out) store_from_f32(p.next_out, gi + e, p.next_out_dt, nxt[e]);
+                if (p.next_f32) p.next_f32[gi + e] = nxt[e];
+                if (p.mean_out) p.mean_out[gi + e] = mean[e];
+                if (p.noise_pred_out) p.noise_pred_out[gi + e] = v[e];
+            }
         }
     }
-    if (do_lp && p.log_prob) {
-        lp_sum = wave_sum(lp_sum);
-        if ((tid & 63) == 0) red[tid >> 6] = lp_sum;
-        __syncthreads();
-        if (tid < 64) {
-            float s = tid < NT / 64 ? red[tid] : 0.f;
-            s = wave_sum(s);
-            if (tid == 0) p.log_prob[b] = s / (float)p.n;
-        }
-    }
-    if (tid == 0) {
+    if (chunk == 0 && tid == 0) {
         if (p.std_dev_t) p.std_dev_t[b] = std_dev;
         if (p.dt_out) p.dt_out[b] = dt;
+    }
+    if (!(do_lp && p.log_prob)) return;   // uniform per workgroup
+    lp_sum = wave_sum(lp_sum);
+    if ((tid & 63) == 0) red[tid >> 6] = lp_sum;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) s += red[w];
+        // publish the partial, then take a ticket (agent-scope release / acquire; cdna guide G16 counter form)
+        __hip_atomic_store(partial + (long)b * NCHUNK + chunk, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned tk = __hip_atomic_fetch_add(ticket + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (tk == NCHUNK - 1);
+        if (is_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            float tot = 0.f;
+            for (int c = 0; c < NCHUNK; ++c)
+                tot += __hip_atomic_load(partial + (long)b * NCHUNK + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p.log_prob[b] = tot / (float)p.n;
+            __hip_atomic_store(ticket + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this slot
+        }
     }
 }
 
 }  // namespace
 
+static float* g_scratch = nullptr;      // SCRATCH_SLOTS x (MAX_B*NCHUNK partials + MAX_B tickets)
+static unsigned g_scratch_next = 0;
+
 hipError_t launch_sde_step(const SdeStepParams& p, hipStream_t stream) {
-    if (p.B <= 0 || p.n <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(sde_step_kernel, dim3(p.B), dim3(NT), 0, stream, p);
+    if (p.B <= 0 || p.n <= 0 || p.B > MAX_B) return hipErrorInvalidValue;
+    constexpr size_t slot_words = (size_t)MAX_B * NCHUNK + MAX_B;
+    if (!g_scratch) {
+        // first use (never inside a stream capture: the rollout warms up eagerly before it is captured)
+        hipError_t e = hipMalloc((void**)&g_scratch, SCRATCH_SLOTS * slot_words * 4);
+        if (e != hipSuccess) return e;
+        e = hipMemset(g_scratch, 0, SCRATCH_SLOTS * slot_words * 4);
+        if (e != hipSuccess) return e;
+    }
+    // launches that may overlap (different streams) use different slots; same-stream launches serialise anyway.
+    // A captured graph keeps the slot it was captured with: the tickets are self-resetting.
+    float* slot = g_scratch + (size_t)(g_scratch_next++ % SCRATCH_SLOTS) * slot_words;
+    hipLaunchKernelGGL(sde_step_kernel, dim3(NCHUNK, p.B), dim3(NT), 0, stream, p, slot, (unsigned*)(slot + (size_t)MAX_B * NCHUNK));
     return hipGetLastError();
 }
 
