@@ -320,7 +320,6 @@ struct mi355_plan {
     bf16_t *pe, *patches, *x, *c, *c0, *xn, *xn2, *cn, *q, *k, *vT, *q2, *k2, *vT2, *o_img, *o_ctx, *hid, *chid;
     bf16_t *tproj, *h1, *p1, *pemb, *semb, *mod_all, *v;
     float *t_dev, *scal;  // t per (step, sample); scalars [3][max_steps] (sigma, sigma_next, eta)
-    char *lat_a, *lat_b;  // storage-dtype latent ping-pong (single-step entry points)
     // rollout I/O staging (fixed addresses: the captured hipGraph bakes pointers in)
     char *io_init, *io_traj;            // init latents (<= fp32), trajectory [max_steps+1][B][n_lat] storage dtype
     float *io_noise, *io_lp;            // step noise [max_steps][B][n_lat] fp32, log-probs [max_steps][B]
@@ -375,7 +374,6 @@ extern "C" int mi355_plan_create(mi355_engine* e, int batch, int n_cfg, int late
     size_t o_p1 = take((int64_t)p->Bp * D, 2), o_pemb = take((int64_t)p->Bp * D, 2), o_semb = take(rows_cond * D, 2);
     size_t o_mod = take(rows_cond * e->mod_cols, 2), o_v = take((int64_t)p->Bp * p->n_lat, 2);
     size_t o_t = take(rows_cond, 4), o_sc = take(3 * (int64_t)max_steps, 4);
-    size_t o_la = take((int64_t)p->B * p->n_lat, 4), o_lb = take((int64_t)p->B * p->n_lat, 4);
     size_t o_ii = take((int64_t)p->B * p->n_lat, 4), o_it = take((int64_t)(max_steps + 1) * p->B * p->n_lat, 4);
     size_t o_in = take((int64_t)max_steps * p->B * p->n_lat, 4), o_il = take((int64_t)max_steps * p->B, 4);
     size_t o_ipe = take((int64_t)p->B * p->Nt * e->cfg.joint_attention_dim, 2), o_ipp = take((int64_t)p->B * e->cfg.pooled_projection_dim, 2);
@@ -404,7 +402,6 @@ extern "C" int mi355_plan_create(mi355_engine* e, int batch, int n_cfg, int late
     p->pemb = (bf16_t*)(w + o_pemb); p->semb = (bf16_t*)(w + o_semb); p->mod_all = (bf16_t*)(w + o_mod);
     p->v = (bf16_t*)(w + o_v);
     p->t_dev = (float*)(w + o_t); p->scal = (float*)(w + o_sc);
-    p->lat_a = w + o_la; p->lat_b = w + o_lb;
     p->io_init = w + o_ii; p->io_traj = w + o_it; p->io_noise = (float*)(w + o_in); p->io_lp = (float*)(w + o_il);
     p->io_pe = (bf16_t*)(w + o_ipe); p->io_pp = (bf16_t*)(w + o_ipp); p->io_ne = (bf16_t*)(w + o_ine); p->io_np = (bf16_t*)(w + o_inp);
     *out = p;
@@ -631,8 +628,6 @@ extern "C" int mi355_denoise_step(mi355_plan* p, void* stream, const void* laten
                     next_in_dtype, sigma, sigma_next, eta, scalar_stride, sigma_max, dynamics, compute_log_prob, next_out,
                     next_f32, mean_out, noise_pred_out, log_prob, std_dev_t, dt);
 }
-
-static size_t dt_size(int dt) { return dt == MI355_F32 ? 4 : 2; }
 
 static int g_use_graph = 1;
 

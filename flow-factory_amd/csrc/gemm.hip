@@ -52,95 +52,24 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-// ---- epilogue: called once per (row m, 4 consecutive columns n..n+3) ------------------------
-template <int EPI>
-__device__ __forceinline__ void epi_store(const GemmParams& p, int m, int n, const float (&v)[4], float rstd) {
-    if (m >= p.M) return;
-    if constexpr (EPI == EPI_VT) {
-        // m = feature (row bias), n = token
-        const float b = p.bias[m];
-        const int h = m >> 6, d = m & 63;
-        if (((p.rows_per_sample | p.s_off) & 3) == 0 && n + 3 < p.N) {
-            // 4 consecutive tokens of one sample, 8-byte aligned: one packed store (image stream)
-            const int bi = n / p.rows_per_sample;
-            const int s0 = n - bi * p.rows_per_sample + p.s_off;
-            uint2 o = {pack_bf16(v[0] + b, v[1] + b), pack_bf16(v[2] + b, v[3] + b)};
-            *(uint2*)(p.q + (((long)bi * p.H + h) * 64 + d) * p.S_pad + s0) = o;
-            return;
-        }
+// ---- unpatchify epilogue (proj_out, N = p*p*C = 64): scalar scatter straight from the accumulator layout, called
+// once per (token row m, 4 consecutive feature columns n..n+3); feature f = (pp*patch + qq)*C + c
+__device__ __forceinline__ void unpatch_store(const GemmParams& p, int m, int n, const float (&v)[4]) {
+    if (m >= p.M || n >= p.N) return;
+    const float4 bb = *(const float4*)(p.bias + n);
+    const float y[4] = {v[0] + bb.x, v[1] + bb.y, v[2] + bb.z, v[3] + bb.w};
+    const int tok_per = p.hp * p.wp;
+    const int bi = m / tok_per;
+    const int t = m - bi * tok_per;
+    const int ty = t / p.wp, tx = t - ty * p.wp;
+    const int Himg = p.hp * p.patch, Wimg = p.wp * p.patch;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int tok = n + r;
-            if (tok < p.N) {
-                const int bi = tok / p.rows_per_sample;
-                const int s = tok - bi * p.rows_per_sample + p.s_off;
-                p.q[(((long)bi * p.H + h) * 64 + d) * p.S_pad + s] = f2bf(v[r] + b);
-            }
-        }
-        return;
-    } else {
-        if (n >= p.N) return;  // N % 4 == 0 for all column-bias epilogues
-        const float4 bb = *(const float4*)(p.bias + n);
-        float y[4] = {v[0] + bb.x, v[1] + bb.y, v[2] + bb.z, v[3] + bb.w};
-        if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_SILU || EPI == EPI_BIAS_GELU) {
-            if constexpr (EPI == EPI_BIAS_SILU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = silu_f(round_bf16(y[r]));
-            }
-            if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = gelu_tanh_f(y[r]);
-            }
-            uint2 o = {pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3])};
-            *(uint2*)(p.out + (long)m * p.ldo + n) = o;
-        } else if constexpr (EPI == EPI_POSADD || EPI == EPI_ADDSRC_SILU) {
-            const long arow = (long)(m % p.rows_per_sample);
-            const uint2 a = *(const uint2*)(p.aux + arow * p.ld_aux + n);
-            y[0] += bf_lo(a.x); y[1] += bf_hi(a.x); y[2] += bf_lo(a.y); y[3] += bf_hi(a.y);
-            if constexpr (EPI == EPI_ADDSRC_SILU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[r] = silu_f(round_bf16(y[r]));
-            }
-            uint2 o = {pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3])};
-            *(uint2*)(p.out + (long)m * p.ldo + n) = o;
-        } else if constexpr (EPI == EPI_GATE_RES) {
-            const int bi = m / p.rows_per_sample;
-            const uint2 g = *(const uint2*)(p.aux + (long)bi * p.ld_aux + n);
-            bf16_t* xp = p.out + (long)m * p.ldo + n;
-            const uint2 x = *(const uint2*)xp;
-            y[0] = bf_lo(x.x) + bf_lo(g.x) * y[0];
-            y[1] = bf_hi(x.x) + bf_hi(g.x) * y[1];
-            y[2] = bf_lo(x.y) + bf_lo(g.y) * y[2];
-            y[3] = bf_hi(x.y) + bf_hi(g.y) * y[3];
-            uint2 o = {pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3])};
-            *(uint2*)xp = o;
-        } else if constexpr (EPI == EPI_QK_NORM) {
-            const int D = p.H * 64;
-            const bool is_k = n >= D;
-            const int nn = is_k ? n - D : n;
-            const int h = nn >> 6, d = nn & 63;
-            const float4 w = *(const float4*)((is_k ? p.nw_k : p.nw_q) + d);
-            const int bi = m / p.rows_per_sample;
-            const int s = m - bi * p.rows_per_sample + p.s_off;
-            bf16_t* dst = (is_k ? p.k : p.q) + (((long)bi * p.H + h) * p.S_pad + s) * 64 + d;
-            uint2 o = {pack_bf16(y[0] * rstd * w.x, y[1] * rstd * w.y), pack_bf16(y[2] * rstd * w.z, y[3] * rstd * w.w)};
-            *(uint2*)dst = o;
-        } else if constexpr (EPI == EPI_UNPATCH) {
-            // token m -> (b, py, px); feature n..n+3 -> ((pp*patch + qq)*C + c)
-            const int tok_per = p.hp * p.wp;
-            const int bi = m / tok_per;
-            const int t = m - bi * tok_per;
-            const int ty = t / p.wp, tx = t - ty * p.wp;
-            const int Himg = p.hp * p.patch, Wimg = p.wp * p.patch;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int f = n + r;
-                const int c = f % p.out_ch;
-                const int pq = f / p.out_ch;
-                const int pp = pq / p.patch, qq = pq - pp * p.patch;
-                p.out[(((long)bi * p.out_ch + c) * Himg + ty * p.patch + pp) * Wimg + tx * p.patch + qq] = f2bf(y[r]);
-            }
-        }
+    for (int r = 0; r < 4; ++r) {
+        const int f = n + r;
+        const int c = f % p.out_ch;
+        const int pq = f / p.out_ch;
+        const int pp = pq / p.patch, qq = pq - pp * p.patch;
+        p.out[(((long)bi * p.out_ch + c) * Himg + ty * p.patch + pp) * Wimg + tx * p.patch + qq] = f2bf(y[r]);
     }
 }
 
@@ -401,7 +330,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
 #pragma unroll
             for (int j = 0; j < C::NI; ++j) {
                 const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                epi_store<EPI>(p, mrow + i * 16, ncol + j * 16, v, 1.0f);
+                unpatch_store(p, mrow + i * 16, ncol + j * 16, v);
             }
     } else {
         __syncthreads();  // every wave is done reading the operand ring: reuse it as epilogue staging
@@ -688,10 +617,12 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
     // this on every text-stream / small-batch shape: profiles/r01_gemm_variants.txt)
     const long big = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
     if (g_gemm_variant == 0) {
-        if (big >= 200) return launch_cfg<256, 256, 2, 4, EPI>(p, stream);
+        if (big >= 200 && EPI != EPI_UNPATCH) return launch_cfg<256, 256, 2, 4, EPI>(p, stream);
         return launch_cfg<128, 128, 2, 2, EPI>(p, stream);
     }
-    if (big >= g_pp_min_tiles) return launch_pp<EPI>(p, stream);
+    if constexpr (EPI != EPI_UNPATCH) {   // (proj_out, N = 64: scalar-scatter epilogue, always the 128x128 kernel)
+        if (big >= g_pp_min_tiles) return launch_pp<EPI>(p, stream);
+    }
     return launch_cfg<128, 128, 2, 2, EPI>(p, stream);
 }
 

@@ -65,6 +65,31 @@ def test_forward_tiny_vs_oracle(tiny, B, h, w, Nt, lat_dt):
     assert _rel(y, refq) < 1.5e-2, _rel(y, refq)   # vs oracle with bf16 round-trips at the autocast points
 
 
+def test_forward_large_token_count_dispatch(tiny):
+    """Forward batch 8 at 1024^2 token counts (M = 32768 rows) on the tiny model: every GEMM of the image stream goes
+    through the persistent ping-pong kernel (>= 128 tiles) except proj_out (N = 64, scalar-scatter epilogue)."""
+    from oracle import mmditx_ref as M
+    cfg, engine, e, sd = tiny
+    import copy
+    g = torch.Generator().manual_seed(77)
+    B, h, w, Nt = 8, 128, 128, 21
+    cfg_big = copy.copy(cfg)
+    cfg_big.pos_embed_max_size = 24
+    x = torch.randn(B, 16, 48, 48, generator=g).half()     # 24x24 patches fit pos_embed_max_size 24: Ni = 576
+    enc = torch.randn(B, Nt, cfg.joint_attention_dim, generator=g).bfloat16()
+    pooled = torch.randn(B, cfg.pooled_projection_dim, generator=g).bfloat16()
+    t = torch.full((B,), 700.0)
+    # 64 samples x 576 tokens = 36864 rows >= 128 tiles of 256
+    reps = 8
+    xb, eb, pb = x.repeat(reps, 1, 1, 1), enc.repeat(reps, 1, 1), pooled.repeat(reps, 1)
+    plan = e.plan(B * reps, 1, 48, 48, Nt, 1)
+    y = plan.transformer_forward(xb.cuda(), t.repeat(reps).cuda(), eb.cuda(), pb.cuda())
+    ref = M.mmdit_forward(sd, cfg, x.float(), t, enc.float(), pooled.float())
+    assert _rel(y[:B], ref) < 2e-2
+    for r in range(1, reps):
+        assert torch.equal(y[r * B:(r + 1) * B], y[:B])   # identical samples -> identical results in every tile position
+
+
 def test_forward_cfg_batch_order(tiny):
     """n_cfg == 2: forward batch is [negative, positive] on duplicated latents (sd3_5.py:409-413)."""
     from oracle import mmditx_ref as M
