@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--size", type=int, default=1024)
     ap.add_argument("--denoise-steps", type=int, default=28)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-selfcheck", action="store_true", help="skip the untimed kernel-variant cross-check of one rollout")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--kernel-timing", choices=["attention", "all"], default="attention",
                     help="hipEvent brackets in the timed region: the dominant kernel only (default) or every class")
@@ -154,6 +155,22 @@ def main():
         lib.mi355_tune_set(3, args.pp_min_tiles)
     for _ in range(args.warmup):
         samples = one_rollout()
+    if not args.no_selfcheck:
+        # untimed sanity net: the same seeded rollout through the first-correct-path kernels (simple GEMM schedule,
+        # plain online softmax, eager launches) must reproduce the shipped kernels' trajectory
+        def seeded():
+            torch.cuda.manual_seed(1234 + rank)
+            out = one_rollout()
+            return torch.stack([o.all_latents for o in out]).float(), torch.stack([o.log_probs for o in out])
+        lat_a, lp_a = seeded()
+        for k, v in ((0, 0), (1, 0), (2, 0)):
+            lib.mi355_tune_set(k, v)
+        lat_b, lp_b = seeded()
+        for k, v in ((0, 1), (1, 1), (2, 0 if args.no_graph else 1)):
+            lib.mi355_tune_set(k, v)
+        rel = float((lat_a - lat_b).norm() / lat_b.norm())
+        if not (rel < 2e-2 and torch.allclose(lp_a, lp_b, rtol=1e-3)):
+            raise SystemExit(f"bench selfcheck failed: kernel variants disagree (latents rel-L2 {rel:.3e}, log-probs {lp_a.tolist()} vs {lp_b.tolist()})")
     timing = not args.no_kernel_timing
     fence()
     if args.no_graph:
