@@ -26,6 +26,17 @@ static int fail(const char* fmt, ...) {
     g_err = buf;
     return 1;
 }
+namespace mi355 {
+int errorf(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+}  // namespace mi355
 #define HIPCHK(x)                                                                          \
     do {                                                                                   \
         hipError_t _e = (x);                                                               \
@@ -768,6 +779,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 1) { set_attn_variant(value); return 0; }
     if (key == 2) { g_use_graph = value; return 0; }
     if (key == 3) { set_pp_min_tiles(value); return 0; }
+    if (key == 4) { set_conv_cfg(value); return 0; }
     return fail("mi355_tune_set: unknown key %d", key);
 }
 

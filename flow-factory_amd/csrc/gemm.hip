@@ -142,7 +142,7 @@ __device__ __forceinline__ void store_row8(const GemmParams& p, int m, int n, in
         }
         if (vec) {
             uint4 o;
-            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_SILU || EPI == EPI_BIAS_GELU) o = val;
+            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_SILU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ROW) o = val;
             else o = make_uint4(pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7]));
             *(uint4*)op = o;
         } else {
@@ -166,7 +166,7 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
     for (int j = 0; j < 4; ++j) {
         const int n = n_base + j * 16 + 4 * fkg;
         bcol[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (EPI != EPI_VT) {
+        if constexpr (EPI != EPI_VT && EPI != EPI_BIAS_ROW) {
             if (FULL || n < p.N) bcol[j] = *(const float4*)(p.bias + n);
         }
         if constexpr (EPI == EPI_QK_NORM) {
@@ -180,16 +180,17 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
         const int r = i * 16 + frow;
         float y[4][4];
         float brow = 0.f;
-        if constexpr (EPI == EPI_VT) {
+        constexpr bool ROWB = (EPI == EPI_VT || EPI == EPI_BIAS_ROW);
+        if constexpr (ROWB) {
             const int m = m_base + r;
             brow = p.bias[m < p.M ? m : p.M - 1];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            y[j][0] = acc[i][j][0] + (EPI == EPI_VT ? brow : bcol[j].x);
-            y[j][1] = acc[i][j][1] + (EPI == EPI_VT ? brow : bcol[j].y);
-            y[j][2] = acc[i][j][2] + (EPI == EPI_VT ? brow : bcol[j].z);
-            y[j][3] = acc[i][j][3] + (EPI == EPI_VT ? brow : bcol[j].w);
+            y[j][0] = acc[i][j][0] + (ROWB ? brow : bcol[j].x);
+            y[j][1] = acc[i][j][1] + (ROWB ? brow : bcol[j].y);
+            y[j][2] = acc[i][j][2] + (ROWB ? brow : bcol[j].z);
+            y[j][3] = acc[i][j][3] + (ROWB ? brow : bcol[j].w);
         }
         if constexpr (EPI == EPI_QK_NORM) {
             float ss = 0.f;
@@ -232,7 +233,7 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, bool CONV = false>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
     using C = Cfg<BM, BN, WM, WN>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -257,13 +258,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
     const int srow = lane >> 3, spc = lane & 7;
     const bf16_t* srcA[C::GA];
     const bf16_t* srcW[C::GW];
+    int cy[C::GA], cx[C::GA];                             // CONV: output pixel of the row; srcA = sample base + chunk
 #pragma unroll
     for (int i = 0; i < C::GA; ++i) {
         const int row = (wave + i * C::NW) * 8 + srow;   // row inside the A tile
         const int c = spc ^ ((row >> 1) & 7);             // logical chunk stored at physical chunk spc
         int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;  // clamp: rows beyond M are never stored
-        srcA[i] = p.A + (long)gm * p.lda + c * 8;
+        if constexpr (CONV) {
+            const int hw = p.conv_h * p.conv_w;
+            const int bi = gm / hw, pix = gm - bi * hw;
+            cy[i] = pix / p.conv_w; cx[i] = pix - cy[i] * p.conv_w;
+            srcA[i] = p.A + (long)bi * ((hw >> (2 * p.conv_up)) * (long)p.conv_cin) + c * 8;
+        } else {
+            srcA[i] = p.A + (long)gm * p.lda + c * 8;
+        }
     }
+    const bf16_t* zsrc = nullptr;
+    if constexpr (CONV) zsrc = p.zero_page + spc * 8;
 #pragma unroll
     for (int i = 0; i < C::GW; ++i) {
         const int row = (wave + i * C::NW) * 8 + srow;
@@ -275,8 +286,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
     auto stage = [&](int kt, int buf) {
         char* base = smem + buf * C::STAGE;
         const long ko = (long)kt * BK;
+        if constexpr (CONV) {
+            // K-tile kt lies inside one tap (conv_cin % 64 == 0): gather the shifted pixel's channels, zeros outside
+            const int k0 = kt * BK;
+            const int tap = k0 / p.conv_cin, c0 = k0 - tap * p.conv_cin;
+            const int ky = tap / 3, dy = ky - 1, dx = tap - ky * 3 - 1;
+            const int win = p.conv_w >> p.conv_up;
 #pragma unroll
-        for (int i = 0; i < C::GA; ++i) glds16(srcA[i] + ko, base + (wave + i * C::NW) * 1024);
+            for (int i = 0; i < C::GA; ++i) {
+                const int yy = cy[i] + dy, xx = cx[i] + dx;
+                const bool ok = (unsigned)yy < (unsigned)p.conv_h && (unsigned)xx < (unsigned)p.conv_w;
+                const bf16_t* src = srcA[i] + ((long)((yy >> p.conv_up) * win + (xx >> p.conv_up)) * p.conv_cin + c0);
+                glds16(ok ? src : zsrc, base + (wave + i * C::NW) * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < C::GA; ++i) glds16(srcA[i] + ko, base + (wave + i * C::NW) * 1024);
+        }
 #pragma unroll
         for (int i = 0; i < C::GW; ++i) glds16(srcW[i] + ko, base + C::A_BYTES + (wave + i * C::NW) * 1024);
     };
@@ -321,7 +347,39 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
     }
 
     // ---- epilogue
-    if constexpr (EPI == EPI_UNPATCH) {
+    if constexpr (EPI == EPI_F32 || EPI == EPI_IMG) {
+        // straight from the accumulator layout: fp32 scores (16 B per lane) / the <= 4 image channels of conv_out
+        const int mrow = m0 + wm * C::TM + frow;
+        const int ncol = n0 + wn * C::TN + 4 * fkg;
+#pragma unroll
+        for (int i = 0; i < C::MI; ++i)
+#pragma unroll
+            for (int j = 0; j < C::NI; ++j) {
+                const int m = mrow + i * 16, n = ncol + j * 16;
+                if (m >= p.M || n >= p.N) continue;
+                if constexpr (EPI == EPI_F32) {
+                    const float sc = p.q_scale;
+                    float* op = p.out_f32 + (long)m * p.ldo + n;
+                    if (n + 4 <= p.N && (p.ldo & 3) == 0) {
+                        *(float4*)op = make_float4(acc[i][j][0] * sc, acc[i][j][1] * sc, acc[i][j][2] * sc, acc[i][j][3] * sc);
+                    } else {
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < p.N) op[e] = acc[i][j][e] * sc;
+                    }
+                } else {
+                    const int hw = p.conv_h * p.conv_w;
+                    const int bi = m / hw, pix = m - bi * hw;
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e >= p.N) break;
+                        // bf16 VAE semantics: the conv output and the denormalised image are each rounded to bf16
+                        float y = round_bf16(acc[i][j][e] + p.bias[n + e]);
+                        if (p.img_post) y = fminf(fmaxf(round_bf16(y * 0.5f + 0.5f), 0.f), 1.f);
+                        const long o = ((long)bi * p.N + n + e) * hw + pix;
+                        if (p.out_f32) p.out_f32[o] = y; else p.out[o] = f2bf(y);
+                    }
+                }
+            }
+    } else if constexpr (EPI == EPI_UNPATCH) {
         // tiny N (64): scalar scatter straight from the accumulator layout
         const int mrow = m0 + wm * C::TM + frow;
         const int ncol = n0 + wn * C::TN + 4 * fkg;
@@ -594,10 +652,10 @@ hipError_t launch_pp(const GemmParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, bool CONV = false>
 hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
     using C = Cfg<BM, BN, WM, WN>;
-    auto kern = gemm_kernel<BM, BN, WM, WN, EPI>;
+    auto kern = gemm_kernel<BM, BN, WM, WN, EPI, CONV>;
     constexpr int smem = 2 * C::STAGE;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
@@ -626,14 +684,40 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
     return launch_cfg<128, 128, 2, 2, EPI>(p, stream);
 }
 
+// VAE decode shapes (simple 2-stage kernel; CONV = implicit 3x3 gather on the A operand)
+int g_conv_cfg = 0;   // A/B knob: 0 auto, 1 force 128x128, 2 force 256x128, 3 force 256x256
+template <int EPI, bool CONV>
+hipError_t launch_simple(const GemmParams& p, hipStream_t stream) {
+    int cfg = g_conv_cfg;
+    if (cfg == 0) {
+        const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+        cfg = (p.N >= 256 && t256 >= 128) ? 3 : (p.N >= 128 && (long)((p.M + 255) / 256) * ((p.N + 127) / 128) >= 256) ? 2 : 1;
+    }
+    if (cfg == 3) return launch_cfg<256, 256, 2, 4, EPI, CONV>(p, stream);
+    if (cfg == 2) return launch_cfg<256, 128, 4, 2, EPI, CONV>(p, stream);
+    return launch_cfg<128, 128, 2, 2, EPI, CONV>(p, stream);
+}
+
 }  // namespace
 
+void set_conv_cfg(int v) { g_conv_cfg = v; }
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 void set_pp_min_tiles(int v) { g_pp_min_tiles = v; }
 int get_gemm_variant() { return g_gemm_variant; }
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
     if (p.K % BK != 0 || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;
+    if (p.conv_cin > 0) {
+        if (p.conv_cin % BK != 0 || p.K != 9 * p.conv_cin || !p.zero_page || p.M % (p.conv_h * p.conv_w) != 0 ||
+            (p.conv_up && ((p.conv_h | p.conv_w) & 1)))
+            return hipErrorInvalidValue;
+        switch (p.epi) {
+            case EPI_BIAS: return launch_simple<EPI_BIAS, true>(p, stream);
+            case EPI_POSADD: return launch_simple<EPI_POSADD, true>(p, stream);
+            case EPI_IMG: return p.N <= 4 ? launch_cfg<128, 128, 2, 2, EPI_IMG, true>(p, stream) : hipErrorInvalidValue;
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (p.epi) {
         case EPI_BIAS: return launch_epi<EPI_BIAS>(p, stream);
         case EPI_BIAS_SILU: return launch_epi<EPI_BIAS_SILU>(p, stream);
@@ -644,6 +728,8 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
         case EPI_QK_NORM: return launch_epi<EPI_QK_NORM>(p, stream);
         case EPI_VT: return launch_epi<EPI_VT>(p, stream);
         case EPI_UNPATCH: return launch_epi<EPI_UNPATCH>(p, stream);
+        case EPI_BIAS_ROW: return launch_simple<EPI_BIAS_ROW, false>(p, stream);
+        case EPI_F32: return launch_simple<EPI_F32, false>(p, stream);
         default: return hipErrorInvalidValue;
     }
 }

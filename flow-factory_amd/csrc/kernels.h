@@ -20,6 +20,10 @@ enum GemmEpi : int {
     EPI_QK_NORM,        // per-head RMSNorm of (acc + bias) then scatter to q/k [b][h][s][64]
     EPI_VT,             // rows = features, cols = tokens: vT[b][h][d][s] = bf16(acc + bias[m])
     EPI_UNPATCH,        // proj_out: scatter (token, (p,q,c)) -> latent [b][c][y][x] (bf16)
+    // ---- VAE decode (vae_engine.hip); these three always run on the simple 2-stage kernel
+    EPI_BIAS_ROW,       // out[m][n] = bf16(acc + bias[m])              (row-major; swapped-operand V^T of the mid attention)
+    EPI_F32,            // out_f32[m][n] = acc * q_scale                (attention scores, no bias)
+    EPI_IMG,            // conv_out: image[b][n][y][x] = post(acc + bias[n]), n < N <= 4, fp32 or bf16 NCHW
     EPI_COUNT
 };
 
@@ -39,6 +43,14 @@ struct GemmParams {
     float q_scale;            // EPI_QK_NORM: extra factor on the normalised q (softmax scale folded in); 0 = 1.0
     // EPI_UNPATCH
     int hp, wp, patch, out_ch;
+    // EPI_F32 / EPI_IMG
+    float* out_f32;           // EPI_F32 target; EPI_IMG: fp32 image (or nullptr -> bf16 image in `out`)
+    int img_post;             // EPI_IMG: 1 = (x/2 + 0.5).clamp(0,1)
+    // implicit 3x3 convolution, padding 1 (conv_cin > 0): A is an NHWC activation tensor [B][Hin][Win][conv_cin], row m of the
+    // GEMM is output pixel (b, y, x) of a conv_h x conv_w image, K = 9*conv_cin with k = tap*conv_cin + c (tap = ky*3 + kx);
+    // conv_up = 1: the input is (conv_h/2) x (conv_w/2) and is nearest-2x upsampled on the fly (Upsample2D + conv)
+    int conv_cin, conv_h, conv_w, conv_up;
+    const bf16_t* zero_page;  // >= 128 B of zeros: source of the padding taps
     // optional s_memtime trace (debug): per workgroup, per tile 4 stamps {tile start, main loop start, main loop end, epilogue end}
     long long* trace;
     int dbg_skip_prefetch;    // debug ablation: the K-loop prefetches are not issued (results are garbage)
@@ -48,6 +60,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);
 void set_gemm_variant(int v);
 int get_gemm_variant();
 void set_pp_min_tiles(int v);
+void set_conv_cfg(int v);       // VAE conv tile shape A/B knob (0 auto)
 void set_attn_variant(int v);  // 0 = plain online softmax, 1 = deferred-rescale (default)
 int get_attn_variant();  // tuning / A-B knob: 0 = simple 2-stage 256x256 kernel, 1 = ping-pong (default)
 
@@ -85,6 +98,22 @@ hipError_t launch_pos_crop(const bf16_t* pos, bf16_t* out, int max_size, int hp,
 hipError_t launch_time_proj(const float* t, int rows, int dim, int t_round_dt, bf16_t* out, hipStream_t stream);
 // generic dtype conversion (weights binding); n elements
 hipError_t launch_convert(const void* src, int src_dt, void* dst, int dst_dt, long n, hipStream_t stream);
+
+// ------------------------------------------------------------------------------ VAE decode (vae.hip)
+// latents [B][C][HW] (storage dtype) -> NHWC bf16 [B*HW][Cpad] = bf16(lat / scale + shift), channels >= C zero
+hipError_t launch_vae_ingest(const void* lat, int dt, bf16_t* out, int B, int C, int Cpad, long HW, float scale, float shift,
+                             hipStream_t st);
+// GroupNorm over NHWC bf16 [B][HW][C] (+ optional SiLU) -> y (may alias x).  part: >= B*gn_num_chunks*C*2 floats of scratch,
+// ad: B*2*C floats of scratch (per-channel affine).  Deterministic (fixed-order partial sums).
+int gn_num_chunks(long HW, int C);
+hipError_t launch_group_norm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, float* part, float* ad, int B, long HW,
+                             int C, int groups, float eps, bool silu, hipStream_t st);
+// p[r][:] = softmax(scale * s[r][:]) for `rows` rows of n fp32 scores (n % 4 == 0), bf16 out
+hipError_t launch_softmax_rows(const float* s, bf16_t* p, long rows, int n, float scale, hipStream_t st);
+// conv weight [Co][Ci][taps] (any dtype) -> bf16 [Co][taps][Cpad] (k = tap*Cpad + ci; ci >= Ci zero); taps = 1 for 1x1 / linear
+hipError_t launch_conv_repack(const void* src, int dt, bf16_t* dst, int Co, int Ci, int Cpad, int taps, hipStream_t st);
+// shared error sink of the C ABI (engine.hip): formats into mi355_last_error(), returns 1
+int errorf(const char* fmt, ...);
 
 // --------------------------------------------------------------------------- SDE step (K15)
 enum Dynamics : int { DYN_ODE = 0, DYN_FLOW_SDE = 1, DYN_DANCE_SDE = 2, DYN_CPS = 3 };

@@ -1,0 +1,212 @@
+// mi355_flow -- HBM-bound kernels of the VAE decode: NHWC activations, bf16.
+//   * latent ingest: NCHW storage dtype -> NHWC bf16 (channels zero-padded to 64), z / scaling + shift fused
+//   * GroupNorm(+SiLU): two deterministic reduction passes (per-chunk channel partials -> per-(sample, channel) affine)
+//     and one apply pass; every pass reads / writes whole 16-byte channel vectors of consecutive pixels (full lines)
+//   * row softmax of the mid-block attention scores (fp32 in, bf16 probabilities out)
+//   * conv / linear weight repack at bind time ([Co][Ci][kh][kw] -> [Co][tap][Ci_pad], K-contiguous for the implicit GEMM)
+#include "kernels.h"
+
+namespace mi355 {
+
+namespace {
+
+// ------------------------------------------------------------------------------------ ingest
+__global__ __launch_bounds__(256) void vae_ingest_kernel(const void* lat, int dt, bf16_t* out, int C, int Cpad, long HW,
+                                                         float scale, float shift) {
+    // one thread per (pixel, 8-channel chunk); grid.y = sample
+    const long b = blockIdx.y;
+    const int chunks = Cpad / 8;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= HW * chunks) return;
+    const long pix = idx / chunks;
+    const int c0 = (int)(idx - pix * chunks) * 8;
+    float y[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int c = c0 + e;
+        y[e] = c < C ? load_as_f32(lat, (b * C + c) * HW + pix, dt) / scale + shift : 0.f;
+    }
+    *(uint4*)(out + (b * HW + pix) * Cpad + c0) =
+        make_uint4(pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7]));
+}
+
+// --------------------------------------------------------------------------------- GroupNorm
+// pass 1: part[b][chunk][c][2] = (sum, sum of squares) of channel c over the chunk's pixels
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* x, float* part, long HW, int C, long rows_per_chunk) {
+    __shared__ float red[256 * 16];
+    const int lpr = C >> 3;                  // lanes per pixel row (C <= 2048)
+    const int rpi = 256 / lpr;               // pixel rows per iteration
+    const int slot = threadIdx.x % lpr, r0 = threadIdx.x / lpr;
+    const long b = blockIdx.y, chunk = blockIdx.x;
+    const long lo = chunk * rows_per_chunk;
+    long hi = lo + rows_per_chunk; hi = hi < HW ? hi : HW;
+    float s[8], ss[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+    if (r0 < rpi) {
+        const bf16_t* base = x + b * HW * C + slot * 8;
+        for (long r = lo + r0; r < hi; r += rpi) {
+            const uint4 v = *(const uint4*)(base + r * C);
+            const float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[threadIdx.x * 16 + e] = s[e]; red[threadIdx.x * 16 + 8 + e] = ss[e]; }
+    __syncthreads();
+    // fixed-order sum over the rpi row-lanes of each (channel, stat): deterministic
+    float* dst = part + (b * gridDim.x + chunk) * (long)C * 2;
+    for (int o = threadIdx.x; o < C * 2; o += 256) {
+        const int c = o >> 1, st = o & 1;
+        const int sl = c >> 3, e = c & 7;
+        float a = 0.f;
+        for (int r = 0; r < rpi; ++r) a += red[(r * lpr + sl) * 16 + st * 8 + e];
+        dst[o] = a;
+    }
+}
+
+// pass 2: one wave per (sample, group): mean / rstd in double, then the per-channel affine a = rstd*gamma, d = beta - mean*a
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* part, int nchunk, int C, int groups, long HW, float eps,
+                                                         const float* gamma, const float* beta, float* ad /*[B][2][C]*/) {
+    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int cpg = C / groups;
+    double s = 0.0, ss = 0.0;
+    const int n = nchunk * cpg;
+    for (int i = lane; i < n; i += 64) {
+        const int chunk = i / cpg, c = g * cpg + (i - chunk * cpg);
+        const float* p = part + (((long)b * nchunk + chunk) * C + c) * 2;
+        s += (double)p[0]; ss += (double)p[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+    const double cnt = (double)HW * cpg;
+    const double mean = s / cnt;
+    double var = ss / cnt - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+        const float a = rstd * gamma[c];
+        ad[((long)b * 2 + 0) * C + c] = a;
+        ad[((long)b * 2 + 1) * C + c] = beta[c] - (float)mean * a;
+    }
+}
+
+// pass 3: y = x*a + d, optional SiLU, bf16
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x, bf16_t* y, const float* ad, long HW, int C, long rows_per_chunk) {
+    const int lpr = C >> 3, rpi = 256 / lpr;
+    const int slot = threadIdx.x % lpr, r0 = threadIdx.x / lpr;
+    if (r0 >= rpi) return;
+    const long b = blockIdx.y, chunk = blockIdx.x;
+    const long lo = chunk * rows_per_chunk;
+    long hi = lo + rows_per_chunk; hi = hi < HW ? hi : HW;
+    float a[8], d[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = ad[(b * 2 + 0) * C + slot * 8 + e]; d[e] = ad[(b * 2 + 1) * C + slot * 8 + e]; }
+    const long off = b * HW * C + slot * 8;
+    for (long r = lo + r0; r < hi; r += rpi) {
+        const uint4 v = *(const uint4*)(x + off + r * C);
+        float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            f[e] = f[e] * a[e] + d[e];
+            if (SILU) f[e] = silu_f(f[e]);
+        }
+        *(uint4*)(y + off + r * C) = make_uint4(pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3]), pack_bf16(f[4], f[5]), pack_bf16(f[6], f[7]));
+    }
+}
+
+// --------------------------------------------------------------------------------- softmax
+// one workgroup per row: p[row][:] = softmax(scale * s[row][:]) (bf16).  n % 4 == 0.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, bf16_t* p, int n, float scale_log2e) {
+    __shared__ float red[8];
+    const long row = blockIdx.x;
+    const float4* src = (const float4*)(s + row * n);
+    const int n4 = n >> 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = src[i];
+        m = fmaxf(fmaxf(fmaxf(m, v.x), fmaxf(v.y, v.z)), v.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float mb = m * scale_log2e;
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = src[i];
+        sum += exp2f(v.x * scale_log2e - mb) + exp2f(v.y * scale_log2e - mb) + exp2f(v.z * scale_log2e - mb) + exp2f(v.w * scale_log2e - mb);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    uint2* dst = (uint2*)(p + row * n);
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = src[i];
+        dst[i] = make_uint2(pack_bf16(exp2f(v.x * scale_log2e - mb) * inv, exp2f(v.y * scale_log2e - mb) * inv),
+                            pack_bf16(exp2f(v.z * scale_log2e - mb) * inv, exp2f(v.w * scale_log2e - mb) * inv));
+    }
+}
+
+// ------------------------------------------------------------------------------ weight repack
+__global__ __launch_bounds__(256) void conv_repack_kernel(const void* src, int dt, bf16_t* dst, int Co, int Ci, int Cpad, int taps) {
+    const long n = (long)Co * taps * Cpad;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int ci = (int)(i % Cpad);
+    const long t = i / Cpad;
+    const int tap = (int)(t % taps), co = (int)(t / taps);
+    dst[i] = ci < Ci ? f2bf(load_as_f32(src, ((long)co * Ci + ci) * taps + tap, dt)) : f2bf(0.f);
+}
+
+}  // namespace
+
+hipError_t launch_vae_ingest(const void* lat, int dt, bf16_t* out, int B, int C, int Cpad, long HW, float scale, float shift,
+                             hipStream_t st) {
+    const long n = HW * (Cpad / 8);
+    hipLaunchKernelGGL(vae_ingest_kernel, dim3((unsigned)((n + 255) / 256), B), dim3(256), 0, st, lat, dt, out, C, Cpad, HW, scale, shift);
+    return hipGetLastError();
+}
+
+int gn_num_chunks(long HW, int C) {
+    // ~1 MiB of activations per workgroup, at most 1024 chunks per sample (the partial buffer is sized for that)
+    const int rpi = 256 / (C >> 3);
+    long rows = (1L << 20) / (C * 2);
+    rows = (rows + rpi - 1) / rpi * rpi;
+    long n = (HW + rows - 1) / rows;
+    if (n > 1024) n = 1024;
+    return (int)n;
+}
+
+hipError_t launch_group_norm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, float* part, float* ad, int B, long HW,
+                             int C, int groups, float eps, bool silu, hipStream_t st) {
+    if (C % 8 || C > 2048 || 256 % (C >> 3) || C % groups) return hipErrorInvalidValue;
+    const int nchunk = gn_num_chunks(HW, C);
+    const int rpi = 256 / (C >> 3);
+    long rpc = (HW + nchunk - 1) / nchunk;
+    rpc = (rpc + rpi - 1) / rpi * rpi;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, part, HW, C, rpc);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, st, part, nchunk, C, groups, HW, eps, gamma, beta, ad);
+    if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nchunk, B), dim3(256), 0, st, x, y, ad, HW, C, rpc);
+    else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nchunk, B), dim3(256), 0, st, x, y, ad, HW, C, rpc);
+    return hipGetLastError();
+}
+
+hipError_t launch_softmax_rows(const float* s, bf16_t* p, long rows, int n, float scale, hipStream_t st) {
+    if (n % 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, s, p, n, scale * 1.44269504088896340736f);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_repack(const void* src, int dt, bf16_t* dst, int Co, int Ci, int Cpad, int taps, hipStream_t st) {
+    const long n = (long)Co * taps * Cpad;
+    hipLaunchKernelGGL(conv_repack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dt, dst, Co, Ci, Cpad, taps);
+    return hipGetLastError();
+}
+
+}  // namespace mi355

@@ -28,6 +28,14 @@ class ModelCfg(C.Structure):
     ]
 
 
+class VaeCfg(C.Structure):
+    _fields_ = [
+        ("latent_channels", C.c_int32), ("out_channels", C.c_int32), ("num_blocks", C.c_int32),
+        ("layers_per_block", C.c_int32), ("norm_num_groups", C.c_int32), ("block_out_channels", C.c_int32 * 8),
+        ("eps", C.c_float), ("scaling_factor", C.c_float), ("shift_factor", C.c_float),
+    ]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -57,6 +65,19 @@ SIGNATURES = {
     "mi355_op_linear_trace": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "mi355_op_attention": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "mi355_op_ln_modulate": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F]),
+    "mi355_vae_create": (_I, [C.POINTER(VaeCfg), C.POINTER(_P)]),
+    "mi355_vae_destroy": (_I, [_P]),
+    "mi355_vae_bind_weight": (_I, [_P, C.c_char_p, _P, _I, _I, C.POINTER(_L), _P]),
+    "mi355_vae_weights_ready": (_I, [_P]),
+    "mi355_vae_num_params": (_I, [_P]),
+    "mi355_vae_param_name": (C.c_char_p, [_P, _I]),
+    "mi355_vae_plan_create": (_I, [_P, _I, _I, _I, C.POINTER(_P)]),
+    "mi355_vae_plan_destroy": (_I, [_P]),
+    "mi355_vae_plan_workspace_bytes": (_L, [_P]),
+    "mi355_vae_decode": (_I, [_P, _P, _P, _I, _I, _P, _I, _I]),
+    "mi355_op_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
+    "mi355_op_conv_repack": (_I, [_P, _P, _I, _P, _I, _I, _I, _I]),
+    "mi355_op_group_norm": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _I]),
     "mi355_profile_enable": (_I, [_I]),
     "mi355_tune_set": (_I, [_I, _I]),
     "mi355_profile_collect": (_I, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

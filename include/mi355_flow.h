@@ -138,13 +138,56 @@ int mi355_op_attention(void* stream, const void* q, const void* k, const void* v
 int mi355_op_ln_modulate(void* stream, const void* x, const void* shift, const void* scale, void* out, int M, int D,
                          int rows_per_sample, float eps);
 
+/* ---- VAE decode ----------------------------------------------
+ * Replaces `pipeline.vae.decode(latents / scaling_factor + shift_factor)` + `image_processor.postprocess(.., 'pt')`
+ * of SD3_5Adapter.decode_latents (reference src/flow_factory/models/stable_diffusion/sd3_5.py:161-172); the decoder is
+ * diffusers' AutoencoderKL (HF state-dict names `decoder.*`).  Weights are bound like the transformer's: any of
+ * fp32 / bf16 / fp16 device tensors in torch layout ([Co][Ci][3][3] convs, [out][in] linears), repacked on bind. */
+typedef struct mi355_vae mi355_vae;
+typedef struct mi355_vae_plan mi355_vae_plan;
+typedef struct mi355_vae_cfg {
+    int32_t latent_channels, out_channels;
+    int32_t num_blocks, layers_per_block, norm_num_groups;
+    int32_t block_out_channels[8];   /* encoder order, as in the HF config (decoder walks it reversed) */
+    float eps, scaling_factor, shift_factor;
+} mi355_vae_cfg;
+int mi355_vae_create(const mi355_vae_cfg* cfg, mi355_vae** out);
+int mi355_vae_destroy(mi355_vae* vae);
+int mi355_vae_bind_weight(mi355_vae* vae, const char* name, const void* src, int dtype, int ndim, const int64_t* shape,
+                          void* stream);
+int mi355_vae_weights_ready(mi355_vae* vae);
+int mi355_vae_num_params(mi355_vae* vae);
+const char* mi355_vae_param_name(mi355_vae* vae, int i);
+/* workspace for up to max_batch images decoded from latent_h x latent_w latents (latent_h*latent_w % 64 == 0) */
+int mi355_vae_plan_create(mi355_vae* vae, int max_batch, int latent_h, int latent_w, mi355_vae_plan** out);
+int mi355_vae_plan_destroy(mi355_vae_plan* plan);
+int64_t mi355_vae_plan_workspace_bytes(mi355_vae_plan* plan);
+/* latents [batch][latent_channels][h][w] (lat_dtype) -> images [batch][out_channels][8h][8w] (img_dtype: 0 fp32, 1 bf16;
+ * values are bf16-representable either way: the reference decodes in the VAE's bf16);
+ * postprocess = 1 applies (x/2 + 0.5).clamp(0, 1).  Enqueues on `stream`, never synchronises. */
+int mi355_vae_decode(mi355_vae_plan* plan, void* stream, const void* latents, int lat_dtype, int batch, void* images,
+                     int img_dtype, int postprocess);
+
+/* VAE operator-level entry points (unit tests / microbenchmarks).  NHWC bf16 activations.
+ * conv3x3: x [B][H>>up][W>>up][Cin] (Cin % 64 == 0), w_packed [Cout][9][Cin] bf16 (mi355_op_conv_repack), padding 1,
+ * optional nearest-2x upsample of x folded in, optional residual [B*H*W][Cout] added (may alias out) -> out [B*H*W][Cout] */
+int mi355_op_conv3x3(void* stream, const void* x, const void* w_packed, const float* bias, const void* residual, void* out,
+                     int B, int H, int W, int Cin, int Cout, int upsample);
+/* torch conv weight [Cout][Cin][taps] (dtype) -> bf16 [Cout][taps][Cin_pad] */
+int mi355_op_conv_repack(void* stream, const void* w, int dtype, void* w_packed, int Cout, int Cin, int Cin_pad, int taps);
+/* GroupNorm (+SiLU) over x [B][HW][C] bf16; scratch: >= B*(2048*C + 2*C) floats */
+int mi355_op_group_norm(void* stream, const void* x, const float* gamma, const float* beta, void* out, float* scratch,
+                        int B, int64_t HW, int C, int groups, float eps, int silu);
+
 /* ---- measurement: hipEvent brackets per kernel class, recorded on the launch stream ---------
  * enable(1) starts recording every launch of {attention, gemm, ln_modulate, sde_step, misc};
  * collect() waits for the events and returns summed elapsed milliseconds and launch counts (5 each). */
 int mi355_profile_enable(int on);
 /* A/B knob for kernel variants (key 0 = schedule of the 256x256 GEMM: 0 simple 2-stage, 1 ping-pong (default);
  * key 1 = attention softmax: 0 plain online softmax, 1 deferred rescale (default);
- * key 2 = hipGraph replay of the rollout loop: 0 eager launches, 1 captured graph (default)). */
+ * key 2 = hipGraph replay of the rollout loop: 0 eager launches, 1 captured graph (default);
+ * key 3 = smallest 256x256-tile grid that takes the ping-pong kernel (default 128);
+ * key 4 = VAE conv tile shape: 0 auto (default), 1 128x128, 2 256x128, 3 256x256). */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);
 

@@ -12,23 +12,27 @@ out = sys.argv[1]
 def short(name):
     for key, tag in (("attn_kernel", "attn_kernel"), ("gemm_pp_kernel", None), ("gemm_kernel", None), ("ln_mod_kernel", "ln_mod_kernel"),
                      ("sde_step_kernel", "sde_step_kernel"), ("patchify", "patchify_kernel"), ("time_proj", "time_proj_kernel"),
-                     ("convert_kernel", "convert_kernel"), ("pos_crop", "pos_crop_kernel")):
+                     ("convert_kernel", "convert_kernel"), ("pos_crop", "pos_crop_kernel"), ("gn_partial", "gn_partial_kernel"),
+                     ("gn_finalize", "gn_finalize_kernel"), ("gn_apply", "gn_apply_kernel"), ("softmax_rows", "softmax_rows_kernel"),
+                     ("vae_ingest", "vae_ingest_kernel"), ("conv_repack", "conv_repack_kernel")):
         if key in name:
             if tag:
                 return tag
             # gemm_kernelILi256ELi256ELi2ELi4ELi5EE -> gemm<256,256,epi5>
             import re
-            epi = ["bias", "bias_silu", "bias_gelu", "posadd", "addsrc_silu", "gate_res", "qk_norm", "vT", "unpatch"]
+            epi = ["bias", "bias_silu", "bias_gelu", "posadd", "addsrc_silu", "gate_res", "qk_norm", "vT", "unpatch", "bias_row",
+                   "f32", "img"]
             mp = re.search(r"gemm_pp_kernel<(\d+)>", name)
             if mp:
                 return f"gemm_pp<256x256,{epi[int(mp.group(1))]}>"
-            m = re.search(r"gemm_kernelILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d+)EE", name) or \
-                re.search(r"gemm_kernel<(\d+), (\d+), \d+, \d+, (\d+)>", name)
-            return f"gemm<{m.group(1)}x{m.group(2)},{epi[int(m.group(3))]}>" if m else "gemm"
+            m = re.search(r"gemm_kernelILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d+)E", name) or \
+                re.search(r"gemm_kernel<(\d+), (\d+), \d+, \d+, (\d+)", name)
+            conv = "conv" if ("true>" in name or "ELb1EE" in name) else "gemm"
+            return f"{conv}<{m.group(1)}x{m.group(2)},{epi[int(m.group(3))]}>" if m else "gemm"
     return name[:60]
 
 
-stats = glob.glob(os.path.join(out, "prof_stats", "**", "*kernel_stats*.csv"), recursive=True)
+stats = glob.glob(os.path.join(out, "**", "*kernel_stats*.csv"), recursive=True)
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     print("== rocprofv3 --kernel-trace --stats (bench.py --steps 1 --warmup 1):", os.path.basename(stats[0]))
