@@ -685,14 +685,17 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
 }
 
 // VAE decode shapes (simple 2-stage kernel; CONV = implicit 3x3 gather on the A operand)
-int g_conv_cfg = 0;   // A/B knob: 0 auto, 1 force 128x128, 2 force 256x128, 3 force 256x256
+int g_conv_cfg = 0;   // A/B knob: 0 auto, 1 force 128x128, 2 force 256x128, 3 force 256x256, 4 force 512x128
 template <int EPI, bool CONV>
 hipError_t launch_simple(const GemmParams& p, hipStream_t stream) {
     int cfg = g_conv_cfg;
     if (cfg == 0) {
         const long t256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
-        cfg = (p.N >= 256 && t256 >= 128) ? 3 : (p.N >= 128 && (long)((p.M + 255) / 256) * ((p.N + 127) / 128) >= 256) ? 2 : 1;
+        // N = 128 (the full-resolution convolutions): a 512x128 tile gives every wave the 128x64 sub-tile of the 256x256
+        // kernel (LDS bytes per MFMA halve against 256x128's 64x64 sub-tiles, which are LDS-read bound)
+        cfg = (p.N >= 256 && t256 >= 128) ? 3 : (p.N >= 128 && (long)((p.M + 511) / 512) * ((p.N + 127) / 128) >= 256) ? 4 : 1;
     }
+    if (cfg == 4) return launch_cfg<512, 128, 4, 2, EPI, CONV>(p, stream);
     if (cfg == 3) return launch_cfg<256, 256, 2, 4, EPI, CONV>(p, stream);
     if (cfg == 2) return launch_cfg<256, 128, 4, 2, EPI, CONV>(p, stream);
     return launch_cfg<128, 128, 2, 2, EPI, CONV>(p, stream);

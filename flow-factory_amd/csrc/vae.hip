@@ -45,12 +45,21 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* x, float*
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
     if (r0 < rpi) {
         const bf16_t* base = x + b * HW * C + slot * 8;
-        for (long r = lo + r0; r < hi; r += rpi) {
-            const uint4 v = *(const uint4*)(base + r * C);
+        auto acc8 = [&](const uint4 v) {
             const float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
 #pragma unroll
             for (int e = 0; e < 8; ++e) { s[e] += f[e]; ss[e] += f[e] * f[e]; }
+        };
+        long r = lo + r0;
+        // 4 independent 16-byte loads in flight per lane (the row order of the sums is unchanged)
+        for (; r + 3L * rpi < hi; r += 4L * rpi) {
+            const uint4 v0 = *(const uint4*)(base + r * C);
+            const uint4 v1 = *(const uint4*)(base + (r + rpi) * C);
+            const uint4 v2 = *(const uint4*)(base + (r + 2L * rpi) * C);
+            const uint4 v3 = *(const uint4*)(base + (r + 3L * rpi) * C);
+            acc8(v0); acc8(v1); acc8(v2); acc8(v3);
         }
+        for (; r < hi; r += rpi) acc8(*(const uint4*)(base + r * C));
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) { red[threadIdx.x * 16 + e] = s[e]; red[threadIdx.x * 16 + 8 + e] = ss[e]; }
@@ -105,16 +114,27 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x, bf16_t* 
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a[e] = ad[(b * 2 + 0) * C + slot * 8 + e]; d[e] = ad[(b * 2 + 1) * C + slot * 8 + e]; }
     const long off = b * HW * C + slot * 8;
-    for (long r = lo + r0; r < hi; r += rpi) {
-        const uint4 v = *(const uint4*)(x + off + r * C);
+    auto one = [&](const uint4 v) -> uint4 {
         float f[8] = {bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y), bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w)};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             f[e] = f[e] * a[e] + d[e];
             if (SILU) f[e] = silu_f(f[e]);
         }
-        *(uint4*)(y + off + r * C) = make_uint4(pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3]), pack_bf16(f[4], f[5]), pack_bf16(f[6], f[7]));
+        return make_uint4(pack_bf16(f[0], f[1]), pack_bf16(f[2], f[3]), pack_bf16(f[4], f[5]), pack_bf16(f[6], f[7]));
+    };
+    long r = lo + r0;
+    for (; r + 3L * rpi < hi; r += 4L * rpi) {
+        const uint4 v0 = *(const uint4*)(x + off + r * C);
+        const uint4 v1 = *(const uint4*)(x + off + (r + rpi) * C);
+        const uint4 v2 = *(const uint4*)(x + off + (r + 2L * rpi) * C);
+        const uint4 v3 = *(const uint4*)(x + off + (r + 3L * rpi) * C);
+        *(uint4*)(y + off + r * C) = one(v0);
+        *(uint4*)(y + off + (r + rpi) * C) = one(v1);
+        *(uint4*)(y + off + (r + 2L * rpi) * C) = one(v2);
+        *(uint4*)(y + off + (r + 3L * rpi) * C) = one(v3);
     }
+    for (; r < hi; r += rpi) *(uint4*)(y + off + r * C) = one(*(const uint4*)(x + off + r * C));
 }
 
 // --------------------------------------------------------------------------------- softmax
@@ -174,9 +194,10 @@ hipError_t launch_vae_ingest(const void* lat, int dt, bf16_t* out, int B, int C,
 }
 
 int gn_num_chunks(long HW, int C) {
-    // ~1 MiB of activations per workgroup, at most 1024 chunks per sample (the partial buffer is sized for that)
+    // ~128 KiB of activations per workgroup (>= 8 workgroups per CU once a sample exceeds ~256 MiB / B), at most 1024 chunks
+    // per sample (the partial buffer is sized for that)
     const int rpi = 256 / (C >> 3);
-    long rows = (1L << 20) / (C * 2);
+    long rows = (1L << 17) / (C * 2);
     rows = (rows + rpi - 1) / rpi * rpi;
     long n = (HW + rows - 1) / rows;
     if (n > 1024) n = 1024;

@@ -273,7 +273,8 @@ class SD3_5NativeAdapter(NativeRolloutMixin):
     def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[TransformerConfig] = None,
                  scheduler: Optional[FlowMatchEulerDiscreteSDEScheduler] = None, latent_storage_dtype: Optional[str] = "fp16",
                  transformer_dtype: torch.dtype = torch.bfloat16, device: Union[str, torch.device] = "cuda",
-                 vae_decode: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
+                 vae_decode: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+                 vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, vae_config=None, vae_max_batch: int = 4):
         if not torch.cuda.is_available():
             raise RuntimeError("mi355_flow: no GPU visible; the native rollout engine has no CPU path")
         self.device = torch.device(device)
@@ -283,6 +284,13 @@ class SD3_5NativeAdapter(NativeRolloutMixin):
         self.engine = Engine(config or TransformerConfig())
         self.refresh_weights(state_dict)
         self._vae_decode = vae_decode
+        self.vae_decoder = None
+        self.vae_max_batch = vae_max_batch
+        if vae_state_dict is not None:
+            from .vae import VAEConfig, VAEDecoder
+            self.vae_decoder = VAEDecoder(vae_config or VAEConfig())
+            self.vae_decoder.bind_state_dict(vae_state_dict)
+            self.vae_decoder.ready()
 
     @property
     def latent_storage_dtype(self) -> Optional[torch.dtype]:
@@ -308,7 +316,13 @@ class SD3_5NativeAdapter(NativeRolloutMixin):
                            "(the Flow-Factory plugin inherits encode_prompt from SD3_5Adapter)")
 
     def decode_latents(self, latents: torch.Tensor, output_type: str = "pt"):
-        """VAE decode is outside the first bar: delegated to an attached decoder."""
-        if self._vae_decode is None:
+        """sd3_5.py:161-172.  With `vae_state_dict` the native decoder (mi355_vae_*) produces the 'pt' images; a custom
+        `vae_decode` callable takes precedence; with neither the samples carry no image."""
+        if self._vae_decode is not None:
+            return self._vae_decode(latents)
+        if self.vae_decoder is None:
             return None
-        return self._vae_decode(latents)
+        if output_type not in ("pt", "np"):
+            raise ValueError("mi355_flow standalone adapter decodes to 'pt' or 'np' (PIL conversion lives in the pipeline's image_processor)")
+        img = self.vae_decoder.decode(latents, postprocess=True, out_dtype=torch.bfloat16, max_batch=self.vae_max_batch)
+        return img if output_type == "pt" else img.float().permute(0, 2, 3, 1).cpu().numpy()

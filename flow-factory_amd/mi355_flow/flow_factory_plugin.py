@@ -21,6 +21,7 @@ except Exception as e:  # noqa: BLE001
 
 from .adapter import NativeRolloutMixin
 from .engine import Engine, TransformerConfig
+from .vae import VAEConfig, VAEDecoder
 
 if _RefAdapter is not None:  # pragma: no cover
 
@@ -37,6 +38,10 @@ if _RefAdapter is not None:  # pragma: no cover
                 pos_embed_max_size=tc.pos_embed_max_size, dual_layers=tuple(tc.dual_attention_layers)))
             self._bound_version = -1
             self._weights_version = 0
+            # the VAE is frozen (`_freeze_vae`, models/abc.py): bind its decoder once
+            self.vae_decoder = VAEDecoder(VAEConfig.from_hf(self.pipeline.vae.config))
+            self.vae_decoder.bind_state_dict(self.pipeline.vae.state_dict())
+            self.vae_decoder.ready()
 
         # the engine computes in bf16 like the reference's autocast run
         @property
@@ -58,6 +63,14 @@ if _RefAdapter is not None:  # pragma: no cover
         def eval(self, *a, **k):
             self._weights_version += 1
             return _RefAdapter.eval(self, *a, **k)
+
+        @torch.no_grad()
+        def decode_latents(self, latents, output_type="pil"):
+            # sd3_5.py:161-172 with vae.decode on the native decoder; 'pt' is what the rollout asks for (sd3_5.py:307)
+            if output_type == "pt":
+                return self.vae_decoder.decode(latents, postprocess=True, out_dtype=torch.bfloat16)
+            images = self.vae_decoder.decode(latents, postprocess=False, out_dtype=torch.bfloat16)
+            return self.pipeline.image_processor.postprocess(images, output_type=output_type)
 
         @torch.no_grad()
         def inference(self, *args, **kwargs):

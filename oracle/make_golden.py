@@ -251,6 +251,17 @@ def gen_mmdit_tiny():
                         log_probs=_np(ro["log_probs"]), noise_levels=_np(nl))
 
 
+def gen_vae_tiny():
+    """[SELF] VAE decoder restatement (parity unpinned, oracle/vae_ref.py): drift guard only."""
+    from oracle import vae_ref
+    cfg = vae_ref.tiny_config()
+    sd = vae_ref.make_synthetic_state_dict(cfg, seed=99)
+    z = torch.randn(1, 16, 4, 4, generator=torch.Generator().manual_seed(98))
+    raw = vae_ref.vae_decode(sd, cfg, z, postprocess=False)
+    img = vae_ref.vae_decode(sd, cfg, z, quant=lambda t: t.bfloat16().float(), postprocess=True)
+    np.savez_compressed(os.path.join(OUT, "vae_tiny_self.npz"), raw=_np(raw), img_bf16=_np(img))
+
+
 # ------------------------------------------------------------------ [REF] group-contiguous sampler (DP partitioner)
 def gen_sampler():
     import importlib.util
@@ -283,6 +294,7 @@ def main():
     gen_collectors(ns)
     gen_advantages()
     gen_mmdit_tiny()
+    gen_vae_tiny()
     gen_sampler()
     print(f"wrote fixtures to {OUT} ({n} scheduler step cases)")
 

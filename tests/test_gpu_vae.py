@@ -26,6 +26,7 @@ def vae_mod():
     (1, 10, 6, 64, 3, False, False),         # tiny N, ragged M
     (4, 128, 128, 128, 128, False, True),    # 256x128 tiles
     (2, 128, 128, 64, 256, False, False),    # 256x256 tiles
+    (2, 256, 256, 128, 128, False, False),   # 512x128 tiles (the full-resolution layers)
 ])
 def test_conv3x3_matches_torch(vae_mod, B, H, W, Cin, Cout, up, res):
     g = torch.Generator().manual_seed(B * 1000 + H + Cin + Cout)
@@ -142,3 +143,36 @@ def test_decode_errors(vae_mod):
     with pytest.raises(ValueError):
         dec.decode(torch.zeros(1, 16, 8, 8))      # CPU tensor: no fallback
     dec.close()
+
+
+def test_adapter_inference_attaches_native_images(vae_mod):
+    """`inference()` ends with decode_latents(final latents, 'pt') (sd3_5.py:307): with a bound VAE the samples carry images."""
+    from oracle import mmditx_ref as M, vae_ref
+    from mi355_flow.adapter import SD3_5NativeAdapter
+    from mi355_flow.engine import TransformerConfig
+    cfg_o = M.tiny_config(num_layers=2, num_heads=2, dual_layers=(0,), joint_attention_dim=128, pooled_projection_dim=128,
+                          pos_embed_max_size=24)
+    sd = M.make_synthetic_state_dict(cfg_o, seed=5, std=0.05)
+    tc = TransformerConfig(num_layers=2, num_heads=2, joint_attention_dim=128, pooled_projection_dim=128, pos_embed_max_size=24,
+                           dual_layers=(0,))
+    vcfg_o = vae_ref.tiny_config()
+    vsd = vae_ref.make_synthetic_state_dict(vcfg_o, 21)
+    vcfg = vae_mod.VAEConfig(block_out_channels=tuple(vcfg_o.block_out_channels), layers_per_block=vcfg_o.layers_per_block)
+    ad = SD3_5NativeAdapter({k: v.cuda() for k, v in sd.items()}, tc, vae_state_dict={k: v.cuda() for k, v in vsd.items()},
+                            vae_config=vcfg)
+    ad.rollout()
+    g = torch.Generator().manual_seed(3)
+    B = 2
+    pe = torch.randn(B, 7, 128, generator=g).bfloat16().cuda()
+    pp = torch.randn(B, 128, generator=g).bfloat16().cuda()
+    samples = ad.inference(prompt=["a", "b"], height=64, width=64, num_inference_steps=3, guidance_scale=1.0,
+                           prompt_embeds=pe, pooled_prompt_embeds=pp, trajectory_indices="all")
+    assert len(samples) == B
+    for s in samples:
+        assert s.image is not None and tuple(s.image.shape) == (3, 64, 64) and s.image.dtype == torch.bfloat16
+        assert 0.0 <= s.image.float().min().item() and s.image.float().max().item() <= 1.0
+    final = torch.stack([s.all_latents[-1] for s in samples])
+    ref = vae_ref.vae_decode(vsd, vcfg_o, final.float().cpu(), quant=_bf, postprocess=True)
+    got = torch.stack([s.image for s in samples]).float().cpu()
+    assert (got - ref).abs().mean().item() < 1e-2
+    ad.engine.close()

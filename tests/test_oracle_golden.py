@@ -109,6 +109,30 @@ def test_mmdit_oracle_self_consistency():
     assert (y - y2).abs().max() > 1e-3
 
 
+def test_vae_oracle_self_consistency():
+    """[SELF] fixture for the (unpinned) AutoencoderKL decoder restatement + architecture facts that are public:
+    the SD3 decoder has 49.5 M parameters in 138 tensors and costs ~10.5 TFLOP per 1024^2 image."""
+    from oracle import vae_ref
+    z = _load("vae_tiny_self.npz")
+    cfg = vae_ref.tiny_config()
+    sd = vae_ref.make_synthetic_state_dict(cfg, seed=99)
+    lat = torch.randn(1, 16, 4, 4, generator=torch.Generator().manual_seed(98))
+    raw = vae_ref.vae_decode(sd, cfg, lat, postprocess=False)
+    assert raw.shape == (1, 3, 32, 32)
+    np.testing.assert_allclose(raw.numpy(), z["raw"], rtol=1e-4, atol=1e-5)
+    img = vae_ref.vae_decode(sd, cfg, lat, quant=lambda t: t.bfloat16().float(), postprocess=True)
+    assert np.abs(img.numpy() - z["img_bf16"]).max() <= 2 ** -7   # one bf16 ulp below 1.0
+    assert img.min() >= 0 and img.max() <= 1
+    shapes = vae_ref.state_dict_shapes(vae_ref.SD3_VAE)
+    assert len(shapes) == 138
+    assert abs(sum(int(np.prod(s)) for s in shapes.values()) / 49.545e6 - 1) < 1e-3
+    assert abs(vae_ref.decode_flops(vae_ref.SD3_VAE, 128, 128) / 1.047e13 - 1) < 2e-3
+    # every layer matters: zeroing a late conv changes the image
+    sd2 = dict(sd)
+    sd2["decoder.up_blocks.3.resnets.1.conv2.weight"] = sd["decoder.up_blocks.3.resnets.1.conv2.weight"] * 0
+    assert (vae_ref.vae_decode(sd2, cfg, lat, postprocess=False) - raw).abs().max() > 1e-3
+
+
 def test_flops_formula():
     # SURVEY.md 8(d): F(4096,333) = 1.125e13, F(256,333) = 9.09e11
     assert abs(mmditx_ref.forward_flops(mmditx_ref.SD35_MEDIUM, 4096, 333) / 1.125e13 - 1) < 2e-3
