@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--kernel-timing", choices=["attention", "all"], default="attention",
                     help="hipEvent brackets in the timed region: the dominant kernel only (default) or every class")
     ap.add_argument("--pp-min-tiles", type=int, default=None, help="(tuning) smallest 256x256-tile grid that uses the ping-pong GEMM")
+    ap.add_argument("--no-vae", action="store_true", help="skip the (untimed w.r.t. `value`) VAE-decode leg")
     ap.add_argument("--no-graph", action="store_true", help="launch the rollout eagerly instead of replaying the hipGraph")
     args = ap.parse_args()
 
@@ -236,6 +237,32 @@ def main():
                         "flops_per_forward_per_sample": F, "note": "wall-clock of the whole rollout incl. host glue; north-star target 0.40"},
             "by_class": by_class,
         }
+    if rank == 0 and not args.no_vae:
+        # image decode that closes the reference's rollout (sd3_5.py:307): reported beside the metric,
+        # not inside it -- `value` counts denoise steps, the decode is once per sample
+        from mi355_flow.vae import VAEConfig, VAEDecoder
+        from mi355_flow.weights import synthetic_vae_state_dict, vae_decode_flops
+        vcfg = VAEConfig()
+        dec = VAEDecoder(vcfg)
+        dec.bind_state_dict(synthetic_vae_state_dict(vcfg, device=dev))
+        dec.ready()
+        zl = torch.randn(B, 16, lat, lat, device=dev, generator=g).half()
+        vb = min(4, B)
+        dec.decode(zl, max_batch=vb)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(3):
+            img = dec.decode(zl, max_batch=vb)
+        e1.record()
+        torch.cuda.synchronize()
+        v_ms = e0.elapsed_time(e1) / 3 / B
+        v_tf = vae_decode_flops(vcfg, lat, lat) / (v_ms * 1e-3) / 1e12
+        out["vae_decode"] = {"ms_per_image": round(v_ms, 3), "achieved": round(v_tf, 1), "unit": "TFLOP/s", "frac": round(v_tf / PEAK_BF16_TFLOPS, 4),
+                             "flops_per_image": vae_decode_flops(vcfg, lat, lat), "micro_batch": vb,
+                             "share_of_rollout": round(v_ms * B / (elapsed / args.steps * 1e3), 4),
+                             "note": "SD3 AutoencoderKL decoder, synthetic weights; outside the timed region"}
+        assert bool(torch.isfinite(img.float()).all())
+        dec.close()
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

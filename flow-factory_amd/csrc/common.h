@@ -27,15 +27,17 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf16(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float round_bf16(float f) { return bf2f(f2bf(f)); }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-// GELU(tanh approximation), as torch.nn.functional.gelu(approximate="tanh")
+// 1/x by v_rcp_f32 (1 ulp): every use below is followed by a bf16 rounding (2^-9), an IEEE division would cost ~10 VALU ops
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float silu_f(float x) { return x * fast_rcp(1.0f + __expf(-x)); }
+// GELU(tanh approximation), as torch.nn.functional.gelu(approximate="tanh"):
+//   0.5 x (1 + tanh(u)) = x * sigmoid(2u),  u = sqrt(2/pi) (x + 0.044715 x^3)
+// evaluated as x / (1 + 2^(-x (c0 + c1 x^2))) with log2(e) folded into the constants: 5 VALU + v_exp + v_rcp per element
 __device__ __forceinline__ float gelu_tanh_f(float x) {
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    // tanh(u) = 1 - 2/(exp(2u)+1)
-    float e = __expf(2.0f * u);
-    float t = 1.0f - 2.0f / (e + 1.0f);
-    return 0.5f * x * (1.0f + t);
+    const float c0 = 2.0f * 0.7978845608028654f * 1.4426950408889634f;
+    const float c1 = c0 * 0.044715f;
+    const float t = x * (c0 + c1 * x * x);
+    return x * fast_rcp(1.0f + __builtin_amdgcn_exp2f(-t));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -75,26 +75,32 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* x, float*
     }
 }
 
-// pass 2: one wave per (sample, group): mean / rstd in double, then the per-channel affine a = rstd*gamma, d = beta - mean*a
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* part, int nchunk, int C, int groups, long HW, float eps,
-                                                         const float* gamma, const float* beta, float* ad /*[B][2][C]*/) {
-    const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+// pass 2: one workgroup per (sample, group): mean / rstd in double (fixed summation order), then the per-channel affine
+// a = rstd*gamma, d = beta - mean*a
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* part, int nchunk, int C, int groups, long HW, float eps,
+                                                          const float* gamma, const float* beta, float* ad /*[B][2][C]*/) {
+    __shared__ double red[2][4];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cpg = C / groups;
     double s = 0.0, ss = 0.0;
     const int n = nchunk * cpg;
-    for (int i = lane; i < n; i += 64) {
+    for (int i = tid; i < n; i += 256) {
         const int chunk = i / cpg, c = g * cpg + (i - chunk * cpg);
-        const float* p = part + (((long)b * nchunk + chunk) * C + c) * 2;
-        s += (double)p[0]; ss += (double)p[1];
+        const float2 v = *(const float2*)(part + (((long)b * nchunk + chunk) * C + c) * 2);
+        s += (double)v.x; ss += (double)v.y;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+    if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
+    __syncthreads();
+    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    ss = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
     const double cnt = (double)HW * cpg;
     const double mean = s / cnt;
     double var = ss / cnt - mean * mean;
     var = var > 0.0 ? var : 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) {
+    for (int c = g * cpg + tid; c < (g + 1) * cpg; c += 256) {
         const float a = rstd * gamma[c];
         ad[((long)b * 2 + 0) * C + c] = a;
         ad[((long)b * 2 + 1) * C + c] = beta[c] - (float)mean * a;
@@ -212,7 +218,7 @@ hipError_t launch_group_norm(const bf16_t* x, bf16_t* y, const float* gamma, con
     long rpc = (HW + nchunk - 1) / nchunk;
     rpc = (rpc + rpi - 1) / rpi * rpi;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, part, HW, C, rpc);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(64), 0, st, part, nchunk, C, groups, HW, eps, gamma, beta, ad);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, st, part, nchunk, C, groups, HW, eps, gamma, beta, ad);
     if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nchunk, B), dim3(256), 0, st, x, y, ad, HW, C, rpc);
     else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nchunk, B), dim3(256), 0, st, x, y, ad, HW, C, rpc);
     return hipGetLastError();

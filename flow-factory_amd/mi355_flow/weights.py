@@ -65,3 +65,74 @@ def synthetic_state_dict(cfg: TransformerConfig, device="cuda", seed: int = 1234
             t = t * (0.5 / std)  # O(1) like the sincos table
         sd[name] = t.to(dtype)
     return sd
+
+
+# --------------------------------------------------------------------------------- VAE decoder
+def expected_vae_shapes(cfg) -> Dict[str, Tuple[int, ...]]:
+    """HF `AutoencoderKL` decoder parameters (`decoder.*`) for a `mi355_flow.vae.VAEConfig`."""
+    out: Dict[str, Tuple[int, ...]] = {}
+
+    def conv(n, co, ci, k=3):
+        out[n + ".weight"], out[n + ".bias"] = (co, ci, k, k), (co,)
+
+    def norm(n, c):
+        out[n + ".weight"], out[n + ".bias"] = (c,), (c,)
+
+    def resnet(n, ci, co):
+        norm(n + ".norm1", ci); conv(n + ".conv1", co, ci)
+        norm(n + ".norm2", co); conv(n + ".conv2", co, co)
+        if ci != co:
+            conv(n + ".conv_shortcut", co, ci, 1)
+
+    rev = list(reversed(cfg.block_out_channels))
+    top = rev[0]
+    conv("decoder.conv_in", top, cfg.latent_channels)
+    resnet("decoder.mid_block.resnets.0", top, top)
+    norm("decoder.mid_block.attentions.0.group_norm", top)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        out[f"decoder.mid_block.attentions.0.{n}.weight"], out[f"decoder.mid_block.attentions.0.{n}.bias"] = (top, top), (top,)
+    resnet("decoder.mid_block.resnets.1", top, top)
+    prev = top
+    for i, co in enumerate(rev):
+        for j in range(cfg.layers_per_block + 1):
+            resnet(f"decoder.up_blocks.{i}.resnets.{j}", prev if j == 0 else co, co)
+        if i != len(rev) - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", co, co)
+        prev = co
+    norm("decoder.conv_norm_out", prev)
+    conv("decoder.conv_out", cfg.out_channels, prev)
+    return out
+
+
+def synthetic_vae_state_dict(cfg, device="cuda", seed: int = 4242, dtype: torch.dtype = torch.bfloat16) -> Dict[str, torch.Tensor]:
+    """Variance-preserving random init (weights N(0, 1/fan_in), norm weights 1 + N(0, 0.1^2), biases N(0, 0.05^2)):
+    activations stay O(1) through the ~30 layers, so a benchmark exercises realistic value ranges."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for name, shape in expected_vae_shapes(cfg).items():
+        t = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
+        if "norm" in name and name.endswith(".weight"):
+            t = 1.0 + 0.1 * t
+        elif name.endswith(".bias"):
+            t = 0.05 * t
+        else:
+            t = t / math.sqrt(math.prod(shape[1:]))
+        sd[name] = t.to(dtype)
+    return sd
+
+
+def vae_decode_flops(cfg, h: int, w: int) -> float:
+    """Algorithmic conv / linear / attention FLOPs of one image decode from (h, w) latents (2 FLOP/MAC)."""
+    rev = list(reversed(cfg.block_out_channels))
+    top, hw = rev[0], h * w
+    mac = hw * 9 * cfg.latent_channels * top + 4 * hw * 9 * top * top + 4 * hw * top * top + 2 * hw * hw * top
+    prev, res = top, hw
+    for i, co in enumerate(rev):
+        for j in range(cfg.layers_per_block + 1):
+            ci = prev if j == 0 else co
+            mac += res * 9 * ci * co + res * 9 * co * co + (res * ci * co if ci != co else 0)
+        if i != len(rev) - 1:
+            res *= 4
+            mac += res * 9 * co * co
+        prev = co
+    return 2.0 * (mac + res * 9 * rev[-1] * cfg.out_channels)
