@@ -263,7 +263,9 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
         }
-        float psum = 0.f;
+        // row sums from the PACKED bf16 probabilities (the values the P.V MFMA consumes) with v_dot2c_f32_bf16 against
+        // (1, 1): 16 dot2 on 4 independent accumulators instead of 32 v_add_f32
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
         unsigned pk[2][8];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -271,10 +273,12 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
             for (int r = 0; r < 16; r += 2) {
                 const float p0 = __builtin_amdgcn_exp2f(s[kb][r]);
                 const float p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
-                psum += p0 + p1;
-                pk[kb][r >> 1] = pack_bf16(p0, p1);
+                const unsigned u = pack_bf16(p0, p1);
+                pk[kb][r >> 1] = u;
+                ps[(r >> 1) & 3] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2, u), __builtin_bit_cast(bf16v2, 0x3f803f80u),
+                                                                   ps[(r >> 1) & 3], false);
             }
-        l_run += psum;
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int kb = c >> 1, sh = (c & 1) * 4;
