@@ -1,0 +1,237 @@
+// mi355_flow -- attention with head_dim 128 (FLUX.1 joint / single-stream attention): non-causal
+// softmax(q k^T / sqrt(128)) v, flash-style, for gfx950.  Same construction as attention.hip (d = 64):
+//   q, k : [B][H][S_pad][128] bf16 (per-head RMSNorm + RoPE already applied), vT : [B][H][128][S_pad] bf16;
+//   one wave = 32 queries, one query per lane: S^T = K.Q^T (8 k-steps of 16 over d) and O^T += V^T.P^T (4 blocks of 32
+//   d-rows) on v_mfma_f32_32x32x16_bf16; K rows fed in the permuted order that makes the packed softmax registers the
+//   B fragments of the second MFMA; deferred rescale with -m as the MFMA C operand.
+// Per 64-key tile a wave issues 32 MFMAs (1024 cycles) against the same ~130 VALU slots as d = 64, so this kernel is
+// MFMA-bound where the d = 64 one is VALU-co-bound.  The K tile is kept as TWO 64x64 sub-tiles (d halves) so that every
+// LDS row stays 128 bytes and the conflict-free XOR swizzle of the d = 64 kernel carries over unchanged.
+#include "kernels.h"
+
+namespace mi355 {
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int HD = 128;
+constexpr int KV = 64;                          // keys per tile
+constexpr int QW = 32;                          // queries per wave
+constexpr int SUB_BYTES = KV * 64 * 2;          // one 64x64 bf16 sub-tile (8 KiB)
+constexpr int K_BYTES = 2 * SUB_BYTES;          // K tile: d halves
+constexpr int V_BYTES = HD * KV * 2;            // V^T tile: 128 rows (d) x 64 keys
+constexpr int STAGE_BYTES = K_BYTES + V_BYTES;  // 32 KiB
+constexpr float SCALE_LOG2E = 0.08838834764831845f * 1.4426950408889634f;   // 1/sqrt(128) * log2(e)
+
+__device__ __forceinline__ int key_perm(int i) {
+    const int a = i >> 3, g = (i >> 2) & 1, b = i & 3;
+    return 16 * (a >> 1) + 8 * g + 4 * (a & 1) + b;
+}
+
+template <int NWAVE>
+__global__ __launch_bounds__(NWAVE * 64, 2) void attn128_kernel(Attn128Params p) {
+    constexpr int QB = QW * NWAVE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, lg = lane >> 5;
+    // XCD-aware work order (blockIdx % 8 = XCD): the q-blocks of one (b, h) share an L2
+    const int nqb = (p.S + QB - 1) / QB;
+    const int nwg = nqb * p.H * p.B;
+    int wid = blockIdx.x;
+    {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = wid & 7;
+        wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (wid >> 3);
+    }
+    const int qblk = wid % nqb;
+    const int bhi = wid / nqb;
+    const int h = bhi % p.H, b = bhi / p.H;
+    const long bh = (long)b * p.H + h;
+    const bf16_t* Qg = p.q + bh * p.S_pad * HD;
+    const bf16_t* Kg = p.k + bh * p.S_pad * HD;
+    const bf16_t* Vg = p.vT + bh * HD * p.S_pad;
+
+    // ---- Q fragments (B operand): lane holds Q[q][kk*16 + lg*8 .. +8], kk = 0..7
+    const int q_row = qblk * QB + wave * QW + lq;
+    const int q_ld = q_row < p.S ? q_row : p.S - 1;
+    bf16x8 qf[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) qf[kk] = *(const bf16x8*)(Qg + (long)q_ld * HD + kk * 16 + lg * 8);
+    if (!p.q_prescaled) {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            u32x4 u = __builtin_bit_cast(u32x4, qf[kk]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u[e] = pack_bf16(bf_lo(u[e]) * SCALE_LOG2E, bf_hi(u[e]) * SCALE_LOG2E);
+            qf[kk] = __builtin_bit_cast(bf16x8, u);
+        }
+    }
+
+    // ---- staging: a tile = 32 glds groups of 8 rows x 128 B: groups 0..15 = K (sub-tile g>>3, rows 8*(g&7)..), 16..31 = V^T rows
+    constexpr int NG = 16 / NWAVE;
+    const bf16_t* srcK[NG];
+    const bf16_t* srcV[NG];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int g = wave + i * NWAVE;                   // 0..15
+        const int krow = (g & 7) * 8 + (lane >> 3);       // key inside the tile
+        const int kc = (lane & 7) ^ ((krow >> 1) & 7);
+        srcK[i] = Kg + (long)krow * HD + (g >> 3) * 64 + kc * 8;            // + tile*64*HD
+        const int vrow = g * 8 + (lane >> 3);             // d
+        const int vc = (lane & 7) ^ ((vrow >> 1) & 7);
+        srcV[i] = Vg + (long)vrow * p.S_pad + vc * 8;                        // + tile*64
+    }
+    auto stage = [&](int t, int buf) {
+        char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < NG; ++i) {
+            const int g = wave + i * NWAVE;
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcK[i] + (long)t * KV * HD), (lptr_t)(base + g * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcV[i] + (long)t * KV), (lptr_t)(base + K_BYTES + g * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets
+    const int krow = key_perm(lq);
+    int offK[4];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) offK[k4] = krow * 128 + (((2 * k4 + lg) ^ ((krow >> 1) & 7)) << 4);
+    int offV[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) offV[c] = K_BYTES + lq * 128 + (((2 * c + lg) ^ ((lq >> 1) & 7)) << 4);
+
+    f32x16 o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = (f32x16){0};
+    float l_run = 0.f;
+    const int nt = (p.S + KV - 1) / KV;
+    stage(0, 0);
+
+    constexpr float THR = 6.0f;
+    float m_run = 0.f;
+    f32x16 negm = (f32x16){0};
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+        const char* sb = smem + (t & 1) * STAGE_BYTES;
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const bf16x8 kf = *(const bf16x8*)(sb + offK[0] + kb * 4096);
+            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], negm, 0, 0, 0);
+        }
+#pragma unroll
+        for (int kk = 1; kk < 8; ++kk) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const bf16x8 kf = *(const bf16x8*)(sb + (kk >> 2) * SUB_BYTES + offK[kk & 3] + kb * 4096);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
+            }
+        }
+        if (t == nt - 1) {
+            const int kbase = t * KV + 8 * lg;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kbase + 32 * kb + 16 * (r >> 3) + (r & 7);
+                    if (key >= p.S) s[kb][r] = -1e30f;
+                }
+        }
+        float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[0][r]), s[0][r + 1]);
+        mx = fmaxf(mx, s[0][15]);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[1][r]), s[1][r + 1]);
+        if (t == 0 || __any(mx > THR)) {
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float delta = (t == 0) ? mx : fmaxf(mx, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            m_run += delta;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) negm[r] = -m_run;
+            l_run *= alpha;
+#pragma unroll
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        float psum = 0.f;
+        unsigned pk[2][8];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(s[kb][r]);
+                const float p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
+                psum += p0 + p1;
+                pk[kb][r >> 1] = pack_bf16(p0, p1);
+            }
+        l_run += psum;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int kb = c >> 1, sh = (c & 1) * 4;
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+            const u32x4 uu = {pk[kb][sh + 0], pk[kb][sh + 1], pk[kb][sh + 2], pk[kb][sh + 3]};
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, uu);
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const bf16x8 vf = *(const bf16x8*)(sb + offV[c] + db * 4096);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- finalize: 1/l, stage O through LDS (row = query, 256 B; 16-byte chunks XOR-swizzled by q & 7) for full-row stores
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_run;
+    __syncthreads();
+    char* ob = smem + wave * (QW * HD * 2);
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int d0 = 32 * db + 8 * a + 4 * lg;
+            uint2 w = {pack_bf16(o[db][4 * a] * inv, o[db][4 * a + 1] * inv), pack_bf16(o[db][4 * a + 2] * inv, o[db][4 * a + 3] * inv)};
+            const int chunk = (d0 >> 3) ^ (lq & 7);
+            *(uint2*)(ob + lq * 256 + chunk * 16 + (d0 & 7) * 2) = w;
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int r = it * 4 + (lane >> 4), c = lane & 15;
+        const uint4 val = *(const uint4*)(ob + r * 256 + ((c ^ (r & 7)) << 4));
+        const int qi = qblk * QB + wave * QW + r;
+        if (qi < p.S) {
+            bf16_t* dst = (qi < p.n_first) ? p.o_first + ((long)b * p.n_first + qi) * p.ld_first
+                                           : p.o_rest + ((long)b * (p.S - p.n_first) + (qi - p.n_first)) * p.ld_rest;
+            *(uint4*)(dst + h * HD + c * 8) = val;
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream) {
+    if (p.S <= 0 || p.S_pad % KV != 0 || p.S_pad < p.S || p.n_first < 0 || p.n_first > p.S) return hipErrorInvalidValue;
+    auto kern = attn128_kernel<8>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(((p.S + 255) / 256) * p.H * p.B), dim3(512), 2 * STAGE_BYTES, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace mi355

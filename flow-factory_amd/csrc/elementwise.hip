@@ -9,8 +9,8 @@ namespace {
 
 // ------------------------------------------------------------------ LayerNorm + modulate
 // One wave per row; the row (D <= 8*64*MAXC) stays in registers: exact two-pass mean/variance.
-constexpr int LN_MAXC = 4;  // 16-byte chunks per lane -> D <= 2048
-
+// LN_MAXC 16-byte chunks per lane: 4 -> D <= 2048 (SD3.5, D = 1536), 8 -> D <= 4096 (FLUX.1, D = 3072)
+template <int LN_MAXC>
 __global__ __launch_bounds__(256) void ln_mod_kernel(LnModParams p) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -132,8 +132,9 @@ inline int grid_for(long total, int block) {
 }  // namespace
 
 hipError_t launch_ln_mod(const LnModParams& p, hipStream_t stream) {
-    if (p.D % 8 != 0 || p.D > 8 * 64 * LN_MAXC || p.M <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(ln_mod_kernel, dim3((p.M + 3) / 4), dim3(256), 0, stream, p);
+    if (p.D % 8 != 0 || p.D > 8 * 64 * 8 || p.M <= 0) return hipErrorInvalidValue;
+    if (p.D <= 2048) hipLaunchKernelGGL(ln_mod_kernel<4>, dim3((p.M + 3) / 4), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(ln_mod_kernel<8>, dim3((p.M + 3) / 4), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -95,12 +95,13 @@ __device__ __forceinline__ void store_row8(const GemmParams& p, int m, int n, in
         *(uint4*)dst = val;
         return;
     } else if constexpr (EPI == EPI_VT) {
-        // m = feature, n.. = 8 tokens
-        const int h = m >> 6, d = m & 63;
+        // m = feature, n.. = 8 tokens; head_dim 64 (hd_shift 0) or 1 << hd_shift
+        const int hs = p.hd_shift ? p.hd_shift : 6;
+        const int h = m >> hs, d = m & ((1 << hs) - 1);
         if (full && ((p.rows_per_sample | p.s_off) & 7) == 0) {
             const int bi = n / p.rows_per_sample;
             const int s0 = n - bi * p.rows_per_sample + p.s_off;
-            *(uint4*)(p.q + (((long)bi * p.H + h) * 64 + d) * p.S_pad + s0) = val;
+            *(uint4*)(p.q + ((((long)bi * p.H + h) << hs) + d) * p.S_pad + s0) = val;
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -108,7 +109,7 @@ __device__ __forceinline__ void store_row8(const GemmParams& p, int m, int n, in
                 if (tok < p.N) {
                     const int bi = tok / p.rows_per_sample;
                     const int s = tok - bi * p.rows_per_sample + p.s_off;
-                    p.q[(((long)bi * p.H + h) * 64 + d) * p.S_pad + s] = f2bf(y[e]);
+                    p.q[((((long)bi * p.H + h) << hs) + d) * p.S_pad + s] = f2bf(y[e]);
                 }
             }
         }
@@ -678,8 +679,12 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
         if (big >= 200 && EPI != EPI_UNPATCH) return launch_cfg<256, 256, 2, 4, EPI>(p, stream);
         return launch_cfg<128, 128, 2, 2, EPI>(p, stream);
     }
+    // the ping-pong kernel addresses its operands with 32-bit byte offsets from the base pointers
+    const bool fits32 = ((size_t)p.M * (size_t)p.lda + (size_t)p.K) * 2 < (1ull << 32) &&
+                        ((size_t)p.N * (size_t)p.ldw + (size_t)p.K) * 2 < (1ull << 32);
     if constexpr (EPI != EPI_UNPATCH) {   // (proj_out, N = 64: scalar-scatter epilogue, always the 128x128 kernel)
-        if (big >= g_pp_min_tiles) return launch_pp<EPI>(p, stream);
+        if (big >= g_pp_min_tiles && fits32) return launch_pp<EPI>(p, stream);
+        if (big >= 200) return launch_cfg<256, 256, 2, 4, EPI>(p, stream);    // > 4 GiB operand (FLUX modulation table)
     }
     return launch_cfg<128, 128, 2, 2, EPI>(p, stream);
 }

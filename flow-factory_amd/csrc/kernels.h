@@ -40,6 +40,7 @@ struct GemmParams {
     bf16_t* q; bf16_t* k;     // q,k: [B][H][S_pad][64];  EPI_VT: q = vT [B][H][64][S_pad]
     const float* nw_q; const float* nw_k;   // RMSNorm weights [64]
     int H, S_pad, s_off; float eps;
+    int hd_shift;             // EPI_VT: log2(head_dim) (0 = 6, head_dim 64)
     float q_scale;            // EPI_QK_NORM: extra factor on the normalised q (softmax scale folded in); 0 = 1.0
     // EPI_UNPATCH
     int hp, wp, patch, out_ch;
@@ -75,6 +76,31 @@ struct AttnParams {
     int q_prescaled;   // 1: q already carries the softmax scale 0.125*log2(e) (folded into the q RMSNorm epilogue)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
+
+// head_dim 128 (FLUX.1, attention128.hip): q,k [B][H][S_pad][128], vT [B][H][128][S_pad].  Query s < n_first of sample b is
+// written to o_first[(b*n_first + s)*ld_first + h*128 + d], the others to o_rest[(b*(S-n_first) + s-n_first)*ld_rest + ...].
+struct Attn128Params {
+    const bf16_t* q; const bf16_t* k; const bf16_t* vT;
+    bf16_t* o_first; long ld_first; int n_first;
+    bf16_t* o_rest; long ld_rest;
+    int B, H, S, S_pad;
+    int q_prescaled;   // 1: q carries log2(e)/sqrt(128) already (rope_norm kernel)
+};
+hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream);
+
+// per-head RMSNorm (weight, eps) + rotary embedding of the q and k projections (flux_ops.hip):
+//   src rows [M][src_ld]: q at column q_col + h*128, k at k_col + h*128 (bf16, bias already added);
+//   row m = (sample b, token m % rows_per_sample) -> joint position s = s_off + token; rot = cs[s][pair] = (cos, sin);
+//   q_out / k_out [B][H][S_pad][128]; q additionally multiplied by q_scale (softmax scale * log2 e).
+struct RopeNormParams {
+    const bf16_t* src; long src_ld; int q_col, k_col;
+    const float* nw_q; const float* nw_k;     // [128]
+    const float2* cs;                         // [S_joint][64]
+    bf16_t* q_out; bf16_t* k_out;
+    int M, H, rows_per_sample, s_off, S_pad;
+    float eps, q_scale;
+};
+hipError_t launch_rope_norm(const RopeNormParams& p, hipStream_t stream);
 
 // ------------------------------------------------------------------------------ elementwise
 // LayerNorm(no affine, eps) + AdaLN modulate: out = LN(x)*(1+scale[b]) + shift[b]; optional

@@ -36,6 +36,14 @@ class VaeCfg(C.Structure):
     ]
 
 
+class FluxCfg(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32), ("num_layers", C.c_int32), ("num_single_layers", C.c_int32), ("num_heads", C.c_int32),
+        ("head_dim", C.c_int32), ("joint_attention_dim", C.c_int32), ("pooled_projection_dim", C.c_int32),
+        ("guidance_embeds", C.c_int32), ("time_proj_dim", C.c_int32), ("axes_dims_rope", C.c_int32 * 3), ("eps", C.c_float),
+    ]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -75,6 +83,20 @@ SIGNATURES = {
     "mi355_vae_plan_destroy": (_I, [_P]),
     "mi355_vae_plan_workspace_bytes": (_L, [_P]),
     "mi355_vae_decode": (_I, [_P, _P, _P, _I, _I, _P, _I, _I]),
+    "mi355_flux_create": (_I, [C.POINTER(FluxCfg), C.POINTER(_P)]),
+    "mi355_flux_destroy": (_I, [_P]),
+    "mi355_flux_bind_weight": (_I, [_P, C.c_char_p, _P, _I, _I, C.POINTER(_L), _P]),
+    "mi355_flux_weights_ready": (_I, [_P]),
+    "mi355_flux_num_params": (_I, [_P]),
+    "mi355_flux_param_name": (C.c_char_p, [_P, _I]),
+    "mi355_flux_plan_create": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_P)]),
+    "mi355_flux_plan_destroy": (_I, [_P]),
+    "mi355_flux_plan_workspace_bytes": (_L, [_P]),
+    "mi355_flux_forward": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "mi355_flux_rollout": (_I, [_P, _P, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _I, _F, _P, _I, _I, _P, _P, _P,
+                                C.POINTER(C.c_int32), _P, _P, _P, _I]),
+    "mi355_op_attention128": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I]),
+    "mi355_op_rope_norm": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F]),
     "mi355_op_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
     "mi355_op_conv_repack": (_I, [_P, _P, _I, _P, _I, _I, _I, _I]),
     "mi355_op_group_norm": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _I]),

@@ -1,0 +1,464 @@
+"""FLUX.1 rollout on the native engine (mi355_flux_*): host mirror of `Flux1Adapter.inference` / `.forward`
+(reference src/flow_factory/models/flux/flux1.py:151-289, :294-346) -- SURVEY.md 8(f) row N3.
+
+Same contract as the SD3.5 path (`mi355_flow.adapter`): reference argument names and defaults, the reference's RNG draw
+order, trajectory / log-prob / callback collectors, no CPU or PyTorch fallback.  FLUX specifics kept from the reference:
+packed latents `(B, h/2*w/2, 64)`, `img_ids` from `prepare_latents`, `timestep = t / 1000`, embedded guidance (no CFG,
+no negative prompt), dynamic-shift `mu` from the image sequence length.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _lib
+from ._lib import DYNAMICS, FluxCfg
+from .engine import _bf16c, _ptr, _stream, dtype_code, sde_step
+from .samples import Flux1Sample
+from .scheduler import FlowMatchEulerDiscreteSDEScheduler, SDESchedulerOutput, set_scheduler_timesteps
+from .trajectory import TrajectoryIndicesType, _resolve, create_callback_collector, create_trajectory_collector
+
+_DTYPE_MAP = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16,
+              "fp32": torch.float32, "float32": torch.float32}
+VAE_SCALE_FACTOR = 8
+
+
+@dataclass
+class FluxConfig:
+    """diffusers FluxTransformer2DModel config fields the engine needs (FLUX.1-dev defaults)."""
+    in_channels: int = 64
+    num_layers: int = 19
+    num_single_layers: int = 38
+    num_attention_heads: int = 24
+    attention_head_dim: int = 128
+    joint_attention_dim: int = 4096
+    pooled_projection_dim: int = 768
+    guidance_embeds: bool = True
+    axes_dims_rope: Tuple[int, int, int] = (16, 56, 56)
+    time_proj_dim: int = 256
+    eps: float = 1e-6
+
+    @property
+    def dim(self) -> int:
+        return self.num_attention_heads * self.attention_head_dim
+
+    def to_c(self) -> FluxCfg:
+        return FluxCfg(self.in_channels, self.num_layers, self.num_single_layers, self.num_attention_heads, self.attention_head_dim,
+                       self.joint_attention_dim, self.pooled_projection_dim, int(self.guidance_embeds), self.time_proj_dim,
+                       (C.c_int32 * 3)(*self.axes_dims_rope), self.eps)
+
+
+def pack_latents(lat: torch.Tensor) -> torch.Tensor:
+    """FluxPipeline._pack_latents: (B, C, h, w) -> (B, h/2*w/2, 4C)."""
+    B, Cc, h, w = lat.shape
+    return lat.view(B, Cc, h // 2, 2, w // 2, 2).permute(0, 2, 4, 1, 3, 5).reshape(B, (h // 2) * (w // 2), Cc * 4)
+
+
+def unpack_latents(x: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """FluxPipeline._unpack_latents on the latent grid: (B, h/2*w/2, 4C) -> (B, C, h, w)."""
+    B, _, ch = x.shape
+    return x.view(B, h // 2, w // 2, ch // 4, 2, 2).permute(0, 3, 1, 4, 2, 5).reshape(B, ch // 4, h, w)
+
+
+def prepare_latent_image_ids(hp: int, wp: int, device, dtype) -> torch.Tensor:
+    """FluxPipeline._prepare_latent_image_ids: (hp*wp, 3) = [0, row, col]."""
+    ids = torch.zeros(hp, wp, 3)
+    ids[..., 1] = ids[..., 1] + torch.arange(hp)[:, None]
+    ids[..., 2] = ids[..., 2] + torch.arange(wp)[None, :]
+    return ids.reshape(hp * wp, 3).to(device=device, dtype=dtype)
+
+
+def model_scalar(value: float, dtype: torch.dtype) -> float:
+    """`x.to(hidden_states.dtype) * 1000` of FluxTransformer2DModel.forward for a python / fp32 scalar."""
+    return float((torch.tensor(float(value), dtype=torch.float32).to(dtype) * 1000).float())
+
+
+class FluxEngine:
+    """Owns the packed bf16 copy of the FLUX transformer weights (mi355_flux)."""
+
+    def __init__(self, cfg: FluxConfig = FluxConfig()):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        h = C.c_void_p()
+        c = cfg.to_c()
+        _lib.check(self.lib.mi355_flux_create(C.byref(c), C.byref(h)), "flux_create")
+        self._h = h
+        self._plans: Dict[tuple, "FluxPlan"] = {}
+
+    def param_names(self) -> List[str]:
+        n = self.lib.mi355_flux_num_params(self._h)
+        return [self.lib.mi355_flux_param_name(self._h, i).decode() for i in range(n)]
+
+    def bind_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        names = self.param_names()
+        missing = [n for n in names if n not in state_dict]
+        if missing and strict:
+            raise KeyError(f"mi355_flow: FLUX state dict lacks {len(missing)} parameters, first: {missing[0]}")
+        st = _stream()
+        for n in names:
+            if n not in state_dict:
+                continue
+            t = state_dict[n].detach()
+            if not t.is_cuda:
+                t = t.cuda(non_blocking=True)
+            t = t.contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            _lib.check(self.lib.mi355_flux_bind_weight(self._h, n.encode(), t.data_ptr(), dtype_code(t.dtype), t.dim(), shape, st),
+                       f"flux_bind_weight({n})")
+        torch.cuda.current_stream().synchronize()
+
+    def ready(self) -> None:
+        _lib.check(self.lib.mi355_flux_weights_ready(self._h), "flux_weights_ready")
+
+    def plan(self, batch: int, latent_h: int, latent_w: int, n_text: int, max_steps: int) -> "FluxPlan":
+        key = (batch, latent_h, latent_w, n_text)
+        p = self._plans.get(key)
+        if p is None or p.max_steps < max_steps:
+            if p is not None:
+                p.close()
+            p = FluxPlan(self, batch, latent_h, latent_w, n_text, max_steps)
+            self._plans[key] = p
+        return p
+
+    def close(self) -> None:
+        for p in self._plans.values():
+            p.close()
+        self._plans.clear()
+        if self._h:
+            self.lib.mi355_flux_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FluxPlan:
+    def __init__(self, engine: FluxEngine, batch: int, latent_h: int, latent_w: int, n_text: int, max_steps: int):
+        self.engine, self.lib = engine, engine.lib
+        self.batch, self.h, self.w, self.n_text, self.max_steps = batch, latent_h, latent_w, n_text, max_steps
+        self.Ni = (latent_h // 2) * (latent_w // 2)
+        self.C = engine.cfg.in_channels
+        h = C.c_void_p()
+        _lib.check(self.lib.mi355_flux_plan_create(engine._h, batch, latent_h, latent_w, n_text, max_steps, C.byref(h)), "flux_plan_create")
+        self._h = h
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self.lib.mi355_flux_plan_workspace_bytes(self._h))
+
+    def close(self) -> None:
+        if self._h:
+            self.lib.mi355_flux_plan_destroy(self._h)
+            self._h = None
+
+    def transformer_forward(self, latents: torch.Tensor, t_model: torch.Tensor, guidance_model: Optional[torch.Tensor],
+                            prompt_embeds: torch.Tensor, pooled: torch.Tensor) -> torch.Tensor:
+        """latents (B, Ni, 64) packed; t_model / guidance_model (B,) = the values the network embeds."""
+        B = self.batch
+        assert latents.shape == (B, self.Ni, self.C), latents.shape
+        dev = latents.device
+        tm = t_model.to(device=dev, dtype=torch.float32).reshape(-1)
+        tm = (tm.expand(B) if tm.numel() == 1 else tm).contiguous()
+        gm = None
+        if guidance_model is not None:
+            gm = guidance_model.to(device=dev, dtype=torch.float32).reshape(-1)
+            gm = (gm.expand(B) if gm.numel() == 1 else gm).contiguous()
+        out = torch.empty((B, self.Ni, self.C), device=dev, dtype=torch.bfloat16)
+        latents = latents.contiguous()
+        pe, pp = _bf16c(prompt_embeds), _bf16c(pooled)
+        _lib.check(self.lib.mi355_flux_forward(self._h, _stream(), _ptr(latents), dtype_code(latents.dtype), _ptr(tm), _ptr(gm), _ptr(pe),
+                                               _ptr(pp), _ptr(out)), "flux_forward")
+        return out
+
+    def rollout(self, timesteps: Sequence[float], sigmas: Sequence[float], noise_levels: Sequence[float], dynamics: str,
+                guidance_scale: float, init_latents: torch.Tensor, storage_dtype: torch.dtype, step_noise: Optional[torch.Tensor],
+                prompt_embeds: torch.Tensor, pooled: torch.Tensor, keep_positions: Optional[Sequence[int]] = None,
+                compute_log_prob: bool = True):
+        """Returns (kept_latents [n_kept, B, Ni, 64] storage dtype, log_probs [N, B] fp32 (nan where not computed), final)."""
+        N, B = len(timesteps), self.batch
+        assert len(sigmas) == N + 1 and len(noise_levels) == N
+        dev = init_latents.device
+        keep = list(range(N + 1)) if keep_positions is None else sorted(set(int(k) for k in keep_positions))
+        slots = [-1] * (N + 1)
+        for s, pos in enumerate(keep):
+            slots[pos] = s
+        shape = (B, self.Ni, self.C)
+        assert tuple(init_latents.shape) == shape, init_latents.shape
+        out_lat = torch.empty((len(keep),) + shape, device=dev, dtype=storage_dtype)
+        out_lp = torch.full((N, B), float("nan"), device=dev, dtype=torch.float32)
+        out_fin = torch.empty(shape, device=dev, dtype=storage_dtype)
+        fa = C.c_float * N
+        ts_c, nl_c = fa(*[float(t) for t in timesteps]), fa(*[float(e) for e in noise_levels])
+        sg_c = (C.c_float * (N + 1))(*[float(s) for s in sigmas])
+        sl_c = (C.c_int32 * (N + 1))(*slots)
+        init_latents = init_latents.contiguous()
+        if step_noise is not None:
+            step_noise = step_noise.contiguous()
+            assert step_noise.dtype == torch.float32 and step_noise.shape == (N,) + shape, step_noise.shape
+        pe, pp = _bf16c(prompt_embeds), _bf16c(pooled)
+        _lib.check(self.lib.mi355_flux_rollout(
+            self._h, _stream(), N, ts_c, sg_c, nl_c, DYNAMICS[dynamics], float(guidance_scale), _ptr(init_latents),
+            dtype_code(init_latents.dtype), dtype_code(storage_dtype), _ptr(step_noise), _ptr(pe), _ptr(pp), sl_c, _ptr(out_lat),
+            _ptr(out_lp), _ptr(out_fin), int(bool(compute_log_prob))), "flux_rollout")
+        return out_lat, out_lp, out_fin
+
+
+class Flux1NativeAdapter:
+    """Standalone FLUX.1 adapter (no Flow-Factory import): engine + scheduler (+ optional native VAE decoder)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[FluxConfig] = None,
+                 scheduler: Optional[FlowMatchEulerDiscreteSDEScheduler] = None, latent_storage_dtype: Optional[str] = "fp16",
+                 transformer_dtype: torch.dtype = torch.bfloat16, device: Union[str, torch.device] = "cuda",
+                 vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, vae_config=None, vae_max_batch: int = 4):
+        if not torch.cuda.is_available():
+            raise RuntimeError("mi355_flow: no GPU visible; the native rollout engine has no CPU path")
+        self.device = torch.device(device)
+        self.transformer_dtype = transformer_dtype
+        self._latent_storage = latent_storage_dtype
+        # FLUX.1 scheduler config: dynamic shifting (mu from the image sequence length)
+        self.scheduler = scheduler or FlowMatchEulerDiscreteSDEScheduler(shift=3.0, use_dynamic_shifting=True, sde_steps=[1, 2, 3],
+                                                                         num_sde_steps=1)
+        self.engine = FluxEngine(config or FluxConfig())
+        self.refresh_weights(state_dict)
+        self.vae_decoder = None
+        self.vae_max_batch = vae_max_batch
+        if vae_state_dict is not None:
+            from .vae import VAEConfig, VAEDecoder
+            self.vae_decoder = VAEDecoder(vae_config or VAEConfig(scaling_factor=0.3611, shift_factor=0.1159))
+            self.vae_decoder.bind_state_dict(vae_state_dict)
+            self.vae_decoder.ready()
+
+    @property
+    def latent_storage_dtype(self) -> Optional[torch.dtype]:
+        return _DTYPE_MAP.get(self._latent_storage) if self._latent_storage else None
+
+    def refresh_weights(self, state_dict: Dict[str, torch.Tensor]) -> None:
+        self.engine.bind_state_dict(state_dict)
+        self.engine.ready()
+
+    def rollout(self):
+        self.scheduler.rollout()
+
+    def eval(self):
+        self.scheduler.eval()
+
+    def train(self, mode: bool = True):
+        self.scheduler.train(mode)
+
+    def cast_latents(self, latents: torch.Tensor, default_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        target = self.latent_storage_dtype or default_dtype
+        if target is None or latents.dtype == target:
+            return latents
+        if target == torch.float16:
+            latents = latents.clamp(-65504.0, 65504.0)
+        return latents.to(target)
+
+    def encode_prompt(self, *a, **k):
+        raise RuntimeError("mi355_flow standalone adapter has no text encoders: pass prompt_embeds / pooled_prompt_embeds")
+
+    def decode_latents(self, latents: torch.Tensor, height: int, width: int, output_type: str = "pt"):
+        """flux1.py:138-147: unpack, / scaling + shift, vae.decode, postprocess."""
+        if self.vae_decoder is None:
+            return None
+        if output_type not in ("pt", "np"):
+            raise ValueError("mi355_flow standalone adapter decodes to 'pt' or 'np'")
+        lat = unpack_latents(latents, int(height) // VAE_SCALE_FACTOR, int(width) // VAE_SCALE_FACTOR).contiguous()
+        img = self.vae_decoder.decode(lat, postprocess=True, out_dtype=torch.bfloat16, max_batch=self.vae_max_batch)
+        return img if output_type == "pt" else img.float().permute(0, 2, 3, 1).cpu().numpy()
+
+    # ------------------------------------------------------------------ rollout (flux1.py:151-289)
+    @torch.no_grad()
+    def inference(
+        self,
+        prompt: Optional[Union[str, List[str]]] = None,
+        height: int = 512,
+        width: int = 512,
+        num_inference_steps: int = 28,
+        guidance_scale: float = 3.5,
+        generator: Optional[torch.Generator] = None,
+        prompt_ids: Optional[torch.Tensor] = None,
+        prompt_embeds: Optional[torch.Tensor] = None,
+        pooled_prompt_embeds: Optional[torch.Tensor] = None,
+        joint_attention_kwargs: Optional[Dict[str, Any]] = None,
+        compute_log_prob: bool = True,
+        extra_call_back_kwargs: List[str] = [],
+        trajectory_indices: TrajectoryIndicesType = "all",
+    ) -> List[Flux1Sample]:
+        device = self.device
+        if joint_attention_kwargs:
+            raise ValueError("mi355_flow: joint_attention_kwargs are not supported by the native engine")
+        if prompt_embeds is None:
+            enc = self.encode_prompt(prompt)
+            prompt_embeds, pooled_prompt_embeds, prompt_ids = enc["prompt_embeds"], enc["pooled_prompt_embeds"], enc["prompt_ids"]
+        else:
+            prompt_embeds, pooled_prompt_embeds = prompt_embeds.to(device), pooled_prompt_embeds.to(device)
+        B = len(prompt_embeds)
+        dtype = prompt_embeds.dtype
+        Cl = self.engine.cfg.in_channels // 4
+        # FluxPipeline.prepare_latents: height = 2 * (height // (vae_scale_factor * 2))
+        h = 2 * (int(height) // (VAE_SCALE_FACTOR * 2))
+        w = 2 * (int(width) // (VAE_SCALE_FACTOR * 2))
+        N = int(num_inference_steps)
+        Ni = (h // 2) * (w // 2)
+
+        # RNG in the reference's order: prepare_latents draws (B, 16, h, w) in the prompt dtype and packs it; the scheduler then
+        # draws one fp32 tensor of the PACKED shape per step (randn_tensor(noise_pred.shape)), also when noise_level == 0
+        latents = pack_latents(torch.randn((B, Cl, h, w), generator=generator, device=device, dtype=dtype))
+        latent_image_ids = prepare_latent_image_ids(h // 2, w // 2, device, dtype)
+        step_noise = torch.empty((N, B, Ni, Cl * 4), device=device, dtype=torch.float32)
+        for i in range(N):
+            step_noise[i] = torch.randn((B, Ni, Cl * 4), generator=generator, device=device, dtype=torch.float32)
+
+        timesteps = set_scheduler_timesteps(self.scheduler, N, seq_len=latents.shape[1], device=device)
+        ts_host = [float(t) for t in timesteps.tolist()]
+        sig_host = [float(s) for s in self.scheduler.sigmas.tolist()]
+        eta_host = self.scheduler.host_noise_levels()
+        storage = self.latent_storage_dtype or dtype
+        plan = self.engine.plan(B, h, w, prompt_embeds.shape[1], N)
+        if any(k != "noise_level" for k in extra_call_back_kwargs):
+            raise ValueError("mi355_flow: the FLUX rollout captures only 'noise_level' as an extra callback value")
+        kept = _resolve(trajectory_indices, N + 1)
+        keep_positions = list(range(N + 1)) if kept is None else sorted(kept)
+        lat_kept, log_probs, final = plan.rollout(ts_host, sig_host, eta_host, self.scheduler.dynamics_type, guidance_scale, latents,
+                                                  storage, step_noise, prompt_embeds, pooled_prompt_embeds,
+                                                  keep_positions=keep_positions, compute_log_prob=compute_log_prob)
+        pos_to_slot = {p: s for s, p in enumerate(keep_positions)}
+
+        latent_collector = create_trajectory_collector(trajectory_indices, N)
+        log_prob_collector = create_trajectory_collector(trajectory_indices, N) if compute_log_prob else None
+        callback_collector = create_callback_collector(trajectory_indices, N)
+        if latent_collector.should_collect(0):
+            latent_collector.collect(lat_kept[pos_to_slot[0]], 0)
+        for i in range(N):
+            if latent_collector.should_collect(i + 1):
+                latent_collector.collect(lat_kept[pos_to_slot[i + 1]], i + 1)
+            if compute_log_prob and eta_host[i] > 0:
+                log_prob_collector.collect(log_probs[i], i)
+            callback_collector.collect_step(step_idx=i, output=None, keys=extra_call_back_kwargs, capturable={"noise_level": eta_host[i]})
+
+        images = self.decode_latents(final, height, width, output_type="pt")
+        cb_res = callback_collector.get_result()
+        cb_map = callback_collector.get_index_map()
+        all_latents = latent_collector.get_result()
+        latent_index_map = latent_collector.get_index_map()
+        all_log_probs = log_prob_collector.get_result() if compute_log_prob else None
+        log_prob_index_map = log_prob_collector.get_index_map() if compute_log_prob else None
+        lat_stack = torch.stack(all_latents, dim=1) if all_latents else None
+        lp_stack = torch.stack(all_log_probs, dim=1) if all_log_probs else None
+        return [
+            Flux1Sample(
+                timesteps=timesteps,
+                all_latents=lat_stack[b] if lat_stack is not None else None,
+                log_probs=lp_stack[b] if lp_stack is not None else None,
+                latent_index_map=latent_index_map,
+                log_prob_index_map=log_prob_index_map,
+                prompt=prompt[b] if isinstance(prompt, list) else prompt,
+                prompt_ids=prompt_ids[b] if prompt_ids is not None else None,
+                prompt_embeds=prompt_embeds[b],
+                pooled_prompt_embeds=pooled_prompt_embeds[b],
+                height=height, width=width,
+                image=images[b] if images is not None else None,
+                img_ids=latent_image_ids,
+                extra_kwargs={**{k: v[b] for k, v in cb_res.items()}, "callback_index_map": cb_map},
+            )
+            for b in range(B)
+        ]
+
+    # ------------------------------------------------------------------ single step / replay (flux1.py:294-346), no-grad
+    @torch.no_grad()
+    def forward(
+        self,
+        t: torch.Tensor,
+        latents: torch.Tensor,
+        prompt_embeds: torch.Tensor,
+        pooled_prompt_embeds: torch.Tensor,
+        img_ids: Optional[torch.Tensor] = None,
+        t_next: Optional[torch.Tensor] = None,
+        next_latents: Optional[torch.Tensor] = None,
+        guidance_scale: Union[float, List[float]] = 3.5,
+        noise_level: Optional[float] = None,
+        joint_attention_kwargs: Optional[Dict[str, Any]] = None,
+        compute_log_prob: bool = True,
+        return_kwargs: List[str] = ["noise_pred", "next_latents", "next_latents_mean", "std_dev_t", "dt", "log_prob"],
+        height: Optional[int] = None,
+        width: Optional[int] = None,
+    ) -> SDESchedulerOutput:
+        if joint_attention_kwargs:
+            raise ValueError("mi355_flow: joint_attention_kwargs are not supported by the native engine")
+        B, Ni, _ = latents.shape
+        dev = latents.device
+        # the latent grid is recovered from img_ids (rows / cols) when given, else it must be square or passed explicitly
+        if img_ids is not None:
+            hp, wp = int(img_ids[:, 1].max().item()) + 1, int(img_ids[:, 2].max().item()) + 1
+        elif height is not None and width is not None:
+            hp, wp = int(height) // 16, int(width) // 16
+        else:
+            hp = wp = int(round(Ni ** 0.5))
+        if hp * wp != Ni:
+            raise ValueError(f"mi355_flow: cannot recover the latent grid of {Ni} packed tokens (pass img_ids or height/width)")
+        plan = self.engine.plan(B, 2 * hp, 2 * wp, prompt_embeds.shape[1], 1)
+        t = torch.as_tensor(t, device=dev, dtype=torch.float32).reshape(-1)
+        # timestep = t.expand(B) / 1000 (fp32); the model does `.to(latents.dtype) * 1000` (rounded again to that dtype)
+        tm = ((t.double() / 1000).float().to(latents.dtype) * 1000).float()   # exact quotient, as the fused rollout's host math
+        g = torch.as_tensor(guidance_scale, device=dev, dtype=latents.dtype).reshape(-1)
+        gm = (g * 1000).float()
+        v = plan.transformer_forward(latents, tm, gm if self.engine.cfg.guidance_embeds else None, prompt_embeds, pooled_prompt_embeds)
+        sched = self.scheduler
+        if t_next is None:
+            idx = [sched.index_for_timestep(x) for x in t]
+            t_next = torch.stack([sched.timesteps[j + 1] if j + 1 < len(sched.timesteps) else torch.zeros(()) for j in idx]).to(dev)
+        t_next = torch.as_tensor(t_next, device=dev, dtype=torch.float32).reshape(-1)
+        dyn = sched.dynamics_type
+        sigma, sigma_next = (t.double() / 1000).float(), (t_next.double() / 1000).float()   # exact fp32 quotients (see adapter.forward)
+        if sched.is_eval or dyn == "ODE":
+            noise_level = 0.0
+        elif noise_level is None:
+            noise_level = sched.get_noise_level_for_sigma(sigma)
+        noise = None
+        if next_latents is None and dyn != "ODE":
+            noise = torch.randn(latents.shape, device=dev, dtype=torch.float32)
+        want = tuple(k for k in return_kwargs if k in ("next_latents", "next_latents_mean", "noise_pred", "std_dev_t", "dt"))
+        o = sde_step(v, None, 1.0, latents, sigma, sigma_next, noise_level, float(sched.sigmas[1]), dyn, noise=noise,
+                     next_latents=next_latents, compute_log_prob=compute_log_prob, want=want)
+        view = (-1, 1, 1)
+        res = dict(
+            noise_pred=o.noise_pred,
+            next_latents=o.next_latents if next_latents is None else next_latents.float(),
+            next_latents_mean=o.next_latents_mean,
+            std_dev_t=o.std_dev_t.view(view) if o.std_dev_t is not None else None,
+            dt=o.dt.view(view) if o.dt is not None else None,
+            log_prob=o.log_prob if compute_log_prob else None,
+        )
+        return SDESchedulerOutput.from_dict({k: res[k] for k in return_kwargs if k in res})
+
+
+# ----------------------------------------------------------------------------- operator-level wrappers (tests, microbench)
+def op_attention128(q: torch.Tensor, k: torch.Tensor, vT: torch.Tensor, S: int, n_first: Optional[int] = None, q_prescaled: bool = False):
+    """q, k: [B, H, S_pad, 128] bf16; vT: [B, H, 128, S_pad] bf16 -> (o_first [B*n_first, H*128], o_rest [B*(S-n_first), H*128])."""
+    lib = _lib.load()
+    B, H, S_pad, _ = q.shape
+    n_first = S if n_first is None else n_first
+    D = H * 128
+    o1 = torch.empty((B * n_first, D), device=q.device, dtype=torch.bfloat16)
+    o2 = torch.empty((B * (S - n_first), D), device=q.device, dtype=torch.bfloat16) if n_first < S else None
+    _lib.check(lib.mi355_op_attention128(_stream(), _ptr(q), _ptr(k), _ptr(vT), _ptr(o1), D, n_first, _ptr(o2), D, B, H, S, S_pad,
+                                         int(q_prescaled)), "op_attention128")
+    return o1, o2
+
+
+def op_rope_norm(src: torch.Tensor, q_col: int, k_col: int, nw_q: torch.Tensor, nw_k: torch.Tensor, cos_sin: torch.Tensor, B: int, H: int,
+                 rows_per_sample: int, s_off: int, S_pad: int, eps: float = 1e-6, q_scale: float = 1.0):
+    """src [M, ld] bf16 (q at q_col, k at k_col); cos_sin [S, 64, 2] fp32 -> q, k [B, H, S_pad, 128] bf16 (zero elsewhere)."""
+    lib = _lib.load()
+    M = src.shape[0]
+    q = torch.zeros((B, H, S_pad, 128), device=src.device, dtype=torch.bfloat16)
+    k = torch.zeros_like(q)
+    _lib.check(lib.mi355_op_rope_norm(_stream(), _ptr(src), src.shape[1], q_col, k_col, _ptr(nw_q), _ptr(nw_k), _ptr(cos_sin), _ptr(q), _ptr(k),
+                                      M, H, rows_per_sample, s_off, S_pad, eps, q_scale), "op_rope_norm")
+    return q, k

@@ -56,3 +56,10 @@ class SD3_5Sample:
                 setattr(self, k, v.to(device))
         self.extra_kwargs = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in self.extra_kwargs.items()}
         return self
+
+
+@dataclass
+class Flux1Sample(SD3_5Sample):
+    """`Flux1Sample` (reference src/flow_factory/models/flux/flux1.py:53-60): packed latents `(P, Ni, 64)` in `all_latents`,
+    plus the `img_ids` shared by the batch.  No negative prompt (guidance is embedded)."""
+    img_ids: Optional[torch.Tensor] = None

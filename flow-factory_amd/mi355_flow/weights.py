@@ -136,3 +136,63 @@ def vae_decode_flops(cfg, h: int, w: int) -> float:
             mac += res * 9 * co * co
         prev = co
     return 2.0 * (mac + res * 9 * rev[-1] * cfg.out_channels)
+
+
+# --------------------------------------------------------------------------------- FLUX.1 transformer
+def expected_flux_shapes(cfg) -> Dict[str, Tuple[int, ...]]:
+    """HF `FluxTransformer2DModel` parameters for a `mi355_flow.flux.FluxConfig`."""
+    D, hd = cfg.dim, cfg.attention_head_dim
+    out: Dict[str, Tuple[int, ...]] = {}
+
+    def lin(n, o, i):
+        out[n + ".weight"], out[n + ".bias"] = (o, i), (o,)
+
+    lin("x_embedder", D, cfg.in_channels)
+    lin("context_embedder", D, cfg.joint_attention_dim)
+    for e in ["timestep_embedder"] + (["guidance_embedder"] if cfg.guidance_embeds else []):
+        lin(f"time_text_embed.{e}.linear_1", D, cfg.time_proj_dim)
+        lin(f"time_text_embed.{e}.linear_2", D, D)
+    lin("time_text_embed.text_embedder.linear_1", D, cfg.pooled_projection_dim)
+    lin("time_text_embed.text_embedder.linear_2", D, D)
+    for i in range(cfg.num_layers):
+        b = f"transformer_blocks.{i}"
+        lin(f"{b}.norm1.linear", 6 * D, D)
+        lin(f"{b}.norm1_context.linear", 6 * D, D)
+        for n in ("to_q", "to_k", "to_v", "add_q_proj", "add_k_proj", "add_v_proj", "to_out.0", "to_add_out"):
+            lin(f"{b}.attn.{n}", D, D)
+        for n in ("norm_q", "norm_k", "norm_added_q", "norm_added_k"):
+            out[f"{b}.attn.{n}.weight"] = (hd,)
+        lin(f"{b}.ff.net.0.proj", 4 * D, D); lin(f"{b}.ff.net.2", D, 4 * D)
+        lin(f"{b}.ff_context.net.0.proj", 4 * D, D); lin(f"{b}.ff_context.net.2", D, 4 * D)
+    for i in range(cfg.num_single_layers):
+        b = f"single_transformer_blocks.{i}"
+        lin(f"{b}.norm.linear", 3 * D, D)
+        lin(f"{b}.proj_mlp", 4 * D, D)
+        lin(f"{b}.proj_out", D, 5 * D)
+        for n in ("to_q", "to_k", "to_v"):
+            lin(f"{b}.attn.{n}", D, D)
+        for n in ("norm_q", "norm_k"):
+            out[f"{b}.attn.{n}.weight"] = (hd,)
+    lin("norm_out.linear", 2 * D, D)
+    lin("proj_out", cfg.in_channels, D)
+    return out
+
+
+def synthetic_flux_state_dict(cfg, device="cuda", seed: int = 2468, std: float = 0.02, dtype: torch.dtype = torch.bfloat16):
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for name, shape in expected_flux_shapes(cfg).items():
+        t = torch.randn(shape, generator=g, device=device, dtype=torch.float32) * std
+        if ".norm_" in name and len(shape) == 1:
+            t = t + 1.0
+        sd[name] = t.to(dtype)
+    return sd
+
+
+def flux_forward_flops(cfg, Ni: int, Nt: int) -> float:
+    """Algorithmic matmul FLOPs of one FLUX forward for one sample (2 FLOP/MAC; conditioning MLPs / modulation linears excluded)."""
+    D, S = cfg.dim, Ni + Nt
+    dbl = cfg.num_layers * (S * 12 * D * D + 2 * S * S * D)
+    sgl = cfg.num_single_layers * (S * 12 * D * D + 2 * S * S * D)
+    emb = Ni * cfg.in_channels * D + Nt * cfg.joint_attention_dim * D + Ni * D * cfg.in_channels
+    return 2.0 * (dbl + sgl + emb)

@@ -168,6 +168,47 @@ int64_t mi355_vae_plan_workspace_bytes(mi355_vae_plan* plan);
 int mi355_vae_decode(mi355_vae_plan* plan, void* stream, const void* latents, int lat_dtype, int batch, void* images,
                      int img_dtype, int postprocess);
 
+/* ---- FLUX.1 rollout ------------------------------------------------------
+ * Replaces `self.transformer(hidden_states=packed latents, timestep=t/1000, guidance, pooled_projections,
+ * encoder_hidden_states, txt_ids=0, img_ids)` + `self.scheduler.step(...)` in Flux1Adapter.inference / .forward
+ * (reference src/flow_factory/models/flux/flux1.py:151-289 loop, :294-346 forward).  Weights bind by the HF names of
+ * diffusers' FluxTransformer2DModel.  Latents are PACKED: [B][(h/2)*(w/2)][in_channels = 64]. */
+typedef struct mi355_flux mi355_flux;
+typedef struct mi355_flux_plan mi355_flux_plan;
+typedef struct mi355_flux_cfg {
+    int32_t in_channels, num_layers, num_single_layers, num_heads, head_dim;
+    int32_t joint_attention_dim, pooled_projection_dim, guidance_embeds, time_proj_dim;
+    int32_t axes_dims_rope[3];
+    float eps;
+} mi355_flux_cfg;
+int mi355_flux_create(const mi355_flux_cfg* cfg, mi355_flux** out);
+int mi355_flux_destroy(mi355_flux* e);
+int mi355_flux_bind_weight(mi355_flux* e, const char* name, const void* src, int dtype, int ndim, const int64_t* shape,
+                           void* stream);
+int mi355_flux_weights_ready(mi355_flux* e);
+int mi355_flux_num_params(mi355_flux* e);
+const char* mi355_flux_param_name(mi355_flux* e, int i);
+/* latent_h x latent_w = the UNPACKED latent grid (e.g. 128 x 128 for 1024^2); n_text = T5 sequence length */
+int mi355_flux_plan_create(mi355_flux* e, int batch, int latent_h, int latent_w, int n_text, int max_steps,
+                           mi355_flux_plan** out);
+int mi355_flux_plan_destroy(mi355_flux_plan* plan);
+int64_t mi355_flux_plan_workspace_bytes(mi355_flux_plan* plan);
+/* transformer only: t_model / guidance_model = the values the network embeds (device fp32 [B]); v_out bf16 packed */
+int mi355_flux_forward(mi355_flux_plan* plan, void* stream, const void* latents, int lat_dtype, const float* t_model,
+                       const float* guidance_model, const void* prompt_embeds, const void* pooled, void* v_out);
+/* the whole N-step loop, zero host syncs; arguments as mi355_rollout (no negative prompt: guidance is embedded) */
+int mi355_flux_rollout(mi355_flux_plan* plan, void* stream, int n_steps, const float* timesteps_host, const float* sigmas_host,
+                       const float* noise_levels_host, int dynamics, float guidance_scale, const void* init_latents,
+                       int init_dtype, int storage_dtype, const float* step_noise, const void* prompt_embeds, const void* pooled,
+                       const int32_t* keep_slot_host, void* out_latents, float* out_log_probs, void* out_final,
+                       int compute_log_prob);
+/* head_dim-128 attention / RMSNorm+RoPE operators (unit tests) */
+int mi355_op_attention128(void* stream, const void* q, const void* k, const void* vT, void* o_first, int64_t ld_first,
+                          int n_first, void* o_rest, int64_t ld_rest, int B, int H, int S, int S_pad, int q_prescaled);
+int mi355_op_rope_norm(void* stream, const void* src, int64_t src_ld, int q_col, int k_col, const float* nw_q,
+                       const float* nw_k, const float* cos_sin, void* q_out, void* k_out, int M, int H, int rows_per_sample,
+                       int s_off, int S_pad, float eps, float q_scale);
+
 /* VAE operator-level entry points (unit tests / microbenchmarks).  NHWC bf16 activations.
  * conv3x3: x [B][H>>up][W>>up][Cin] (Cin % 64 == 0), w_packed [Cout][9][Cin] bf16 (mi355_op_conv_repack), padding 1,
  * optional nearest-2x upsample of x folded in, optional residual [B*H*W][Cout] added (may alias out) -> out [B*H*W][Cout] */
