@@ -219,19 +219,29 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn128_kernel(Attn128Params p)
     }
 }
 
-}  // namespace
+int g_attn128_variant = 0;   // 0: 8 waves x 32 queries, 1 workgroup / CU; 1: 4 waves, 2 workgroups / CU (independent barrier domains)
 
-hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream) {
-    if (p.S <= 0 || p.S_pad % KV != 0 || p.S_pad < p.S || p.n_first < 0 || p.n_first > p.S) return hipErrorInvalidValue;
-    auto kern = attn128_kernel<8>;
+template <int NWAVE>
+hipError_t launch128(const Attn128Params& p, hipStream_t stream) {
+    auto kern = attn128_kernel<NWAVE>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(((p.S + 255) / 256) * p.H * p.B), dim3(512), 2 * STAGE_BYTES, stream, p);
+    constexpr int QB = 32 * NWAVE;
+    hipLaunchKernelGGL(kern, dim3(((p.S + QB - 1) / QB) * p.H * p.B), dim3(NWAVE * 64), 2 * STAGE_BYTES, stream, p);
     return hipGetLastError();
+}
+
+}  // namespace
+
+void set_attn128_variant(int v) { g_attn128_variant = v; }
+
+hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream) {
+    if (p.S <= 0 || p.S_pad % KV != 0 || p.S_pad < p.S || p.n_first < 0 || p.n_first > p.S) return hipErrorInvalidValue;
+    return g_attn128_variant == 1 ? launch128<4>(p, stream) : launch128<8>(p, stream);
 }
 
 }  // namespace mi355

@@ -780,6 +780,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 2) { g_use_graph = value; return 0; }
     if (key == 3) { set_pp_min_tiles(value); return 0; }
     if (key == 4) { set_conv_cfg(value); return 0; }
+    if (key == 5) { set_attn128_variant(value); return 0; }
     return fail("mi355_tune_set: unknown key %d", key);
 }
 

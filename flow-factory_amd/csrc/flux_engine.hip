@@ -602,7 +602,7 @@ extern "C" int mi355_flux_rollout(mi355_flux_plan* p, void* stream, int n_steps,
 // ----------------------------------------------------------------------- operator-level API
 extern "C" int mi355_op_attention128(void* stream, const void* q, const void* k, const void* vT, void* o_first, int64_t ld_first,
                                      int n_first, void* o_rest, int64_t ld_rest, int B, int H, int S, int S_pad, int q_prescaled) {
-    if (!q || !k || !vT || !o_first) return errorf("mi355_op_attention128: null argument");
+    if (!q || !k || !vT || (n_first > 0 && !o_first)) return errorf("mi355_op_attention128: null argument");
     if (n_first < S && !o_rest) return errorf("mi355_op_attention128: o_rest is NULL but n_first < S");
     Attn128Params a;
     memset(&a, 0, sizeof(a));

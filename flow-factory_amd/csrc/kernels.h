@@ -87,6 +87,7 @@ struct Attn128Params {
     int q_prescaled;   // 1: q carries log2(e)/sqrt(128) already (rope_norm kernel)
 };
 hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream);
+void set_attn128_variant(int v);   // 0: 8-wave workgroups (default), 1: 4-wave workgroups
 
 // per-head RMSNorm (weight, eps) + rotary embedding of the q and k projections (flux_ops.hip):
 //   src rows [M][src_ld]: q at column q_col + h*128, k at k_col + h*128 (bf16, bias already added);

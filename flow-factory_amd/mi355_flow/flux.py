@@ -447,7 +447,7 @@ def op_attention128(q: torch.Tensor, k: torch.Tensor, vT: torch.Tensor, S: int, 
     D = H * 128
     o1 = torch.empty((B * n_first, D), device=q.device, dtype=torch.bfloat16)
     o2 = torch.empty((B * (S - n_first), D), device=q.device, dtype=torch.bfloat16) if n_first < S else None
-    _lib.check(lib.mi355_op_attention128(_stream(), _ptr(q), _ptr(k), _ptr(vT), _ptr(o1), D, n_first, _ptr(o2), D, B, H, S, S_pad,
+    _lib.check(lib.mi355_op_attention128(_stream(), _ptr(q), _ptr(k), _ptr(vT), _ptr(o1) if n_first > 0 else None, D, n_first, _ptr(o2), D, B, H, S, S_pad,
                                          int(q_prescaled)), "op_attention128")
     return o1, o2
 

@@ -262,6 +262,20 @@ def gen_vae_tiny():
     np.savez_compressed(os.path.join(OUT, "vae_tiny_self.npz"), raw=_np(raw), img_bf16=_np(img))
 
 
+def gen_flux_tiny():
+    """[SELF] FLUX.1 transformer restatement (parity unpinned, oracle/flux_ref.py): drift guard only."""
+    from oracle import flux_ref as Fx
+    cfg = Fx.tiny_config()
+    sd = Fx.make_synthetic_state_dict(cfg, seed=31)
+    g = torch.Generator().manual_seed(32)
+    B, h, w, Nt = 2, 4, 6, 5
+    x = Fx.pack_latents(torch.randn(B, 16, h, w, generator=g))
+    enc = torch.randn(B, Nt, cfg.joint_attention_dim, generator=g)
+    pool = torch.randn(B, cfg.pooled_projection_dim, generator=g)
+    y = Fx.flux_forward(sd, cfg, x, torch.tensor([0.9, 0.4]), torch.tensor([3.5, 3.5]), pool, enc, Fx.prepare_img_ids(h // 2, w // 2))
+    np.savez_compressed(os.path.join(OUT, "flux_tiny_self.npz"), y=_np(y))
+
+
 # ------------------------------------------------------------------ [REF] group-contiguous sampler (DP partitioner)
 def gen_sampler():
     import importlib.util
@@ -295,6 +309,7 @@ def main():
     gen_advantages()
     gen_mmdit_tiny()
     gen_vae_tiny()
+    gen_flux_tiny()
     gen_sampler()
     print(f"wrote fixtures to {OUT} ({n} scheduler step cases)")
 

@@ -22,13 +22,18 @@ def main():
         B, H, S = a.batch, 24, (a.size // 16) ** 2 + a.n_text
         S_pad = (S + 63) // 64 * 64
         q = torch.randn(B, H, S_pad, 128, device=dev).bfloat16(); k = torch.randn_like(q); vT = torch.randn(B, H, 128, S_pad, device=dev).bfloat16()
-        flux.op_attention128(q, k, vT, S); torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10): flux.op_attention128(q, k, vT, S)
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
-        print(json.dumps({"op": "attention128", "B": B, "H": H, "S": S, "ms": round(ms, 3), "tflops": round(4.0 * B * H * S * S * 128 / ms / 1e9, 1)}))
+        from mi355_flow import _lib
+        for var in (0, 1, 0, 1):
+            _lib.check(_lib.load().mi355_tune_set(5, var))
+            flux.op_attention128(q, k, vT, S); torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): flux.op_attention128(q, k, vT, S)
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            print(json.dumps({"op": "attention128", "variant": var, "B": B, "H": H, "S": S, "ms": round(ms, 3),
+                              "tflops": round(4.0 * B * H * S * S * 128 / ms / 1e9, 1)}))
+        _lib.check(_lib.load().mi355_tune_set(5, 0))
         return
     cfg = flux.FluxConfig()
     sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=1, seed=42, dynamics_type="Flow-SDE",

@@ -133,6 +133,35 @@ def test_vae_oracle_self_consistency():
     assert (vae_ref.vae_decode(sd2, cfg, lat, postprocess=False) - raw).abs().max() > 1e-3
 
 
+def test_flux_oracle_self_consistency():
+    """[SELF] fixture for the (unpinned) FluxTransformer2DModel restatement + public architecture facts: FLUX.1-dev has
+    11 901 408 320 parameters; RoPE is a rotation (norm preserving) and the identity on the text tokens (ids = 0)."""
+    from oracle import flux_ref as Fx
+    z = _load("flux_tiny_self.npz")
+    cfg = Fx.tiny_config()
+    sd = Fx.make_synthetic_state_dict(cfg, seed=31)
+    g = torch.Generator().manual_seed(32)
+    B, h, w, Nt = 2, 4, 6, 5
+    lat = torch.randn(B, 16, h, w, generator=g)
+    x = Fx.pack_latents(lat)
+    assert torch.equal(Fx.unpack_latents(x, h, w), lat)
+    enc = torch.randn(B, Nt, cfg.joint_attention_dim, generator=g)
+    pool = torch.randn(B, cfg.pooled_projection_dim, generator=g)
+    ids = Fx.prepare_img_ids(h // 2, w // 2)
+    y = Fx.flux_forward(sd, cfg, x, torch.tensor([0.9, 0.4]), torch.tensor([3.5, 3.5]), pool, enc, ids)
+    np.testing.assert_allclose(y.numpy(), z["y"], rtol=1e-4, atol=1e-5)
+    assert sum(int(np.prod(s)) for s in Fx.state_dict_shapes(Fx.FLUX1_DEV).values()) == 11_901_408_320
+    cos, sin = Fx.rope_cos_sin(torch.cat([torch.zeros(Nt, 3), ids], 0))
+    v = torch.randn(1, 2, Nt + ids.shape[0], 128, generator=g)
+    r = Fx.apply_rope(v, cos, sin)
+    torch.testing.assert_close(r.norm(dim=-1), v.norm(dim=-1), rtol=1e-5, atol=1e-5)
+    assert torch.equal(r[:, :, :Nt], v[:, :, :Nt])
+    # single-stream blocks matter
+    sd2 = dict(sd)
+    sd2["single_transformer_blocks.1.proj_out.weight"] = sd["single_transformer_blocks.1.proj_out.weight"] * 0
+    assert (Fx.flux_forward(sd2, cfg, x, torch.tensor([0.9, 0.4]), torch.tensor([3.5, 3.5]), pool, enc, ids) - y).abs().max() > 1e-4
+
+
 def test_flops_formula():
     # SURVEY.md 8(d): F(4096,333) = 1.125e13, F(256,333) = 9.09e11
     assert abs(mmditx_ref.forward_flops(mmditx_ref.SD35_MEDIUM, 4096, 333) / 1.125e13 - 1) < 2e-3
