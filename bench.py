@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--kernel-timing", choices=["attention", "all"], default="attention",
                     help="hipEvent brackets in the timed region: the dominant kernel only (default) or every class")
     ap.add_argument("--pp-min-tiles", type=int, default=None, help="(tuning) smallest 256x256-tile grid that uses the ping-pong GEMM")
+    ap.add_argument("--model", choices=["sd3_5", "flux1"], default="sd3_5",
+                    help="sd3_5 = BASELINE.json configs[1] (the metric's config); flux1 = FLUX.1-dev geometry (configs[2], SURVEY 8(f) N3)")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed w.r.t. `value`) VAE-decode leg")
     ap.add_argument("--no-graph", action="store_true", help="launch the rollout eagerly instead of replaying the hipGraph")
     args = ap.parse_args()
@@ -124,27 +126,50 @@ def main():
     from mi355_flow.trajectory import compute_trajectory_indices
     from mi355_flow.weights import synthetic_state_dict
 
-    cfg = TransformerConfig()  # SD3.5-medium
-    torch.manual_seed(42 + rank)  # reference: set_seed(seed, device_specific=True) (trainers/loader.py:70)
-    sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=1, seed=42,
-                                               dynamics_type="Flow-SDE", shift=3.0)
-    adapter = SD3_5NativeAdapter(synthetic_state_dict(cfg, device=dev, seed=1234), cfg, sched, latent_storage_dtype="fp16",
-                                 device=dev)
+    flux_mode = args.model == "flux1"
     B, N = args.batch, args.denoise_steps
-    cfg_on = args.guidance > 1.0
     g = torch.Generator(device=dev).manual_seed(4321 + rank)
-    pe = torch.randn(B, N_TEXT, cfg.joint_attention_dim, device=dev, generator=g).bfloat16()
-    pp = torch.randn(B, cfg.pooled_projection_dim, device=dev, generator=g).bfloat16()
-    ne = torch.randn(B, N_TEXT, cfg.joint_attention_dim, device=dev, generator=g).bfloat16() if cfg_on else None
-    npl = torch.randn(B, cfg.pooled_projection_dim, device=dev, generator=g).bfloat16() if cfg_on else None
-    adapter.rollout()
-    traj = compute_trajectory_indices(sched.train_timesteps, N)
+    torch.manual_seed(42 + rank)  # reference: set_seed(seed, device_specific=True) (trainers/loader.py:70)
+    if flux_mode:
+        from mi355_flow.flux import Flux1NativeAdapter, FluxConfig
+        from mi355_flow.weights import flux_forward_flops, synthetic_flux_state_dict
+        cfg = FluxConfig()  # FLUX.1-dev
+        n_text = 512
+        sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=1, seed=42,
+                                                   dynamics_type="Flow-SDE", shift=3.0, use_dynamic_shifting=True)
+        adapter = Flux1NativeAdapter(synthetic_flux_state_dict(cfg, device=dev, seed=1234), cfg, sched, latent_storage_dtype="fp16", device=dev)
+        torch.cuda.empty_cache()
+        cfg_on = False
+        if args.guidance == 1.0:
+            args.guidance = 3.5   # embedded guidance (examples/grpo/full/flux1/default.yaml); no second forward
+        pe = torch.randn(B, n_text, cfg.joint_attention_dim, device=dev, generator=g).bfloat16()
+        pp = torch.randn(B, cfg.pooled_projection_dim, device=dev, generator=g).bfloat16()
+        adapter.rollout()
+        traj = compute_trajectory_indices(sched.train_timesteps, N)
 
-    def one_rollout():
-        return adapter.inference(prompt=None, height=args.size, width=args.size, num_inference_steps=N,
-                                 guidance_scale=args.guidance, prompt_embeds=pe, pooled_prompt_embeds=pp,
-                                 negative_prompt_embeds=ne, negative_pooled_prompt_embeds=npl, compute_log_prob=True,
-                                 trajectory_indices=traj)
+        def one_rollout():
+            return adapter.inference(prompt=None, height=args.size, width=args.size, num_inference_steps=N, guidance_scale=args.guidance,
+                                     prompt_embeds=pe, pooled_prompt_embeds=pp, compute_log_prob=True, trajectory_indices=traj)
+    else:
+        cfg = TransformerConfig()  # SD3.5-medium
+        n_text = N_TEXT
+        sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=1, seed=42,
+                                                   dynamics_type="Flow-SDE", shift=3.0)
+        adapter = SD3_5NativeAdapter(synthetic_state_dict(cfg, device=dev, seed=1234), cfg, sched, latent_storage_dtype="fp16",
+                                     device=dev)
+        cfg_on = args.guidance > 1.0
+        pe = torch.randn(B, N_TEXT, cfg.joint_attention_dim, device=dev, generator=g).bfloat16()
+        pp = torch.randn(B, cfg.pooled_projection_dim, device=dev, generator=g).bfloat16()
+        ne = torch.randn(B, N_TEXT, cfg.joint_attention_dim, device=dev, generator=g).bfloat16() if cfg_on else None
+        npl = torch.randn(B, cfg.pooled_projection_dim, device=dev, generator=g).bfloat16() if cfg_on else None
+        adapter.rollout()
+        traj = compute_trajectory_indices(sched.train_timesteps, N)
+
+        def one_rollout():
+            return adapter.inference(prompt=None, height=args.size, width=args.size, num_inference_steps=N,
+                                     guidance_scale=args.guidance, prompt_embeds=pe, pooled_prompt_embeds=pp,
+                                     negative_prompt_embeds=ne, negative_pooled_prompt_embeds=npl, compute_log_prob=True,
+                                     trajectory_indices=traj)
 
     def fence():
         if world > 1:
@@ -156,7 +181,7 @@ def main():
         lib.mi355_tune_set(3, args.pp_min_tiles)
     for _ in range(args.warmup):
         samples = one_rollout()
-    if not args.no_selfcheck:
+    if not args.no_selfcheck and not flux_mode:
         # untimed sanity net: the same seeded rollout through the first-correct-path kernels (simple GEMM schedule,
         # plain online softmax, eager launches) must reproduce the shipped kernels' trajectory
         def seeded():
@@ -172,7 +197,7 @@ def main():
         rel = float((lat_a - lat_b).norm() / lat_b.norm())
         if not (rel < 2e-2 and torch.allclose(lp_a, lp_b, rtol=1e-3)):
             raise SystemExit(f"bench selfcheck failed: kernel variants disagree (latents rel-L2 {rel:.3e}, log-probs {lp_a.tolist()} vs {lp_b.tolist()})")
-    timing = not args.no_kernel_timing
+    timing = not args.no_kernel_timing and not flux_mode   # (per-class hipEvent brackets exist in the SD3.5 engine only)
     fence()
     if args.no_graph:
         lib.mi355_tune_set(2, 0)
@@ -199,19 +224,21 @@ def main():
 
     n_cfg = 2 if cfg_on else 1
     lat = args.size // 8
-    Ni = (lat // cfg.patch_size) ** 2
+    Ni = (lat // 2) ** 2
     denoise_steps_total = B * N * args.steps * world
     value = denoise_steps_total / elapsed
-    F = forward_flops(cfg, Ni, N_TEXT)
+    F = flux_forward_flops(cfg, Ni, n_text) if flux_mode else forward_flops(cfg, Ni, N_TEXT)
     fwd_tflops = n_cfg * F * (B * N * args.steps) / elapsed / 1e12  # per GPU
     out = {
-        "metric": "denoise-steps/sec (whole node), SD3.5-medium 1024^2 GRPO rollout", "value": round(value, 3),
+        "metric": ("denoise-steps/sec (whole node), FLUX.1-dev 1024^2 GRPO rollout" if flux_mode else
+                   "denoise-steps/sec (whole node), SD3.5-medium 1024^2 GRPO rollout"), "value": round(value, 3),
         "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"SD3.5-medium T2I GRPO rollout, {args.size}x{args.size}, {N} denoise steps (Flow-SDE, 1 SDE step, "
+        "config": {"workload": f"{'FLUX.1-dev (11.9 B parameters, embedded guidance)' if flux_mode else 'SD3.5-medium'} T2I GRPO rollout, "
+                               f"{args.size}x{args.size}, {N} denoise steps (Flow-SDE, 1 SDE step, "
                                f"log-prob fused), batch {B}/GPU, n_cfg={n_cfg}, fp16 latent storage; 1 bench step = 1 rollout micro-batch",
-                   "global_batch": B * world, "tokens_per_sample": Ni + N_TEXT, "n_cfg": n_cfg, "denoise_steps": N,
+                   "global_batch": B * world, "tokens_per_sample": Ni + n_text, "n_cfg": n_cfg, "denoise_steps": N,
                    "parallelism": f"dp{world} (rollout shards by prompt group, no data-path collective)"},
     }
     if timing and rank == 0:
@@ -237,12 +264,16 @@ def main():
                         "flops_per_forward_per_sample": F, "note": "wall-clock of the whole rollout incl. host glue; north-star target 0.40"},
             "by_class": by_class,
         }
+    if flux_mode and rank == 0:
+        out["roofline"] = {"bound": "mfma", "kernel": "whole FLUX.1 forward (MFMA GEMMs + head_dim-128 attention), wall-clock of the rollout",
+                           "achieved": round(fwd_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fwd_tflops / PEAK_BF16_TFLOPS, 4),
+                           "traffic": None, "flops_per_forward_per_sample": F}
     if rank == 0 and not args.no_vae:
         # image decode that closes the reference's rollout (sd3_5.py:307): reported beside the metric,
         # not inside it -- `value` counts denoise steps, the decode is once per sample
         from mi355_flow.vae import VAEConfig, VAEDecoder
         from mi355_flow.weights import synthetic_vae_state_dict, vae_decode_flops
-        vcfg = VAEConfig()
+        vcfg = VAEConfig(scaling_factor=0.3611, shift_factor=0.1159) if flux_mode else VAEConfig()
         dec = VAEDecoder(vcfg)
         dec.bind_state_dict(synthetic_vae_state_dict(vcfg, device=dev))
         dec.ready()
@@ -264,7 +295,7 @@ def main():
         assert bool(torch.isfinite(img.float()).all())
         dec.close()
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not flux_mode:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -85,9 +85,78 @@ if _RefAdapter is not None:  # pragma: no cover
             self._sync_weights()
             return NativeRolloutMixin.forward(self, *args, **kwargs)
 
+    try:
+        from flow_factory.models.flux.flux1 import Flux1Adapter as _RefFlux
+    except Exception:  # noqa: BLE001
+        _RefFlux = None
+
+    if _RefFlux is not None:
+        from .flux import Flux1NativeAdapter as _FluxMirror, FluxConfig, FluxEngine, unpack_latents
+
+        class Flux1NativeAdapter(_RefFlux):
+            """`Flux1Adapter` (flux1.py) with the GRPO rollout on the MI355X engine: `model.model_type:
+            mi355_flow.flow_factory_plugin.Flux1NativeAdapter`.  inference() / no-grad forward() / decode_latents() are the
+            standalone mirror's methods (same signatures as the reference's), bound onto the reference adapter."""
+
+            def __init__(self, config, accelerator):
+                _RefFlux.__init__(self, config, accelerator)
+                tc = self.pipeline.transformer.config
+                self.engine = FluxEngine(FluxConfig(
+                    in_channels=tc.in_channels, num_layers=tc.num_layers, num_single_layers=tc.num_single_layers,
+                    num_attention_heads=tc.num_attention_heads, attention_head_dim=tc.attention_head_dim,
+                    joint_attention_dim=tc.joint_attention_dim, pooled_projection_dim=tc.pooled_projection_dim,
+                    guidance_embeds=bool(tc.guidance_embeds), axes_dims_rope=tuple(tc.axes_dims_rope)))
+                self._bound_version, self._weights_version = -1, 0
+                self.vae_max_batch = 4
+                self.vae_decoder = VAEDecoder(VAEConfig.from_hf(self.pipeline.vae.config))
+                self.vae_decoder.bind_state_dict(self.pipeline.vae.state_dict())
+                self.vae_decoder.ready()
+
+            @property
+            def transformer_dtype(self):
+                return self.pipeline.transformer.dtype
+
+            def _sync_weights(self):
+                if self._bound_version != self._weights_version:
+                    self.engine.bind_state_dict(self.accelerator.unwrap_model(self.transformer).state_dict())
+                    self.engine.ready()
+                    self._bound_version = self._weights_version
+
+            def rollout(self, *a, **k):
+                self._weights_version += 1
+                return _RefFlux.rollout(self, *a, **k)
+
+            def eval(self, *a, **k):
+                self._weights_version += 1
+                return _RefFlux.eval(self, *a, **k)
+
+            @torch.no_grad()
+            def decode_latents(self, latents, height, width, output_type="pil"):
+                lat = unpack_latents(latents, int(height) // 8, int(width) // 8).contiguous()
+                if output_type == "pt":
+                    return self.vae_decoder.decode(lat, postprocess=True, out_dtype=torch.bfloat16, max_batch=self.vae_max_batch)
+                images = self.vae_decoder.decode(lat, postprocess=False, out_dtype=torch.bfloat16, max_batch=self.vae_max_batch)
+                return self.pipeline.image_processor.postprocess(images, output_type=output_type)
+
+            @torch.no_grad()
+            def inference(self, *args, **kwargs):
+                self._sync_weights()
+                return _FluxMirror.inference(self, *args, **kwargs)
+
+            def forward(self, *args, **kwargs):
+                if torch.is_grad_enabled():          # optimize(): autograd stays on the reference path (SURVEY.md 8(f) N1)
+                    return _RefFlux.forward(self, *args, **kwargs)
+                self._sync_weights()
+                return _FluxMirror.forward(self, *args, **kwargs)
+
 else:
 
     class SD3_5NativeAdapter:  # type: ignore[no-redef]
         def __init__(self, *a, **k):
             raise ImportError("mi355_flow.flow_factory_plugin needs an importable `flow_factory` (with diffusers/peft): "
                               f"{_IMPORT_ERROR!r}.  Use mi355_flow.adapter.SD3_5NativeAdapter standalone instead.")
+
+    class Flux1NativeAdapter:  # type: ignore[no-redef]
+        def __init__(self, *a, **k):
+            raise ImportError("mi355_flow.flow_factory_plugin needs an importable `flow_factory` (with diffusers/peft): "
+                              f"{_IMPORT_ERROR!r}.  Use mi355_flow.flux.Flux1NativeAdapter standalone instead.")
