@@ -272,8 +272,8 @@ extern "C" int mi355_engine_create(const mi355_model_cfg* cfg, mi355_engine** ou
     hipError_t e2 = hipMalloc((void**)&e->arena32, e->cap32);
     if (e1 != hipSuccess || e2 != hipSuccess) {
         int r = fail("mi355_engine_create: hipMalloc of %zu + %zu bytes failed", e->cap16, e->cap32);
-        if (e->arena16) hipFree(e->arena16);
-        if (e->arena32) hipFree(e->arena32);
+        if (e->arena16) (void)hipFree(e->arena16);
+        if (e->arena32) (void)hipFree(e->arena32);
         delete e;
         return r;
     }
@@ -284,8 +284,8 @@ extern "C" int mi355_engine_create(const mi355_model_cfg* cfg, mi355_engine** ou
 
 extern "C" int mi355_engine_destroy(mi355_engine* e) {
     if (!e) return 0;
-    if (e->arena16) hipFree(e->arena16);
-    if (e->arena32) hipFree(e->arena32);
+    if (e->arena16) (void)hipFree(e->arena16);
+    if (e->arena32) (void)hipFree(e->arena32);
     delete e;
     return 0;
 }
@@ -397,7 +397,7 @@ extern "C" int mi355_plan_create(mi355_engine* e, int batch, int n_cfg, int late
     }
     // zero once: the padded key rows / columns of q,k,vT must stay finite (attention masks them)
     if (hipMemset(p->ws, 0, off) != hipSuccess) {
-        hipFree(p->ws);
+        (void)hipFree(p->ws);
         delete p;
         return fail("mi355_plan_create: hipMemset failed");
     }
