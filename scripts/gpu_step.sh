@@ -1,3 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 600 python scripts/attn_ab.py > gpurun_out/attn_ab.log 2>&1; cat gpurun_out/attn_ab.log
+timeout 900 python -m pytest tests/test_gpu_flux.py -q -k "full_width" 2>&1 | tail -5

@@ -155,3 +155,28 @@ def test_flux_errors(fx):
     with pytest.raises(RuntimeError, match="must be even"):
         eng.plan(1, 5, 4, 8, 1)
     eng.close()
+
+
+def test_flux_full_width_blocks_large_grid_dispatch(fx):
+    """FLUX.1-dev WIDTH (D = 3072, 24 heads x 128, T5 width 4096) with 1 double + 2 single blocks at a token count that takes the
+    large-grid paths (persistent ping-pong GEMMs incl. the K = 15 360 proj_out, 8-wave attention128, EPI_VT head_dim 128)."""
+    from oracle import flux_ref as R
+    cfg_o = R.FluxConfig(num_layers=1, num_single_layers=2)
+    sd = {k: _bf(v) for k, v in R.make_synthetic_state_dict(cfg_o, seed=5, std=0.02).items()}
+    cfg = fx.FluxConfig(num_layers=1, num_single_layers=2)
+    eng = fx.FluxEngine(cfg)
+    eng.bind_state_dict({k: v.cuda() for k, v in sd.items()})
+    eng.ready()
+    B, h, w, Nt = 4, 64, 64, 512
+    g = torch.Generator().manual_seed(3)
+    x = R.pack_latents(torch.randn(B, 16, h, w, generator=g)).half()
+    enc = _bf(torch.randn(B, Nt, 4096, generator=g))
+    pool = _bf(torch.randn(B, 768, generator=g))
+    tm = torch.tensor([875.0, 600.0, 310.5, 48.0])
+    gm = torch.full((B,), 3500.0)
+    plan = eng.plan(B, h, w, Nt, 1)
+    got = plan.transformer_forward(x.cuda(), tm, gm, enc.cuda(), pool.cuda()).float().cpu()
+    ref = R.flux_forward(sd, cfg_o, x.float(), tm, gm, pool, enc, R.prepare_img_ids(h // 2, w // 2), premultiplied=True)
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < 2e-2, rel
+    eng.close()
