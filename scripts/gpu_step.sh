@@ -1,3 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_flux.py -q -k "full_width" 2>&1 | tail -5
+timeout 120 ./scripts/mb/mfma_valu_mix 2>&1 | tee gpurun_out/mfma_valu_mix.log
