@@ -1,3 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 120 ./scripts/mb/mfma_valu_mix 2>&1 | tee gpurun_out/mfma_valu_mix.log
+timeout 300 python scripts/flux_bench.py --attn-only 2>&1 | tee gpurun_out/flux_attn_ab.log
