@@ -682,9 +682,14 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
     // the ping-pong kernel addresses its operands with 32-bit byte offsets from the base pointers
     const bool fits32 = ((size_t)p.M * (size_t)p.lda + (size_t)p.K) * 2 < (1ull << 32) &&
                         ((size_t)p.N * (size_t)p.ldw + (size_t)p.K) * 2 < (1ull << 32);
+    // wave quantisation: the ping-pong kernel runs ceil(tiles256 / 256 CUs) rounds of one 256x256 tile (= 4 units of 128x128 work);
+    // the 128x128 kernel ceil(tiles128 / 512) rounds of two co-resident tiles at ~72 % of the ping-pong per-tile rate (measured,
+    // profiles/r01_gemm_variants.txt).  E.g. the text stream at B=8 (M = 2664): q|k 132 big tiles = half the CUs idle -> 128x128.
+    const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    const double cost_pp = 4.0 * (double)((big + 255) / 256), cost_128 = 2.78 * (double)((t128 + 511) / 512);
     if constexpr (EPI != EPI_UNPATCH) {   // (proj_out, N = 64: scalar-scatter epilogue, always the 128x128 kernel)
-        if (big >= g_pp_min_tiles && fits32) return launch_pp<EPI>(p, stream);
-        if (big >= 200) return launch_cfg<256, 256, 2, 4, EPI>(p, stream);    // > 4 GiB operand (FLUX modulation table)
+        if (big >= g_pp_min_tiles && fits32 && cost_pp <= cost_128) return launch_pp<EPI>(p, stream);
+        if (big >= 200 && !fits32) return launch_cfg<256, 256, 2, 4, EPI>(p, stream);    // > 4 GiB operand (FLUX modulation table)
     }
     return launch_cfg<128, 128, 2, 2, EPI>(p, stream);
 }

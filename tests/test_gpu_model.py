@@ -201,3 +201,27 @@ def test_full_size_model_256(eng_full=None):
         assert r < 3e-2, r
     finally:
         e.close()
+
+
+def test_sd35_large_width_blocks():
+    """The same adapter serves SD3.5-LARGE (38 blocks, 38 heads x 64 = 2432 wide, no dual-attention layers, pos_embed_max_size 192):
+    here its width with 2 blocks (the last one context_pre_only) at 512x512, B = 2, vs the fp32 oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import mmditx_ref as M
+    cfg = M.tiny_config(num_layers=2, num_heads=38, dual_layers=(), joint_attention_dim=4096, pooled_projection_dim=2048,
+                        pos_embed_max_size=192)
+    engine, e, sd = _setup(cfg, std=0.02, seed=99)
+    try:
+        g = torch.Generator().manual_seed(8)
+        B, h, w, Nt = 2, 64, 64, 77
+        x = torch.randn(B, 16, h, w, generator=g).half()
+        enc = torch.randn(B, Nt, 4096, generator=g).bfloat16()
+        pooled = torch.randn(B, 2048, generator=g).bfloat16()
+        t = torch.tensor([650.0, 120.0])
+        y = e.plan(B, 1, h, w, Nt, 1).transformer_forward(x.cuda(), t.cuda(), enc.cuda(), pooled.cuda())
+        ref = M.mmdit_forward(sd, cfg, x.float(), t, enc.float(), pooled.float())
+        assert torch.isfinite(y.float()).all()
+        assert _rel(y, ref) < 2e-2
+    finally:
+        e.close()
