@@ -179,6 +179,8 @@ def main():
     lib = _lib.load()
     if args.pp_min_tiles is not None:
         lib.mi355_tune_set(3, args.pp_min_tiles)
+    if os.environ.get("MI355_ATTN_STATIC") == "0":     # A/B: keep the running-max softmax even where the static bound holds
+        lib.mi355_tune_set(6, 0)
     for _ in range(args.warmup):
         samples = one_rollout()
     if not args.no_selfcheck and not flux_mode:

@@ -29,7 +29,8 @@ __device__ __forceinline__ int key_perm(int i) {
     return 16 * (a >> 1) + 8 * g + 4 * (a & 1) + b;
 }
 
-template <int NWAVE>
+// STATIC: |score| <= p.score_bound <= 60 proven by the caller (see attention.hip): no running max, no rescale.
+template <int NWAVE, bool STATIC = false>
 __global__ __launch_bounds__(NWAVE * 64, 2) void attn128_kernel(Attn128Params p) {
     constexpr int QB = QW * NWAVE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -122,7 +123,8 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn128_kernel(Attn128Params p)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const bf16x8 kf = *(const bf16x8*)(sb + offK[0] + kb * 4096);
-            s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], negm, 0, 0, 0);
+            if constexpr (STATIC) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], (f32x16){0}, 0, 0, 0);
+            else s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], negm, 0, 0, 0);
         }
 #pragma unroll
         for (int kk = 1; kk < 8; ++kk) {
@@ -142,13 +144,16 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn128_kernel(Attn128Params p)
                     if (key >= p.S) s[kb][r] = -1e30f;
                 }
         }
-        float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
+        float mx = 0.f;
+        if constexpr (!STATIC) {
+        mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[0][2]);
 #pragma unroll
         for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s[0][r]), s[0][r + 1]);
         mx = fmaxf(mx, s[0][15]);
 #pragma unroll
         for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, s[1][r]), s[1][r + 1]);
-        if (t == 0 || __any(mx > THR)) {
+        }
+        if (!STATIC && (t == 0 || __any(mx > THR))) {
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float delta = (t == 0) ? mx : fmaxf(mx, 0.f);
             const float alpha = __builtin_amdgcn_exp2f(-delta);
@@ -221,9 +226,9 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn128_kernel(Attn128Params p)
 
 int g_attn128_variant = 0;   // 0: 8 waves x 32 queries, 1 workgroup / CU; 1: 4 waves, 2 workgroups / CU (independent barrier domains)
 
-template <int NWAVE>
+template <int NWAVE, bool STATIC>
 hipError_t launch128(const Attn128Params& p, hipStream_t stream) {
-    auto kern = attn128_kernel<NWAVE>;
+    auto kern = attn128_kernel<NWAVE, STATIC>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES);
@@ -241,7 +246,9 @@ void set_attn128_variant(int v) { g_attn128_variant = v; }
 
 hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream) {
     if (p.S <= 0 || p.S_pad % KV != 0 || p.S_pad < p.S || p.n_first < 0 || p.n_first > p.S) return hipErrorInvalidValue;
-    return g_attn128_variant == 1 ? launch128<4>(p, stream) : launch128<8>(p, stream);
+    if (g_attn128_variant == 1) return launch128<4, false>(p, stream);
+    if (p.score_bound > 0.f && p.score_bound <= 60.f) return launch128<8, true>(p, stream);
+    return launch128<8, false>(p, stream);
 }
 
 }  // namespace mi355

@@ -132,6 +132,7 @@ struct BlockW {
     float *b_qk, *b_v, *b_o, *b_cqk, *b_cv, *b_co, *b_qk2, *b_v2, *b_o2, *b_ff1, *b_ff2, *b_cff1, *b_cff2;
     float *nq, *nk, *ncq, *nck, *nq2, *nk2;
     int mod_img, mod_ctx;  // column offsets into a mod_all row
+    float bound_joint = 0.f, bound_dual = 0.f;   // proven |score| bounds of the two attentions (update_score_bounds)
 };
 
 struct mi355_engine {
@@ -146,6 +147,8 @@ struct mi355_engine {
     std::vector<BlockW> blk;
     std::map<std::string, Slot> slots;
     std::vector<std::string> names;
+    bool bounds_dirty = true;   // a norm weight was (re)bound since the last update_score_bounds
+    int bounds_ver = 0;
 
     bf16_t* a16(int64_t n) {
         size_t bytes = ((size_t)n * 2 + 255) & ~(size_t)255;
@@ -309,6 +312,7 @@ extern "C" int mi355_engine_bind_weight(mi355_engine* e, const char* name, const
     if (dtype < 0 || dtype > 2) return fail("mi355_engine_bind_weight: bad dtype %d", dtype);
     HIPCHK(launch_convert(src, dtype, it->second.dst, it->second.dst_dt, n, (hipStream_t)stream));
     it->second.bound = true;
+    if (strstr(name, ".norm_")) e->bounds_dirty = true;
     return 0;
 }
 
@@ -339,7 +343,7 @@ struct mi355_plan {
     // hipGraph of the whole N-step loop
     hipGraphExec_t gexec = nullptr;
     bool warmed = false;
-    int g_steps = -1, g_dyn = -1, g_storage = -1, g_init = -1, g_clp = -1, g_attn = -1, g_gemm = -1;
+    int g_steps = -1, g_dyn = -1, g_storage = -1, g_init = -1, g_clp = -1, g_attn = -1, g_gemm = -1, g_bounds = -1;
     float g_guidance = 0.f, g_sigma_max = 0.f;
 };
 
@@ -427,6 +431,33 @@ extern "C" int mi355_plan_destroy(mi355_plan* p) {
     return 0;
 }
 extern "C" int64_t mi355_plan_workspace_bytes(mi355_plan* p) { return p ? (int64_t)p->ws_bytes : 0; }
+
+// ---- static score bounds ----------------------------------------------------------------------
+// q and k reach the attention kernel RMS-normalised per head: ||q_hat|| <= 8 max|w_q|, ||k_hat|| <= 8 max|w_k| (64 dims), so with
+// the folded scale |score| <= 64 * 0.125 * log2(e) * max|w_q| * max|w_k| (Cauchy-Schwarz; 2 % slack for the bf16 roundings).  When
+// that is <= 60 the softmax needs no running max (attention.hip, STATIC).  Recomputed (one small D2H copy + stream sync) only after
+// a norm weight was re-bound, i.e. once per weight refresh, never inside a rollout.
+static int g_attn_static = 1;
+static int update_score_bounds(mi355_engine* e, hipStream_t st) {
+    if (!e->bounds_dirty) return 0;
+    std::vector<float> host(e->used32 / 4);
+    HIPCHK(hipMemcpyAsync(host.data(), e->arena32, e->used32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    auto amax = [&](const float* dev) {
+        const float* h = host.data() + (dev - (const float*)e->arena32);
+        float m = 0.f;
+        for (int i = 0; i < 64; ++i) m = fmaxf(m, fabsf(h[i]));
+        return m;
+    };
+    const float c = 64.0f * 0.125f * 1.4426950408889634f * 1.02f;
+    for (auto& b : e->blk) {
+        b.bound_joint = c * fmaxf(amax(b.nq), amax(b.ncq)) * fmaxf(amax(b.nk), amax(b.nck));
+        b.bound_dual = b.dual ? c * amax(b.nq2) * amax(b.nk2) : 0.f;
+    }
+    e->bounds_dirty = false;
+    ++e->bounds_ver;
+    return 0;
+}
 
 // ---------------------------------------------------------------------------------- forward
 static GemmParams gp(const bf16_t* A, long lda, const bf16_t* W, long ldw, int M, int N, int K, int epi,
@@ -545,14 +576,16 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
         CHK(qkv_proj(p, st, p->xn, Mi, Ni, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk, p->q, p->k, p->vT, p->S_pad, 0));
         CHK(qkv_proj(p, st, p->cn, Mc, Nt, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck, p->q, p->k, p->vT, p->S_pad, Ni));
         {
-            AttnParams a{p->q, p->k, p->vT, p->o_img, p->o_ctx, p->Bp, H, p->S, p->S_pad, Ni, get_attn_variant() >= 1};
+            AttnParams a{p->q, p->k, p->vT, p->o_img, p->o_ctx, p->Bp, H, p->S, p->S_pad, Ni, get_attn_variant() >= 1,
+                         g_attn_static ? b.bound_joint : 0.f};
             HIPCHK(attn_p(a, st));
         }
         CHK(gate_res(p, st, p->o_img, D, b.w_o, b.b_o, p->x, Mi, Ni, mod, mi + 2 * D));
         if (!b.last) CHK(gate_res(p, st, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
         if (b.dual) {
             CHK(qkv_proj(p, st, p->xn2, Mi, Ni, b.w_qk2, b.b_qk2, b.w_v2, b.b_v2, b.nq2, b.nk2, p->q2, p->k2, p->vT2, Ni_pad, 0));
-            AttnParams a{p->q2, p->k2, p->vT2, p->o_img, p->o_ctx, p->Bp, H, Ni, Ni_pad, Ni, get_attn_variant() >= 1};
+            AttnParams a{p->q2, p->k2, p->vT2, p->o_img, p->o_ctx, p->Bp, H, Ni, Ni_pad, Ni, get_attn_variant() >= 1,
+                         g_attn_static ? b.bound_dual : 0.f};
             HIPCHK(attn_p(a, st));
             CHK(gate_res(p, st, p->o_img, D, b.w_o2, b.b_o2, p->x, Mi, Ni, mod, mi + 8 * D));
         }
@@ -587,6 +620,7 @@ extern "C" int mi355_transformer_forward(mi355_plan* p, void* stream, const void
     if (!p || !latents || !t || !v_out) return fail("mi355_transformer_forward: null argument");
     CHK(mi355_engine_weights_ready(p->e));
     hipStream_t st = (hipStream_t)stream;
+    CHK(update_score_bounds(p->e, st));
     CHK(prepare_prompt(p, st, enc_a, pooled_a, enc_b, pooled_b));
     HIPCHK(hipMemcpyAsync(p->t_dev, t, (size_t)p->Bp * 4, hipMemcpyDeviceToDevice, st));
     CHK(prepare_conditioning(p, st, 1, t_round_dtype));
@@ -685,6 +719,7 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
     if (dynamics < 0 || dynamics > 3) return fail("mi355_rollout: unknown dynamics %d", dynamics);
     CHK(mi355_engine_weights_ready(p->e));
     hipStream_t st = (hipStream_t)stream;
+    CHK(update_score_bounds(p->e, st));
     const int Bp = p->Bp;
     // ---- host-side per-step scalars (the reference computes them with .item() syncs inside the loop)
     std::vector<float>& tt = p->host_t;   // plan-owned: must outlive the async H2D copies
@@ -720,7 +755,8 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
     if (g_use_graph && !g_prof.on && p->warmed) {
         const bool same = p->gexec && p->g_steps == n_steps && p->g_dyn == dynamics && p->g_storage == storage_dtype &&
                           p->g_init == init_dtype && p->g_clp == clp && p->g_guidance == guidance && p->g_sigma_max == sigma_max &&
-                          p->g_attn == get_attn_variant() && p->g_gemm == get_gemm_variant();
+                          p->g_attn == get_attn_variant() && p->g_gemm == get_gemm_variant() &&
+                          p->g_bounds == p->e->bounds_ver * 2 + (g_attn_static != 0);
         if (!same) {
             if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
             hipGraph_t graph = nullptr;
@@ -741,6 +777,7 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
             if (p->gexec) {
                 p->g_steps = n_steps; p->g_dyn = dynamics; p->g_storage = storage_dtype; p->g_init = init_dtype; p->g_clp = clp;
                 p->g_guidance = guidance; p->g_sigma_max = sigma_max; p->g_attn = get_attn_variant(); p->g_gemm = get_gemm_variant();
+                p->g_bounds = p->e->bounds_ver * 2 + (g_attn_static != 0);
             } else {
                 (void)hipGetLastError();
                 g_err = "mi355_rollout: hipGraph capture failed, running the launch sequence eagerly";  // same kernels
@@ -781,6 +818,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 3) { set_pp_min_tiles(value); return 0; }
     if (key == 4) { set_conv_cfg(value); return 0; }
     if (key == 5) { set_attn128_variant(value); return 0; }
+    if (key == 6) { g_attn_static = value; return 0; }
     return fail("mi355_tune_set: unknown key %d", key);
 }
 
@@ -809,7 +847,8 @@ extern "C" int mi355_op_attention(void* stream, const void* q, const void* k, co
                                   int H, int S, int S_pad, int n_img) {
     if (!q || !k || !vT || !o_img) return fail("mi355_op_attention: null argument");
     if (n_img < S && !o_ctx) return fail("mi355_op_attention: o_ctx is NULL but S > n_img");
-    AttnParams a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vT, (bf16_t*)o_img, (bf16_t*)o_ctx, B, H, S, S_pad, n_img, 0};
+    AttnParams a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)vT, (bf16_t*)o_img, (bf16_t*)o_ctx, B, H, S, S_pad, n_img, 0,
+                 g_attn_static >= 2 ? (float)g_attn_static : 0.f};
     HIPCHK(attn_p(a, (hipStream_t)stream));
     return 0;
 }

@@ -42,12 +42,14 @@ struct DoubleW {
     float *b_qk, *b_v, *b_o, *b_cqk, *b_cv, *b_co, *b_ff1, *b_ff2, *b_cff1, *b_cff2;
     float *nq, *nk, *ncq, *nck;
     int mod_img, mod_ctx;
+    float bound = 0.f;     // proven |score| bound of the block's attention (update_score_bounds)
 };
 struct SingleW {
     bf16_t *w_qk, *w_v, *w_mlp, *w_out;
     float *b_qk, *b_v, *b_mlp, *b_out;
     float *nq, *nk;
     int mod;
+    float bound = 0.f;
 };
 
 // value-round an fp32 to a storage dtype on the host (bf16 / fp16 round-to-nearest-even)
@@ -88,6 +90,7 @@ struct mi355_flux {
     std::vector<SingleW> sgl;
     std::map<std::string, FSlot> slots;
     std::vector<std::string> names;
+    bool bounds_dirty = true;
 
     bf16_t* a16(int64_t n) {
         size_t bytes = ((size_t)n * 2 + 255) & ~(size_t)255;
@@ -232,6 +235,7 @@ extern "C" int mi355_flux_bind_weight(mi355_flux* e, const char* name, const voi
     if (dtype < 0 || dtype > 2) return errorf("mi355_flux_bind_weight: bad dtype %d", dtype);
     HIPCHK(launch_convert(src, dtype, it->second.dst, it->second.dst_dt, n, (hipStream_t)stream));
     it->second.bound = true;
+    if (strstr(name, ".norm_")) e->bounds_dirty = true;
     return 0;
 }
 extern "C" int mi355_flux_weights_ready(mi355_flux* e) {
@@ -351,6 +355,25 @@ extern "C" int64_t mi355_flux_plan_workspace_bytes(mi355_flux_plan* p) { return 
 // ---------------------------------------------------------------------------------- forward
 namespace {
 
+// |score| <= 128 / sqrt(128) * log2(e) * max|w_q| * max|w_k| (RoPE preserves norms; see engine.hip update_score_bounds)
+int update_score_bounds(mi355_flux* e, hipStream_t st) {
+    if (!e->bounds_dirty) return 0;
+    std::vector<float> host(e->used32 / 4);
+    HIPCHK(hipMemcpyAsync(host.data(), e->arena32, e->used32, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    auto amax = [&](const float* dev) {
+        const float* h = host.data() + (dev - (const float*)e->arena32);
+        float m = 0.f;
+        for (int i = 0; i < 128; ++i) m = fmaxf(m, fabsf(h[i]));
+        return m;
+    };
+    const float c = 11.313708f * 1.4426950408889634f * 1.02f;
+    for (auto& b : e->dbl) b.bound = c * fmaxf(amax(b.nq), amax(b.ncq)) * fmaxf(amax(b.nk), amax(b.nck));
+    for (auto& b : e->sgl) b.bound = c * amax(b.nq) * amax(b.nk);
+    e->bounds_dirty = false;
+    return 0;
+}
+
 // step-invariant work: context embedder, pooled-text MLP, guidance MLP -> pemb = text_emb + guidance_emb
 int prepare_prompt(mi355_flux_plan* p, hipStream_t st, const void* enc, const void* pooled) {
     mi355_flux* e = p->e;
@@ -428,11 +451,12 @@ int gate_res(mi355_flux_plan* p, hipStream_t st, const bf16_t* A, long lda, int 
     return 0;
 }
 
-int attention(mi355_flux_plan* p, hipStream_t st, bf16_t* o_first, long ld_first, int n_first, bf16_t* o_rest, long ld_rest) {
+int attention(mi355_flux_plan* p, hipStream_t st, bf16_t* o_first, long ld_first, int n_first, bf16_t* o_rest, long ld_rest, float bound) {
     Attn128Params a;
     memset(&a, 0, sizeof(a));
     a.q = p->q; a.k = p->k; a.vT = p->vT; a.o_first = o_first; a.ld_first = ld_first; a.n_first = n_first;
     a.o_rest = o_rest; a.ld_rest = ld_rest; a.B = p->B; a.H = p->e->H; a.S = p->S; a.S_pad = p->S_pad; a.q_prescaled = 1;
+    a.score_bound = bound;
     HIPCHK(launch_attention128(a, st));
     return 0;
 }
@@ -458,7 +482,7 @@ int forward_core(mi355_flux_plan* p, hipStream_t st, const void* latents, int la
         CHK(qkv(p, st, p->cn, p->Mc, Nt, 0, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck));
         CHK(ln_mod(p, st, p->x, p->xn, mod, p->Mi, Ni, mi, mi + D));
         CHK(qkv(p, st, p->xn, p->Mi, Ni, Nt, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk));
-        CHK(attention(p, st, p->o_ctx, D, Nt, p->o_img, D));
+        CHK(attention(p, st, p->o_ctx, D, Nt, p->o_img, D, b.bound));
         CHK(gate_res(p, st, p->o_img, D, D, b.w_o, b.b_o, p->x, p->Mi, Ni, mod, mi + 2 * D));
         CHK(gate_res(p, st, p->o_ctx, D, D, b.w_co, b.b_co, p->c, p->Mc, Nt, mod, mc + 2 * D));
         CHK(ln_mod(p, st, p->x, p->xn, mod, p->Mi, Ni, mi + 3 * D, mi + 4 * D));
@@ -482,7 +506,7 @@ int forward_core(mi355_flux_plan* p, hipStream_t st, const void* latents, int la
         CHK(qkv(p, st, p->yn, p->M, S, 0, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk));
         GemmParams gm = gp(p->yn, D, b.w_mlp, D, p->M, F, D, EPI_BIAS_GELU, b.b_mlp, p->big + D, D + F);
         HIPCHK(launch_gemm(gm, st));
-        CHK(attention(p, st, p->big, D + F, S, p->big, D + F));
+        CHK(attention(p, st, p->big, D + F, S, p->big, D + F, b.bound));
         CHK(gate_res(p, st, p->big, D + F, D + F, b.w_out, b.b_out, p->y, p->M, S, mod, m0 + 2 * D));
     }
     // image rows back to a contiguous stream, AdaLayerNormContinuous (scale first), proj_out
@@ -519,6 +543,7 @@ extern "C" int mi355_flux_forward(mi355_flux_plan* p, void* stream, const void* 
     if (lat_dtype < 0 || lat_dtype > 2) return errorf("mi355_flux_forward: bad latent dtype %d", lat_dtype);
     CHK(mi355_flux_weights_ready(p->e));
     hipStream_t st = (hipStream_t)stream;
+    CHK(update_score_bounds(p->e, st));
     HIPCHK(hipMemcpyAsync(p->t_dev, t_model, (size_t)p->B * 4, hipMemcpyDeviceToDevice, st));
     if (guidance_model) HIPCHK(hipMemcpyAsync(p->g_dev, guidance_model, (size_t)p->B * 4, hipMemcpyDeviceToDevice, st));
     CHK(prepare_prompt(p, st, prompt_embeds, pooled));
@@ -542,6 +567,7 @@ extern "C" int mi355_flux_rollout(mi355_flux_plan* p, void* stream, int n_steps,
     if (dynamics < 0 || dynamics > 3) return errorf("mi355_flux_rollout: unknown dynamics %d", dynamics);
     CHK(mi355_flux_weights_ready(p->e));
     hipStream_t st = (hipStream_t)stream;
+    CHK(update_score_bounds(p->e, st));
     const int B = p->B;
     std::vector<float>& tt = p->host_t;
     std::vector<float>& sc = p->host_sc;

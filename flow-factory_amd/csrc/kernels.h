@@ -74,6 +74,7 @@ struct AttnParams {
     bf16_t* o_img; bf16_t* o_ctx;
     int B, H, S, S_pad, n_img;
     int q_prescaled;   // 1: q already carries the softmax scale 0.125*log2(e) (folded into the q RMSNorm epilogue)
+    float score_bound; // > 0: proven bound on |q.k| * scale * log2(e); <= 60 selects the no-running-max kernel (0 = unknown)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 
@@ -85,6 +86,7 @@ struct Attn128Params {
     bf16_t* o_rest; long ld_rest;
     int B, H, S, S_pad;
     int q_prescaled;   // 1: q carries log2(e)/sqrt(128) already (rope_norm kernel)
+    float score_bound; // > 0: proven bound on |score| (log2 domain); <= 60 selects the no-running-max kernel
 };
 hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream);
 void set_attn128_variant(int v);   // 0: 8-wave workgroups (default), 1: 4-wave workgroups

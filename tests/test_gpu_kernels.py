@@ -72,6 +72,37 @@ def test_attention(eng, B, H, S, n_img):
     assert float((got.float() - ref).abs().max()) < 0.05
 
 
+@pytest.mark.parametrize("B,H,S,n_img", [(2, 3, 333 + 256, 256), (1, 4, 4429, 4096)])
+def test_attention_static_bound_kernel(eng, B, H, S, n_img):
+    """The no-running-max kernel (selected by the engine when the q/k norm weights prove |score| <= 60 in the log2 domain) against
+    fp32 SDPA, and against the deferred-rescale kernel on the same inputs."""
+    from mi355_flow import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(S)
+    S_pad = (S + 63) // 64 * 64
+    q = torch.zeros(B, H, S_pad, 64, device="cuda", dtype=torch.bfloat16)
+    k = torch.zeros_like(q)
+    v = torch.zeros_like(q)
+    # RMS-normalised rows like the engine's q / k (norm 8): |score| * 0.125 * log2(e) <= 11.6
+    nrm = lambda t: t / t.pow(2).mean(-1, keepdim=True).sqrt()
+    q[:, :, :S] = nrm(torch.randn(B, H, S, 64, device="cuda", generator=g)).bfloat16()
+    k[:, :, :S] = nrm(torch.randn(B, H, S, 64, device="cuda", generator=g)).bfloat16()
+    v[:, :, :S] = torch.randn(B, H, S, 64, device="cuda", generator=g).bfloat16()
+    vT = v.transpose(2, 3).contiguous()
+    dyn_img, dyn_ctx = eng.op_attention(q, k, vT, S, n_img)
+    try:
+        _lib.check(lib.mi355_tune_set(6, 12))
+        o_img, o_ctx = eng.op_attention(q, k, vT, S, n_img)
+    finally:
+        _lib.check(lib.mi355_tune_set(6, 1))
+    ref = torch.nn.functional.scaled_dot_product_attention(q[:, :, :S].float(), k[:, :, :S].float(), v[:, :, :S].float())
+    ref = ref.transpose(1, 2).reshape(B, S, H * 64)
+    got = torch.cat([o_img.view(B, n_img, H * 64), o_ctx.view(B, S - n_img, H * 64)], 1)
+    dyn = torch.cat([dyn_img.view(B, n_img, H * 64), dyn_ctx.view(B, S - n_img, H * 64)], 1)
+    assert _rel(got, ref) < 6e-3, _rel(got, ref)
+    assert _rel(got, dyn) < 6e-3
+
+
 def test_attention_online_softmax_rescale(eng):
     """Force the running-max update late in the key loop (cdna guide rule 26): one spiked key in the
     last tile must take over the softmax of its query row."""
