@@ -1,11 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_model.py tests/test_gpu_adapter.py tests/test_gpu_rollout_variants.py -q 2>&1 | tail -4
-timeout 600 python bench.py --no-cpu-baseline --no-vae --steps 3 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('static on ', d['value'], d['ms_per_step'], 'attn', r['achieved'], 'fwd', r['forward']['achieved'], r['forward']['frac'])"
-MI355_ATTN_STATIC=0 timeout 600 python bench.py --no-cpu-baseline --no-vae --steps 3 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('static off', d['value'], d['ms_per_step'], 'attn', r['achieved'], 'fwd', r['forward']['achieved'], r['forward']['frac'])"
+timeout 600 python scripts/attn_ab.py 2>&1 | tee gpurun_out/attn_ab.log
