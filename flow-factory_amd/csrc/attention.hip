@@ -212,10 +212,13 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
     constexpr float THR = 6.0f;
     float m_run = 0.f;
     f32x16 negm = (f32x16){0};
+    // a wave whose 32 queries all lie beyond S (tail of the last query block: 179 of its 256 rows at S = 4429) only helps staging
+    const bool wave_active = (qblk * QB + wave * QW) < p.S;
     for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+        if (!wave_active) continue;
         const char* sb = smem + (t & 1) * STAGE_BYTES;
         f32x16 s[2];
 #pragma unroll

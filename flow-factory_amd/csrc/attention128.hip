@@ -114,10 +114,12 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn128_kernel(Attn128Params p)
     constexpr float THR = 6.0f;
     float m_run = 0.f;
     f32x16 negm = (f32x16){0};
+    const bool wave_active = (qblk * QB + wave * QW) < p.S;   // waves past the last query only help staging
     for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+        if (!wave_active) continue;
         const char* sb = smem + (t & 1) * STAGE_BYTES;
         f32x16 s[2];
 #pragma unroll
