@@ -50,9 +50,12 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn128_kernel(Attn128Params p)
     const int bhi = wid / nqb;
     const int h = bhi % p.H, b = bhi / p.H;
     const long bh = (long)b * p.H + h;
+    // keys / values may be a different sequence (cross-attention): S_kv == 0 means self-attention over the S queries
+    const int Skv = p.S_kv > 0 ? p.S_kv : p.S;
+    const int Skv_pad = p.S_kv > 0 ? p.S_kv_pad : p.S_pad;
     const bf16_t* Qg = p.q + bh * p.S_pad * HD;
-    const bf16_t* Kg = p.k + bh * p.S_pad * HD;
-    const bf16_t* Vg = p.vT + bh * HD * p.S_pad;
+    const bf16_t* Kg = p.k + bh * Skv_pad * HD;
+    const bf16_t* Vg = p.vT + bh * HD * Skv_pad;
 
     // ---- Q fragments (B operand): lane holds Q[q][kk*16 + lg*8 .. +8], kk = 0..7
     const int q_row = qblk * QB + wave * QW + lq;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn128_kernel(Attn128Params p)
         srcK[i] = Kg + (long)krow * HD + (g >> 3) * 64 + kc * 8;            // + tile*64*HD
         const int vrow = g * 8 + (lane >> 3);             // d
         const int vc = (lane & 7) ^ ((vrow >> 1) & 7);
-        srcV[i] = Vg + (long)vrow * p.S_pad + vc * 8;                        // + tile*64
+        srcV[i] = Vg + (long)vrow * Skv_pad + vc * 8;                        // + tile*64
     }
     auto stage = [&](int t, int buf) {
         char* base = smem + buf * STAGE_BYTES;
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn128_kernel(Attn128Params p)
 #pragma unroll
     for (int db = 0; db < 4; ++db) o[db] = (f32x16){0};
     float l_run = 0.f;
-    const int nt = (p.S + KV - 1) / KV;
+    const int nt = (Skv + KV - 1) / KV;
     stage(0, 0);
 
     constexpr float THR = 6.0f;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn128_kernel(Attn128Params p)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kbase + 32 * kb + 16 * (r >> 3) + (r & 7);
-                    if (key >= p.S) s[kb][r] = -1e30f;
+                    if (key >= Skv) s[kb][r] = -1e30f;
                 }
         }
         float mx = 0.f;
@@ -247,7 +250,8 @@ hipError_t launch128(const Attn128Params& p, hipStream_t stream) {
 void set_attn128_variant(int v) { g_attn128_variant = v; }
 
 hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream) {
-    if (p.S <= 0 || p.S_pad % KV != 0 || p.S_pad < p.S || p.n_first < 0 || p.n_first > p.S) return hipErrorInvalidValue;
+    if (p.S <= 0 || p.S_pad < p.S || p.n_first < 0 || p.n_first > p.S) return hipErrorInvalidValue;
+    if (p.S_kv > 0 ? (p.S_kv_pad % KV != 0 || p.S_kv_pad < p.S_kv) : (p.S_pad % KV != 0)) return hipErrorInvalidValue;
     if (g_attn128_variant == 1) return launch128<4, false>(p, stream);
     if (p.score_bound > 0.f && p.score_bound <= 60.f) return launch128<8, true>(p, stream);
     return launch128<8, false>(p, stream);

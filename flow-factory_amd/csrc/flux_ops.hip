@@ -32,7 +32,79 @@ __global__ __launch_bounds__(256) void rope_norm_kernel(RopeNormParams p) {
     *(unsigned*)(p.k_out + o) = pack_bf16(ka, kb);
 }
 
+// Wan: one wave per token row; lane l owns rotary pair l of EVERY head (pairs l, l+64, l+128, ... of the row), so the row RMS is one
+// wave reduction and every load / store instruction of the wave covers 256 contiguous bytes.
+template <int MAXH>
+__global__ __launch_bounds__(256) void norm_rope_full_kernel(NormRopeFullParams p) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= p.M) return;
+    const int b = m / p.rows_per_sample;
+    const int s = m - b * p.rows_per_sample + p.s_off;
+    const bf16_t* row = p.src + (long)m * p.src_ld + p.col + 2 * lane;
+    float x0[MAXH], x1[MAXH];
+    float ss = 0.f;
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h)
+        if (h < p.H) {
+            const unsigned u = *(const unsigned*)(row + h * 128);
+            x0[h] = bf_lo(u); x1[h] = bf_hi(u);
+            ss += x0[h] * x0[h] + x1[h] * x1[h];
+        }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)(p.H * 128) + p.eps);
+    float c = 1.f, sn = 0.f;
+    if (p.cs) { const float2 cs = p.cs[(long)s * 64 + lane]; c = cs.x; sn = cs.y; }
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h)
+        if (h < p.H) {
+            const float2 w = *(const float2*)(p.weight + h * 128 + 2 * lane);
+            const float a = x0[h] * rstd * w.x, bb = x1[h] * rstd * w.y;
+            const float ra = (a * c - bb * sn) * p.out_scale, rb = (bb * c + a * sn) * p.out_scale;
+            *(unsigned*)(p.out + (((long)b * p.H + h) * p.S_pad + s) * 128 + 2 * lane) = pack_bf16(ra, rb);
+        }
+}
+
+__global__ __launch_bounds__(256) void bcast_add_kernel(const bf16_t* a, const float* table, bf16_t* out, long out_ld, int rows, int W, int J) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;      // over rows * J * W / 2 pairs
+    const long per_row = (long)J * (W / 2);
+    if (i >= rows * per_row) return;
+    const int m = (int)(i / per_row);
+    const long r = i - m * per_row;
+    const int j = (int)(r / (W / 2)), x = (int)(r - (long)j * (W / 2)) * 2;
+    const unsigned u = *(const unsigned*)(a + (long)m * W + x);
+    const float2 t = *(const float2*)(table + (long)j * W + x);
+    *(unsigned*)(out + (long)m * out_ld + (long)j * W + x) = pack_bf16(bf_lo(u) + t.x, bf_hi(u) + t.y);
+}
+
+__global__ __launch_bounds__(256) void affine_to_mod_kernel(const float* weight, const float* bias, bf16_t* out, int D) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= D) return;
+    out[d] = f2bf(bias[d]);
+    out[D + d] = f2bf(weight[d] - 1.0f);
+}
+
 }  // namespace
+
+hipError_t launch_norm_rope_full(const NormRopeFullParams& p, hipStream_t stream) {
+    if (p.M <= 0 || p.H <= 0 || p.H > 48 || (p.src_ld & 1) || (p.col & 1)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((p.M + 3) / 4));
+    if (p.H <= 12) hipLaunchKernelGGL(norm_rope_full_kernel<12>, grid, dim3(256), 0, stream, p);
+    else if (p.H <= 24) hipLaunchKernelGGL(norm_rope_full_kernel<24>, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(norm_rope_full_kernel<48>, grid, dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_bcast_add(const bf16_t* a, const float* table, bf16_t* out, long out_ld, int rows, int W, int J, hipStream_t stream) {
+    if (W & 1) return hipErrorInvalidValue;
+    const long n = (long)rows * J * (W / 2);
+    hipLaunchKernelGGL(bcast_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, table, out, out_ld, rows, W, J);
+    return hipGetLastError();
+}
+
+hipError_t launch_affine_to_mod(const float* weight, const float* bias, bf16_t* out, int D, hipStream_t stream) {
+    hipLaunchKernelGGL(affine_to_mod_kernel, dim3((D + 255) / 256), dim3(256), 0, stream, weight, bias, out, D);
+    return hipGetLastError();
+}
 
 hipError_t launch_rope_norm(const RopeNormParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.H <= 0 || (p.src_ld & 1) || (p.q_col & 1) || (p.k_col & 1)) return hipErrorInvalidValue;

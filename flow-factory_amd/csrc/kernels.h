@@ -87,6 +87,7 @@ struct Attn128Params {
     int B, H, S, S_pad;
     int q_prescaled;   // 1: q carries log2(e)/sqrt(128) already (rope_norm kernel)
     float score_bound; // > 0: proven bound on |score| (log2 domain); <= 60 selects the no-running-max kernel
+    int S_kv, S_kv_pad; // cross-attention: keys / values are a different sequence (k [B][H][S_kv_pad][128], vT [B][H][128][S_kv_pad]); 0 = self
 };
 hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream);
 void set_attn128_variant(int v);   // 0: 8-wave workgroups (default), 1: 4-wave workgroups
@@ -104,6 +105,23 @@ struct RopeNormParams {
     float eps, q_scale;
 };
 hipError_t launch_rope_norm(const RopeNormParams& p, hipStream_t stream);
+
+// Wan: RMSNorm ACROSS heads (over the whole row of H*128 features, weight [H*128]) + optional rotary embedding (cs == nullptr: none)
+// of ONE projection: src rows [M][src_ld] at column `col` -> out [B][H][S_pad][128] (row m = sample m / rows_per_sample, position
+// s_off + m % rows_per_sample), multiplied by out_scale.
+struct NormRopeFullParams {
+    const bf16_t* src; long src_ld; int col;
+    const float* weight;                      // [H*128]
+    const float2* cs;                         // [S][64] (cos, sin) or nullptr
+    bf16_t* out;
+    int M, H, rows_per_sample, s_off, S_pad;
+    float eps, out_scale;
+};
+hipError_t launch_norm_rope_full(const NormRopeFullParams& p, hipStream_t stream);
+// out[m][j*W + x] = bf16(a[m][x] + table[j][x])   (a bf16 [rows][W], table fp32 [J][W]): Wan modulation = scale_shift_table + time_proj
+hipError_t launch_bcast_add(const bf16_t* a, const float* table, bf16_t* out, long out_ld, int rows, int W, int J, hipStream_t stream);
+// LayerNorm affine (weight, bias fp32 [D]) -> the (shift, scale) row layout of ln_mod: out[0][d] = bias, out[1][d] = weight - 1
+hipError_t launch_affine_to_mod(const float* weight, const float* bias, bf16_t* out, int D, hipStream_t stream);
 
 // ------------------------------------------------------------------------------ elementwise
 // LayerNorm(no affine, eps) + AdaLN modulate: out = LN(x)*(1+scale[b]) + shift[b]; optional

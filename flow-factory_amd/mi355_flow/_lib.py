@@ -44,6 +44,14 @@ class FluxCfg(C.Structure):
     ]
 
 
+class WanCfg(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32), ("out_channels", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32),
+        ("head_dim", C.c_int32), ("ffn_dim", C.c_int32), ("text_dim", C.c_int32), ("freq_dim", C.c_int32),
+        ("patch_t", C.c_int32), ("patch_h", C.c_int32), ("patch_w", C.c_int32), ("eps", C.c_float),
+    ]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -97,6 +105,18 @@ SIGNATURES = {
                                 C.POINTER(C.c_int32), _P, _P, _P, _I]),
     "mi355_op_attention128": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I]),
     "mi355_op_rope_norm": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F]),
+    "mi355_wan_create": (_I, [C.POINTER(WanCfg), C.POINTER(_P)]),
+    "mi355_wan_destroy": (_I, [_P]),
+    "mi355_wan_bind_weight": (_I, [_P, C.c_char_p, _P, _I, _I, C.POINTER(_L), _P]),
+    "mi355_wan_weights_ready": (_I, [_P]),
+    "mi355_wan_num_params": (_I, [_P]),
+    "mi355_wan_param_name": (C.c_char_p, [_P, _I]),
+    "mi355_wan_plan_create": (_I, [_P, _I, _I, _I, _I, _I, _I, _I, C.POINTER(_P)]),
+    "mi355_wan_plan_destroy": (_I, [_P]),
+    "mi355_wan_plan_workspace_bytes": (_L, [_P]),
+    "mi355_wan_forward": (_I, [_P, _P, _P, _I, _P, _P, _P, _P]),
+    "mi355_wan_rollout": (_I, [_P, _P, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _I, _F, _P, _I, _I, _P, _P, _P,
+                               C.POINTER(C.c_int32), _P, _P, _P, _I]),
     "mi355_op_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
     "mi355_op_conv_repack": (_I, [_P, _P, _I, _P, _I, _I, _I, _I]),
     "mi355_op_group_norm": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _I]),

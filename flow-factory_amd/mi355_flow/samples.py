@@ -63,3 +63,10 @@ class Flux1Sample(SD3_5Sample):
     """`Flux1Sample` (reference src/flow_factory/models/flux/flux1.py:53-60): packed latents `(P, Ni, 64)` in `all_latents`,
     plus the `img_ids` shared by the batch.  No negative prompt (guidance is embedded)."""
     img_ids: Optional[torch.Tensor] = None
+
+
+@dataclass
+class WanT2VSample(SD3_5Sample):
+    """`WanT2VSample` (reference src/flow_factory/models/wan/wan2_t2v.py): video latents `(P, 16, T, h, w)` in `all_latents`, the decoded
+    clip in `video` (None unless a video decoder is attached)."""
+    video: Optional[torch.Tensor] = None

@@ -1,0 +1,410 @@
+"""Wan2.1 text-to-video rollout on the native engine (mi355_wan_*): host mirror of `Wan2_T2V_Adapter.inference` / `.forward`
+(reference src/flow_factory/models/wan/wan2_t2v.py:234-421, :426-543) -- SURVEY.md 8(f) row N4, single-transformer Wan2.1.
+
+Kept from the reference: latents `(B, 16, T, h, w)` drawn in fp32 (`prepare_latents(dtype=float32)`), `timestep = t.expand(B)` with
+the scheduler's integer timesteps, classifier-free guidance as `u + g (c - u)` (here one forward over the batch [negative, positive]
+instead of two passes), `UniPCMultistepSDEScheduler.step` in rollout mode = the four SDE / ODE dynamics with sigma = t / 1000.
+Not covered (raise): Wan2.2 `boundary_ratio` / `transformer_2`, `expand_timesteps`, `attention_kwargs`.  The causal 3-D video VAE is
+not native: `decode_latents` delegates to an attached callable (samples carry no video otherwise).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DYNAMICS, WanCfg
+from .engine import _bf16c, _ptr, _stream, dtype_code, sde_step
+from .samples import WanT2VSample
+from .scheduler import FlowMatchEulerDiscreteSDEScheduler, SDESchedulerOutput
+from .trajectory import TrajectoryIndicesType, _resolve, create_callback_collector, create_trajectory_collector
+
+_DTYPE_MAP = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16,
+              "fp32": torch.float32, "float32": torch.float32}
+VAE_SCALE_SPATIAL, VAE_SCALE_TEMPORAL = 8, 4
+
+
+@dataclass
+class WanConfig:
+    """diffusers WanTransformer3DModel config fields the engine needs (Wan2.1-T2V-1.3B defaults)."""
+    in_channels: int = 16
+    out_channels: int = 16
+    num_layers: int = 30
+    num_attention_heads: int = 12
+    attention_head_dim: int = 128
+    ffn_dim: int = 8960
+    text_dim: int = 4096
+    freq_dim: int = 256
+    patch_size: Tuple[int, int, int] = (1, 2, 2)
+    eps: float = 1e-6
+
+    @property
+    def dim(self) -> int:
+        return self.num_attention_heads * self.attention_head_dim
+
+    def to_c(self) -> WanCfg:
+        return WanCfg(self.in_channels, self.out_channels, self.num_layers, self.num_attention_heads, self.attention_head_dim, self.ffn_dim,
+                      self.text_dim, self.freq_dim, self.patch_size[0], self.patch_size[1], self.patch_size[2], self.eps)
+
+
+class UniPCMultistepSDEScheduler(FlowMatchEulerDiscreteSDEScheduler):
+    """Rollout-mode mirror of the reference's `UniPCMultistepSDEScheduler` (scheduler/unipc_multistep.py): the SDE-step selection
+    mixin and `step()` are shared with the flow-match scheduler (its train / rollout branch is the same four dynamics,
+    :296-421); the schedule is diffusers' UniPC flow schedule (`use_flow_sigmas`, `flow_shift`): integer timesteps."""
+
+    def __init__(self, flow_shift: float = 3.0, **kw):
+        kw.setdefault("shift", flow_shift)
+        super().__init__(**kw)
+        self.config["flow_shift"] = flow_shift
+
+    def set_timesteps(self, num_inference_steps: Optional[int] = None, device=None, **_ignored) -> None:
+        n_train = self.config.num_train_timesteps
+        shift = self.config["flow_shift"]
+        alphas = np.linspace(1, 1 / n_train, num_inference_steps + 1)
+        sig = 1.0 - alphas
+        sig = np.flip(shift * sig / (1 + (shift - 1) * sig))[:-1].copy()
+        ts = (sig * n_train).copy().astype(np.int64)
+        self.timesteps = torch.from_numpy(ts).to(device=device)
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0.0]]).astype(np.float32)).to(device=device)
+        self.num_inference_steps = len(ts)
+        self._host_timesteps = [float(x) for x in ts.tolist()]
+
+
+class WanEngine:
+    def __init__(self, cfg: WanConfig = WanConfig()):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        h = C.c_void_p()
+        c = cfg.to_c()
+        _lib.check(self.lib.mi355_wan_create(C.byref(c), C.byref(h)), "wan_create")
+        self._h = h
+        self._plans: Dict[tuple, "WanPlan"] = {}
+
+    def param_names(self) -> List[str]:
+        n = self.lib.mi355_wan_num_params(self._h)
+        return [self.lib.mi355_wan_param_name(self._h, i).decode() for i in range(n)]
+
+    def bind_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        names = self.param_names()
+        missing = [n for n in names if n not in state_dict]
+        if missing and strict:
+            raise KeyError(f"mi355_flow: Wan state dict lacks {len(missing)} parameters, first: {missing[0]}")
+        st = _stream()
+        for n in names:
+            if n not in state_dict:
+                continue
+            t = state_dict[n].detach()
+            if not t.is_cuda:
+                t = t.cuda(non_blocking=True)
+            t = t.contiguous()
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            _lib.check(self.lib.mi355_wan_bind_weight(self._h, n.encode(), t.data_ptr(), dtype_code(t.dtype), t.dim(), shape, st),
+                       f"wan_bind_weight({n})")
+        torch.cuda.current_stream().synchronize()
+
+    def ready(self) -> None:
+        _lib.check(self.lib.mi355_wan_weights_ready(self._h), "wan_weights_ready")
+
+    def plan(self, batch: int, n_cfg: int, T: int, h: int, w: int, n_text: int, max_steps: int) -> "WanPlan":
+        key = (batch, n_cfg, T, h, w, n_text)
+        p = self._plans.get(key)
+        if p is None or p.max_steps < max_steps:
+            if p is not None:
+                p.close()
+            p = WanPlan(self, batch, n_cfg, T, h, w, n_text, max_steps)
+            self._plans[key] = p
+        return p
+
+    def close(self) -> None:
+        for p in self._plans.values():
+            p.close()
+        self._plans.clear()
+        if self._h:
+            self.lib.mi355_wan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class WanPlan:
+    def __init__(self, engine: WanEngine, batch: int, n_cfg: int, T: int, h: int, w: int, n_text: int, max_steps: int):
+        self.engine, self.lib = engine, engine.lib
+        self.batch, self.n_cfg, self.T, self.h, self.w, self.n_text, self.max_steps = batch, n_cfg, T, h, w, n_text, max_steps
+        self.C = engine.cfg.in_channels
+        hd = C.c_void_p()
+        _lib.check(self.lib.mi355_wan_plan_create(engine._h, batch, n_cfg, T, h, w, n_text, max_steps, C.byref(hd)), "wan_plan_create")
+        self._h = hd
+
+    @property
+    def workspace_bytes(self) -> int:
+        return int(self.lib.mi355_wan_plan_workspace_bytes(self._h))
+
+    def close(self) -> None:
+        if self._h:
+            self.lib.mi355_wan_plan_destroy(self._h)
+            self._h = None
+
+    def transformer_forward(self, latents: torch.Tensor, t: torch.Tensor, enc_a: torch.Tensor, enc_b: Optional[torch.Tensor] = None):
+        """latents (B, 16, T, h, w); t (B*n_cfg,) or scalar; n_cfg == 2: enc_a = negative, enc_b = positive, output (2B, ...)."""
+        B, Bp = self.batch, self.batch * self.n_cfg
+        assert tuple(latents.shape) == (B, self.C, self.T, self.h, self.w), latents.shape
+        dev = latents.device
+        t = t.to(device=dev, dtype=torch.float32).reshape(-1)
+        t = (t.expand(Bp) if t.numel() == 1 else (t.repeat(self.n_cfg) if t.numel() == B and self.n_cfg == 2 else t)).contiguous()
+        assert t.numel() == Bp
+        out = torch.empty((Bp, self.engine.cfg.out_channels, self.T, self.h, self.w), device=dev, dtype=torch.bfloat16)
+        latents = latents.contiguous()
+        ea = _bf16c(enc_a)
+        eb = _bf16c(enc_b) if enc_b is not None else None
+        _lib.check(self.lib.mi355_wan_forward(self._h, _stream(), _ptr(latents), dtype_code(latents.dtype), _ptr(t), _ptr(ea), _ptr(eb),
+                                              _ptr(out)), "wan_forward")
+        return out
+
+    def rollout(self, timesteps: Sequence[float], sigmas: Sequence[float], noise_levels: Sequence[float], dynamics: str, guidance: float,
+                init_latents: torch.Tensor, storage_dtype: torch.dtype, step_noise: Optional[torch.Tensor], prompt_embeds: torch.Tensor,
+                neg_embeds: Optional[torch.Tensor] = None, keep_positions: Optional[Sequence[int]] = None, compute_log_prob: bool = True):
+        N, B = len(timesteps), self.batch
+        assert len(sigmas) == N + 1 and len(noise_levels) == N
+        dev = init_latents.device
+        keep = list(range(N + 1)) if keep_positions is None else sorted(set(int(k) for k in keep_positions))
+        slots = [-1] * (N + 1)
+        for s, pos in enumerate(keep):
+            slots[pos] = s
+        shape = (B, self.C, self.T, self.h, self.w)
+        assert tuple(init_latents.shape) == shape, init_latents.shape
+        out_lat = torch.empty((len(keep),) + shape, device=dev, dtype=storage_dtype)
+        out_lp = torch.full((N, B), float("nan"), device=dev, dtype=torch.float32)
+        out_fin = torch.empty(shape, device=dev, dtype=storage_dtype)
+        fa = C.c_float * N
+        ts_c, nl_c = fa(*[float(t) for t in timesteps]), fa(*[float(e) for e in noise_levels])
+        sg_c = (C.c_float * (N + 1))(*[float(s) for s in sigmas])
+        sl_c = (C.c_int32 * (N + 1))(*slots)
+        init_latents = init_latents.contiguous()
+        if step_noise is not None:
+            step_noise = step_noise.contiguous()
+            assert step_noise.dtype == torch.float32 and tuple(step_noise.shape) == (N,) + shape, step_noise.shape
+        pe = _bf16c(prompt_embeds)
+        ne = _bf16c(neg_embeds) if neg_embeds is not None else None
+        _lib.check(self.lib.mi355_wan_rollout(
+            self._h, _stream(), N, ts_c, sg_c, nl_c, DYNAMICS[dynamics], float(guidance), _ptr(init_latents), dtype_code(init_latents.dtype),
+            dtype_code(storage_dtype), _ptr(step_noise), _ptr(pe), _ptr(ne), sl_c, _ptr(out_lat), _ptr(out_lp), _ptr(out_fin),
+            int(bool(compute_log_prob))), "wan_rollout")
+        return out_lat, out_lp, out_fin
+
+
+class Wan2T2VNativeAdapter:
+    """Standalone Wan2.1 T2V adapter (no Flow-Factory import): engine + UniPC-SDE scheduler (+ optional video decoder callable)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[WanConfig] = None,
+                 scheduler: Optional[UniPCMultistepSDEScheduler] = None, latent_storage_dtype: Optional[str] = "fp16",
+                 transformer_dtype: torch.dtype = torch.bfloat16, device: Union[str, torch.device] = "cuda",
+                 video_decode: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("mi355_flow: no GPU visible; the native rollout engine has no CPU path")
+        self.device = torch.device(device)
+        self.transformer_dtype = transformer_dtype
+        self._latent_storage = latent_storage_dtype
+        self.scheduler = scheduler or UniPCMultistepSDEScheduler(flow_shift=3.0, sde_steps=[1, 2, 3], num_sde_steps=1)
+        self.engine = WanEngine(config or WanConfig())
+        self.refresh_weights(state_dict)
+        self._video_decode = video_decode
+
+    @property
+    def latent_storage_dtype(self) -> Optional[torch.dtype]:
+        return _DTYPE_MAP.get(self._latent_storage) if self._latent_storage else None
+
+    def refresh_weights(self, state_dict: Dict[str, torch.Tensor]) -> None:
+        self.engine.bind_state_dict(state_dict)
+        self.engine.ready()
+
+    def rollout(self):
+        self.scheduler.rollout()
+
+    def eval(self):
+        self.scheduler.eval()
+
+    def train(self, mode: bool = True):
+        self.scheduler.train(mode)
+
+    def cast_latents(self, latents: torch.Tensor, default_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        target = self.latent_storage_dtype or default_dtype
+        if target is None or latents.dtype == target:
+            return latents
+        if target == torch.float16:
+            latents = latents.clamp(-65504.0, 65504.0)
+        return latents.to(target)
+
+    def encode_prompt(self, *a, **k):
+        raise RuntimeError("mi355_flow standalone adapter has no text encoder: pass prompt_embeds (and negative_prompt_embeds for CFG)")
+
+    def decode_latents(self, latents: torch.Tensor, output_type: str = "pt"):
+        return self._video_decode(latents) if self._video_decode is not None else None
+
+    # ------------------------------------------------------------------ rollout (wan2_t2v.py:234-421)
+    @torch.no_grad()
+    def inference(
+        self,
+        prompt: Optional[Union[str, List[str]]] = None,
+        negative_prompt: Optional[Union[str, List[str]]] = None,
+        height: int = 480,
+        width: int = 832,
+        num_frames: int = 81,
+        num_inference_steps: int = 50,
+        guidance_scale: float = 5.0,
+        guidance_scale_2: Optional[float] = None,
+        generator: Optional[torch.Generator] = None,
+        prompt_ids: Optional[torch.Tensor] = None,
+        prompt_embeds: Optional[torch.Tensor] = None,
+        negative_prompt_ids: Optional[torch.Tensor] = None,
+        negative_prompt_embeds: Optional[torch.Tensor] = None,
+        compute_log_prob: bool = False,
+        attention_kwargs: Optional[Dict[str, Any]] = None,
+        max_sequence_length: int = 512,
+        extra_call_back_kwargs: List[str] = [],
+        trajectory_indices: TrajectoryIndicesType = "all",
+    ) -> List[WanT2VSample]:
+        device = self.device
+        if attention_kwargs:
+            raise ValueError("mi355_flow: attention_kwargs are not supported by the native engine")
+        if guidance_scale_2 is not None and guidance_scale_2 != guidance_scale:
+            raise ValueError("mi355_flow: guidance_scale_2 (Wan2.2 two-expert models) is not supported")
+        if (num_frames - 1) % VAE_SCALE_TEMPORAL != 0:
+            num_frames = num_frames // VAE_SCALE_TEMPORAL * VAE_SCALE_TEMPORAL + 1
+        num_frames = max(num_frames, 1)
+        ps = self.engine.cfg.patch_size
+        hm, wm = VAE_SCALE_SPATIAL * ps[1], VAE_SCALE_SPATIAL * ps[2]
+        height, width = height // hm * hm, width // wm * wm
+        if prompt_embeds is None:
+            enc = self.encode_prompt(prompt=prompt, negative_prompt=negative_prompt, guidance_scale=guidance_scale)
+            prompt_embeds, prompt_ids = enc["prompt_embeds"], enc["prompt_ids"]
+            negative_prompt_embeds, negative_prompt_ids = enc.get("negative_prompt_embeds"), enc.get("negative_prompt_ids")
+        prompt_embeds = prompt_embeds.to(device).to(self.transformer_dtype)
+        if negative_prompt_embeds is not None:
+            negative_prompt_embeds = negative_prompt_embeds.to(device).to(self.transformer_dtype)
+        do_cfg = guidance_scale > 1.0 and negative_prompt_embeds is not None
+        B = prompt_embeds.shape[0]
+        N = int(num_inference_steps)
+        self.scheduler.set_timesteps(N, device=device)
+        timesteps = self.scheduler.timesteps
+        Cl = self.engine.cfg.in_channels
+        T, h, w = (num_frames - 1) // VAE_SCALE_TEMPORAL + 1, height // VAE_SCALE_SPATIAL, width // VAE_SCALE_SPATIAL
+        # RNG in the reference's order: prepare_latents in fp32, then one fp32 draw per step
+        latents = torch.randn((B, Cl, T, h, w), generator=generator, device=device, dtype=torch.float32)
+        step_noise = torch.empty((N, B, Cl, T, h, w), device=device, dtype=torch.float32)
+        for i in range(N):
+            step_noise[i] = torch.randn((B, Cl, T, h, w), generator=generator, device=device, dtype=torch.float32)
+        ts_host = [float(t) for t in timesteps.tolist()]
+        sig_host = [float(s) for s in self.scheduler.sigmas.tolist()]
+        eta_host = self.scheduler.host_noise_levels()
+        storage = self.latent_storage_dtype or torch.float32       # cast_latents(latents) with no default: fp32 stays fp32
+        if any(k != "noise_level" for k in extra_call_back_kwargs):
+            raise ValueError("mi355_flow: the Wan rollout captures only 'noise_level' as an extra callback value")
+        plan = self.engine.plan(B, 2 if do_cfg else 1, T, h, w, prompt_embeds.shape[1], N)
+        kept = _resolve(trajectory_indices, N + 1)
+        keep_positions = list(range(N + 1)) if kept is None else sorted(kept)
+        lat_kept, log_probs, final = plan.rollout(ts_host, sig_host, eta_host, self.scheduler.dynamics_type, guidance_scale, latents, storage,
+                                                  step_noise, prompt_embeds, negative_prompt_embeds if do_cfg else None,
+                                                  keep_positions=keep_positions, compute_log_prob=compute_log_prob)
+        pos_to_slot = {p: s for s, p in enumerate(keep_positions)}
+        latent_collector = create_trajectory_collector(trajectory_indices, N)
+        log_prob_collector = create_trajectory_collector(trajectory_indices, N) if compute_log_prob else None
+        callback_collector = create_callback_collector(trajectory_indices, N)
+        if latent_collector.should_collect(0):
+            latent_collector.collect(lat_kept[pos_to_slot[0]], 0)
+        for i in range(N):
+            if latent_collector.should_collect(i + 1):
+                latent_collector.collect(lat_kept[pos_to_slot[i + 1]], i + 1)
+            if compute_log_prob and eta_host[i] > 0:
+                log_prob_collector.collect(log_probs[i], i)
+            callback_collector.collect_step(step_idx=i, output=None, keys=extra_call_back_kwargs, capturable={"noise_level": eta_host[i]})
+        videos = self.decode_latents(final, output_type="pt")
+        cb_res, cb_map = callback_collector.get_result(), callback_collector.get_index_map()
+        all_latents = latent_collector.get_result()
+        all_log_probs = log_prob_collector.get_result() if compute_log_prob else None
+        lat_stack = torch.stack(all_latents, dim=1) if all_latents else None
+        lp_stack = torch.stack(all_log_probs, dim=1) if all_log_probs else None
+        return [
+            WanT2VSample(
+                timesteps=timesteps,
+                all_latents=lat_stack[b] if lat_stack is not None else None,
+                log_probs=lp_stack[b] if lp_stack is not None else None,
+                latent_index_map=latent_collector.get_index_map(),
+                log_prob_index_map=log_prob_collector.get_index_map() if compute_log_prob else None,
+                video=videos[b] if videos is not None else None,
+                height=height, width=width,
+                prompt=prompt[b] if isinstance(prompt, list) else prompt,
+                prompt_ids=prompt_ids[b] if prompt_ids is not None else None,
+                prompt_embeds=prompt_embeds[b],
+                negative_prompt=negative_prompt[b] if isinstance(negative_prompt, list) else negative_prompt,
+                negative_prompt_ids=negative_prompt_ids[b] if negative_prompt_ids is not None else None,
+                negative_prompt_embeds=negative_prompt_embeds[b] if negative_prompt_embeds is not None else None,
+                extra_kwargs={**{k: v[b] for k, v in cb_res.items()}, "callback_index_map": cb_map},
+            )
+            for b in range(B)
+        ]
+
+    # ------------------------------------------------------------------ single step / replay (wan2_t2v.py:426-543), no-grad
+    @torch.no_grad()
+    def forward(
+        self,
+        t: torch.Tensor,
+        latents: torch.Tensor,
+        prompt_embeds: torch.Tensor,
+        negative_prompt_embeds: Optional[torch.Tensor] = None,
+        guidance_scale: float = 5.0,
+        guidance_scale_2: Optional[float] = None,
+        t_next: Optional[torch.Tensor] = None,
+        next_latents: Optional[torch.Tensor] = None,
+        noise_level: Optional[float] = None,
+        attention_kwargs: Optional[Dict[str, Any]] = None,
+        compute_log_prob: bool = True,
+        return_kwargs: List[str] = ["noise_pred", "next_latents", "next_latents_mean", "std_dev_t", "dt", "log_prob"],
+        boundary_timestep: Optional[float] = None,
+    ) -> SDESchedulerOutput:
+        if attention_kwargs:
+            raise ValueError("mi355_flow: attention_kwargs are not supported by the native engine")
+        if boundary_timestep is not None:
+            raise ValueError("mi355_flow: boundary_timestep (Wan2.2 two-expert models) is not supported")
+        dev = latents.device
+        B, _, T, h, w = latents.shape
+        t = torch.as_tensor(t, device=dev, dtype=torch.float32).reshape(-1)
+        t0 = t[0]                                       # `t = t[0] if t.ndim == 1 else t`: one scalar timestep per call
+        sched = self.scheduler
+        if t_next is None:
+            idx = sched.index_for_timestep(t0)
+            t_next = sched.timesteps[idx + 1].float() if idx + 1 < len(sched.timesteps) else torch.zeros(())
+        t_next = torch.as_tensor(t_next, device=dev, dtype=torch.float32).reshape(-1)[0]
+        do_cfg = negative_prompt_embeds is not None and guidance_scale > 1.0
+        plan = self.engine.plan(B, 2 if do_cfg else 1, T, h, w, prompt_embeds.shape[1], 1)
+        v = plan.transformer_forward(latents, t0.reshape(1), negative_prompt_embeds if do_cfg else prompt_embeds, prompt_embeds if do_cfg else None)
+        vu, vt = (v[:B], v[B:]) if do_cfg else (None, v)
+        dyn = sched.dynamics_type
+        sigma, sigma_next = (t0.double() / 1000).float(), (t_next.double() / 1000).float()
+        if sched.is_eval or dyn == "ODE":
+            noise_level = 0.0
+        elif noise_level is None:
+            noise_level = sched.get_noise_level_for_timestep(float(t0))
+        noise = None
+        if next_latents is None and dyn != "ODE":
+            noise = torch.randn(latents.shape, device=dev, dtype=torch.float32)
+        want = tuple(k for k in return_kwargs if k in ("next_latents", "next_latents_mean", "noise_pred", "std_dev_t", "dt"))
+        o = sde_step(vt, vu, guidance_scale, latents, sigma, sigma_next, noise_level, float(sched.sigmas[1]), dyn, noise=noise,
+                     next_latents=next_latents, compute_log_prob=compute_log_prob, want=want)
+        view = (-1, 1, 1, 1, 1)
+        res = dict(
+            noise_pred=o.noise_pred,
+            next_latents=o.next_latents if next_latents is None else next_latents.float(),
+            next_latents_mean=o.next_latents_mean,
+            std_dev_t=o.std_dev_t.view(view) if o.std_dev_t is not None else None,
+            dt=o.dt.view(view) if o.dt is not None else None,
+            log_prob=o.log_prob if compute_log_prob else None,
+        )
+        return SDESchedulerOutput.from_dict({k: res[k] for k in return_kwargs if k in res})

@@ -196,3 +196,55 @@ def flux_forward_flops(cfg, Ni: int, Nt: int) -> float:
     sgl = cfg.num_single_layers * (S * 12 * D * D + 2 * S * S * D)
     emb = Ni * cfg.in_channels * D + Nt * cfg.joint_attention_dim * D + Ni * D * cfg.in_channels
     return 2.0 * (dbl + sgl + emb)
+
+
+# --------------------------------------------------------------------------------- Wan2.1 transformer
+def expected_wan_shapes(cfg) -> Dict[str, Tuple[int, ...]]:
+    """HF `WanTransformer3DModel` parameters for a `mi355_flow.wan.WanConfig`."""
+    D = cfg.dim
+    out: Dict[str, Tuple[int, ...]] = {}
+
+    def lin(n, o, i):
+        out[n + ".weight"], out[n + ".bias"] = (o, i), (o,)
+
+    out["patch_embedding.weight"], out["patch_embedding.bias"] = (D, cfg.in_channels) + tuple(cfg.patch_size), (D,)
+    lin("condition_embedder.time_embedder.linear_1", D, cfg.freq_dim)
+    lin("condition_embedder.time_embedder.linear_2", D, D)
+    lin("condition_embedder.time_proj", 6 * D, D)
+    lin("condition_embedder.text_embedder.linear_1", D, cfg.text_dim)
+    lin("condition_embedder.text_embedder.linear_2", D, D)
+    for i in range(cfg.num_layers):
+        b = f"blocks.{i}"
+        out[f"{b}.scale_shift_table"] = (1, 6, D)
+        for a in ("attn1", "attn2"):
+            for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                lin(f"{b}.{a}.{n}", D, D)
+            out[f"{b}.{a}.norm_q.weight"] = (D,)
+            out[f"{b}.{a}.norm_k.weight"] = (D,)
+        out[f"{b}.norm2.weight"], out[f"{b}.norm2.bias"] = (D,), (D,)
+        lin(f"{b}.ffn.net.0.proj", cfg.ffn_dim, D)
+        lin(f"{b}.ffn.net.2", D, cfg.ffn_dim)
+    out["scale_shift_table"] = (1, 2, D)
+    lin("proj_out", cfg.out_channels * math.prod(cfg.patch_size), D)
+    return out
+
+
+def synthetic_wan_state_dict(cfg, device="cuda", seed: int = 1357, std: float = 0.02, dtype: torch.dtype = torch.bfloat16):
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for name, shape in expected_wan_shapes(cfg).items():
+        t = torch.randn(shape, generator=g, device=device, dtype=torch.float32) * std
+        if ".norm_q." in name or ".norm_k." in name or name.endswith("norm2.weight"):
+            t = t + 1.0
+        if "scale_shift_table" in name:
+            t = t * (0.3 / std)
+        sd[name] = t.to(dtype)
+    return sd
+
+
+def wan_forward_flops(cfg, S: int, Nt: int) -> float:
+    """Algorithmic matmul FLOPs of one Wan forward for one sample (2 FLOP/MAC; conditioning MLPs excluded)."""
+    D, Fd = cfg.dim, cfg.ffn_dim
+    per_layer = S * (4 * D * D) + 2 * S * S * D + S * 2 * D * D + Nt * 2 * D * D + 2 * S * Nt * D + S * 2 * D * Fd
+    emb = S * cfg.in_channels * 4 * D + S * D * cfg.out_channels * 4 + Nt * cfg.text_dim * D + Nt * D * D
+    return 2.0 * (cfg.num_layers * per_layer + emb)

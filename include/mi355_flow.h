@@ -209,6 +209,38 @@ int mi355_op_rope_norm(void* stream, const void* src, int64_t src_ld, int q_col,
                        const float* nw_k, const float* cos_sin, void* q_out, void* k_out, int M, int H, int rows_per_sample,
                        int s_off, int S_pad, float eps, float q_scale);
 
+/* ---- Wan2.1 text-to-video rollout ------------------------------------------
+ * Replaces the cond / uncond `transformer(hidden_states=latents (B,16,T,h,w), timestep=t.expand(B), encoder_hidden_states)` passes,
+ * the CFG combine and `scheduler.step(...)` in Wan2_T2V_Adapter.inference / .forward (reference
+ * src/flow_factory/models/wan/wan2_t2v.py:344-376, :426-543), single-transformer Wan2.1 configuration.  Weights bind by the HF names
+ * of diffusers' WanTransformer3DModel.  CFG is one forward over the batch [negative, positive]. */
+typedef struct mi355_wan mi355_wan;
+typedef struct mi355_wan_plan mi355_wan_plan;
+typedef struct mi355_wan_cfg {
+    int32_t in_channels, out_channels, num_layers, num_heads, head_dim, ffn_dim, text_dim, freq_dim;
+    int32_t patch_t, patch_h, patch_w;
+    float eps;
+} mi355_wan_cfg;
+int mi355_wan_create(const mi355_wan_cfg* cfg, mi355_wan** out);
+int mi355_wan_destroy(mi355_wan* e);
+int mi355_wan_bind_weight(mi355_wan* e, const char* name, const void* src, int dtype, int ndim, const int64_t* shape, void* stream);
+int mi355_wan_weights_ready(mi355_wan* e);
+int mi355_wan_num_params(mi355_wan* e);
+const char* mi355_wan_param_name(mi355_wan* e, int i);
+/* latent grid (T, h, w) = ((frames-1)/4+1, H/8, W/8); n_cfg 1 or 2 */
+int mi355_wan_plan_create(mi355_wan* e, int batch, int n_cfg, int latent_t, int latent_h, int latent_w, int n_text, int max_steps,
+                          mi355_wan_plan** out);
+int mi355_wan_plan_destroy(mi355_wan_plan* plan);
+int64_t mi355_wan_plan_workspace_bytes(mi355_wan_plan* plan);
+/* transformer only: t [batch*n_cfg] device fp32; enc_b NULL when n_cfg == 1, else forward batch = [enc_a, enc_b]; v_out bf16 */
+int mi355_wan_forward(mi355_wan_plan* plan, void* stream, const void* latents, int lat_dtype, const float* t, const void* enc_a,
+                      const void* enc_b, void* v_out);
+/* the whole N-step loop (arguments as mi355_rollout, no pooled embeddings; sigma of a step = t / 1000) */
+int mi355_wan_rollout(mi355_wan_plan* plan, void* stream, int n_steps, const float* timesteps_host, const float* sigmas_host,
+                      const float* noise_levels_host, int dynamics, float guidance, const void* init_latents, int init_dtype,
+                      int storage_dtype, const float* step_noise, const void* prompt_embeds, const void* neg_embeds,
+                      const int32_t* keep_slot_host, void* out_latents, float* out_log_probs, void* out_final, int compute_log_prob);
+
 /* VAE operator-level entry points (unit tests / microbenchmarks).  NHWC bf16 activations.
  * conv3x3: x [B][H>>up][W>>up][Cin] (Cin % 64 == 0), w_packed [Cout][9][Cin] bf16 (mi355_op_conv_repack), padding 1,
  * optional nearest-2x upsample of x folded in, optional residual [B*H*W][Cout] added (may alias out) -> out [B*H*W][Cout] */
