@@ -149,12 +149,69 @@ if _RefAdapter is not None:  # pragma: no cover
                 self._sync_weights()
                 return _FluxMirror.forward(self, *args, **kwargs)
 
+    try:
+        from flow_factory.models.wan.wan2_t2v import Wan2_T2V_Adapter as _RefWan
+    except Exception:  # noqa: BLE001
+        _RefWan = None
+
+    if _RefWan is not None:
+        from .wan import Wan2T2VNativeAdapter as _WanMirror, WanConfig, WanEngine
+
+        class Wan2T2VNativeAdapter(_RefWan):
+            """`Wan2_T2V_Adapter` (wan2_t2v.py) with the Wan2.1 rollout on the MI355X engine (single transformer; Wan2.2's
+            `transformer_2` / `boundary_ratio` configurations stay on the reference path).  The video VAE is the pipeline's."""
+
+            def __init__(self, config, accelerator):
+                _RefWan.__init__(self, config, accelerator)
+                if getattr(self.pipeline.config, "boundary_ratio", None) is not None or getattr(self.pipeline, "transformer_2", None) is not None:
+                    raise ValueError("mi355_flow: two-expert Wan2.2 pipelines are not supported by the native engine")
+                tc = self.pipeline.transformer.config
+                self.engine = WanEngine(WanConfig(
+                    in_channels=tc.in_channels, out_channels=tc.out_channels, num_layers=tc.num_layers,
+                    num_attention_heads=tc.num_attention_heads, attention_head_dim=tc.attention_head_dim, ffn_dim=tc.ffn_dim,
+                    text_dim=tc.text_dim, freq_dim=tc.freq_dim, patch_size=tuple(tc.patch_size), eps=tc.eps))
+                self._bound_version, self._weights_version = -1, 0
+
+            @property
+            def transformer_dtype(self):
+                return self.pipeline.transformer.dtype
+
+            def _sync_weights(self):
+                if self._bound_version != self._weights_version:
+                    self.engine.bind_state_dict(self.accelerator.unwrap_model(self.transformer).state_dict())
+                    self.engine.ready()
+                    self._bound_version = self._weights_version
+
+            def rollout(self, *a, **k):
+                self._weights_version += 1
+                return _RefWan.rollout(self, *a, **k)
+
+            def eval(self, *a, **k):
+                self._weights_version += 1
+                return _RefWan.eval(self, *a, **k)
+
+            @torch.no_grad()
+            def inference(self, *args, **kwargs):
+                self._sync_weights()
+                return _WanMirror.inference(self, *args, **kwargs)
+
+            def forward(self, *args, **kwargs):
+                if torch.is_grad_enabled():
+                    return _RefWan.forward(self, *args, **kwargs)
+                self._sync_weights()
+                return _WanMirror.forward(self, *args, **kwargs)
+
 else:
 
     class SD3_5NativeAdapter:  # type: ignore[no-redef]
         def __init__(self, *a, **k):
             raise ImportError("mi355_flow.flow_factory_plugin needs an importable `flow_factory` (with diffusers/peft): "
                               f"{_IMPORT_ERROR!r}.  Use mi355_flow.adapter.SD3_5NativeAdapter standalone instead.")
+
+    class Wan2T2VNativeAdapter:  # type: ignore[no-redef]
+        def __init__(self, *a, **k):
+            raise ImportError("mi355_flow.flow_factory_plugin needs an importable `flow_factory` (with diffusers/peft): "
+                              f"{_IMPORT_ERROR!r}.  Use mi355_flow.wan.Wan2T2VNativeAdapter standalone instead.")
 
     class Flux1NativeAdapter:  # type: ignore[no-redef]
         def __init__(self, *a, **k):

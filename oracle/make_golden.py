@@ -276,6 +276,19 @@ def gen_flux_tiny():
     np.savez_compressed(os.path.join(OUT, "flux_tiny_self.npz"), y=_np(y))
 
 
+def gen_wan_tiny():
+    """[SELF] Wan2.1 transformer restatement (parity unpinned, oracle/wan_ref.py): drift guard only."""
+    from oracle import wan_ref as W
+    cfg = W.tiny_config()
+    sd = W.make_synthetic_state_dict(cfg, seed=41)
+    g = torch.Generator().manual_seed(42)
+    B, T, h, w, Nt = 2, 2, 4, 6, 5
+    x = torch.randn(B, 16, T, h, w, generator=g)
+    enc = torch.randn(B, Nt, cfg.text_dim, generator=g)
+    y = W.wan_forward(sd, cfg, x, torch.tensor([874.0, 249.0]), enc)
+    np.savez_compressed(os.path.join(OUT, "wan_tiny_self.npz"), y=_np(y))
+
+
 # ------------------------------------------------------------------ [REF] group-contiguous sampler (DP partitioner)
 def gen_sampler():
     import importlib.util
@@ -310,6 +323,7 @@ def main():
     gen_mmdit_tiny()
     gen_vae_tiny()
     gen_flux_tiny()
+    gen_wan_tiny()
     gen_sampler()
     print(f"wrote fixtures to {OUT} ({n} scheduler step cases)")
 

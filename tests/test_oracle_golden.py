@@ -162,6 +162,30 @@ def test_flux_oracle_self_consistency():
     assert (Fx.flux_forward(sd2, cfg, x, torch.tensor([0.9, 0.4]), torch.tensor([3.5, 3.5]), pool, enc, ids) - y).abs().max() > 1e-4
 
 
+def test_wan_oracle_self_consistency():
+    """[SELF] fixture for the (unpinned) WanTransformer3DModel restatement + checks of its pieces against torch built-ins: the per-frame
+    (1,2,2) patchify equals Conv3d, the 3-D rotary embedding is a rotation, un-patchify inverts the token order."""
+    from oracle import wan_ref as W
+    z = _load("wan_tiny_self.npz")
+    cfg = W.tiny_config()
+    sd = W.make_synthetic_state_dict(cfg, seed=41)
+    g = torch.Generator().manual_seed(42)
+    B, T, h, w, Nt = 2, 2, 4, 6, 5
+    x = torch.randn(B, 16, T, h, w, generator=g)
+    enc = torch.randn(B, Nt, cfg.text_dim, generator=g)
+    y = W.wan_forward(sd, cfg, x, torch.tensor([874.0, 249.0]), enc)
+    np.testing.assert_allclose(y.numpy(), z["y"], rtol=1e-4, atol=1e-5)
+    conv = torch.nn.functional.conv3d(x, sd["patch_embedding.weight"], sd["patch_embedding.bias"], stride=(1, 2, 2)).flatten(2).transpose(1, 2)
+    mine = torch.nn.functional.linear(W.patchify(x), sd["patch_embedding.weight"].reshape(cfg.dim, -1), sd["patch_embedding.bias"])
+    torch.testing.assert_close(mine, conv, rtol=1e-5, atol=1e-5)
+    cos, sin = W.rope_cos_sin(T, h // 2, w // 2)
+    v = torch.randn(1, 2, T * (h // 2) * (w // 2), 128, generator=g)
+    torch.testing.assert_close(W.apply_rope(v, cos, sin).norm(dim=-1), v.norm(dim=-1), rtol=1e-5, atol=1e-5)
+    assert W.rope_axes(128) == (44, 42, 42)
+    ts, sig = W.unipc_flow_schedule(4, 3.0)
+    assert ts.dtype == torch.int64 and ts.tolist() == sorted(ts.tolist(), reverse=True) and float(sig[-1]) == 0.0
+
+
 def test_flops_formula():
     # SURVEY.md 8(d): F(4096,333) = 1.125e13, F(256,333) = 9.09e11
     assert abs(mmditx_ref.forward_flops(mmditx_ref.SD35_MEDIUM, 4096, 333) / 1.125e13 - 1) < 2e-3
