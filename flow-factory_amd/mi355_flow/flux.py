@@ -321,14 +321,22 @@ class Flux1NativeAdapter:
         eta_host = self.scheduler.host_noise_levels()
         storage = self.latent_storage_dtype or dtype
         plan = self.engine.plan(B, h, w, prompt_embeds.shape[1], N)
-        if any(k != "noise_level" for k in extra_call_back_kwargs):
-            raise ValueError("mi355_flow: the FLUX rollout captures only 'noise_level' as an extra callback value")
+        stepwise = any(k != "noise_level" for k in extra_call_back_kwargs)
         kept = _resolve(trajectory_indices, N + 1)
         keep_positions = list(range(N + 1)) if kept is None else sorted(kept)
-        lat_kept, log_probs, final = plan.rollout(ts_host, sig_host, eta_host, self.scheduler.dynamics_type, guidance_scale, latents,
-                                                  storage, step_noise, prompt_embeds, pooled_prompt_embeds,
-                                                  keep_positions=keep_positions, compute_log_prob=compute_log_prob)
-        pos_to_slot = {p: s for s, p in enumerate(keep_positions)}
+        step_outputs = None
+        if not stepwise:
+            lat_kept, log_probs, final = plan.rollout(ts_host, sig_host, eta_host, self.scheduler.dynamics_type, guidance_scale, latents,
+                                                      storage, step_noise, prompt_embeds, pooled_prompt_embeds,
+                                                      keep_positions=keep_positions, compute_log_prob=compute_log_prob)
+            pos_to_slot = {p: s for s, p in enumerate(keep_positions)}
+        else:
+            # per-step engine calls (still all-HIP) for rollouts that ask for per-step callback tensors
+            lat_kept, log_probs, step_outputs = self._rollout_stepwise(plan, ts_host, sig_host, eta_host, guidance_scale, latents, storage,
+                                                                       step_noise, prompt_embeds, pooled_prompt_embeds, compute_log_prob,
+                                                                       extra_call_back_kwargs)
+            final = lat_kept[N]
+            pos_to_slot = {p: p for p in range(N + 1)}
 
         latent_collector = create_trajectory_collector(trajectory_indices, N)
         log_prob_collector = create_trajectory_collector(trajectory_indices, N) if compute_log_prob else None
@@ -340,7 +348,8 @@ class Flux1NativeAdapter:
                 latent_collector.collect(lat_kept[pos_to_slot[i + 1]], i + 1)
             if compute_log_prob and eta_host[i] > 0:
                 log_prob_collector.collect(log_probs[i], i)
-            callback_collector.collect_step(step_idx=i, output=None, keys=extra_call_back_kwargs, capturable={"noise_level": eta_host[i]})
+            callback_collector.collect_step(step_idx=i, output=step_outputs[i] if step_outputs is not None else None,
+                                            keys=extra_call_back_kwargs, capturable={"noise_level": eta_host[i]})
 
         images = self.decode_latents(final, height, width, output_type="pt")
         cb_res = callback_collector.get_result()
@@ -369,6 +378,29 @@ class Flux1NativeAdapter:
             )
             for b in range(B)
         ]
+
+    def _rollout_stepwise(self, plan, ts, sig, eta, guidance, latents, storage, step_noise, pe, pp, compute_log_prob, extra_keys):
+        N, B = len(ts), latents.shape[0]
+        cur = self.cast_latents(latents, storage)
+        all_lat = [cur]
+        log_probs = torch.full((N, B), float("nan"), device=latents.device)
+        outs = []
+        want = tuple(k for k in extra_keys if k in ("next_latents", "next_latents_mean", "noise_pred", "std_dev_t", "dt"))
+        f32 = lambda v: torch.tensor(float(v), dtype=torch.float32)
+        gm = (torch.tensor(float(guidance)).to(storage) * 1000).float().reshape(1) if self.engine.cfg.guidance_embeds else None
+        for i in range(N):
+            t_next = ts[i + 1] if i + 1 < N else 0.0
+            clp = compute_log_prob and eta[i] > 0
+            tm = ((f32(ts[i]) / f32(1000.0)).to(storage) * 1000).float().reshape(1)      # as mi355_flux_rollout's host math
+            v = plan.transformer_forward(cur, tm, gm, pe, pp)
+            o = sde_step(v, None, 1.0, cur, f32(ts[i]) / f32(1000.0), f32(t_next) / f32(1000.0), eta[i], sig[1], self.scheduler.dynamics_type,
+                         noise=step_noise[i], compute_log_prob=clp, want=want)
+            if clp:
+                log_probs[i] = o.log_prob
+            cur = o.next_storage
+            all_lat.append(cur)
+            outs.append(o)
+        return all_lat, log_probs, outs
 
     # ------------------------------------------------------------------ single step / replay (flux1.py:294-346), no-grad
     @torch.no_grad()

@@ -180,3 +180,27 @@ def test_flux_full_width_blocks_large_grid_dispatch(fx):
     rel = ((got - ref).norm() / ref.norm()).item()
     assert rel < 2e-2, rel
     eng.close()
+
+
+def test_flux_stepwise_callbacks_equal_fused_rollout(fx):
+    """extra_call_back_kwargs that need per-step tensors switch to per-step engine calls: same kernels, bit-identical trajectory."""
+    from oracle import flux_ref as R
+    from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
+    cfg_o = R.tiny_config()
+    sd, cfg = _setup(fx, cfg_o, seed=3)
+    sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[0, 1, 2], num_sde_steps=2, seed=1, dynamics_type="Flow-SDE",
+                                               shift=3.0, use_dynamic_shifting=True)
+    ad = fx.Flux1NativeAdapter({k: v.cuda() for k, v in sd.items()}, cfg, sched)
+    ad.rollout()
+    g = torch.Generator().manual_seed(1)
+    pe = torch.randn(2, 16, cfg_o.joint_attention_dim, generator=g).bfloat16().cuda()
+    pp = torch.randn(2, cfg_o.pooled_projection_dim, generator=g).bfloat16().cuda()
+    kw = dict(prompt=["a", "b"], height=64, width=64, num_inference_steps=4, guidance_scale=3.5, prompt_embeds=pe, pooled_prompt_embeds=pp)
+    torch.cuda.manual_seed(5)
+    a = ad.inference(**kw)
+    torch.cuda.manual_seed(5)
+    b = ad.inference(**kw, extra_call_back_kwargs=["noise_pred", "noise_level"])
+    for sa, sb in zip(a, b):
+        assert torch.equal(sa.all_latents, sb.all_latents) and torch.equal(sa.log_probs, sb.log_probs)
+        assert sb.extra_kwargs["noise_pred"].shape[0] == 4 and sb.extra_kwargs["noise_pred"].shape[1:] == sa.all_latents.shape[1:]
+    ad.engine.close()

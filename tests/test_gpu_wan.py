@@ -111,3 +111,25 @@ def test_wan_errors(wn):
     with pytest.raises(RuntimeError, match="has not been bound"):
         plan.transformer_forward(torch.zeros(1, 16, 1, 4, 4).cuda(), torch.tensor([500.0]), torch.zeros(1, 8, 64).cuda())
     eng.close()
+
+
+def test_wan_stepwise_callbacks_equal_fused_rollout(wn):
+    from oracle import wan_ref as R
+    cfg_o = R.tiny_config()
+    sd, cfg = _setup(wn, cfg_o, seed=8)
+    sched = wn.UniPCMultistepSDEScheduler(flow_shift=3.0, noise_level=0.7, sde_steps=[0, 1, 2], num_sde_steps=2, seed=1)
+    ad = wn.Wan2T2VNativeAdapter({k: v.cuda() for k, v in sd.items()}, cfg, sched)
+    ad.rollout()
+    g = torch.Generator().manual_seed(1)
+    pe = torch.randn(2, 9, cfg_o.text_dim, generator=g).bfloat16().cuda()
+    ne = torch.randn(2, 9, cfg_o.text_dim, generator=g).bfloat16().cuda()
+    kw = dict(prompt=["a", "b"], height=32, width=48, num_frames=5, num_inference_steps=4, guidance_scale=4.0, prompt_embeds=pe,
+              negative_prompt_embeds=ne, compute_log_prob=True)
+    torch.cuda.manual_seed(5)
+    a = ad.inference(**kw)
+    torch.cuda.manual_seed(5)
+    b = ad.inference(**kw, extra_call_back_kwargs=["noise_pred"])
+    for sa, sb in zip(a, b):
+        assert torch.equal(sa.all_latents, sb.all_latents) and torch.equal(sa.log_probs, sb.log_probs)
+        assert sb.extra_kwargs["noise_pred"].shape == (4,) + tuple(sa.all_latents.shape[1:])
+    ad.engine.close()
