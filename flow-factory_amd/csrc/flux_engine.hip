@@ -18,20 +18,10 @@
 #include <vector>
 
 #include "../../include/mi355_flow.h"
-#include "kernels.h"
+#include "engine_common.h"
 
 using namespace mi355;
 
-#define HIPCHK(x)                                                                          \
-    do {                                                                                   \
-        hipError_t _e = (x);                                                               \
-        if (_e != hipSuccess) return errorf("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
-    } while (0)
-#define CHK(x)                 \
-    do {                       \
-        int _r = (x);          \
-        if (_r) return _r;     \
-    } while (0)
 
 namespace {
 
@@ -64,15 +54,6 @@ float host_round(float v, int dt) {
         return v;
     }
     return (float)(_Float16)v;
-}
-
-GemmParams gp(const bf16_t* A, long lda, const bf16_t* W, long ldw, int M, int N, int K, int epi, const float* bias, bf16_t* out,
-              long ldo) {
-    GemmParams g;
-    memset(&g, 0, sizeof(g));
-    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.epi = epi; g.bias = bias;
-    g.out = out; g.ldo = ldo; g.rows_per_sample = M > 0 ? M : 1; g.eps = 1e-6f;
-    return g;
 }
 
 }  // namespace
@@ -272,7 +253,7 @@ extern "C" int mi355_flux_plan_create(mi355_flux* e, int batch, int latent_h, in
     p->Ni = p->hp * p->wp; p->Nt = n_text; p->S = p->Ni + p->Nt; p->S_pad = (p->S + 63) / 64 * 64;
     p->Mi = batch * p->Ni; p->Mc = batch * p->Nt; p->M = batch * p->S; p->max_steps = max_steps;
     p->n_lat = (int64_t)p->Ni * e->cfg.in_channels;
-    const int D = e->D, F = e->F, C = e->cfg.in_channels;
+    const int D = e->D, F = e->F;
     const int64_t rows_cond = (int64_t)max_steps * batch;
     size_t off = 0;
     auto take = [&](int64_t elems, int esz) {
@@ -378,17 +359,17 @@ int update_score_bounds(mi355_flux* e, hipStream_t st) {
 int prepare_prompt(mi355_flux_plan* p, hipStream_t st, const void* enc, const void* pooled) {
     mi355_flux* e = p->e;
     const int D = e->D, J = e->cfg.joint_attention_dim, P = e->cfg.pooled_projection_dim, T = e->cfg.time_proj_dim;
-    GemmParams g = gp((const bf16_t*)enc, J, e->w_ctx, J, p->Mc, D, J, EPI_BIAS, e->b_ctx, p->c0, D);
+    GemmParams g = make_gemm((const bf16_t*)enc, J, e->w_ctx, J, p->Mc, D, J, EPI_BIAS, e->b_ctx, p->c0, D);
     HIPCHK(launch_gemm(g, st));
-    GemmParams g1 = gp((const bf16_t*)pooled, P, e->w_p1, P, p->B, D, P, EPI_BIAS_SILU, e->b_p1, p->p1, D);
+    GemmParams g1 = make_gemm((const bf16_t*)pooled, P, e->w_p1, P, p->B, D, P, EPI_BIAS_SILU, e->b_p1, p->p1, D);
     HIPCHK(launch_gemm(g1, st));
-    GemmParams g2 = gp(p->p1, D, e->w_p2, D, p->B, D, D, EPI_BIAS, e->b_p2, p->pemb, D);
+    GemmParams g2 = make_gemm(p->p1, D, e->w_p2, D, p->B, D, D, EPI_BIAS, e->b_p2, p->pemb, D);
     HIPCHK(launch_gemm(g2, st));
     if (e->cfg.guidance_embeds) {
         HIPCHK(launch_time_proj(p->g_dev, p->B, T, DT_F32, p->gproj, st));
-        GemmParams g3 = gp(p->gproj, T, e->w_g1, T, p->B, D, T, EPI_BIAS_SILU, e->b_g1, p->p1, D);
+        GemmParams g3 = make_gemm(p->gproj, T, e->w_g1, T, p->B, D, T, EPI_BIAS_SILU, e->b_g1, p->p1, D);
         HIPCHK(launch_gemm(g3, st));
-        GemmParams g4 = gp(p->p1, D, e->w_g2, D, p->B, D, D, EPI_POSADD, e->b_g2, p->gemb, D);    // + text_emb
+        GemmParams g4 = make_gemm(p->p1, D, e->w_g2, D, p->B, D, D, EPI_POSADD, e->b_g2, p->gemb, D);    // + text_emb
         g4.aux = p->pemb; g4.ld_aux = D; g4.rows_per_sample = p->B;
         HIPCHK(launch_gemm(g4, st));
     } else {
@@ -403,12 +384,12 @@ int prepare_conditioning(mi355_flux_plan* p, hipStream_t st, int nsteps) {
     const int D = e->D, T = e->cfg.time_proj_dim;
     const int rows = nsteps * p->B;
     HIPCHK(launch_time_proj(p->t_dev, rows, T, DT_F32, p->tproj, st));
-    GemmParams g1 = gp(p->tproj, T, e->w_t1, T, rows, D, T, EPI_BIAS_SILU, e->b_t1, p->h1, D);
+    GemmParams g1 = make_gemm(p->tproj, T, e->w_t1, T, rows, D, T, EPI_BIAS_SILU, e->b_t1, p->h1, D);
     HIPCHK(launch_gemm(g1, st));
-    GemmParams g2 = gp(p->h1, D, e->w_t2, D, rows, D, D, EPI_ADDSRC_SILU, e->b_t2, p->semb, D);
+    GemmParams g2 = make_gemm(p->h1, D, e->w_t2, D, rows, D, D, EPI_ADDSRC_SILU, e->b_t2, p->semb, D);
     g2.aux = p->gemb; g2.ld_aux = D; g2.rows_per_sample = p->B;
     HIPCHK(launch_gemm(g2, st));
-    GemmParams g3 = gp(p->semb, D, e->w_mod, D, rows, e->mod_cols, D, EPI_BIAS, e->b_mod, p->mod_all, e->mod_cols);
+    GemmParams g3 = make_gemm(p->semb, D, e->w_mod, D, rows, e->mod_cols, D, EPI_BIAS, e->b_mod, p->mod_all, e->mod_cols);
     HIPCHK(launch_gemm(g3, st));
     return 0;
 }
@@ -429,7 +410,7 @@ int qkv(mi355_flux_plan* p, hipStream_t st, const bf16_t* xin, int M, int rps, i
         const bf16_t* w_v, const float* b_v, const float* nq, const float* nk) {
     mi355_flux* e = p->e;
     const int D = e->D;
-    GemmParams g = gp(xin, D, w_qk, D, M, 2 * D, D, EPI_BIAS, b_qk, p->qkbuf, 2 * D);
+    GemmParams g = make_gemm(xin, D, w_qk, D, M, 2 * D, D, EPI_BIAS, b_qk, p->qkbuf, 2 * D);
     HIPCHK(launch_gemm(g, st));
     RopeNormParams r;
     memset(&r, 0, sizeof(r));
@@ -437,7 +418,7 @@ int qkv(mi355_flux_plan* p, hipStream_t st, const bf16_t* xin, int M, int rps, i
     r.q_out = p->q; r.k_out = p->k; r.M = M; r.H = e->H; r.rows_per_sample = rps; r.s_off = s_off; r.S_pad = p->S_pad;
     r.eps = e->cfg.eps; r.q_scale = 0.08838834764831845f * 1.4426950408889634f;
     HIPCHK(launch_rope_norm(r, st));
-    GemmParams gv = gp(w_v, D, xin, D, D, M, D, EPI_VT, b_v, nullptr, 0);
+    GemmParams gv = make_gemm(w_v, D, xin, D, D, M, D, EPI_VT, b_v, nullptr, 0);
     gv.q = p->vT; gv.H = e->H; gv.S_pad = p->S_pad; gv.s_off = s_off; gv.rows_per_sample = rps; gv.hd_shift = 7;
     HIPCHK(launch_gemm(gv, st));
     return 0;
@@ -445,7 +426,7 @@ int qkv(mi355_flux_plan* p, hipStream_t st, const bf16_t* xin, int M, int rps, i
 
 int gate_res(mi355_flux_plan* p, hipStream_t st, const bf16_t* A, long lda, int K, const bf16_t* W, const float* bias, bf16_t* x,
              int M, int rps, const bf16_t* mod, int gate_off) {
-    GemmParams g = gp(A, lda, W, K, M, p->e->D, K, EPI_GATE_RES, bias, x, p->e->D);
+    GemmParams g = make_gemm(A, lda, W, K, M, p->e->D, K, EPI_GATE_RES, bias, x, p->e->D);
     g.aux = mod + gate_off; g.ld_aux = p->e->mod_cols; g.rows_per_sample = rps;
     HIPCHK(launch_gemm(g, st));
     return 0;
@@ -472,7 +453,7 @@ int forward_core(mi355_flux_plan* p, hipStream_t st, const void* latents, int la
         HIPCHK(launch_convert(latents, lat_dt, p->lat16, DT_BF16, (long)p->B * p->n_lat, st));
         lat = p->lat16;
     }
-    GemmParams gx = gp(lat, C, e->w_x, C, p->Mi, D, C, EPI_BIAS, e->b_x, p->x, D);
+    GemmParams gx = make_gemm(lat, C, e->w_x, C, p->Mi, D, C, EPI_BIAS, e->b_x, p->x, D);
     HIPCHK(launch_gemm(gx, st));
     HIPCHK(hipMemcpyAsync(p->c, p->c0, (size_t)p->Mc * D * 2, hipMemcpyDeviceToDevice, st));
     for (int i = 0; i < e->L; ++i) {
@@ -486,11 +467,11 @@ int forward_core(mi355_flux_plan* p, hipStream_t st, const void* latents, int la
         CHK(gate_res(p, st, p->o_img, D, D, b.w_o, b.b_o, p->x, p->Mi, Ni, mod, mi + 2 * D));
         CHK(gate_res(p, st, p->o_ctx, D, D, b.w_co, b.b_co, p->c, p->Mc, Nt, mod, mc + 2 * D));
         CHK(ln_mod(p, st, p->x, p->xn, mod, p->Mi, Ni, mi + 3 * D, mi + 4 * D));
-        GemmParams f1 = gp(p->xn, D, b.w_ff1, D, p->Mi, F, D, EPI_BIAS_GELU, b.b_ff1, p->big, F);
+        GemmParams f1 = make_gemm(p->xn, D, b.w_ff1, D, p->Mi, F, D, EPI_BIAS_GELU, b.b_ff1, p->big, F);
         HIPCHK(launch_gemm(f1, st));
         CHK(gate_res(p, st, p->big, F, F, b.w_ff2, b.b_ff2, p->x, p->Mi, Ni, mod, mi + 5 * D));
         CHK(ln_mod(p, st, p->c, p->cn, mod, p->Mc, Nt, mc + 3 * D, mc + 4 * D));
-        GemmParams c1 = gp(p->cn, D, b.w_cff1, D, p->Mc, F, D, EPI_BIAS_GELU, b.b_cff1, p->big, F);
+        GemmParams c1 = make_gemm(p->cn, D, b.w_cff1, D, p->Mc, F, D, EPI_BIAS_GELU, b.b_cff1, p->big, F);
         HIPCHK(launch_gemm(c1, st));
         CHK(gate_res(p, st, p->big, F, F, b.w_cff2, b.b_cff2, p->c, p->Mc, Nt, mod, mc + 5 * D));
     }
@@ -504,7 +485,7 @@ int forward_core(mi355_flux_plan* p, hipStream_t st, const void* latents, int la
         const int m0 = b.mod;                          // chunks: shift, scale, gate
         CHK(ln_mod(p, st, p->y, p->yn, mod, p->M, S, m0, m0 + D));
         CHK(qkv(p, st, p->yn, p->M, S, 0, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk));
-        GemmParams gm = gp(p->yn, D, b.w_mlp, D, p->M, F, D, EPI_BIAS_GELU, b.b_mlp, p->big + D, D + F);
+        GemmParams gm = make_gemm(p->yn, D, b.w_mlp, D, p->M, F, D, EPI_BIAS_GELU, b.b_mlp, p->big + D, D + F);
         HIPCHK(launch_gemm(gm, st));
         CHK(attention(p, st, p->big, D + F, S, p->big, D + F, b.bound));
         CHK(gate_res(p, st, p->big, D + F, D + F, b.w_out, b.b_out, p->y, p->M, S, mod, m0 + 2 * D));
@@ -513,7 +494,7 @@ int forward_core(mi355_flux_plan* p, hipStream_t st, const void* latents, int la
     HIPCHK(hipMemcpy2DAsync(p->x, (size_t)Ni * rowb, p->y + (size_t)Nt * D, (size_t)S * rowb, (size_t)Ni * rowb, p->B,
                             hipMemcpyDeviceToDevice, st));
     CHK(ln_mod(p, st, p->x, p->xn, mod, p->Mi, Ni, e->mod_out + D, e->mod_out));
-    GemmParams go = gp(p->xn, D, e->w_proj, D, p->Mi, C, D, EPI_BIAS, e->b_proj, v_out, C);
+    GemmParams go = make_gemm(p->xn, D, e->w_proj, D, p->Mi, C, D, EPI_BIAS, e->b_proj, v_out, C);
     HIPCHK(launch_gemm(go, st));
     return 0;
 }

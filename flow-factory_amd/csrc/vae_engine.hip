@@ -15,20 +15,10 @@
 #include <vector>
 
 #include "../../include/mi355_flow.h"
-#include "kernels.h"
+#include "engine_common.h"
 
 using namespace mi355;
 
-#define HIPCHK(x)                                                                          \
-    do {                                                                                   \
-        hipError_t _e = (x);                                                               \
-        if (_e != hipSuccess) return errorf("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
-    } while (0)
-#define CHK(x)                 \
-    do {                       \
-        int _r = (x);          \
-        if (_r) return _r;     \
-    } while (0)
 
 namespace {
 
@@ -263,15 +253,6 @@ extern "C" int64_t mi355_vae_plan_workspace_bytes(mi355_vae_plan* p) { return p 
 // ------------------------------------------------------------------------------------ decode
 namespace {
 
-GemmParams base_gemm(const bf16_t* A, long lda, const bf16_t* W, long ldw, long M, int N, int K, int epi, const float* bias,
-                     bf16_t* out, long ldo) {
-    GemmParams g;
-    memset(&g, 0, sizeof(g));
-    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = (int)M; g.N = N; g.K = K; g.epi = epi; g.bias = bias;
-    g.out = out; g.ldo = ldo; g.rows_per_sample = (int)M; g.eps = 1e-6f;
-    return g;
-}
-
 struct Ctx {
     mi355_vae_plan* p; hipStream_t st; int B;
 };
@@ -280,7 +261,7 @@ struct Ctx {
 int conv3(const Ctx& c, const ConvW& cw, const bf16_t* in, bf16_t* out, int H, int W, int up, const bf16_t* res) {
     const long M = (long)c.B * H * W;
     if (M > 0x7fffffffL) return errorf("mi355_vae_decode: %ld pixels exceed the GEMM row range", M);
-    GemmParams g = base_gemm(in, cw.cipad, cw.w, 9L * cw.cipad, M, cw.co, 9 * cw.cipad, res ? EPI_POSADD : EPI_BIAS, cw.b, out, cw.co);
+    GemmParams g = make_gemm(in, cw.cipad, cw.w, 9L * cw.cipad, M, cw.co, 9 * cw.cipad, res ? EPI_POSADD : EPI_BIAS, cw.b, out, cw.co);
     g.conv_cin = cw.cipad; g.conv_h = H; g.conv_w = W; g.conv_up = up; g.zero_page = c.p->v->zero_page;
     g.aux = res; g.ld_aux = cw.co;
     HIPCHK(launch_gemm(g, c.st));
@@ -301,7 +282,7 @@ int resnet(const Ctx& c, const Resnet& r, int H, int W) {
     CHK(conv3(c, r.c1, p->T1, p->T2, H, W, 0, nullptr));
     CHK(group_norm(c, r.n2, p->T2, p->T1, HW, true));
     if (r.has_sc) {
-        GemmParams g = base_gemm(p->X, r.ci, r.sc.w, r.ci, M, r.co, r.ci, EPI_BIAS, r.sc.b, p->T2, r.co);
+        GemmParams g = make_gemm(p->X, r.ci, r.sc.w, r.ci, M, r.co, r.ci, EPI_BIAS, r.sc.b, p->T2, r.co);
         HIPCHK(launch_gemm(g, c.st));
         CHK(conv3(c, r.c2, p->T1, p->X, H, W, 0, p->T2));
     } else {
@@ -318,22 +299,22 @@ int mid_attention(const Ctx& c, int H, int W) {
     const int C = v->attn_gn.c;
     const long S = (long)H * W, M = c.B * S;
     CHK(group_norm(c, v->attn_gn, p->X, p->T1, S, false));
-    GemmParams gqk = base_gemm(p->T1, C, v->to_qk.w, C, M, 2 * C, C, EPI_BIAS, v->to_qk.b, p->T2, 2 * C);
+    GemmParams gqk = make_gemm(p->T1, C, v->to_qk.w, C, M, 2 * C, C, EPI_BIAS, v->to_qk.b, p->T2, 2 * C);
     HIPCHK(launch_gemm(gqk, c.st));
     const float scale = 1.0f / sqrtf((float)C);
     for (int b = 0; b < c.B; ++b) {
         const bf16_t* hn = p->T1 + (size_t)b * S * C;
         const bf16_t* q = p->T2 + (size_t)b * S * 2 * C;
-        GemmParams gv = base_gemm(v->to_v.w, C, hn, C, C, (int)S, C, EPI_BIAS_ROW, v->to_v.b, p->VT, S);
+        GemmParams gv = make_gemm(v->to_v.w, C, hn, C, C, (int)S, C, EPI_BIAS_ROW, v->to_v.b, p->VT, S);
         HIPCHK(launch_gemm(gv, c.st));
-        GemmParams gs = base_gemm(q, 2 * C, q + C, 2 * C, S, (int)S, C, EPI_F32, nullptr, nullptr, S);
+        GemmParams gs = make_gemm(q, 2 * C, q + C, 2 * C, S, (int)S, C, EPI_F32, nullptr, nullptr, S);
         gs.out_f32 = p->SC; gs.q_scale = 1.0f;
         HIPCHK(launch_gemm(gs, c.st));
         HIPCHK(launch_softmax_rows(p->SC, p->P, S, (int)S, scale, c.st));
-        GemmParams go = base_gemm(p->P, S, p->VT, S, S, C, (int)S, EPI_BIAS, v->zero_bias, p->Y + (size_t)b * S * C, C);
+        GemmParams go = make_gemm(p->P, S, p->VT, S, S, C, (int)S, EPI_BIAS, v->zero_bias, p->Y + (size_t)b * S * C, C);
         HIPCHK(launch_gemm(go, c.st));
     }
-    GemmParams gout = base_gemm(p->Y, C, v->to_out.w, C, M, C, C, EPI_POSADD, v->to_out.b, p->X, C);
+    GemmParams gout = make_gemm(p->Y, C, v->to_out.w, C, M, C, C, EPI_POSADD, v->to_out.b, p->X, C);
     gout.aux = p->X; gout.ld_aux = C;
     HIPCHK(launch_gemm(gout, c.st));
     return 0;
@@ -372,7 +353,7 @@ extern "C" int mi355_vae_decode(mi355_vae_plan* p, void* stream, const void* lat
     {
         const ConvW& cw = v->conv_out;
         const long M = (long)batch * H * W;
-        GemmParams g = base_gemm(p->T1, cw.cipad, cw.w, 9L * cw.cipad, M, cw.co, 9 * cw.cipad, EPI_IMG, cw.b, nullptr, 0);
+        GemmParams g = make_gemm(p->T1, cw.cipad, cw.w, 9L * cw.cipad, M, cw.co, 9 * cw.cipad, EPI_IMG, cw.b, nullptr, 0);
         g.conv_cin = cw.cipad; g.conv_h = H; g.conv_w = W; g.zero_page = v->zero_page;
         g.img_post = postprocess;
         if (img_dtype == DT_F32) g.out_f32 = (float*)images; else g.out = (bf16_t*)images;
@@ -393,7 +374,7 @@ extern "C" int mi355_op_conv3x3(void* stream, const void* x, const void* w_packe
         HIPCHK(hipMemset(g_zero_page, 0, 256));
     }
     const long M = (long)B * H * W;
-    GemmParams g = base_gemm((const bf16_t*)x, Cin, (const bf16_t*)w_packed, 9L * Cin, M, Cout, 9 * Cin,
+    GemmParams g = make_gemm((const bf16_t*)x, Cin, (const bf16_t*)w_packed, 9L * Cin, M, Cout, 9 * Cin,
                              residual ? EPI_POSADD : EPI_BIAS, bias, (bf16_t*)out, Cout);
     g.conv_cin = Cin; g.conv_h = H; g.conv_w = W; g.conv_up = upsample; g.zero_page = g_zero_page;
     g.aux = (const bf16_t*)residual; g.ld_aux = Cout;

@@ -19,20 +19,10 @@
 #include <vector>
 
 #include "../../include/mi355_flow.h"
-#include "kernels.h"
+#include "engine_common.h"
 
 using namespace mi355;
 
-#define HIPCHK(x)                                                                          \
-    do {                                                                                   \
-        hipError_t _e = (x);                                                               \
-        if (_e != hipSuccess) return errorf("%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
-    } while (0)
-#define CHK(x)                 \
-    do {                       \
-        int _r = (x);          \
-        if (_r) return _r;     \
-    } while (0)
 
 namespace {
 
@@ -45,15 +35,6 @@ struct WanBlockW {
     float* table;          // scale_shift_table [6][D] fp32
     bf16_t* ln2_mod;       // (bias, weight - 1) rows for ln_mod, built at weights_ready time
 };
-
-GemmParams gp(const bf16_t* A, long lda, const bf16_t* W, long ldw, int M, int N, int K, int epi, const float* bias, bf16_t* out,
-              long ldo) {
-    GemmParams g;
-    memset(&g, 0, sizeof(g));
-    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.M = M; g.N = N; g.K = K; g.epi = epi; g.bias = bias;
-    g.out = out; g.ldo = ldo; g.rows_per_sample = M > 0 ? M : 1; g.eps = 1e-6f;
-    return g;
-}
 
 }  // namespace
 
@@ -356,7 +337,7 @@ int norm_rope(mi355_wan_plan* p, hipStream_t st, const bf16_t* src, long ld, int
 
 int vt_proj(mi355_wan_plan* p, hipStream_t st, const bf16_t* w_v, const float* b_v, const bf16_t* xin, int M, int rps, bf16_t* vT, int S_pad) {
     const int D = p->e->D;
-    GemmParams gv = gp(w_v, D, xin, D, D, M, D, EPI_VT, b_v, nullptr, 0);
+    GemmParams gv = make_gemm(w_v, D, xin, D, D, M, D, EPI_VT, b_v, nullptr, 0);
     gv.q = vT; gv.H = p->e->H; gv.S_pad = S_pad; gv.s_off = 0; gv.rows_per_sample = rps; gv.hd_shift = 7;
     HIPCHK(launch_gemm(gv, st));
     return 0;
@@ -364,7 +345,7 @@ int vt_proj(mi355_wan_plan* p, hipStream_t st, const bf16_t* w_v, const float* b
 
 int gate_res(mi355_wan_plan* p, hipStream_t st, const bf16_t* A, int K, const bf16_t* W, const float* bias, bf16_t* x, int M, int rps,
              const bf16_t* mod, int gate_off) {
-    GemmParams g = gp(A, K, W, K, M, p->e->D, K, EPI_GATE_RES, bias, x, p->e->D);
+    GemmParams g = make_gemm(A, K, W, K, M, p->e->D, K, EPI_GATE_RES, bias, x, p->e->D);
     g.aux = mod + gate_off; g.ld_aux = p->mod_cols; g.rows_per_sample = rps;
     HIPCHK(launch_gemm(g, st));
     return 0;
@@ -378,15 +359,15 @@ int prepare_prompt(mi355_wan_plan* p, hipStream_t st, const void* enc_a, const v
     if (p->ncfg == 2 && !enc_b) return errorf("n_cfg == 2 needs both prompt halves");
     for (int half = 0; half < p->ncfg; ++half) {
         const int rows = p->B * p->Nt;
-        GemmParams g1 = gp((const bf16_t*)encs[half], J, e->w_x1, J, rows, D, J, EPI_BIAS_GELU, e->b_x1, p->c1 + (int64_t)half * rows * D, D);
+        GemmParams g1 = make_gemm((const bf16_t*)encs[half], J, e->w_x1, J, rows, D, J, EPI_BIAS_GELU, e->b_x1, p->c1 + (int64_t)half * rows * D, D);
         HIPCHK(launch_gemm(g1, st));
     }
-    GemmParams g2 = gp(p->c1, D, e->w_x2, D, p->Mc, D, D, EPI_BIAS, e->b_x2, p->ctx, D);
+    GemmParams g2 = make_gemm(p->c1, D, e->w_x2, D, p->Mc, D, D, EPI_BIAS, e->b_x2, p->ctx, D);
     HIPCHK(launch_gemm(g2, st));
     const int64_t kx_el = (int64_t)p->Bp * e->H * p->Nt_pad * 128;
     for (int i = 0; i < e->L; ++i) {
         const WanBlockW& b = e->blk[i];
-        GemmParams gk = gp(p->ctx, D, b.w_kv2, D, p->Mc, D, D, EPI_BIAS, b.b_kv2, p->kvbuf, D);     // to_k
+        GemmParams gk = make_gemm(p->ctx, D, b.w_kv2, D, p->Mc, D, D, EPI_BIAS, b.b_kv2, p->kvbuf, D);     // to_k
         HIPCHK(launch_gemm(gk, st));
         CHK(norm_rope(p, st, p->kvbuf, D, 0, b.nk2, false, p->kx + i * kx_el, p->Mc, p->Nt, p->Nt_pad, 1.0f));
         CHK(vt_proj(p, st, b.w_kv2 + (int64_t)D * D, b.b_kv2 + D, p->ctx, p->Mc, p->Nt, p->vTx + i * kx_el, p->Nt_pad));
@@ -400,13 +381,13 @@ int prepare_conditioning(mi355_wan_plan* p, hipStream_t st, int nsteps) {
     const int D = e->D, T = e->cfg.freq_dim;
     const int rows = nsteps * p->Bp;
     HIPCHK(launch_time_proj(p->t_dev, rows, T, DT_F32, p->tproj_in, st));
-    GemmParams g1 = gp(p->tproj_in, T, e->w_t1, T, rows, D, T, EPI_BIAS_SILU, e->b_t1, p->h1, D);
+    GemmParams g1 = make_gemm(p->tproj_in, T, e->w_t1, T, rows, D, T, EPI_BIAS_SILU, e->b_t1, p->h1, D);
     HIPCHK(launch_gemm(g1, st));
-    GemmParams g2 = gp(p->h1, D, e->w_t2, D, rows, D, D, EPI_BIAS, e->b_t2, p->temb, D);
+    GemmParams g2 = make_gemm(p->h1, D, e->w_t2, D, rows, D, D, EPI_BIAS, e->b_t2, p->temb, D);
     HIPCHK(launch_gemm(g2, st));
-    GemmParams g3 = gp(p->h1, D, e->w_t2, D, rows, D, D, EPI_BIAS_SILU, e->b_t2, p->semb, D);       // silu(temb) for time_proj
+    GemmParams g3 = make_gemm(p->h1, D, e->w_t2, D, rows, D, D, EPI_BIAS_SILU, e->b_t2, p->semb, D);       // silu(temb) for time_proj
     HIPCHK(launch_gemm(g3, st));
-    GemmParams g4 = gp(p->semb, D, e->w_tp, D, rows, 6 * D, D, EPI_BIAS, e->b_tp, p->tp6, 6 * D);
+    GemmParams g4 = make_gemm(p->semb, D, e->w_tp, D, rows, 6 * D, D, EPI_BIAS, e->b_tp, p->tp6, 6 * D);
     HIPCHK(launch_gemm(g4, st));
     for (int i = 0; i < e->L; ++i)
         HIPCHK(launch_bcast_add(p->tp6, e->blk[i].table, p->mod_all + (int64_t)i * 6 * D, p->mod_cols, rows, 6 * D, 1, st));
@@ -420,14 +401,14 @@ int forward_core(mi355_wan_plan* p, hipStream_t st, const void* latents, int lat
     const int D = e->D, F = e->F, M = p->M, S = p->S;
     const int64_t kx_el = (int64_t)p->Bp * e->H * p->Nt_pad * 128;
     HIPCHK(launch_patchify(latents, lat_dt, p->patches, p->B, p->ncfg, e->cfg.in_channels, p->T * p->h, p->w, 2, st));
-    GemmParams g0 = gp(p->patches, e->KP, e->w_patch, e->KP, M, D, e->KP, EPI_BIAS, e->b_patch, p->x, D);
+    GemmParams g0 = make_gemm(p->patches, e->KP, e->w_patch, e->KP, M, D, e->KP, EPI_BIAS, e->b_patch, p->x, D);
     HIPCHK(launch_gemm(g0, st));
     for (int i = 0; i < e->L; ++i) {
         const WanBlockW& b = e->blk[i];
         const int m0 = i * 6 * D;        // chunks: shift, scale, gate, c_shift, c_scale, c_gate
         // ---- self-attention
         CHK(ln_mod(p, st, p->x, p->xn, mod, p->mod_cols, M, S, m0, m0 + D));
-        GemmParams gq = gp(p->xn, D, b.w_qk, D, M, 2 * D, D, EPI_BIAS, b.b_qk, p->qkbuf, 2 * D);
+        GemmParams gq = make_gemm(p->xn, D, b.w_qk, D, M, 2 * D, D, EPI_BIAS, b.b_qk, p->qkbuf, 2 * D);
         HIPCHK(launch_gemm(gq, st));
         CHK(norm_rope(p, st, p->qkbuf, 2 * D, 0, b.nq, true, p->q, M, S, p->S_pad, kScale));
         CHK(norm_rope(p, st, p->qkbuf, 2 * D, D, b.nk, true, p->k, M, S, p->S_pad, 1.0f));
@@ -442,7 +423,7 @@ int forward_core(mi355_wan_plan* p, hipStream_t st, const void* latents, int lat
         CHK(gate_res(p, st, p->o, D, b.w_o, b.b_o, p->x, M, S, mod, m0 + 2 * D));
         // ---- cross-attention to the cached text keys / values
         CHK(ln_mod(p, st, p->x, p->xn, b.ln2_mod, 0, M, S, 0, D));
-        GemmParams gq2 = gp(p->xn, D, b.w_q2, D, M, D, D, EPI_BIAS, b.b_q2, p->qkbuf, D);
+        GemmParams gq2 = make_gemm(p->xn, D, b.w_q2, D, M, D, D, EPI_BIAS, b.b_q2, p->qkbuf, D);
         HIPCHK(launch_gemm(gq2, st));
         CHK(norm_rope(p, st, p->qkbuf, D, 0, b.nq2, false, p->q, M, S, p->S_pad, kScale));
         {
@@ -453,18 +434,18 @@ int forward_core(mi355_wan_plan* p, hipStream_t st, const void* latents, int lat
             a.S_kv = p->Nt; a.S_kv_pad = p->Nt_pad; a.score_bound = e->bound_cross[i];
             HIPCHK(launch_attention128(a, st));
         }
-        GemmParams go2 = gp(p->o, D, b.w_o2, D, M, D, D, EPI_POSADD, b.b_o2, p->x, D);
+        GemmParams go2 = make_gemm(p->o, D, b.w_o2, D, M, D, D, EPI_POSADD, b.b_o2, p->x, D);
         go2.aux = p->x; go2.ld_aux = D; go2.rows_per_sample = M;
         HIPCHK(launch_gemm(go2, st));
         // ---- feed-forward
         CHK(ln_mod(p, st, p->x, p->xn, mod, p->mod_cols, M, S, m0 + 3 * D, m0 + 4 * D));
-        GemmParams f1 = gp(p->xn, D, b.w_ff1, D, M, F, D, EPI_BIAS_GELU, b.b_ff1, p->hid, F);
+        GemmParams f1 = make_gemm(p->xn, D, b.w_ff1, D, M, F, D, EPI_BIAS_GELU, b.b_ff1, p->hid, F);
         HIPCHK(launch_gemm(f1, st));
         CHK(gate_res(p, st, p->hid, F, b.w_ff2, b.b_ff2, p->x, M, S, mod, m0 + 5 * D));
     }
     const int mo = e->L * 6 * D;         // output modulation: shift, scale
     CHK(ln_mod(p, st, p->x, p->xn, mod, p->mod_cols, M, S, mo, mo + D));
-    GemmParams g = gp(p->xn, D, e->w_proj, D, M, e->NO, D, EPI_UNPATCH, e->b_proj, v_out, 0);
+    GemmParams g = make_gemm(p->xn, D, e->w_proj, D, M, e->NO, D, EPI_UNPATCH, e->b_proj, v_out, 0);
     g.hp = p->T * p->hp; g.wp = p->wp; g.patch = 2; g.out_ch = e->cfg.out_channels;
     HIPCHK(launch_gemm(g, st));
     return 0;
