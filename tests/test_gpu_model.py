@@ -258,3 +258,19 @@ def test_large_norm_weights_fall_back_to_running_max():
         assert _rel(y, ref) < 3e-2        # very peaked softmaxes: bf16 q/k rounding shows a little more
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("B,h,w,Nt", [(1, 2, 2, 1), (1, 2, 4, 3), (5, 6, 2, 2)])
+def test_forward_degenerate_sizes(tiny, B, h, w, Nt):
+    """Smallest legal shapes: one image token (2x2 latent), one text token, odd batch -- every kernel on its ragged / scalar tail path."""
+    from oracle import mmditx_ref as M
+    cfg, engine, e, sd = tiny
+    g = torch.Generator().manual_seed(B * 100 + h * 10 + Nt)
+    x = torch.randn(B, 16, h, w, generator=g).half()
+    enc = torch.randn(B, Nt, cfg.joint_attention_dim, generator=g).bfloat16()
+    pooled = torch.randn(B, cfg.pooled_projection_dim, generator=g).bfloat16()
+    t = torch.full((B,), 500.0)
+    y = e.plan(B, 1, h, w, Nt, 1).transformer_forward(x.cuda(), t.cuda(), enc.cuda(), pooled.cuda())
+    ref = M.mmdit_forward(sd, cfg, x.float(), t, enc.float(), pooled.float())
+    assert torch.isfinite(y.float()).all()
+    assert _rel(y, ref) < 2e-2
