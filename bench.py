@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- denoise-steps/sec of the SD3.5-medium 1024^2 GRPO rollout on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W      (N > 1: re-executes itself under torch.distributed.run, one rank per GPU;
+                                                        when already launched that way -- RANK / WORLD_SIZE set -- it just runs its rank)
 
 One bench "step" = ONE rollout micro-batch through the drop-in API (`SD3_5NativeAdapter.inference`):
 `--batch` samples x 28 SDE/ODE denoise steps at 1024x1024 (latents 16x128x128, 4096 image + 333 text
@@ -50,11 +51,13 @@ def attention_flops(cfg, Ni, Nt):
     return 2.0 * (L * 2 * (Ni + Nt) ** 2 * D + Ld * 2 * Ni * Ni * D), L + Ld  # flops / forward / sample, launches
 
 
-def cpu_baseline(budget_s=30.0):
-    """Oracle on the host cores, bounded: one fp32 MMDiT-X forward at the bench shape if it fits the
-    budget (probed on the 256^2 shape first), else the 256^2 forward scaled by the FLOP ratio."""
+def cpu_baseline(budget_s=150.0):
+    """Oracle on the host cores: ONE measured fp32 MMDiT-X forward (= one denoise step, n_cfg = 1) of one sample at the bench
+    shape (1024^2: 4096 + 333 tokens, 11.25 TFLOP).  A 256^2 forward is timed first; only if its FLOP-scaled estimate exceeds
+    `budget_s` is the 1024^2 figure extrapolated (and labelled so) instead of measured."""
     from oracle import mmditx_ref as M
     cfg = M.SD35_MEDIUM
+    torch.set_num_threads(os.cpu_count() or 1)
     cores = torch.get_num_threads()
     # timing only: draw the 2.5 B fp32 weights on the GPU and copy them down (the CPU generator needs ~1 min)
     from mi355_flow.engine import TransformerConfig
@@ -78,11 +81,71 @@ def cpu_baseline(budget_s=30.0):
     est = t256 * f1024 / f256
     if est <= budget_s:
         t1024 = run(128)
-        return dict(value=1.0 / t1024, unit="denoise-steps/sec", cores=cores, kind="port",
-                    sample=f"1 fp32 oracle forward (= 1 denoise step, n_cfg=1) of 1 sample at 1024^2, {t1024:.2f} s measured; "
-                           f"256^2 forward {t256:.2f} s")
-    return dict(value=1.0 / est, unit="denoise-steps/sec", cores=cores, kind="port",
-                sample=f"1 fp32 oracle forward at 256^2 ({t256:.2f} s measured) EXTRAPOLATED x{f1024 / f256:.1f} by FLOPs to 1024^2")
+        return dict(value=round(1.0 / t1024, 5), unit="denoise-steps/sec", cores=cores, kind="port", measured=True,
+                    sample=f"1 fp32 oracle forward (= 1 denoise step, n_cfg=1) of 1 sample at 1024^2: {t1024:.2f} s MEASURED on {cores} threads "
+                           f"({f1024 / t1024 / 1e12:.2f} TFLOP/s); 256^2 forward {t256:.2f} s")
+    return dict(value=round(1.0 / est, 5), unit="denoise-steps/sec", cores=cores, kind="port", measured=False,
+                sample=f"1 fp32 oracle forward at 256^2 ({t256:.2f} s measured) EXTRAPOLATED x{f1024 / f256:.1f} by FLOPs to 1024^2 "
+                       f"(estimate {est:.0f} s > budget {budget_s:.0f} s)")
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` typed by hand: re-execute under torch.distributed.run (one rank per GPU, RCCL rendezvous on
+    127.0.0.1) with the same arguments; the ranks see RANK / WORLD_SIZE and take the normal path."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args, world, rank):
+    """Launcher / aggregation self-test WITHOUT a GPU (tests/test_dist_gloo.py): same rendezvous, barriers, MAX-over-ranks timing,
+    per-rank gather and JSON assembly as the real path, on the gloo backend with the rollout replaced by a sleep.  Not a measurement."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    B, N = args.batch, args.denoise_steps
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        time.sleep(0.01)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.05 * (1 + rank))          # rank r is slower: MAX over ranks must pick the last rank
+    fence()
+    elapsed = time.perf_counter() - t0
+    per_rank = [elapsed]
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank = [float(x.item()) for x in allt]
+        elapsed = max(per_rank)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "denoise-steps/sec (whole node), SD3.5-medium 1024^2 GRPO rollout", "value": round(B * N * args.steps * world / elapsed, 3),
+            "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "dry-run", "config": {"workload": "launcher self-test (no GPU work)", "global_batch": B * world},
+            "world": {"backend": "gloo", "world_size": world,
+                      "per_rank_denoise_steps_per_s": [round(B * N * args.steps / t, 3) for t in per_rank]}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -104,13 +167,20 @@ def main():
                     help="sd3_5 = BASELINE.json configs[1] (the metric's config); flux1 = FLUX.1-dev geometry (configs[2], SURVEY 8(f) N3)")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed w.r.t. `value`) VAE-decode leg")
     ap.add_argument("--no-graph", action="store_true", help="launch the rollout eagerly instead of replaying the hipGraph")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher self-test without a GPU: gloo backend, the rollout replaced by a fixed sleep per micro-batch "
+                         "(tests/test_dist_gloo.py); the JSON line is marked \"data\": \"dry-run\" and is NOT a measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rollout engine has no CPU path")
     torch.cuda.set_device(local)
@@ -218,10 +288,13 @@ def main():
     if timing:
         _lib.check(lib.mi355_profile_collect(ms, cnt), "profile_collect")
         lib.mi355_profile_enable(0)
+    per_rank = [elapsed]
     if world > 1:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        allt = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(allt, tt)
+        per_rank = [float(x.item()) for x in allt]
+        elapsed = max(per_rank)                      # MAX over ranks
     assert len(samples) == B and samples[0].all_latents.shape[0] == len(traj) and torch.isfinite(samples[0].log_probs).all()
 
     n_cfg = 2 if cfg_on else 1
@@ -242,6 +315,8 @@ def main():
                                f"log-prob fused), batch {B}/GPU, n_cfg={n_cfg}, fp16 latent storage; 1 bench step = 1 rollout micro-batch",
                    "global_batch": B * world, "tokens_per_sample": Ni + n_text, "n_cfg": n_cfg, "denoise_steps": N,
                    "parallelism": f"dp{world} (rollout shards by prompt group, no data-path collective)"},
+        "world": {"backend": "nccl (RCCL)" if world > 1 else None, "world_size": world,
+                  "per_rank_denoise_steps_per_s": [round(B * N * args.steps / t, 3) for t in per_rank]},
     }
     if timing and rank == 0:
         attn_fl, attn_launches = attention_flops(cfg, Ni, N_TEXT)
@@ -252,20 +327,58 @@ def main():
         a_flop = attn_fl * B * n_cfg / attn_launches        # mean algorithmic FLOPs of one attention launch (forward batch B*n_cfg)
         achieved = a_flop / (a_ms * 1e-3) / 1e12 if a_ms > 0 else 0.0
         gemm_fl = (F - attn_fl) * B * fwd_per_timed        # fwd_per_timed already counts the n_cfg forwards
-        traffic = None
+        # HBM bytes per launch come from a rocprofv3 --pmc pass (counters cannot be read from inside the process): the committed
+        # summary names the commit it was collected at; `traffic` is null when there is none
+        traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_attention.json")
         if os.path.isfile(pmc):
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            pj = json.load(open(pmc))
+            traffic = pj.get("hbm_bytes_per_launch")
+            traffic_src = f"profiles/pmc_attention.json@{pj.get('commit', 'round-' + str(pj.get('round')))} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        ainfo = adapter.engine.attention_info()
         out["roofline"] = {
             "bound": "mfma", "kernel": "attn_kernel (joint S=4429 x24, dual S=4096 x13 per forward)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-            "traffic": traffic, "flops_per_launch": a_flop, "ms_per_launch": round(a_ms, 4),
+            "traffic": traffic, "traffic_source": traffic_src, "flops_per_launch": a_flop, "ms_per_launch": round(a_ms, 4),
+            "static_softmax": ainfo["static"] == ainfo["total"] and os.environ.get("MI355_ATTN_STATIC") != "0",
+            "static_softmax_launches": f"{ainfo['static']}/{ainfo['total']} (proven |score| bound {ainfo['max_bound']:.1f} <= 60 selects it per layer: "
+                                       "weight-dependent -- see attention_dynamic for the kernel every checkpoint can run)",
             **({"gemm": {"achieved": round(gemm_fl / (ms[1] * 1e-3) / 1e12, 1),
                          "frac": round(gemm_fl / (ms[1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}} if ms[1] > 0 else {}),
             "forward": {"achieved": round(fwd_tflops, 1), "frac": round(fwd_tflops / PEAK_BF16_TFLOPS, 4),
                         "flops_per_forward_per_sample": F, "note": "wall-clock of the whole rollout incl. host glue; north-star target 0.40"},
             "by_class": by_class,
         }
+    if timing and rank == 0 and world == 1:
+        # (a) the running-max ("dynamic") attention kernel on the same rollout: what a checkpoint whose q/k norm weights do not
+        #     prove the static bound would run;  (b) graph-replay vs eager wall clock of one rollout (the timed region above runs
+        #     eagerly because the event brackets cannot live inside a captured graph)
+        def timed_rollout():
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            one_rollout()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t1
+        lib.mi355_tune_set(6, 0)
+        one_rollout()                                   # re-capture / warm with the dynamic kernel
+        lib.mi355_profile_enable(2)
+        dyn_wall = timed_rollout()
+        _lib.check(lib.mi355_profile_collect(ms, cnt), "profile_collect")
+        lib.mi355_profile_enable(0)
+        d_ms = ms[0] / max(cnt[0], 1)
+        lib.mi355_tune_set(6, 0 if os.environ.get("MI355_ATTN_STATIC") == "0" else 1)
+        out["roofline"]["attention_dynamic"] = {"achieved": round(a_flop / (d_ms * 1e-3) / 1e12, 1), "ms_per_launch": round(d_ms, 4),
+                                                "frac": round(a_flop / (d_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                                "rollout_denoise_steps_per_s": round(B * N / dyn_wall, 3)}
+        lib.mi355_tune_set(2, 1)
+        one_rollout(); one_rollout()                    # eager warm-up + capture
+        g_s = min(timed_rollout() for _ in range(2))
+        lib.mi355_tune_set(2, 0)
+        e_s = min(timed_rollout() for _ in range(2))
+        lib.mi355_tune_set(2, 0 if args.no_graph else 1)
+        out["graph_vs_eager"] = {"graph_ms_per_rollout": round(g_s * 1e3, 2), "eager_ms_per_rollout": round(e_s * 1e3, 2),
+                                 "graph_denoise_steps_per_s": round(B * N / g_s, 3), "eager_denoise_steps_per_s": round(B * N / e_s, 3),
+                                 "note": "untimed w.r.t. `value`; one hipGraph launch replays the whole N-step loop (~7 850 kernels)"}
     if flux_mode and rank == 0:
         out["roofline"] = {"bound": "mfma", "kernel": "whole FLUX.1 forward (MFMA GEMMs + head_dim-128 attention), wall-clock of the rollout",
                            "achieved": round(fwd_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fwd_tflops / PEAK_BF16_TFLOPS, 4),

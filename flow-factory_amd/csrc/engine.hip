@@ -459,6 +459,24 @@ static int update_score_bounds(mi355_engine* e, hipStream_t st) {
     return 0;
 }
 
+// how many attention launches of a forward take the static-bound (no running max) kernel with the weights bound now
+extern "C" int mi355_engine_attention_info(mi355_engine* e, void* stream, int* n_static, int* n_total, float* max_bound) {
+    if (!e) return fail("mi355_engine_attention_info: null engine");
+    CHK(mi355_engine_weights_ready(e));
+    CHK(update_score_bounds(e, (hipStream_t)stream));
+    int ns = 0, nt = 0;
+    float mb = 0.f;
+    for (auto& b : e->blk) {
+        ++nt; if (g_attn_static && b.bound_joint > 0.f && b.bound_joint <= 60.f) ++ns;
+        mb = fmaxf(mb, b.bound_joint);
+        if (b.dual) { ++nt; if (g_attn_static && b.bound_dual > 0.f && b.bound_dual <= 60.f) ++ns; mb = fmaxf(mb, b.bound_dual); }
+    }
+    if (n_static) *n_static = ns;
+    if (n_total) *n_total = nt;
+    if (max_bound) *max_bound = mb;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------- forward
 static GemmParams gp(const bf16_t* A, long lda, const bf16_t* W, long ldw, int M, int N, int K, int epi,
                      const float* bias, bf16_t* out, long ldo) {
@@ -627,7 +645,7 @@ extern "C" int mi355_transformer_forward(mi355_plan* p, void* stream, const void
     return forward_core(p, st, latents, lat_dtype, p->mod_all, (bf16_t*)v_out);
 }
 
-static int sde_call(hipStream_t st, int batch, int64_t n, const void* v_text, const void* v_uncond, float guidance,
+static int sde_call(hipStream_t st, int batch, int64_t n, const void* v_text, const void* v_uncond, int v_dtype, float guidance,
                     const void* latents, int lat_dtype, const float* noise, const void* next_in, int next_in_dtype,
                     const float* sigma, const float* sigma_next, const float* eta, int scalar_stride, float sigma_max,
                     int dynamics, int compute_log_prob, void* next_out, float* next_f32, float* mean_out,
@@ -636,9 +654,10 @@ static int sde_call(hipStream_t st, int batch, int64_t n, const void* v_text, co
     if (!next_in && !noise && dynamics != MI355_ODE) return fail("mi355_sde_step: SDE rollout step needs `noise`");
     if (dynamics < 0 || dynamics > 3) return fail("mi355_sde_step: unknown dynamics %d", dynamics);
     if (lat_dtype < 0 || lat_dtype > 2) return fail("mi355_sde_step: bad latent dtype %d", lat_dtype);
+    if (v_dtype < 0 || v_dtype > 2) return fail("mi355_sde_step: bad noise_pred dtype %d", v_dtype);
     SdeStepParams s;
     memset(&s, 0, sizeof(s));
-    s.v_text = (const bf16_t*)v_text; s.v_uncond = (const bf16_t*)v_uncond; s.guidance = guidance;
+    s.v_text = (const bf16_t*)v_text; s.v_uncond = (const bf16_t*)v_uncond; s.v_dt = v_dtype; s.guidance = guidance;
     s.latents = latents; s.lat_dt = lat_dtype; s.noise = noise; s.next_in = next_in; s.next_in_dt = next_in_dtype;
     s.sigma = sigma; s.sigma_next = sigma_next; s.eta = eta; s.scalar_stride = scalar_stride; s.sigma_max = sigma_max;
     s.dynamics = dynamics; s.compute_log_prob = compute_log_prob; s.B = batch; s.n = n;
@@ -648,13 +667,13 @@ static int sde_call(hipStream_t st, int batch, int64_t n, const void* v_text, co
     return 0;
 }
 
-extern "C" int mi355_sde_step(void* stream, int batch, int64_t n, const void* v_text, const void* v_uncond, float guidance,
+extern "C" int mi355_sde_step(void* stream, int batch, int64_t n, const void* v_text, const void* v_uncond, int v_dtype, float guidance,
                               const void* latents, int lat_dtype, const float* noise, const void* next_in,
                               int next_in_dtype, const float* sigma, const float* sigma_next, const float* eta,
                               int scalar_stride, float sigma_max, int dynamics, int compute_log_prob, void* next_out,
                               float* next_f32, float* mean_out, float* noise_pred_out, float* log_prob, float* std_dev_t,
                               float* dt) {
-    return sde_call((hipStream_t)stream, batch, n, v_text, v_uncond, guidance, latents, lat_dtype, noise, next_in,
+    return sde_call((hipStream_t)stream, batch, n, v_text, v_uncond, v_dtype, guidance, latents, lat_dtype, noise, next_in,
                     next_in_dtype, sigma, sigma_next, eta, scalar_stride, sigma_max, dynamics, compute_log_prob, next_out,
                     next_f32, mean_out, noise_pred_out, log_prob, std_dev_t, dt);
 }
@@ -669,7 +688,7 @@ extern "C" int mi355_denoise_step(mi355_plan* p, void* stream, const void* laten
     CHK(mi355_transformer_forward(p, stream, latents, lat_dtype, t, lat_dtype, enc_a, pooled_a, enc_b, pooled_b, p->v));
     const bf16_t* vu = p->ncfg == 2 ? p->v : nullptr;
     const bf16_t* vt = p->ncfg == 2 ? p->v + (int64_t)p->B * p->n_lat : p->v;
-    return sde_call((hipStream_t)stream, p->B, p->n_lat, vt, vu, guidance, latents, lat_dtype, noise, next_in,
+    return sde_call((hipStream_t)stream, p->B, p->n_lat, vt, vu, MI355_BF16, guidance, latents, lat_dtype, noise, next_in,
                     next_in_dtype, sigma, sigma_next, eta, scalar_stride, sigma_max, dynamics, compute_log_prob, next_out,
                     next_f32, mean_out, noise_pred_out, log_prob, std_dev_t, dt);
 }
@@ -696,7 +715,7 @@ static int rollout_body(mi355_plan* p, hipStream_t st, int n_steps, int dynamics
         const bf16_t* vt = p->ncfg == 2 ? p->v + (int64_t)p->B * p->n_lat : p->v;
         // the log-prob of a step is only meaningful (and only read) when its noise level is > 0; the kernel
         // checks eta on the device so that the launch sequence does not depend on which steps are SDE steps
-        CHK(sde_call(st, p->B, p->n_lat, vt, vu, guidance, cur, storage_dtype, p->io_noise + (int64_t)i * p->B * p->n_lat,
+        CHK(sde_call(st, p->B, p->n_lat, vt, vu, MI355_BF16, guidance, cur, storage_dtype, p->io_noise + (int64_t)i * p->B * p->n_lat,
                      nullptr, 0, p->scal + i, p->scal + p->max_steps + i, p->scal + 2 * p->max_steps + i, 0, sigma_max,
                      dynamics, compute_log_prob ? 2 : 0, nxt, nullptr, nullptr, nullptr,
                      compute_log_prob ? p->io_lp + (int64_t)i * p->B : nullptr, nullptr, nullptr));
@@ -779,8 +798,11 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
                 p->g_guidance = guidance; p->g_sigma_max = sigma_max; p->g_attn = get_attn_variant(); p->g_gemm = get_gemm_variant();
                 p->g_bounds = p->e->bounds_ver * 2 + (g_attn_static != 0);
             } else {
-                (void)hipGetLastError();
-                g_err = "mi355_rollout: hipGraph capture failed, running the launch sequence eagerly";  // same kernels
+                // no silent fallback (header convention, reference constraints.md:144-145): the caller decides whether to
+                // retry with eager launches (mi355_tune_set(2, 0))
+                const hipError_t last = hipGetLastError();
+                return fail("mi355_rollout: hipGraph capture / instantiation of the %d-step loop failed (%s); "
+                            "mi355_tune_set(2, 0) selects eager launches", n_steps, hipGetErrorString(ce != hipSuccess ? ce : last));
             }
         }
         if (p->gexec) {

@@ -504,7 +504,7 @@ int sde_call(hipStream_t st, int batch, int64_t n, const bf16_t* v, const void* 
              void* next_out, float* log_prob) {
     SdeStepParams s;
     memset(&s, 0, sizeof(s));
-    s.v_text = v; s.v_uncond = nullptr; s.guidance = 1.0f;
+    s.v_text = v; s.v_uncond = nullptr; s.v_dt = DT_BF16; s.guidance = 1.0f;
     s.latents = latents; s.lat_dt = lat_dtype; s.noise = noise;
     s.sigma = sigma; s.sigma_next = sigma_next; s.eta = eta; s.scalar_stride = 0; s.sigma_max = sigma_max;
     s.dynamics = dynamics; s.compute_log_prob = compute_log_prob; s.B = batch; s.n = n;

@@ -167,6 +167,8 @@ enum Dynamics : int { DYN_ODE = 0, DYN_FLOW_SDE = 1, DYN_DANCE_SDE = 2, DYN_CPS 
 struct SdeStepParams {
     const bf16_t* v_text;     // network output (bf16) [B][n]; with CFG: text branch
     const bf16_t* v_uncond;   // nullptr => no CFG
+    int v_dt;                 // dtype of v_text / v_uncond (DT_BF16 for the engine's own output; fp32 / fp16 predictions
+                              // of standalone scheduler.step() callers are read exactly, like the reference's noise_pred.float())
     float guidance;
     const void* latents; int lat_dt;          // x_i, storage dtype
     const float* noise;                       // eps [B][n] fp32 (ignored when next_in != nullptr)

@@ -25,10 +25,12 @@ constexpr int NCHUNK = 64;          // workgroups per sample
 constexpr int SCRATCH_SLOTS = 16;   // launches in flight that may share the scratch ring
 constexpr int MAX_B = 4096;
 
-__device__ __forceinline__ float cfg_bf16(float vu, float vt, float g) {
-    const float d = round_bf16(vt - vu);
-    const float s = round_bf16(g * d);
-    return round_bf16(vu + s);
+// CFG combine `u + g * (c - u)` evaluated op by op in the tensors' dtype, as torch does (sd3_5.py:431-433)
+__device__ __forceinline__ float cfg_combine(float vu, float vt, float g, int dt) {
+    if (dt == DT_F32) return vu + g * (vt - vu);
+    const float d = round_to_dtype(vt - vu, dt);
+    const float s = round_to_dtype(g * d, dt);
+    return round_to_dtype(vu + s, dt);
 }
 
 __device__ __forceinline__ void load4(const void* p, long i, int dt, float (&o)[4]) {
@@ -100,12 +102,12 @@ __global__ __launch_bounds__(NT) void sde_step_kernel(SdeStepParams p, float* pa
         const int cnt = hi - i >= 4 ? 4 : (int)(hi - i);
         float v[4], x[4], nz[4] = {0.f, 0.f, 0.f, 0.f}, nin[4], mean[4], nxt[4];
         if (cnt == 4 && (p.n & 3) == 0) {
-            load4(p.v_text, gi, DT_BF16, v);
+            load4(p.v_text, gi, p.v_dt, v);
             if (p.v_uncond) {
                 float u[4];
-                load4(p.v_uncond, gi, DT_BF16, u);
+                load4(p.v_uncond, gi, p.v_dt, u);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = cfg_bf16(u[e], v[e], p.guidance);
+                for (int e = 0; e < 4; ++e) v[e] = cfg_combine(u[e], v[e], p.guidance, p.v_dt);
             }
             load4(p.latents, gi, p.lat_dt, x);
             if (p.next_in) load4(p.next_in, gi, p.next_in_dt, nin);
@@ -113,8 +115,8 @@ __global__ __launch_bounds__(NT) void sde_step_kernel(SdeStepParams p, float* pa
         } else {
             for (int e = 0; e < 4; ++e) {
                 const long g = gi + (e < cnt ? e : 0);
-                v[e] = bf2f(p.v_text[g]);
-                if (p.v_uncond) v[e] = cfg_bf16(bf2f(p.v_uncond[g]), v[e], p.guidance);
+                v[e] = load_as_f32(p.v_text, g, p.v_dt);
+                if (p.v_uncond) v[e] = cfg_combine(load_as_f32(p.v_uncond, g, p.v_dt), v[e], p.guidance, p.v_dt);
                 x[e] = load_as_f32(p.latents, g, p.lat_dt);
                 nin[e] = p.next_in ? load_as_f32(p.next_in, g, p.next_in_dt) : 0.f;
                 nz[e] = (!p.next_in && dyn != DYN_ODE) ? p.noise[g] : 0.f;
@@ -196,7 +198,7 @@ static float* g_scratch = nullptr;      // SCRATCH_SLOTS x (MAX_B*NCHUNK partial
 static unsigned g_scratch_next = 0;
 
 hipError_t launch_sde_step(const SdeStepParams& p, hipStream_t stream) {
-    if (p.B <= 0 || p.n <= 0 || p.B > MAX_B) return hipErrorInvalidValue;
+    if (p.B <= 0 || p.n <= 0 || p.B > MAX_B || p.v_dt < 0 || p.v_dt > 2) return hipErrorInvalidValue;
     constexpr size_t slot_words = (size_t)MAX_B * NCHUNK + MAX_B;
     if (!g_scratch) {
         // first use (never inside a stream capture: the rollout warms up eagerly before it is captured)

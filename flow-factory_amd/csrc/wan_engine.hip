@@ -523,7 +523,7 @@ extern "C" int mi355_wan_rollout(mi355_wan_plan* p, void* stream, int n_steps, c
         memset(&s, 0, sizeof(s));
         s.v_uncond = p->ncfg == 2 ? p->v : nullptr;
         s.v_text = p->ncfg == 2 ? p->v + nl : p->v;
-        s.guidance = guidance; s.latents = cur; s.lat_dt = storage_dtype;
+        s.v_dt = DT_BF16; s.guidance = guidance; s.latents = cur; s.lat_dt = storage_dtype;
         s.noise = step_noise ? p->io_noise + (int64_t)i * nl : nullptr;
         s.sigma = p->scal + i; s.sigma_next = p->scal + p->max_steps + i; s.eta = p->scal + 2 * p->max_steps + i; s.scalar_stride = 0;
         s.sigma_max = sigma_max; s.dynamics = dynamics; s.compute_log_prob = clp ? 2 : 0; s.B = B; s.n = p->n_lat;

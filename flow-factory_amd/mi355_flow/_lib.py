@@ -65,13 +65,14 @@ SIGNATURES = {
     "mi355_engine_destroy": (_I, [_P]),
     "mi355_engine_bind_weight": (_I, [_P, C.c_char_p, _P, _I, _I, C.POINTER(_L), _P]),
     "mi355_engine_weights_ready": (_I, [_P]),
+    "mi355_engine_attention_info": (_I, [_P, _P, C.POINTER(_I), C.POINTER(_I), C.POINTER(_F)]),
     "mi355_engine_num_params": (_I, [_P]),
     "mi355_engine_param_name": (C.c_char_p, [_P, _I]),
     "mi355_plan_create": (_I, [_P, _I, _I, _I, _I, _I, _I, C.POINTER(_P)]),
     "mi355_plan_destroy": (_I, [_P]),
     "mi355_plan_workspace_bytes": (_L, [_P]),
     "mi355_transformer_forward": (_I, [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P]),
-    "mi355_sde_step": (_I, [_P, _I, _L, _P, _P, _F, _P, _I, _P, _P, _I, _P, _P, _P, _I, _F, _I, _I,
+    "mi355_sde_step": (_I, [_P, _I, _L, _P, _P, _I, _F, _P, _I, _P, _P, _I, _P, _P, _P, _I, _F, _I, _I,
                             _P, _P, _P, _P, _P, _P, _P]),
     "mi355_denoise_step": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P, _P, _P, _I, _F, _I, _I,
                                 _P, _P, _P, _P, _P, _P, _P]),

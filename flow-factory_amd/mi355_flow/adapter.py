@@ -19,7 +19,8 @@ import torch
 
 from .engine import Engine, TransformerConfig
 from .samples import SD3_5Sample
-from .scheduler import FlowMatchEulerDiscreteSDEScheduler, SDESchedulerOutput, set_scheduler_timesteps
+from .scheduler import (FlowMatchEulerDiscreteSDEScheduler, SDESchedulerOutput, host_noise_levels, randn_tensor,
+                        set_scheduler_timesteps)
 from .trajectory import (TrajectoryIndicesType, create_callback_collector, create_trajectory_collector, _resolve)
 
 logger = logging.getLogger(__name__)
@@ -36,6 +37,29 @@ class NativeRolloutMixin:
 
     engine: Engine
     scheduler: FlowMatchEulerDiscreteSDEScheduler
+    # hooks the Flow-Factory plugin overrides with the reference's own objects (flow_factory_plugin.py): the sample class the
+    # trainer stacks (`BaseSample.stack`, trainers/grpo.py:215), the schedule setter and the scheduler-output container
+    _sample_cls = SD3_5Sample
+    _output_cls = SDESchedulerOutput
+    _set_timesteps = staticmethod(set_scheduler_timesteps)
+
+    def _before_engine_call(self) -> None:
+        """Hook run at the top of inference() / forward(): the Flow-Factory plugin re-binds changed weights here."""
+
+    def _check_joint_attention_kwargs(self, jak: Optional[Dict[str, Any]]) -> None:
+        """`joint_attention_kwargs` (sd3_5.py:421-428 forwards them to the transformer): diffusers consumes `scale` (LoRA scale of
+        the peft backend: `scale_lora_layers`) and IP-adapter inputs.  The engine honours `scale` through the weight binding (LoRA
+        deltas are merged with that extra factor; no effect without LoRA layers, as in diffusers); anything else raises."""
+        jak = dict(jak or {})
+        scale = float(jak.pop("scale", 1.0))
+        if jak:
+            raise NotImplementedError(f"mi355_flow: joint_attention_kwargs {sorted(jak)} are not supported by the native engine "
+                                      "(only the LoRA `scale` is)")
+        live = getattr(self, "_live_weights", None)
+        if live is not None:
+            live.set_lora_scale(scale)
+        elif scale != 1.0:
+            logger.warning("joint_attention_kwargs['scale'] has no effect: no LoRA layers are bound to the native engine")
 
     # -------------------------------------------------------------- latent casting (models/abc.py:172-182)
     def cast_latents(self, latents: torch.Tensor, default_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
@@ -68,10 +92,10 @@ class NativeRolloutMixin:
         extra_call_back_kwargs: List[str] = [],
         trajectory_indices: TrajectoryIndicesType = "all",
     ) -> List[SD3_5Sample]:
+        self._before_engine_call()
         device = self.device
         dtype = self.transformer_dtype
-        if joint_attention_kwargs:
-            raise ValueError("mi355_flow: joint_attention_kwargs (LoRA scale, IP-adapter, ...) are not supported by the native engine")
+        self._check_joint_attention_kwargs(joint_attention_kwargs)
         do_cfg = guidance_scale > 1.0
         has_neg = negative_prompt is not None or (negative_prompt_embeds is not None and negative_pooled_prompt_embeds is not None)
         if do_cfg and not has_neg:
@@ -97,18 +121,22 @@ class NativeRolloutMixin:
         h, w = int(height) // VAE_SCALE_FACTOR, int(width) // VAE_SCALE_FACTOR
         N = int(num_inference_steps)
 
-        # RNG, in the reference's order on `generator` (None = the global device generator):
-        # prepare_latents (transformer dtype), then one fp32 draw per step -- also when noise_level == 0
-        latents = torch.randn((B, C, h, w), generator=generator, device=device, dtype=dtype)
-        step_noise = torch.empty((N, B, C, h, w), device=device, dtype=torch.float32)
-        for i in range(N):
-            step_noise[i] = torch.randn((B, C, h, w), generator=generator, device=device, dtype=torch.float32)
+        # RNG, in the reference's order on `generator` (None = the global device generator; a CPU generator draws on the host like
+        # diffusers' randn_tensor): prepare_latents (transformer dtype), then one fp32 draw per step -- also when noise_level == 0,
+        # but none at all under ODE dynamics (flow_match_euler_discrete.py:329-340 draws nothing)
+        dyn = self.scheduler.dynamics_type
+        latents = randn_tensor((B, C, h, w), generator=generator, device=device, dtype=dtype)
+        step_noise = None
+        if dyn != "ODE":
+            step_noise = torch.empty((N, B, C, h, w), device=device, dtype=torch.float32)
+            for i in range(N):
+                step_noise[i] = randn_tensor((B, C, h, w), generator=generator, device=device, dtype=torch.float32)
 
         ps = self.engine.cfg.patch_size
-        timesteps = set_scheduler_timesteps(self.scheduler, N, seq_len=(h // ps) * (w // ps), device=device)
+        timesteps = self._set_timesteps(self.scheduler, N, seq_len=(h // ps) * (w // ps), device=device)
         ts_host = [float(t) for t in timesteps.tolist()]          # one D2H before the loop, none inside
         sig_host = [float(s) for s in self.scheduler.sigmas.tolist()]
-        eta_host = self.scheduler.host_noise_levels()
+        eta_host = host_noise_levels(self.scheduler, N)
         storage = self.latent_storage_dtype or dtype
 
         n_text = prompt_embeds.shape[1]
@@ -118,7 +146,7 @@ class NativeRolloutMixin:
         keep_positions = list(range(N + 1)) if kept is None else sorted(kept)
         if not stepwise:
             lat_kept, log_probs, final = plan.rollout(
-                ts_host, sig_host, eta_host, self.scheduler.dynamics_type, guidance_scale, latents, storage, step_noise,
+                ts_host, sig_host, eta_host, dyn, guidance_scale, latents, storage, step_noise,
                 prompt_embeds, pooled_prompt_embeds, negative_prompt_embeds if do_cfg else None,
                 negative_pooled_prompt_embeds if do_cfg else None, keep_positions=keep_positions,
                 compute_log_prob=compute_log_prob)
@@ -159,7 +187,7 @@ class NativeRolloutMixin:
         lp_stack = torch.stack(all_log_probs, dim=1) if all_log_probs else None        # (B, P')
         samples = []
         for b in range(B):
-            samples.append(SD3_5Sample(
+            samples.append(self._sample_cls(
                 timesteps=timesteps,
                 all_latents=lat_stack[b] if lat_stack is not None else None,
                 log_probs=lp_stack[b] if lp_stack is not None else None,
@@ -194,7 +222,8 @@ class NativeRolloutMixin:
             enc_a, pool_a, enc_b, pool_b = (ne, npl, pe, pp) if ne is not None else (pe, pp, None, None)
             o = plan.denoise_step(cur, torch.tensor(ts[i]), enc_a, pool_a, enc_b, pool_b, guidance,
                                   torch.tensor(ts[i]) / 1000, torch.tensor(t_next) / 1000, eta[i], sig[1],
-                                  self.scheduler.dynamics_type, noise=step_noise[i], compute_log_prob=clp, want=want)
+                                  self.scheduler.dynamics_type, noise=step_noise[i] if step_noise is not None else None,
+                                  compute_log_prob=clp, want=want)
             if clp:
                 log_probs[i] = o.log_prob
             cur = o.next_storage
@@ -219,10 +248,8 @@ class NativeRolloutMixin:
         compute_log_prob: bool = True,
         return_kwargs: List[str] = ["noise_pred", "next_latents", "next_latents_mean", "std_dev_t", "dt", "log_prob"],
     ) -> SDESchedulerOutput:
-        if joint_attention_kwargs:
-            raise ValueError("mi355_flow: joint_attention_kwargs are not supported by the native engine")
-        if not latents.is_cuda:
-            raise RuntimeError("mi355_flow forward: latents must be on the GPU (no CPU fallback)")
+        self._before_engine_call()
+        self._check_joint_attention_kwargs(joint_attention_kwargs)
         B = latents.shape[0]
         dev = latents.device
         if guidance_scale > 1.0 and (negative_prompt_embeds is None or negative_pooled_prompt_embeds is None):
@@ -247,7 +274,7 @@ class NativeRolloutMixin:
             noise_level = sched.get_noise_level_for_sigma(sigma.reshape(-1)) if sigma.ndim else sched.get_noise_level_for_sigma(float(sigma))
         noise = None
         if next_latents is None and dyn != "ODE":
-            noise = torch.randn(latents.shape, device=dev, dtype=torch.float32)  # same draw as randn_tensor(:352-357)
+            noise = randn_tensor(latents.shape, device=dev, dtype=torch.float32)  # the draw of flow_match_euler_discrete.py:352-357
         plan = self.engine.plan(B, 2 if do_cfg else 1, latents.shape[2], latents.shape[3], prompt_embeds.shape[1], 1)
         enc = (negative_prompt_embeds, negative_pooled_prompt_embeds, prompt_embeds, pooled_prompt_embeds) if do_cfg else \
               (prompt_embeds, pooled_prompt_embeds, None, None)
@@ -264,7 +291,7 @@ class NativeRolloutMixin:
             dt=o.dt.view(view) if o.dt is not None else None,
             log_prob=o.log_prob if compute_log_prob else None,
         )
-        return SDESchedulerOutput.from_dict({k: res[k] for k in return_kwargs if k in res})
+        return self._output_cls.from_dict({k: res[k] for k in return_kwargs if k in res})
 
 
 class SD3_5NativeAdapter(NativeRolloutMixin):

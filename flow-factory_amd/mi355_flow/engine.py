@@ -68,7 +68,64 @@ class TransformerConfig:
                         self.time_proj_dim, self.ff_mult, mask, self.eps)
 
 
-class Engine:
+class WeightHolder:
+    """Shared weight-binding half of the four engines (`mi355_engine_*`, `mi355_flux_*`, `mi355_wan_*`, `mi355_vae_*`): the C side
+    owns a re-packed bf16 copy of every named parameter; binding copies / converts one torch tensor into its slot."""
+
+    _ABI = "engine"      # C symbol infix
+    _WHAT = "transformer"
+
+    def _fn(self, suffix: str):
+        return getattr(self.lib, f"mi355_{self._ABI}_{suffix}")
+
+    def param_names(self) -> List[str]:
+        names = getattr(self, "_names", None)
+        if names is None:
+            n = self._fn("num_params")(self._h)
+            names = self._names = [self._fn("param_name")(self._h, i).decode() for i in range(n)]
+        return names
+
+    def bind_tensor(self, name: str, t: torch.Tensor) -> None:
+        """Enqueue the conversion of ONE parameter on the current stream; call `finish_binding()` after the last one (the source
+        may be a temporary: a merged LoRA weight, a gathered FSDP shard, a host tensor's device copy)."""
+        t = t.detach()
+        if not t.is_cuda:
+            t = t.cuda(non_blocking=True)
+        t = t.contiguous()
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        _lib.check(self._fn("bind_weight")(self._h, name.encode(), t.data_ptr(), dtype_code(t.dtype), t.dim(), shape, _stream()),
+                   f"{self._ABI}_bind_weight({name})")
+        self._keepalive = getattr(self, "_keepalive", [])
+        self._keepalive.append(t)
+
+    def finish_binding(self) -> None:
+        # conversion kernels read the (possibly temporary) source tensors asynchronously
+        torch.cuda.current_stream().synchronize()
+        self._keepalive = []
+
+    def bind_state_dict(self, state_dict: Dict[str, torch.Tensor], partial: bool = False, strict: Optional[bool] = None) -> None:
+        """Copy / re-pack torch Parameters (HF names) into the engine.  Call again after every optimizer step, EMA swap or LoRA
+        merge: the weights are live during GRPO.  A state dict that lacks any expected name RAISES unless `partial=True`
+        (a refresh with foreign key names -- e.g. un-merged peft keys -- must never leave stale weights bound silently;
+        reference fail-fast rule, constraints.md:144-145).  `strict` is the deprecated inverse of `partial`."""
+        if strict is not None:
+            partial = not strict
+        names = self.param_names()
+        missing = [n for n in names if n not in state_dict]
+        if missing and not partial:
+            raise KeyError(f"mi355_flow: {self._WHAT} state dict lacks {len(missing)} of {len(names)} parameters, first: {missing[0]}"
+                           + (" (peft-wrapped keys? bind through mi355_flow.binding.LiveWeights, which merges LoRA deltas)"
+                              if any("base_layer" in k or "lora_" in k for k in state_dict) else ""))
+        for n in names:
+            if n in state_dict:
+                self.bind_tensor(n, state_dict[n])
+        self.finish_binding()
+
+    def ready(self) -> None:
+        _lib.check(self._fn("weights_ready")(self._h), f"{self._ABI}_weights_ready")
+
+
+class Engine(WeightHolder):
     """Owns the packed bf16 copy of the transformer weights (mi355_engine)."""
 
     def __init__(self, cfg: TransformerConfig):
@@ -80,33 +137,11 @@ class Engine:
         self._h = h
         self._plans: Dict[tuple, "Plan"] = {}
 
-    def param_names(self) -> List[str]:
-        n = self.lib.mi355_engine_num_params(self._h)
-        return [self.lib.mi355_engine_param_name(self._h, i).decode() for i in range(n)]
-
-    def bind_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True) -> None:
-        """Copy / re-pack torch Parameters (HF names) into the engine.  Call again after every
-        optimizer step, EMA swap or LoRA merge: the weights are live during GRPO."""
-        names = self.param_names()
-        missing = [n for n in names if n not in state_dict]
-        if missing and strict:
-            raise KeyError(f"mi355_flow: state dict lacks {len(missing)} parameters, first: {missing[0]}")
-        st = _stream()
-        for n in names:
-            if n not in state_dict:
-                continue
-            t = state_dict[n].detach()
-            if not t.is_cuda:
-                t = t.cuda(non_blocking=True)
-            t = t.contiguous()
-            shape = (C.c_int64 * t.dim())(*t.shape)
-            _lib.check(self.lib.mi355_engine_bind_weight(self._h, n.encode(), t.data_ptr(), dtype_code(t.dtype),
-                                                         t.dim(), shape, st), f"bind_weight({n})")
-        # conversion kernels read the (possibly temporary) source tensors asynchronously
-        torch.cuda.current_stream().synchronize()
-
-    def ready(self) -> None:
-        _lib.check(self.lib.mi355_engine_weights_ready(self._h), "weights_ready")
+    def attention_info(self) -> Dict[str, float]:
+        """{'static': launches of a forward on the static-bound softmax kernel, 'total': attention launches, 'max_bound': ...}"""
+        ns, nt, mb = C.c_int(), C.c_int(), C.c_float()
+        _lib.check(self.lib.mi355_engine_attention_info(self._h, _stream(), C.byref(ns), C.byref(nt), C.byref(mb)), "attention_info")
+        return {"static": ns.value, "total": nt.value, "max_bound": mb.value}
 
     def plan(self, batch: int, n_cfg: int, latent_h: int, latent_w: int, n_text: int, max_steps: int) -> "Plan":
         key = (batch, n_cfg, latent_h, latent_w, n_text)
@@ -286,12 +321,14 @@ def sde_step(v_text, v_uncond, guidance, latents, sigma, sigma_next, eta, sigma_
     n = latents[0].numel()
     sig, sig_n, et, stride = _scalars(sigma, sigma_next, eta, B, latents.device)
     outs = _StepOutputs(B, latents, want, compute_log_prob)
-    v_text = _bf16c(v_text)
-    v_uncond = _bf16c(v_uncond) if v_uncond is not None else None
+    # the prediction keeps its dtype (reference: `noise_pred.float()`, flow_match_euler_discrete.py:310): no silent bf16 rounding
+    v_text = v_text.contiguous()
+    vdt = dtype_code(v_text.dtype)
+    v_uncond = v_uncond.to(v_text.dtype).contiguous() if v_uncond is not None else None
     noise = noise.to(torch.float32).contiguous() if noise is not None else None
     nxt_in = next_latents.contiguous() if next_latents is not None else None
     _lib.check(lib.mi355_sde_step(
-        _stream(), B, n, _ptr(v_text), _ptr(v_uncond), float(guidance), _ptr(latents), dtype_code(latents.dtype), _ptr(noise),
+        _stream(), B, n, _ptr(v_text), _ptr(v_uncond), vdt, float(guidance), _ptr(latents), dtype_code(latents.dtype), _ptr(noise),
         _ptr(nxt_in), dtype_code(nxt_in.dtype) if nxt_in is not None else 0, _ptr(sig), _ptr(sig_n), _ptr(et), stride,
         float(sigma_max), DYNAMICS[dynamics], int(bool(compute_log_prob)), *outs.ptrs()), "sde_step")
     return outs

@@ -1,68 +1,146 @@
-"""The binding a Flow-Factory installation uses:  `model.model_type: mi355_flow.flow_factory_plugin.SD3_5NativeAdapter`.
+"""The binding a Flow-Factory installation uses:  `model.model_type: mi355_flow.flow_factory_plugin.SD3_5NativeAdapter`
+(also `...Flux1NativeAdapter`, `...Wan2T2VNativeAdapter`).
 
-Flow-Factory resolves an unknown `model_type` as a python path (reference
-src/flow_factory/models/registry.py:69-82) and constructs `cls(config=config, accelerator=accelerator)`
-(models/loader.py:61-64).  The class below IS the reference's `SD3_5Adapter` (pipeline loading, text
-encoders, VAE, LoRA, EMA, checkpoints, device placement all inherited) with the rollout hot path
-(`inference`, no-grad `forward`) routed to libmi355flow.so through `NativeRolloutMixin`.
+Flow-Factory resolves an unknown `model_type` as a python path (reference src/flow_factory/models/registry.py:69-82) and
+constructs `cls(config=config, accelerator=accelerator)` (models/loader.py:61-64).  Each class below IS the reference's own
+adapter (pipeline loading, text encoders, LoRA, EMA, checkpoints, device placement, the reference's scheduler object and its
+sample classes all inherited) with the rollout hot path routed to libmi355flow.so:
 
-Importing this module needs `flow_factory` (+ diffusers, peft): it is NOT importable in the build
-container; `mi355_flow.adapter` carries the same code path standalone and is what the tests run.
+  * `inference()` and the no-grad `forward()` come from the rollout mixins (`mi355_flow.adapter.NativeRolloutMixin`,
+    `mi355_flow.flux.FluxRolloutMixin`, `mi355_flow.wan.WanRolloutMixin`), which only use the PUBLIC scheduler / adapter
+    contract (scheduler/abc.py:76-153) -- nothing mirror-only;
+  * the samples returned are the REFERENCE's `SD3_5Sample` / `Flux1Sample` / `WanT2VSample` (`_sample_cls` hook), so
+    `BaseSample.stack` in `optimize()` (trainers/grpo.py:215) and the group ids (`unique_id`) are the reference's;
+  * weights are LIVE: every engine call is preceded by `LiveWeights.sync()` (mi355_flow/binding.py), which re-binds exactly
+    the tensors that changed -- after `optimizer.step()`, inside `use_ema_parameters()` / `use_ref_parameters()` /
+    `use_named_parameters()` (the KL reference forward of trainers/grpo.py:281-292 sees the reference weights, not the
+    rollout-time policy), with peft LoRA deltas merged (and dropped while `disable_adapter()` is active), FSDP2 shards gathered;
+  * grad-mode `forward()` -- the `optimize()` replay -- runs the engine's differentiable path when the trainable
+    parameter set is supported by it (mi355_flow/autograd.py: identical forward arithmetic => ratio == 1 before any update),
+    else the reference's autograd path.
+
+Importing this module needs an importable `flow_factory`.
 """
 from __future__ import annotations
 
+import functools
+import logging
+from contextlib import contextmanager
+
 import torch
 
-try:  # pragma: no cover - exercised only inside a Flow-Factory installation
-    from flow_factory.models.stable_diffusion.sd3_5 import SD3_5Adapter as _RefAdapter
+from .adapter import NativeRolloutMixin
+from .binding import LiveWeights
+from .engine import Engine, TransformerConfig
+from .vae import VAEConfig, VAEDecoder
+
+logger = logging.getLogger(__name__)
+
+try:
+    from flow_factory.models.stable_diffusion.sd3_5 import SD3_5Adapter as _RefAdapter, SD3_5Sample as _RefSD3Sample
+    from flow_factory.scheduler import SDESchedulerOutput as _RefOutput, set_scheduler_timesteps as _ref_set_timesteps
+    _IMPORT_ERROR = None
 except Exception as e:  # noqa: BLE001
     _RefAdapter = None
     _IMPORT_ERROR = e
 
-from .adapter import NativeRolloutMixin
-from .engine import Engine, TransformerConfig
-from .vae import VAEConfig, VAEDecoder
 
-if _RefAdapter is not None:  # pragma: no cover
+class _LiveBinding:
+    """Weight-liveness half shared by the three plugin classes: owns `self._live_weights`, invalidates it wherever the reference
+    swaps parameters behind the engine's back (`param.data.copy_` does not bump autograd version counters)."""
 
-    class SD3_5NativeAdapter(NativeRolloutMixin, _RefAdapter):
-        """`SD3_5Adapter` with the GRPO rollout running on the MI355X engine."""
+    def _init_live(self, engine) -> None:
+        self.engine = engine
+        self._live_weights = LiveWeights(engine, lambda: self.transformer)
+
+    def _sync_weights(self) -> int:
+        n = self._live_weights.sync()
+        if n:
+            self.engine.ready()
+        return n
+
+    def _before_engine_call(self) -> None:     # hook of the rollout mixins (top of inference() / no-grad forward())
+        self._sync_weights()
+
+    # mode switches (models/abc.py:351-378)
+    def rollout(self, *a, **k):
+        self._live_weights.invalidate()
+        return super().rollout(*a, **k)
+
+    def eval(self, *a, **k):
+        self._live_weights.invalidate()
+        return super().eval(*a, **k)
+
+    def train(self, *a, **k):
+        self._live_weights.invalidate()
+        return super().train(*a, **k)
+
+    # parameter-swap contexts (models/abc.py:523-531, :556-597, :660-682): in-place `.data.copy_` swaps on enter AND on exit
+    @contextmanager
+    def use_ema_parameters(self):
+        with super().use_ema_parameters():
+            self._live_weights.invalidate()
+            try:
+                yield
+            finally:
+                self._live_weights.invalidate()
+
+    @contextmanager
+    def use_ref_parameters(self):
+        with super().use_ref_parameters():
+            self._live_weights.invalidate()
+            try:
+                yield
+            finally:
+                self._live_weights.invalidate()
+
+    @contextmanager
+    def use_named_parameters(self, name: str):
+        with super().use_named_parameters(name):
+            self._live_weights.invalidate()
+            try:
+                yield
+            finally:
+                self._live_weights.invalidate()
+
+    def load_checkpoint(self, *a, **k):
+        out = super().load_checkpoint(*a, **k)
+        if hasattr(self, "_live_weights"):
+            self._live_weights.invalidate()
+        return out
+
+    # the engine computes in bf16 like the reference's autocast run
+    @property
+    def transformer_dtype(self):
+        return self.pipeline.transformer.dtype
+
+
+def _native_vae(pipeline):
+    """The VAE is frozen (`_freeze_vae`, models/abc.py:1727-1733): bind its decoder once."""
+    dec = VAEDecoder(VAEConfig.from_hf(pipeline.vae.config))
+    dec.bind_state_dict(pipeline.vae.state_dict())
+    dec.ready()
+    return dec
+
+
+if _RefAdapter is not None:
+
+    class SD3_5NativeAdapter(_LiveBinding, NativeRolloutMixin, _RefAdapter):
+        """`SD3_5Adapter` (reference models/stable_diffusion/sd3_5.py) with the GRPO rollout on the MI355X engine."""
+
+        _sample_cls = _RefSD3Sample
+        _output_cls = _RefOutput
+        _set_timesteps = staticmethod(_ref_set_timesteps)
 
         def __init__(self, config, accelerator):
             _RefAdapter.__init__(self, config, accelerator)
             tc = self.pipeline.transformer.config
-            self.engine = Engine(TransformerConfig(
+            self._init_live(Engine(TransformerConfig(
                 in_channels=tc.in_channels, out_channels=tc.out_channels, patch_size=tc.patch_size,
                 num_layers=tc.num_layers, num_heads=tc.num_attention_heads, head_dim=tc.attention_head_dim,
                 joint_attention_dim=tc.joint_attention_dim, pooled_projection_dim=tc.pooled_projection_dim,
-                pos_embed_max_size=tc.pos_embed_max_size, dual_layers=tuple(tc.dual_attention_layers)))
-            self._bound_version = -1
-            self._weights_version = 0
-            # the VAE is frozen (`_freeze_vae`, models/abc.py): bind its decoder once
-            self.vae_decoder = VAEDecoder(VAEConfig.from_hf(self.pipeline.vae.config))
-            self.vae_decoder.bind_state_dict(self.pipeline.vae.state_dict())
-            self.vae_decoder.ready()
-
-        # the engine computes in bf16 like the reference's autocast run
-        @property
-        def transformer_dtype(self):
-            return self.pipeline.transformer.dtype
-
-        def _sync_weights(self):
-            if self._bound_version != self._weights_version:
-                module = self.accelerator.unwrap_model(self.transformer)
-                self.engine.bind_state_dict(module.state_dict())  # LoRA: merge first (peft `merge_adapter`) or bind merged weights
-                self.engine.ready()
-                self._bound_version = self._weights_version
-
-        # weights are live: every mode switch that can change them invalidates the packed copy
-        def rollout(self, *a, **k):
-            self._weights_version += 1
-            return _RefAdapter.rollout(self, *a, **k)
-
-        def eval(self, *a, **k):
-            self._weights_version += 1
-            return _RefAdapter.eval(self, *a, **k)
+                pos_embed_max_size=tc.pos_embed_max_size, dual_layers=tuple(getattr(tc, "dual_attention_layers", ()) or ()))))
+            self.vae_decoder = _native_vae(self.pipeline)
 
         @torch.no_grad()
         def decode_latents(self, latents, output_type="pil"):
@@ -72,63 +150,50 @@ if _RefAdapter is not None:  # pragma: no cover
             images = self.vae_decoder.decode(latents, postprocess=False, out_dtype=torch.bfloat16)
             return self.pipeline.image_processor.postprocess(images, output_type=output_type)
 
-        @torch.no_grad()
-        def inference(self, *args, **kwargs):
-            self._sync_weights()
-            return NativeRolloutMixin.inference(self, *args, **kwargs)
-
+        # NOTE: `inference` is the mixin's own method (no wrapper): the trainer filters its kwargs by `inspect.signature`
+        # (utils/base.py:38-63, trainers/grpo.py:165), so the parameter list IS the ABI.  `forward` keeps it through `wraps`.
+        @functools.wraps(NativeRolloutMixin.forward)
         def forward(self, *args, **kwargs):
-            # optimize() (trainers/grpo.py:263) needs autograd through the transformer: that stays on the
-            # reference path until the backward kernels exist.  The rollout is no-grad.
             if torch.is_grad_enabled():
+                self._sync_weights()
+                # optimize() replay (trainers/grpo.py:263): the engine's differentiable forward/backward when it covers the
+                # trainable set; otherwise the reference's autograd path (e.g. trainable text encoders, DoRA)
+                from .autograd import grad_forward_supported, sd3_grad_forward
+                why = grad_forward_supported(self)
+                if why is None:
+                    return sd3_grad_forward(self, *args, **kwargs)
+                if not getattr(self, "_warned_ref_grad", False):
+                    logger.warning("mi355_flow: grad-mode forward() falls back to the reference autograd path (%s); rollout "
+                                   "log-probs then differ from the replay by the engine-vs-torch arithmetic difference", why)
+                    self._warned_ref_grad = True
                 return _RefAdapter.forward(self, *args, **kwargs)
-            self._sync_weights()
             return NativeRolloutMixin.forward(self, *args, **kwargs)
 
     try:
-        from flow_factory.models.flux.flux1 import Flux1Adapter as _RefFlux
+        from flow_factory.models.flux.flux1 import Flux1Adapter as _RefFlux, Flux1Sample as _RefFluxSample
     except Exception:  # noqa: BLE001
         _RefFlux = None
 
     if _RefFlux is not None:
-        from .flux import Flux1NativeAdapter as _FluxMirror, FluxConfig, FluxEngine, unpack_latents
+        from .flux import FluxConfig, FluxEngine, FluxRolloutMixin, unpack_latents
 
-        class Flux1NativeAdapter(_RefFlux):
-            """`Flux1Adapter` (flux1.py) with the GRPO rollout on the MI355X engine: `model.model_type:
-            mi355_flow.flow_factory_plugin.Flux1NativeAdapter`.  inference() / no-grad forward() / decode_latents() are the
-            standalone mirror's methods (same signatures as the reference's), bound onto the reference adapter."""
+        class Flux1NativeAdapter(_LiveBinding, FluxRolloutMixin, _RefFlux):
+            """`Flux1Adapter` (reference models/flux/flux1.py) with the GRPO rollout on the MI355X engine."""
+
+            _sample_cls = _RefFluxSample
+            _output_cls = _RefOutput
+            _set_timesteps = staticmethod(_ref_set_timesteps)
 
             def __init__(self, config, accelerator):
                 _RefFlux.__init__(self, config, accelerator)
                 tc = self.pipeline.transformer.config
-                self.engine = FluxEngine(FluxConfig(
+                self._init_live(FluxEngine(FluxConfig(
                     in_channels=tc.in_channels, num_layers=tc.num_layers, num_single_layers=tc.num_single_layers,
                     num_attention_heads=tc.num_attention_heads, attention_head_dim=tc.attention_head_dim,
                     joint_attention_dim=tc.joint_attention_dim, pooled_projection_dim=tc.pooled_projection_dim,
-                    guidance_embeds=bool(tc.guidance_embeds), axes_dims_rope=tuple(tc.axes_dims_rope)))
-                self._bound_version, self._weights_version = -1, 0
+                    guidance_embeds=bool(tc.guidance_embeds), axes_dims_rope=tuple(tc.axes_dims_rope))))
                 self.vae_max_batch = 4
-                self.vae_decoder = VAEDecoder(VAEConfig.from_hf(self.pipeline.vae.config))
-                self.vae_decoder.bind_state_dict(self.pipeline.vae.state_dict())
-                self.vae_decoder.ready()
-
-            @property
-            def transformer_dtype(self):
-                return self.pipeline.transformer.dtype
-
-            def _sync_weights(self):
-                if self._bound_version != self._weights_version:
-                    self.engine.bind_state_dict(self.accelerator.unwrap_model(self.transformer).state_dict())
-                    self.engine.ready()
-                    self._bound_version = self._weights_version
-
-            def rollout(self, *a, **k):
-                self._weights_version += 1
-                return _RefFlux.rollout(self, *a, **k)
-
-            def eval(self, *a, **k):
-                self._weights_version += 1
-                return _RefFlux.eval(self, *a, **k)
+                self.vae_decoder = _native_vae(self.pipeline)
 
             @torch.no_grad()
             def decode_latents(self, latents, height, width, output_type="pil"):
@@ -138,82 +203,57 @@ if _RefAdapter is not None:  # pragma: no cover
                 images = self.vae_decoder.decode(lat, postprocess=False, out_dtype=torch.bfloat16, max_batch=self.vae_max_batch)
                 return self.pipeline.image_processor.postprocess(images, output_type=output_type)
 
-            @torch.no_grad()
-            def inference(self, *args, **kwargs):
-                self._sync_weights()
-                return _FluxMirror.inference(self, *args, **kwargs)
-
+            @functools.wraps(FluxRolloutMixin.forward)
             def forward(self, *args, **kwargs):
-                if torch.is_grad_enabled():          # optimize(): autograd stays on the reference path
+                if torch.is_grad_enabled():          # optimize(): autograd stays on the reference path for FLUX
                     return _RefFlux.forward(self, *args, **kwargs)
-                self._sync_weights()
-                return _FluxMirror.forward(self, *args, **kwargs)
+                return FluxRolloutMixin.forward(self, *args, **kwargs)
 
     try:
-        from flow_factory.models.wan.wan2_t2v import Wan2_T2V_Adapter as _RefWan
+        from flow_factory.models.wan.wan2_t2v import Wan2_T2V_Adapter as _RefWan, WanT2VSample as _RefWanSample
     except Exception:  # noqa: BLE001
         _RefWan = None
 
     if _RefWan is not None:
-        from .wan import Wan2T2VNativeAdapter as _WanMirror, WanConfig, WanEngine
+        from .wan import WanConfig, WanEngine, WanRolloutMixin
 
-        class Wan2T2VNativeAdapter(_RefWan):
-            """`Wan2_T2V_Adapter` (wan2_t2v.py) with the Wan2.1 rollout on the MI355X engine (single transformer; Wan2.2's
-            `transformer_2` / `boundary_ratio` configurations stay on the reference path).  The video VAE is the pipeline's."""
+        class Wan2T2VNativeAdapter(_LiveBinding, WanRolloutMixin, _RefWan):
+            """`Wan2_T2V_Adapter` (reference models/wan/wan2_t2v.py) with the Wan2.1 rollout on the MI355X engine (single transformer;
+            Wan2.2's `transformer_2` / `boundary_ratio` pipelines are rejected).  The video VAE is the pipeline's; evaluation-mode
+            sampling (diffusers' UniPC multistep solver) stays on the reference path."""
+
+            _sample_cls = _RefWanSample
+            _output_cls = _RefOutput
 
             def __init__(self, config, accelerator):
                 _RefWan.__init__(self, config, accelerator)
                 if getattr(self.pipeline.config, "boundary_ratio", None) is not None or getattr(self.pipeline, "transformer_2", None) is not None:
                     raise ValueError("mi355_flow: two-expert Wan2.2 pipelines are not supported by the native engine")
                 tc = self.pipeline.transformer.config
-                self.engine = WanEngine(WanConfig(
+                self._init_live(WanEngine(WanConfig(
                     in_channels=tc.in_channels, out_channels=tc.out_channels, num_layers=tc.num_layers,
                     num_attention_heads=tc.num_attention_heads, attention_head_dim=tc.attention_head_dim, ffn_dim=tc.ffn_dim,
-                    text_dim=tc.text_dim, freq_dim=tc.freq_dim, patch_size=tuple(tc.patch_size), eps=tc.eps))
-                self._bound_version, self._weights_version = -1, 0
+                    text_dim=tc.text_dim, freq_dim=tc.freq_dim, patch_size=tuple(tc.patch_size), eps=tc.eps)))
 
-            @property
-            def transformer_dtype(self):
-                return self.pipeline.transformer.dtype
+            def _eval_inference(self, **kwargs):
+                return _RefWan.inference(self, **kwargs)
 
-            def _sync_weights(self):
-                if self._bound_version != self._weights_version:
-                    self.engine.bind_state_dict(self.accelerator.unwrap_model(self.transformer).state_dict())
-                    self.engine.ready()
-                    self._bound_version = self._weights_version
-
-            def rollout(self, *a, **k):
-                self._weights_version += 1
-                return _RefWan.rollout(self, *a, **k)
-
-            def eval(self, *a, **k):
-                self._weights_version += 1
-                return _RefWan.eval(self, *a, **k)
-
-            @torch.no_grad()
-            def inference(self, *args, **kwargs):
-                self._sync_weights()
-                return _WanMirror.inference(self, *args, **kwargs)
-
+            @functools.wraps(WanRolloutMixin.forward)
             def forward(self, *args, **kwargs):
-                if torch.is_grad_enabled():
+                if torch.is_grad_enabled() or bool(getattr(self.scheduler, "is_eval", False)):
                     return _RefWan.forward(self, *args, **kwargs)
-                self._sync_weights()
-                return _WanMirror.forward(self, *args, **kwargs)
+                return WanRolloutMixin.forward(self, *args, **kwargs)
 
 else:
 
-    class SD3_5NativeAdapter:  # type: ignore[no-redef]
-        def __init__(self, *a, **k):
-            raise ImportError("mi355_flow.flow_factory_plugin needs an importable `flow_factory` (with diffusers/peft): "
-                              f"{_IMPORT_ERROR!r}.  Use mi355_flow.adapter.SD3_5NativeAdapter standalone instead.")
+    def _unavailable(name: str, standalone: str):
+        class _Missing:
+            def __init__(self, *a, **k):
+                raise ImportError(f"mi355_flow.flow_factory_plugin.{name} needs an importable `flow_factory` (with diffusers / peft): "
+                                  f"{_IMPORT_ERROR!r}.  Use {standalone} standalone instead.")
+        _Missing.__name__ = _Missing.__qualname__ = name
+        return _Missing
 
-    class Wan2T2VNativeAdapter:  # type: ignore[no-redef]
-        def __init__(self, *a, **k):
-            raise ImportError("mi355_flow.flow_factory_plugin needs an importable `flow_factory` (with diffusers/peft): "
-                              f"{_IMPORT_ERROR!r}.  Use mi355_flow.wan.Wan2T2VNativeAdapter standalone instead.")
-
-    class Flux1NativeAdapter:  # type: ignore[no-redef]
-        def __init__(self, *a, **k):
-            raise ImportError("mi355_flow.flow_factory_plugin needs an importable `flow_factory` (with diffusers/peft): "
-                              f"{_IMPORT_ERROR!r}.  Use mi355_flow.flux.Flux1NativeAdapter standalone instead.")
+    SD3_5NativeAdapter = _unavailable("SD3_5NativeAdapter", "mi355_flow.adapter.SD3_5NativeAdapter")
+    Flux1NativeAdapter = _unavailable("Flux1NativeAdapter", "mi355_flow.flux.Flux1NativeAdapter")
+    Wan2T2VNativeAdapter = _unavailable("Wan2T2VNativeAdapter", "mi355_flow.wan.Wan2T2VNativeAdapter")

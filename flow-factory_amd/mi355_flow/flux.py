@@ -16,9 +16,10 @@ import torch
 
 from . import _lib
 from ._lib import DYNAMICS, FluxCfg
-from .engine import _bf16c, _ptr, _stream, dtype_code, sde_step
+from .engine import WeightHolder, _bf16c, _ptr, _stream, dtype_code, sde_step
 from .samples import Flux1Sample
-from .scheduler import FlowMatchEulerDiscreteSDEScheduler, SDESchedulerOutput, set_scheduler_timesteps
+from .scheduler import (FlowMatchEulerDiscreteSDEScheduler, SDESchedulerOutput, host_noise_levels, randn_tensor,
+                        set_scheduler_timesteps)
 from .trajectory import TrajectoryIndicesType, _resolve, create_callback_collector, create_trajectory_collector
 
 _DTYPE_MAP = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16,
@@ -76,7 +77,7 @@ def model_scalar(value: float, dtype: torch.dtype) -> float:
     return float((torch.tensor(float(value), dtype=torch.float32).to(dtype) * 1000).float())
 
 
-class FluxEngine:
+class FluxEngine(WeightHolder):
     """Owns the packed bf16 copy of the FLUX transformer weights (mi355_flux)."""
 
     def __init__(self, cfg: FluxConfig = FluxConfig()):
@@ -88,30 +89,7 @@ class FluxEngine:
         self._h = h
         self._plans: Dict[tuple, "FluxPlan"] = {}
 
-    def param_names(self) -> List[str]:
-        n = self.lib.mi355_flux_num_params(self._h)
-        return [self.lib.mi355_flux_param_name(self._h, i).decode() for i in range(n)]
-
-    def bind_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True) -> None:
-        names = self.param_names()
-        missing = [n for n in names if n not in state_dict]
-        if missing and strict:
-            raise KeyError(f"mi355_flow: FLUX state dict lacks {len(missing)} parameters, first: {missing[0]}")
-        st = _stream()
-        for n in names:
-            if n not in state_dict:
-                continue
-            t = state_dict[n].detach()
-            if not t.is_cuda:
-                t = t.cuda(non_blocking=True)
-            t = t.contiguous()
-            shape = (C.c_int64 * t.dim())(*t.shape)
-            _lib.check(self.lib.mi355_flux_bind_weight(self._h, n.encode(), t.data_ptr(), dtype_code(t.dtype), t.dim(), shape, st),
-                       f"flux_bind_weight({n})")
-        torch.cuda.current_stream().synchronize()
-
-    def ready(self) -> None:
-        _lib.check(self.lib.mi355_flux_weights_ready(self._h), "flux_weights_ready")
+    _ABI, _WHAT = "flux", "FLUX transformer"
 
     def plan(self, batch: int, latent_h: int, latent_w: int, n_text: int, max_steps: int) -> "FluxPlan":
         key = (batch, latent_h, latent_w, n_text)
@@ -209,47 +187,28 @@ class FluxPlan:
         return out_lat, out_lp, out_fin
 
 
-class Flux1NativeAdapter:
-    """Standalone FLUX.1 adapter (no Flow-Factory import): engine + scheduler (+ optional native VAE decoder)."""
+class FluxRolloutMixin:
+    """`inference()` / `forward()` of `Flux1Adapter` (reference models/flux/flux1.py:151-289, :294-346) on the engine.  Host classes
+    provide `engine` (FluxEngine), `scheduler`, `device`, `latent_storage_dtype`, `encode_prompt`, `decode_latents(latents, height,
+    width, output_type)`.  Used by the standalone `Flux1NativeAdapter` below and, mixed in FRONT of the reference's own `Flux1Adapter`,
+    by `mi355_flow.flow_factory_plugin.Flux1NativeAdapter`."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[FluxConfig] = None,
-                 scheduler: Optional[FlowMatchEulerDiscreteSDEScheduler] = None, latent_storage_dtype: Optional[str] = "fp16",
-                 transformer_dtype: torch.dtype = torch.bfloat16, device: Union[str, torch.device] = "cuda",
-                 vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, vae_config=None, vae_max_batch: int = 4):
-        if not torch.cuda.is_available():
-            raise RuntimeError("mi355_flow: no GPU visible; the native rollout engine has no CPU path")
-        self.device = torch.device(device)
-        self.transformer_dtype = transformer_dtype
-        self._latent_storage = latent_storage_dtype
-        # FLUX.1 scheduler config: dynamic shifting (mu from the image sequence length)
-        self.scheduler = scheduler or FlowMatchEulerDiscreteSDEScheduler(shift=3.0, use_dynamic_shifting=True, sde_steps=[1, 2, 3],
-                                                                         num_sde_steps=1)
-        self.engine = FluxEngine(config or FluxConfig())
-        self.refresh_weights(state_dict)
-        self.vae_decoder = None
-        self.vae_max_batch = vae_max_batch
-        if vae_state_dict is not None:
-            from .vae import VAEConfig, VAEDecoder
-            self.vae_decoder = VAEDecoder(vae_config or VAEConfig(scaling_factor=0.3611, shift_factor=0.1159))
-            self.vae_decoder.bind_state_dict(vae_state_dict)
-            self.vae_decoder.ready()
+    _sample_cls = Flux1Sample
+    _output_cls = SDESchedulerOutput
+    _set_timesteps = staticmethod(set_scheduler_timesteps)
 
-    @property
-    def latent_storage_dtype(self) -> Optional[torch.dtype]:
-        return _DTYPE_MAP.get(self._latent_storage) if self._latent_storage else None
+    def _before_engine_call(self) -> None:
+        """Hook run at the top of inference() / forward(): the Flow-Factory plugin re-binds changed weights here."""
 
-    def refresh_weights(self, state_dict: Dict[str, torch.Tensor]) -> None:
-        self.engine.bind_state_dict(state_dict)
-        self.engine.ready()
-
-    def rollout(self):
-        self.scheduler.rollout()
-
-    def eval(self):
-        self.scheduler.eval()
-
-    def train(self, mode: bool = True):
-        self.scheduler.train(mode)
+    def _check_joint_attention_kwargs(self, jak) -> None:
+        jak = dict(jak or {})
+        scale = float(jak.pop("scale", 1.0))
+        if jak:
+            raise NotImplementedError(f"mi355_flow: joint_attention_kwargs {sorted(jak)} are not supported by the native engine "
+                                      "(only the LoRA `scale` is)")
+        live = getattr(self, "_live_weights", None)
+        if live is not None:
+            live.set_lora_scale(scale)
 
     def cast_latents(self, latents: torch.Tensor, default_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
         target = self.latent_storage_dtype or default_dtype
@@ -258,19 +217,6 @@ class Flux1NativeAdapter:
         if target == torch.float16:
             latents = latents.clamp(-65504.0, 65504.0)
         return latents.to(target)
-
-    def encode_prompt(self, *a, **k):
-        raise RuntimeError("mi355_flow standalone adapter has no text encoders: pass prompt_embeds / pooled_prompt_embeds")
-
-    def decode_latents(self, latents: torch.Tensor, height: int, width: int, output_type: str = "pt"):
-        """flux1.py:138-147: unpack, / scaling + shift, vae.decode, postprocess."""
-        if self.vae_decoder is None:
-            return None
-        if output_type not in ("pt", "np"):
-            raise ValueError("mi355_flow standalone adapter decodes to 'pt' or 'np'")
-        lat = unpack_latents(latents, int(height) // VAE_SCALE_FACTOR, int(width) // VAE_SCALE_FACTOR).contiguous()
-        img = self.vae_decoder.decode(lat, postprocess=True, out_dtype=torch.bfloat16, max_batch=self.vae_max_batch)
-        return img if output_type == "pt" else img.float().permute(0, 2, 3, 1).cpu().numpy()
 
     # ------------------------------------------------------------------ rollout (flux1.py:151-289)
     @torch.no_grad()
@@ -290,9 +236,9 @@ class Flux1NativeAdapter:
         extra_call_back_kwargs: List[str] = [],
         trajectory_indices: TrajectoryIndicesType = "all",
     ) -> List[Flux1Sample]:
+        self._before_engine_call()
         device = self.device
-        if joint_attention_kwargs:
-            raise ValueError("mi355_flow: joint_attention_kwargs are not supported by the native engine")
+        self._check_joint_attention_kwargs(joint_attention_kwargs)
         if prompt_embeds is None:
             enc = self.encode_prompt(prompt)
             prompt_embeds, pooled_prompt_embeds, prompt_ids = enc["prompt_embeds"], enc["pooled_prompt_embeds"], enc["prompt_ids"]
@@ -309,16 +255,20 @@ class Flux1NativeAdapter:
 
         # RNG in the reference's order: prepare_latents draws (B, 16, h, w) in the prompt dtype and packs it; the scheduler then
         # draws one fp32 tensor of the PACKED shape per step (randn_tensor(noise_pred.shape)), also when noise_level == 0
-        latents = pack_latents(torch.randn((B, Cl, h, w), generator=generator, device=device, dtype=dtype))
+        # (no step draws at all under ODE dynamics: the reference's ODE branch draws nothing)
+        dyn = self.scheduler.dynamics_type
+        latents = pack_latents(randn_tensor((B, Cl, h, w), generator=generator, device=device, dtype=dtype))
         latent_image_ids = prepare_latent_image_ids(h // 2, w // 2, device, dtype)
-        step_noise = torch.empty((N, B, Ni, Cl * 4), device=device, dtype=torch.float32)
-        for i in range(N):
-            step_noise[i] = torch.randn((B, Ni, Cl * 4), generator=generator, device=device, dtype=torch.float32)
+        step_noise = None
+        if dyn != "ODE":
+            step_noise = torch.empty((N, B, Ni, Cl * 4), device=device, dtype=torch.float32)
+            for i in range(N):
+                step_noise[i] = randn_tensor((B, Ni, Cl * 4), generator=generator, device=device, dtype=torch.float32)
 
-        timesteps = set_scheduler_timesteps(self.scheduler, N, seq_len=latents.shape[1], device=device)
+        timesteps = self._set_timesteps(self.scheduler, N, seq_len=latents.shape[1], device=device)
         ts_host = [float(t) for t in timesteps.tolist()]
         sig_host = [float(s) for s in self.scheduler.sigmas.tolist()]
-        eta_host = self.scheduler.host_noise_levels()
+        eta_host = host_noise_levels(self.scheduler, N)
         storage = self.latent_storage_dtype or dtype
         plan = self.engine.plan(B, h, w, prompt_embeds.shape[1], N)
         stepwise = any(k != "noise_level" for k in extra_call_back_kwargs)
@@ -361,7 +311,7 @@ class Flux1NativeAdapter:
         lat_stack = torch.stack(all_latents, dim=1) if all_latents else None
         lp_stack = torch.stack(all_log_probs, dim=1) if all_log_probs else None
         return [
-            Flux1Sample(
+            self._sample_cls(
                 timesteps=timesteps,
                 all_latents=lat_stack[b] if lat_stack is not None else None,
                 log_probs=lp_stack[b] if lp_stack is not None else None,
@@ -394,7 +344,7 @@ class Flux1NativeAdapter:
             tm = ((f32(ts[i]) / f32(1000.0)).to(storage) * 1000).float().reshape(1)      # as mi355_flux_rollout's host math
             v = plan.transformer_forward(cur, tm, gm, pe, pp)
             o = sde_step(v, None, 1.0, cur, f32(ts[i]) / f32(1000.0), f32(t_next) / f32(1000.0), eta[i], sig[1], self.scheduler.dynamics_type,
-                         noise=step_noise[i], compute_log_prob=clp, want=want)
+                         noise=step_noise[i] if step_noise is not None else None, compute_log_prob=clp, want=want)
             if clp:
                 log_probs[i] = o.log_prob
             cur = o.next_storage
@@ -421,8 +371,8 @@ class Flux1NativeAdapter:
         height: Optional[int] = None,
         width: Optional[int] = None,
     ) -> SDESchedulerOutput:
-        if joint_attention_kwargs:
-            raise ValueError("mi355_flow: joint_attention_kwargs are not supported by the native engine")
+        self._before_engine_call()
+        self._check_joint_attention_kwargs(joint_attention_kwargs)
         B, Ni, _ = latents.shape
         dev = latents.device
         # the latent grid is recovered from img_ids (rows / cols) when given, else it must be square or passed explicitly
@@ -454,7 +404,7 @@ class Flux1NativeAdapter:
             noise_level = sched.get_noise_level_for_sigma(sigma)
         noise = None
         if next_latents is None and dyn != "ODE":
-            noise = torch.randn(latents.shape, device=dev, dtype=torch.float32)
+            noise = randn_tensor(latents.shape, device=dev, dtype=torch.float32)
         want = tuple(k for k in return_kwargs if k in ("next_latents", "next_latents_mean", "noise_pred", "std_dev_t", "dt"))
         o = sde_step(v, None, 1.0, latents, sigma, sigma_next, noise_level, float(sched.sigmas[1]), dyn, noise=noise,
                      next_latents=next_latents, compute_log_prob=compute_log_prob, want=want)
@@ -467,10 +417,68 @@ class Flux1NativeAdapter:
             dt=o.dt.view(view) if o.dt is not None else None,
             log_prob=o.log_prob if compute_log_prob else None,
         )
-        return SDESchedulerOutput.from_dict({k: res[k] for k in return_kwargs if k in res})
+        return self._output_cls.from_dict({k: res[k] for k in return_kwargs if k in res})
 
 
 # ----------------------------------------------------------------------------- operator-level wrappers (tests, microbench)
+
+
+class Flux1NativeAdapter(FluxRolloutMixin):
+    """Standalone FLUX.1 adapter (no Flow-Factory import): engine + scheduler (+ optional native VAE decoder)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[FluxConfig] = None,
+                 scheduler: Optional[FlowMatchEulerDiscreteSDEScheduler] = None, latent_storage_dtype: Optional[str] = "fp16",
+                 transformer_dtype: torch.dtype = torch.bfloat16, device: Union[str, torch.device] = "cuda",
+                 vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, vae_config=None, vae_max_batch: int = 4):
+        if not torch.cuda.is_available():
+            raise RuntimeError("mi355_flow: no GPU visible; the native rollout engine has no CPU path")
+        self.device = torch.device(device)
+        self.transformer_dtype = transformer_dtype
+        self._latent_storage = latent_storage_dtype
+        # FLUX.1 scheduler config: dynamic shifting (mu from the image sequence length)
+        self.scheduler = scheduler or FlowMatchEulerDiscreteSDEScheduler(shift=3.0, use_dynamic_shifting=True, sde_steps=[1, 2, 3],
+                                                                         num_sde_steps=1)
+        self.engine = FluxEngine(config or FluxConfig())
+        self.refresh_weights(state_dict)
+        self.vae_decoder = None
+        self.vae_max_batch = vae_max_batch
+        if vae_state_dict is not None:
+            from .vae import VAEConfig, VAEDecoder
+            self.vae_decoder = VAEDecoder(vae_config or VAEConfig(scaling_factor=0.3611, shift_factor=0.1159))
+            self.vae_decoder.bind_state_dict(vae_state_dict)
+            self.vae_decoder.ready()
+
+    @property
+    def latent_storage_dtype(self) -> Optional[torch.dtype]:
+        return _DTYPE_MAP.get(self._latent_storage) if self._latent_storage else None
+
+    def refresh_weights(self, state_dict: Dict[str, torch.Tensor]) -> None:
+        self.engine.bind_state_dict(state_dict)
+        self.engine.ready()
+
+    def rollout(self):
+        self.scheduler.rollout()
+
+    def eval(self):
+        self.scheduler.eval()
+
+    def train(self, mode: bool = True):
+        self.scheduler.train(mode)
+
+    def encode_prompt(self, *a, **k):
+        raise RuntimeError("mi355_flow standalone adapter has no text encoders: pass prompt_embeds / pooled_prompt_embeds")
+
+    def decode_latents(self, latents: torch.Tensor, height: int, width: int, output_type: str = "pt"):
+        """flux1.py:138-147: unpack, / scaling + shift, vae.decode, postprocess."""
+        if self.vae_decoder is None:
+            return None
+        if output_type not in ("pt", "np"):
+            raise ValueError("mi355_flow standalone adapter decodes to 'pt' or 'np'")
+        lat = unpack_latents(latents, int(height) // VAE_SCALE_FACTOR, int(width) // VAE_SCALE_FACTOR).contiguous()
+        img = self.vae_decoder.decode(lat, postprocess=True, out_dtype=torch.bfloat16, max_batch=self.vae_max_batch)
+        return img if output_type == "pt" else img.float().permute(0, 2, 3, 1).cpu().numpy()
+
+
 def op_attention128(q: torch.Tensor, k: torch.Tensor, vT: torch.Tensor, S: int, n_first: Optional[int] = None, q_prescaled: bool = False):
     """q, k: [B, H, S_pad, 128] bf16; vT: [B, H, 128, S_pad] bf16 -> (o_first [B*n_first, H*128], o_rest [B*(S-n_first), H*128])."""
     lib = _lib.load()

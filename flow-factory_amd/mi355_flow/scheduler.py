@@ -77,6 +77,47 @@ def set_scheduler_timesteps(scheduler, num_inference_steps: int, seq_len: Option
     return scheduler.timesteps
 
 
+def host_noise_levels(scheduler, num_steps: Optional[int] = None) -> List[float]:
+    """Per-step noise levels of a rollout as host floats (what `mi355_rollout` consumes: no `.item()` sync per step), derived from
+    the PUBLIC SDE-scheduler contract only -- `current_sde_steps`, `noise_level`, `is_eval`, `dynamics_type` (reference
+    scheduler/abc.py:76-153, flow_match_euler_discrete.py:126-198) -- so it works on the reference's own scheduler classes under
+    the Flow-Factory plugin as well as on the mirrors in this package.  Equals `get_noise_level_for_timestep(t_i)` per step, with
+    the `is_eval` / ODE override of `step()` (:316-317) applied."""
+    n = int(num_steps) if num_steps is not None else len(scheduler.timesteps)
+    if bool(getattr(scheduler, "is_eval", False)) or getattr(scheduler, "dynamics_type", None) == "ODE":
+        return [0.0] * n
+    cur = {int(i) for i in torch.as_tensor(scheduler.current_sde_steps).reshape(-1).tolist()}
+    eta = float(scheduler.noise_level)
+    return [eta if i in cur else 0.0 for i in range(n)]
+
+
+def randn_tensor(shape, generator=None, device=None, dtype=None) -> torch.Tensor:
+    """diffusers.utils.torch_utils.randn_tensor semantics (the draw the reference makes at sd3_5.py:242 via prepare_latents and at
+    flow_match_euler_discrete.py:352): a CPU generator draws on the CPU and the result moves to `device`; a list of generators
+    draws one sample each; a generator on another accelerator raises."""
+    device = torch.device(device) if device is not None else torch.device("cpu")
+    shape = tuple(shape)
+    gens = generator if isinstance(generator, (list, tuple)) else [generator]
+    rand_device = device
+    g0 = gens[0]
+    if g0 is not None:
+        gtype = g0.device.type
+        if gtype != device.type:
+            if gtype == "cpu":
+                rand_device = torch.device("cpu")
+            else:
+                raise ValueError(f"Cannot generate a {device} tensor from a generator of type {gtype}.")
+    if isinstance(generator, (list, tuple)):
+        if len(generator) == 1:
+            generator = generator[0]
+        else:
+            if len(generator) != shape[0]:
+                raise ValueError(f"got {len(generator)} generators for a batch of {shape[0]}")
+            one = (1,) + shape[1:]
+            return torch.cat([torch.randn(one, generator=g, device=rand_device, dtype=dtype) for g in generator], 0).to(device)
+    return torch.randn(shape, generator=generator, device=rand_device, dtype=dtype).to(device)
+
+
 class FlowMatchEulerDiscreteSDEScheduler:
     """Flow-match Euler scheduler with SDE noise injection on selected steps (GRPO rollouts)."""
 
@@ -219,11 +260,8 @@ class FlowMatchEulerDiscreteSDEScheduler:
         return out
 
     def host_noise_levels(self) -> List[float]:
-        """Per-step noise levels as host floats: what the engine's rollout consumes (no .item() per step)."""
-        n = len(self.timesteps)
-        cur = set(int(i) for i in self.current_sde_steps.tolist())
-        off = self.is_eval or self.dynamics_type == "ODE"
-        return [0.0 if off or i not in cur else float(self.noise_level) for i in range(n)]
+        """Per-step noise levels as host floats (see the module-level `host_noise_levels`)."""
+        return host_noise_levels(self)
 
     def get_noise_level_for_timestep(self, timestep):
         if not isinstance(timestep, torch.Tensor) or timestep.ndim == 0:
@@ -309,7 +347,7 @@ class FlowMatchEulerDiscreteSDEScheduler:
                 sigma_max = float(self.sigmas[1])
                 self._host_sigma1, self._host_sigma1_n = sigma_max, self.num_inference_steps
         if next_latents is None and dyn != "ODE" and variance_noise is None:
-            variance_noise = torch.randn(noise_pred.shape, generator=generator, device=noise_pred.device, dtype=torch.float32)
+            variance_noise = randn_tensor(noise_pred.shape, generator=generator, device=noise_pred.device, dtype=torch.float32)
         want = [k for k in return_kwargs if k in ("next_latents", "next_latents_mean", "std_dev_t", "dt", "noise_pred")]
         if not return_dict:
             want = ["next_latents", "next_latents_mean", "std_dev_t", "dt", "noise_pred"]

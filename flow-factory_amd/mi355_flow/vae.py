@@ -17,7 +17,7 @@ import torch
 
 from . import _lib
 from ._lib import VaeCfg
-from .engine import _ptr, _stream, dtype_code
+from .engine import WeightHolder, _ptr, _stream, dtype_code
 
 
 @dataclass
@@ -53,7 +53,7 @@ class VAEConfig:
         return 2 ** (len(self.block_out_channels) - 1)
 
 
-class VAEDecoder:
+class VAEDecoder(WeightHolder):
     """Owns the repacked bf16 decoder weights (mi355_vae) and per-shape workspaces (mi355_vae_plan)."""
 
     def __init__(self, cfg: VAEConfig = VAEConfig()):
@@ -65,30 +65,7 @@ class VAEDecoder:
         self._h = h
         self._plans: Dict[tuple, C.c_void_p] = {}
 
-    def param_names(self) -> List[str]:
-        n = self.lib.mi355_vae_num_params(self._h)
-        return [self.lib.mi355_vae_param_name(self._h, i).decode() for i in range(n)]
-
-    def bind_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True) -> None:
-        names = self.param_names()
-        missing = [n for n in names if n not in state_dict]
-        if missing and strict:
-            raise KeyError(f"mi355_flow: VAE state dict lacks {len(missing)} parameters, first: {missing[0]}")
-        st = _stream()
-        for n in names:
-            if n not in state_dict:
-                continue
-            t = state_dict[n].detach()
-            if not t.is_cuda:
-                t = t.cuda(non_blocking=True)
-            t = t.contiguous()
-            shape = (C.c_int64 * t.dim())(*t.shape)
-            _lib.check(self.lib.mi355_vae_bind_weight(self._h, n.encode(), t.data_ptr(), dtype_code(t.dtype), t.dim(), shape, st),
-                       f"vae_bind_weight({n})")
-        torch.cuda.current_stream().synchronize()
-
-    def ready(self) -> None:
-        _lib.check(self.lib.mi355_vae_weights_ready(self._h), "vae_weights_ready")
+    _ABI, _WHAT = "vae", "VAE decoder"
 
     def _plan(self, batch: int, h: int, w: int) -> C.c_void_p:
         key = (h, w)

@@ -18,9 +18,9 @@ import torch
 
 from . import _lib
 from ._lib import DYNAMICS, WanCfg
-from .engine import _bf16c, _ptr, _stream, dtype_code, sde_step
+from .engine import WeightHolder, _bf16c, _ptr, _stream, dtype_code, sde_step
 from .samples import WanT2VSample
-from .scheduler import FlowMatchEulerDiscreteSDEScheduler, SDESchedulerOutput
+from .scheduler import FlowMatchEulerDiscreteSDEScheduler, SDESchedulerOutput, host_noise_levels, randn_tensor
 from .trajectory import TrajectoryIndicesType, _resolve, create_callback_collector, create_trajectory_collector
 
 _DTYPE_MAP = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16,
@@ -74,7 +74,7 @@ class UniPCMultistepSDEScheduler(FlowMatchEulerDiscreteSDEScheduler):
         self._host_timesteps = [float(x) for x in ts.tolist()]
 
 
-class WanEngine:
+class WanEngine(WeightHolder):
     def __init__(self, cfg: WanConfig = WanConfig()):
         self.lib = _lib.load()
         self.cfg = cfg
@@ -84,30 +84,7 @@ class WanEngine:
         self._h = h
         self._plans: Dict[tuple, "WanPlan"] = {}
 
-    def param_names(self) -> List[str]:
-        n = self.lib.mi355_wan_num_params(self._h)
-        return [self.lib.mi355_wan_param_name(self._h, i).decode() for i in range(n)]
-
-    def bind_state_dict(self, state_dict: Dict[str, torch.Tensor], strict: bool = True) -> None:
-        names = self.param_names()
-        missing = [n for n in names if n not in state_dict]
-        if missing and strict:
-            raise KeyError(f"mi355_flow: Wan state dict lacks {len(missing)} parameters, first: {missing[0]}")
-        st = _stream()
-        for n in names:
-            if n not in state_dict:
-                continue
-            t = state_dict[n].detach()
-            if not t.is_cuda:
-                t = t.cuda(non_blocking=True)
-            t = t.contiguous()
-            shape = (C.c_int64 * t.dim())(*t.shape)
-            _lib.check(self.lib.mi355_wan_bind_weight(self._h, n.encode(), t.data_ptr(), dtype_code(t.dtype), t.dim(), shape, st),
-                       f"wan_bind_weight({n})")
-        torch.cuda.current_stream().synchronize()
-
-    def ready(self) -> None:
-        _lib.check(self.lib.mi355_wan_weights_ready(self._h), "wan_weights_ready")
+    _ABI, _WHAT = "wan", "Wan transformer"
 
     def plan(self, batch: int, n_cfg: int, T: int, h: int, w: int, n_text: int, max_steps: int) -> "WanPlan":
         key = (batch, n_cfg, T, h, w, n_text)
@@ -200,39 +177,25 @@ class WanPlan:
         return out_lat, out_lp, out_fin
 
 
-class Wan2T2VNativeAdapter:
-    """Standalone Wan2.1 T2V adapter (no Flow-Factory import): engine + UniPC-SDE scheduler (+ optional video decoder callable)."""
+class WanRolloutMixin:
+    """`inference()` / `forward()` of `Wan2_T2V_Adapter` (reference models/wan/wan2_t2v.py:234-421, :426-543) on the engine, for the
+    single-transformer Wan2.1 configuration.  Host classes provide `engine` (WanEngine), `scheduler`, `device`, `transformer_dtype`,
+    `latent_storage_dtype`, `encode_prompt`, `decode_latents(latents, output_type)`.
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[WanConfig] = None,
-                 scheduler: Optional[UniPCMultistepSDEScheduler] = None, latent_storage_dtype: Optional[str] = "fp16",
-                 transformer_dtype: torch.dtype = torch.bfloat16, device: Union[str, torch.device] = "cuda",
-                 video_decode: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
-        if not torch.cuda.is_available():
-            raise RuntimeError("mi355_flow: no GPU visible; the native rollout engine has no CPU path")
-        self.device = torch.device(device)
-        self.transformer_dtype = transformer_dtype
-        self._latent_storage = latent_storage_dtype
-        self.scheduler = scheduler or UniPCMultistepSDEScheduler(flow_shift=3.0, sde_steps=[1, 2, 3], num_sde_steps=1)
-        self.engine = WanEngine(config or WanConfig())
-        self.refresh_weights(state_dict)
-        self._video_decode = video_decode
+    Evaluation mode: the reference's `UniPCMultistepSDEScheduler.step` delegates to diffusers' UniPC multistep predictor-corrector
+    when `is_eval` (scheduler/unipc_multistep.py:282-285), which the engine does not implement -- `inference()` in eval mode is
+    routed to `_eval_inference` (the Flow-Factory plugin sends it to the reference path; standalone it raises) instead of silently
+    sampling with a first-order Euler step."""
 
-    @property
-    def latent_storage_dtype(self) -> Optional[torch.dtype]:
-        return _DTYPE_MAP.get(self._latent_storage) if self._latent_storage else None
+    _sample_cls = WanT2VSample
+    _output_cls = SDESchedulerOutput
 
-    def refresh_weights(self, state_dict: Dict[str, torch.Tensor]) -> None:
-        self.engine.bind_state_dict(state_dict)
-        self.engine.ready()
+    def _before_engine_call(self) -> None:
+        """Hook run at the top of inference() / forward(): the Flow-Factory plugin re-binds changed weights here."""
 
-    def rollout(self):
-        self.scheduler.rollout()
-
-    def eval(self):
-        self.scheduler.eval()
-
-    def train(self, mode: bool = True):
-        self.scheduler.train(mode)
+    def _eval_inference(self, **kwargs):
+        raise NotImplementedError("mi355_flow: evaluation-mode sampling for Wan uses diffusers' UniPC multistep solver in the reference "
+                                  "(unipc_multistep.py:282-285); the native engine implements the rollout (SDE / Euler) branch only")
 
     def cast_latents(self, latents: torch.Tensor, default_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
         target = self.latent_storage_dtype or default_dtype
@@ -241,12 +204,6 @@ class Wan2T2VNativeAdapter:
         if target == torch.float16:
             latents = latents.clamp(-65504.0, 65504.0)
         return latents.to(target)
-
-    def encode_prompt(self, *a, **k):
-        raise RuntimeError("mi355_flow standalone adapter has no text encoder: pass prompt_embeds (and negative_prompt_embeds for CFG)")
-
-    def decode_latents(self, latents: torch.Tensor, output_type: str = "pt"):
-        return self._video_decode(latents) if self._video_decode is not None else None
 
     # ------------------------------------------------------------------ rollout (wan2_t2v.py:234-421)
     @torch.no_grad()
@@ -272,8 +229,17 @@ class Wan2T2VNativeAdapter:
         trajectory_indices: TrajectoryIndicesType = "all",
     ) -> List[WanT2VSample]:
         device = self.device
+        if bool(getattr(self.scheduler, "is_eval", False)):
+            return self._eval_inference(
+                prompt=prompt, negative_prompt=negative_prompt, height=height, width=width, num_frames=num_frames,
+                num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, guidance_scale_2=guidance_scale_2,
+                generator=generator, prompt_ids=prompt_ids, prompt_embeds=prompt_embeds, negative_prompt_ids=negative_prompt_ids,
+                negative_prompt_embeds=negative_prompt_embeds, compute_log_prob=compute_log_prob, attention_kwargs=attention_kwargs,
+                max_sequence_length=max_sequence_length, extra_call_back_kwargs=extra_call_back_kwargs,
+                trajectory_indices=trajectory_indices)
+        self._before_engine_call()
         if attention_kwargs:
-            raise ValueError("mi355_flow: attention_kwargs are not supported by the native engine")
+            raise NotImplementedError("mi355_flow: attention_kwargs are not supported by the native engine")
         if guidance_scale_2 is not None and guidance_scale_2 != guidance_scale:
             raise ValueError("mi355_flow: guidance_scale_2 (Wan2.2 two-expert models) is not supported")
         if (num_frames - 1) % VAE_SCALE_TEMPORAL != 0:
@@ -297,13 +263,16 @@ class Wan2T2VNativeAdapter:
         Cl = self.engine.cfg.in_channels
         T, h, w = (num_frames - 1) // VAE_SCALE_TEMPORAL + 1, height // VAE_SCALE_SPATIAL, width // VAE_SCALE_SPATIAL
         # RNG in the reference's order: prepare_latents in fp32, then one fp32 draw per step
-        latents = torch.randn((B, Cl, T, h, w), generator=generator, device=device, dtype=torch.float32)
-        step_noise = torch.empty((N, B, Cl, T, h, w), device=device, dtype=torch.float32)
-        for i in range(N):
-            step_noise[i] = torch.randn((B, Cl, T, h, w), generator=generator, device=device, dtype=torch.float32)
+        # (none of the step draws under ODE dynamics: the reference's ODE branch draws nothing)
+        latents = randn_tensor((B, Cl, T, h, w), generator=generator, device=device, dtype=torch.float32)
+        step_noise = None
+        if self.scheduler.dynamics_type != "ODE":
+            step_noise = torch.empty((N, B, Cl, T, h, w), device=device, dtype=torch.float32)
+            for i in range(N):
+                step_noise[i] = randn_tensor((B, Cl, T, h, w), generator=generator, device=device, dtype=torch.float32)
         ts_host = [float(t) for t in timesteps.tolist()]
         sig_host = [float(s) for s in self.scheduler.sigmas.tolist()]
-        eta_host = self.scheduler.host_noise_levels()
+        eta_host = host_noise_levels(self.scheduler, N)
         storage = self.latent_storage_dtype or torch.float32       # cast_latents(latents) with no default: fp32 stays fp32
         stepwise = any(k != "noise_level" for k in extra_call_back_kwargs)
         plan = self.engine.plan(B, 2 if do_cfg else 1, T, h, w, prompt_embeds.shape[1], N)
@@ -340,7 +309,7 @@ class Wan2T2VNativeAdapter:
         lat_stack = torch.stack(all_latents, dim=1) if all_latents else None
         lp_stack = torch.stack(all_log_probs, dim=1) if all_log_probs else None
         return [
-            WanT2VSample(
+            self._sample_cls(
                 timesteps=timesteps,
                 all_latents=lat_stack[b] if lat_stack is not None else None,
                 log_probs=lp_stack[b] if lp_stack is not None else None,
@@ -374,7 +343,8 @@ class Wan2T2VNativeAdapter:
             v = plan.transformer_forward(cur, f32(ts[i]).reshape(1), ne if ne is not None else pe, pe if ne is not None else None)
             vu, vt = (v[:B], v[B:]) if ne is not None else (None, v)
             o = sde_step(vt, vu, guidance, cur, f32(ts[i]) / f32(1000.0), f32(t_next) / f32(1000.0), eta[i], sig[1],
-                         self.scheduler.dynamics_type, noise=step_noise[i], compute_log_prob=clp, want=want)
+                         self.scheduler.dynamics_type, noise=step_noise[i] if step_noise is not None else None, compute_log_prob=clp,
+                         want=want)
             if clp:
                 log_probs[i] = o.log_prob
             cur = o.next_storage
@@ -400,8 +370,9 @@ class Wan2T2VNativeAdapter:
         return_kwargs: List[str] = ["noise_pred", "next_latents", "next_latents_mean", "std_dev_t", "dt", "log_prob"],
         boundary_timestep: Optional[float] = None,
     ) -> SDESchedulerOutput:
+        self._before_engine_call()
         if attention_kwargs:
-            raise ValueError("mi355_flow: attention_kwargs are not supported by the native engine")
+            raise NotImplementedError("mi355_flow: attention_kwargs are not supported by the native engine")
         if boundary_timestep is not None:
             raise ValueError("mi355_flow: boundary_timestep (Wan2.2 two-expert models) is not supported")
         dev = latents.device
@@ -425,7 +396,7 @@ class Wan2T2VNativeAdapter:
             noise_level = sched.get_noise_level_for_timestep(float(t0))
         noise = None
         if next_latents is None and dyn != "ODE":
-            noise = torch.randn(latents.shape, device=dev, dtype=torch.float32)
+            noise = randn_tensor(latents.shape, device=dev, dtype=torch.float32)
         want = tuple(k for k in return_kwargs if k in ("next_latents", "next_latents_mean", "noise_pred", "std_dev_t", "dt"))
         o = sde_step(vt, vu, guidance_scale, latents, sigma, sigma_next, noise_level, float(sched.sigmas[1]), dyn, noise=noise,
                      next_latents=next_latents, compute_log_prob=compute_log_prob, want=want)
@@ -438,4 +409,45 @@ class Wan2T2VNativeAdapter:
             dt=o.dt.view(view) if o.dt is not None else None,
             log_prob=o.log_prob if compute_log_prob else None,
         )
-        return SDESchedulerOutput.from_dict({k: res[k] for k in return_kwargs if k in res})
+        return self._output_cls.from_dict({k: res[k] for k in return_kwargs if k in res})
+
+
+class Wan2T2VNativeAdapter(WanRolloutMixin):
+    """Standalone Wan2.1 T2V adapter (no Flow-Factory import): engine + UniPC-SDE scheduler (+ optional video decoder callable)."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[WanConfig] = None,
+                 scheduler: Optional[UniPCMultistepSDEScheduler] = None, latent_storage_dtype: Optional[str] = "fp16",
+                 transformer_dtype: torch.dtype = torch.bfloat16, device: Union[str, torch.device] = "cuda",
+                 video_decode: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("mi355_flow: no GPU visible; the native rollout engine has no CPU path")
+        self.device = torch.device(device)
+        self.transformer_dtype = transformer_dtype
+        self._latent_storage = latent_storage_dtype
+        self.scheduler = scheduler or UniPCMultistepSDEScheduler(flow_shift=3.0, sde_steps=[1, 2, 3], num_sde_steps=1)
+        self.engine = WanEngine(config or WanConfig())
+        self.refresh_weights(state_dict)
+        self._video_decode = video_decode
+
+    @property
+    def latent_storage_dtype(self) -> Optional[torch.dtype]:
+        return _DTYPE_MAP.get(self._latent_storage) if self._latent_storage else None
+
+    def refresh_weights(self, state_dict: Dict[str, torch.Tensor]) -> None:
+        self.engine.bind_state_dict(state_dict)
+        self.engine.ready()
+
+    def rollout(self):
+        self.scheduler.rollout()
+
+    def eval(self):
+        self.scheduler.eval()
+
+    def train(self, mode: bool = True):
+        self.scheduler.train(mode)
+
+    def encode_prompt(self, *a, **k):
+        raise RuntimeError("mi355_flow standalone adapter has no text encoder: pass prompt_embeds (and negative_prompt_embeds for CFG)")
+
+    def decode_latents(self, latents: torch.Tensor, output_type: str = "pt"):
+        return self._video_decode(latents) if self._video_decode is not None else None

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define MI355_FLOW_VERSION 1
+#define MI355_FLOW_VERSION 2
 
 enum { MI355_F32 = 0, MI355_BF16 = 1, MI355_F16 = 2 };
 enum { MI355_ODE = 0, MI355_FLOW_SDE = 1, MI355_DANCE_SDE = 2, MI355_CPS = 3 };
@@ -64,6 +64,10 @@ int mi355_engine_bind_weight(mi355_engine* e, const char* name, const void* src,
                              const int64_t* shape, void* stream);
 /* 0 if every parameter of the config has been bound at least once, else error listing the first missing. */
 int mi355_engine_weights_ready(mi355_engine* e);
+/* With the weights bound now: how many of the forward's `n_total` attention launches run the static-bound softmax kernel (selected
+ * per layer when the q/k RMSNorm weights prove |score| <= 60 in the log2 domain; the others keep the running-max kernel), and the
+ * largest proven bound.  Synchronises `stream` once if a norm weight changed since the last query (never inside a rollout). */
+int mi355_engine_attention_info(mi355_engine* e, void* stream, int* n_static, int* n_total, float* max_bound);
 /* number of parameter tensors the engine expects, and the i-th expected name (for binding loops) */
 int mi355_engine_num_params(mi355_engine* e);
 const char* mi355_engine_param_name(mi355_engine* e, int i);
@@ -88,13 +92,15 @@ int mi355_transformer_forward(mi355_plan* p, void* stream, const void* latents, 
                               const void* pooled_b, void* v_out);
 
 /* ---- fused CFG-combine + SDE/ODE step + log-prob (K14-K17), usable standalone ---------------
- * v_text/v_uncond : bf16 [batch][n]; v_uncond NULL => no CFG.   latents: storage dtype.
+ * v_text/v_uncond : [batch][n] of `v_dtype` (the engine's own network output is bf16; fp32 / fp16 predictions are read exactly,
+ *                   like the reference's `noise_pred.float()`, and CFG is combined op by op in that dtype); v_uncond NULL => no CFG.
+ *                   latents: storage dtype.
  * noise           : fp32 eps [batch][n] (rollout) -- ignored when next_in != NULL (replay).
  * sigma/sigma_next/eta : device fp32, one value (scalar_stride 0) or one per sample (stride 1).
  * outputs (any may be NULL): next_out (storage dtype `lat_dtype`), next_f32 (value-rounded fp32,
  * what the reference's step() returns), mean_out fp32, noise_pred_out fp32 (CFG-combined),
  * log_prob/std_dev_t/dt [batch] fp32. */
-int mi355_sde_step(void* stream, int batch, int64_t n, const void* v_text, const void* v_uncond, float guidance,
+int mi355_sde_step(void* stream, int batch, int64_t n, const void* v_text, const void* v_uncond, int v_dtype, float guidance,
                    const void* latents, int lat_dtype, const float* noise, const void* next_in, int next_in_dtype,
                    const float* sigma, const float* sigma_next, const float* eta, int scalar_stride, float sigma_max,
                    int dynamics, int compute_log_prob, void* next_out, float* next_f32, float* mean_out,

@@ -1,0 +1,251 @@
+"""Test doubles for driving `mi355_flow.flow_factory_plugin` on a CPU-only box: a pseudo-pipeline with HF-named torch parameters,
+a single-process accelerator and an engine that records what was bound / launched instead of calling libmi355flow.so.
+(The real engine needs a GPU; the plugin's Python binding -- class construction, weight liveness, sample classes, kwargs
+filtering, mode switches -- does not.)"""
+from __future__ import annotations
+
+import types
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn as nn
+
+
+# --------------------------------------------------------------------------------------- modules with HF parameter names
+def build_module_tree(shapes: Dict[str, Tuple[int, ...]], buffers=("pos_embed.pos_embed",), seed=0, std=0.05, cls=nn.Module) -> nn.Module:
+    """Nested nn.Modules whose `named_parameters()` / attribute paths are exactly `shapes`' keys."""
+    g = torch.Generator().manual_seed(seed)
+    root = cls()
+    for name, shape in shapes.items():
+        parts = name.split(".")
+        mod = root
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, nn.Module())
+            mod = getattr(mod, p)
+        val = torch.randn(shape, generator=g) * std
+        if ".norm_" in name and len(shape) == 1:
+            val = val + 1.0
+        if name in buffers:
+            mod.register_buffer(parts[-1], val)
+        else:
+            mod.register_parameter(parts[-1], nn.Parameter(val))
+    return root
+
+
+class FakeTransformer(nn.Module):
+    """Parameters only: the native path must never call the torch forward."""
+
+    calls = 0
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    def forward(self, *a, **k):
+        type(self).calls += 1
+        raise AssertionError("the torch transformer forward was called on the native rollout path")
+
+
+class FakeLoraLinear(nn.Module):
+    """Shape of a peft `lora.Linear`: base_layer + lora_A / lora_B ModuleDicts + scaling, adapters can be disabled."""
+
+    def __init__(self, base: nn.Module, r=4, alpha=8.0, seed=0):
+        super().__init__()
+        out_f, in_f = base.weight.shape
+        self.base_layer = base
+        g = torch.Generator().manual_seed(seed)
+        a, b = nn.Linear(in_f, r, bias=False), nn.Linear(r, out_f, bias=False)
+        with torch.no_grad():
+            a.weight.copy_(torch.randn(r, in_f, generator=g) * 0.1)
+            b.weight.copy_(torch.randn(out_f, r, generator=g) * 0.1)
+        self.lora_A, self.lora_B = nn.ModuleDict({"default": a}), nn.ModuleDict({"default": b})
+        self.scaling = {"default": alpha / r}
+        self.active_adapters = ["default"]
+        self.disable_adapters = False
+        self.merged = False
+        base.weight.requires_grad_(False)
+
+
+def wrap_lora(root: nn.Module, targets=("to_q", "to_k", "to_v", "to_out.0")) -> List[str]:
+    """Replace every `...<target>` leaf (a module holding weight/bias) by a FakeLoraLinear; returns the wrapped paths."""
+    wrapped = []
+    for path, mod in list(root.named_modules()):
+        if any(path.endswith("." + t) for t in targets) and hasattr(mod, "weight"):
+            parent = root.get_submodule(path.rsplit(".", 1)[0])
+            setattr(parent, path.rsplit(".", 1)[1], FakeLoraLinear(mod, seed=len(wrapped)))
+            wrapped.append(path)
+    return wrapped
+
+
+class FakePeftModel(nn.Module):
+    """`PeftModel(base_model=LoraModel(model=<transformer>))` nesting with a `disable_adapter()` context."""
+
+    def __init__(self, inner: nn.Module):
+        super().__init__()
+        self.peft_config = {"default": object()}
+        self.base_model = nn.Module()
+        self.base_model.add_module("model", inner)
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    def disable_adapter(self):
+        from contextlib import contextmanager
+
+        @contextmanager
+        def ctx():
+            layers = [m for m in self.modules() if isinstance(m, FakeLoraLinear)]
+            for m in layers:
+                m.disable_adapters = True
+            try:
+                yield
+            finally:
+                for m in layers:
+                    m.disable_adapters = False
+        return ctx()
+
+
+# --------------------------------------------------------------------------------------- engine double
+class FakePlan:
+    def __init__(self, engine, key, max_steps):
+        self.engine, self.key, self.max_steps = engine, key, max_steps
+        self.batch, self.n_cfg, self.h, self.w, self.n_text = key
+        self.C = engine.cfg.in_channels
+
+    def rollout(self, timesteps, sigmas, noise_levels, dynamics, guidance, init_latents, storage_dtype, step_noise, prompt_embeds, pooled,
+                neg_embeds=None, neg_pooled=None, keep_positions=None, compute_log_prob=True):
+        N, B = len(timesteps), self.batch
+        self.engine.calls.append(("rollout", dict(N=N, dynamics=dynamics, guidance=guidance, noise_levels=list(noise_levels),
+                                                   keep=list(keep_positions) if keep_positions is not None else None,
+                                                   weights=self.engine.fingerprint())))
+        keep = list(range(N + 1)) if keep_positions is None else sorted(set(keep_positions))
+        shape = (B, self.C, self.h, self.w)
+        g = torch.Generator().manual_seed(5)
+        lat = torch.randn((len(keep),) + shape, generator=g).to(storage_dtype)
+        lp = torch.full((N, B), float("nan"))
+        for i, e in enumerate(noise_levels):
+            if e > 0 and compute_log_prob:
+                lp[i] = -1.0 - 0.01 * i - 0.001 * torch.arange(B)
+        return lat, lp, lat[-1].clone()
+
+    def denoise_step(self, latents, timestep, enc_a, pooled_a, enc_b, pooled_b, guidance, sigma, sigma_next, eta, sigma_max, dynamics,
+                     noise=None, next_latents=None, compute_log_prob=True, want=()):
+        B = latents.shape[0]
+        self.engine.calls.append(("denoise_step", dict(replay=next_latents is not None, weights=self.engine.fingerprint(), eta=eta)))
+        o = types.SimpleNamespace()
+        o.next_storage = latents.clone()
+        for k in ("next_latents", "next_latents_mean", "noise_pred"):
+            setattr(o, k, latents.float().clone() if k in want else None)
+        o.log_prob = torch.full((B,), -1.0) if compute_log_prob else None
+        o.std_dev_t = torch.full((B,), 0.5) if "std_dev_t" in want else None
+        o.dt = torch.full((B,), -0.1) if "dt" in want else None
+        return o
+
+
+class FakeEngine:
+    _ABI, _WHAT = "engine", "transformer"
+    """Stands in for mi355_flow.engine.Engine: same Python surface, keeps the bound tensors (fp32 copies) for inspection."""
+
+    def __init__(self, cfg):
+        from mi355_flow.weights import expected_shapes
+        self.cfg = cfg
+        self._names = list(expected_shapes(cfg).keys())
+        self.bound: Dict[str, torch.Tensor] = {}
+        self.bind_log: List[str] = []
+        self.calls: List[tuple] = []
+        self._plans = {}
+
+    def param_names(self):
+        return self._names
+
+    def bind_tensor(self, name, t):
+        assert name in self._names, name
+        self.bound[name] = t.detach().float().clone()
+        self.bind_log.append(name)
+
+    def finish_binding(self):
+        pass
+
+    def bind_state_dict(self, sd, partial=False, strict=None):
+        from mi355_flow.engine import WeightHolder
+        WeightHolder.bind_state_dict(self, sd, partial=partial, strict=strict)
+
+    def ready(self):
+        missing = [n for n in self._names if n not in self.bound]
+        if missing:
+            raise RuntimeError(f"parameter '{missing[0]}' has not been bound")
+
+    def fingerprint(self) -> float:
+        return float(sum(float(v.double().sum()) for v in self.bound.values()))
+
+    def plan(self, batch, n_cfg, h, w, n_text, max_steps):
+        key = (batch, n_cfg, h, w, n_text)
+        p = self._plans.get(key)
+        if p is None or p.max_steps < max_steps:
+            p = self._plans[key] = FakePlan(self, key, max_steps)
+        return p
+
+    def close(self):
+        pass
+
+
+class FakeVAEDecoder:
+    def __init__(self, cfg=None):
+        self.n = 0
+
+    def bind_state_dict(self, sd, **k):
+        pass
+
+    def ready(self):
+        pass
+
+    def decode(self, latents, postprocess=True, out_dtype=torch.bfloat16, max_batch=4):
+        self.n += 1
+        B, _, h, w = latents.shape
+        return torch.full((B, 3, 8 * h, 8 * w), 0.5, dtype=out_dtype)
+
+
+# --------------------------------------------------------------------------------------- pipeline / accelerator doubles
+class FakeAccelerator:
+    def __init__(self):
+        self.device = torch.device("cpu")
+        self.is_main_process = True
+        self.process_index, self.num_processes = 0, 1
+        self.sync_gradients = True
+        self.state = types.SimpleNamespace(deepspeed_plugin=None, fsdp_plugin=None)
+        self.distributed_type = "NO"
+
+    def unwrap_model(self, m, **k):
+        return m
+
+    def prepare(self, *mods):
+        return mods if len(mods) != 1 else mods[0]
+
+
+def make_pipeline(cfg, transformer: nn.Module):
+    """A "pseudo-pipeline" (reference guidance/new_model.md:574-718): a plain object exposing flat component attributes."""
+    from oracle import diffusers_stub as D
+
+    tc = types.SimpleNamespace(
+        in_channels=cfg.in_channels, out_channels=cfg.out_channels, patch_size=cfg.patch_size, num_layers=cfg.num_layers,
+        num_attention_heads=cfg.num_heads, attention_head_dim=cfg.head_dim, joint_attention_dim=cfg.joint_attention_dim,
+        pooled_projection_dim=cfg.pooled_projection_dim, pos_embed_max_size=cfg.pos_embed_max_size,
+        dual_attention_layers=tuple(cfg.dual_layers))
+    transformer.config = tc
+    vae = nn.Module()
+    vae.add_module("decoder", nn.Linear(2, 2))
+    vae.config = types.SimpleNamespace(scaling_factor=1.5305, shift_factor=0.0609, latent_channels=16, block_out_channels=(128, 256, 512, 512),
+                                       layers_per_block=2, norm_num_groups=32, out_channels=3)
+    pipe = types.SimpleNamespace()
+    pipe.transformer = transformer
+    pipe.vae = vae
+    pipe.text_encoder = nn.Linear(2, 2)
+    pipe.tokenizer = object()
+    pipe.tokenizer_3 = object()
+    pipe.scheduler = D.FlowMatchEulerDiscreteScheduler(num_train_timesteps=1000, shift=3.0, use_dynamic_shifting=False)
+    pipe.image_processor = types.SimpleNamespace(postprocess=lambda x, output_type="pt": x)
+    pipe.maybe_free_model_hooks = lambda: None
+    pipe.components = {"transformer": transformer, "vae": vae, "text_encoder": pipe.text_encoder}
+    return pipe

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mi355_flow.h but not exported"
     assert sorted(_lib.SIGNATURES) == names  # the ctypes table binds exactly the declared ABI
-    assert lib.mi355_version() == 1
+    assert lib.mi355_version() == 2
 
 
 def test_error_convention_without_gpu():

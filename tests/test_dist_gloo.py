@@ -58,3 +58,27 @@ def test_two_rank_advantages_and_partition(tmp_path):
     owned = [set(x["owned"].tolist()) for x in r]
     assert not (owned[0] & owned[1]) and len(owned[0]) == len(owned[1]) == 8
     assert all(float(x["tmax"][0]) == 2.0 for x in r)
+
+
+def test_bench_self_launches_n_ranks_and_aggregates():
+    """`python bench.py --gpus 2` typed by hand re-executes itself under torch.distributed.run.  GPU-less check of
+    the launcher path: gloo rendezvous on 127.0.0.1, barrier-bracketed timing, MAX over ranks, per-rank gather, ONE JSON line from
+    rank 0 -- with the rollout replaced by a sleep (`--dry-run`; the engine itself is covered by the -m gpu tests)."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--dry-run",
+                        "--batch", "4", "--denoise-steps", "10"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                      # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["data"] == "dry-run" and j["scaling"] == "weak"
+    assert j["world"]["world_size"] == 2 and len(j["world"]["per_rank_denoise_steps_per_s"]) == 2
+    wall = j["ms_per_step"] * 1e-3 * 2
+    assert wall >= 0.05 * 2 * 2 * 0.99                    # the slow rank (2 x 0.1 s) bounds the job: MAX over ranks
+    assert abs(j["value"] - 4 * 10 * 2 * 2 / wall) < 0.02 * j["value"]      # whole-job aggregate over both ranks

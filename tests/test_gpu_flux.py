@@ -204,3 +204,27 @@ def test_flux_stepwise_callbacks_equal_fused_rollout(fx):
         assert torch.equal(sa.all_latents, sb.all_latents) and torch.equal(sa.log_probs, sb.log_probs)
         assert sb.extra_kwargs["noise_pred"].shape[0] == 4 and sb.extra_kwargs["noise_pred"].shape[1:] == sa.all_latents.shape[1:]
     ad.engine.close()
+
+
+def test_flux_full_width_blocks_at_1024_token_count(fx):
+    """BASELINE.json configs[2] token count: FLUX.1-dev width, one double-stream + one single-stream block at 1024^2
+    (4096 image + 512 text = 4608 joint tokens), B = 1, vs the fp32 oracle (model body unpinned, oracle/flux_ref.py)."""
+    from oracle import flux_ref as R
+    cfg_o = R.FluxConfig(num_layers=1, num_single_layers=1)
+    sd = {k: _bf(v) for k, v in R.make_synthetic_state_dict(cfg_o, seed=11, std=0.02).items()}
+    eng = fx.FluxEngine(fx.FluxConfig(num_layers=1, num_single_layers=1))
+    eng.bind_state_dict({k: v.cuda() for k, v in sd.items()})
+    eng.ready()
+    B, h, w, Nt = 1, 128, 128, 512
+    g = torch.Generator().manual_seed(17)
+    x = R.pack_latents(torch.randn(B, 16, h, w, generator=g)).half()
+    enc = _bf(torch.randn(B, Nt, 4096, generator=g))
+    pool = _bf(torch.randn(B, 768, generator=g))
+    tm, gm = torch.tensor([640.0]), torch.full((B,), 3500.0)
+    got = eng.plan(B, h, w, Nt, 1).transformer_forward(x.cuda(), tm, gm, enc.cuda(), pool.cuda()).float().cpu()
+    with torch.no_grad():
+        ref = R.flux_forward(sd, cfg_o, x.float(), tm, gm, pool, enc, R.prepare_img_ids(h // 2, w // 2), premultiplied=True)
+    rel = ((got - ref).norm() / ref.norm()).item()
+    print(f"FLUX full-width 1+1 blocks, S = 4608: rel-L2 {rel:.3e}")
+    assert rel < 2e-2, rel
+    eng.close()

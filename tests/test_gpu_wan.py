@@ -133,3 +133,28 @@ def test_wan_stepwise_callbacks_equal_fused_rollout(wn):
         assert torch.equal(sa.all_latents, sb.all_latents) and torch.equal(sa.log_probs, sb.log_probs)
         assert sb.extra_kwargs["noise_pred"].shape == (4,) + tuple(sa.all_latents.shape[1:])
     ad.engine.close()
+
+
+def test_wan_full_width_blocks_at_4608_tokens(wn):
+    """Wan2.1-T2V-1.3B WIDTH (D = 1536, 12 heads x 128, ffn 8960, T5 width 4096) with 2 blocks on a 4 x 48 x 96 latent grid
+    (4 * 24 * 48 = 4608 video tokens: large-grid GEMMs, 8-wave attention128 with S_kv != S for the cross-attention), B = 1,
+    CFG on (forward batch 2), vs the fp32 oracle (model body unpinned, oracle/wan_ref.py)."""
+    from oracle import wan_ref as R
+    cfg_o = R.WanConfig(num_layers=2)
+    sd, cfg = _setup(wn, cfg_o, seed=77)
+    eng = wn.WanEngine(cfg)
+    eng.bind_state_dict({k: v.cuda() for k, v in sd.items()})
+    eng.ready()
+    B, T, h, w, Nt = 1, 4, 48, 96, 226
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 16, T, h, w, generator=g).half()
+    pe = _bf(torch.randn(B, Nt, cfg_o.text_dim, generator=g))
+    ne = _bf(torch.randn(B, Nt, cfg_o.text_dim, generator=g))
+    t = torch.tensor([601.0])
+    got = eng.plan(B, 2, T, h, w, Nt, 1).transformer_forward(x.cuda(), t, ne.cuda(), pe.cuda()).float().cpu()
+    with torch.no_grad():
+        ref = torch.cat([R.wan_forward(sd, cfg_o, x.float(), t.expand(B), ne), R.wan_forward(sd, cfg_o, x.float(), t.expand(B), pe)])
+    rel = ((got - ref).norm() / ref.norm()).item()
+    print(f"Wan full-width 2 blocks, S = 4608: rel-L2 {rel:.3e}")
+    assert rel < 2e-2, rel
+    eng.close()

@@ -1,0 +1,297 @@
+"""CPU test of the Flow-Factory plugin binding (`mi355_flow.flow_factory_plugin`) against the REFERENCE's own classes.
+
+The reference package is imported whole from /root/reference/src under `oracle/ref_package.py` (auto-stubs for the absent
+diffusers / peft / deepspeed; test infrastructure only) and the plugin classes are constructed exactly as Flow-Factory does --
+`cls(config, accelerator)` with the reference's own example YAML -- on top of a pseudo-pipeline with HF-named parameters; the
+engine is replaced by a recording double at the Python boundary (the real one needs a GPU; its parity is tests/test_gpu_*).
+Checked: signatures (the kwargs-filter ABI), attribute surface, reference sample classes + `BaseSample.stack`, group ids,
+weight liveness across optimizer steps / `use_ref_parameters` / LoRA `disable_adapter`, fail-fast on foreign state-dict keys.
+/root/reference does not exist on the GPU box: everything here skips there.
+"""
+import inspect
+import types
+
+import pytest
+import torch
+
+from oracle import ref_package
+
+pytestmark = pytest.mark.skipif(not ref_package.available(), reason="needs /root/reference (build container only)")
+
+import _plugin_fakes as F  # noqa: E402
+
+YAML_FULL = "/root/reference/examples/grpo/full/sd3_5/default.yaml"
+YAML_LORA = "/root/reference/examples/grpo/lora/sd3_5/nocfg.yaml"
+
+
+@pytest.fixture(scope="module")
+def ref():
+    ref_package.install()
+    import mi355_flow.flow_factory_plugin as P
+    if P._RefAdapter is None:      # imported earlier in this process without the reference on sys.path
+        import importlib
+        P = importlib.reload(P)
+    assert P._RefAdapter is not None, P._IMPORT_ERROR
+    P.Engine, P.VAEDecoder = F.FakeEngine, F.FakeVAEDecoder
+    P.VAEConfig = types.SimpleNamespace(from_hf=lambda c: c)
+    return P
+
+
+def _tiny_cfg():
+    from mi355_flow.engine import TransformerConfig
+    return TransformerConfig(num_layers=3, num_heads=2, joint_attention_dim=128, pooled_projection_dim=128, pos_embed_max_size=24,
+                             dual_layers=(0, 1))
+
+
+def _make(P, yaml, kl_beta=0.0, lora=False):
+    from flow_factory.hparams import Arguments
+    from mi355_flow.weights import expected_shapes
+    cfg = Arguments.load_from_yaml(yaml)
+    cfg.training_args.kl_beta = kl_beta
+    if lora:
+        cfg.model_args.finetune_type = "full"      # peft itself is absent: the LoRA wrapping is done by hand below
+    tcfg = _tiny_cfg()
+    tr = F.build_module_tree(expected_shapes(tcfg), cls=F.FakeTransformer)
+
+    class Plug(P.SD3_5NativeAdapter):
+        def load_pipeline(self):
+            return F.make_pipeline(tcfg, tr)
+
+    ad = Plug(cfg, F.FakeAccelerator())
+    ad.post_init()
+    return ad, cfg, tr
+
+
+def _embeds(B=2, Nt=13, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return dict(prompt_embeds=torch.randn(B, Nt, 128, generator=g), pooled_prompt_embeds=torch.randn(B, 128, generator=g),
+                negative_prompt_embeds=torch.randn(B, Nt, 128, generator=g), negative_pooled_prompt_embeds=torch.randn(B, 128, generator=g))
+
+
+# ------------------------------------------------------------------------------------------------- the kwargs-filter ABI
+def _params(fn):
+    return [(k, p.default) for k, p in inspect.signature(fn).parameters.items() if k != "self"]
+
+
+def test_signatures_equal_the_references(ref):
+    """`filter_kwargs(inspect.signature)` (utils/base.py:38-63; trainers/grpo.py:165,252) makes parameter names the ABI: same names,
+    same order, same defaults; no `**kwargs` catch-all (it would let the trainer's whole training_args dict through)."""
+    from flow_factory.models.flux.flux1 import Flux1Adapter
+    from flow_factory.models.stable_diffusion.sd3_5 import SD3_5Adapter
+    from flow_factory.models.wan.wan2_t2v import Wan2_T2V_Adapter
+    pairs = [(ref.SD3_5NativeAdapter, SD3_5Adapter), (ref.Flux1NativeAdapter, Flux1Adapter), (ref.Wan2T2VNativeAdapter, Wan2_T2V_Adapter)]
+    for ours, theirs in pairs:
+        for meth in ("inference", "forward"):
+            a, b = _params(getattr(ours, meth)), _params(getattr(theirs, meth))
+            # trailing optional extensions are allowed (FLUX forward: height / width to recover a non-square packed grid)
+            assert [k for k, _ in a][:len(b)] == [k for k, _ in b], (ours.__name__, meth)
+            assert all(d is not inspect.Parameter.empty for _, d in a[len(b):]), (ours.__name__, meth)
+            for (k, da), (_, db) in zip(a, b):
+                if db is inspect.Parameter.empty:
+                    continue          # a required reference parameter may carry a default here (superset)
+                assert da == db, (ours.__name__, meth, k, da, db)
+            kinds = {p.kind for p in inspect.signature(getattr(ours, meth)).parameters.values()}
+            assert inspect.Parameter.VAR_KEYWORD not in kinds and inspect.Parameter.VAR_POSITIONAL not in kinds
+
+
+def test_mixins_touch_only_public_scheduler_api(ref):
+    """Every scheduler attribute the rollout mixins read exists on the reference's own scheduler classes."""
+    from flow_factory.scheduler import FlowMatchEulerDiscreteSDEScheduler, UniPCMultistepSDEScheduler
+    import re
+    import mi355_flow.adapter as A, mi355_flow.flux as FX, mi355_flow.wan as W, mi355_flow.scheduler as S
+    used = set()
+    for mod, names in ((A, ["NativeRolloutMixin"]), (FX, ["FluxRolloutMixin"]), (W, ["WanRolloutMixin"])):
+        for n in names:
+            used |= set(re.findall(r"(?:self\.scheduler|sched|scheduler)\.([a-zA-Z_]+)", inspect.getsource(getattr(mod, n))))
+    used |= set(re.findall(r"scheduler\.([a-zA-Z_]+)", inspect.getsource(S.host_noise_levels)))
+    used -= {"py", "abc"}
+    assert {"dynamics_type", "sigmas", "is_eval"} <= used
+    for cls in (FlowMatchEulerDiscreteSDEScheduler, UniPCMultistepSDEScheduler):
+        # instance attributes (set in __init__ / set_timesteps) and members inherited from the diffusers base scheduler
+        # (FlowMatchEulerDiscreteScheduler / UniPCMultistepScheduler: a placeholder class in this container)
+        inst_attrs = {"timesteps", "sigmas", "noise_level", "dynamics_type", "seed", "config", "index_for_timestep", "set_timesteps"}
+        for attr in used:
+            assert hasattr(cls, attr) or attr in inst_attrs, (cls.__name__, attr)
+
+
+def test_host_noise_levels_on_the_reference_scheduler(ref):
+    from flow_factory.scheduler import FlowMatchEulerDiscreteSDEScheduler, set_scheduler_timesteps
+    from mi355_flow.scheduler import host_noise_levels
+    for seed in (1, 42, 77):
+        s = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[1, 2, 3, 5], num_sde_steps=2, seed=seed, shift=3.0)
+        set_scheduler_timesteps(s, 8, seq_len=256)
+        assert host_noise_levels(s, 8) == pytest.approx(s.get_noise_levels().tolist())
+        assert [host_noise_levels(s, 8)[i] for i in range(8)] == [float(s.get_noise_level_for_timestep(t)) for t in s.timesteps]
+        s.eval()
+        assert host_noise_levels(s, 8) == [0.0] * 8
+    s = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, dynamics_type="ODE", shift=3.0)
+    set_scheduler_timesteps(s, 4, seq_len=256)
+    assert host_noise_levels(s, 4) == [0.0] * 4
+
+
+# ------------------------------------------------------------------------------------------------- rollout through the plugin
+def test_rollout_returns_reference_samples_that_stack(ref):
+    from flow_factory.models.stable_diffusion.sd3_5 import SD3_5Sample as RefSample
+    from flow_factory.samples import BaseSample
+    from flow_factory.utils.base import filter_kwargs
+    from flow_factory.utils.trajectory_collector import compute_trajectory_indices
+    ad, cfg, tr = _make(ref, YAML_FULL)
+    assert type(ad.scheduler).__module__.startswith("flow_factory.")        # the reference's own scheduler object
+    ad.scheduler.set_seed(0 + cfg.training_args.seed)
+    ad.rollout()
+    N = cfg.training_args.num_inference_steps
+    traj = compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N)
+    B = 2
+    batch = dict(prompt=["a cat", "a dog"], prompt_ids=torch.arange(B * 5).reshape(B, 5), **_embeds(B),
+                 negative_prompt=["", ""], negative_prompt_ids=torch.zeros(B, 5, dtype=torch.long), some_dataset_column=[1, 2])
+    # exactly what GRPOTrainer.sample does (trainers/grpo.py:159-166): the whole training_args mapping + the batch, filtered by signature
+    kw = filter_kwargs(ad.inference, **{**cfg.training_args, "compute_log_prob": True, "trajectory_indices": traj, **batch})
+    assert "some_dataset_column" not in kw and "clip_range" not in kw and kw["num_inference_steps"] == N
+    samples = ad.inference(**kw)
+    assert F.FakeTransformer.calls == 0
+    kind, call = ad.engine.calls[-1]
+    assert kind == "rollout" and call["N"] == N and call["dynamics"] == "Flow-SDE"
+    sde = sorted(int(i) for i in ad.scheduler.current_sde_steps.tolist())
+    assert [i for i, e in enumerate(call["noise_levels"]) if e > 0] == sde and call["keep"] == sorted(traj)
+    assert len(samples) == B and all(type(s) is RefSample for s in samples)
+    s0 = samples[0]
+    assert s0.all_latents.shape[0] == len(traj) and s0.all_latents.dtype == torch.float16        # latent_storage_dtype default
+    assert s0.image.shape == (3, cfg.training_args.resolution[0], cfg.training_args.resolution[1]) if isinstance(cfg.training_args.resolution, (list, tuple)) else True
+    stacked = BaseSample.stack(samples)                                                             # optimize(): trainers/grpo.py:215
+    assert stacked["all_latents"].shape[:2] == (B, len(traj)) and stacked["log_probs"].shape == (B, len(sde))
+    assert stacked["latent_index_map"].shape == (N + 1,) and stacked["timesteps"].shape == (B, N)
+    lm = stacked["latent_index_map"]
+    for t_idx in sde:                                        # the positions optimize() reads exist (grpo.py:229-247)
+        assert lm[t_idx] >= 0 and lm[t_idx + 1] >= 0 and stacked["log_prob_index_map"][t_idx] >= 0
+    assert samples[0].unique_id != samples[1].unique_id
+
+    # the standalone mirror classes give the same ids and the same stacked layout
+    from mi355_flow import samples as MS
+    mirrors = [MS.SD3_5Sample(**{f.name: getattr(s, f.name) for f in __import__("dataclasses").fields(MS.SD3_5Sample)
+                                 if f.name not in ("_unique_id",) and hasattr(s, f.name)}) for s in samples]
+    assert [m.unique_id for m in mirrors] == [s.unique_id for s in samples]
+    ms = MS.BaseSample.stack(mirrors)
+    assert set(ms) == set(stacked)
+    for k, v in stacked.items():
+        if isinstance(v, torch.Tensor):
+            assert torch.equal(ms[k], v), k
+
+
+def test_unique_id_matches_reference_for_ids_only_and_negative_prompts(ref):
+    from flow_factory.models.stable_diffusion.sd3_5 import SD3_5Sample as RefSample
+    from mi355_flow.samples import SD3_5Sample
+    cases = [dict(prompt="x"), dict(prompt_ids=torch.tensor([3, 1, 4])), dict(prompt="x", negative_prompt="bad"),
+             dict(prompt_ids=torch.tensor([3, 1, 4]), negative_prompt_ids=torch.tensor([9, 9])), dict()]
+    for c in cases:
+        assert SD3_5Sample(**c).unique_id == RefSample(**c).unique_id, c
+    s = SD3_5Sample(prompt="x")
+    before = s.unique_id
+    s.prompt = "y"                       # id fields reset the cache (samples.py:204-209)
+    assert s.unique_id != before and s.unique_id == RefSample(prompt="y").unique_id
+
+
+# ------------------------------------------------------------------------------------------------- weight liveness
+def test_weights_follow_optimizer_steps_and_reference_swaps(ref):
+    """the no-grad forward inside optimize() -- the KL reference forward under `use_ref_parameters()`
+    (trainers/grpo.py:281-292) -- must see the CURRENT / REFERENCE weights, not the ones packed at rollout time."""
+    ad, cfg, tr = _make(ref, YAML_FULL, kl_beta=0.01)
+    assert ad._ref_ema is not None
+    eng = ad.engine
+    ad.rollout()
+    e = _embeds()
+    fwd = dict(t=torch.tensor([900.0, 900.0]), t_next=torch.tensor([750.0, 750.0]), latents=torch.zeros(2, 16, 16, 16, dtype=torch.float16),
+               next_latents=torch.zeros(2, 16, 16, 16, dtype=torch.float16), noise_level=0.7, compute_log_prob=True,
+               guidance_scale=1.0, return_kwargs=["log_prob", "dt"], prompt_embeds=e["prompt_embeds"],
+               pooled_prompt_embeds=e["pooled_prompt_embeds"])
+    with torch.no_grad():
+        ad.scheduler.set_timesteps(10)
+        ad.forward(**fwd)
+    n_all = len(eng.param_names())
+    assert len(eng.bind_log) == n_all                      # first use binds everything
+    w0 = eng.calls[-1][1]["weights"]
+    # (1) nothing changed -> nothing re-bound
+    with torch.no_grad():
+        ad.forward(**fwd)
+    assert len(eng.bind_log) == n_all and eng.calls[-1][1]["weights"] == w0
+    # (2) an optimizer step (in-place update under no_grad, bumps the version counters of the trainable tensors only)
+    ad.train()
+    trainable = ad.get_trainable_parameters()
+    opt = torch.optim.SGD(trainable, lr=0.5)
+    for p in trainable:
+        p.grad = torch.ones_like(p)
+    opt.step()
+    before = len(eng.bind_log)
+    with torch.no_grad():
+        ad.forward(**fwd)
+    rebound = eng.bind_log[before:]
+    assert sorted(rebound) == sorted(n for n, p in tr.named_parameters() if p.requires_grad) and len(rebound) == len(trainable) < n_all
+    w1 = eng.calls[-1][1]["weights"]
+    assert w1 != w0
+    name = "transformer_blocks.0.attn.to_q.weight"
+    assert torch.allclose(eng.bound[name], tr.get_submodule("transformer_blocks.0.attn.to_q").weight.detach().float())
+    # (3) the KL reference forward: under use_ref_parameters() the engine sees the ORIGINAL weights, afterwards the current ones again
+    with torch.no_grad(), ad.use_ref_parameters():
+        ad.forward(**{**fwd, "compute_log_prob": False, "return_kwargs": ["noise_pred"]})
+    assert eng.calls[-1][1]["weights"] == pytest.approx(w0, rel=1e-9)
+    with torch.no_grad():
+        ad.forward(**fwd)
+    assert eng.calls[-1][1]["weights"] == pytest.approx(w1, rel=1e-9)
+    assert F.FakeTransformer.calls == 0
+
+
+def test_lora_deltas_are_merged_and_dropped_under_disable_adapter(ref):
+    """peft-wrapped transformers bind `W + scaling * B @ A` per target module; `disable_adapter()` (the LoRA
+    branch of use_ref_parameters, models/abc.py:560-583) binds the bare base weight; raw peft state dicts are rejected loudly."""
+    ad, cfg, tr = _make(ref, YAML_LORA, lora=True)
+    wrapped = F.wrap_lora(tr)
+    assert len(wrapped) == 3 * 4 + 2 * 4          # attn of 3 blocks + attn2 of the 2 dual blocks
+    peft = F.FakePeftModel(tr)
+    ad.set_component("transformer", peft)
+    eng = ad.engine
+    ad._live_weights.invalidate()
+    ad._sync_weights()
+    lay = tr.get_submodule("transformer_blocks.1.attn.to_k")
+    base = lay.base_layer.weight.detach().float()
+    delta = lay.scaling["default"] * (lay.lora_B["default"].weight.detach().float() @ lay.lora_A["default"].weight.detach().float())
+    name = "transformer_blocks.1.attn.to_k.weight"
+    assert torch.allclose(eng.bound[name], base + delta, atol=1e-6) and float(delta.abs().max()) > 1e-3
+    assert torch.allclose(eng.bound["transformer_blocks.1.attn.to_k.bias"], lay.base_layer.bias.detach().float())
+    assert torch.allclose(eng.bound["transformer_blocks.1.ff.net.0.proj.weight"], tr.get_submodule("transformer_blocks.1.ff.net.0.proj").weight.detach().float())
+    # LoRA training step: only A / B change -> only the wrapped weights re-bind
+    with torch.no_grad():
+        lay.lora_B["default"].weight.add_(0.25)
+    before = len(eng.bind_log)
+    ad._sync_weights()
+    assert eng.bind_log[before:] == [name]
+    # the `scale` of joint_attention_kwargs (diffusers scale_lora_layers) multiplies the deltas
+    ad._check_joint_attention_kwargs({"scale": 0.5})
+    ad._sync_weights()
+    delta2 = lay.scaling["default"] * (lay.lora_B["default"].weight.detach().float() @ lay.lora_A["default"].weight.detach().float())
+    assert torch.allclose(eng.bound[name], base + 0.5 * delta2, atol=1e-6)
+    ad._check_joint_attention_kwargs(None)
+    with pytest.raises(NotImplementedError, match="ip_adapter"):
+        ad._check_joint_attention_kwargs({"ip_adapter_image_embeds": 1})
+    # reference policy = adapters disabled
+    with peft.disable_adapter():
+        ad._sync_weights()
+        assert torch.allclose(eng.bound[name], base)
+    ad._sync_weights()
+    assert torch.allclose(eng.bound[name], base + delta2, atol=1e-6)
+    # a raw peft state dict has foreign keys: binding it directly must raise, never leave stale weights behind
+    sd = peft.state_dict()
+    assert any("base_layer" in k for k in sd)
+    with pytest.raises(KeyError, match="lacks"):
+        eng.bind_state_dict(sd)
+    with pytest.raises(KeyError, match="lacks"):
+        eng.bind_state_dict({k.replace("base_model.model.", ""): v for k, v in sd.items()})
+
+
+def test_missing_parameters_fail_fast(ref):
+    from mi355_flow.binding import LiveWeights
+    from mi355_flow.weights import expected_shapes
+    tcfg = _tiny_cfg()
+    shapes = dict(expected_shapes(tcfg))
+    shapes.pop("transformer_blocks.2.attn.to_v.bias")
+    tr = F.build_module_tree(shapes)
+    with pytest.raises(KeyError, match="to_v.bias"):
+        LiveWeights(F.FakeEngine(tcfg), lambda: tr).sync()
