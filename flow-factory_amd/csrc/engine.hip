@@ -342,6 +342,8 @@ struct mi355_plan {
     std::vector<float> host_t, host_sc;
     // hipGraph of the whole N-step loop
     hipGraphExec_t gexec = nullptr;
+    hipStream_t cap_stream = nullptr;   // capture happens on a plan-owned stream: the caller's may be the legacy default stream (torch's
+                                        // current stream unless the user switched), which cannot be captured; the graph is LAUNCHED on the caller's
     bool warmed = false;
     int g_steps = -1, g_dyn = -1, g_storage = -1, g_init = -1, g_clp = -1, g_attn = -1, g_gemm = -1, g_bounds = -1;
     float g_guidance = 0.f, g_sigma_max = 0.f;
@@ -426,6 +428,7 @@ extern "C" int mi355_plan_create(mi355_engine* e, int batch, int n_cfg, int late
 extern "C" int mi355_plan_destroy(mi355_plan* p) {
     if (!p) return 0;
     if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
+    if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     if (p->ws) (void)hipFree(p->ws);
     delete p;
     return 0;
@@ -779,10 +782,13 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
         if (!same) {
             if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
             hipGraph_t graph = nullptr;
-            hipError_t ce = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+            hipError_t ce = hipSuccess;
+            if (!p->cap_stream) ce = hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking);
+            if (ce == hipSuccess) ce = hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed);
             if (ce == hipSuccess) {
-                const int rc = rollout_body(p, st, n_steps, dynamics, guidance, init_dtype, storage_dtype, sigma_max, clp);
-                ce = hipStreamEndCapture(st, &graph);
+                // nothing executes here: the body's launches / D2D copies on plan-owned buffers become graph nodes
+                const int rc = rollout_body(p, p->cap_stream, n_steps, dynamics, guidance, init_dtype, storage_dtype, sigma_max, clp);
+                ce = hipStreamEndCapture(p->cap_stream, &graph);
                 if (rc != 0 || ce != hipSuccess || !graph) {
                     if (graph) (void)hipGraphDestroy(graph);
                     graph = nullptr;
