@@ -57,8 +57,7 @@ def cpu_baseline(budget_s=150.0):
     `budget_s` is the 1024^2 figure extrapolated (and labelled so) instead of measured."""
     from oracle import mmditx_ref as M
     cfg = M.SD35_MEDIUM
-    torch.set_num_threads(os.cpu_count() or 1)
-    cores = torch.get_num_threads()
+    cores = torch.get_num_threads()      # torch's default = the physical cores (one thread per SMT sibling is 40x SLOWER here: measured)
     # timing only: draw the 2.5 B fp32 weights on the GPU and copy them down (the CPU generator needs ~1 min)
     from mi355_flow.engine import TransformerConfig
     from mi355_flow.weights import synthetic_state_dict

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
     f32x16 o[2];
     o[0] = (f32x16){0}; o[1] = (f32x16){0};
     float l_run = 0.f;
+    float m_fin = 0.f;          // running max at the end of the key loop, log2 domain (for the optional log-sum-exp output)
     const int nt = (p.S + KV - 1) / KV;
     stage(0, 0);
     if constexpr (!V2) {
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
             }
         }
     }
+    m_fin = m_run * SCALE_LOG2E;
 
     } else {
     // ---- deferred-rescale online softmax.  q carries 0.125*log2(e); the running max m (log2 domain) enters the
@@ -301,11 +303,14 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
             }
         }
     }
+    m_fin = m_run;
     }
 
     // ---- finalize: 1/l (both half-wave partial sums), stage O through LDS for full-row stores
     l_run += __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_run;
+    // training-mode forward: L = log2 sum_j 2^(s_j) per query, so that the backward rebuilds P = 2^(s - L) without a second softmax pass
+    if (p.lse && lg == 0 && q_row < p.S) p.lse[bh * p.S_pad + q_row] = m_fin + __log2f(l_run);
     __syncthreads();  // all waves done with the K/V ring
     // wave region: 32 queries x 64 d bf16 = 4 KiB, row = query (128 B), 16-B chunk XOR-swizzled by (q&7)
     char* ob = smem + wave * 4096;

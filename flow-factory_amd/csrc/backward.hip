@@ -1,0 +1,402 @@
+// mi355_flow -- HBM-bound kernels of the MMDiT BACKWARD (the `optimize()` replay of
+// reference src/flow_factory/trainers/grpo.py:185-342 needs d loss / d weights of the transformer the rollout ran).
+// Everything here is a row / tile streaming kernel: 16-byte accesses, one wave per row where a row reduction is
+// needed, fp32 arithmetic on bf16 activations / gradients.  The matrix work of the backward (dgrad / wgrad GEMMs,
+// the two flash-attention backward passes) lives in gemm.hip / attention_bwd.hip.
+#include "kernels.h"
+
+namespace mi355 {
+namespace {
+
+__device__ __forceinline__ void unpack8(const uint4 u, float (&v)[8]) {
+    v[0] = bf_lo(u.x); v[1] = bf_hi(u.x); v[2] = bf_lo(u.y); v[3] = bf_hi(u.y);
+    v[4] = bf_lo(u.z); v[5] = bf_hi(u.z); v[6] = bf_lo(u.w); v[7] = bf_hi(u.w);
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+    return make_uint4(pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7]));
+}
+
+// ------------------------------------------------------------------ LayerNorm + AdaLN-modulate backward
+// forward (ln_mod_kernel):  xn = LN(x) * (1 + scale[b]) + shift[b]   [, xn2 = LN(x) * (1 + scale2[b]) + shift2[b]]
+// backward w.r.t. x:        g  = dxn * (1 + scale) [+ dxn2 * (1 + scale2)]
+//                           dx = rstd * (g - mean(g) - xhat * mean(g * xhat))          (no affine LN weight)
+// dx is ADDED to dres (the residual-stream gradient arriving from later layers) when accumulate != 0.
+template <int LN_MAXC>
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(LnModBwdParams p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const int nchunk = p.D >> 3;
+    const int b = row / p.rows_per_sample;
+    const bf16_t* mod = p.mod + (long)b * p.mod_ld;
+    float v[LN_MAXC][8], g[LN_MAXC][8];
+    float sum = 0.f;
+    const long ro = (long)row * p.D;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            unpack8(*(const uint4*)(p.x + ro + ch * 8), v[c]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += v[c][e];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)p.D;
+    float sq = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[c][e] -= mean; sq += v[c][e] * v[c][e]; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            float d1[8], s1[8];
+            unpack8(*(const uint4*)(p.dy + ro + ch * 8), d1);
+            unpack8(*(const uint4*)(mod + p.scale_off + ch * 8), s1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[c][e] = d1[e] * (1.f + s1[e]);
+            if (p.dy2) {
+                unpack8(*(const uint4*)(p.dy2 + ro + ch * 8), d1);
+                unpack8(*(const uint4*)(mod + p.scale2_off + ch * 8), s1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[c][e] += d1[e] * (1.f + s1[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[c][e] *= rstd;                         // xhat
+                sg += g[c][e];
+                sgx += g[c][e] * v[c][e];
+            }
+        }
+    }
+    const float mg = wave_sum(sg) / (float)p.D, mgx = wave_sum(sgx) / (float)p.D;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int ch = lane + c * 64;
+        if (ch < nchunk) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rstd * (g[c][e] - mg - v[c][e] * mgx);
+            if (p.accumulate) {
+                float r[8];
+                unpack8(*(const uint4*)(p.dres + ro + ch * 8), r);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += r[e];
+            }
+            *(uint4*)(p.dres + ro + ch * 8) = pack8(o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ gated residual backward
+// forward (EPI_GATE_RES): x' = x + gate[b] * y.   dy[m][n] = gate[m / rps][n] * dx'[m][n]   (dx = dx' passes through)
+__global__ __launch_bounds__(256) void gate_mul_kernel(const bf16_t* dx, const bf16_t* gate, long gate_ld, bf16_t* dy, long M, int D, int rps) {
+    const int chunks = D >> 3;
+    const long total = M * chunks;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / chunks;
+        const int ch = (int)(i - m * chunks);
+        float a[8], gt[8];
+        unpack8(*(const uint4*)(dx + m * D + ch * 8), a);
+        unpack8(*(const uint4*)(gate + (m / rps) * gate_ld + ch * 8), gt);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] *= gt[e];
+        *(uint4*)(dy + m * D + ch * 8) = pack8(a);
+    }
+}
+
+// hid = gelu_tanh(pre): recomputes the MLP hidden activation (the A operand of the ff2 weight gradient) from the stashed pre-activation
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* pre, bf16_t* out, long n8) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        float a[8];
+        unpack8(*(const uint4*)(pre + i * 8), a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = gelu_tanh_f(a[e]);
+        *(uint4*)(out + i * 8) = pack8(a);
+    }
+}
+
+// ------------------------------------------------------------------ tile transposes (64 x 64 bf16 through LDS, +2 B row pad)
+// in: rows x cols (row stride ld_in), batch stride bs_in;  out[c][r] (row stride ld_out), rows >= `rows` up to rows_pad are written as 0
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* in, long ld_in, long bs_in, bf16_t* out, long ld_out, long bs_out,
+                                                        int rows, int cols, int rows_pad) {
+    __shared__ bf16_t tile[64][66];
+    const int tr = blockIdx.x * 64, tc = blockIdx.y * 64;
+    const bf16_t* ib = in + (long)blockIdx.z * bs_in;
+    bf16_t* ob = out + (long)blockIdx.z * bs_out;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 4 rows per pass
+#pragma unroll 4
+    for (int r = ty; r < 64; r += 4) {
+        const int gr = tr + r, gc = tc + tx;
+        tile[r][tx] = (gr < rows && gc < cols) ? ib[(long)gr * ld_in + gc] : (bf16_t)0;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int c = ty; c < 64; c += 4) {
+        const int gc = tc + c, gr = tr + tx;
+        if (gc < cols && gr < rows_pad) ob[(long)gc * ld_out + gr] = tile[tx][c];
+    }
+}
+
+// ------------------------------------------------------------------ attention backward: prologue
+// token-major o / do (image rows, then context rows, as the forward wrote o) -> per (b, h):
+//   doh [B][H][S_pad][64] = do rows, doT [B][H][64][S_pad], delta [B][H][S_pad] = sum_d do * o   (fp32)
+// one workgroup = 64 tokens of one (b, h); padded rows (s >= S) are left untouched (zero-initialised buffers)
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnBwdPrepParams p) {
+    __shared__ bf16_t tile[64][66];
+    const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int D = p.H * 64, n_ctx = p.S - p.n_img;
+    const long bh = (long)b * p.H + h;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // 4 waves x 16 tokens: lane = d
+    for (int r = w; r < 64; r += 4) {
+        const int s = s0 + r;
+        float dov = 0.f, ov = 0.f;
+        if (s < p.S) {
+            const long row = (s < p.n_img) ? ((long)b * p.n_img + s) : ((long)b * n_ctx + (s - p.n_img));
+            const bf16_t* dop = (s < p.n_img) ? p.do_img : p.do_ctx;
+            const bf16_t* op = (s < p.n_img) ? p.o_img : p.o_ctx;
+            if (dop) dov = bf2f(dop[row * D + h * 64 + lane]);      // do_ctx == nullptr: the context output is unused (last block)
+            ov = bf2f(op[row * D + h * 64 + lane]);
+            p.doh[(bh * p.S_pad + s) * 64 + lane] = f2bf(dov);
+            const float dl = wave_sum(dov * ov);
+            if (lane == 0) p.delta[bh * p.S_pad + s] = dl;
+        }
+        tile[r][lane] = f2bf(dov);
+    }
+    __syncthreads();
+    for (int d = w; d < 64; d += 4) {
+        const int s = s0 + lane;
+        if (s < p.S) p.doT[(bh * 64 + d) * p.S_pad + s] = tile[lane][d];
+    }
+}
+
+// ------------------------------------------------------------------ attention backward: epilogue
+// per-head RMSNorm backward of q, k + gather of (dq, dk, dv) [B][H][S_pad][64] into token-major rows [tokens][3D] = [dq_pre | dk_pre | dv]
+// of the image stream (s < n_img) and the context stream.  forward: y = x * r * w  (x = projection + bias, r = 1/rms over the head's 64
+// features; for q, w already carries the folded softmax scale):  xhat = y / w,  g = dy * w,  dx = r * (g - xhat * mean(g * xhat)).
+// One wave per token, lane = feature d, loop over heads.
+__global__ __launch_bounds__(256) void rms_bwd_gather_kernel(RmsBwdParams p) {
+    const int lane = threadIdx.x & 63;
+    const long tok = blockIdx.x * 4L + (threadIdx.x >> 6);     // b * S + s
+    if (tok >= (long)p.B * p.S) return;
+    const int b = (int)(tok / p.S), s = (int)(tok - (long)b * p.S);
+    const bool img = s < p.n_img;
+    const int n_ctx = p.S - p.n_img;
+    const long row = img ? ((long)b * p.n_img + s) : ((long)b * n_ctx + (s - p.n_img));
+    bf16_t* out = (img ? p.out_img : p.out_ctx) + row * (3L * p.H * 64);
+    const float* rstd = (img ? p.rstd_img : p.rstd_ctx) + row * (2L * p.H);
+    const float wq = (img ? p.nw_q : p.nw_cq)[lane] * p.q_scale, wk = (img ? p.nw_k : p.nw_ck)[lane];
+    const int D = p.H * 64;
+    for (int h = 0; h < p.H; ++h) {
+        const long src = (((long)b * p.H + h) * p.S_pad + s) * 64 + lane;
+        {
+            const float y = bf2f(p.q[src]), dy = bf2f(p.dq[src]);
+            const float xh = fabsf(wq) > 1e-20f ? y / wq : 0.f;
+            const float g = dy * wq;
+            const float mgx = wave_sum(g * xh) * (1.0f / 64.0f);
+            out[h * 64 + lane] = f2bf(rstd[h] * (g - xh * mgx));
+        }
+        {
+            const float y = bf2f(p.k[src]), dy = bf2f(p.dk[src]);
+            const float xh = fabsf(wk) > 1e-20f ? y / wk : 0.f;
+            const float g = dy * wk;
+            const float mgx = wave_sum(g * xh) * (1.0f / 64.0f);
+            out[D + h * 64 + lane] = f2bf(rstd[p.H + h] * (g - xh * mgx));
+        }
+        out[2 * D + h * 64 + lane] = p.dv[src];
+    }
+}
+
+// ------------------------------------------------------------------ bias gradient: db[n] (+)= sum_m dY[m][n]
+// grid.x = column chunks of 256 (one column per thread, coalesced rows), grid.y = row slabs; slab partials are summed in a fixed
+// order by the last-arriving workgroup-free second launch (colsum_finish): deterministic
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* dy, long ld, long M, int N, float* part, int nslab) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const long per = (M + nslab - 1) / nslab;
+    const long lo = blockIdx.y * per, hi = lo + per < M ? lo + per : M;
+    float s = 0.f;
+    for (long m = lo; m < hi; ++m) s += bf2f(dy[m * ld + n]);
+    part[(long)blockIdx.y * N + n] = s;
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* part, int nslab, int N, float* out, int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int i = 0; i < nslab; ++i) s += part[(long)i * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+// split-K second stage: out[i] (+)= sum_s part[s][i], fixed order
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, long stride, int nsplit, float* out, long n, int accumulate) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nsplit; ++k) s += part[(long)k * stride + i];
+        out[i] = accumulate ? out[i] + s : s;
+    }
+}
+
+// ------------------------------------------------------------------ proj_out backward prologue: un-patchify transposed
+// dv [B'][C][hp*p][wp*p] (fp32) -> dproj [B'*hp*wp][p*p*C] bf16, feature f = (pp*p + qq)*C + c  (the forward's EPI_UNPATCH order)
+__global__ void unpatch_bwd_kernel(const float* dv, bf16_t* out, int Bp, int C, int hp, int wp, int patch) {
+    const int NO = patch * patch * C;
+    const long total = (long)Bp * hp * wp * NO;
+    const int Himg = hp * patch, Wimg = wp * patch;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(i % NO);
+        const long tok = i / NO;
+        const int tx = (int)(tok % wp), ty = (int)((tok / wp) % hp), b = (int)(tok / ((long)wp * hp));
+        const int c = f % C, pq = f / C, pp = pq / patch, qq = pq - pp * patch;
+        out[i] = f2bf(dv[(((long)b * C + c) * Himg + ty * patch + pp) * Wimg + tx * patch + qq]);
+    }
+}
+
+// ------------------------------------------------------------------ SDE step backward (adjoint of sde_step_kernel w.r.t. the network output)
+// inputs: upstream gradients g_lp [B] (d loss / d log_prob), g_np / g_mean [B][n] fp32 (d loss / d noise_pred, d next_latents_mean; optional);
+// the step's own inputs (v_text / v_uncond bf16, x, x' = next_in) to re-evaluate x' - mean.  Output dv [n_cfg*B][n] fp32 in the forward-batch
+// order [uncond, text]:  v = vu + g (vt - vu)  =>  dvt = g dv, dvu = (1 - g) dv  (bf16 roundings of the combine are treated as identity).
+//   ODE:       mean = x + v dt                                   dmean/dv = dt,                     lp = 0
+//   Flow-SDE:  mean = x c1 + v c2 dt                             dmean/dv = c2 dt,                  lp = mean_i[-(x'-mean)^2 / (2 sv^2)] + const
+//   Dance-SDE: mean = x + (v + k (x sigma + sigma v (1-sigma)) / sigma^2) dt   dmean/dv = dt (1 + k (1-sigma)/sigma),  lp as Flow-SDE
+//   CPS:       mean = (x - sigma v) a + (x + v (1-sigma)) bq     dmean/dv = -sigma a + (1-sigma) bq,  lp = mean_i[-(x'-mean)^2]
+__global__ __launch_bounds__(256) void sde_step_bwd_kernel(SdeBwdParams p) {
+    const int b = blockIdx.y;
+    const float sigma = p.sigma[b * p.scalar_stride], sigma_next = p.sigma_next[b * p.scalar_stride];
+    float eta = p.eta[b * p.scalar_stride];
+    const int dyn = p.dynamics;
+    if (dyn == DYN_ODE) eta = 0.f;
+    const float dt = sigma_next - sigma;
+    float c1 = 1.f, dm = dt, lpk = 0.f;       // mean = x * c1x(x-part, only needed to rebuild mean) ...; dm = dmean/dv; lpk: dlp/dmean_i = lpk * (x' - mean_i)
+    float std_dev = 0.f, c2dt = dt, dance_k = 0.f, cps_a = 0.f, cps_b = 0.f;
+    const float inv_n = 1.0f / (float)p.n;
+    if (dyn == DYN_FLOW_SDE) {
+        const float sden = (sigma == 1.0f) ? p.sigma_max : sigma;
+        std_dev = sqrtf(sigma / (1.0f - sden)) * eta;
+        const float s2 = std_dev * std_dev;
+        c1 = 1.0f + s2 / (2.0f * sigma) * dt;
+        c2dt = (1.0f + s2 * (1.0f - sigma) / (2.0f * sigma)) * dt;
+        dm = c2dt;
+        const float sv = std_dev * sqrtf(-dt);
+        lpk = sv > 0.f ? 1.0f / (sv * sv) : 0.f;          // d/dmean [-(x'-mean)^2 / (2 sv^2)] = (x'-mean) / sv^2
+    } else if (dyn == DYN_DANCE_SDE) {
+        std_dev = eta;
+        dance_k = 0.5f * eta * eta;
+        dm = dt * (1.0f + dance_k * (1.0f - sigma) / sigma);
+        const float sv = std_dev * sqrtf(-dt);
+        lpk = sv > 0.f ? 1.0f / (sv * sv) : 0.f;
+    } else if (dyn == DYN_CPS) {
+        std_dev = sigma_next * sinf(eta * 1.57079632679f);
+        cps_a = 1.0f - sigma_next;
+        cps_b = sqrtf(fmaxf(sigma_next * sigma_next - std_dev * std_dev, 0.f));
+        dm = -sigma * cps_a + (1.0f - sigma) * cps_b;
+        lpk = 2.0f;                                        // d/dmean [-(x'-mean)^2] = 2 (x'-mean)
+    }
+    const float glp = (p.g_lp && p.compute_log_prob) ? p.g_lp[b] * inv_n : 0.f;
+    const long base = (long)b * p.n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < p.n; i += (long)gridDim.x * blockDim.x) {
+        const long gi = base + i;
+        float v = bf2f(p.v_text[gi]);
+        if (p.v_uncond) {
+            const float u = bf2f(p.v_uncond[gi]);
+            v = round_bf16(u + round_bf16(p.guidance * round_bf16(v - u)));
+        }
+        const float x = load_as_f32(p.latents, gi, p.lat_dt);
+        float mean;
+        if (dyn == DYN_ODE) mean = x + v * dt;
+        else if (dyn == DYN_FLOW_SDE) mean = x * c1 + v * c2dt;
+        else if (dyn == DYN_DANCE_SDE) {
+            const float x0 = x - sigma * v;
+            mean = x + (v + dance_k * (x - x0 * (1.0f - sigma)) / (sigma * sigma)) * dt;
+        } else {
+            mean = (x - sigma * v) * cps_a + (x + v * (1.0f - sigma)) * cps_b;
+        }
+        float gmean = p.g_mean ? p.g_mean[gi] : 0.f;
+        if (glp != 0.f && p.next_in) gmean += glp * lpk * (load_as_f32(p.next_in, gi, p.next_in_dt) - mean);
+        float dv = gmean * dm + (p.g_np ? p.g_np[gi] : 0.f);
+        if (p.v_uncond) {
+            p.dv[gi] = (1.0f - p.guidance) * dv;                       // uncond half first: forward batch order [negative, positive]
+            p.dv[(long)p.B * p.n + gi] = p.guidance * dv;
+        } else {
+            p.dv[gi] = dv;
+        }
+    }
+}
+
+inline int grid_for(long total, int block) {
+    long g = (total + block - 1) / block;
+    return (int)(g > 16384 ? 16384 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+hipError_t launch_ln_mod_bwd(const LnModBwdParams& p, hipStream_t st) {
+    if (p.D % 8 != 0 || p.D > 8 * 64 * 8 || p.M <= 0) return hipErrorInvalidValue;
+    if (p.D <= 2048) hipLaunchKernelGGL(ln_mod_bwd_kernel<4>, dim3((p.M + 3) / 4), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(ln_mod_bwd_kernel<8>, dim3((p.M + 3) / 4), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_gate_mul(const bf16_t* dx, const bf16_t* gate, long gate_ld, bf16_t* dy, long M, int D, int rps, hipStream_t st) {
+    if (D % 8 || M <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gate_mul_kernel, dim3(grid_for(M * (D >> 3), 256)), dim3(256), 0, st, dx, gate, gate_ld, dy, M, D, rps);
+    return hipGetLastError();
+}
+
+hipError_t launch_gelu_fwd(const bf16_t* pre, bf16_t* out, long n, hipStream_t st) {
+    if (n % 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n >> 3, 256)), dim3(256), 0, st, pre, out, n >> 3);
+    return hipGetLastError();
+}
+
+hipError_t launch_transpose(const bf16_t* in, long ld_in, long bs_in, bf16_t* out, long ld_out, long bs_out, int rows, int cols, int rows_pad,
+                            int batch, hipStream_t st) {
+    if (rows <= 0 || cols <= 0 || batch <= 0 || rows_pad < rows) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(transpose_kernel, dim3((rows_pad + 63) / 64, (cols + 63) / 64, batch), dim3(256), 0, st, in, ld_in, bs_in, out, ld_out,
+                       bs_out, rows, cols, rows_pad);
+    return hipGetLastError();
+}
+
+hipError_t launch_attn_bwd_prep(const AttnBwdPrepParams& p, hipStream_t st) {
+    hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((p.S + 63) / 64, p.H, p.B), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_rms_bwd_gather(const RmsBwdParams& p, hipStream_t st) {
+    const long tokens = (long)p.B * p.S;
+    hipLaunchKernelGGL(rms_bwd_gather_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_colsum(const bf16_t* dy, long ld, long M, int N, float* scratch, float* out, int accumulate, hipStream_t st) {
+    const int nslab = (int)(M >= 4096 ? 64 : (M + 63) / 64);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, nslab), dim3(256), 0, st, dy, ld, M, N, scratch, nslab);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, st, scratch, nslab, N, out, accumulate);
+    return hipGetLastError();
+}
+
+hipError_t launch_splitk_reduce(const float* part, long stride, int nsplit, float* out, long n, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, part, stride, nsplit, out, n, accumulate);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpatch_bwd(const float* dv, bf16_t* out, int Bp, int C, int hp, int wp, int patch, hipStream_t st) {
+    const long total = (long)Bp * hp * wp * patch * patch * C;
+    hipLaunchKernelGGL(unpatch_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, dv, out, Bp, C, hp, wp, patch);
+    return hipGetLastError();
+}
+
+hipError_t launch_sde_step_bwd(const SdeBwdParams& p, hipStream_t st) {
+    if (p.B <= 0 || p.n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sde_step_bwd_kernel, dim3(grid_for(p.n, 256) > 256 ? 256 : grid_for(p.n, 256), p.B), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+}  // namespace mi355

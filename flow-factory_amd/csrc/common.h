@@ -40,6 +40,14 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     return x * fast_rcp(1.0f + __builtin_amdgcn_exp2f(-t));
 }
 
+// d/dx of gelu_tanh_f: s + x s (1 - s) 2u'(x), s = sigmoid(2u), 2u = x (k0 + k1 x^2), (2u)' = k0 + 3 k1 x^2
+__device__ __forceinline__ float gelu_tanh_grad_f(float x) {
+    const float k0 = 2.0f * 0.7978845608028654f, k1 = k0 * 0.044715f;
+    const float x2 = x * x;
+    const float s = fast_rcp(1.0f + __expf(-x * (k0 + k1 * x2)));
+    return s + x * s * (1.0f - s) * (k0 + 3.0f * k1 * x2);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

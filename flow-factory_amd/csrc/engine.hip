@@ -118,6 +118,13 @@ static hipError_t attn_p(const AttnParams& a, hipStream_t st) { ProfScope ps(PC_
 static hipError_t lnmod_p(const LnModParams& l, hipStream_t st) { ProfScope ps(PC_LNMOD, st); return launch_ln_mod(l, st); }
 static hipError_t sde_p(const SdeStepParams& s, hipStream_t st) { ProfScope ps(PC_SDE, st); return launch_sde_step(s, st); }
 
+// training-mode state (engine_train.inc, included at the end of this file)
+struct mi355_engine;
+struct mi355_plan;
+static void train_release(mi355_plan* p);
+static void train_release_engine(mi355_engine* e);
+static void train_mark_dirty(mi355_engine* e);
+
 // ------------------------------------------------------------------------------------ engine
 struct Slot {
     void* dst;      // device destination (bf16_t* or float*)
@@ -287,6 +294,7 @@ extern "C" int mi355_engine_create(const mi355_model_cfg* cfg, mi355_engine** ou
 
 extern "C" int mi355_engine_destroy(mi355_engine* e) {
     if (!e) return 0;
+    train_release_engine(e);
     if (e->arena16) (void)hipFree(e->arena16);
     if (e->arena32) (void)hipFree(e->arena32);
     delete e;
@@ -312,6 +320,7 @@ extern "C" int mi355_engine_bind_weight(mi355_engine* e, const char* name, const
     if (dtype < 0 || dtype > 2) return fail("mi355_engine_bind_weight: bad dtype %d", dtype);
     HIPCHK(launch_convert(src, dtype, it->second.dst, it->second.dst_dt, n, (hipStream_t)stream));
     it->second.bound = true;
+    train_mark_dirty(e);
     if (strstr(name, ".norm_")) e->bounds_dirty = true;
     return 0;
 }
@@ -427,6 +436,7 @@ extern "C" int mi355_plan_create(mi355_engine* e, int batch, int n_cfg, int late
 
 extern "C" int mi355_plan_destroy(mi355_plan* p) {
     if (!p) return 0;
+    train_release(p);
     if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     if (p->ws) (void)hipFree(p->ws);
@@ -896,3 +906,5 @@ extern "C" int mi355_op_ln_modulate(void* stream, const void* x, const void* shi
     HIPCHK(lnmod_p(l, (hipStream_t)stream));
     return 0;
 }
+
+#include "engine_train.inc"

@@ -117,7 +117,12 @@ __device__ __forceinline__ void store_row8(const GemmParams& p, int m, int n, in
     } else {
         bf16_t* op = p.out + (long)m * p.ldo + n;
         const bool vec = FULL || (full && ((p.ldo & 7) == 0));
-        if constexpr (EPI == EPI_POSADD || EPI == EPI_ADDSRC_SILU) {
+        if constexpr (EPI == EPI_DGELU) {
+            const bf16_t* ap = p.aux + (long)m * p.ld_aux + n;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (n + e < p.N) y[e] *= gelu_tanh_grad_f(bf2f(ap[e]));
+        } else if constexpr (EPI == EPI_POSADD || EPI == EPI_ADDSRC_SILU) {
             const bf16_t* ap = p.aux + (long)(m % p.rows_per_sample) * p.ld_aux + n;
 #pragma unroll
             for (int e = 0; e < 8; ++e)
@@ -163,6 +168,39 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
     const int frow = lane & 15, fkg = lane >> 4;
     float4 bcol[4];
     float4 nw[4];
+    if constexpr (EPI == EPI_BIAS_GELU) {
+        // training-mode forward: the pre-activation goes to the stash first (same wave-private staging, LDS ops of a wave are in order)
+        if (p.stash) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const int r = i * 16 + frow;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = n_base + j * 16 + 4 * fkg;
+                    float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (FULL || n < p.N) bb = *(const float4*)(p.bias + n);
+                    const int chunk = (j * 2 + (fkg >> 1)) ^ (r & 7);
+                    uint2 o = {pack_bf16(acc[i][j][0] + bb.x, acc[i][j][1] + bb.y), pack_bf16(acc[i][j][2] + bb.z, acc[i][j][3] + bb.w)};
+                    *(uint2*)(stg + r * 128 + chunk * 16 + (fkg & 1) * 8) = o;
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NR * 2; ++it) {
+                const int r = it * 8 + (lane >> 3), c = lane & 7;
+                const uint4 val = *(const uint4*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
+                const int m = m_base + r, n = n_base + c * 8;
+                if (FULL || m < p.M) {
+                    bf16_t* sp = p.stash + (long)m * p.ld_stash + n;
+                    if (FULL || (n + 8 <= p.N && (p.ld_stash & 7) == 0)) *(uint4*)sp = val;
+                    else {
+                        const unsigned w4[4] = {val.x, val.y, val.z, val.w};
+                        for (int e = 0; e < 8; ++e)
+                            if (n + e < p.N) sp[e] = (bf16_t)((w4[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+                    }
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n_base + j * 16 + 4 * fkg;
@@ -200,6 +238,10 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
             ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
             const float rstd = rsqrtf(ss * (1.0f / 64.0f) + p.eps);
+            if (p.rstd_out && fkg == 0) {      // training-mode forward: 1/rms of this (row, head) for the RMSNorm backward
+                const int m = m_base + r;
+                if (FULL || m < p.M) p.rstd_out[(long)m * (2 * p.H) + (n_base >> 6)] = rstd;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 y[j][0] *= rstd * nw[j].x; y[j][1] *= rstd * nw[j].y; y[j][2] *= rstd * nw[j].z; y[j][3] *= rstd * nw[j].w;
@@ -246,12 +288,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
 
     // ---- XCD-aware tile mapping: consecutive tiles -> same XCD (blockIdx.x % 8 is the XCD)
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-    const int nblk = ntm * ntn;
+    const int nsplit = (EPI == EPI_F32 && p.k_split > 1) ? p.k_split : 1;
+    const int nblk = ntm * ntn * nsplit;
     int bid = blockIdx.x;
     {
         const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
         bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
     }
+    const int split = bid / (ntm * ntn);          // (splits of one tile run on different XCDs: they share no operand bytes)
+    bid -= split * (ntm * ntn);
     const int tm = bid / ntn, tn = bid - tm * ntn;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -325,12 +370,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < C::NI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nt = p.K / BK;
-    stage(0, 0);
+    const int nt_all = p.K / BK;
+    const int kt0 = (int)((long)nt_all * split / nsplit);
+    const int nt = (int)((long)nt_all * (split + 1) / nsplit) - kt0;      // K-tiles of this split (all of them without split-K)
+    if (nt > 0) stage(kt0, 0);
     for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // tile t landed for every wave; everyone is done reading the other buffer
-        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+        if (t + 1 < nt) stage(kt0 + t + 1, (t + 1) & 1);
         const char* sb = smem + (t & 1) * C::STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -360,7 +407,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
                 if (m >= p.M || n >= p.N) continue;
                 if constexpr (EPI == EPI_F32) {
                     const float sc = p.q_scale;
-                    float* op = p.out_f32 + (long)m * p.ldo + n;
+                    float* op = p.out_f32 + (long)split * p.split_stride + (long)m * p.ldo + n;
                     if (n + 4 <= p.N && (p.ldo & 3) == 0) {
                         *(float4*)op = make_float4(acc[i][j][0] * sc, acc[i][j][1] * sc, acc[i][j][2] * sc, acc[i][j][3] * sc);
                     } else {
@@ -665,7 +712,8 @@ hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
-    hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(C::NT), smem, stream, p);
+    const int nsplit = (EPI == EPI_F32 && p.k_split > 1) ? p.k_split : 1;
+    hipLaunchKernelGGL(kern, dim3(ntm * ntn * nsplit), dim3(C::NT), smem, stream, p);
     return hipGetLastError();
 }
 
@@ -741,6 +789,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
         case EPI_QK_NORM: return launch_epi<EPI_QK_NORM>(p, stream);
         case EPI_VT: return launch_epi<EPI_VT>(p, stream);
         case EPI_UNPATCH: return launch_epi<EPI_UNPATCH>(p, stream);
+        case EPI_DGELU: return launch_epi<EPI_DGELU>(p, stream);
         case EPI_BIAS_ROW: return launch_simple<EPI_BIAS_ROW, false>(p, stream);
         case EPI_F32: return launch_simple<EPI_F32, false>(p, stream);
         default: return hipErrorInvalidValue;

@@ -24,6 +24,8 @@ enum GemmEpi : int {
     EPI_BIAS_ROW,       // out[m][n] = bf16(acc + bias[m])              (row-major; swapped-operand V^T of the mid attention)
     EPI_F32,            // out_f32[m][n] = acc * q_scale                (attention scores, no bias)
     EPI_IMG,            // conv_out: image[b][n][y][x] = post(acc + bias[n]), n < N <= 4, fp32 or bf16 NCHW
+    // ---- backward (engine_train.inc)
+    EPI_DGELU,          // out[m][n] = bf16((acc + bias[n]) * gelu_tanh'(aux[m][n]))   (aux = stashed pre-activation, row stride ld_aux)
     EPI_COUNT
 };
 
@@ -52,6 +54,13 @@ struct GemmParams {
     // conv_up = 1: the input is (conv_h/2) x (conv_w/2) and is nearest-2x upsampled on the fly (Upsample2D + conv)
     int conv_cin, conv_h, conv_w, conv_up;
     const bf16_t* zero_page;  // >= 128 B of zeros: source of the padding taps
+    // training-mode forward (the main output is bit-identical to the rollout's): EPI_BIAS_GELU also stores the pre-activation
+    // bf16(acc + bias) to `stash` (row stride ld_stash); EPI_QK_NORM stores the per-(row, head) 1/rms to rstd_out[m * 2H + head]
+    bf16_t* stash; long ld_stash;
+    float* rstd_out;
+    // split-K (EPI_F32 on the 2-stage kernel only: weight gradients, output tiles << CUs): split s of k_split accumulates K-tiles
+    // [s*nt/k_split, (s+1)*nt/k_split) into out_f32 + s * split_stride (deterministic second-stage reduction by the caller)
+    int k_split; long split_stride;
     // optional s_memtime trace (debug): per workgroup, per tile 4 stamps {tile start, main loop start, main loop end, epilogue end}
     long long* trace;
     int dbg_skip_prefetch;    // debug ablation: the K-loop prefetches are not issued (results are garbage)
@@ -75,6 +84,7 @@ struct AttnParams {
     int B, H, S, S_pad, n_img;
     int q_prescaled;   // 1: q already carries the softmax scale 0.125*log2(e) (folded into the q RMSNorm epilogue)
     float score_bound; // > 0: proven bound on |q.k| * scale * log2(e); <= 60 selects the no-running-max kernel (0 = unknown)
+    float* lse;        // optional [B][H][S_pad] fp32: log2-sum-exp of the scaled scores per query (training-mode forward; nullptr = not written)
 };
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream);
 
@@ -161,6 +171,61 @@ hipError_t launch_softmax_rows(const float* s, bf16_t* p, long rows, int n, floa
 hipError_t launch_conv_repack(const void* src, int dt, bf16_t* dst, int Co, int Ci, int Cpad, int taps, hipStream_t st);
 // shared error sink of the C ABI (engine.hip): formats into mi355_last_error(), returns 1
 int errorf(const char* fmt, ...);
+
+// ------------------------------------------------------------------------------ backward (backward.hip, attention_bwd.hip)
+// dres (+)= d/dx of [LN(x)*(1+scale)+shift](dy) [+ the same for a second modulated copy (dy2, scale2)]; x, dy, dres [M][D] bf16
+struct LnModBwdParams {
+    const bf16_t* x; const bf16_t* dy; const bf16_t* dy2; bf16_t* dres;
+    const bf16_t* mod; long mod_ld; int scale_off, scale2_off;
+    int M, D, rows_per_sample; float eps; int accumulate;
+};
+hipError_t launch_ln_mod_bwd(const LnModBwdParams& p, hipStream_t stream);
+// dy[m][:] = gate[m / rps][:] * dx[m][:]
+hipError_t launch_gate_mul(const bf16_t* dx, const bf16_t* gate, long gate_ld, bf16_t* dy, long M, int D, int rps, hipStream_t stream);
+hipError_t launch_gelu_fwd(const bf16_t* pre, bf16_t* out, long n, hipStream_t stream);
+// out[z][c][r] = in[z][r][c] for r < rows (0 for rows <= r < rows_pad), 64 x 64 tiles through LDS
+hipError_t launch_transpose(const bf16_t* in, long ld_in, long bs_in, bf16_t* out, long ld_out, long bs_out, int rows, int cols, int rows_pad,
+                            int batch, hipStream_t stream);
+struct AttnBwdPrepParams {
+    const bf16_t* o_img; const bf16_t* o_ctx; const bf16_t* do_img; const bf16_t* do_ctx;   // token-major [.][H*64]; do_ctx may be null (zeros)
+    bf16_t* doh; bf16_t* doT; float* delta;                                               // [B][H][S_pad][64], [B][H][64][S_pad], [B][H][S_pad]
+    int B, H, S, S_pad, n_img;
+};
+hipError_t launch_attn_bwd_prep(const AttnBwdPrepParams& p, hipStream_t stream);
+struct RmsBwdParams {
+    const bf16_t* q; const bf16_t* k;                      // stored (normalised) q~, k [B][H][S_pad][64]
+    const bf16_t* dq; const bf16_t* dk; const bf16_t* dv;  // gradients in the same layout
+    const float* rstd_img; const float* rstd_ctx;          // [rows][2H] from the forward's q|k epilogue
+    const float* nw_q; const float* nw_k; const float* nw_cq; const float* nw_ck;   // RMSNorm weights [64] (image / context stream)
+    float q_scale;                                         // factor folded into the stored q (softmax scale * log2 e)
+    bf16_t* out_img; bf16_t* out_ctx;                      // [rows][3*H*64] = [dq_pre | dk_pre | dv]
+    int B, H, S, S_pad, n_img;
+};
+hipError_t launch_rms_bwd_gather(const RmsBwdParams& p, hipStream_t stream);
+// out[n] (+)= sum_m dy[m][n]; scratch >= 64 * N floats
+hipError_t launch_colsum(const bf16_t* dy, long ld, long M, int N, float* scratch, float* out, int accumulate, hipStream_t stream);
+hipError_t launch_splitk_reduce(const float* part, long stride, int nsplit, float* out, long n, int accumulate, hipStream_t stream);
+hipError_t launch_unpatch_bwd(const float* dv, bf16_t* out, int Bp, int C, int hp, int wp, int patch, hipStream_t stream);
+struct SdeBwdParams {
+    const bf16_t* v_text; const bf16_t* v_uncond; float guidance;
+    const void* latents; int lat_dt; const void* next_in; int next_in_dt;
+    const float* sigma; const float* sigma_next; const float* eta; int scalar_stride; float sigma_max;
+    int dynamics; int compute_log_prob; int B; long n;
+    const float* g_lp; const float* g_np; const float* g_mean;     // upstream gradients (any may be null)
+    float* dv;                                                     // [n_cfg*B][n] fp32, order [uncond, text]
+};
+hipError_t launch_sde_step_bwd(const SdeBwdParams& p, hipStream_t stream);
+// flash-attention backward, head_dim 64 (attention_bwd.hip).  q (pre-scaled by log2(e)/8), k, v, doh: [B][H][S_pad][64];
+// qT, kT, doT: [B][H][64][S_pad]; lse (log2 domain), delta: [B][H][S_pad] fp32.  Outputs dq (w.r.t. the stored, pre-scaled q), dk, dv
+// [B][H][S_pad][64] bf16.  Two deterministic passes: key-block-outer (dk, dv) and query-block-outer (dq).
+struct AttnBwdParams {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* doh;
+    const bf16_t* qT; const bf16_t* kT; const bf16_t* doT;
+    const float* lse; const float* delta;
+    bf16_t* dq; bf16_t* dk; bf16_t* dv;
+    int B, H, S, S_pad;
+};
+hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream);
 
 // --------------------------------------------------------------------------- SDE step (K15)
 enum Dynamics : int { DYN_ODE = 0, DYN_FLOW_SDE = 1, DYN_DANCE_SDE = 2, DYN_CPS = 3 };

@@ -78,6 +78,13 @@ SIGNATURES = {
                                 _P, _P, _P, _P, _P, _P, _P]),
     "mi355_rollout": (_I, [_P, _P, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _I, _F, _P, _I, _I, _P,
                            _P, _P, _P, _P, C.POINTER(C.c_int32), _P, _P, _P, _I]),
+    "mi355_engine_set_grad": (_I, [_P, C.c_char_p, _P]),
+    "mi355_engine_clear_grads": (_I, [_P]),
+    "mi355_engine_grad_supported": (_I, [_P, C.c_char_p]),
+    "mi355_plan_training_bytes": (_L, [_P]),
+    "mi355_denoise_step_train": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "mi355_denoise_step_backward": (_I, [_P, _P, _P, _I, _F, _P, _I, _P, _P, _P, _I, _F, _I, _I, _P, _P, _P]),
+    "mi355_op_attention_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
     "mi355_op_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I]),
     "mi355_op_linear_trace": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "mi355_op_attention": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),

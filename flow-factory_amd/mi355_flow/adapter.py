@@ -46,6 +46,11 @@ class NativeRolloutMixin:
     def _before_engine_call(self) -> None:
         """Hook run at the top of inference() / forward(): the Flow-Factory plugin re-binds changed weights here."""
 
+    def _grad_fallback(self, why: str, kwargs: Dict[str, Any]):
+        """Grad-mode forward() with trainable parameters the native backward does not cover.  The Flow-Factory plugin overrides this
+        with the reference's autograd path; standalone there is no other implementation to fall back to."""
+        raise NotImplementedError(f"mi355_flow: grad-mode forward() is not available: {why}")
+
     def _check_joint_attention_kwargs(self, jak: Optional[Dict[str, Any]]) -> None:
         """`joint_attention_kwargs` (sd3_5.py:421-428 forwards them to the transformer): diffusers consumes `scale` (LoRA scale of
         the peft backend: `scale_lora_layers`) and IP-adapter inputs.  The engine honours `scale` through the weight binding (LoRA
@@ -280,9 +285,27 @@ class NativeRolloutMixin:
               (prompt_embeds, pooled_prompt_embeds, None, None)
         sigma_max = float(sched.sigmas[1])
         want = tuple(k for k in return_kwargs if k in ("next_latents", "next_latents_mean", "noise_pred", "std_dev_t", "dt"))
+        view = (-1, 1, 1, 1)
+        if torch.is_grad_enabled() and next_latents is not None and getattr(self, "_live_weights", None) is not None:
+            # optimize() replay (trainers/grpo.py:263): the engine's differentiable step when its backward covers the trainable set
+            from . import autograd as AG
+            why = AG.unsupported_reason(self)
+            if why is None:
+                call = dict(latents=latents, timestep=t, enc_a=enc[0], pooled_a=enc[1], enc_b=enc[2], pooled_b=enc[3], guidance=guidance_scale,
+                            sigma=sigma, sigma_next=sigma_next, eta=noise_level, sigma_max=sigma_max, dynamics=dyn,
+                            next_latents=next_latents, compute_log_prob=compute_log_prob)
+                lp, npred, mean, std, dtt = AG.denoise_replay(self, plan, call)
+                res = dict(noise_pred=npred, next_latents=next_latents.float(), next_latents_mean=mean, std_dev_t=std.view(view),
+                           dt=dtt.view(view), log_prob=lp if compute_log_prob else None)
+                return self._output_cls.from_dict({k: res[k] for k in return_kwargs if k in res})
+            if not why.startswith("the bound module has no trainable"):
+                return self._grad_fallback(why, dict(
+                    t=t, latents=latents, prompt_embeds=prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds,
+                    negative_prompt_embeds=negative_prompt_embeds, negative_pooled_prompt_embeds=negative_pooled_prompt_embeds,
+                    guidance_scale=guidance_scale, t_next=t_next, next_latents=next_latents, noise_level=noise_level,
+                    joint_attention_kwargs=joint_attention_kwargs, compute_log_prob=compute_log_prob, return_kwargs=return_kwargs))
         o = plan.denoise_step(latents, t, enc[0], enc[1], enc[2], enc[3], guidance_scale, sigma, sigma_next, noise_level,
                               sigma_max, dyn, noise=noise, next_latents=next_latents, compute_log_prob=compute_log_prob, want=want)
-        view = (-1, 1, 1, 1)
         res = dict(
             noise_pred=o.noise_pred,
             next_latents=o.next_latents if next_latents is None else next_latents.float(),
@@ -297,7 +320,7 @@ class NativeRolloutMixin:
 class SD3_5NativeAdapter(NativeRolloutMixin):
     """Standalone adapter (no Flow-Factory import): engine + scheduler + optional VAE decoder."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[TransformerConfig] = None,
+    def __init__(self, state_dict: Union[Dict[str, torch.Tensor], torch.nn.Module], config: Optional[TransformerConfig] = None,
                  scheduler: Optional[FlowMatchEulerDiscreteSDEScheduler] = None, latent_storage_dtype: Optional[str] = "fp16",
                  transformer_dtype: torch.dtype = torch.bfloat16, device: Union[str, torch.device] = "cuda",
                  vae_decode: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
@@ -309,7 +332,16 @@ class SD3_5NativeAdapter(NativeRolloutMixin):
         self._latent_storage = latent_storage_dtype
         self.scheduler = scheduler or FlowMatchEulerDiscreteSDEScheduler(shift=3.0, sde_steps=[1, 2, 3], num_sde_steps=1)
         self.engine = Engine(config or TransformerConfig())
-        self.refresh_weights(state_dict)
+        self._live_weights = None
+        if isinstance(state_dict, torch.nn.Module):
+            # a torch module with HF parameter names (possibly DDP / peft wrapped): its CURRENT parameters are re-bound before every
+            # engine call, and grad-mode forward() differentiates w.r.t. its trainable parameters (mi355_flow/autograd.py)
+            from .binding import LiveWeights
+            module = state_dict
+            self._live_weights = LiveWeights(self.engine, lambda: module)
+            self._sync_weights()
+        else:
+            self.refresh_weights(state_dict)
         self._vae_decode = vae_decode
         self.vae_decoder = None
         self.vae_max_batch = vae_max_batch
@@ -322,6 +354,17 @@ class SD3_5NativeAdapter(NativeRolloutMixin):
     @property
     def latent_storage_dtype(self) -> Optional[torch.dtype]:
         return _DTYPE_MAP.get(self._latent_storage) if self._latent_storage else None
+
+    def _sync_weights(self) -> int:
+        if self._live_weights is None:
+            return 0
+        n = self._live_weights.sync()
+        if n:
+            self.engine.ready()
+        return n
+
+    def _before_engine_call(self) -> None:
+        self._sync_weights()
 
     def refresh_weights(self, state_dict: Dict[str, torch.Tensor]) -> None:
         """Re-pack the (live) torch parameters: call after optimizer steps / EMA swaps / LoRA merges."""

@@ -1,15 +1,165 @@
-"""Differentiable engine forward for the `optimize()` replay (reference trainers/grpo.py:185-342).
+"""Differentiable engine forward for the `optimize()` replay (reference
+src/flow_factory/trainers/grpo.py:185-342).
 
-Placeholder until the backward kernels land in this round: `grad_forward_supported` reports why the native path is not
-taken, and the plugin then uses the reference's autograd path."""
+`GRPOTrainer.optimize` calls `adapter.forward(t, latents, next_latents=x_{i+1}, ...)` WITH autograd, builds the PPO-clip loss
+from `output.log_prob` (+ an optional KL term from `noise_pred` / `next_latents_mean`) and calls `accelerator.backward(loss)`.
+`denoise_replay` below is that forward on the engine:
+
+  * forward  = `mi355_denoise_step_train`: the launch sequence of the rollout's denoise step (same kernels, same epilogues), so
+    the replay log-prob is bit-identical to the rollout's and `ratio == exp(0) == 1` before any update -- the reference's
+    train/inference-consistency invariant (.agents/knowledge/topics/train_inference_consistency.md:20-29), which cannot hold to
+    the default `clip_range` of +-1e-4 when the replay runs on a different implementation than the rollout;
+  * backward = `mi355_denoise_step_backward`: hand-written HIP (flash-attention backward, dgrad GEMMs with fused GELU', LayerNorm /
+    RMSNorm backward, split-K wgrad), fp32 weight gradients handed to torch autograd as the gradients of the (possibly
+    LoRA-merged) weight tensors -- so LoRA A/B gradients, DDP's bucketed all-reduce (RCCL) and DeepSpeed's hooks all see ordinary
+    `.grad` flow.  Merged LoRA weights `W + s * B @ A` are built with autograd here and bound to the engine as they are.
+
+Supported trainable set: weights / biases of the linear layers inside the transformer blocks (attention projections of both
+streams, attn2, the MLPs) -- the reference's default `target_modules` for full fine-tuning and for LoRA.  Anything else trainable
+(AdaLN modulation linears, embedders, norms) makes `unsupported_reason` return a message and the caller falls back.
+"""
 from __future__ import annotations
 
-from typing import Optional
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .binding import LiveWeights, _LoraWeight, _Plain, _full, unwrap_module
+from .engine import DYNAMICS, _bf16c, _scalars
 
 
-def grad_forward_supported(adapter) -> Optional[str]:
-    return "the native backward is not built yet"
+# --------------------------------------------------------------------------------------------- trainable sources
+def _lora_trainable(src: _LoraWeight) -> bool:
+    lay = src.layer
+    return any(lay.lora_A[a].weight.requires_grad or lay.lora_B[a].weight.requires_grad for a in src._active())
 
 
-def sd3_grad_forward(adapter, *args, **kwargs):
-    raise NotImplementedError("mi355_flow: native grad-mode forward is not built yet")
+def trainable_sources(live: LiveWeights) -> List[Tuple[str, object]]:
+    """(engine parameter name, source) for every source that carries a trainable torch tensor."""
+    live.sync()                      # resolves the sources against the current module tree
+    out = []
+    for name, src in live._sources.items():
+        if isinstance(src, _Plain):
+            if getattr(src.t, "requires_grad", False):
+                out.append((name, src))
+        elif isinstance(src, _LoraWeight):
+            if _lora_trainable(src) or src.layer.base_layer.weight.requires_grad:
+                out.append((name, src))
+    return out
+
+
+def _covered_tensor_ids(pairs: Sequence[Tuple[str, object]]) -> set:
+    ids = set()
+    for _, src in pairs:
+        if isinstance(src, _Plain):
+            ids.add(id(src.t))
+        else:
+            lay = src.layer
+            ids.add(id(lay.base_layer.weight))
+            for a in src._active():
+                ids.add(id(lay.lora_A[a].weight))
+                ids.add(id(lay.lora_B[a].weight))
+    return ids
+
+
+def unsupported_reason(host) -> Optional[str]:
+    """None when the engine's backward covers every trainable parameter of the bound module; else why not."""
+    live: Optional[LiveWeights] = getattr(host, "_live_weights", None)
+    if live is None:
+        return "no torch module is bound to the engine (weights were bound from a state dict)"
+    pairs = trainable_sources(live)
+    if not pairs:
+        return "the bound module has no trainable parameter"
+    eng = host.engine
+    for name, _ in pairs:
+        if not eng.grad_supported(name):
+            return f"parameter '{name}' is outside the native backward's scope (linear layers of the transformer blocks)"
+    covered = _covered_tensor_ids(pairs)
+    root = unwrap_module(live.get_module())
+    for pname, prm in root.named_parameters():
+        if prm.requires_grad and id(prm) not in covered:
+            return f"trainable parameter '{pname}' has no counterpart in the engine's backward"
+    return None
+
+
+grad_forward_supported = unsupported_reason      # name used by the Flow-Factory plugin
+
+
+def _materialise_with_grad(src, lora_scale: float) -> torch.Tensor:
+    """The tensor the engine binds for this source, connected to the trainable leaves by autograd."""
+    if isinstance(src, _Plain):
+        return src.t
+    lay = src.layer
+    w = _full(lay.base_layer.weight)
+    out = w.float() if w.requires_grad else w.detach().float()
+    for a in src._active():
+        A, B = _full(lay.lora_A[a].weight).float(), _full(lay.lora_B[a].weight).float()
+        delta = (B @ A) * (float(lay.scaling[a]) * float(lora_scale))
+        out = out + (delta.t() if getattr(lay, "fan_in_fan_out", False) else delta)
+    return out
+
+
+# --------------------------------------------------------------------------------------------- DDP reducer arming
+def _ddp_of(module):
+    m = module
+    for _ in range(4):
+        if type(m).__name__ == "DistributedDataParallel":
+            return m
+        nxt = getattr(m, "_orig_mod", None)
+        if nxt is None:
+            return None
+        m = nxt
+    return None
+
+
+# --------------------------------------------------------------------------------------------- the autograd node
+class _DenoiseReplayFn(torch.autograd.Function):
+    """(log_prob [B], noise_pred [B,C,h,w], next_latents_mean [B,C,h,w]) = step(weights); d/d weights by the engine."""
+
+    @staticmethod
+    def forward(ctx, host, plan, names, call, *weights):
+        call["_keep"] = {}
+        o = plan.denoise_step_train(**call)
+        ctx.set_materialize_grads(False)
+        ctx.host, ctx.plan, ctx.names, ctx.call = host, plan, names, call
+        ctx.w_meta = [(w.shape, w.dtype) for w in weights]
+        ctx.mark_non_differentiable(o.std_dev_t, o.dt)
+        return o.log_prob, o.noise_pred, o.next_latents_mean, o.std_dev_t, o.dt
+
+    @staticmethod
+    def backward(ctx, g_lp, g_np, g_mean, _g_std, _g_dt):
+        host, plan = ctx.host, ctx.plan
+        # the weights may have been swapped after the forward (KL reference pass under use_ref_parameters, trainers/grpo.py:281-292):
+        # re-bind the current (policy) weights before the data-gradient GEMMs read them
+        sync = getattr(host, "_sync_weights", None)
+        if sync is not None:
+            sync()
+        eng = plan.engine
+        if g_lp is None and g_np is None and g_mean is None:
+            return (None,) * (4 + len(ctx.names))
+        dev = next(g for g in (g_lp, g_np, g_mean) if g is not None).device
+        grads: Dict[str, torch.Tensor] = {}
+        eng.clear_grads()
+        for name, (shape, _) in zip(ctx.names, ctx.w_meta):
+            grads[name] = torch.zeros(shape, device=dev, dtype=torch.float32)
+            eng.set_grad(name, grads[name])
+        plan.denoise_step_backward(ctx.call, g_lp, g_np, g_mean)
+        eng.clear_grads()
+        outs = tuple(grads[n].to(dt) for n, (_, dt) in zip(ctx.names, ctx.w_meta))
+        return (None, None, None, None) + outs
+
+
+def denoise_replay(host, plan, call: dict):
+    """Run the differentiable replay step; returns (log_prob, noise_pred, next_latents_mean, std_dev_t, dt) with autograd attached to
+    the trainable parameters behind `host._live_weights`."""
+    live: LiveWeights = host._live_weights
+    pairs = trainable_sources(live)
+    names = [n for n, _ in pairs]
+    weights = [_materialise_with_grad(s, live.lora_scale) for _, s in pairs]
+    ddp = _ddp_of(live.get_module())
+    if ddp is not None:
+        ddp._pre_forward()                      # arms buffer sync / lazy init exactly like DDP.forward
+    out = _DenoiseReplayFn.apply(host, plan, names, call, *weights)
+    if ddp is not None:
+        ddp._post_forward(out[0])               # reducer.prepare_for_backward: bucketed gradient all-reduce during our backward
+    return out

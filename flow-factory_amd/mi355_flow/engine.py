@@ -137,6 +137,19 @@ class Engine(WeightHolder):
         self._h = h
         self._plans: Dict[tuple, "Plan"] = {}
 
+    # ---------------------------------------------------------------- weight gradients (mi355_flow/autograd.py)
+    def grad_supported(self, name: str) -> bool:
+        return self.lib.mi355_engine_grad_supported(self._h, name.encode()) == 0
+
+    def set_grad(self, name: str, grad: torch.Tensor) -> None:
+        """Register the fp32 buffer the next backward writes d loss / d `name` into (same shape as the parameter)."""
+        if grad.dtype != torch.float32 or not grad.is_contiguous():
+            raise ValueError("mi355_flow: gradient buffers are contiguous fp32 tensors")
+        _lib.check(self.lib.mi355_engine_set_grad(self._h, name.encode(), _ptr(grad)), f"set_grad({name})")
+
+    def clear_grads(self) -> None:
+        _lib.check(self.lib.mi355_engine_clear_grads(self._h), "clear_grads")
+
     def attention_info(self) -> Dict[str, float]:
         """{'static': launches of a forward on the static-bound softmax kernel, 'total': attention launches, 'max_bound': ...}"""
         ns, nt, mb = C.c_int(), C.c_int(), C.c_float()
@@ -235,6 +248,50 @@ class Plan:
             dtype_code(nxt_in.dtype) if nxt_in is not None else 0, _ptr(sig), _ptr(sig_n), _ptr(et), stride,
             float(sigma_max), DYNAMICS[dynamics], int(bool(compute_log_prob)), *outs.ptrs()), "denoise_step")
         return outs
+
+    # ---------------------------------------------------------------- differentiable replay step (optimize())
+    def denoise_step_train(self, latents, timestep, enc_a, pooled_a, enc_b, pooled_b, guidance, sigma, sigma_next, eta, sigma_max,
+                           dynamics: str, next_latents, compute_log_prob=True, _keep=None):
+        """mi355_denoise_step_train: the replay forward on per-block activation buffers (bit-identical outputs to `denoise_step`).
+        `_keep` (a dict) receives the prepared device tensors so that `denoise_step_backward` can pass the same pointers."""
+        B, dev = self.batch, latents.device
+        latents = latents.contiguous()
+        t = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
+        if t.numel() == 1:
+            t = t.expand(B * self.n_cfg)
+        elif t.numel() == B and self.n_cfg == 2:
+            t = t.repeat(2)
+        t = t.contiguous()
+        sig, sig_n, et, stride = _scalars(sigma, sigma_next, eta, B, dev)
+        outs = _StepOutputs(B, latents, ("next_latents_mean", "noise_pred", "std_dev_t", "dt"), True)
+        enc_a, pooled_a = _bf16c(enc_a), _bf16c(pooled_a)
+        enc_b = _bf16c(enc_b) if enc_b is not None else None
+        pooled_b = _bf16c(pooled_b) if pooled_b is not None else None
+        nxt = next_latents.contiguous()
+        _lib.check(self.lib.mi355_denoise_step_train(
+            self._h, _stream(), _ptr(latents), dtype_code(latents.dtype), _ptr(t), _ptr(enc_a), _ptr(pooled_a), _ptr(enc_b), _ptr(pooled_b),
+            float(guidance), _ptr(nxt), dtype_code(nxt.dtype), _ptr(sig), _ptr(sig_n), _ptr(et), stride, float(sigma_max),
+            DYNAMICS[dynamics], int(bool(compute_log_prob)), None, _ptr(outs.next_latents_mean), _ptr(outs.noise_pred),
+            _ptr(outs.log_prob), _ptr(outs.std_dev_t), _ptr(outs.dt)), "denoise_step_train")
+        if _keep is not None:
+            _keep.update(latents=latents, nxt=nxt, sig=sig, sig_n=sig_n, et=et, stride=stride, guidance=float(guidance),
+                         sigma_max=float(sigma_max), dynamics=DYNAMICS[dynamics], clp=int(bool(compute_log_prob)))
+        return outs
+
+    def denoise_step_backward(self, call: dict, g_log_prob, g_noise_pred, g_mean) -> None:
+        """mi355_denoise_step_backward for the step recorded in `call['_keep']`; gradients go to the buffers registered with
+        `Engine.set_grad`."""
+        k = call["_keep"]
+        f32 = lambda g: None if g is None else g.to(torch.float32).contiguous()
+        g_lp, g_np, g_mn = f32(g_log_prob), f32(g_noise_pred), f32(g_mean)
+        _lib.check(self.lib.mi355_denoise_step_backward(
+            self._h, _stream(), _ptr(k["latents"]), dtype_code(k["latents"].dtype), k["guidance"], _ptr(k["nxt"]), dtype_code(k["nxt"].dtype),
+            _ptr(k["sig"]), _ptr(k["sig_n"]), _ptr(k["et"]), k["stride"], k["sigma_max"], k["dynamics"], k["clp"], _ptr(g_lp), _ptr(g_np),
+            _ptr(g_mn)), "denoise_step_backward")
+
+    @property
+    def training_bytes(self) -> int:
+        return int(self.lib.mi355_plan_training_bytes(self._h))
 
     # ---------------------------------------------------------------- whole rollout
     def rollout(self, timesteps: Sequence[float], sigmas: Sequence[float], noise_levels: Sequence[float], dynamics: str,

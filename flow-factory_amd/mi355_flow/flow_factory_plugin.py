@@ -150,24 +150,16 @@ if _RefAdapter is not None:
             images = self.vae_decoder.decode(latents, postprocess=False, out_dtype=torch.bfloat16)
             return self.pipeline.image_processor.postprocess(images, output_type=output_type)
 
-        # NOTE: `inference` is the mixin's own method (no wrapper): the trainer filters its kwargs by `inspect.signature`
-        # (utils/base.py:38-63, trainers/grpo.py:165), so the parameter list IS the ABI.  `forward` keeps it through `wraps`.
-        @functools.wraps(NativeRolloutMixin.forward)
-        def forward(self, *args, **kwargs):
-            if torch.is_grad_enabled():
-                self._sync_weights()
-                # optimize() replay (trainers/grpo.py:263): the engine's differentiable forward/backward when it covers the
-                # trainable set; otherwise the reference's autograd path (e.g. trainable text encoders, DoRA)
-                from .autograd import grad_forward_supported, sd3_grad_forward
-                why = grad_forward_supported(self)
-                if why is None:
-                    return sd3_grad_forward(self, *args, **kwargs)
-                if not getattr(self, "_warned_ref_grad", False):
-                    logger.warning("mi355_flow: grad-mode forward() falls back to the reference autograd path (%s); rollout "
-                                   "log-probs then differ from the replay by the engine-vs-torch arithmetic difference", why)
-                    self._warned_ref_grad = True
-                return _RefAdapter.forward(self, *args, **kwargs)
-            return NativeRolloutMixin.forward(self, *args, **kwargs)
+        # NOTE: `inference` / `forward` are the mixin's own methods (no wrappers): the trainer filters its kwargs by
+        # `inspect.signature` (utils/base.py:38-63, trainers/grpo.py:165,252), so the parameter lists ARE the ABI.  Grad-mode
+        # forward() -- the optimize() replay (grpo.py:263) -- runs the engine's differentiable step (mi355_flow/autograd.py) when
+        # its backward covers the trainable set; otherwise this hook sends it to the reference's autograd path.
+        def _grad_fallback(self, why, kwargs):
+            if not getattr(self, "_warned_ref_grad", False):
+                logger.warning("mi355_flow: grad-mode forward() uses the reference autograd path (%s); the replay log-prob then differs "
+                               "from the rollout's by the engine-vs-torch arithmetic difference", why)
+                self._warned_ref_grad = True
+            return _RefAdapter.forward(self, **kwargs)
 
     try:
         from flow_factory.models.flux.flux1 import Flux1Adapter as _RefFlux, Flux1Sample as _RefFluxSample

@@ -129,6 +129,31 @@ int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const float* timeste
                   const void* pooled, const void* neg_embeds, const void* neg_pooled, const int32_t* keep_slot_host,
                   void* out_latents, float* out_log_probs, void* out_final, int compute_log_prob);
 
+/* ---- differentiable denoise step: the `optimize()` replay -------------------
+ * Replaces the grad-mode `SD3_5Adapter.forward(..., next_latents=x_{i+1})` + `loss.backward()` of GRPOTrainer.optimize (reference
+ * src/flow_factory/trainers/grpo.py:229-263, :330): the forward is the launch sequence of mi355_denoise_step on per-block activation
+ * buffers (log-prob bit-identical to the rollout's), the backward turns the upstream gradients of (log_prob [batch], noise_pred,
+ * next_latents_mean [batch][C][h][w] fp32; any may be NULL) into fp32 weight gradients, written (overwritten) into the buffers
+ * registered with mi355_engine_set_grad (same shape as the parameter; NULL un-registers).  Supported parameters: weights and biases of
+ * the linear layers inside the transformer blocks (mi355_engine_grad_supported == 0); the data gradient covers the whole network.
+ * The caller re-binds the CURRENT weights before the backward if they were swapped after the forward. */
+int mi355_engine_set_grad(mi355_engine* e, const char* name, float* grad);
+int mi355_engine_clear_grads(mi355_engine* e);
+int mi355_engine_grad_supported(mi355_engine* e, const char* name);
+int64_t mi355_plan_training_bytes(mi355_plan* p);
+int mi355_denoise_step_train(mi355_plan* p, void* stream, const void* latents, int lat_dtype, const float* t, const void* enc_a,
+                             const void* pooled_a, const void* enc_b, const void* pooled_b, float guidance, const void* next_in,
+                             int next_in_dtype, const float* sigma, const float* sigma_next, const float* eta, int scalar_stride,
+                             float sigma_max, int dynamics, int compute_log_prob, float* next_f32, float* mean_out,
+                             float* noise_pred_out, float* log_prob, float* std_dev_t, float* dt);
+int mi355_denoise_step_backward(mi355_plan* p, void* stream, const void* latents, int lat_dtype, float guidance, const void* next_in,
+                                int next_in_dtype, const float* sigma, const float* sigma_next, const float* eta, int scalar_stride,
+                                float sigma_max, int dynamics, int compute_log_prob, const float* g_log_prob, const float* g_noise_pred,
+                                const float* g_mean);
+/* unit-test helper: attention forward (q pre-scaled by log2(e)/8) + flash backward; d_o / o token-major [B*S][H*64]; synchronises */
+int mi355_op_attention_fwd_bwd(void* stream, const void* q, const void* k, const void* vT, const void* d_o, void* o, void* dq, void* dk,
+                               void* dv, int B, int H, int S, int S_pad);
+
 /* ---- operator-level entry points (unit tests, per-kernel profiling) ------------------------- */
 /* out[M][N] (bf16, ld = N) = A[M][K] . W[N][K]^T + bias[N] (fp32 bias); act: 0 none, 1 silu, 2 gelu-tanh */
 int mi355_op_linear(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,

@@ -1,0 +1,277 @@
+"""GPU tests of the differentiable replay step (reference src/flow_factory/trainers/grpo.py:185-342), through the
+C ABI (`mi355_denoise_step_train` / `mi355_denoise_step_backward`, `mi355_op_attention_fwd_bwd`):
+
+  * flash-attention backward vs torch autograd of fp32 SDPA on the same bf16 inputs (rel-L2 <= 2e-2: P and dZ are rounded to bf16
+    before their MFMAs, like every flash backward);
+  * the train / inference consistency invariant IN GRAD MODE: the replay log-prob of `forward()` with autograd enabled is
+    bit-identical to the no-grad replay and to the rollout's log-prob (ratio == exp(0) == 1 exactly);
+  * weight gradients of a PPO-style loss (log-prob term + a KL-like noise_pred term) vs torch autograd through the fp32 oracle
+    (oracle/mmditx_ref.py, differentiable) on identical bf16-rounded weights: per-parameter rel-L2 <= 5e-2 (bf16 activations and
+    activation gradients through 3 blocks; the oracle is fp32 end to end), cosine >= 0.995;
+  * LoRA: gradients reach lora_A / lora_B through the merged weight, equal to the chain rule applied to the dense gradient;
+  * an optimizer step changes the replay log-prob (weights are live) and the next backward still works.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import _plugin_fakes as PF
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+def _cos(a, b):
+    a, b = a.float().cpu().flatten(), b.float().cpu().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return torch.device("cuda")
+
+
+# ------------------------------------------------------------------------------------------------- attention backward
+@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (2, 3, 333 + 256), (1, 2, 1000), (1, 4, 4429)])
+def test_attention_backward_matches_autograd(gpu, B, H, S):
+    import ctypes as C
+    from mi355_flow import _lib
+    from mi355_flow.engine import _ptr, _stream
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(S * 7 + H)
+    S_pad = (S + 63) // 64 * 64
+    c = 0.125 * 1.4426950408889634
+    q = torch.zeros(B, H, S_pad, 64, device="cuda", dtype=torch.bfloat16)
+    k, v = torch.zeros_like(q), torch.zeros_like(q)
+    q[:, :, :S] = (torch.randn(B, H, S, 64, device="cuda", generator=g) * c).bfloat16()          # stored q carries log2(e)/8
+    k[:, :, :S] = (torch.randn(B, H, S, 64, device="cuda", generator=g) * 1.3).bfloat16()
+    v[:, :, :S] = torch.randn(B, H, S, 64, device="cuda", generator=g).bfloat16()
+    vT = v.transpose(2, 3).contiguous()
+    do = torch.randn(B * S, H * 64, device="cuda", generator=g).bfloat16()
+    o = torch.empty_like(do)
+    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(q), torch.zeros_like(q)
+    _lib.check(lib.mi355_op_attention_fwd_bwd(_stream(), _ptr(q), _ptr(k), _ptr(vT), _ptr(do), _ptr(o), _ptr(dq), _ptr(dk), _ptr(dv),
+                                              B, H, S, S_pad), "op_attention_fwd_bwd")
+    # reference: softmax(ln2 * q~ k^T) v in fp32 with autograd, gradients w.r.t. the STORED (pre-scaled) q
+    qr = q[:, :, :S].float().requires_grad_(True)
+    kr = k[:, :, :S].float().requires_grad_(True)
+    vr = v[:, :, :S].float().requires_grad_(True)
+    p = torch.softmax((qr @ kr.transpose(2, 3)) * math.log(2.0), dim=-1)
+    oref = (p @ vr).transpose(1, 2).reshape(B * S, H * 64)
+    oref.backward(do.float())
+    assert _rel(o, oref) < 6e-3
+    for name, got, ref in (("dq", dq, qr.grad), ("dk", dk, kr.grad), ("dv", dv, vr.grad)):
+        r = _rel(got[:, :, :S], ref)
+        assert r < 2e-2 and _cos(got[:, :, :S], ref) > 0.9995, (name, r)
+        assert float(got[:, :, S:].float().abs().max()) == 0.0 if S_pad > S else True       # padded rows are never written
+
+
+# ------------------------------------------------------------------------------------------------- model-level gradients
+def _tiny():
+    from mi355_flow.engine import TransformerConfig
+    from oracle import mmditx_ref as M
+    cfg_e = TransformerConfig(num_layers=3, num_heads=2, joint_attention_dim=128, pooled_projection_dim=128, pos_embed_max_size=24,
+                              dual_layers=(0, 1))
+    cfg_o = M.tiny_config(num_layers=3, num_heads=2, dual_layers=(0, 1), joint_attention_dim=128, pooled_projection_dim=128,
+                          pos_embed_max_size=24)
+    return cfg_e, cfg_o
+
+
+def _build(train_filter, seed=3, std=0.08):
+    """torch module with HF-named parameters (bf16-representable fp32 values) + the standalone adapter bound to it."""
+    from mi355_flow.adapter import SD3_5NativeAdapter
+    from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
+    from mi355_flow.weights import expected_shapes
+    cfg_e, cfg_o = _tiny()
+    mod = PF.build_module_tree(expected_shapes(cfg_e), seed=seed, std=std).cuda()
+    with torch.no_grad():
+        for prm in mod.parameters():
+            prm.copy_(prm.bfloat16().float())
+        for n, b in mod.named_buffers():
+            b.copy_(b.bfloat16().float())
+    for n, prm in mod.named_parameters():
+        prm.requires_grad_(train_filter(n))
+    sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=1, seed=42, shift=3.0)
+    ad = SD3_5NativeAdapter(mod, cfg_e, sched, latent_storage_dtype="fp16")
+    ad.rollout()
+    return ad, mod, cfg_o
+
+
+BLOCK_LINEARS = (".attn.to_q.", ".attn.to_k.", ".attn.to_v.", ".attn.to_out.0.", ".attn.add_q_proj.", ".attn.add_k_proj.", ".attn.add_v_proj.",
+                 ".attn.to_add_out.", ".attn2.to_q.", ".attn2.to_k.", ".attn2.to_v.", ".attn2.to_out.0.", ".ff.net.0.proj.", ".ff.net.2.",
+                 ".ff_context.net.0.proj.", ".ff_context.net.2.")
+
+
+def _inputs(B, h, w, Nt, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda *s: torch.randn(*s, generator=g)
+    return dict(x=mk(B, 16, h, w).half(), x1=mk(B, 16, h, w).half(), pe=mk(B, Nt, 128).bfloat16(), pp=mk(B, 128).bfloat16(),
+                ne=mk(B, Nt, 128).bfloat16(), npl=mk(B, 128).bfloat16(), wlp=mk(B), wnp=mk(B, 16, h, w))
+
+
+def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w):
+    """The same loss through the fp32 oracle network + the Flow-SDE step written in differentiable torch (CPU)."""
+    from oracle import mmditx_ref as M
+    sd = {n: p_.detach().cpu().float().requires_grad_(p_.requires_grad) for n, p_ in list(mod.named_parameters()) + list(mod.named_buffers())}
+    x, x1 = inp["x"].float(), inp["x1"].float()
+    B = x.shape[0]
+    tt = torch.full((B,), float(torch.tensor(t).half()))            # the network sees t rounded to the latent dtype (sd3_5.py:394)
+    if guidance > 1.0:
+        v2 = M.mmdit_forward(sd, cfg_o, torch.cat([x, x]), torch.cat([tt, tt]), torch.cat([inp["ne"], inp["pe"]]).float(),
+                             torch.cat([inp["npl"], inp["pp"]]).float())
+        vu, vt = v2.chunk(2)
+        v = vu + guidance * (vt - vu)
+    else:
+        v = M.mmdit_forward(sd, cfg_o, x, tt, inp["pe"].float(), inp["pp"].float())
+    sigma, sigma_n = t / 1000.0, t_next / 1000.0
+    dt = sigma_n - sigma
+    std = math.sqrt(sigma / (1 - (sigma_max if sigma == 1.0 else sigma))) * eta
+    mean = x * (1 + std ** 2 / (2 * sigma) * dt) + v * (1 + std ** 2 * (1 - sigma) / (2 * sigma)) * dt
+    sv = std * math.sqrt(-dt)
+    lp = (-((x1 - mean) ** 2) / (2 * sv ** 2) - math.log(sv) - math.log(math.sqrt(2 * math.pi))).mean(dim=(1, 2, 3))
+    loss = (inp["wlp"] * lp).sum() + kl_w * (inp["wnp"] * v).mean()
+    loss.backward()
+    return lp.detach(), {n: s.grad for n, s in sd.items() if s.requires_grad}
+
+
+@pytest.mark.parametrize("guidance", [1.0, 4.5])
+def test_replay_gradients_match_oracle_autograd_and_ratio_is_one(gpu, guidance):
+    ad, mod, cfg_o = _build(lambda n: any(k in n for k in BLOCK_LINEARS))
+    B, h, w, Nt = 2, 16, 16, 13
+    inp = _inputs(B, h, w, Nt, seed=5)
+    t, t_next, eta, smax = 900.0, 750.0, 0.7, 0.9
+    ad.scheduler.set_timesteps(4)
+    cfg_on = guidance > 1.0
+    kw = dict(t=torch.full((B,), t), t_next=torch.full((B,), t_next), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+              prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(),
+              negative_prompt_embeds=inp["ne"].cuda() if cfg_on else None, negative_pooled_prompt_embeds=inp["npl"].cuda() if cfg_on else None,
+              guidance_scale=guidance, noise_level=eta, compute_log_prob=True, return_kwargs=["log_prob", "noise_pred", "dt"])
+    ad.scheduler.sigmas = ad.scheduler.sigmas.clone()
+    ad.scheduler.sigmas[1] = smax
+    with torch.no_grad():
+        ref_out = ad.forward(**kw)                      # the no-grad replay (what round 1 shipped)
+    out = ad.forward(**kw)                              # grad mode: the engine's differentiable step
+    assert out.log_prob.requires_grad and out.noise_pred.requires_grad
+    assert torch.equal(out.log_prob.detach(), ref_out.log_prob)          # ratio == exp(0) == 1.0 EXACTLY in grad mode
+    assert torch.equal(out.noise_pred.detach(), ref_out.noise_pred)
+    kl_w = 3.0
+    loss = (inp["wlp"].cuda() * out.log_prob).sum() + kl_w * (inp["wnp"].cuda() * out.noise_pred).mean()
+    loss.backward()
+    lp_ref, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w)
+    np.testing.assert_allclose(out.log_prob.detach().cpu().numpy(), lp_ref.numpy(), rtol=5e-3)
+    worst, worst_name, n = 0.0, None, 0
+    for name, prm in mod.named_parameters():
+        if not prm.requires_grad:
+            assert prm.grad is None
+            continue
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
+        ref = g_ref[name]
+        if float(ref.norm()) < 1e-12:                   # e.g. add_q_proj of the context-pre-only last block: exactly zero both sides
+            assert float(prm.grad.float().norm()) < 1e-6, name
+            continue
+        r = _rel(prm.grad, ref)
+        n += 1
+        if r > worst:
+            worst, worst_name = r, name
+        assert r < 5e-2 and _cos(prm.grad, ref) > 0.995, (name, r, _cos(prm.grad, ref))
+    print(f"guidance {guidance}: {n} parameter gradients vs fp32 oracle autograd, worst rel-L2 {worst:.3e} ({worst_name})")
+    assert n >= 60
+    ad.engine.close()
+
+
+def test_gradients_ragged_shapes_and_partial_trainable_set(gpu):
+    """Odd batch, non-square grid, text length not a multiple of anything; only the attention projections of the image stream are
+    trainable (the reference's default target modules, models/abc.py:382-385): frozen parameters get no gradient."""
+    targets = (".to_q.", ".to_k.", ".to_v.", ".to_out.0.")
+    ad, mod, cfg_o = _build(lambda n: any(k in n for k in targets), seed=9)
+    B, h, w, Nt = 3, 8, 24, 5
+    inp = _inputs(B, h, w, Nt, seed=11)
+    t, t_next, eta, smax = 750.0, 500.0, 0.7, 0.9
+    ad.scheduler.set_timesteps(4)
+    ad.scheduler.sigmas = ad.scheduler.sigmas.clone()
+    ad.scheduler.sigmas[1] = smax
+    kw = dict(t=torch.full((B,), t), t_next=torch.full((B,), t_next), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+              prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(), guidance_scale=1.0, noise_level=eta,
+              compute_log_prob=True, return_kwargs=["log_prob", "dt"])
+    out = ad.forward(**kw)
+    (inp["wlp"].cuda() * out.log_prob).sum().backward()
+    _, g_ref = _oracle_loss(mod, cfg_o, inp, 1.0, t, t_next, eta, smax, 0.0)
+    n = 0
+    for name, prm in mod.named_parameters():
+        if prm.requires_grad:
+            assert _rel(prm.grad, g_ref[name]) < 5e-2, (name, _rel(prm.grad, g_ref[name]))
+            n += 1
+        else:
+            assert prm.grad is None
+    assert n == 2 * 4 * (3 + 2)          # weight + bias of 4 projections in attn (3 blocks) and attn2 (2 dual blocks)
+    # a weight update is seen by the next replay (weights are live) and the backward keeps working
+    lp0 = out.log_prob.detach().clone()
+    opt = torch.optim.SGD([p_ for p_ in mod.parameters() if p_.requires_grad], lr=5e-2)
+    opt.step()
+    opt.zero_grad()
+    out2 = ad.forward(**kw)
+    assert not torch.equal(out2.log_prob.detach(), lp0)
+    out2.log_prob.sum().backward()
+    assert all(torch.isfinite(p_.grad).all() for p_ in mod.parameters() if p_.requires_grad)
+    ad.engine.close()
+
+
+def test_lora_gradients_flow_through_the_merged_weight(gpu):
+    ad, mod, cfg_o = _build(lambda n: False, seed=21)
+    PF.wrap_lora(mod)
+    mod.cuda()
+    for n, prm in mod.named_parameters():
+        prm.requires_grad_("lora_" in n)
+    ad._live_weights.invalidate()
+    ad._live_weights._root_id = None            # the module tree changed: re-resolve
+    B, h, w, Nt = 2, 16, 16, 13
+    inp = _inputs(B, h, w, Nt, seed=2)
+    ad.scheduler.set_timesteps(4)
+    kw = dict(t=torch.full((B,), 900.0), t_next=torch.full((B,), 750.0), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+              prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(), guidance_scale=1.0, noise_level=0.7,
+              compute_log_prob=True, return_kwargs=["log_prob", "dt"])
+    out = ad.forward(**kw)
+    (inp["wlp"].cuda() * out.log_prob).sum().backward()
+    lay = mod.get_submodule("transformer_blocks.1.attn.to_q")
+    A, Bm = lay.lora_A["default"].weight, lay.lora_B["default"].weight
+    assert A.grad is not None and Bm.grad is not None and lay.base_layer.weight.grad is None
+    assert float(A.grad.norm()) > 0 and float(Bm.grad.norm()) > 0
+    # dense check: make the merged weight itself a leaf, take its gradient, apply the chain rule by hand
+    from mi355_flow import autograd as AG
+    pairs = dict(AG.trainable_sources(ad._live_weights))
+    src = pairs["transformer_blocks.1.attn.to_q.weight"]
+    Wm = AG._materialise_with_grad(src, 1.0).detach().requires_grad_(True)
+    names = list(pairs)
+    ws = [AG._materialise_with_grad(s, 1.0).detach().requires_grad_(n_ == "transformer_blocks.1.attn.to_q.weight") for n_, s in pairs.items()]
+    ws[names.index("transformer_blocks.1.attn.to_q.weight")] = Wm
+    plan = ad.engine.plan(B, 1, h, w, Nt, 1)
+    t32 = torch.full((B,), 900.0)
+    call = dict(latents=inp["x"].cuda(), timestep=t32, enc_a=inp["pe"].cuda(), pooled_a=inp["pp"].cuda(), enc_b=None, pooled_b=None, guidance=1.0,
+                sigma=torch.full((B,), 0.9), sigma_next=torch.full((B,), 0.75), eta=torch.full((B,), 0.7), sigma_max=float(ad.scheduler.sigmas[1]),
+                dynamics="Flow-SDE", next_latents=inp["x1"].cuda(), compute_log_prob=True)
+    lp = AG._DenoiseReplayFn.apply(ad, plan, names, call, *ws)[0]
+    (inp["wlp"].cuda() * lp).sum().backward()
+    s = lay.scaling["default"]
+    assert _rel(Bm.grad, s * (Wm.grad @ A.detach().t())) < 2e-2
+    assert _rel(A.grad, s * (Bm.detach().t() @ Wm.grad)) < 2e-2
+    ad.engine.close()
+
+
+def test_unsupported_trainable_set_raises_standalone(gpu):
+    ad, mod, cfg_o = _build(lambda n: n.endswith("norm1.linear.weight"))
+    B, h, w, Nt = 1, 8, 8, 4
+    inp = _inputs(B, h, w, Nt)
+    ad.scheduler.set_timesteps(4)
+    with pytest.raises(NotImplementedError, match="outside the native backward"):
+        ad.forward(t=torch.full((B,), 900.0), t_next=torch.full((B,), 750.0), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+                   prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(), guidance_scale=1.0, noise_level=0.7)
+    ad.engine.close()
