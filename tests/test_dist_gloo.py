@@ -82,3 +82,60 @@ def test_bench_self_launches_n_ranks_and_aggregates():
     wall = j["ms_per_step"] * 1e-3 * 2
     assert wall >= 0.05 * 2 * 2 * 0.99                    # the slow rank (2 x 0.1 s) bounds the job: MAX over ranks
     assert abs(j["value"] - 4 * 10 * 2 * 2 / wall) < 0.02 * j["value"]      # whole-job aggregate over both ranks
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mi355_flow import autograd as AG
+    torch.manual_seed(0)
+    mod = torch.nn.Sequential(torch.nn.Linear(4, 3), torch.nn.Linear(3, 2))
+    mod[0].bias.requires_grad_(False)                       # a frozen parameter: not in the reducer
+    ddp = torch.nn.parallel.DistributedDataParallel(mod)
+    params = [p for p in mod.parameters() if p.requires_grad]
+
+    class EngineLike(torch.autograd.Function):              # gradients come from outside torch, like _DenoiseReplayFn's
+        @staticmethod
+        def forward(ctx, scale, *ws):
+            ctx.scale, ctx.shapes = scale, [w.shape for w in ws]
+            return torch.zeros(())
+
+        @staticmethod
+        def backward(ctx, g):
+            return (None,) + tuple(torch.full(s, float(ctx.scale)) * g for s in ctx.shapes)
+
+    found = AG._ddp_of(ddp)
+    assert found is ddp
+    found._pre_forward()
+    out = EngineLike.apply(float(rank + 1), *params)
+    found._post_forward(out)
+    out.backward()
+    ok = all(torch.allclose(p.grad, torch.full_like(p.grad, (1.0 + 2.0) / 2)) for p in params) and mod[0].bias.grad is None
+    # gradient accumulation: no all-reduce inside no_sync()
+    for p in params:
+        p.grad = None
+    with ddp.no_sync():
+        found._pre_forward()
+        out = EngineLike.apply(float(rank + 1), *params)
+        found._post_forward(out)
+        out.backward()
+    ok = ok and all(torch.allclose(p.grad, torch.full_like(p.grad, float(rank + 1))) for p in params)
+    np.save(os.path.join(out_dir, f"ddp_{rank}.npy"), np.array([int(ok)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_reducer_is_armed_around_the_engine_autograd_node(tmp_path):
+    """north star: "gradient all-reduce on RCCL for the policy update".  The engine's autograd node bypasses `module.forward`, so
+    `mi355_flow.autograd.denoise_replay` arms DDP's reducer itself (`_pre_forward` / `_post_forward`, what DDP.forward does): the
+    gradients the node returns are then bucket-all-reduced (here on gloo; `nccl` = RCCL on the GPUs) exactly like ordinary ones, and
+    `no_sync()` accumulation windows (accelerator.accumulate, trainers/grpo.py:236) skip the reduction."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(int(np.load(tmp_path / f"ddp_{r}.npy")[0]) == 1 for r in range(2))
