@@ -216,16 +216,37 @@ __global__ __launch_bounds__(256) void rms_bwd_gather_kernel(RmsBwdParams p) {
 }
 
 // ------------------------------------------------------------------ bias gradient: db[n] (+)= sum_m dY[m][n]
-// grid.x = column chunks of 256 (one column per thread, coalesced rows), grid.y = row slabs; slab partials are summed in a fixed
-// order by the last-arriving workgroup-free second launch (colsum_finish): deterministic
+// workgroup = 32 column groups (8 columns, one 16-byte load each) x 8 row lanes over one row slab; slab partials are summed in a fixed
+// order by a second launch (colsum_finish): deterministic.  N % 8 == 0 and ld % 8 == 0 take the vector path.
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* dy, long ld, long M, int N, float* part, int nslab) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float red[8][256];
+    const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int n0 = blockIdx.x * 256 + cg * 8;
     const long per = (M + nslab - 1) / nslab;
     const long lo = blockIdx.y * per, hi = lo + per < M ? lo + per : M;
-    float s = 0.f;
-    for (long m = lo; m < hi; ++m) s += bf2f(dy[m * ld + n]);
-    part[(long)blockIdx.y * N + n] = s;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (n0 + 8 <= N && (ld & 7) == 0) {
+        for (long m = lo + rl; m < hi; m += 8) {
+            float a[8];
+            unpack8(*(const uint4*)(dy + m * ld + n0), a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += a[e];
+        }
+    } else {
+        for (long m = lo + rl; m < hi; m += 8)
+            for (int e = 0; e < 8; ++e)
+                if (n0 + e < N) s[e] += bf2f(dy[m * ld + n0 + e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = s[e];
+    __syncthreads();
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += red[r][threadIdx.x];
+        part[(long)blockIdx.y * N + n] = t;
+    }
 }
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* part, int nslab, int N, float* out, int accumulate) {
     const int n = blockIdx.x * 256 + threadIdx.x;
@@ -376,7 +397,7 @@ hipError_t launch_rms_bwd_gather(const RmsBwdParams& p, hipStream_t st) {
 }
 
 hipError_t launch_colsum(const bf16_t* dy, long ld, long M, int N, float* scratch, float* out, int accumulate, hipStream_t st) {
-    const int nslab = (int)(M >= 4096 ? 64 : (M + 63) / 64);
+    const int nslab = (int)(M >= 8192 ? 64 : (M + 127) / 128);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, nslab), dim3(256), 0, st, dy, ld, M, N, scratch, nslab);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, st, scratch, nslab, N, out, accumulate);
     return hipGetLastError();

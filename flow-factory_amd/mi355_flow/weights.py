@@ -248,3 +248,24 @@ def wan_forward_flops(cfg, S: int, Nt: int) -> float:
     per_layer = S * (4 * D * D) + 2 * S * S * D + S * 2 * D * D + Nt * 2 * D * D + 2 * S * Nt * D + S * 2 * D * Fd
     emb = S * cfg.in_channels * 4 * D + S * D * cfg.out_channels * 4 + Nt * cfg.text_dim * D + Nt * D * D
     return 2.0 * (cfg.num_layers * per_layer + emb)
+
+
+# --------------------------------------------------------------------------------- torch module with HF parameter names
+def module_from_state_dict(state_dict: Dict[str, torch.Tensor], buffers: Tuple[str, ...] = ("pos_embed.pos_embed",)) -> torch.nn.Module:
+    """A parameter-only `nn.Module` tree whose attribute paths / `named_parameters()` are exactly the keys of `state_dict`
+    (e.g. `transformer_blocks.3.attn.to_q.weight`).  It has no forward: the engine is the forward.  Bound to a standalone adapter
+    (`SD3_5NativeAdapter(module, ...)`) it gives optimizers, DDP, LoRA wrappers and checkpoints something to hold on to, and
+    grad-mode `adapter.forward()` differentiates w.r.t. whichever of its parameters have `requires_grad` (mi355_flow/autograd.py)."""
+    root = torch.nn.Module()
+    for name, value in state_dict.items():
+        parts = name.split(".")
+        mod = root
+        for p in parts[:-1]:
+            if not hasattr(mod, p):
+                mod.add_module(p, torch.nn.Module())
+            mod = getattr(mod, p)
+        if name in buffers:
+            mod.register_buffer(parts[-1], value)
+        else:
+            mod.register_parameter(parts[-1], torch.nn.Parameter(value, requires_grad=False))
+    return root

@@ -116,3 +116,55 @@ def test_config_b_forward_1024_vs_oracle(full):
     y2 = plan2.transformer_forward(torch.cat([x, x]).cuda(), t.repeat(2).cuda(), torch.cat([enc, enc]).cuda(),
                                    torch.cat([pooled, pooled]).cuda())
     assert _rel(y2[0:1], ref) < 3e-2 and _rel(y2[1:2], ref) < 3e-2
+
+
+def test_config_a_replay_gradients_vs_oracle_autograd(full):
+    """SURVEY.md 8(f) N1 at the real geometry: the differentiable replay step on full SD3.5-medium (256^2, B = 1) -- grad-mode log-prob
+    bit-identical to the no-grad replay (ratio == 1), weight gradients of the attention projections of blocks 0 / 12 / 23 (the
+    reference's default target modules, models/abc.py:382-385) vs torch autograd through the fp32 oracle on the host cores."""
+    from mi355_flow.adapter import SD3_5NativeAdapter
+    from mi355_flow.engine import TransformerConfig
+    from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
+    from mi355_flow.weights import module_from_state_dict
+    from test_gpu_backward import _cos, _inputs, _oracle_loss
+    e, sd, cfg = full
+    mod = module_from_state_dict({k: v.clone().cuda() for k, v in sd.items()})          # fp32 master copy of the bf16-rounded values
+    picks = ("transformer_blocks.0.", "transformer_blocks.12.", "transformer_blocks.23.")
+    for n, p in mod.named_parameters():
+        p.requires_grad_(n.startswith(picks) and any(k in n for k in (".to_q.", ".to_k.", ".to_v.", ".to_out.0.")))
+    sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=1, seed=42, shift=3.0)
+    ad = SD3_5NativeAdapter(mod, TransformerConfig(), sched, latent_storage_dtype="fp16")
+    ad.rollout()
+    try:
+        B, h, w = 1, 32, 32
+        g = torch.Generator().manual_seed(77)
+        inp = dict(x=torch.randn(B, 16, h, w, generator=g).half(), pe=torch.randn(B, N_TEXT, 4096, generator=g).bfloat16(),
+                   pp=torch.randn(B, 2048, generator=g).bfloat16(), wlp=torch.ones(B), wnp=torch.zeros(B, 16, h, w))
+        t, t_next, eta, smax = 900.0, 750.0, 0.7, 0.9
+        sched.set_timesteps(4)
+        # a plausible stored transition: x' = mean + noise comes from the engine's own rollout step
+        with torch.no_grad():
+            o0 = ad.forward(t=torch.full((B,), t), t_next=torch.full((B,), t_next), latents=inp["x"].cuda(), prompt_embeds=inp["pe"].cuda(),
+                            pooled_prompt_embeds=inp["pp"].cuda(), guidance_scale=1.0, noise_level=eta, return_kwargs=["next_latents", "log_prob"])
+        inp["x1"] = o0.next_latents.half().cpu()
+        kw = dict(t=torch.full((B,), t), t_next=torch.full((B,), t_next), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+                  prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(), guidance_scale=1.0, noise_level=eta,
+                  compute_log_prob=True, return_kwargs=["log_prob", "dt"])
+        with torch.no_grad():
+            ref = ad.forward(**kw)
+        out = ad.forward(**kw)
+        assert torch.equal(out.log_prob.detach(), ref.log_prob) and torch.equal(ref.log_prob, o0.log_prob)      # rollout == replay == grad replay
+        out.log_prob.sum().backward()
+        lp_ref, g_ref = _oracle_loss(mod, cfg, inp, 1.0, t, t_next, eta, smax, 0.0)
+        np.testing.assert_allclose(out.log_prob.detach().cpu().numpy(), lp_ref.numpy(), rtol=1e-3)
+        worst, n = 0.0, 0
+        for name, prm in mod.named_parameters():
+            if not prm.requires_grad:
+                continue
+            r = _rel(prm.grad, g_ref[name])
+            worst, n = max(worst, r), n + 1
+            assert r < 6e-2 and _cos(prm.grad, g_ref[name]) > 0.99, (name, r)
+        print(f"full SD3.5-medium replay gradients: {n} tensors, worst rel-L2 vs fp32 oracle autograd {worst:.3e}")
+        assert n == 8 * 3 + 8 * 2
+    finally:
+        ad.engine.close()
