@@ -590,7 +590,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
     int tile_i = 0, t = 0, par = 0;
     long long* trc = nullptr;
     if (p.trace && (wave == 0 || wave == 4) && lane == 0) trc = p.trace + ((long)blockIdx.x * 16 * 2 + grp) * 4;
-    if (trc) { trc[0] = __builtin_amdgcn_s_memtime(); trc[1] = trc[0]; }
+    long long* trc_wall = trc ? trc + 15 * 8 : nullptr;   // slot 15: s_memrealtime (100 MHz, one time base for the whole device) at WG start / end
+    if (trc) { trc[0] = __builtin_amdgcn_s_memtime(); trc[1] = trc[0]; trc_wall[0] = __builtin_amdgcn_s_memrealtime(); }
 #define PP_EPILOGUE(SB)                                                                                        \
     do {                                                                                                          \
         /* no wave has an LDS read of this stage pending here (P3 reads nothing; every wave's P2 reads were  */  \
@@ -674,6 +675,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
         PP_BARRIER(); PP_MFMA(1, 0);
         if (grp == 0) PP_BARRIER();  // pairs with group 1's barrier in front of its last MFMA cluster
         PP_EPILOGUE(sb);
+        if (trc_wall) trc_wall[3] = __builtin_amdgcn_s_memrealtime();
     }
 #undef PP_EPILOGUE
 #undef PP_BARRIER
