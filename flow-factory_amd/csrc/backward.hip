@@ -22,77 +22,117 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
 //                           dx = rstd * (g - mean(g) - xhat * mean(g * xhat))          (no affine LN weight)
 // dx is ADDED to dres (the residual-stream gradient arriving from later layers) when accumulate != 0.
 template <int LN_MAXC>
-__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(LnModBwdParams p) {
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(LnModBwdParams p, int rows_per_wave) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.M) return;
+    const int first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rows_per_wave;
+    if (first >= p.M) return;
+    const int last = first + rows_per_wave < p.M ? first + rows_per_wave : p.M;
     const int nchunk = p.D >> 3;
-    const int b = row / p.rows_per_sample;
-    const bf16_t* mod = p.mod + (long)b * p.mod_ld;
-    float v[LN_MAXC][8], g[LN_MAXC][8];
-    float sum = 0.f;
-    const long ro = (long)row * p.D;
+    // optional per-sample gradients of the modulation vectors: column partials over this wave's rows live in registers and are flushed
+    // with fp32 atomics when the sample changes / at the end (rows_per_wave x fewer atomics than elements; summation order not fixed)
+    float ash[LN_MAXC][8], asc[LN_MAXC][8], ash2[LN_MAXC][8], asc2[LN_MAXC][8];
+    int cur_b = first / p.rows_per_sample;
+    auto zero_acc = [&]() {
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-        const int ch = lane + c * 64;
-        if (ch < nchunk) {
-            unpack8(*(const uint4*)(p.x + ro + ch * 8), v[c]);
+        for (int c = 0; c < LN_MAXC; ++c)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sum += v[c][e];
-        }
-    }
-    const float mean = wave_sum(sum) / (float)p.D;
-    float sq = 0.f;
+            for (int e = 0; e < 8; ++e) { ash[c][e] = 0.f; asc[c][e] = 0.f; ash2[c][e] = 0.f; asc2[c][e] = 0.f; }
+    };
+    auto flush = [&](int bb) {
+        float* dm = p.dmod + (long)bb * p.mod_ld;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-        const int ch = lane + c * 64;
-        if (ch < nchunk) {
+        for (int c = 0; c < LN_MAXC; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nchunk) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { v[c][e] -= mean; sq += v[c][e] * v[c][e]; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
-    float sg = 0.f, sgx = 0.f;
-#pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-        const int ch = lane + c * 64;
-        if (ch < nchunk) {
-            float d1[8], s1[8];
-            unpack8(*(const uint4*)(p.dy + ro + ch * 8), d1);
-            unpack8(*(const uint4*)(mod + p.scale_off + ch * 8), s1);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) g[c][e] = d1[e] * (1.f + s1[e]);
-            if (p.dy2) {
-                unpack8(*(const uint4*)(p.dy2 + ro + ch * 8), d1);
-                unpack8(*(const uint4*)(mod + p.scale2_off + ch * 8), s1);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) g[c][e] += d1[e] * (1.f + s1[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                v[c][e] *= rstd;                         // xhat
-                sg += g[c][e];
-                sgx += g[c][e] * v[c][e];
+                for (int e = 0; e < 8; ++e) {
+                    unsafeAtomicAdd(dm + p.shift_off + ch * 8 + e, ash[c][e]);
+                    unsafeAtomicAdd(dm + p.scale_off + ch * 8 + e, asc[c][e]);
+                    if (p.dy2) {
+                        unsafeAtomicAdd(dm + p.shift2_off + ch * 8 + e, ash2[c][e]);
+                        unsafeAtomicAdd(dm + p.scale2_off + ch * 8 + e, asc2[c][e]);
+                    }
+                }
             }
         }
-    }
-    const float mg = wave_sum(sg) / (float)p.D, mgx = wave_sum(sgx) / (float)p.D;
+    };
+    if (p.dmod) zero_acc();
+    for (int row = first; row < last; ++row) {
+        const int b = row / p.rows_per_sample;
+        if (p.dmod && b != cur_b) { flush(cur_b); zero_acc(); cur_b = b; }
+        const bf16_t* mod = p.mod + (long)b * p.mod_ld;
+        float v[LN_MAXC][8], g[LN_MAXC][8];
+        float sum = 0.f;
+        const long ro = (long)row * p.D;
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-        const int ch = lane + c * 64;
-        if (ch < nchunk) {
-            float o[8];
+        for (int c = 0; c < LN_MAXC; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nchunk) {
+                unpack8(*(const uint4*)(p.x + ro + ch * 8), v[c]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = rstd * (g[c][e] - mg - v[c][e] * mgx);
-            if (p.accumulate) {
-                float r[8];
-                unpack8(*(const uint4*)(p.dres + ro + ch * 8), r);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] += r[e];
+                for (int e = 0; e < 8; ++e) sum += v[c][e];
             }
-            *(uint4*)(p.dres + ro + ch * 8) = pack8(o);
+        }
+        const float mean = wave_sum(sum) / (float)p.D;
+        float sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < LN_MAXC; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nchunk) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { v[c][e] -= mean; sq += v[c][e] * v[c][e]; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)p.D + p.eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int c = 0; c < LN_MAXC; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nchunk) {
+                float d1[8], s1[8];
+                unpack8(*(const uint4*)(p.dy + ro + ch * 8), d1);
+                unpack8(*(const uint4*)(mod + p.scale_off + ch * 8), s1);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[c][e] *= rstd;                         // xhat
+                    g[c][e] = d1[e] * (1.f + s1[e]);
+                    if (p.dmod) { ash[c][e] += d1[e]; asc[c][e] += d1[e] * v[c][e]; }
+                }
+                if (p.dy2) {
+                    unpack8(*(const uint4*)(p.dy2 + ro + ch * 8), d1);
+                    unpack8(*(const uint4*)(mod + p.scale2_off + ch * 8), s1);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        g[c][e] += d1[e] * (1.f + s1[e]);
+                        if (p.dmod) { ash2[c][e] += d1[e]; asc2[c][e] += d1[e] * v[c][e]; }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    sg += g[c][e];
+                    sgx += g[c][e] * v[c][e];
+                }
+            }
+        }
+        const float mg = wave_sum(sg) / (float)p.D, mgx = wave_sum(sgx) / (float)p.D;
+#pragma unroll
+        for (int c = 0; c < LN_MAXC; ++c) {
+            const int ch = lane + c * 64;
+            if (ch < nchunk) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rstd * (g[c][e] - mg - v[c][e] * mgx);
+                if (p.accumulate) {
+                    float r[8];
+                    unpack8(*(const uint4*)(p.dres + ro + ch * 8), r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += r[e];
+                }
+                *(uint4*)(p.dres + ro + ch * 8) = pack8(o);
+            }
         }
     }
+    if (p.dmod) flush(cur_b);
 }
 
 // ------------------------------------------------------------------ gated residual backward
@@ -110,6 +150,54 @@ __global__ __launch_bounds__(256) void gate_mul_kernel(const bf16_t* dx, const b
         for (int e = 0; e < 8; ++e) a[e] *= gt[e];
         *(uint4*)(dy + m * D + ch * 8) = pack8(a);
     }
+}
+
+// gate_mul + d gate: workgroup = 64 rows x 256 columns-of-8 ... thread t owns 8 columns (one 16-byte chunk) of a 64-row slab of ONE sample
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const bf16_t* dx, const bf16_t* gate, long gate_ld, const bf16_t* y, bf16_t* dy, float* dgate,
+                                                       long dg_ld, long M, int D, int rps) {
+    const int chunks = D >> 3;
+    const int ch = blockIdx.x * 256 + threadIdx.x;
+    if (ch >= chunks) return;
+    const long r0 = (long)blockIdx.y * 64, r1 = r0 + 64 < M ? r0 + 64 : M;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    long cur_b = r0 / rps;
+    for (long m = r0; m < r1; ++m) {
+        const long b = m / rps;
+        if (b != cur_b) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { unsafeAtomicAdd(dgate + cur_b * dg_ld + ch * 8 + e, acc[e]); acc[e] = 0.f; }
+            cur_b = b;
+        }
+        float a[8], gt[8], yy[8];
+        unpack8(*(const uint4*)(dx + m * D + ch * 8), a);
+        unpack8(*(const uint4*)(gate + b * gate_ld + ch * 8), gt);
+        unpack8(*(const uint4*)(y + m * D + ch * 8), yy);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { acc[e] += a[e] * yy[e]; a[e] *= gt[e]; }
+        *(uint4*)(dy + m * D + ch * 8) = pack8(a);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) unsafeAtomicAdd(dgate + cur_b * dg_ld + ch * 8 + e, acc[e]);
+}
+
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const bf16_t* dy, const bf16_t* pre, bf16_t* dx, long n8) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        float a[8], x[8];
+        unpack8(*(const uint4*)(dy + i * 8), a);
+        unpack8(*(const uint4*)(pre + i * 8), x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float sg = fast_rcp(1.0f + __expf(-x[e]));
+            a[e] *= sg * (1.0f + x[e] * (1.0f - sg));
+        }
+        *(uint4*)(dx + i * 8) = pack8(a);
+    }
+}
+
+__global__ __launch_bounds__(256) void f32_to_bf16_pad_kernel(const float* in, bf16_t* out, long rows, long rows_pad, long cols) {
+    const long total = rows_pad * cols;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        out[i] = (i / cols) < rows ? f2bf(in[i]) : (bf16_t)0;
 }
 
 // hid = gelu_tanh(pre): recomputes the MLP hidden activation (the A operand of the ff2 weight gradient) from the stashed pre-activation
@@ -183,36 +271,59 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnBwdPrepParams p)
 // of the image stream (s < n_img) and the context stream.  forward: y = x * r * w  (x = projection + bias, r = 1/rms over the head's 64
 // features; for q, w already carries the folded softmax scale):  xhat = y / w,  g = dy * w,  dx = r * (g - xhat * mean(g * xhat)).
 // One wave per token, lane = feature d, loop over heads.
-__global__ __launch_bounds__(256) void rms_bwd_gather_kernel(RmsBwdParams p) {
-    const int lane = threadIdx.x & 63;
-    const long tok = blockIdx.x * 4L + (threadIdx.x >> 6);     // b * S + s
-    if (tok >= (long)p.B * p.S) return;
-    const int b = (int)(tok / p.S), s = (int)(tok - (long)b * p.S);
-    const bool img = s < p.n_img;
-    const int n_ctx = p.S - p.n_img;
-    const long row = img ? ((long)b * p.n_img + s) : ((long)b * n_ctx + (s - p.n_img));
-    bf16_t* out = (img ? p.out_img : p.out_ctx) + row * (3L * p.H * 64);
-    const float* rstd = (img ? p.rstd_img : p.rstd_ctx) + row * (2L * p.H);
-    const float wq = (img ? p.nw_q : p.nw_cq)[lane] * p.q_scale, wk = (img ? p.nw_k : p.nw_ck)[lane];
+__global__ __launch_bounds__(256) void rms_bwd_gather_kernel(RmsBwdParams p, int tokens_per_wave) {
+    __shared__ float red[4][4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long total = (long)p.B * p.S;
+    const long t0 = ((long)blockIdx.x * 4 + wv) * tokens_per_wave;
+    float dwq = 0.f, dwk = 0.f, dwcq = 0.f, dwck = 0.f;         // lane = feature d: sum of dy * xhat over this wave's tokens and all heads
     const int D = p.H * 64;
-    for (int h = 0; h < p.H; ++h) {
-        const long src = (((long)b * p.H + h) * p.S_pad + s) * 64 + lane;
-        {
-            const float y = bf2f(p.q[src]), dy = bf2f(p.dq[src]);
-            const float xh = fabsf(wq) > 1e-20f ? y / wq : 0.f;
-            const float g = dy * wq;
-            const float mgx = wave_sum(g * xh) * (1.0f / 64.0f);
-            out[h * 64 + lane] = f2bf(rstd[h] * (g - xh * mgx));
+    const int n_ctx = p.S - p.n_img;
+    for (long tok = t0; tok < t0 + tokens_per_wave && tok < total; ++tok) {
+        const int b = (int)(tok / p.S), s = (int)(tok - (long)b * p.S);
+        const bool img = s < p.n_img;
+        const long row = img ? ((long)b * p.n_img + s) : ((long)b * n_ctx + (s - p.n_img));
+        bf16_t* out = (img ? p.out_img : p.out_ctx) + row * (3L * D);
+        const float* rstd = (img ? p.rstd_img : p.rstd_ctx) + row * (2L * p.H);
+        const float wq = (img ? p.nw_q : p.nw_cq)[lane] * p.q_scale, wk = (img ? p.nw_k : p.nw_ck)[lane];
+        float aq = 0.f, ak = 0.f;
+        for (int h = 0; h < p.H; ++h) {
+            const long src = (((long)b * p.H + h) * p.S_pad + s) * 64 + lane;
+            {
+                const float y = bf2f(p.q[src]), dy = bf2f(p.dq[src]);
+                const float xh = fabsf(wq) > 1e-20f ? y / wq : 0.f;
+                const float g = dy * wq;
+                const float mgx = wave_sum(g * xh) * (1.0f / 64.0f);
+                out[h * 64 + lane] = f2bf(rstd[h] * (g - xh * mgx));
+                aq += dy * xh;
+            }
+            {
+                const float y = bf2f(p.k[src]), dy = bf2f(p.dk[src]);
+                const float xh = fabsf(wk) > 1e-20f ? y / wk : 0.f;
+                const float g = dy * wk;
+                const float mgx = wave_sum(g * xh) * (1.0f / 64.0f);
+                out[D + h * 64 + lane] = f2bf(rstd[p.H + h] * (g - xh * mgx));
+                ak += dy * xh;
+            }
+            out[2 * D + h * 64 + lane] = p.dv[src];
         }
-        {
-            const float y = bf2f(p.k[src]), dy = bf2f(p.dk[src]);
-            const float xh = fabsf(wk) > 1e-20f ? y / wk : 0.f;
-            const float g = dy * wk;
-            const float mgx = wave_sum(g * xh) * (1.0f / 64.0f);
-            out[D + h * 64 + lane] = f2bf(rstd[p.H + h] * (g - xh * mgx));
-        }
-        out[2 * D + h * 64 + lane] = p.dv[src];
+        if (img) { dwq += aq; dwk += ak; } else { dwcq += aq; dwck += ak; }
     }
+    if (p.dw_part) {      // (uniform per launch) fixed-order workgroup partials -> launch_rms_dw_finish
+        red[wv][0][lane] = dwq; red[wv][1][lane] = dwk; red[wv][2][lane] = dwcq; red[wv][3][lane] = dwck;
+        __syncthreads();
+        const int which = threadIdx.x >> 6;
+        p.dw_part[((long)blockIdx.x * 4 + which) * 64 + lane] = (red[0][which][lane] + red[1][which][lane]) + (red[2][which][lane] + red[3][which][lane]);
+    }
+}
+
+__global__ __launch_bounds__(256) void rms_dw_finish_kernel(const float* part, int nwg, float q_scale, float* dw_q, float* dw_k, float* dw_cq, float* dw_ck) {
+    const int which = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int i = 0; i < nwg; ++i) s += part[((long)i * 4 + which) * 64 + lane];
+    // y = xhat * (q_scale * w): d/dw = q_scale * sum dy * xhat for the q weights
+    float* dst = which == 0 ? dw_q : which == 1 ? dw_k : which == 2 ? dw_cq : dw_ck;
+    if (dst) dst[lane] = (which == 0 || which == 2) ? s * q_scale : s;
 }
 
 // ------------------------------------------------------------------ bias gradient: db[n] (+)= sum_m dY[m][n]
@@ -360,8 +471,29 @@ inline int grid_for(long total, int block) {
 
 hipError_t launch_ln_mod_bwd(const LnModBwdParams& p, hipStream_t st) {
     if (p.D % 8 != 0 || p.D > 8 * 64 * 8 || p.M <= 0) return hipErrorInvalidValue;
-    if (p.D <= 2048) hipLaunchKernelGGL(ln_mod_bwd_kernel<4>, dim3((p.M + 3) / 4), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(ln_mod_bwd_kernel<8>, dim3((p.M + 3) / 4), dim3(256), 0, st, p);
+    const int rpw = p.dmod ? 16 : 1;         // rows per wave: 16 with the modulation-gradient partials in registers
+    const int grid = (p.M + 4 * rpw - 1) / (4 * rpw);
+    if (p.D <= 2048) hipLaunchKernelGGL(ln_mod_bwd_kernel<4>, dim3(grid), dim3(256), 0, st, p, rpw);
+    else hipLaunchKernelGGL(ln_mod_bwd_kernel<8>, dim3(grid), dim3(256), 0, st, p, rpw);
+    return hipGetLastError();
+}
+
+hipError_t launch_gate_bwd(const bf16_t* dx, const bf16_t* gate, long gate_ld, const bf16_t* y, bf16_t* dy, float* dgate, long dg_ld, long M, int D,
+                           int rps, hipStream_t st) {
+    if (D % 8 || M <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(((D >> 3) + 255) / 256, (unsigned)((M + 63) / 64)), dim3(256), 0, st, dx, gate, gate_ld, y, dy, dgate, dg_ld,
+                       M, D, rps);
+    return hipGetLastError();
+}
+
+hipError_t launch_silu_bwd(const bf16_t* dy, const bf16_t* pre, bf16_t* dx, long n, hipStream_t st) {
+    if (n % 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(n >> 3, 256)), dim3(256), 0, st, dy, pre, dx, n >> 3);
+    return hipGetLastError();
+}
+
+hipError_t launch_f32_to_bf16_pad(const float* in, bf16_t* out, long rows, long rows_pad, long cols, hipStream_t st) {
+    hipLaunchKernelGGL(f32_to_bf16_pad_kernel, dim3(grid_for(rows_pad * cols, 256)), dim3(256), 0, st, in, out, rows, rows_pad, cols);
     return hipGetLastError();
 }
 
@@ -390,9 +522,17 @@ hipError_t launch_attn_bwd_prep(const AttnBwdPrepParams& p, hipStream_t st) {
     return hipGetLastError();
 }
 
+// tokens per wave: 1 normally, 8 when the norm-weight partials are wanted (8 x fewer partial rows to sum)
+int rms_bwd_grid(int B, int S) { return (int)(((long)B * S + 31) / 32); }
 hipError_t launch_rms_bwd_gather(const RmsBwdParams& p, hipStream_t st) {
     const long tokens = (long)p.B * p.S;
-    hipLaunchKernelGGL(rms_bwd_gather_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, st, p);
+    if (p.dw_part) hipLaunchKernelGGL(rms_bwd_gather_kernel, dim3((unsigned)rms_bwd_grid(p.B, p.S)), dim3(256), 0, st, p, 8);
+    else hipLaunchKernelGGL(rms_bwd_gather_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, st, p, 1);
+    return hipGetLastError();
+}
+
+hipError_t launch_rms_dw_finish(const float* part, int nwg, float q_scale, float* dw_q, float* dw_k, float* dw_cq, float* dw_ck, hipStream_t st) {
+    hipLaunchKernelGGL(rms_dw_finish_kernel, dim3(1), dim3(256), 0, st, part, nwg, q_scale, dw_q, dw_k, dw_cq, dw_ck);
     return hipGetLastError();
 }
 

@@ -168,8 +168,8 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
     const int frow = lane & 15, fkg = lane >> 4;
     float4 bcol[4];
     float4 nw[4];
-    if constexpr (EPI == EPI_BIAS_GELU) {
-        // training-mode forward: the pre-activation goes to the stash first (same wave-private staging, LDS ops of a wave are in order)
+    if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_GATE_RES) {
+        // training-mode forward: the pre-activation (GELU) / the un-gated projection (gated residual) goes to the stash first (same wave-private staging, LDS ops of a wave are in order)
         if (p.stash) {
 #pragma unroll
             for (int i = 0; i < NR; ++i) {

@@ -178,10 +178,20 @@ struct LnModBwdParams {
     const bf16_t* x; const bf16_t* dy; const bf16_t* dy2; bf16_t* dres;
     const bf16_t* mod; long mod_ld; int scale_off, scale2_off;
     int M, D, rows_per_sample; float eps; int accumulate;
+    // optional: gradients of the modulation vectors, ADDED (fp32 atomics) into dmod[b * mod_ld + {shift,scale}_off + d]:
+    // dshift = sum_tokens dy, dscale = sum_tokens dy * xhat  (and the same for the second modulated copy)
+    float* dmod; int shift_off, shift2_off;
 };
 hipError_t launch_ln_mod_bwd(const LnModBwdParams& p, hipStream_t stream);
 // dy[m][:] = gate[m / rps][:] * dx[m][:]
 hipError_t launch_gate_mul(const bf16_t* dx, const bf16_t* gate, long gate_ld, bf16_t* dy, long M, int D, int rps, hipStream_t stream);
+// the same plus dgate[b][n] += sum_{m in sample b} dx[m][n] * y[m][n]  (y = the stashed un-gated projection; fp32 atomics into dgate, row stride dg_ld)
+hipError_t launch_gate_bwd(const bf16_t* dx, const bf16_t* gate, long gate_ld, const bf16_t* y, bf16_t* dy, float* dgate, long dg_ld, long M, int D,
+                           int rps, hipStream_t stream);
+// dx = dy * silu'(pre)  (bf16, n % 8 == 0)
+hipError_t launch_silu_bwd(const bf16_t* dy, const bf16_t* pre, bf16_t* dx, long n, hipStream_t stream);
+// fp32 -> bf16 rows with zero padding: out[r][c] = r < rows ? in[r][c] : 0 for r < rows_pad
+hipError_t launch_f32_to_bf16_pad(const float* in, bf16_t* out, long rows, long rows_pad, long cols, hipStream_t stream);
 hipError_t launch_gelu_fwd(const bf16_t* pre, bf16_t* out, long n, hipStream_t stream);
 // out[z][c][r] = in[z][r][c] for r < rows (0 for rows <= r < rows_pad), 64 x 64 tiles through LDS
 hipError_t launch_transpose(const bf16_t* in, long ld_in, long bs_in, bf16_t* out, long ld_out, long bs_out, int rows, int cols, int rows_pad,
@@ -200,7 +210,12 @@ struct RmsBwdParams {
     float q_scale;                                         // factor folded into the stored q (softmax scale * log2 e)
     bf16_t* out_img; bf16_t* out_ctx;                      // [rows][3*H*64] = [dq_pre | dk_pre | dv]
     int B, H, S, S_pad, n_img;
+    float* dw_part;                                        // optional [gridDim.x][4][64]: per-workgroup partial RMSNorm-weight gradients
+                                                           // (norm_q, norm_k, norm_added_q, norm_added_k), summed by launch_rms_dw_finish
 };
+// dw[which][64] = sum over workgroups of part[wg][which][64] (fixed order); outputs may be null; q gradients are w.r.t. the UNSCALED weight
+hipError_t launch_rms_dw_finish(const float* part, int nwg, float q_scale, float* dw_q, float* dw_k, float* dw_cq, float* dw_ck, hipStream_t stream);
+int rms_bwd_grid(int B, int S);
 hipError_t launch_rms_bwd_gather(const RmsBwdParams& p, hipStream_t stream);
 // out[n] (+)= sum_m dy[m][n]; scratch >= 64 * N floats
 hipError_t launch_colsum(const bf16_t* dy, long ld, long M, int N, float* scratch, float* out, int accumulate, hipStream_t stream);

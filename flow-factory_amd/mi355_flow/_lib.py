@@ -80,6 +80,7 @@ SIGNATURES = {
                            _P, _P, _P, _P, C.POINTER(C.c_int32), _P, _P, _P, _I]),
     "mi355_engine_set_grad": (_I, [_P, C.c_char_p, _P]),
     "mi355_engine_clear_grads": (_I, [_P]),
+    "mi355_engine_set_train_scope": (_I, [_P, _I]),
     "mi355_engine_grad_supported": (_I, [_P, C.c_char_p]),
     "mi355_plan_training_bytes": (_L, [_P]),
     "mi355_denoise_step_train": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _I, _F, _I, _I, _P, _P, _P, _P, _P, _P]),

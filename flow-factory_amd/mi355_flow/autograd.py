@@ -14,9 +14,12 @@ from `output.log_prob` (+ an optional KL term from `noise_pred` / `next_latents_
     LoRA-merged) weight tensors -- so LoRA A/B gradients, DDP's bucketed all-reduce (RCCL) and DeepSpeed's hooks all see ordinary
     `.grad` flow.  Merged LoRA weights `W + s * B @ A` are built with autograd here and bound to the engine as they are.
 
-Supported trainable set: weights / biases of the linear layers inside the transformer blocks (attention projections of both
-streams, attn2, the MLPs) -- the reference's default `target_modules` for full fine-tuning and for LoRA.  Anything else trainable
-(AdaLN modulation linears, embedders, norms) makes `unsupported_reason` return a message and the caller falls back.
+Supported trainable set: every parameter of the transformer.  The default gradient scope covers the weights / biases of the linear
+layers inside the transformer blocks (attention projections of both streams, attn2, the MLPs) -- the reference's default
+`target_modules` for full fine-tuning and for LoRA; when anything else is trainable (`target_modules: all`: AdaLN modulation
+linears, q/k norm weights, timestep / pooled-text MLPs, embedders, proj_out) `denoise_replay` switches the engine to its full
+scope for that step (`mi355_engine_set_train_scope`).  `unsupported_reason` reports what cannot be differentiated natively (a
+module that is not bound, trainable tensors the engine does not know) and the caller falls back.
 """
 from __future__ import annotations
 
@@ -73,7 +76,7 @@ def unsupported_reason(host) -> Optional[str]:
     eng = host.engine
     for name, _ in pairs:
         if not eng.grad_supported(name):
-            return f"parameter '{name}' is outside the native backward's scope (linear layers of the transformer blocks)"
+            return f"parameter '{name}' is outside the native backward's scope"
     covered = _covered_tensor_ids(pairs)
     root = unwrap_module(live.get_module())
     for pname, prm in root.named_parameters():
@@ -156,6 +159,8 @@ def denoise_replay(host, plan, call: dict):
     pairs = trainable_sources(live)
     names = [n for n, _ in pairs]
     weights = [_materialise_with_grad(s, live.lora_scale) for _, s in pairs]
+    # parameters outside the blocks' linear layers (target_modules: all) need the full gradient scope: more is stashed by the forward
+    plan.engine.set_train_scope(any(plan.engine.grad_supported(n) == 2 for n in names))
     ddp = _ddp_of(live.get_module())
     if ddp is not None:
         ddp._pre_forward()                      # arms buffer sync / lazy init exactly like DDP.forward

@@ -138,8 +138,12 @@ class Engine(WeightHolder):
         self._plans: Dict[tuple, "Plan"] = {}
 
     # ---------------------------------------------------------------- weight gradients (mi355_flow/autograd.py)
-    def grad_supported(self, name: str) -> bool:
-        return self.lib.mi355_engine_grad_supported(self._h, name.encode()) == 0
+    def grad_supported(self, name: str) -> int:
+        """0 = no gradient for this parameter, 1 = in the default scope (the blocks' linear layers), 2 = in the full scope only."""
+        return {0: 1, 2: 2}.get(self.lib.mi355_engine_grad_supported(self._h, name.encode()), 0)
+
+    def set_train_scope(self, full: bool) -> None:
+        _lib.check(self.lib.mi355_engine_set_train_scope(self._h, int(bool(full))), "set_train_scope")
 
     def set_grad(self, name: str, grad: torch.Tensor) -> None:
         """Register the fp32 buffer the next backward writes d loss / d `name` into (same shape as the parameter)."""

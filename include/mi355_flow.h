@@ -138,6 +138,10 @@ int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const float* timeste
  * the linear layers inside the transformer blocks (mi355_engine_grad_supported == 0); the data gradient covers the whole network.
  * The caller re-binds the CURRENT weights before the backward if they were swapped after the forward. */
 int mi355_engine_set_grad(mi355_engine* e, const char* name, float* grad);
+/* Gradient scope of the NEXT training-mode forward: 0 (default) = the blocks' linear layers; 1 = every parameter (`target_modules: all`):
+ * AdaLN modulation linears, q/k RMSNorm weights, timestep / pooled-text MLPs, context_embedder, patch embedding, proj_out as well.  The
+ * forward then stashes the un-gated projections too.  mi355_engine_grad_supported: 0 = default scope, 2 = full scope only, 1 = never. */
+int mi355_engine_set_train_scope(mi355_engine* e, int full);
 int mi355_engine_clear_grads(mi355_engine* e);
 int mi355_engine_grad_supported(mi355_engine* e, const char* name);
 int64_t mi355_plan_training_bytes(mi355_plan* p);

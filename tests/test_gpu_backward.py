@@ -9,7 +9,9 @@ C ABI (`mi355_denoise_step_train` / `mi355_denoise_step_backward`, `mi355_op_att
     (oracle/mmditx_ref.py, differentiable) on identical bf16-rounded weights: per-parameter rel-L2 <= 5e-2 (bf16 activations and
     activation gradients through 3 blocks; the oracle is fp32 end to end), cosine >= 0.995;
   * LoRA: gradients reach lora_A / lora_B through the merged weight, equal to the chain rule applied to the dense gradient;
-  * an optimizer step changes the replay log-prob (weights are live) and the next backward still works.
+  * an optimizer step changes the replay log-prob (weights are live) and the next backward still works;
+  * full scope (`target_modules: all`): gradients of EVERY parameter (AdaLN modulation linears, norm weights, conditioning MLPs, embedders,
+    proj_out) vs the oracle.
 """
 import math
 
@@ -266,12 +268,41 @@ def test_lora_gradients_flow_through_the_merged_weight(gpu):
     ad.engine.close()
 
 
-def test_unsupported_trainable_set_raises_standalone(gpu):
-    ad, mod, cfg_o = _build(lambda n: n.endswith("norm1.linear.weight"))
-    B, h, w, Nt = 1, 8, 8, 4
-    inp = _inputs(B, h, w, Nt)
+def test_full_scope_gradients_of_every_parameter(gpu):
+    """`target_modules: all`: every parameter of the transformer trainable -- AdaLN modulation linears (per-sample token sums of d shift /
+    d scale / d gate), q/k RMSNorm weights, timestep / pooled-text MLPs, context_embedder, patch embedding, proj_out, on top of the blocks'
+    linear layers -- vs torch autograd through the fp32 oracle.  CFG on (n_cfg = 2: the conditioning path sees both prompt halves)."""
+    ad, mod, cfg_o = _build(lambda n: True, seed=13)
+    B, h, w, Nt = 2, 16, 16, 13
+    inp = _inputs(B, h, w, Nt, seed=17)
+    t, t_next, eta, smax, guidance = 900.0, 750.0, 0.7, 0.9, 3.0
     ad.scheduler.set_timesteps(4)
-    with pytest.raises(NotImplementedError, match="outside the native backward"):
-        ad.forward(t=torch.full((B,), 900.0), t_next=torch.full((B,), 750.0), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
-                   prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(), guidance_scale=1.0, noise_level=0.7)
+    kw = dict(t=torch.full((B,), t), t_next=torch.full((B,), t_next), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+              prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(), negative_prompt_embeds=inp["ne"].cuda(),
+              negative_pooled_prompt_embeds=inp["npl"].cuda(), guidance_scale=guidance, noise_level=eta, compute_log_prob=True,
+              return_kwargs=["log_prob", "noise_pred", "dt"])
+    with torch.no_grad():
+        ref_out = ad.forward(**kw)
+    out = ad.forward(**kw)
+    assert torch.equal(out.log_prob.detach(), ref_out.log_prob)          # the extra stashes do not touch the forward results
+    kl_w = 2.0
+    ((inp["wlp"].cuda() * out.log_prob).sum() + kl_w * (inp["wnp"].cuda() * out.noise_pred).mean()).backward()
+    _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w)
+    worst = {}
+    n = 0
+    for name, prm in mod.named_parameters():
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
+        ref = g_ref[name]
+        if float(ref.norm()) < 1e-12:
+            assert float(prm.grad.float().norm()) < 1e-6, name
+            continue
+        r, c = _rel(prm.grad, ref), _cos(prm.grad, ref)
+        kind = ("mod" if ".linear." in name and "norm" in name else "norm_w" if ".norm_" in name else
+                "cond" if name.startswith("time_text_embed") else "embed" if name.startswith(("pos_embed", "context_embedder", "proj_out")) else "block")
+        if r > worst.get(kind, (0.0, ""))[0]:
+            worst[kind] = (r, name)
+        assert r < 6e-2 and c > 0.99, (name, r, c)
+        n += 1
+    print("full scope:", n, "parameter gradients; worst rel-L2 per kind:", {k: f"{v[0]:.3e} ({v[1]})" for k, v in worst.items()})
+    assert n >= 80 + 3 * 4 + 16 + 8 + 6 - 4
     ad.engine.close()
