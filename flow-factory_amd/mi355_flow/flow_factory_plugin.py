@@ -57,56 +57,67 @@ class _LiveBinding:
         n = self._live_weights.sync()
         if n:
             self.engine.ready()
+        live2 = getattr(self, "_live_weights_2", None)          # Wan2.2: the second expert
+        if live2 is not None:
+            n2 = live2.sync()
+            if n2:
+                self.engine_2.ready()
+            n += n2
         return n
+
+    def _invalidate(self) -> None:
+        self._live_weights.invalidate()
+        if getattr(self, "_live_weights_2", None) is not None:
+            self._live_weights_2.invalidate()
 
     def _before_engine_call(self) -> None:     # hook of the rollout mixins (top of inference() / no-grad forward())
         self._sync_weights()
 
     # mode switches (models/abc.py:351-378)
     def rollout(self, *a, **k):
-        self._live_weights.invalidate()
+        self._invalidate()
         return super().rollout(*a, **k)
 
     def eval(self, *a, **k):
-        self._live_weights.invalidate()
+        self._invalidate()
         return super().eval(*a, **k)
 
     def train(self, *a, **k):
-        self._live_weights.invalidate()
+        self._invalidate()
         return super().train(*a, **k)
 
     # parameter-swap contexts (models/abc.py:523-531, :556-597, :660-682): in-place `.data.copy_` swaps on enter AND on exit
     @contextmanager
     def use_ema_parameters(self):
         with super().use_ema_parameters():
-            self._live_weights.invalidate()
+            self._invalidate()
             try:
                 yield
             finally:
-                self._live_weights.invalidate()
+                self._invalidate()
 
     @contextmanager
     def use_ref_parameters(self):
         with super().use_ref_parameters():
-            self._live_weights.invalidate()
+            self._invalidate()
             try:
                 yield
             finally:
-                self._live_weights.invalidate()
+                self._invalidate()
 
     @contextmanager
     def use_named_parameters(self, name: str):
         with super().use_named_parameters(name):
-            self._live_weights.invalidate()
+            self._invalidate()
             try:
                 yield
             finally:
-                self._live_weights.invalidate()
+                self._invalidate()
 
     def load_checkpoint(self, *a, **k):
         out = super().load_checkpoint(*a, **k)
         if hasattr(self, "_live_weights"):
-            self._live_weights.invalidate()
+            self._invalidate()
         return out
 
     # the engine computes in bf16 like the reference's autocast run
@@ -210,22 +221,36 @@ if _RefAdapter is not None:
         from .wan import WanConfig, WanEngine, WanRolloutMixin
 
         class Wan2T2VNativeAdapter(_LiveBinding, WanRolloutMixin, _RefWan):
-            """`Wan2_T2V_Adapter` (reference models/wan/wan2_t2v.py) with the Wan2.1 rollout on the MI355X engine (single transformer;
-            Wan2.2's `transformer_2` / `boundary_ratio` pipelines are rejected).  The video VAE is the pipeline's; evaluation-mode
-            sampling (diffusers' UniPC multistep solver) stays on the reference path."""
+            """`Wan2_T2V_Adapter` (reference models/wan/wan2_t2v.py) with the rollout on the MI355X engine: single-transformer Wan2.1, and
+            two-expert Wan2.2 pipelines (`transformer` while t >= boundary_ratio * 1000, `transformer_2` below, each with its own
+            guidance scale: wan2_t2v.py:476-487) as two engines stepped per timestep.  Per-token timesteps (`expand_timesteps`, TI2V-5B)
+            are rejected.  The video VAE is the pipeline's; evaluation-mode sampling (diffusers' UniPC multistep solver) stays on the
+            reference path."""
 
             _sample_cls = _RefWanSample
             _output_cls = _RefOutput
 
             def __init__(self, config, accelerator):
                 _RefWan.__init__(self, config, accelerator)
-                if getattr(self.pipeline.config, "boundary_ratio", None) is not None or getattr(self.pipeline, "transformer_2", None) is not None:
-                    raise ValueError("mi355_flow: two-expert Wan2.2 pipelines are not supported by the native engine")
-                tc = self.pipeline.transformer.config
-                self._init_live(WanEngine(WanConfig(
-                    in_channels=tc.in_channels, out_channels=tc.out_channels, num_layers=tc.num_layers,
-                    num_attention_heads=tc.num_attention_heads, attention_head_dim=tc.attention_head_dim, ffn_dim=tc.ffn_dim,
-                    text_dim=tc.text_dim, freq_dim=tc.freq_dim, patch_size=tuple(tc.patch_size), eps=tc.eps)))
+                if getattr(self.pipeline.config, "expand_timesteps", False):
+                    raise ValueError("mi355_flow: per-token timesteps (expand_timesteps, Wan2.2-TI2V-5B) are not supported by the native engine")
+
+                def wcfg(tc):
+                    return WanConfig(in_channels=tc.in_channels, out_channels=tc.out_channels, num_layers=tc.num_layers,
+                                     num_attention_heads=tc.num_attention_heads, attention_head_dim=tc.attention_head_dim, ffn_dim=tc.ffn_dim,
+                                     text_dim=tc.text_dim, freq_dim=tc.freq_dim, patch_size=tuple(tc.patch_size), eps=tc.eps)
+                ratio = getattr(self.pipeline.config, "boundary_ratio", None)
+                second = getattr(self.pipeline, "transformer_2", None)
+                if second is not None and ratio is not None and 0 < ratio < 1:
+                    self._init_live(WanEngine(wcfg(self.pipeline.transformer.config)))
+                    self.engine_2 = WanEngine(wcfg(second.config))
+                    self._live_weights_2 = LiveWeights(self.engine_2, lambda: self.transformer_2)
+                    self.boundary_ratio = float(ratio)
+                elif second is not None and ratio is not None and ratio >= 1:        # only the low-noise expert is ever used
+                    self._init_live(WanEngine(wcfg(second.config)))
+                    self._live_weights = LiveWeights(self.engine, lambda: self.transformer_2)
+                else:
+                    self._init_live(WanEngine(wcfg(self.pipeline.transformer.config)))
 
             def _eval_inference(self, **kwargs):
                 return _RefWan.inference(self, **kwargs)

@@ -189,6 +189,23 @@ class WanRolloutMixin:
 
     _sample_cls = WanT2VSample
     _output_cls = SDESchedulerOutput
+    # Wan2.2 two-expert pipelines (wan2_t2v.py:476-487): `engine` holds the high-noise expert (`pipeline.transformer`, used while
+    # t >= boundary_ratio * num_train_timesteps with `guidance_scale`), `engine_2` the low-noise one (`pipeline.transformer_2`, with
+    # `guidance_scale_2`).  None = single-transformer Wan2.1.  Per-token timesteps (`expand_timesteps`, TI2V-5B) are not supported.
+    engine_2 = None
+    boundary_ratio: Optional[float] = None
+
+    def _boundary_timestep(self, boundary_timestep: Optional[float] = None) -> Optional[float]:
+        if boundary_timestep is None and self.boundary_ratio is not None:
+            boundary_timestep = float(self.boundary_ratio) * float(self.scheduler.config.get("num_train_timesteps", 1000))
+        return boundary_timestep
+
+    def _expert(self, t: float, guidance_scale: float, guidance_scale_2: Optional[float], boundary_timestep: Optional[float]):
+        """(engine, guidance) for a step at timestep t: the reference's selection rule."""
+        bt = self._boundary_timestep(boundary_timestep)
+        if self.engine_2 is None or bt is None or t >= bt:
+            return self.engine, guidance_scale
+        return self.engine_2, (guidance_scale_2 if guidance_scale_2 is not None else guidance_scale)
 
     def _before_engine_call(self) -> None:
         """Hook run at the top of inference() / forward(): the Flow-Factory plugin re-binds changed weights here."""
@@ -240,8 +257,8 @@ class WanRolloutMixin:
         self._before_engine_call()
         if attention_kwargs:
             raise NotImplementedError("mi355_flow: attention_kwargs are not supported by the native engine")
-        if guidance_scale_2 is not None and guidance_scale_2 != guidance_scale:
-            raise ValueError("mi355_flow: guidance_scale_2 (Wan2.2 two-expert models) is not supported")
+        if guidance_scale_2 is not None and guidance_scale_2 != guidance_scale and self.engine_2 is None:
+            raise ValueError("mi355_flow: guidance_scale_2 needs a two-expert (Wan2.2) adapter: no second transformer is bound")
         if (num_frames - 1) % VAE_SCALE_TEMPORAL != 0:
             num_frames = num_frames // VAE_SCALE_TEMPORAL * VAE_SCALE_TEMPORAL + 1
         num_frames = max(num_frames, 1)
@@ -255,7 +272,9 @@ class WanRolloutMixin:
         prompt_embeds = prompt_embeds.to(device).to(self.transformer_dtype)
         if negative_prompt_embeds is not None:
             negative_prompt_embeds = negative_prompt_embeds.to(device).to(self.transformer_dtype)
-        do_cfg = guidance_scale > 1.0 and negative_prompt_embeds is not None
+        two = self.engine_2 is not None
+        g2 = guidance_scale_2 if guidance_scale_2 is not None else guidance_scale
+        do_cfg = (guidance_scale > 1.0 or (two and g2 > 1.0)) and negative_prompt_embeds is not None
         B = prompt_embeds.shape[0]
         N = int(num_inference_steps)
         self.scheduler.set_timesteps(N, device=device)
@@ -274,8 +293,10 @@ class WanRolloutMixin:
         sig_host = [float(s) for s in self.scheduler.sigmas.tolist()]
         eta_host = host_noise_levels(self.scheduler, N)
         storage = self.latent_storage_dtype or torch.float32       # cast_latents(latents) with no default: fp32 stays fp32
-        stepwise = any(k != "noise_level" for k in extra_call_back_kwargs)
+        # two experts: per-step engine calls (each step picks its expert and guidance by the boundary rule; still all-HIP)
+        stepwise = two or any(k != "noise_level" for k in extra_call_back_kwargs)
         plan = self.engine.plan(B, 2 if do_cfg else 1, T, h, w, prompt_embeds.shape[1], N)
+        plan_2 = self.engine_2.plan(B, 2 if do_cfg else 1, T, h, w, prompt_embeds.shape[1], N) if two else None
         kept = _resolve(trajectory_indices, N + 1)
         keep_positions = list(range(N + 1)) if kept is None else sorted(kept)
         step_outputs = None
@@ -287,7 +308,8 @@ class WanRolloutMixin:
         else:
             lat_kept, log_probs, step_outputs = self._rollout_stepwise(plan, ts_host, sig_host, eta_host, guidance_scale, latents, storage,
                                                                        step_noise, prompt_embeds, negative_prompt_embeds if do_cfg else None,
-                                                                       compute_log_prob, extra_call_back_kwargs)
+                                                                       compute_log_prob, extra_call_back_kwargs, plan_2=plan_2,
+                                                                       guidance_2=g2)
             final = lat_kept[N]
             pos_to_slot = {p: p for p in range(N + 1)}
         latent_collector = create_trajectory_collector(trajectory_indices, N)
@@ -328,8 +350,9 @@ class WanRolloutMixin:
             for b in range(B)
         ]
 
-    def _rollout_stepwise(self, plan, ts, sig, eta, guidance, latents, storage, step_noise, pe, ne, compute_log_prob, extra_keys):
-        """Per-step engine calls (still all-HIP) for rollouts that ask for per-step callback tensors."""
+    def _rollout_stepwise(self, plan, ts, sig, eta, guidance, latents, storage, step_noise, pe, ne, compute_log_prob, extra_keys, plan_2=None,
+                          guidance_2=None):
+        """Per-step engine calls (still all-HIP) for rollouts that ask for per-step callback tensors, and for two-expert pipelines."""
         N, B = len(ts), latents.shape[0]
         cur = self.cast_latents(latents, storage)
         all_lat = [cur]
@@ -340,9 +363,15 @@ class WanRolloutMixin:
         for i in range(N):
             t_next = ts[i + 1] if i + 1 < N else 0.0
             clp = compute_log_prob and eta[i] > 0
-            v = plan.transformer_forward(cur, f32(ts[i]).reshape(1), ne if ne is not None else pe, pe if ne is not None else None)
-            vu, vt = (v[:B], v[B:]) if ne is not None else (None, v)
-            o = sde_step(vt, vu, guidance, cur, f32(ts[i]) / f32(1000.0), f32(t_next) / f32(1000.0), eta[i], sig[1],
+            bt = self._boundary_timestep()
+            low = plan_2 is not None and bt is not None and ts[i] < bt
+            pl, gd = (plan_2, guidance_2) if low else (plan, guidance)
+            cfg_i = ne is not None and gd > 1.0          # the reference decides CFG per expert (wan2_t2v.py:489-498)
+            if not cfg_i and pl.n_cfg == 2:
+                pl = pl.engine.plan(B, 1, pl.T, pl.h, pl.w, pl.n_text, 1)
+            v = pl.transformer_forward(cur, f32(ts[i]).reshape(1), ne if cfg_i else pe, pe if cfg_i else None)
+            vu, vt = (v[:B], v[B:]) if cfg_i else (None, v)
+            o = sde_step(vt, vu, gd, cur, f32(ts[i]) / f32(1000.0), f32(t_next) / f32(1000.0), eta[i], sig[1],
                          self.scheduler.dynamics_type, noise=step_noise[i] if step_noise is not None else None, compute_log_prob=clp,
                          want=want)
             if clp:
@@ -373,8 +402,8 @@ class WanRolloutMixin:
         self._before_engine_call()
         if attention_kwargs:
             raise NotImplementedError("mi355_flow: attention_kwargs are not supported by the native engine")
-        if boundary_timestep is not None:
-            raise ValueError("mi355_flow: boundary_timestep (Wan2.2 two-expert models) is not supported")
+        if boundary_timestep is not None and self.engine_2 is None:
+            raise ValueError("mi355_flow: boundary_timestep needs a two-expert (Wan2.2) adapter: no second transformer is bound")
         dev = latents.device
         B, _, T, h, w = latents.shape
         t = torch.as_tensor(t, device=dev, dtype=torch.float32).reshape(-1)
@@ -384,8 +413,9 @@ class WanRolloutMixin:
             idx = sched.index_for_timestep(t0)
             t_next = sched.timesteps[idx + 1].float() if idx + 1 < len(sched.timesteps) else torch.zeros(())
         t_next = torch.as_tensor(t_next, device=dev, dtype=torch.float32).reshape(-1)[0]
+        eng, guidance_scale = self._expert(float(t0), guidance_scale, guidance_scale_2, boundary_timestep)
         do_cfg = negative_prompt_embeds is not None and guidance_scale > 1.0
-        plan = self.engine.plan(B, 2 if do_cfg else 1, T, h, w, prompt_embeds.shape[1], 1)
+        plan = eng.plan(B, 2 if do_cfg else 1, T, h, w, prompt_embeds.shape[1], 1)
         v = plan.transformer_forward(latents, t0.reshape(1), negative_prompt_embeds if do_cfg else prompt_embeds, prompt_embeds if do_cfg else None)
         vu, vt = (v[:B], v[B:]) if do_cfg else (None, v)
         dyn = sched.dynamics_type
@@ -418,7 +448,8 @@ class Wan2T2VNativeAdapter(WanRolloutMixin):
     def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[WanConfig] = None,
                  scheduler: Optional[UniPCMultistepSDEScheduler] = None, latent_storage_dtype: Optional[str] = "fp16",
                  transformer_dtype: torch.dtype = torch.bfloat16, device: Union[str, torch.device] = "cuda",
-                 video_decode: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
+                 video_decode: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+                 state_dict_2: Optional[Dict[str, torch.Tensor]] = None, boundary_ratio: Optional[float] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("mi355_flow: no GPU visible; the native rollout engine has no CPU path")
         self.device = torch.device(device)
@@ -427,6 +458,13 @@ class Wan2T2VNativeAdapter(WanRolloutMixin):
         self.scheduler = scheduler or UniPCMultistepSDEScheduler(flow_shift=3.0, sde_steps=[1, 2, 3], num_sde_steps=1)
         self.engine = WanEngine(config or WanConfig())
         self.refresh_weights(state_dict)
+        if state_dict_2 is not None:            # Wan2.2: low-noise expert (`transformer_2`), same architecture
+            if boundary_ratio is None:
+                raise ValueError("mi355_flow: a two-expert Wan2.2 adapter needs `boundary_ratio` (pipeline.config.boundary_ratio)")
+            self.engine_2 = WanEngine(config or WanConfig())
+            self.engine_2.bind_state_dict(state_dict_2)
+            self.engine_2.ready()
+            self.boundary_ratio = float(boundary_ratio)
         self._video_decode = video_decode
 
     @property

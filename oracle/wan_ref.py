@@ -244,3 +244,34 @@ def rollout(sd, cfg: WanConfig, prompt_embeds, negative_prompt_embeds, guidance_
         all_lat.append(lat)
         lps.append(out["log_prob"] if clp else torch.full((B,), float("nan")))
     return dict(all_latents=torch.stack(all_lat, 0), log_probs=torch.stack(lps, 0))
+
+
+def rollout_two_expert(sd_hi, sd_lo, cfg: WanConfig, boundary_timestep, prompt_embeds, negative_prompt_embeds, guidance_scale, guidance_scale_2,
+                       init_latents, step_noise, timesteps, sigmas, noise_levels, storage_dtype=torch.float16, dynamics_type="Flow-SDE",
+                       compute_log_prob=True):
+    """Wan2.2 two-expert loop (reference wan2_t2v.py:476-487 inside the loop of :344-376): the high-noise expert with `guidance_scale`
+    while t >= boundary_timestep, the low-noise expert with `guidance_scale_2` below; CFG is decided per expert."""
+    from . import scheduler_ref as S
+    from .rollout_ref import cfg_combine_bf16
+    N = len(timesteps)
+    lat = S.cast_latents(init_latents, storage_dtype)
+    all_lat, lps = [lat], []
+    sigma_max = float(sigmas[1])
+    B = lat.shape[0]
+    for i in range(N):
+        t = timesteps[i].float()
+        t_next = timesteps[i + 1].float() if i + 1 < N else torch.tensor(0.0)
+        sd, g = (sd_hi, guidance_scale) if float(t) >= boundary_timestep else (sd_lo, guidance_scale_2)
+        eta = float(noise_levels[i])
+        clp = compute_log_prob and eta > 0
+        x_in = lat.to(torch.bfloat16).float()
+        v = wan_forward(sd, cfg, x_in, t.expand(B), prompt_embeds.float()).to(torch.bfloat16)
+        if negative_prompt_embeds is not None and g > 1.0:
+            vu = wan_forward(sd, cfg, x_in, t.expand(B), negative_prompt_embeds.float()).to(torch.bfloat16)
+            v = cfg_combine_bf16(vu, v, g)
+        out = S.sde_step(v, lat, t / 1000, t_next / 1000, eta, dynamics_type=dynamics_type, sigma_max=sigma_max,
+                         variance_noise=step_noise[i], compute_log_prob=clp)
+        lat = S.cast_latents(out["next_latents"], storage_dtype)
+        all_lat.append(lat)
+        lps.append(out["log_prob"] if clp else torch.full((B,), float("nan")))
+    return dict(all_latents=torch.stack(all_lat, 0), log_probs=torch.stack(lps, 0))

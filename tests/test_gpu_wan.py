@@ -158,3 +158,60 @@ def test_wan_full_width_blocks_at_4608_tokens(wn):
     print(f"Wan full-width 2 blocks, S = 4608: rel-L2 {rel:.3e}")
     assert rel < 2e-2, rel
     eng.close()
+
+
+def test_wan22_two_expert_rollout_matches_oracle_and_replays(wn):
+    """Wan2.2 two-expert pipelines (reference wan2_t2v.py:476-487): high-noise expert + `guidance_scale` while t >= boundary_ratio * 1000,
+    low-noise expert + `guidance_scale_2` below (here <= 1: that expert runs without CFG).  Latents / log-probs vs the oracle's
+    two-expert loop; replay of a step on EITHER side of the boundary reproduces the rollout log-prob bit for bit."""
+    from oracle import wan_ref as R
+    cfg_o = R.tiny_config()
+    sd_hi, cfg = _setup(wn, cfg_o, seed=12)
+    sd_lo, _ = _setup(wn, cfg_o, seed=99)
+    sched = wn.UniPCMultistepSDEScheduler(flow_shift=3.0, noise_level=0.7, sde_steps=[0, 1, 2, 3, 4], num_sde_steps=5, seed=42, dynamics_type="Flow-SDE")
+    ratio = 0.9                                   # boundary timestep 900: with N = 5, shift 3 the schedule crosses it after 2 steps
+    ad = wn.Wan2T2VNativeAdapter({k: v.cuda() for k, v in sd_hi.items()}, cfg, sched, latent_storage_dtype="fp16",
+                                 state_dict_2={k: v.cuda() for k, v in sd_lo.items()}, boundary_ratio=ratio)
+    ad.rollout()
+    B, Nt, N, H, W, frames = 2, 12, 5, 64, 96, 9
+    g = torch.Generator().manual_seed(4)
+    pe = torch.randn(B, Nt, cfg_o.text_dim, generator=g).bfloat16()
+    ne = torch.randn(B, Nt, cfg_o.text_dim, generator=g).bfloat16()
+    g1, g2 = 4.0, 1.0
+    torch.cuda.manual_seed(31)
+    samples = ad.inference(prompt=["a", "b"], height=H, width=W, num_frames=frames, num_inference_steps=N, guidance_scale=g1, guidance_scale_2=g2,
+                           prompt_embeds=pe.cuda(), negative_prompt_embeds=ne.cuda(), compute_log_prob=True, trajectory_indices="all")
+    torch.cuda.manual_seed(31)
+    T, h, w = 3, 8, 12
+    init = torch.randn((B, 16, T, h, w), device="cuda", dtype=torch.float32).cpu()
+    noise = torch.stack([torch.randn((B, 16, T, h, w), device="cuda", dtype=torch.float32) for _ in range(N)]).cpu()
+    ts, sig = R.unipc_flow_schedule(N, 3.0)
+    hi_steps = [i for i in range(N) if float(ts[i]) >= 900.0]
+    assert 0 < len(hi_steps) < N, ts                                       # both experts are exercised
+    nl = ad.scheduler.host_noise_levels()
+    ref = R.rollout_two_expert(sd_hi, sd_lo, cfg_o, 900.0, pe, ne, g1, g2, init, noise, ts, sig, nl, torch.float16)
+    for b in range(B):
+        got = samples[b].all_latents.float().cpu()
+        for pos in range(N + 1):
+            r = ref["all_latents"][pos, b].float()
+            assert ((got[pos] - r).norm() / r.norm()).item() < 2e-2, (b, pos)
+        sde = [i for i in range(N) if nl[i] > 0]
+        torch.testing.assert_close(samples[b].log_probs.cpu(), torch.stack([ref["log_probs"][i, b] for i in sde]), rtol=1e-3, atol=1e-4)
+    # a single-expert run with the high-noise weights differs after the boundary: the second expert really ran
+    one = wn.Wan2T2VNativeAdapter({k: v.cuda() for k, v in sd_hi.items()}, cfg, sched, latent_storage_dtype="fp16")
+    one.rollout()
+    torch.cuda.manual_seed(31)
+    s1 = one.inference(prompt=["a", "b"], height=H, width=W, num_frames=frames, num_inference_steps=N, guidance_scale=g1, prompt_embeds=pe.cuda(),
+                       negative_prompt_embeds=ne.cuda(), compute_log_prob=True, trajectory_indices="all")
+    k = len(hi_steps)
+    assert torch.equal(s1[0].all_latents[:k + 1], samples[0].all_latents[:k + 1]) and not torch.equal(s1[0].all_latents[k + 1], samples[0].all_latents[k + 1])
+    # replay on both sides of the boundary: ratio == 1 exactly
+    for i in (hi_steps[-1], hi_steps[-1] + 1):
+        x_i = torch.stack([s.all_latents[i] for s in samples]).cuda()
+        x_n = torch.stack([s.all_latents[i + 1] for s in samples]).cuda()
+        out = ad.forward(t=samples[0].timesteps[i].reshape(1).expand(B).cuda(), latents=x_i, prompt_embeds=pe.cuda(), negative_prompt_embeds=ne.cuda(),
+                         guidance_scale=g1, guidance_scale_2=g2, t_next=(samples[0].timesteps[i + 1] if i + 1 < N else torch.zeros(())).reshape(1).expand(B).cuda(),
+                         next_latents=x_n, noise_level=nl[i], compute_log_prob=True, return_kwargs=["log_prob"])
+        old = torch.stack([s.log_probs[i] for s in samples]).cuda()
+        assert torch.equal(out.log_prob, old), i
+    ad.engine.close(); ad.engine_2.close(); one.engine.close()
