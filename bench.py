@@ -250,6 +250,9 @@ def main():
         lib.mi355_tune_set(3, args.pp_min_tiles)
     if os.environ.get("MI355_ATTN_STATIC") == "0":     # A/B: keep the running-max softmax even where the static bound holds
         lib.mi355_tune_set(6, 0)
+    for kv in filter(None, os.environ.get("MI355_TUNE", "").split(",")):      # A/B of kernel variants: "key=value,..." (mi355_tune_set)
+        k_, v_ = kv.split("=")
+        _lib.check(lib.mi355_tune_set(int(k_), int(v_)), "tune_set")
     for _ in range(args.warmup):
         samples = one_rollout()
     if not args.no_selfcheck and not flux_mode:

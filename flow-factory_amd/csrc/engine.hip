@@ -857,6 +857,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 4) { set_conv_cfg(value); return 0; }
     if (key == 5) { set_attn128_variant(value); return 0; }
     if (key == 6) { g_attn_static = value; return 0; }
+    if (key == 7) { set_raster_gm(value); return 0; }
     return fail("mi355_tune_set: unknown key %d", key);
 }
 
@@ -875,8 +876,9 @@ extern "C" int mi355_op_linear(void* stream, const void* A, const void* W, const
 extern "C" int mi355_op_linear_trace(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                                      void* trace) {
     GemmParams g = gp((const bf16_t*)A, K, (const bf16_t*)W, K, M, N, K, EPI_BIAS, bias, (bf16_t*)out, N);
-    g.trace = (long long*)trace;
-    g.dbg_skip_prefetch = getenv("MI355_DBG_SKIP_PREFETCH") != nullptr;
+    g.trace = (long long*)trace;     // (may be null: then this is the plain launch with the ablation knobs below)
+    g.dbg_skip_prefetch = getenv("MI355_DBG_SKIP_PREFETCH") ? 1 : 0;                       // ablations (results are garbage)
+    if (getenv("MI355_DBG_MASK")) g.dbg_skip_prefetch = atoi(getenv("MI355_DBG_MASK"));   // bit 0: no K-loop prefetch, bit 1: no LDS fragment reads
     HIPCHK(launch_gemm(g, (hipStream_t)stream));
     return 0;
 }

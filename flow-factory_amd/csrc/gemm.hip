@@ -22,7 +22,21 @@ namespace mi355 {
 namespace {
 
 constexpr int BK = 64;
+int g_raster_gm = 6;          // tile rows per raster band (0 = plain row-major order); mi355_tune_set(7, v)
 int g_pp_min_tiles = 128;     // smallest 256x256-tile grid for gemm_pp_kernel
+
+// linear tile id -> (tm, tn).  Bands of `gm` tile rows are walked column by column, so the ~32 consecutive ids that the workgroups of one
+// XCD hold at any time form a near-square block: gm A-panels + ~32/gm W-panels stream through that XCD's L2 per round instead of ~1 + 32
+// (row-major order on a wide N).  The mapping does not touch the arithmetic of a tile: results are bit-identical for every gm.
+__device__ __forceinline__ void tile_coords(int tile, int ntm, int ntn, int gm, int& tm, int& tn) {
+    if (gm <= 0) { tm = tile / ntn; tn = tile - tm * ntn; return; }
+    const int band = tile / (gm * ntn);
+    const int first = band * gm;
+    const int rows = ntm - first < gm ? ntm - first : gm;
+    const int r = tile - band * gm * ntn;
+    tn = r / rows;
+    tm = first + (r - tn * rows);
+}
 int g_gemm_variant = 1;  // large grids: 0 simple 2-stage kernel, 1 persistent ping-pong kernel
 // (a 32x32x16-MFMA / 2-phases-per-K-tile ping-pong variant was measured 6-10 % SLOWER than the 16x16x32 / 4-phase one
 //  on every shape of this model and was dropped: profiles/r01_gemm_variants.txt)
@@ -297,7 +311,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
     }
     const int split = bid / (ntm * ntn);          // (splits of one tile run on different XCDs: they share no operand bytes)
     bid -= split * (ntm * ntn);
-    const int tm = bid / ntn, tn = bid - tm * ntn;
+    int tm, tn;
+    tile_coords(bid, ntm, ntn, p.raster_gm, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
 
     // ---- staging addresses: lane -> (row in 8-row group, physical 16B chunk)
@@ -468,7 +483,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
 //   unit order U0 = A rows of quadrant-row 0 (both groups), U2/U3 = W rows of quadrant-col 0/1, U1 = A
 //   rows of quadrant-row 1;  phase P0: (0,0) reads A0,B0 | P1: (0,1) reads B1 | P2: (1,1) reads A1 |
 //   P3: (1,0) reads nothing;  prefetch order for tile t+1: U0, U2, U3, U1.
-template <int EPI>
+// DBG (ablation builds only, EPI_BIAS, results are garbage): bit 0 no K-loop prefetch, bit 1 no LDS fragment reads after the first K-tile,
+// bit 2 no epilogue at all (accumulators just reset), bit 3 epilogue without its global stores
+template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
     constexpr int BM = 256, BN = 256, TM = 128, TN = 64;
     constexpr int A_BYTES = BM * BK * 2, STAGE = 2 * A_BYTES;
@@ -498,7 +515,8 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
     int ldsoff[4][2];
     int m0 = 0, n0 = 0;
     auto set_tile = [&](int tile) {
-        const int tm = tile / ntn, tn = tile - tm * ntn;
+        int tm, tn;
+        tile_coords(tile, ntm, ntn, p.raster_gm, tm, tn);
         m0 = tm * BM; n0 = tn * BN;
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -523,7 +541,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
             }
     };
     auto stage_unit = [&](int u, long ko, char* base) {
-        if (p.dbg_skip_prefetch && ko != 0) return;   // (ablation only)
+        if constexpr ((DBG & 1) != 0) { if (ko != 0) return; }
         const char* gb = (u < 2 ? (const char*)p.A : (const char*)p.W) + ko * 2;   // uniform
         glds16(gb + soff[u][0], base + ldsoff[u][0]);
         glds16(gb + soff[u][1], base + ldsoff[u][1]);
@@ -548,11 +566,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();             \
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
+    bool dbg_noread = false;
 #define PP_READ_A(qm)                                                                                   \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)     \
+    if (!((DBG & 2) && dbg_noread)) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)     \
         af[mi][kk] = *(const bf16x8*)(sb + offX[kk] + (qm) * 8192 + mi * 2048)
 #define PP_READ_B(qn)                                                                                   \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)     \
+    if (!((DBG & 2) && dbg_noread)) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)     \
         bfr[qn][ni][kk] = *(const bf16x8*)(sb + offW[kk] + (qn) * 4096 + ni * 2048)
 #define PP_MFMA(qm, qn)                                                                                 \
     do {                                                                                                \
@@ -609,7 +628,13 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
                 a2[i][j] = acc[qq * 2 + i][j];                                                                    \
                 acc[qq * 2 + i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                 \
             }                                                                                                     \
-            if (full_tile) epilogue_part<EPI, 2, true>(p, a2, em0 + grp * TM + qq * 32, en0 + wn * TN, stg, lane); \
+            if constexpr ((DBG & 4) != 0) { float sink = 0.f;                                                                  \
+                _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)                     \
+                    sink += (a2[i][j][0] + a2[i][j][1]) + (a2[i][j][2] + a2[i][j][3]);                                        \
+                if (sink == 12345.678f) p.out[lane] = 1; }                                                                    \
+            else if constexpr ((DBG & 8) != 0) { GemmParams pd = p; pd.M = 0; pd.N = 0;                                        \
+                epilogue_part<EPI, 2, false>(pd, a2, em0 + grp * TM + qq * 32, en0 + wn * TN, stg, lane); }                    \
+            else if (full_tile) epilogue_part<EPI, 2, true>(p, a2, em0 + grp * TM + qq * 32, en0 + wn * TN, stg, lane); \
             else epilogue_part<EPI, 2, false>(p, a2, em0 + grp * TM + qq * 32, en0 + wn * TN, stg, lane);          \
             __builtin_amdgcn_sched_barrier(0);                                                                    \
         }                                                                                                         \
@@ -652,6 +677,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // retires U0,U2 of the next step (and any epilogue stores)
         PP_BARRIER(); PP_MFMA(1, 0); PP_BARRIER();
         after_epi = false;
+        if constexpr ((DBG & 2) != 0) dbg_noread = true;
         if (last_k) {
             PP_EPILOGUE(sb);
             t = 0;
@@ -684,9 +710,9 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
 #undef PP_MFMA
 }
 
-template <int EPI>
+template <int EPI, int DBG = 0>
 hipError_t launch_pp(const GemmParams& p, hipStream_t stream) {
-    auto kern = gemm_pp_kernel<EPI>;
+    auto kern = gemm_pp_kernel<EPI, DBG>;
     constexpr int smem = 2 * 2 * 256 * BK * 2 + 8 * 4096;   // operand ring + epilogue staging = 160 KiB
     static bool attr_set = false;
     if (!attr_set) {
@@ -738,7 +764,21 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     const double cost_pp = 4.0 * (double)((big + 255) / 256), cost_128 = 2.78 * (double)((t128 + 511) / 512);
     if constexpr (EPI != EPI_UNPATCH) {   // (proj_out, N = 64: scalar-scatter epilogue, always the 128x128 kernel)
-        if (big >= g_pp_min_tiles && fits32 && cost_pp <= cost_128) return launch_pp<EPI>(p, stream);
+        if (big >= g_pp_min_tiles && fits32 && cost_pp <= cost_128) {
+            if constexpr (EPI == EPI_BIAS) {      // ablation builds (scripts/gemm_ablate.py)
+                switch (p.dbg_skip_prefetch) {
+                    case 0: break;
+                    case 1: return launch_pp<EPI, 1>(p, stream);
+                    case 2: return launch_pp<EPI, 2>(p, stream);
+                    case 3: return launch_pp<EPI, 3>(p, stream);
+                    case 4: return launch_pp<EPI, 4>(p, stream);
+                    case 7: return launch_pp<EPI, 7>(p, stream);
+                    case 8: return launch_pp<EPI, 8>(p, stream);
+                    default: return hipErrorInvalidValue;
+                }
+            }
+            return launch_pp<EPI>(p, stream);
+        }
         if (big >= 200 && !fits32) return launch_cfg<256, 256, 2, 4, EPI>(p, stream);    // > 4 GiB operand (FLUX modulation table)
     }
     return launch_cfg<128, 128, 2, 2, EPI>(p, stream);
@@ -768,7 +808,11 @@ void set_gemm_variant(int v) { g_gemm_variant = v; }
 void set_pp_min_tiles(int v) { g_pp_min_tiles = v; }
 int get_gemm_variant() { return g_gemm_variant; }
 
-hipError_t launch_gemm(const GemmParams& p, hipStream_t stream) {
+void set_raster_gm(int v) { g_raster_gm = v; }
+
+hipError_t launch_gemm(const GemmParams& p_in, hipStream_t stream) {
+    GemmParams p = p_in;
+    p.raster_gm = g_raster_gm;
     if (p.K % BK != 0 || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;
     if (p.conv_cin > 0) {
         if (p.conv_cin % BK != 0 || p.K != 9 * p.conv_cin || !p.zero_page || p.M % (p.conv_h * p.conv_w) != 0 ||

@@ -61,6 +61,7 @@ struct GemmParams {
     // split-K (EPI_F32 on the 2-stage kernel only: weight gradients, output tiles << CUs): split s of k_split accumulates K-tiles
     // [s*nt/k_split, (s+1)*nt/k_split) into out_f32 + s * split_stride (deterministic second-stage reduction by the caller)
     int k_split; long split_stride;
+    int raster_gm;            // tile rows per raster band (set by launch_gemm from the global knob)
     // optional s_memtime trace (debug): per workgroup, per tile 4 stamps {tile start, main loop start, main loop end, epilogue end}
     long long* trace;
     int dbg_skip_prefetch;    // debug ablation: the K-loop prefetches are not issued (results are garbage)
@@ -70,6 +71,7 @@ hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);
 void set_gemm_variant(int v);
 int get_gemm_variant();
 void set_pp_min_tiles(int v);
+void set_raster_gm(int v);      // GEMM tile raster: tile rows per band (0 = row-major)
 void set_conv_cfg(int v);       // VAE conv tile shape A/B knob (0 auto)
 void set_attn_variant(int v);  // 0 = plain online softmax, 1 = deferred-rescale (default)
 int get_attn_variant();  // tuning / A-B knob: 0 = simple 2-stage 256x256 kernel, 1 = ping-pong (default)

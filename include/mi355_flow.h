@@ -298,7 +298,9 @@ int mi355_profile_enable(int on);
  * key 4 = VAE conv tile shape: 0 auto (default), 1 128x128, 2 256x128, 3 256x256, 4 512x128;
  * key 5 = head_dim-128 attention workgroup: 0 = 8 waves (default), 1 = 4 waves;
  * key 6 = static-bound softmax (no running max when the q/k norm weights prove |score| <= 60): 1 on (default), 0 off,
- *         v >= 2: mi355_op_attention asserts the bound v itself (unit tests)). */
+ *         v >= 2: mi355_op_attention asserts the bound v itself (unit tests));
+ * key 7 = GEMM tile raster: tile rows per band, walked column by column so that the tiles an XCD holds at any time form a near-square block
+ *         (default 6; 0 = plain row-major order).  Results are bit-identical for every value. */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);
 
