@@ -21,8 +21,8 @@ def short(name):
             # gemm_kernelILi256ELi256ELi2ELi4ELi5EE -> gemm<256,256,epi5>
             import re
             epi = ["bias", "bias_silu", "bias_gelu", "posadd", "addsrc_silu", "gate_res", "qk_norm", "vT", "unpatch", "bias_row",
-                   "f32", "img"]
-            mp = re.search(r"gemm_pp_kernel<(\d+)>", name)
+                   "f32", "img", "dgelu"]
+            mp = re.search(r"gemm_pp_kernel<(\d+)(?:, \d+)?>", name)
             if mp:
                 return f"gemm_pp<256x256,{epi[int(mp.group(1))]}>"
             m = re.search(r"gemm_kernelILi(\d+)ELi(\d+)ELi\d+ELi\d+ELi(\d+)E", name) or \
@@ -61,3 +61,20 @@ for d in sorted(glob.glob(os.path.join(out, "prof_pmc_*"))):
         summary.setdefault(k, {}).update({c: v for c, v in per.items()})
         summary[k]["launches"] = max(cnt[k].values())
 json.dump(summary, open(os.path.join(out, "pmc_per_launch.json"), "w"), indent=1)
+
+# the dominant kernel's HBM traffic per launch, as bench.py's roofline.traffic reads it (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in
+# KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads -> doubled; WRITE_SIZE as is)
+a = summary.get("attn_kernel", {})
+if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
+    import subprocess
+    try:
+        sha = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True, cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+    except Exception:
+        sha = ""
+    sha = sha or os.environ.get("MI355_COMMIT", "unknown")
+    json.dump({"round": 2, "commit": sha, "kernel": "mi355::attn_kernel (mean over the joint S=4429 and dual S=4096 launches of a forward, forward batch 8)",
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 0 --denoise-steps 2",
+               "FETCH_SIZE_kb_per_launch": a["FETCH_SIZE"], "WRITE_SIZE_kb_per_launch": a["WRITE_SIZE"],
+               "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> doubled; WRITE_SIZE as is",
+               "hbm_bytes_per_launch": int(a["FETCH_SIZE"] * 1024 * 2 + a["WRITE_SIZE"] * 1024), "algorithmic_bytes_per_launch": 435400000},
+              open(os.path.join(out, "pmc_attention.json"), "w"), indent=1)
