@@ -51,7 +51,8 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn128_kernel(Attn128Params p)
     const int h = bhi % p.H, b = bhi / p.H;
     const long bh = (long)b * p.H + h;
     // keys / values may be a different sequence (cross-attention): S_kv == 0 means self-attention over the S queries
-    const int Skv = p.S_kv > 0 ? p.S_kv : p.S;
+    int Skv = p.S_kv > 0 ? p.S_kv : p.S;
+    if (p.kv_len) Skv = min(Skv, max(1, __builtin_amdgcn_readfirstlane(p.kv_len[b])));
     const int Skv_pad = p.S_kv > 0 ? p.S_kv_pad : p.S_pad;
     const bf16_t* Qg = p.q + bh * p.S_pad * HD;
     const bf16_t* Kg = p.k + bh * Skv_pad * HD;

@@ -83,7 +83,53 @@ __global__ __launch_bounds__(256) void affine_to_mod_kernel(const float* weight,
     out[D + d] = f2bf(weight[d] - 1.0f);
 }
 
+// Qwen-Image txt_norm: RMSNorm over a whole row of D features with a weight (diffusers RMSNorm: fp32 variance, x * rsqrt(var + eps) * w).
+// One wave per row; a lane walks the row in 4-byte pairs (every load instruction of the wave covers 256 contiguous bytes).
+__global__ __launch_bounds__(256) void rms_rows_kernel(const bf16_t* x, long ldx, const float* w, bf16_t* out, long ldo, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const bf16_t* row = x + (long)m * ldx;
+    float ss = 0.f;
+    for (int d = 2 * lane; d < D; d += 128) {
+        const unsigned u = *(const unsigned*)(row + d);
+        ss += bf_lo(u) * bf_lo(u) + bf_hi(u) * bf_hi(u);
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)D + eps);
+    for (int d = 2 * lane; d < D; d += 128) {
+        const unsigned u = *(const unsigned*)(row + d);
+        const float2 ww = *(const float2*)(w + d);
+        *(unsigned*)(out + (long)m * ldo + d) = pack_bf16(bf_lo(u) * rstd * ww.x, bf_hi(u) * rstd * ww.y);
+    }
+}
+
+// Qwen-Image true-CFG with norm rescale (reference models/qwen_image/qwen_image.py:579-587) on bf16 predictions, every torch op rounding
+// to bf16 as the reference's bf16 tensors do:  comb = neg + g * (pos - neg);  out = comb * (||pos|| / ||comb||), norms over the C = 64
+// channels of a token.  One wave per token, one channel per lane.
+__global__ __launch_bounds__(256) void cfg_rescale_kernel(const bf16_t* neg, const bf16_t* pos, float g, bf16_t* out, long rows) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= rows) return;
+    const float n = bf2f(neg[m * 64 + lane]), c = bf2f(pos[m * 64 + lane]);
+    const float comb = round_bf16(n + round_bf16(g * round_bf16(c - n)));
+    const float cn = round_bf16(sqrtf(wave_sum(c * c)));
+    const float nn = round_bf16(sqrtf(wave_sum(comb * comb)));
+    out[m * 64 + lane] = f2bf(comb * round_bf16(cn / nn));
+}
+
 }  // namespace
+
+hipError_t launch_rms_rows(const bf16_t* x, long ldx, const float* w, bf16_t* out, long ldo, int M, int D, float eps, hipStream_t stream) {
+    if (M <= 0 || D <= 0 || (D & 1) || (ldx & 1) || (ldo & 1)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rms_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, ldx, w, out, ldo, M, D, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_cfg_rescale(const bf16_t* neg, const bf16_t* pos, float g, bf16_t* out, long rows, int C, hipStream_t stream) {
+    if (rows <= 0 || C != 64) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(cfg_rescale_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, neg, pos, g, out, rows);
+    return hipGetLastError();
+}
 
 hipError_t launch_norm_rope_full(const NormRopeFullParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.H <= 0 || p.H > 48 || (p.src_ld & 1) || (p.col & 1)) return hipErrorInvalidValue;

@@ -100,6 +100,7 @@ struct Attn128Params {
     int q_prescaled;   // 1: q carries log2(e)/sqrt(128) already (rope_norm kernel)
     float score_bound; // > 0: proven bound on |score| (log2 domain); <= 60 selects the no-running-max kernel
     int S_kv, S_kv_pad; // cross-attention: keys / values are a different sequence (k [B][H][S_kv_pad][128], vT [B][H][128][S_kv_pad]); 0 = self
+    const int* kv_len;  // optional device [B]: sample b attends to keys [0, kv_len[b]) only (ragged text at the END of the joint sequence)
 };
 hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream);
 void set_attn128_variant(int v);   // 0: 8-wave workgroups (default), 1: 4-wave workgroups
@@ -130,6 +131,9 @@ struct NormRopeFullParams {
     float eps, out_scale;
 };
 hipError_t launch_norm_rope_full(const NormRopeFullParams& p, hipStream_t stream);
+// Qwen-Image: RMSNorm over whole rows (weight fp32 [D]) and the norm-rescaled true-CFG combine over C = 64 channel tokens (flux_ops.hip)
+hipError_t launch_rms_rows(const bf16_t* x, long ldx, const float* w, bf16_t* out, long ldo, int M, int D, float eps, hipStream_t stream);
+hipError_t launch_cfg_rescale(const bf16_t* neg, const bf16_t* pos, float g, bf16_t* out, long rows, int C, hipStream_t stream);
 // out[m][j*W + x] = bf16(a[m][x] + table[j][x])   (a bf16 [rows][W], table fp32 [J][W]): Wan modulation = scale_shift_table + time_proj
 hipError_t launch_bcast_add(const bf16_t* a, const float* table, bf16_t* out, long out_ld, int rows, int W, int J, hipStream_t stream);
 // LayerNorm affine (weight, bias fp32 [D]) -> the (shift, scale) row layout of ln_mod: out[0][d] = bias, out[1][d] = weight - 1

@@ -52,6 +52,14 @@ class WanCfg(C.Structure):
     ]
 
 
+class QwenCfg(C.Structure):
+    _fields_ = [
+        ("in_channels", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("head_dim", C.c_int32),
+        ("joint_attention_dim", C.c_int32), ("time_proj_dim", C.c_int32), ("axes_dims_rope", C.c_int32 * 3),
+        ("scale_rope", C.c_int32), ("eps", C.c_float),
+    ]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -126,6 +134,20 @@ SIGNATURES = {
     "mi355_wan_forward": (_I, [_P, _P, _P, _I, _P, _P, _P, _P]),
     "mi355_wan_rollout": (_I, [_P, _P, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _I, _F, _P, _I, _I, _P, _P, _P,
                                C.POINTER(C.c_int32), _P, _P, _P, _I]),
+    "mi355_qwen_create": (_I, [C.POINTER(QwenCfg), C.POINTER(_P)]),
+    "mi355_qwen_destroy": (_I, [_P]),
+    "mi355_qwen_bind_weight": (_I, [_P, C.c_char_p, _P, _I, _I, C.POINTER(_L), _P]),
+    "mi355_qwen_weights_ready": (_I, [_P]),
+    "mi355_qwen_num_params": (_I, [_P]),
+    "mi355_qwen_param_name": (C.c_char_p, [_P, _I]),
+    "mi355_qwen_plan_create": (_I, [_P, _I, _I, _I, _I, _I, _I, C.POINTER(_P)]),
+    "mi355_qwen_plan_destroy": (_I, [_P]),
+    "mi355_qwen_plan_workspace_bytes": (_L, [_P]),
+    "mi355_qwen_forward": (_I, [_P, _P, _P, _I, _P, _P, C.POINTER(C.c_int32), _F, _P, _P]),
+    "mi355_qwen_rollout": (_I, [_P, _P, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _I, _F, _P, _I, _I, _P, _P,
+                                C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, _P, _P, _I]),
+    "mi355_op_cfg_rescale": (_I, [_P, _P, _P, _F, _P, _L, _I]),
+    "mi355_op_rms_rows": (_I, [_P, _P, _P, _P, _I, _I, _F]),
     "mi355_op_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
     "mi355_op_conv_repack": (_I, [_P, _P, _I, _P, _I, _I, _I, _I]),
     "mi355_op_group_norm": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _I]),

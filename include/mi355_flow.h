@@ -276,6 +276,46 @@ int mi355_wan_rollout(mi355_wan_plan* plan, void* stream, int n_steps, const flo
                       int storage_dtype, const float* step_noise, const void* prompt_embeds, const void* neg_embeds,
                       const int32_t* keep_slot_host, void* out_latents, float* out_log_probs, void* out_final, int compute_log_prob);
 
+/* ---- Qwen-Image -----------------------------------------------
+ * Replaces, inside QwenImageAdapter.inference / .forward (reference models/qwen_image/qwen_image.py:372-423, :476-600), the two
+ * `self.transformer(...)` calls (cond / uncond), the norm-rescaled true-CFG combine (:579-587) and `self.scheduler.step(...)`.
+ * Parameter names are the state_dict() keys of diffusers' QwenImageTransformer2DModel.  Latents are PACKED (B, Ni, 64).
+ * Text: prompt_embeds bf16 [n_cfg*batch][n_text][joint_attention_dim], negative prompts first when n_cfg == 2, zero-padded to
+ * n_text; txt_lens_host int32 [n_cfg*batch] = valid tokens per sample (NULL: all n_text) -- keys past a sample's length are masked. */
+typedef struct mi355_qwen mi355_qwen;
+typedef struct mi355_qwen_plan mi355_qwen_plan;
+typedef struct mi355_qwen_cfg {
+    int32_t in_channels, num_layers, num_heads, head_dim, joint_attention_dim, time_proj_dim;
+    int32_t axes_dims_rope[3];
+    int32_t scale_rope;
+    float eps;
+} mi355_qwen_cfg;
+int mi355_qwen_create(const mi355_qwen_cfg* cfg, mi355_qwen** out);
+int mi355_qwen_destroy(mi355_qwen* e);
+int mi355_qwen_bind_weight(mi355_qwen* e, const char* name, const void* src, int dtype, int ndim, const int64_t* shape, void* stream);
+int mi355_qwen_weights_ready(mi355_qwen* e);
+int mi355_qwen_num_params(mi355_qwen* e);
+const char* mi355_qwen_param_name(mi355_qwen* e, int i);
+/* latent_h x latent_w = the UNPACKED latent grid (128 x 128 for 1024^2); n_cfg = 2 runs [negative | positive] as one forward batch */
+int mi355_qwen_plan_create(mi355_qwen* e, int batch, int n_cfg, int latent_h, int latent_w, int n_text, int max_steps,
+                           mi355_qwen_plan** out);
+int mi355_qwen_plan_destroy(mi355_qwen_plan* plan);
+int64_t mi355_qwen_plan_workspace_bytes(mi355_qwen_plan* plan);
+/* one evaluation incl. the CFG combine: t_model device fp32 [batch] = 1000 * (t/1000 rounded to the latents' dtype), the angle base
+ * of Timesteps(scale=1000); v_out bf16 [batch][Ni][64] = the prediction handed to the scheduler; v_raw (optional) bf16
+ * [n_cfg*batch][Ni][64] = the raw network outputs */
+int mi355_qwen_forward(mi355_qwen_plan* plan, void* stream, const void* latents, int lat_dtype, const float* t_model,
+                       const void* prompt_embeds, const int32_t* txt_lens_host, float guidance_scale, void* v_out, void* v_raw);
+/* the whole N-step loop, zero host syncs; arguments as mi355_flux_rollout; guidance_scale = true-CFG scale (n_cfg == 2) */
+int mi355_qwen_rollout(mi355_qwen_plan* plan, void* stream, int n_steps, const float* timesteps_host, const float* sigmas_host,
+                       const float* noise_levels_host, int dynamics, float guidance_scale, const void* init_latents, int init_dtype,
+                       int storage_dtype, const float* step_noise, const void* prompt_embeds, const int32_t* txt_lens_host,
+                       const int32_t* keep_slot_host, void* out_latents, float* out_log_probs, void* out_final, int compute_log_prob);
+/* operator-level (unit tests): comb = neg + g (pos - neg); out = comb * ||pos|| / ||comb|| per token of `channels` = 64 bf16 values */
+int mi355_op_cfg_rescale(void* stream, const void* v_neg, const void* v_pos, float guidance_scale, void* out, int64_t rows, int channels);
+/* RMSNorm over whole rows: x bf16 [rows][dim], weight fp32 [dim] -> out bf16 [rows][dim] */
+int mi355_op_rms_rows(void* stream, const void* x, const float* weight, void* out, int rows, int dim, float eps);
+
 /* VAE operator-level entry points (unit tests / microbenchmarks).  NHWC bf16 activations.
  * conv3x3: x [B][H>>up][W>>up][Cin] (Cin % 64 == 0), w_packed [Cout][9][Cin] bf16 (mi355_op_conv_repack), padding 1,
  * optional nearest-2x upsample of x folded in, optional residual [B*H*W][Cout] added (may alias out) -> out [B*H*W][Cout] */
