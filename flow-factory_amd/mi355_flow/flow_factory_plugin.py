@@ -261,6 +261,39 @@ if _RefAdapter is not None:
                     return _RefWan.forward(self, *args, **kwargs)
                 return WanRolloutMixin.forward(self, *args, **kwargs)
 
+    try:
+        from flow_factory.models.qwen_image.qwen_image import QwenImageAdapter as _RefQwen, QwenImageSample as _RefQwenSample
+    except Exception:  # noqa: BLE001
+        _RefQwen = None
+
+    if _RefQwen is not None:
+        from .qwen import QwenConfig, QwenEngine, QwenRolloutMixin
+
+        class QwenImageNativeAdapter(_LiveBinding, QwenRolloutMixin, _RefQwen):
+            """`QwenImageAdapter` (reference models/qwen_image/qwen_image.py) with the GRPO rollout on the MI355X engine.  The trainable
+            transformer may be FSDP2-sharded (config/accelerate_configs/fsdp2.yaml): `LiveWeights` binds every parameter through
+            `DTensor.full_tensor()` (all ranks call inference() / forward() together, so the all-gathers line up) into the engine's own
+            resident 41 GB bf16 copy, once per optimiser epoch.  The image VAE stays the pipeline's (`decode_latents` is inherited)."""
+
+            _sample_cls = _RefQwenSample
+            _output_cls = _RefOutput
+            _set_timesteps = staticmethod(_ref_set_timesteps)
+
+            def __init__(self, config, accelerator):
+                _RefQwen.__init__(self, config, accelerator)
+                tc = self.pipeline.transformer.config
+                self.transformer_dtype = self.pipeline.transformer.dtype
+                self._init_live(QwenEngine(QwenConfig(
+                    in_channels=tc.in_channels, num_layers=tc.num_layers, num_attention_heads=tc.num_attention_heads,
+                    attention_head_dim=tc.attention_head_dim, joint_attention_dim=tc.joint_attention_dim,
+                    axes_dims_rope=tuple(tc.axes_dims_rope))))
+
+            @functools.wraps(QwenRolloutMixin.forward)
+            def forward(self, *args, **kwargs):
+                if torch.is_grad_enabled():          # optimize(): autograd stays on the reference path for Qwen-Image
+                    return _RefQwen.forward(self, *args, **kwargs)
+                return QwenRolloutMixin.forward(self, *args, **kwargs)
+
 else:
 
     def _unavailable(name: str, standalone: str):
@@ -274,3 +307,4 @@ else:
     SD3_5NativeAdapter = _unavailable("SD3_5NativeAdapter", "mi355_flow.adapter.SD3_5NativeAdapter")
     Flux1NativeAdapter = _unavailable("Flux1NativeAdapter", "mi355_flow.flux.Flux1NativeAdapter")
     Wan2T2VNativeAdapter = _unavailable("Wan2T2VNativeAdapter", "mi355_flow.wan.Wan2T2VNativeAdapter")
+    QwenImageNativeAdapter = _unavailable("QwenImageNativeAdapter", "mi355_flow.qwen.QwenImageNativeAdapter")

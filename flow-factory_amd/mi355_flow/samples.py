@@ -223,6 +223,16 @@ class Flux1Sample(BaseSample):
 
 
 @dataclass
+class QwenImageSample(BaseSample):
+    """reference qwen_image.py:54-62: packed latents `(P, Ni, 64)` in `all_latents`; per-sample text masks (ragged prompts stay
+    ragged until `_pad_batch_prompt`), `img_shapes = [(1, h/16, w/16)]`."""
+    _shared_fields: ClassVar[frozenset] = frozenset()
+    prompt_embeds_mask: Optional[torch.Tensor] = None
+    negative_prompt_embeds_mask: Optional[torch.Tensor] = None
+    img_shapes: Optional[List[Any]] = None
+
+
+@dataclass
 class WanT2VSample(BaseSample):
     """reference wan2_t2v.py:49-51: video latents `(P, 16, T, h, w)` in `all_latents`, the decoded clip in `video`."""
     _shared_fields: ClassVar[frozenset] = frozenset()

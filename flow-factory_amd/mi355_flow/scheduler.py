@@ -139,11 +139,13 @@ class FlowMatchEulerDiscreteSDEScheduler:
         base_image_seq_len: Optional[int] = 256,
         max_image_seq_len: Optional[int] = 4096,
         time_shift_type: str = "exponential",
+        shift_terminal: Optional[float] = None,
         **kwargs,
     ):
         self.config = _Config(num_train_timesteps=num_train_timesteps, shift=shift, use_dynamic_shifting=use_dynamic_shifting,
                               base_shift=base_shift, max_shift=max_shift, base_image_seq_len=base_image_seq_len,
-                              max_image_seq_len=max_image_seq_len, time_shift_type=time_shift_type, **kwargs)
+                              max_image_seq_len=max_image_seq_len, time_shift_type=time_shift_type, shift_terminal=shift_terminal,
+                              **kwargs)
         self.noise_level = noise_level
         assert self.noise_level >= 0, "Noise level must be non-negative."
         self._sde_steps = torch.tensor(sde_steps, dtype=torch.int64) if sde_steps is not None else None
@@ -189,6 +191,10 @@ class FlowMatchEulerDiscreteSDEScheduler:
             sig = self.time_shift(mu, 1.0, sig)
         else:
             sig = self.shift * sig / (1 + (self.shift - 1) * sig)
+        if self.config.get("shift_terminal"):
+            # diffusers stretch_shift_to_terminal (Qwen-Image: 0.02): rescale so that the last sigma equals shift_terminal
+            one_minus = 1 - np.asarray(sig)
+            sig = (1 - one_minus / (one_minus[-1] / (1 - self.config.shift_terminal))).astype(np.float32)
         sig_t = torch.from_numpy(np.asarray(sig)).to(dtype=torch.float32, device=device)
         self.timesteps = sig_t * n_train
         self.sigmas = torch.cat([sig_t, torch.zeros(1, device=sig_t.device)])

@@ -139,3 +139,68 @@ def test_ddp_reducer_is_armed_around_the_engine_autograd_node(tmp_path):
         port = so.getsockname()[1]
     mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert all(int(np.load(tmp_path / f"ddp_{r}.npy")[0]) == 1 for r in range(2))
+
+
+def _fsdp2_worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from torch.distributed.device_mesh import init_device_mesh
+    from torch.distributed.fsdp import fully_shard
+    import _plugin_fakes as F
+    from mi355_flow.binding import LiveWeights
+    from oracle import qwen_ref as Q
+    shapes = Q.state_dict_shapes(Q.tiny_config(num_layers=2, heads=1, joint_attention_dim=64))
+    mod = F.build_module_tree(shapes, buffers=(), seed=3)                 # same seed on both ranks = the unsharded model
+    want = {k: v.detach().clone() for k, v in mod.named_parameters()}
+    mesh = init_device_mesh("cpu", (world,))
+    for blk in mod.transformer_blocks.children():                          # per-block groups + the root, like accelerate's FSDP2 wrap
+        fully_shard(blk, mesh=mesh)
+    fully_shard(mod, mesh=mesh)
+
+    class Recorder:
+        def __init__(self):
+            self.bound, self.finished = {}, 0
+
+        def param_names(self):
+            return list(shapes)
+
+        def bind_tensor(self, name, t):
+            assert not hasattr(t, "full_tensor"), "the engine must receive whole tensors, not shards"
+            self.bound[name] = t.detach().float().clone()
+
+        def finish_binding(self):
+            self.finished += 1
+
+    eng = Recorder()
+    live = LiveWeights(eng, lambda: mod)
+    n0 = live.sync()
+    ok = n0 == len(shapes) and all(torch.equal(eng.bound[k], want[k]) for k in shapes)
+    ok = ok and live.sync() == 0                                           # nothing changed -> nothing re-bound (no all-gathers)
+    # one optimizer step on the SHARDED parameters: every rank updates its shard in place; the next sync must see it
+    sharded = type(next(mod.parameters())).__name__ == "DTensor" and next(mod.parameters())._local_tensor.numel() < want[next(iter(shapes))].numel()
+    for p in mod.parameters():
+        p.grad = torch.ones_like(p)
+    torch.optim.SGD(mod.parameters(), lr=0.5).step()
+    n1 = live.sync()
+    ok = ok and sharded and n1 == len(shapes) and all(torch.allclose(eng.bound[k], want[k] - 0.5) for k in shapes)
+    np.save(os.path.join(out_dir, f"fsdp_{rank}.npy"), np.array([int(ok), n0, n1]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fsdp2_sharded_module_binds_whole_tensors_and_tracks_optimizer_steps(tmp_path):
+    """SURVEY.md 8(f) N4, config E (Qwen-Image FSDP2, config/accelerate_configs/fsdp2.yaml): the trainable transformer is sharded with
+    `fully_shard`; `LiveWeights.sync()` hands the engine WHOLE tensors (`DTensor.full_tensor()`, a collective all ranks enter together),
+    skips everything unchanged, and re-binds after an in-place optimizer step on the shards (keyed on the DTensor's own version
+    counter: the local shard's does not move)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    mp.spawn(_fsdp2_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        ok, n0, n1 = np.load(tmp_path / f"fsdp_{r}.npy")
+        assert ok == 1 and n0 == n1 > 0, (r, ok, n0, n1)

@@ -78,8 +78,10 @@ def test_signatures_equal_the_references(ref):
     same order, same defaults; no `**kwargs` catch-all (it would let the trainer's whole training_args dict through)."""
     from flow_factory.models.flux.flux1 import Flux1Adapter
     from flow_factory.models.stable_diffusion.sd3_5 import SD3_5Adapter
+    from flow_factory.models.qwen_image.qwen_image import QwenImageAdapter
     from flow_factory.models.wan.wan2_t2v import Wan2_T2V_Adapter
-    pairs = [(ref.SD3_5NativeAdapter, SD3_5Adapter), (ref.Flux1NativeAdapter, Flux1Adapter), (ref.Wan2T2VNativeAdapter, Wan2_T2V_Adapter)]
+    pairs = [(ref.SD3_5NativeAdapter, SD3_5Adapter), (ref.Flux1NativeAdapter, Flux1Adapter), (ref.Wan2T2VNativeAdapter, Wan2_T2V_Adapter),
+             (ref.QwenImageNativeAdapter, QwenImageAdapter)]
     for ours, theirs in pairs:
         for meth in ("inference", "forward"):
             a, b = _params(getattr(ours, meth)), _params(getattr(theirs, meth))
@@ -98,9 +100,9 @@ def test_mixins_touch_only_public_scheduler_api(ref):
     """Every scheduler attribute the rollout mixins read exists on the reference's own scheduler classes."""
     from flow_factory.scheduler import FlowMatchEulerDiscreteSDEScheduler, UniPCMultistepSDEScheduler
     import re
-    import mi355_flow.adapter as A, mi355_flow.flux as FX, mi355_flow.wan as W, mi355_flow.scheduler as S
+    import mi355_flow.adapter as A, mi355_flow.flux as FX, mi355_flow.qwen as QW, mi355_flow.wan as W, mi355_flow.scheduler as S
     used = set()
-    for mod, names in ((A, ["NativeRolloutMixin"]), (FX, ["FluxRolloutMixin"]), (W, ["WanRolloutMixin"])):
+    for mod, names in ((A, ["NativeRolloutMixin"]), (FX, ["FluxRolloutMixin"]), (W, ["WanRolloutMixin"]), (QW, ["QwenRolloutMixin"])):
         for n in names:
             used |= set(re.findall(r"(?:self\.scheduler|sched|scheduler)\.([a-zA-Z_]+)", inspect.getsource(getattr(mod, n))))
     used |= set(re.findall(r"scheduler\.([a-zA-Z_]+)", inspect.getsource(S.host_noise_levels)))
