@@ -319,7 +319,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
     const int srow = lane >> 3, spc = lane & 7;
     const bf16_t* srcA[C::GA];
     const bf16_t* srcW[C::GW];
-    int cy[C::GA], cx[C::GA];                             // CONV: output pixel of the row; srcA = sample base + chunk
+    int cy[C::GA], cx[C::GA], ct[C::GA];                  // CONV: output pixel (and frame) of the row; srcA = frame base + chunk
 #pragma unroll
     for (int i = 0; i < C::GA; ++i) {
         const int row = (wave + i * C::NW) * 8 + srow;   // row inside the A tile
@@ -327,9 +327,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
         int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;  // clamp: rows beyond M are never stored
         if constexpr (CONV) {
             const int hw = p.conv_h * p.conv_w;
-            const int bi = gm / hw, pix = gm - bi * hw;
+            const int bi = gm / hw, pix = gm - bi * hw;       // bi = output frame (b * conv_t + t), or the image index in 2-D
             cy[i] = pix / p.conv_w; cx[i] = pix - cy[i] * p.conv_w;
-            srcA[i] = p.A + (long)bi * ((hw >> (2 * p.conv_up)) * (long)p.conv_cin) + c * 8;
+            int fi = bi;
+            ct[i] = 0;
+            if (p.conv_t > 0) {
+                const int b = bi / p.conv_t;
+                ct[i] = bi - b * p.conv_t;
+                fi = b * p.conv_t_in + ct[i];
+            }
+            srcA[i] = p.A + (long)fi * ((hw >> (2 * p.conv_up)) * (long)p.conv_cin) + c * 8;
         } else {
             srcA[i] = p.A + (long)gm * p.lda + c * 8;
         }
@@ -351,13 +358,17 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
             // K-tile kt lies inside one tap (conv_cin % 64 == 0): gather the shifted pixel's channels, zeros outside
             const int k0 = kt * BK;
             const int tap = k0 / p.conv_cin, c0 = k0 - tap * p.conv_cin;
-            const int ky = tap / 3, dy = ky - 1, dx = tap - ky * 3 - 1;
+            const int ks = p.conv_ks ? p.conv_ks : 3, nsp = ks * ks;
+            const int jt = tap / nsp, sp = tap - jt * nsp;                 // temporal tap, spatial tap
+            const int df = p.conv_kt > 1 ? jt - (p.conv_kt - 1) : 0;        // frame offset <= 0 (causal)
+            const int ky = sp / ks, dy = ky - (ks >> 1), dx = sp - ky * ks - (ks >> 1);
             const int win = p.conv_w >> p.conv_up;
+            const long foff = (long)df * ((long)(p.conv_h >> p.conv_up) * win * p.conv_cin);
 #pragma unroll
             for (int i = 0; i < C::GA; ++i) {
                 const int yy = cy[i] + dy, xx = cx[i] + dx;
-                const bool ok = (unsigned)yy < (unsigned)p.conv_h && (unsigned)xx < (unsigned)p.conv_w;
-                const bf16_t* src = srcA[i] + ((long)((yy >> p.conv_up) * win + (xx >> p.conv_up)) * p.conv_cin + c0);
+                const bool ok = (unsigned)yy < (unsigned)p.conv_h && (unsigned)xx < (unsigned)p.conv_w && ct[i] + df >= 0;
+                const bf16_t* src = srcA[i] + foff + ((long)((yy >> p.conv_up) * win + (xx >> p.conv_up)) * p.conv_cin + c0);
                 glds16(ok ? src : zsrc, base + (wave + i * C::NW) * 1024);
             }
         } else {
@@ -436,6 +447,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
                         if (n + e >= p.N) break;
                         // bf16 VAE semantics: the conv output and the denormalised image are each rounded to bf16
                         float y = round_bf16(acc[i][j][e] + p.bias[n + e]);
+                        if (p.img_clamp) y = fminf(fmaxf(y, -1.f), 1.f);
                         if (p.img_post) y = fminf(fmaxf(round_bf16(y * 0.5f + 0.5f), 0.f), 1.f);
                         const long o = ((long)bi * p.N + n + e) * hw + pix;
                         if (p.out_f32) p.out_f32[o] = y; else p.out[o] = f2bf(y);
@@ -815,8 +827,10 @@ hipError_t launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     p.raster_gm = g_raster_gm;
     if (p.K % BK != 0 || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;
     if (p.conv_cin > 0) {
-        if (p.conv_cin % BK != 0 || p.K != 9 * p.conv_cin || !p.zero_page || p.M % (p.conv_h * p.conv_w) != 0 ||
-            (p.conv_up && ((p.conv_h | p.conv_w) & 1)))
+        const int ks = p.conv_ks ? p.conv_ks : 3, kt3 = p.conv_kt ? p.conv_kt : 1;
+        if (p.conv_cin % BK != 0 || p.K != kt3 * ks * ks * p.conv_cin || !p.zero_page || p.M % (p.conv_h * p.conv_w) != 0 ||
+            (p.conv_up && ((p.conv_h | p.conv_w) & 1)) || (ks != 1 && ks != 3) || (kt3 != 1 && kt3 != 3) ||
+            (kt3 > 1 && (p.conv_t < 1 || p.conv_t_in < p.conv_t)) || (p.conv_t > 0 && (p.M / (p.conv_h * p.conv_w)) % p.conv_t != 0))
             return hipErrorInvalidValue;
         switch (p.epi) {
             case EPI_BIAS: return launch_simple<EPI_BIAS, true>(p, stream);

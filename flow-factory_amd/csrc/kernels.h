@@ -49,10 +49,16 @@ struct GemmParams {
     // EPI_F32 / EPI_IMG
     float* out_f32;           // EPI_F32 target; EPI_IMG: fp32 image (or nullptr -> bf16 image in `out`)
     int img_post;             // EPI_IMG: 1 = (x/2 + 0.5).clamp(0,1)
+    int img_clamp;            // EPI_IMG: 1 = clamp the decoder output to [-1, 1] first (video VAE)
     // implicit 3x3 convolution, padding 1 (conv_cin > 0): A is an NHWC activation tensor [B][Hin][Win][conv_cin], row m of the
     // GEMM is output pixel (b, y, x) of a conv_h x conv_w image, K = 9*conv_cin with k = tap*conv_cin + c (tap = ky*3 + kx);
     // conv_up = 1: the input is (conv_h/2) x (conv_w/2) and is nearest-2x upsampled on the fly (Upsample2D + conv)
     int conv_cin, conv_h, conv_w, conv_up;
+    // causal 3-D extension (video VAE): rows are (b, t, y, x) with conv_t output frames per sample; the input holds conv_t_in frames per
+    // sample (>= conv_t; the A pointer may be advanced by whole frames); conv_kt temporal taps reach BACK in time (frame t + j - (kt-1),
+    // zeros before frame 0); conv_ks = spatial kernel size (3 or 1).  K = kt*ks*ks*conv_cin, k = ((j*ks + ky)*ks + kx)*conv_cin + c.
+    // All zero = the plain 2-D 3x3 convolution above.
+    int conv_t, conv_t_in, conv_kt, conv_ks;
     const bf16_t* zero_page;  // >= 128 B of zeros: source of the padding taps
     // training-mode forward (the main output is bit-identical to the rollout's): EPI_BIAS_GELU also stores the pre-activation
     // bf16(acc + bias) to `stash` (row stride ld_stash); EPI_QK_NORM stores the per-(row, head) 1/rms to rstd_out[m * 2H + head]
@@ -175,6 +181,16 @@ hipError_t launch_group_norm(const bf16_t* x, bf16_t* y, const float* gamma, con
 hipError_t launch_softmax_rows(const float* s, bf16_t* p, long rows, int n, float scale, hipStream_t st);
 // conv weight [Co][Ci][taps] (any dtype) -> bf16 [Co][taps][Cpad] (k = tap*Cpad + ci; ci >= Ci zero); taps = 1 for 1x1 / linear
 hipError_t launch_conv_repack(const void* src, int dt, bf16_t* dst, int Co, int Ci, int Cpad, int taps, hipStream_t st);
+// ---- video VAE (causal 3-D; vae.hip)
+hipError_t launch_softmax_rows_ld(const float* s, long ld_s, bf16_t* p, long ld_p, long rows, int n, float scale, hipStream_t st);
+struct WvaeIngestParams {
+    int B, C, T, Cpad, denorm; long HW;
+    float mean[16], std[16];
+    const float* w_pq; const float* b_pq;     // post_quant_conv [C][C], [C] fp32
+};
+hipError_t launch_wvae_ingest(const void* lat, int dt, bf16_t* out, const WvaeIngestParams& q, hipStream_t st);
+hipError_t launch_wan_rms(const bf16_t* x, bf16_t* y, const float* gamma, long M, int C, int Cpad, bool silu, hipStream_t st);
+hipError_t launch_frame_interleave(const bf16_t* x, const bf16_t* tc, bf16_t* out, int B, int T, long HW, int C, hipStream_t st);
 // shared error sink of the C ABI (engine.hip): formats into mi355_last_error(), returns 1
 int errorf(const char* fmt, ...);
 

@@ -179,6 +179,133 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, bf16_
     }
 }
 
+// softmax over the first n entries of rows with stride ld_s (fp32 scores) -> bf16 probabilities with stride ld_p; columns [n, ld_p) are
+// written as zeros (they are the zero-padded K range of the following P.V GEMM).  ld_s % 4 == 0, ld_p % 4 == 0, any n <= ld_s.
+__global__ __launch_bounds__(256) void softmax_rows_ld_kernel(const float* s, long ld_s, bf16_t* p, long ld_p, int n, float scale_log2e) {
+    __shared__ float red[8];
+    const long row = blockIdx.x;
+    const float4* src = (const float4*)(s + row * ld_s);
+    const int n4 = (n + 3) >> 2, p4 = (int)(ld_p >> 2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    auto load = [&](int i) {
+        float4 v = src[i];
+        const int c = i * 4;
+        if (c + 1 >= n) v.y = -INFINITY;
+        if (c + 2 >= n) v.z = -INFINITY;
+        if (c + 3 >= n) v.w = -INFINITY;
+        return v;
+    };
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = load(i);
+        m = fmaxf(fmaxf(fmaxf(m, v.x), fmaxf(v.y, v.z)), v.w);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float mb = m * scale_log2e;
+    float sum = 0.f;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = load(i);
+        sum += exp2f(v.x * scale_log2e - mb) + exp2f(v.y * scale_log2e - mb) + exp2f(v.z * scale_log2e - mb) + exp2f(v.w * scale_log2e - mb);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    uint2* dst = (uint2*)(p + row * ld_p);
+    for (int i = threadIdx.x; i < p4; i += 256) {
+        if (i < n4) {
+            const float4 v = load(i);
+            dst[i] = make_uint2(pack_bf16(exp2f(v.x * scale_log2e - mb) * inv, exp2f(v.y * scale_log2e - mb) * inv),
+                                pack_bf16(exp2f(v.z * scale_log2e - mb) * inv, exp2f(v.w * scale_log2e - mb) * inv));
+        } else {
+            dst[i] = make_uint2(0u, 0u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ video VAE (causal 3-D, Wan / Qwen-Image)
+// latent ingest: (B, 16, T, h, w) storage dtype -> [B][T][h*w][Cpad] bf16 with the de-normalisation z*std + mean (wan2_t2v.py:217-226) and
+// the 1x1x1 post_quant_conv (a 16x16 matrix per pixel, fp32) fused; channels >= C are zero.  One thread per pixel.
+__global__ __launch_bounds__(256) void wvae_ingest_kernel(const void* lat, int dt, bf16_t* out, WvaeIngestParams q) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;        // over B*T*HW
+    const long n = (long)q.B * q.T * q.HW;
+    if (idx >= n) return;
+    const long pix = idx % q.HW;
+    const long bt = idx / q.HW;
+    const int t = (int)(bt % q.T);
+    const long b = bt / q.T;
+    float z[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        float v = 0.f;
+        if (c < q.C) {
+            v = load_as_f32(lat, ((b * q.C + c) * q.T + t) * q.HW + pix, dt);
+            if (q.denorm) v = v / (1.0f / q.std[c]) + q.mean[c];
+        }
+        z[c] = v;
+    }
+    bf16_t* o = out + idx * q.Cpad;
+    for (int co = 0; co < q.Cpad; co += 2) {
+        float y[2] = {0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if (co + e < q.C) {
+                float a = q.b_pq[co + e];
+                for (int c = 0; c < q.C; ++c) a += q.w_pq[(co + e) * q.C + c] * z[c];
+                y[e] = a;
+            }
+        *(unsigned*)(o + co) = pack_bf16(y[0], y[1]);
+    }
+}
+
+// WanRMS_norm (+ SiLU): y = x / max(||x||_2, 1e-12) * sqrt(C) * gamma over the C real channels of one pixel row; gamma is zero on the
+// padded channels.  One wave per row, 4-byte accesses (every wave instruction covers 256 contiguous bytes).
+template <bool SILU>
+__global__ __launch_bounds__(256) void wan_rms_kernel(const bf16_t* x, bf16_t* y, const float* gamma, long M, int C, int Cpad) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const bf16_t* row = x + m * Cpad;
+    float ss = 0.f;
+    for (int d = 2 * lane; d < Cpad; d += 128) {
+        const unsigned u = *(const unsigned*)(row + d);
+        ss += bf_lo(u) * bf_lo(u) + bf_hi(u) * bf_hi(u);
+    }
+    const float sc = sqrtf((float)C) / fmaxf(sqrtf(wave_sum(ss)), 1e-12f);
+    for (int d = 2 * lane; d < Cpad; d += 128) {
+        const unsigned u = *(const unsigned*)(row + d);
+        const float2 g = *(const float2*)(gamma + d);
+        float a = bf_lo(u) * sc * g.x, b = bf_hi(u) * sc * g.y;
+        if (SILU) { a = a / (1.0f + __expf(-a)); b = b / (1.0f + __expf(-b)); }
+        *(unsigned*)(y + m * Cpad + d) = pack_bf16(a, b);
+    }
+}
+
+// temporal upsampler (WanResample 'upsample3d'): out[b][0] = x[b][0]; out[b][1 + 2t + s][pix][c] = tc[b][t][pix][s*C + c]
+// x [B][T][HW][C], tc [B][T-1][HW][2C], out [B][2T-1][HW][C]; one thread per 16-byte chunk of out
+__global__ __launch_bounds__(256) void frame_interleave_kernel(const bf16_t* x, const bf16_t* tc, bf16_t* out, int B, int T, long HW, int C) {
+    const int cc = C >> 3;
+    const long n = (long)B * (2 * T - 1) * HW * cc;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c8 = (int)(i % cc);
+    long r = i / cc;
+    const long pix = r % HW; r /= HW;
+    const int f = (int)(r % (2 * T - 1));
+    const long b = r / (2 * T - 1);
+    const uint4* src;
+    if (f == 0) src = (const uint4*)(x + ((b * T) * HW + pix) * C) + c8;
+    else {
+        const int t = (f - 1) >> 1, sx = (f - 1) & 1;
+        src = (const uint4*)(tc + ((b * (T - 1) + t) * HW + pix) * (2L * C) + (long)sx * C) + c8;
+    }
+    ((uint4*)out)[i] = *src;
+}
+
 // ------------------------------------------------------------------------------ weight repack
 __global__ __launch_bounds__(256) void conv_repack_kernel(const void* src, int dt, bf16_t* dst, int Co, int Ci, int Cpad, int taps) {
     const long n = (long)Co * taps * Cpad;
@@ -227,6 +354,34 @@ hipError_t launch_group_norm(const bf16_t* x, bf16_t* y, const float* gamma, con
 hipError_t launch_softmax_rows(const float* s, bf16_t* p, long rows, int n, float scale, hipStream_t st) {
     if (n % 4) return hipErrorInvalidValue;
     hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, s, p, n, scale * 1.44269504088896340736f);
+    return hipGetLastError();
+}
+
+hipError_t launch_softmax_rows_ld(const float* s, long ld_s, bf16_t* p, long ld_p, long rows, int n, float scale, hipStream_t st) {
+    if ((ld_s & 3) || (ld_p & 3) || n < 1 || n > ld_s || n > ld_p) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(softmax_rows_ld_kernel, dim3((unsigned)rows), dim3(256), 0, st, s, ld_s, p, ld_p, n, scale * 1.44269504088896340736f);
+    return hipGetLastError();
+}
+
+hipError_t launch_wvae_ingest(const void* lat, int dt, bf16_t* out, const WvaeIngestParams& q, hipStream_t st) {
+    if (q.C < 1 || q.C > 16 || (q.Cpad & 1) || q.Cpad < q.C) return hipErrorInvalidValue;
+    const long n = (long)q.B * q.T * q.HW;
+    hipLaunchKernelGGL(wvae_ingest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, lat, dt, out, q);
+    return hipGetLastError();
+}
+
+hipError_t launch_wan_rms(const bf16_t* x, bf16_t* y, const float* gamma, long M, int C, int Cpad, bool silu, hipStream_t st) {
+    if (M <= 0 || (Cpad & 1) || C > Cpad) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((M + 3) / 4));
+    if (silu) hipLaunchKernelGGL(wan_rms_kernel<true>, grid, dim3(256), 0, st, x, y, gamma, M, C, Cpad);
+    else hipLaunchKernelGGL(wan_rms_kernel<false>, grid, dim3(256), 0, st, x, y, gamma, M, C, Cpad);
+    return hipGetLastError();
+}
+
+hipError_t launch_frame_interleave(const bf16_t* x, const bf16_t* tc, bf16_t* out, int B, int T, long HW, int C, hipStream_t st) {
+    if (T < 2 || (C & 7)) return hipErrorInvalidValue;
+    const long n = (long)B * (2 * T - 1) * HW * (C >> 3);
+    hipLaunchKernelGGL(frame_interleave_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, tc, out, B, T, HW, C);
     return hipGetLastError();
 }
 

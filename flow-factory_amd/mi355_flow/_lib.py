@@ -52,6 +52,13 @@ class WanCfg(C.Structure):
     ]
 
 
+class WvaeCfg(C.Structure):
+    _fields_ = [
+        ("z_dim", C.c_int32), ("base_dim", C.c_int32), ("num_res_blocks", C.c_int32), ("out_channels", C.c_int32),
+        ("dim_mult", C.c_int32 * 4), ("temporal_upsample", C.c_int32 * 3), ("latents_mean", C.c_float * 16), ("latents_std", C.c_float * 16),
+    ]
+
+
 class QwenCfg(C.Structure):
     _fields_ = [
         ("in_channels", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("head_dim", C.c_int32),
@@ -148,6 +155,18 @@ SIGNATURES = {
                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, _P, _P, _I]),
     "mi355_op_cfg_rescale": (_I, [_P, _P, _P, _F, _P, _L, _I]),
     "mi355_op_rms_rows": (_I, [_P, _P, _P, _P, _I, _I, _F]),
+    "mi355_wvae_create": (_I, [C.POINTER(WvaeCfg), C.POINTER(_P)]),
+    "mi355_wvae_destroy": (_I, [_P]),
+    "mi355_wvae_bind_weight": (_I, [_P, C.c_char_p, _P, _I, _I, C.POINTER(_L), _P]),
+    "mi355_wvae_weights_ready": (_I, [_P]),
+    "mi355_wvae_num_params": (_I, [_P]),
+    "mi355_wvae_param_name": (C.c_char_p, [_P, _I]),
+    "mi355_wvae_plan_create": (_I, [_P, _I, _I, _I, _I, C.POINTER(_P)]),
+    "mi355_wvae_plan_destroy": (_I, [_P]),
+    "mi355_wvae_plan_workspace_bytes": (_L, [_P]),
+    "mi355_wvae_decode": (_I, [_P, _P, _P, _I, _I, _P, _I, _I, _I]),
+    "mi355_op_conv3d_causal": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I]),
+    "mi355_op_wan_rms": (_I, [_P, _P, _P, _P, _L, _I, _I, _I]),
     "mi355_op_conv3x3": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
     "mi355_op_conv_repack": (_I, [_P, _P, _I, _P, _I, _I, _I, _I]),
     "mi355_op_group_norm": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, _I, _I, _F, _I]),

@@ -134,6 +134,15 @@ def _native_vae(pipeline):
     return dec
 
 
+def _native_video_vae(pipeline):
+    """The Wan / Qwen-Image VAE (AutoencoderKLWan / AutoencoderKLQwenImage) is frozen too: bind its decoder once."""
+    from .vae import WanVAEConfig, WanVAEDecoder
+    dec = WanVAEDecoder(WanVAEConfig.from_hf(pipeline.vae.config))
+    dec.bind_state_dict(pipeline.vae.state_dict())
+    dec.ready()
+    return dec
+
+
 if _RefAdapter is not None:
 
     class SD3_5NativeAdapter(_LiveBinding, NativeRolloutMixin, _RefAdapter):
@@ -224,7 +233,7 @@ if _RefAdapter is not None:
             """`Wan2_T2V_Adapter` (reference models/wan/wan2_t2v.py) with the rollout on the MI355X engine: single-transformer Wan2.1, and
             two-expert Wan2.2 pipelines (`transformer` while t >= boundary_ratio * 1000, `transformer_2` below, each with its own
             guidance scale: wan2_t2v.py:476-487) as two engines stepped per timestep.  Per-token timesteps (`expand_timesteps`, TI2V-5B)
-            are rejected.  The video VAE is the pipeline's; evaluation-mode sampling (diffusers' UniPC multistep solver) stays on the
+            are rejected.  The causal 3-D video VAE decode is native (csrc/wan_vae_engine.hip); evaluation-mode sampling (diffusers' UniPC multistep solver) stays on the
             reference path."""
 
             _sample_cls = _RefWanSample
@@ -255,6 +264,16 @@ if _RefAdapter is not None:
             def _eval_inference(self, **kwargs):
                 return _RefWan.inference(self, **kwargs)
 
+            @torch.no_grad()
+            def decode_latents(self, latents, output_type="pil"):
+                # wan2_t2v.py:215-230 with vae.decode on the native decoder (de-normalisation fused into its ingest kernel)
+                if getattr(self, "vae_decoder", None) is None:
+                    self.vae_decoder = _native_video_vae(self.pipeline)
+                if output_type == "pt":
+                    return self.vae_decoder.decode(latents, postprocess=True, out_dtype=torch.float32)
+                video = self.vae_decoder.decode(latents, postprocess=False, out_dtype=torch.float32).permute(0, 2, 1, 3, 4)
+                return self.pipeline.video_processor.postprocess_video(video, output_type=output_type)
+
             @functools.wraps(WanRolloutMixin.forward)
             def forward(self, *args, **kwargs):
                 if torch.is_grad_enabled() or bool(getattr(self.scheduler, "is_eval", False)):
@@ -273,7 +292,8 @@ if _RefAdapter is not None:
             """`QwenImageAdapter` (reference models/qwen_image/qwen_image.py) with the GRPO rollout on the MI355X engine.  The trainable
             transformer may be FSDP2-sharded (config/accelerate_configs/fsdp2.yaml): `LiveWeights` binds every parameter through
             `DTensor.full_tensor()` (all ranks call inference() / forward() together, so the all-gathers line up) into the engine's own
-            resident 41 GB bf16 copy, once per optimiser epoch.  The image VAE stays the pipeline's (`decode_latents` is inherited)."""
+            resident 41 GB bf16 copy, once per optimiser epoch.  The image VAE (AutoencoderKLQwenImage = the causal video VAE on one frame) is
+            decoded natively as well."""
 
             _sample_cls = _RefQwenSample
             _output_cls = _RefOutput
@@ -287,6 +307,17 @@ if _RefAdapter is not None:
                     in_channels=tc.in_channels, num_layers=tc.num_layers, num_attention_heads=tc.num_attention_heads,
                     attention_head_dim=tc.attention_head_dim, joint_attention_dim=tc.joint_attention_dim,
                     axes_dims_rope=tuple(tc.axes_dims_rope))))
+
+            @torch.no_grad()
+            def decode_latents(self, latents, height, width, output_type="pil"):
+                # qwen_image.py:197-213 with vae.decode on the native decoder (one latent frame -> the 2-D path of the video VAE)
+                from .qwen import decode_packed_latents
+                if getattr(self, "vae_decoder", None) is None:
+                    self.vae_decoder = _native_video_vae(self.pipeline)
+                if output_type == "pt":
+                    return decode_packed_latents(self.vae_decoder, latents, height, width)
+                images = decode_packed_latents(self.vae_decoder, latents, height, width, postprocess=False)
+                return self.pipeline.image_processor.postprocess(images, output_type=output_type)
 
             @functools.wraps(QwenRolloutMixin.forward)
             def forward(self, *args, **kwargs):

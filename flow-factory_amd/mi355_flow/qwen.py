@@ -461,7 +461,8 @@ class QwenImageNativeAdapter(QwenRolloutMixin):
 
     def __init__(self, source, config: Optional[QwenConfig] = None, scheduler: Optional[FlowMatchEulerDiscreteSDEScheduler] = None,
                  latent_storage_dtype: Optional[str] = "bf16", transformer_dtype: torch.dtype = torch.bfloat16,
-                 device: Union[str, torch.device] = "cuda"):
+                 device: Union[str, torch.device] = "cuda", vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, vae_config=None,
+                 vae_max_batch: int = 4):
         if not torch.cuda.is_available():
             raise RuntimeError("mi355_flow: no GPU visible; the native rollout engine has no CPU path")
         self.device = torch.device(device)
@@ -472,6 +473,13 @@ class QwenImageNativeAdapter(QwenRolloutMixin):
             shift=1.0, use_dynamic_shifting=True, base_shift=0.5, max_shift=0.9, base_image_seq_len=256, max_image_seq_len=8192,
             shift_terminal=0.02, sde_steps=[1, 2, 3], num_sde_steps=1)
         self.engine = QwenEngine(config or QwenConfig())
+        self.vae_decoder = None
+        self.vae_max_batch = vae_max_batch
+        if vae_state_dict is not None:                    # AutoencoderKLQwenImage = the causal 3-D video VAE on one frame
+            from .vae import WanVAEConfig, WanVAEDecoder
+            self.vae_decoder = WanVAEDecoder(vae_config or WanVAEConfig())
+            self.vae_decoder.bind_state_dict(vae_state_dict)
+            self.vae_decoder.ready()
         self._live_weights = None
         if isinstance(source, torch.nn.Module):
             from .binding import LiveWeights
@@ -506,8 +514,22 @@ class QwenImageNativeAdapter(QwenRolloutMixin):
         raise RuntimeError("mi355_flow standalone adapter has no text encoder: pass prompt_embeds + prompt_embeds_mask")
 
     def decode_latents(self, latents: torch.Tensor, height: int, width: int, output_type: str = "pt"):
-        """qwen_image.py:197-213 decodes with AutoencoderKLQwenImage; the standalone adapter carries no VAE and returns no image."""
-        return None
+        """qwen_image.py:197-213: unpack to (B, 16, 1, h, w), latents / (1/std) + mean, vae.decode(...)[:, :, 0], postprocess."""
+        if self.vae_decoder is None:
+            return None
+        if output_type not in ("pt", "np"):
+            raise ValueError("mi355_flow standalone adapter decodes to 'pt' or 'np'")
+        img = decode_packed_latents(self.vae_decoder, latents, height, width, max_batch=self.vae_max_batch)
+        return img if output_type == "pt" else img.float().permute(0, 2, 3, 1).cpu().numpy()
+
+
+def decode_packed_latents(decoder, latents: torch.Tensor, height: int, width: int, postprocess: bool = True, max_batch: int = 4,
+                          out_dtype: torch.dtype = torch.bfloat16) -> torch.Tensor:
+    """Packed (B, Ni, 64) latents -> (B, 3, H, W): `_unpack_latents` to one latent frame, the video VAE decoder on it, frame 0."""
+    h = 2 * (int(height) // (VAE_SCALE_FACTOR * 2))
+    w = 2 * (int(width) // (VAE_SCALE_FACTOR * 2))
+    lat = unpack_latents(latents, h, w).unsqueeze(2).contiguous()
+    return decoder.decode(lat, postprocess=postprocess, out_dtype=out_dtype, max_batch=max_batch)[:, 0]
 
 
 def op_cfg_rescale(v_neg: torch.Tensor, v_pos: torch.Tensor, guidance_scale: float) -> torch.Tensor:

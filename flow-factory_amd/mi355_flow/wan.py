@@ -4,8 +4,8 @@
 Kept from the reference: latents `(B, 16, T, h, w)` drawn in fp32 (`prepare_latents(dtype=float32)`), `timestep = t.expand(B)` with
 the scheduler's integer timesteps, classifier-free guidance as `u + g (c - u)` (here one forward over the batch [negative, positive]
 instead of two passes), `UniPCMultistepSDEScheduler.step` in rollout mode = the four SDE / ODE dynamics with sigma = t / 1000.
-Not covered (raise): Wan2.2 `boundary_ratio` / `transformer_2`, `expand_timesteps`, `attention_kwargs`.  The causal 3-D video VAE is
-not native: `decode_latents` delegates to an attached callable (samples carry no video otherwise).
+Not covered (raise): `expand_timesteps` (Wan2.2-TI2V), `attention_kwargs`.  The causal 3-D video VAE decode is native too
+(`mi355_flow.vae.WanVAEDecoder`, csrc/wan_vae_engine.hip): pass `vae_state_dict` to the standalone adapter (or a `video_decode` callable).
 """
 from __future__ import annotations
 
@@ -449,7 +449,8 @@ class Wan2T2VNativeAdapter(WanRolloutMixin):
                  scheduler: Optional[UniPCMultistepSDEScheduler] = None, latent_storage_dtype: Optional[str] = "fp16",
                  transformer_dtype: torch.dtype = torch.bfloat16, device: Union[str, torch.device] = "cuda",
                  video_decode: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
-                 state_dict_2: Optional[Dict[str, torch.Tensor]] = None, boundary_ratio: Optional[float] = None):
+                 state_dict_2: Optional[Dict[str, torch.Tensor]] = None, boundary_ratio: Optional[float] = None,
+                 vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, vae_config=None, vae_max_batch: int = 1):
         if not torch.cuda.is_available():
             raise RuntimeError("mi355_flow: no GPU visible; the native rollout engine has no CPU path")
         self.device = torch.device(device)
@@ -466,6 +467,13 @@ class Wan2T2VNativeAdapter(WanRolloutMixin):
             self.engine_2.ready()
             self.boundary_ratio = float(boundary_ratio)
         self._video_decode = video_decode
+        self.vae_decoder = None
+        self.vae_max_batch = vae_max_batch
+        if vae_state_dict is not None:
+            from .vae import WanVAEConfig, WanVAEDecoder
+            self.vae_decoder = WanVAEDecoder(vae_config or WanVAEConfig())
+            self.vae_decoder.bind_state_dict(vae_state_dict)
+            self.vae_decoder.ready()
 
     @property
     def latent_storage_dtype(self) -> Optional[torch.dtype]:
@@ -488,4 +496,10 @@ class Wan2T2VNativeAdapter(WanRolloutMixin):
         raise RuntimeError("mi355_flow standalone adapter has no text encoder: pass prompt_embeds (and negative_prompt_embeds for CFG)")
 
     def decode_latents(self, latents: torch.Tensor, output_type: str = "pt"):
+        """wan2_t2v.py:215-230: de-normalise, vae.decode, postprocess_video -> (B, F, 3, H, W) in [0, 1]."""
+        if self.vae_decoder is not None:
+            if output_type not in ("pt", "np"):
+                raise ValueError("mi355_flow standalone adapter decodes to 'pt' or 'np'")
+            vid = self.vae_decoder.decode(latents, postprocess=True, out_dtype=torch.float32, max_batch=self.vae_max_batch)
+            return vid if output_type == "pt" else vid.permute(0, 1, 3, 4, 2).cpu().numpy()
         return self._video_decode(latents) if self._video_decode is not None else None

@@ -316,6 +316,42 @@ int mi355_op_cfg_rescale(void* stream, const void* v_neg, const void* v_pos, flo
 /* RMSNorm over whole rows: x bf16 [rows][dim], weight fp32 [dim] -> out bf16 [rows][dim] */
 int mi355_op_rms_rows(void* stream, const void* x, const float* weight, void* out, int rows, int dim, float eps);
 
+/* ---- causal 3-D video VAE decode (Wan2.1 / Wan2.2-A14B / Qwen-Image VAE) ----------------------------
+ * Replaces `pipeline.vae.decode` + `video_processor.postprocess_video` in Wan2_T2V_Adapter.decode_latents (reference
+ * models/wan/wan2_t2v.py:215-230) and, with one latent frame, `vae.decode(...)[:, :, 0]` + `image_processor.postprocess` in
+ * QwenImageAdapter.decode_latents (models/qwen_image/qwen_image.py:197-213).  Parameter names are the state_dict() keys of diffusers'
+ * AutoencoderKLWan (`post_quant_conv.*`, `decoder.*`).  dim_mult as in the HF config (ascending); temporal_upsample[i] = up block i
+ * doubles the frames (HF `temperal_downsample` reversed). */
+typedef struct mi355_wvae mi355_wvae;
+typedef struct mi355_wvae_plan mi355_wvae_plan;
+typedef struct mi355_wvae_cfg {
+    int32_t z_dim, base_dim, num_res_blocks, out_channels;
+    int32_t dim_mult[4];
+    int32_t temporal_upsample[3];
+    float latents_mean[16], latents_std[16];
+} mi355_wvae_cfg;
+int mi355_wvae_create(const mi355_wvae_cfg* cfg, mi355_wvae** out);
+int mi355_wvae_destroy(mi355_wvae* v);
+int mi355_wvae_bind_weight(mi355_wvae* v, const char* name, const void* src, int dtype, int ndim, const int64_t* shape, void* stream);
+int mi355_wvae_weights_ready(mi355_wvae* v);
+int mi355_wvae_num_params(mi355_wvae* v);
+const char* mi355_wvae_param_name(mi355_wvae* v, int i);
+/* latent grid (T, h, w); h*w must be a multiple of 8 */
+int mi355_wvae_plan_create(mi355_wvae* v, int max_batch, int latent_t, int latent_h, int latent_w, mi355_wvae_plan** out);
+int mi355_wvae_plan_destroy(mi355_wvae_plan* plan);
+int64_t mi355_wvae_plan_workspace_bytes(mi355_wvae_plan* plan);
+/* latents (batch, z_dim, T, h, w) in lat_dtype; denormalise != 0: z = latents / (1/std) + mean first.  video
+ * [batch][F = 1 + 4 (T-1)][out_channels][8h][8w], fp32 (0) or bf16 (1); postprocess != 0: (x/2 + 0.5) clamped to [0, 1], else the
+ * decoder output clamped to [-1, 1] */
+int mi355_wvae_decode(mi355_wvae_plan* plan, void* stream, const void* latents, int lat_dtype, int batch, void* video, int vid_dtype,
+                      int postprocess, int denormalise);
+/* operator-level (unit tests): causal convolution over x [B][T_in][H>>up][W>>up][Cin] bf16 (Cin % 64 == 0) with kt (1 | 3) temporal taps
+ * reaching back in time and ks x ks (1 | 3) spatial taps; w_packed [Cout][kt*ks*ks][Cin] (mi355_op_conv_repack); out [B*T*H*W][Cout] */
+int mi355_op_conv3d_causal(void* stream, const void* x, const void* w_packed, const float* bias, const void* residual, void* out,
+                           int B, int T, int T_in, int H, int W, int Cin, int Cout, int kt, int ks, int upsample);
+/* WanRMS_norm (+ SiLU): rows of C_pad bf16 channels, the first C real; gamma fp32 [C_pad] */
+int mi355_op_wan_rms(void* stream, const void* x, const float* gamma, void* out, int64_t rows, int C, int C_pad, int silu);
+
 /* VAE operator-level entry points (unit tests / microbenchmarks).  NHWC bf16 activations.
  * conv3x3: x [B][H>>up][W>>up][Cin] (Cin % 64 == 0), w_packed [Cout][9][Cin] bf16 (mi355_op_conv_repack), padding 1,
  * optional nearest-2x upsample of x folded in, optional residual [B*H*W][Cout] added (may alias out) -> out [B*H*W][Cout] */
