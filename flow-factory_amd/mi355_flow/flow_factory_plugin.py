@@ -302,7 +302,6 @@ if _RefAdapter is not None:
             def __init__(self, config, accelerator):
                 _RefQwen.__init__(self, config, accelerator)
                 tc = self.pipeline.transformer.config
-                self.transformer_dtype = self.pipeline.transformer.dtype
                 self._init_live(QwenEngine(QwenConfig(
                     in_channels=tc.in_channels, num_layers=tc.num_layers, num_attention_heads=tc.num_attention_heads,
                     attention_head_dim=tc.attention_head_dim, joint_attention_dim=tc.joint_attention_dim,

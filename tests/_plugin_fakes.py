@@ -249,3 +249,83 @@ def make_pipeline(cfg, transformer: nn.Module):
     pipe.maybe_free_model_hooks = lambda: None
     pipe.components = {"transformer": transformer, "vae": vae, "text_encoder": pipe.text_encoder}
     return pipe
+
+
+# --------------------------------------------------------------------------------------- Qwen-Image doubles
+class FakeQwenPlan:
+    def __init__(self, engine, key, max_steps):
+        self.engine, self.key, self.max_steps = engine, key, max_steps
+        self.batch, self.n_cfg, self.h, self.w, self.n_text = key
+        self.Ni, self.C = (self.h // 2) * (self.w // 2), engine.cfg.in_channels
+
+    def rollout(self, timesteps, sigmas, noise_levels, dynamics, guidance, init_latents, storage_dtype, step_noise, embeds, lens=None,
+                keep_positions=None, compute_log_prob=True):
+        N, B = len(timesteps), self.batch
+        assert embeds.shape[0] == B * self.n_cfg and embeds.shape[1] == self.n_text and len(lens) == B * self.n_cfg
+        self.engine.calls.append(("rollout", dict(N=N, dynamics=dynamics, guidance=guidance, noise_levels=list(noise_levels), n_cfg=self.n_cfg,
+                                                   lens=list(lens), n_text=self.n_text, keep=list(keep_positions) if keep_positions is not None else None,
+                                                   weights=self.engine.fingerprint())))
+        keep = list(range(N + 1)) if keep_positions is None else sorted(set(keep_positions))
+        g = torch.Generator().manual_seed(5)
+        lat = torch.randn((len(keep), B, self.Ni, self.C), generator=g).to(storage_dtype)
+        lp = torch.full((N, B), float("nan"))
+        for i, e in enumerate(noise_levels):
+            if e > 0 and compute_log_prob:
+                lp[i] = -1.0 - 0.01 * i - 0.001 * torch.arange(B)
+        return lat, lp, lat[-1].clone()
+
+
+class FakeQwenEngine(FakeEngine):
+    _ABI, _WHAT = "qwen", "Qwen-Image transformer"
+
+    def __init__(self, cfg):
+        from oracle import qwen_ref as Q
+        self.cfg = cfg
+        self._names = list(Q.state_dict_shapes(Q.QwenConfig(num_layers=cfg.num_layers, num_attention_heads=cfg.num_attention_heads,
+                                                            joint_attention_dim=cfg.joint_attention_dim)).keys())
+        self.bound, self.bind_log, self.calls, self._plans = {}, [], [], {}
+
+    def plan(self, batch, n_cfg, h, w, n_text, max_steps):
+        key = (batch, n_cfg, h, w, n_text)
+        p = self._plans.get(key)
+        if p is None or p.max_steps < max_steps:
+            p = self._plans[key] = FakeQwenPlan(self, key, max_steps)
+        return p
+
+
+class FakeVideoVAEDecoder:
+    def __init__(self, cfg=None):
+        self.n = 0
+
+    def bind_state_dict(self, sd, **k):
+        pass
+
+    def ready(self):
+        pass
+
+    def decode(self, latents, postprocess=True, out_dtype=torch.bfloat16, max_batch=1, denormalise=True):
+        self.n += 1
+        B, _, T, h, w = latents.shape
+        return torch.full((B, 1 + 4 * (T - 1), 3, 8 * h, 8 * w), 0.5, dtype=out_dtype)
+
+
+def make_qwen_pipeline(tcfg, transformer: nn.Module):
+    from oracle import diffusers_stub as D
+    transformer.config = types.SimpleNamespace(
+        in_channels=tcfg.in_channels, num_layers=tcfg.num_layers, num_attention_heads=tcfg.num_attention_heads,
+        attention_head_dim=tcfg.attention_head_dim, joint_attention_dim=tcfg.joint_attention_dim, axes_dims_rope=tuple(tcfg.axes_dims_rope))
+    vae = nn.Module()
+    vae.add_module("decoder", nn.Linear(2, 2))
+    vae.config = types.SimpleNamespace(z_dim=16, base_dim=96, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_downsample=(False, True, True),
+                                       latents_mean=[0.0] * 16, latents_std=[1.0] * 16)
+    pipe = types.SimpleNamespace()
+    pipe.transformer, pipe.vae = transformer, vae
+    pipe.text_encoder = nn.Linear(2, 2)
+    pipe.tokenizer = object()
+    pipe.vae_scale_factor = 8
+    pipe.scheduler = D.FlowMatchEulerDiscreteScheduler(num_train_timesteps=1000, shift=1.0, use_dynamic_shifting=True, base_shift=0.5,
+                                                       max_shift=0.9, base_image_seq_len=256, max_image_seq_len=8192)
+    pipe.image_processor = types.SimpleNamespace(postprocess=lambda x, output_type="pt": x)
+    pipe.maybe_free_model_hooks = lambda: None
+    pipe.components = {"transformer": transformer, "vae": vae, "text_encoder": pipe.text_encoder}
+    return pipe

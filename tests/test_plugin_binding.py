@@ -297,3 +297,66 @@ def test_missing_parameters_fail_fast(ref):
     tr = F.build_module_tree(shapes)
     with pytest.raises(KeyError, match="to_v.bias"):
         LiveWeights(F.FakeEngine(tcfg), lambda: tr).sync()
+
+
+# ------------------------------------------------------------------------------------------------- Qwen-Image (config E)
+def test_qwen_image_plugin_rollout_with_ragged_prompts(ref):
+    """`QwenImageNativeAdapter(config, accelerator)` built as Flow-Factory does from the reference's own example YAML
+    (examples/grpo/full/qwen_image/default.yaml): the trainer's kwargs filter, ragged prompt lists, a negative prompt of another length,
+    the reference's `QwenImageSample` and `BaseSample.stack` on the result, the native video-VAE decoder on the single latent frame."""
+    import mi355_flow.qwen as QW
+    from flow_factory.hparams import Arguments
+    from flow_factory.models.qwen_image.qwen_image import QwenImageSample as RefSample
+    from flow_factory.samples import BaseSample
+    from flow_factory.utils.base import filter_kwargs
+    from oracle import qwen_ref as Q
+    P = ref
+    import mi355_flow.vae as MV
+    cfg = Arguments.load_from_yaml("/root/reference/examples/grpo/full/qwen_image/default.yaml")
+    tcfg = QW.QwenConfig(num_layers=2, num_attention_heads=1, joint_attention_dim=64)
+    tr = F.build_module_tree(Q.state_dict_shapes(Q.QwenConfig(num_layers=2, num_attention_heads=1, joint_attention_dim=64)), buffers=(),
+                             cls=F.FakeTransformer)
+    real_engine, real_dec = QW.QwenEngine, MV.WanVAEDecoder
+    import mi355_flow.flow_factory_plugin as PM
+    try:
+        # the plugin resolves these names at construction time inside its module / mi355_flow.vae
+        PM.QwenEngine = F.FakeQwenEngine
+        MV.WanVAEDecoder = F.FakeVideoVAEDecoder
+
+        class Plug(P.QwenImageNativeAdapter):
+            def load_pipeline(self):
+                return F.make_qwen_pipeline(tcfg, tr)
+
+        ad = Plug(cfg, F.FakeAccelerator())
+        ad.post_init()
+        ad.rollout()
+        B, N, J = 3, 6, 64
+        g = torch.Generator().manual_seed(0)
+        lens = [7, 11, 9]
+        batch = dict(prompt=["a", "b", "c"], prompt_embeds=[torch.randn(n, J, generator=g) for n in lens],
+                     prompt_embeds_mask=[torch.ones(n, dtype=torch.long) for n in lens], prompt_ids=[torch.arange(n) for n in lens],
+                     negative_prompt_embeds=torch.randn(B, 4, J, generator=g), negative_prompt_embeds_mask=torch.ones(B, 4, dtype=torch.long),
+                     some_dataset_column=[1, 2, 3])
+        kw = filter_kwargs(ad.inference, **{**cfg.training_args, "compute_log_prob": True, "trajectory_indices": "all", **batch,
+                                            "num_inference_steps": N, "height": 256, "width": 384, "guidance_scale": 4.0})
+        assert "some_dataset_column" not in kw and "clip_range" not in kw
+        samples = ad.inference(**kw)
+        assert F.FakeTransformer.calls == 0
+        kind, call = ad.engine.calls[-1]
+        assert kind == "rollout" and call["N"] == N and call["n_cfg"] == 2 and call["guidance"] == 4.0
+        assert call["lens"] == [4, 4, 4] + lens and call["n_text"] == 32                  # [negative | positive], padded to TEXT_PAD
+        assert len(ad.engine.bind_log) == len(ad.engine.param_names())                   # every parameter bound before the first call
+        assert len(samples) == B and all(type(s) is RefSample for s in samples)
+        s0 = samples[0]
+        assert s0.all_latents.shape == (N + 1, (256 // 16) * (384 // 16), 64) and s0.img_shapes == [(1, 16, 24)]
+        assert s0.prompt_embeds.shape == (7, J) and s0.prompt_embeds_mask.shape == (7,) and s0.negative_prompt_embeds_mask.shape == (4,)
+        assert s0.image.shape == (3, 256, 384) and ad.vae_decoder.n == 1
+        stacked = BaseSample.stack(samples)                                               # optimize(): ragged prompts stay lists
+        assert stacked["all_latents"].shape[:2] == (B, N + 1) and stacked["log_probs"].shape[0] == B
+        assert isinstance(stacked["prompt_embeds"], list) and [e.shape[0] for e in stacked["prompt_embeds"]] == lens
+        assert stacked["negative_prompt_embeds"].shape == (B, 4, J)
+        # guidance_scale <= 1: the negative branch is dropped (qwen_image.py:499-507)
+        ad.inference(**{**kw, "guidance_scale": 1.0})
+        assert ad.engine.calls[-1][1]["n_cfg"] == 1 and ad.engine.calls[-1][1]["lens"] == lens
+    finally:
+        PM.QwenEngine, MV.WanVAEDecoder = real_engine, real_dec
