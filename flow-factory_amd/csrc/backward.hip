@@ -213,19 +213,28 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* pre, bf16_t
 
 // ------------------------------------------------------------------ tile transposes (64 x 64 bf16 through LDS, +2 B row pad)
 // in: rows x cols (row stride ld_in), batch stride bs_in;  out[c][r] (row stride ld_out), rows >= `rows` up to rows_pad are written as 0
+// colpart != nullptr: the column sums of this 64-row tile are written to colpart[blockIdx.x][cols] as well (the bias gradient of a
+// linear layer = column sums of dY, taken while dY streams through for its transpose; summed over the row tiles by colsum_finish)
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* in, long ld_in, long bs_in, bf16_t* out, long ld_out, long bs_out,
-                                                        int rows, int cols, int rows_pad) {
+                                                        int rows, int cols, int rows_pad, float* colpart) {
     __shared__ bf16_t tile[64][66];
+    __shared__ float csum[4][64];
     const int tr = blockIdx.x * 64, tc = blockIdx.y * 64;
     const bf16_t* ib = in + (long)blockIdx.z * bs_in;
     bf16_t* ob = out + (long)blockIdx.z * bs_out;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 4 rows per pass
+    float cs = 0.f;
 #pragma unroll 4
     for (int r = ty; r < 64; r += 4) {
         const int gr = tr + r, gc = tc + tx;
-        tile[r][tx] = (gr < rows && gc < cols) ? ib[(long)gr * ld_in + gc] : (bf16_t)0;
+        const bf16_t v = (gr < rows && gc < cols) ? ib[(long)gr * ld_in + gc] : (bf16_t)0;
+        tile[r][tx] = v;
+        cs += bf2f(v);
     }
+    if (colpart) csum[ty][tx] = cs;
     __syncthreads();
+    if (colpart && ty == 0 && tc + tx < cols)
+        colpart[(long)blockIdx.x * cols + tc + tx] = (csum[0][tx] + csum[1][tx]) + (csum[2][tx] + csum[3][tx]);
 #pragma unroll 4
     for (int c = ty; c < 64; c += 4) {
         const int gc = tc + c, gr = tr + tx;
@@ -513,7 +522,18 @@ hipError_t launch_transpose(const bf16_t* in, long ld_in, long bs_in, bf16_t* ou
                             int batch, hipStream_t st) {
     if (rows <= 0 || cols <= 0 || batch <= 0 || rows_pad < rows) return hipErrorInvalidValue;
     hipLaunchKernelGGL(transpose_kernel, dim3((rows_pad + 63) / 64, (cols + 63) / 64, batch), dim3(256), 0, st, in, ld_in, bs_in, out, ld_out,
-                       bs_out, rows, cols, rows_pad);
+                       bs_out, rows, cols, rows_pad, (float*)nullptr);
+    return hipGetLastError();
+}
+
+// transpose + column sums in one pass over `in`: out = in^T, colsum[cols] = sum over rows (scratch: ((rows_pad + 63) / 64) * cols floats)
+hipError_t launch_transpose_colsum(const bf16_t* in, long ld_in, bf16_t* out, long ld_out, int rows, int cols, int rows_pad, float* scratch,
+                                   float* colsum, hipStream_t st) {
+    if (rows <= 0 || cols <= 0 || rows_pad < rows || !scratch || !colsum) return hipErrorInvalidValue;
+    const int ntile = (rows_pad + 63) / 64;
+    hipLaunchKernelGGL(transpose_kernel, dim3(ntile, (cols + 63) / 64, 1), dim3(256), 0, st, in, ld_in, 0L, out, ld_out, 0L, rows, cols, rows_pad,
+                       scratch);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, scratch, ntile, cols, colsum, 0);
     return hipGetLastError();
 }
 

@@ -218,6 +218,8 @@ hipError_t launch_gelu_fwd(const bf16_t* pre, bf16_t* out, long n, hipStream_t s
 // out[z][c][r] = in[z][r][c] for r < rows (0 for rows <= r < rows_pad), 64 x 64 tiles through LDS
 hipError_t launch_transpose(const bf16_t* in, long ld_in, long bs_in, bf16_t* out, long ld_out, long bs_out, int rows, int cols, int rows_pad,
                             int batch, hipStream_t stream);
+hipError_t launch_transpose_colsum(const bf16_t* in, long ld_in, bf16_t* out, long ld_out, int rows, int cols, int rows_pad, float* scratch,
+                                   float* colsum, hipStream_t stream);
 struct AttnBwdPrepParams {
     const bf16_t* o_img; const bf16_t* o_ctx; const bf16_t* do_img; const bf16_t* do_ctx;   // token-major [.][H*64]; do_ctx may be null (zeros)
     bf16_t* doh; bf16_t* doT; float* delta;                                               // [B][H][S_pad][64], [B][H][64][S_pad], [B][H][S_pad]

@@ -49,14 +49,16 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=4)
     ap.add_argument("--layers", type=int, default=60)
     ap.add_argument("--iters", type=int, default=1)
+    ap.add_argument("--dynamics", default="Flow-SDE", help="Flow-SDE | Dance-SDE | CPS | ODE (DGPO samples with ODE)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     cfg = qwen.QwenConfig(num_layers=a.layers)
     t0 = time.perf_counter()
     ad = qwen.QwenImageNativeAdapter.__new__(qwen.QwenImageNativeAdapter)
     ad.device, ad.transformer_dtype, ad._latent_storage, ad._live_weights = dev, torch.bfloat16, "bf16", None
+    ad.vae_decoder, ad.vae_max_batch = None, 4
     ad.scheduler = qwen.FlowMatchEulerDiscreteSDEScheduler(shift=1.0, use_dynamic_shifting=True, base_shift=0.5, max_shift=0.9, max_image_seq_len=8192,
-                                                           shift_terminal=0.02, sde_steps=[1, 2, 3], num_sde_steps=1)
+                                                           shift_terminal=0.02, sde_steps=[1, 2, 3], num_sde_steps=1, dynamics_type=a.dynamics)
     ad.engine = qwen.QwenEngine(cfg)
     synthetic_weights(ad.engine, dev)
     torch.cuda.synchronize()
@@ -71,7 +73,7 @@ def main():
     ne = torch.randn(B, n_neg, J, device=dev, generator=g).bfloat16() if a.guidance > 1 else None
     nm = torch.ones(B, n_neg, dtype=torch.long, device=dev) if a.guidance > 1 else None
     run = lambda: ad.inference(prompt=None, height=a.size, width=a.size, num_inference_steps=N, guidance_scale=a.guidance, prompt_embeds=pe,
-                               prompt_embeds_mask=pm, negative_prompt_embeds=ne, negative_prompt_embeds_mask=nm, compute_log_prob=True)
+                               prompt_embeds_mask=pm, negative_prompt_embeds=ne, negative_prompt_embeds_mask=nm, compute_log_prob=a.dynamics != "ODE")
     s = run(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.iters): s = run()
@@ -84,9 +86,9 @@ def main():
         S = Ni + nt
         return 2.0 * (cfg.num_layers * (S * 12 * D * D + 2 * S * S * D) + Ni * 64 * D * 2 + nt * J * D)
     F = flops(a.n_text) + (flops(n_neg) if n_cfg == 2 else 0)          # algorithmic: each branch at its own text length
-    ok = bool(torch.isfinite(s[0].all_latents.float()).all() and torch.isfinite(s[0].log_probs).all())
+    ok = bool(torch.isfinite(s[0].all_latents.float()).all() and (s[0].log_probs is None or torch.isfinite(s[0].log_probs).all()))
     n_text_plan = (max(a.n_text, n_neg) + 31) // 32 * 32
-    print(json.dumps({"model": f"Qwen-Image geometry, {cfg.num_layers} layers", "batch": B, "n_cfg": n_cfg, "image": f"{a.size}x{a.size}", "tokens": Ni + a.n_text,
+    print(json.dumps({"model": f"Qwen-Image geometry, {cfg.num_layers} layers", "batch": B, "n_cfg": n_cfg, "dynamics": a.dynamics, "image": f"{a.size}x{a.size}", "tokens": Ni + a.n_text,
                       "denoise_steps": N, "bind_s": round(t_bind, 1), "s_per_rollout": round(el, 3), "denoise_steps_per_s": round(B * N / el, 3),
                       "forward_tflops": round(F * B * N / el / 1e12, 1), "frac_of_2.5PF": round(F * B * N / el / 2.5e15, 4),
                       "flops_per_step_per_sample": F, "finite": ok, "hbm_allocated_gib": round(torch.cuda.mem_get_info()[1] / 2**30 - torch.cuda.mem_get_info()[0] / 2**30, 1),

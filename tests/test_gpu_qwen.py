@@ -66,7 +66,8 @@ def test_rms_rows_and_cfg_rescale_match_torch(qw):
         assert _rel(got.float().norm(dim=-1), pos.float().norm(dim=-1)) < 1e-2
 
 
-@pytest.mark.parametrize("h,w,Nt,B,n_cfg,ragged", [(8, 8, 16, 2, 1, False), (8, 12, 19, 2, 2, True), (16, 8, 40, 1, 2, True), (4, 4, 5, 3, 1, True)])
+@pytest.mark.parametrize("h,w,Nt,B,n_cfg,ragged", [(8, 8, 16, 2, 1, False), (8, 12, 19, 2, 2, True), (16, 8, 40, 1, 2, True), (4, 4, 5, 3, 1, True),
+                                                    (10, 6, 9, 1, 2, True)])     # odd packed grid (5 x 3): the centred RoPE rows / columns of 1328^2 (83 x 83)
 def test_qwen_forward_matches_oracle(qw, h, w, Nt, B, n_cfg, ragged):
     """Tiny width (2 layers, 2 heads), ragged prompts, with and without the negative branch: raw network outputs of both CFG branches
     and the norm-rescaled combination vs the oracle; a padded sample equals the same sample run alone with its text truncated."""
