@@ -358,7 +358,11 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
         else
             hipLaunchKernelGGL((attn_kernel<true, 8>), dim3(((p.S + 255) / 256) * p.H * p.B), dim3(512), 2 * STAGE_BYTES, stream, p);
     } else {
-        hipLaunchKernelGGL((attn_kernel<true, 4>), dim3(((p.S + 127) / 128) * p.H * p.B), dim3(256), 2 * STAGE_BYTES, stream, p);
+        // 4-wave workgroups (128 queries): twice the workgroups at half the size -- the better grid for small batches
+        if (p.score_bound > 0.f && p.score_bound <= 60.f)
+            hipLaunchKernelGGL((attn_kernel<true, 4, true>), dim3(((p.S + 127) / 128) * p.H * p.B), dim3(256), 2 * STAGE_BYTES, stream, p);
+        else
+            hipLaunchKernelGGL((attn_kernel<true, 4>), dim3(((p.S + 127) / 128) * p.H * p.B), dim3(256), 2 * STAGE_BYTES, stream, p);
     }
     return hipGetLastError();
 }
