@@ -21,7 +21,7 @@ from .engine import Engine, TransformerConfig
 from .samples import SD3_5Sample
 from .scheduler import (FlowMatchEulerDiscreteSDEScheduler, SDESchedulerOutput, host_noise_levels, randn_tensor,
                         set_scheduler_timesteps)
-from .trajectory import (TrajectoryIndicesType, create_callback_collector, create_trajectory_collector, _resolve)
+from .trajectory import TrajectoryIndicesType, _resolve, collect_rollout
 
 logger = logging.getLogger(__name__)
 
@@ -167,37 +167,13 @@ class NativeRolloutMixin:
             final = all_lat[N]
 
         # collectors: exactly the reference's bookkeeping (sd3_5.py:265-304) over the engine outputs
-        latent_collector = create_trajectory_collector(trajectory_indices, N)
-        log_prob_collector = create_trajectory_collector(trajectory_indices, N) if compute_log_prob else None
-        callback_collector = create_callback_collector(trajectory_indices, N)
-        if latent_collector.should_collect(0):
-            latent_collector.collect(get_lat(0), 0)
-        for i in range(N):
-            if latent_collector.should_collect(i + 1):
-                latent_collector.collect(get_lat(i + 1), i + 1)
-            if compute_log_prob and eta_host[i] > 0:
-                log_prob_collector.collect(log_probs[i], i)
-            out_i = step_outputs[i] if step_outputs is not None else None
-            callback_collector.collect_step(step_idx=i, output=out_i, keys=extra_call_back_kwargs,
-                                            capturable={"noise_level": eta_host[i]})
-
+        traj = collect_rollout(trajectory_indices, N, get_lat, log_probs, eta_host, compute_log_prob, step_outputs, extra_call_back_kwargs)
         images = self.decode_latents(latents=final, output_type="pt")
-        cb_res = callback_collector.get_result()
-        cb_map = callback_collector.get_index_map()
-        all_latents = latent_collector.get_result()
-        latent_index_map = latent_collector.get_index_map()
-        all_log_probs = log_prob_collector.get_result() if compute_log_prob else None
-        log_prob_index_map = log_prob_collector.get_index_map() if compute_log_prob else None
-        lat_stack = torch.stack(all_latents, dim=1) if all_latents else None           # (B, P, C, h, w)
-        lp_stack = torch.stack(all_log_probs, dim=1) if all_log_probs else None        # (B, P')
         samples = []
         for b in range(B):
             samples.append(self._sample_cls(
                 timesteps=timesteps,
-                all_latents=lat_stack[b] if lat_stack is not None else None,
-                log_probs=lp_stack[b] if lp_stack is not None else None,
-                latent_index_map=latent_index_map,
-                log_prob_index_map=log_prob_index_map,
+                **traj.per_sample(b),
                 prompt=prompt[b] if isinstance(prompt, list) else prompt,
                 prompt_ids=prompt_ids[b] if prompt_ids is not None else None,
                 prompt_embeds=prompt_embeds[b],
@@ -208,7 +184,6 @@ class NativeRolloutMixin:
                 negative_pooled_prompt_embeds=negative_pooled_prompt_embeds[b] if negative_pooled_prompt_embeds is not None else None,
                 height=height, width=width,
                 image=images[b] if images is not None else None,
-                extra_kwargs={**{k: v[b] for k, v in cb_res.items()}, "callback_index_map": cb_map},
             ))
         return samples
 

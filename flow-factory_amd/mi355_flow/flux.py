@@ -20,7 +20,7 @@ from .engine import WeightHolder, _bf16c, _ptr, _stream, dtype_code, sde_step
 from .samples import Flux1Sample
 from .scheduler import (FlowMatchEulerDiscreteSDEScheduler, SDESchedulerOutput, host_noise_levels, randn_tensor,
                         set_scheduler_timesteps)
-from .trajectory import TrajectoryIndicesType, _resolve, create_callback_collector, create_trajectory_collector
+from .trajectory import TrajectoryIndicesType, _resolve, collect_rollout
 
 _DTYPE_MAP = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16,
               "fp32": torch.float32, "float32": torch.float32}
@@ -288,35 +288,13 @@ class FluxRolloutMixin:
             final = lat_kept[N]
             pos_to_slot = {p: p for p in range(N + 1)}
 
-        latent_collector = create_trajectory_collector(trajectory_indices, N)
-        log_prob_collector = create_trajectory_collector(trajectory_indices, N) if compute_log_prob else None
-        callback_collector = create_callback_collector(trajectory_indices, N)
-        if latent_collector.should_collect(0):
-            latent_collector.collect(lat_kept[pos_to_slot[0]], 0)
-        for i in range(N):
-            if latent_collector.should_collect(i + 1):
-                latent_collector.collect(lat_kept[pos_to_slot[i + 1]], i + 1)
-            if compute_log_prob and eta_host[i] > 0:
-                log_prob_collector.collect(log_probs[i], i)
-            callback_collector.collect_step(step_idx=i, output=step_outputs[i] if step_outputs is not None else None,
-                                            keys=extra_call_back_kwargs, capturable={"noise_level": eta_host[i]})
-
+        traj = collect_rollout(trajectory_indices, N, lambda pos: lat_kept[pos_to_slot[pos]], log_probs, eta_host, compute_log_prob,
+                               step_outputs, extra_call_back_kwargs)
         images = self.decode_latents(final, height, width, output_type="pt")
-        cb_res = callback_collector.get_result()
-        cb_map = callback_collector.get_index_map()
-        all_latents = latent_collector.get_result()
-        latent_index_map = latent_collector.get_index_map()
-        all_log_probs = log_prob_collector.get_result() if compute_log_prob else None
-        log_prob_index_map = log_prob_collector.get_index_map() if compute_log_prob else None
-        lat_stack = torch.stack(all_latents, dim=1) if all_latents else None
-        lp_stack = torch.stack(all_log_probs, dim=1) if all_log_probs else None
         return [
             self._sample_cls(
                 timesteps=timesteps,
-                all_latents=lat_stack[b] if lat_stack is not None else None,
-                log_probs=lp_stack[b] if lp_stack is not None else None,
-                latent_index_map=latent_index_map,
-                log_prob_index_map=log_prob_index_map,
+                **traj.per_sample(b),
                 prompt=prompt[b] if isinstance(prompt, list) else prompt,
                 prompt_ids=prompt_ids[b] if prompt_ids is not None else None,
                 prompt_embeds=prompt_embeds[b],
@@ -324,7 +302,6 @@ class FluxRolloutMixin:
                 height=height, width=width,
                 image=images[b] if images is not None else None,
                 img_ids=latent_image_ids,
-                extra_kwargs={**{k: v[b] for k, v in cb_res.items()}, "callback_index_map": cb_map},
             )
             for b in range(B)
         ]

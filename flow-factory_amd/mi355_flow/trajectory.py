@@ -179,3 +179,45 @@ def keep_slots(indices: TrajectoryIndicesType, num_steps: int) -> List[int]:
         else:
             out.append(-1)
     return out
+
+
+class CollectedRollout:
+    """What every adapter's `inference()` hands to its sample class after a rollout: the reference's collector bookkeeping
+    (models/stable_diffusion/sd3_5.py:265-304 and its siblings) applied to the engine's outputs."""
+
+    __slots__ = ("latents", "log_probs", "latent_index_map", "log_prob_index_map", "callbacks", "callback_index_map")
+
+    def per_sample(self, b: int) -> Dict[str, Any]:
+        """The trajectory keyword arguments of sample `b` (latents (P, ...), log-probs (P',), the shared index maps, callback tensors)."""
+        return dict(all_latents=self.latents[b] if self.latents is not None else None,
+                    log_probs=self.log_probs[b] if self.log_probs is not None else None,
+                    latent_index_map=self.latent_index_map, log_prob_index_map=self.log_prob_index_map,
+                    extra_kwargs={**{k: v[b] for k, v in self.callbacks.items()}, "callback_index_map": self.callback_index_map})
+
+
+def collect_rollout(trajectory_indices: TrajectoryIndicesType, num_steps: int, latent_at, log_probs, noise_levels, compute_log_prob: bool,
+                    step_outputs=None, extra_keys=()) -> CollectedRollout:
+    """`latent_at(pos)` -> the stored latents (B, ...) at trajectory position pos (only asked for collected positions);
+    `log_probs[i]` (B,) for SDE steps; `step_outputs[i]` the per-step scheduler outputs when callback tensors were requested."""
+    N = num_steps
+    lat_c = create_trajectory_collector(trajectory_indices, N)
+    lp_c = create_trajectory_collector(trajectory_indices, N) if compute_log_prob else None
+    cb_c = create_callback_collector(trajectory_indices, N)
+    if lat_c.should_collect(0):
+        lat_c.collect(latent_at(0), 0)
+    for i in range(N):
+        if lat_c.should_collect(i + 1):
+            lat_c.collect(latent_at(i + 1), i + 1)
+        if compute_log_prob and noise_levels[i] > 0:
+            lp_c.collect(log_probs[i], i)
+        cb_c.collect_step(step_idx=i, output=step_outputs[i] if step_outputs is not None else None, keys=list(extra_keys),
+                          capturable={"noise_level": noise_levels[i]})
+    out = CollectedRollout()
+    lats = lat_c.get_result()
+    lps = lp_c.get_result() if compute_log_prob else None
+    out.latents = torch.stack(lats, dim=1) if lats else None            # (B, P, ...)
+    out.log_probs = torch.stack(lps, dim=1) if lps else None            # (B, P')
+    out.latent_index_map = lat_c.get_index_map()
+    out.log_prob_index_map = lp_c.get_index_map() if compute_log_prob else None
+    out.callbacks, out.callback_index_map = cb_c.get_result(), cb_c.get_index_map()
+    return out

@@ -21,7 +21,7 @@ from ._lib import DYNAMICS, WanCfg
 from .engine import WeightHolder, _bf16c, _ptr, _stream, dtype_code, sde_step
 from .samples import WanT2VSample
 from .scheduler import FlowMatchEulerDiscreteSDEScheduler, SDESchedulerOutput, host_noise_levels, randn_tensor
-from .trajectory import TrajectoryIndicesType, _resolve, create_callback_collector, create_trajectory_collector
+from .trajectory import TrajectoryIndicesType, _resolve, collect_rollout
 
 _DTYPE_MAP = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16,
               "fp32": torch.float32, "float32": torch.float32}
@@ -312,31 +312,13 @@ class WanRolloutMixin:
                                                                        guidance_2=g2)
             final = lat_kept[N]
             pos_to_slot = {p: p for p in range(N + 1)}
-        latent_collector = create_trajectory_collector(trajectory_indices, N)
-        log_prob_collector = create_trajectory_collector(trajectory_indices, N) if compute_log_prob else None
-        callback_collector = create_callback_collector(trajectory_indices, N)
-        if latent_collector.should_collect(0):
-            latent_collector.collect(lat_kept[pos_to_slot[0]], 0)
-        for i in range(N):
-            if latent_collector.should_collect(i + 1):
-                latent_collector.collect(lat_kept[pos_to_slot[i + 1]], i + 1)
-            if compute_log_prob and eta_host[i] > 0:
-                log_prob_collector.collect(log_probs[i], i)
-            callback_collector.collect_step(step_idx=i, output=step_outputs[i] if step_outputs is not None else None,
-                                            keys=extra_call_back_kwargs, capturable={"noise_level": eta_host[i]})
+        traj = collect_rollout(trajectory_indices, N, lambda pos: lat_kept[pos_to_slot[pos]], log_probs, eta_host, compute_log_prob,
+                               step_outputs, extra_call_back_kwargs)
         videos = self.decode_latents(final, output_type="pt")
-        cb_res, cb_map = callback_collector.get_result(), callback_collector.get_index_map()
-        all_latents = latent_collector.get_result()
-        all_log_probs = log_prob_collector.get_result() if compute_log_prob else None
-        lat_stack = torch.stack(all_latents, dim=1) if all_latents else None
-        lp_stack = torch.stack(all_log_probs, dim=1) if all_log_probs else None
         return [
             self._sample_cls(
                 timesteps=timesteps,
-                all_latents=lat_stack[b] if lat_stack is not None else None,
-                log_probs=lp_stack[b] if lp_stack is not None else None,
-                latent_index_map=latent_collector.get_index_map(),
-                log_prob_index_map=log_prob_collector.get_index_map() if compute_log_prob else None,
+                **traj.per_sample(b),
                 video=videos[b] if videos is not None else None,
                 height=height, width=width,
                 prompt=prompt[b] if isinstance(prompt, list) else prompt,
@@ -345,7 +327,6 @@ class WanRolloutMixin:
                 negative_prompt=negative_prompt[b] if isinstance(negative_prompt, list) else negative_prompt,
                 negative_prompt_ids=negative_prompt_ids[b] if negative_prompt_ids is not None else None,
                 negative_prompt_embeds=negative_prompt_embeds[b] if negative_prompt_embeds is not None else None,
-                extra_kwargs={**{k: v[b] for k, v in cb_res.items()}, "callback_index_map": cb_map},
             )
             for b in range(B)
         ]
