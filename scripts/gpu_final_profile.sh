@@ -10,6 +10,9 @@ timeout 600 python bench.py --no-cpu-baseline --kernel-timing all 2>/dev/null > 
 timeout 600 python bench.py --no-cpu-baseline --guidance 4.5 --batch 4 2>/dev/null > $OUT/final_bench_cfg.json
 timeout 900 python bench.py --model flux1 --steps 1 --warmup 1 2>/dev/null > $OUT/final_bench_flux.json
 timeout 600 python scripts/wan_bench.py --batch 2 --denoise-steps 2 2>/dev/null | tail -1 > $OUT/final_bench_wan.json
+timeout 600 python scripts/qwen_bench.py --batch 2 --denoise-steps 2 2>/dev/null | tail -1 > $OUT/final_bench_qwen.json
+timeout 600 python scripts/wan_vae_bench.py 2>/dev/null | tail -2 > $OUT/final_bench_wan_vae.json
+timeout 600 python scripts/train_bench.py --batch 2 --size 1024 --train attn --iters 2 2>/dev/null | tail -1 > $OUT/final_bench_train.json
 export TMPDIR=/tmp
 cd /tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_stats -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-selfcheck > $OUT/prof_stats.log 2>&1
