@@ -135,9 +135,16 @@ def _native_vae(pipeline):
 
 
 def _native_video_vae(pipeline):
-    """The Wan / Qwen-Image VAE (AutoencoderKLWan / AutoencoderKLQwenImage) is frozen too: bind its decoder once."""
+    """The Wan / Qwen-Image VAE (AutoencoderKLWan / AutoencoderKLQwenImage) is frozen too: bind its decoder once.  Returns False for a
+    VAE variant the engine does not implement (the residual / patchified Wan2.2-TI2V VAE): the caller then keeps the pipeline's own
+    `vae.decode` (a torch GPU path of the reference, outside the rollout's timed hot loop) and says so once."""
     from .vae import WanVAEConfig, WanVAEDecoder
-    dec = WanVAEDecoder(WanVAEConfig.from_hf(pipeline.vae.config))
+    try:
+        cfg = WanVAEConfig.from_hf(pipeline.vae.config)
+    except ValueError as e:
+        logger.warning("mi355_flow: %s -- decode_latents stays on the pipeline's VAE", e)
+        return False
+    dec = WanVAEDecoder(cfg)
     dec.bind_state_dict(pipeline.vae.state_dict())
     dec.ready()
     return dec
@@ -269,6 +276,8 @@ if _RefAdapter is not None:
                 # wan2_t2v.py:215-230 with vae.decode on the native decoder (de-normalisation fused into its ingest kernel)
                 if getattr(self, "vae_decoder", None) is None:
                     self.vae_decoder = _native_video_vae(self.pipeline)
+                if self.vae_decoder is False:
+                    return _RefWan.decode_latents(self, latents, output_type=output_type)
                 if output_type == "pt":
                     return self.vae_decoder.decode(latents, postprocess=True, out_dtype=torch.float32)
                 video = self.vae_decoder.decode(latents, postprocess=False, out_dtype=torch.float32).permute(0, 2, 1, 3, 4)
@@ -313,6 +322,8 @@ if _RefAdapter is not None:
                 from .qwen import decode_packed_latents
                 if getattr(self, "vae_decoder", None) is None:
                     self.vae_decoder = _native_video_vae(self.pipeline)
+                if self.vae_decoder is False:
+                    return _RefQwen.decode_latents(self, latents, height, width, output_type=output_type)
                 if output_type == "pt":
                     return decode_packed_latents(self.vae_decoder, latents, height, width)
                 images = decode_packed_latents(self.vae_decoder, latents, height, width, postprocess=False)
