@@ -215,30 +215,82 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* pre, bf16_t
 // in: rows x cols (row stride ld_in), batch stride bs_in;  out[c][r] (row stride ld_out), rows >= `rows` up to rows_pad are written as 0
 // colpart != nullptr: the column sums of this 64-row tile are written to colpart[blockIdx.x][cols] as well (the bias gradient of a
 // linear layer = column sums of dY, taken while dY streams through for its transpose; summed over the row tiles by colsum_finish)
+// VEC: 16-byte global loads and stores (ld_in, ld_out multiples of 8 elements, 16-byte aligned bases, cols % 8 == 0 not required:
+// a chunk past `cols` reads as zero); the scalar form covers everything else.
+template <bool VEC>
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* in, long ld_in, long bs_in, bf16_t* out, long ld_out, long bs_out,
                                                         int rows, int cols, int rows_pad, float* colpart) {
-    __shared__ bf16_t tile[64][66];
+    __shared__ bf16_t tile[64][72];           // 144-byte row pitch: 16-byte aligned rows, column reads spread over the banks
     __shared__ float csum[4][64];
     const int tr = blockIdx.x * 64, tc = blockIdx.y * 64;
     const bf16_t* ib = in + (long)blockIdx.z * bs_in;
     bf16_t* ob = out + (long)blockIdx.z * bs_out;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 4 rows per pass
-    float cs = 0.f;
+    if constexpr (VEC) {
+        const int ch = threadIdx.x & 7, r0 = threadIdx.x >> 3;            // 8 chunks of 8 columns x 32 rows per pass
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int r = r0 + 32 * pass, gr = tr + r, gc = tc + ch * 8;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (gr < rows && gc + 8 <= cols) v = *(const uint4*)(ib + (long)gr * ld_in + gc);
+            else if (gr < rows && gc < cols) {
+                unsigned u[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (gc + e < cols) u[e >> 1] |= (unsigned)ib[(long)gr * ld_in + gc + e] << ((e & 1) * 16);
+                v = make_uint4(u[0], u[1], u[2], u[3]);
+            }
+            *(uint4*)&tile[r][ch * 8] = v;
+        }
+        __syncthreads();
+        if (colpart) {      // 4 threads per column, 16 rows each
+            const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+            float cs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cs += bf2f(tile[q * 16 + r][c]);
+            csum[q][c] = cs;
+        }
+        // out row = input column c, 8 consecutive input rows per 16-byte store
+        const int rc = threadIdx.x & 7, c0 = threadIdx.x >> 3;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int c = c0 + 32 * pass, gc = tc + c, gr = tr + rc * 8;
+            if (gc < cols && gr < rows_pad) {
+                unsigned u[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) u[e] = (unsigned)tile[rc * 8 + 2 * e][c] | ((unsigned)tile[rc * 8 + 2 * e + 1][c] << 16);
+                if (gr + 8 <= rows_pad) *(uint4*)(ob + (long)gc * ld_out + gr) = make_uint4(u[0], u[1], u[2], u[3]);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (gr + e < rows_pad) ob[(long)gc * ld_out + gr + e] = (bf16_t)(u[e >> 1] >> ((e & 1) * 16));
+                }
+            }
+        }
+        if (colpart) {
+            __syncthreads();
+            if (threadIdx.x < 64 && tc + threadIdx.x < cols)
+                colpart[(long)blockIdx.x * cols + tc + threadIdx.x] =
+                    (csum[0][threadIdx.x] + csum[1][threadIdx.x]) + (csum[2][threadIdx.x] + csum[3][threadIdx.x]);
+        }
+    } else {
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 4 rows per pass
+        float cs = 0.f;
 #pragma unroll 4
-    for (int r = ty; r < 64; r += 4) {
-        const int gr = tr + r, gc = tc + tx;
-        const bf16_t v = (gr < rows && gc < cols) ? ib[(long)gr * ld_in + gc] : (bf16_t)0;
-        tile[r][tx] = v;
-        cs += bf2f(v);
-    }
-    if (colpart) csum[ty][tx] = cs;
-    __syncthreads();
-    if (colpart && ty == 0 && tc + tx < cols)
-        colpart[(long)blockIdx.x * cols + tc + tx] = (csum[0][tx] + csum[1][tx]) + (csum[2][tx] + csum[3][tx]);
+        for (int r = ty; r < 64; r += 4) {
+            const int gr = tr + r, gc = tc + tx;
+            const bf16_t v = (gr < rows && gc < cols) ? ib[(long)gr * ld_in + gc] : (bf16_t)0;
+            tile[r][tx] = v;
+            cs += bf2f(v);
+        }
+        if (colpart) csum[ty][tx] = cs;
+        __syncthreads();
+        if (colpart && ty == 0 && tc + tx < cols)
+            colpart[(long)blockIdx.x * cols + tc + tx] = (csum[0][tx] + csum[1][tx]) + (csum[2][tx] + csum[3][tx]);
 #pragma unroll 4
-    for (int c = ty; c < 64; c += 4) {
-        const int gc = tc + c, gr = tr + tx;
-        if (gc < cols && gr < rows_pad) ob[(long)gc * ld_out + gr] = tile[tx][c];
+        for (int c = ty; c < 64; c += 4) {
+            const int gc = tc + c, gr = tr + tx;
+            if (gc < cols && gr < rows_pad) ob[(long)gc * ld_out + gr] = tile[tx][c];
+        }
     }
 }
 
@@ -518,11 +570,18 @@ hipError_t launch_gelu_fwd(const bf16_t* pre, bf16_t* out, long n, hipStream_t s
     return hipGetLastError();
 }
 
+static bool transpose_vec_ok(const bf16_t* in, long ld_in, long bs_in, const bf16_t* out, long ld_out, long bs_out) {
+    return ((ld_in | ld_out | bs_in | bs_out) & 7) == 0 && (((size_t)in | (size_t)out) & 15) == 0;
+}
+
 hipError_t launch_transpose(const bf16_t* in, long ld_in, long bs_in, bf16_t* out, long ld_out, long bs_out, int rows, int cols, int rows_pad,
                             int batch, hipStream_t st) {
     if (rows <= 0 || cols <= 0 || batch <= 0 || rows_pad < rows) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(transpose_kernel, dim3((rows_pad + 63) / 64, (cols + 63) / 64, batch), dim3(256), 0, st, in, ld_in, bs_in, out, ld_out,
-                       bs_out, rows, cols, rows_pad, (float*)nullptr);
+    const dim3 grid((rows_pad + 63) / 64, (cols + 63) / 64, batch);
+    if (transpose_vec_ok(in, ld_in, bs_in, out, ld_out, bs_out))
+        hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, st, in, ld_in, bs_in, out, ld_out, bs_out, rows, cols, rows_pad, (float*)nullptr);
+    else
+        hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, st, in, ld_in, bs_in, out, ld_out, bs_out, rows, cols, rows_pad, (float*)nullptr);
     return hipGetLastError();
 }
 
@@ -531,8 +590,12 @@ hipError_t launch_transpose_colsum(const bf16_t* in, long ld_in, bf16_t* out, lo
                                    float* colsum, hipStream_t st) {
     if (rows <= 0 || cols <= 0 || rows_pad < rows || !scratch || !colsum) return hipErrorInvalidValue;
     const int ntile = (rows_pad + 63) / 64;
-    hipLaunchKernelGGL(transpose_kernel, dim3(ntile, (cols + 63) / 64, 1), dim3(256), 0, st, in, ld_in, 0L, out, ld_out, 0L, rows, cols, rows_pad,
-                       scratch);
+    if (transpose_vec_ok(in, ld_in, 0, out, ld_out, 0))
+        hipLaunchKernelGGL(transpose_kernel<true>, dim3(ntile, (cols + 63) / 64, 1), dim3(256), 0, st, in, ld_in, 0L, out, ld_out, 0L, rows, cols,
+                           rows_pad, scratch);
+    else
+        hipLaunchKernelGGL(transpose_kernel<false>, dim3(ntile, (cols + 63) / 64, 1), dim3(256), 0, st, in, ld_in, 0L, out, ld_out, 0L, rows, cols,
+                           rows_pad, scratch);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, scratch, ntile, cols, colsum, 0);
     return hipGetLastError();
 }
