@@ -45,7 +45,10 @@ int g_attn_variant = 1;
 // overlap the matrix pipe with the VALU.
 // STATIC: the caller guarantees |score| <= p.score_bound <= 60 (log2 domain; Cauchy-Schwarz on the RMS-normalised q, k and their
 // norm weights), so exp2(score) can neither overflow nor flush to zero in fp32 / bf16: no running max, no rescale, no -m operand.
-template <bool V2, int NWAVE, bool STATIC = false>
+// LSE: also write the per-query log-sum-exp (training-mode forward).  A template parameter, not a runtime test of p.lse: the dynamic
+// 8-wave kernel sits at its 128-VGPR / ~102-SGPR budget, and keeping the extra pointer and row index live across the key loop spilled
+// 14 VGPRs to scratch (measured in round 2: 1046 -> 911 TFLOP/s) -- the rollout instantiations must not pay for the training output.
+template <bool V2, int NWAVE, bool STATIC = false, bool LSE = false>
 __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
     constexpr int QB = QW * NWAVE;  // queries per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -310,7 +313,10 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
     l_run += __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_run;
     // training-mode forward: L = log2 sum_j 2^(s_j) per query, so that the backward rebuilds P = 2^(s - L) without a second softmax pass
-    if (p.lse && lg == 0 && q_row < p.S) p.lse[bh * p.S_pad + q_row] = m_fin + __log2f(l_run);
+    if constexpr (LSE) {
+        const int qr = qblk * QB + wave * QW + (lane & 31);
+        if ((lane >> 5) == 0 && qr < p.S) p.lse[((long)b * p.H + h) * p.S_pad + qr] = m_fin + __log2f(l_run);
+    }
     __syncthreads();  // all waves done with the K/V ring
     // wave region: 32 queries x 64 d bf16 = 4 KiB, row = query (128 B), 16-B chunk XOR-swizzled by (q&7)
     char* ob = smem + wave * 4096;
@@ -348,21 +354,24 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
 void set_attn_variant(int v) { g_attn_variant = v; }
 int get_attn_variant() { return g_attn_variant; }
 
+template <bool V2, int NWAVE, bool STATIC>
+static void launch_variant(const AttnParams& p, hipStream_t stream) {
+    const dim3 grid(((p.S + QW * NWAVE - 1) / (QW * NWAVE)) * p.H * p.B), block(NWAVE * 64);
+    if (p.lse) hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, true>), grid, block, 2 * STAGE_BYTES, stream, p);
+    else hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, false>), grid, block, 2 * STAGE_BYTES, stream, p);
+}
+
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.S <= 0 || p.S_pad % KV != 0 || p.S_pad < p.S) return hipErrorInvalidValue;
-    if (g_attn_variant == 0) {
-        hipLaunchKernelGGL((attn_kernel<false, 8>), dim3(((p.S + 255) / 256) * p.H * p.B), dim3(512), 2 * STAGE_BYTES, stream, p);
-    } else if (g_attn_variant == 1) {
-        if (p.score_bound > 0.f && p.score_bound <= 60.f)
-            hipLaunchKernelGGL((attn_kernel<true, 8, true>), dim3(((p.S + 255) / 256) * p.H * p.B), dim3(512), 2 * STAGE_BYTES, stream, p);
-        else
-            hipLaunchKernelGGL((attn_kernel<true, 8>), dim3(((p.S + 255) / 256) * p.H * p.B), dim3(512), 2 * STAGE_BYTES, stream, p);
+    const bool stat = p.score_bound > 0.f && p.score_bound <= 60.f;
+    if (g_attn_variant == 0) launch_variant<false, 8, false>(p, stream);
+    else if (g_attn_variant == 1) {
+        if (stat) launch_variant<true, 8, true>(p, stream);
+        else launch_variant<true, 8, false>(p, stream);
     } else {
-        // 4-wave workgroups (128 queries): twice the workgroups at half the size -- the better grid for small batches
-        if (p.score_bound > 0.f && p.score_bound <= 60.f)
-            hipLaunchKernelGGL((attn_kernel<true, 4, true>), dim3(((p.S + 127) / 128) * p.H * p.B), dim3(256), 2 * STAGE_BYTES, stream, p);
-        else
-            hipLaunchKernelGGL((attn_kernel<true, 4>), dim3(((p.S + 127) / 128) * p.H * p.B), dim3(256), 2 * STAGE_BYTES, stream, p);
+        // 4-wave workgroups (128 queries): twice the workgroups at half the size (A/B: profiles/r02_small_batch_attention_ab.txt)
+        if (stat) launch_variant<true, 4, true>(p, stream);
+        else launch_variant<true, 4, false>(p, stream);
     }
     return hipGetLastError();
 }

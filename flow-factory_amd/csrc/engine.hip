@@ -879,6 +879,7 @@ extern "C" int mi355_op_linear_trace(void* stream, const void* A, const void* W,
     g.trace = (long long*)trace;     // (may be null: then this is the plain launch with the ablation knobs below)
     g.dbg_skip_prefetch = getenv("MI355_DBG_SKIP_PREFETCH") ? 1 : 0;                       // ablations (results are garbage)
     if (getenv("MI355_DBG_MASK")) g.dbg_skip_prefetch = atoi(getenv("MI355_DBG_MASK"));   // bit 0: no K-loop prefetch, bit 1: no LDS fragment reads
+    if (trace && g.dbg_skip_prefetch == 0) g.dbg_skip_prefetch = 16;                        // the trace lives in its own build of the kernel
     HIPCHK(launch_gemm(g, (hipStream_t)stream));
     return 0;
 }

@@ -21,6 +21,9 @@ namespace mi355 {
 
 namespace {
 
+constexpr bool is_qk_epi(int e) { return e == EPI_QK_NORM || e == EPI_QK_NORM_RSTD; }
+
+
 constexpr int BK = 64;
 int g_raster_gm = 6;          // tile rows per raster band (0 = plain row-major order); mi355_tune_set(7, v)
 int g_pp_min_tiles = 128;     // smallest 256x256-tile grid for gemm_pp_kernel
@@ -99,7 +102,7 @@ template <int EPI, bool FULL>
 __device__ __forceinline__ void store_row8(const GemmParams& p, int m, int n, int n_wave, uint4 val) {
     const bool full = FULL || (n + 8 <= p.N);
     float y[8] = {bf_lo(val.x), bf_hi(val.x), bf_lo(val.y), bf_hi(val.y), bf_lo(val.z), bf_hi(val.z), bf_lo(val.w), bf_hi(val.w)};
-    if constexpr (EPI == EPI_QK_NORM) {
+    if constexpr (is_qk_epi(EPI)) {
         const int D = p.H * 64;
         const bool is_k = n_wave >= D;
         const int h = ((is_k ? n_wave - D : n_wave) >> 6);
@@ -222,7 +225,7 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
         if constexpr (EPI != EPI_VT && EPI != EPI_BIAS_ROW) {
             if (FULL || n < p.N) bcol[j] = *(const float4*)(p.bias + n);
         }
-        if constexpr (EPI == EPI_QK_NORM) {
+        if constexpr (is_qk_epi(EPI)) {
             const bool is_k = n_base >= p.H * 64;
             nw[j] = *(const float4*)((is_k ? p.nw_k : p.nw_q) + j * 16 + 4 * fkg);
             if (!is_k && p.q_scale != 0.f) { nw[j].x *= p.q_scale; nw[j].y *= p.q_scale; nw[j].z *= p.q_scale; nw[j].w *= p.q_scale; }
@@ -245,16 +248,17 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
             y[j][2] = acc[i][j][2] + (ROWB ? brow : bcol[j].z);
             y[j][3] = acc[i][j][3] + (ROWB ? brow : bcol[j].w);
         }
-        if constexpr (EPI == EPI_QK_NORM) {
+        if constexpr (is_qk_epi(EPI)) {
             float ss = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) ss += y[j][0] * y[j][0] + y[j][1] * y[j][1] + y[j][2] * y[j][2] + y[j][3] * y[j][3];
             ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
             const float rstd = rsqrtf(ss * (1.0f / 64.0f) + p.eps);
-            if (p.rstd_out && fkg == 0) {      // training-mode forward: 1/rms of this (row, head) for the RMSNorm backward
+            if constexpr (EPI == EPI_QK_NORM_RSTD) {      // training-mode forward: 1/rms of this (row, head) for the RMSNorm backward
+                // (its own epilogue kind: as a runtime branch it cost the rollout kernel 13 spilled VGPRs)
                 const int m = m_base + r;
-                if (FULL || m < p.M) p.rstd_out[(long)m * (2 * p.H) + (n_base >> 6)] = rstd;
+                if (fkg == 0 && (FULL || m < p.M)) p.rstd_out[(long)m * (2 * p.H) + (n_base >> 6)] = rstd;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
 //   rows of quadrant-row 1;  phase P0: (0,0) reads A0,B0 | P1: (0,1) reads B1 | P2: (1,1) reads A1 |
 //   P3: (1,0) reads nothing;  prefetch order for tile t+1: U0, U2, U3, U1.
 // DBG (ablation builds only, EPI_BIAS, results are garbage): bit 0 no K-loop prefetch, bit 1 no LDS fragment reads after the first K-tile,
-// bit 2 no epilogue at all (accumulators just reset), bit 3 epilogue without its global stores
+// bit 2 no epilogue at all (accumulators just reset), bit 3 epilogue without its global stores; bit 4 (alone): the trace build (valid results)
 template <int EPI, int DBG = 0>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
     constexpr int BM = 256, BN = 256, TM = 128, TN = 64;
@@ -620,9 +624,12 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
     int cur_m0 = m0, cur_n0 = n0;
     int tile_i = 0, t = 0, par = 0;
     long long* trc = nullptr;
-    if (p.trace && (wave == 0 || wave == 4) && lane == 0) trc = p.trace + ((long)blockIdx.x * 16 * 2 + grp) * 4;
-    long long* trc_wall = trc ? trc + 15 * 8 : nullptr;   // slot 15: s_memrealtime (100 MHz, one time base for the whole device) at WG start / end
-    if (trc) { trc[0] = __builtin_amdgcn_s_memtime(); trc[1] = trc[0]; trc_wall[0] = __builtin_amdgcn_s_memrealtime(); }
+    if constexpr ((DBG & 16) != 0) {      // trace build only (scripts/gemm_trace.py): production kernels carry no trace state
+        if (p.trace && (wave == 0 || wave == 4) && lane == 0) trc = p.trace + ((long)blockIdx.x * 16 * 2 + grp) * 4;
+    }
+    // slot 15 of the trace: s_memrealtime (100 MHz, one time base for the whole device) at WG start / end; addressed from p.trace at the
+    // two use sites (a second per-lane pointer held across the main loop costs VGPRs the epilogues do not have)
+    if (trc) { trc[0] = __builtin_amdgcn_s_memtime(); trc[1] = trc[0]; trc[15 * 8] = __builtin_amdgcn_s_memrealtime(); }
 #define PP_EPILOGUE(SB)                                                                                        \
     do {                                                                                                          \
         /* no wave has an LDS read of this stage pending here (P3 reads nothing; every wave's P2 reads were  */  \
@@ -632,7 +639,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                         \
         if (trc) trc[2] = __builtin_amdgcn_s_memtime();                                                          \
         char* stg = smem + 2 * STAGE + stg_off; (void)(SB);                                                       \
-        const bool full_tile = (em0 + BM <= p.M) && (en0 + BN <= p.N) && ((p.ldo & 7) == 0 || EPI == EPI_QK_NORM || EPI == EPI_VT) && \
+        const bool full_tile = (em0 + BM <= p.M) && (en0 + BN <= p.N) && ((p.ldo & 7) == 0 || is_qk_epi(EPI) || EPI == EPI_VT) && \
                                (EPI != EPI_VT || ((p.rows_per_sample | p.s_off) & 7) == 0);                       \
         _Pragma("unroll") for (int qq = 0; qq < 4; ++qq) {                                                        \
             f32x4 a2[2][4];                                                                                       \
@@ -713,7 +720,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(GemmParams p) {
         PP_BARRIER(); PP_MFMA(1, 0);
         if (grp == 0) PP_BARRIER();  // pairs with group 1's barrier in front of its last MFMA cluster
         PP_EPILOGUE(sb);
-        if (trc_wall) trc_wall[3] = __builtin_amdgcn_s_memrealtime();
+        if constexpr ((DBG & 16) != 0) {
+            if (p.trace && (wave == 0 || wave == 4) && lane == 0)
+                p.trace[((long)blockIdx.x * 16 * 2 + grp) * 4 + 15 * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+        }
     }
 #undef PP_EPILOGUE
 #undef PP_BARRIER
@@ -786,6 +796,7 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
                     case 4: return launch_pp<EPI, 4>(p, stream);
                     case 7: return launch_pp<EPI, 7>(p, stream);
                     case 8: return launch_pp<EPI, 8>(p, stream);
+                    case 16: return launch_pp<EPI, 16>(p, stream);      // s_memtime / s_memrealtime trace build
                     default: return hipErrorInvalidValue;
                 }
             }
@@ -846,7 +857,7 @@ hipError_t launch_gemm(const GemmParams& p_in, hipStream_t stream) {
         case EPI_POSADD: return launch_epi<EPI_POSADD>(p, stream);
         case EPI_ADDSRC_SILU: return launch_epi<EPI_ADDSRC_SILU>(p, stream);
         case EPI_GATE_RES: return launch_epi<EPI_GATE_RES>(p, stream);
-        case EPI_QK_NORM: return launch_epi<EPI_QK_NORM>(p, stream);
+        case EPI_QK_NORM: return p.rstd_out ? launch_epi<EPI_QK_NORM_RSTD>(p, stream) : launch_epi<EPI_QK_NORM>(p, stream);
         case EPI_VT: return launch_epi<EPI_VT>(p, stream);
         case EPI_UNPATCH: return launch_epi<EPI_UNPATCH>(p, stream);
         case EPI_DGELU: return launch_epi<EPI_DGELU>(p, stream);

@@ -26,6 +26,7 @@ enum GemmEpi : int {
     EPI_IMG,            // conv_out: image[b][n][y][x] = post(acc + bias[n]), n < N <= 4, fp32 or bf16 NCHW
     // ---- backward (engine_train.inc)
     EPI_DGELU,          // out[m][n] = bf16((acc + bias[n]) * gelu_tanh'(aux[m][n]))   (aux = stashed pre-activation, row stride ld_aux)
+    EPI_QK_NORM_RSTD,   // EPI_QK_NORM that also stores the per-(row, head) 1/rms to rstd_out (training-mode forward; selected by launch_gemm)
     EPI_COUNT
 };
 

@@ -22,7 +22,7 @@ for (M, N, K) in [(32768, 1536, 1536), (32768, 6144, 1536), (32768, 1536, 6144)]
     e1.record(); torch.cuda.synchronize()
     ev_us = e0.elapsed_time(e1) * 1e3
     t = tr.cpu().numpy().reshape(256, 16, 2, 4).astype(np.float64)
-    ntile = int((t[0, :, 0, 3] > 0).sum())
+    ntile = int((t[0, :15, 0, 3] > 0).sum())          # slot 15 holds the device-wide stamps, not a tile
     starts = t[:, 0, 0, 0]; ends = t[:, ntile - 1, :, 3].max(axis=1)
     live = starts > 0
     t0 = starts[live].min()

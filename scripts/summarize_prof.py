@@ -21,7 +21,7 @@ def short(name):
             # gemm_kernelILi256ELi256ELi2ELi4ELi5EE -> gemm<256,256,epi5>
             import re
             epi = ["bias", "bias_silu", "bias_gelu", "posadd", "addsrc_silu", "gate_res", "qk_norm", "vT", "unpatch", "bias_row",
-                   "f32", "img", "dgelu"]
+                   "f32", "img", "dgelu", "qk_norm_rstd"]
             mp = re.search(r"gemm_pp_kernel<(\d+)(?:, \d+)?>", name)
             if mp:
                 return f"gemm_pp<256x256,{epi[int(mp.group(1))]}>"
