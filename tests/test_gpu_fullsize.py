@@ -47,7 +47,7 @@ def full():
 
 def test_config_a_rollout_and_replay_vs_oracle(full):
     """BASELINE.json configs[0]: 256^2, N = 4, B = 1, Flow-SDE eta 0.7, one SDE step of [1,2,3] (seed 42), fp16 storage."""
-    from oracle import rollout_ref as R, scheduler_ref as S
+    from oracle import mmditx_ref as M, rollout_ref as R, scheduler_ref as S
     e, sd, cfg = full
     B, h, w, N = 1, 32, 32, 4
     g = torch.Generator().manual_seed(4321)
@@ -72,6 +72,14 @@ def test_config_a_rollout_and_replay_vs_oracle(full):
     assert len(steps) == 1
     i = steps[0]
     np.testing.assert_allclose(lp[i].cpu().numpy(), ref["log_probs"][i].numpy(), rtol=1e-3)   # rollout log-prob, north star
+    # how much of that distance is bf16 itself: the same oracle with bf16 round-trips where the reference's bf16 network rounds
+    # (what a diffusers bf16 run computes, up to accumulation order) against its own fp32 self -- the engine should sit in that band
+    refq = R.rollout(sd, cfg, pe, pp, None, None, 1.0, init, noise, ts, sig, nl, torch.float16, quant=M.bf16_round)
+    band = max(_rel(refq["all_latents"][j], ref["all_latents"][j]) for j in range(1, N + 1))
+    worst_q = max(_rel(lat[j], refq["all_latents"][j]) for j in range(1, N + 1))
+    print(f"config A: bf16-emulating oracle vs fp32 oracle, worst per-step latent rel-L2 {band:.3e}; engine vs bf16-emulating oracle {worst_q:.3e}; "
+          f"engine vs fp32 oracle {worst:.3e}")
+    assert worst < 3.0 * band + 2e-3, (worst, band)          # the engine is no further from fp32 than a bf16 network is (x3 slack)
 
     # ---- replay (what optimize() computes, trainers/grpo.py:229-263) on the ENGINE's stored transition, evaluated by the ORACLE
     x_i, x_n = lat[i].cpu(), lat[i + 1].cpu()
