@@ -315,7 +315,7 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
     // training-mode forward: L = log2 sum_j 2^(s_j) per query, so that the backward rebuilds P = 2^(s - L) without a second softmax pass
     if constexpr (LSE) {
         const int qr = qblk * QB + wave * QW + (lane & 31);
-        if ((lane >> 5) == 0 && qr < p.S) p.lse[((long)b * p.H + h) * p.S_pad + qr] = m_fin + __log2f(l_run);
+        if (p.lse && (lane >> 5) == 0 && qr < p.S) p.lse[((long)b * p.H + h) * p.S_pad + qr] = m_fin + __log2f(l_run);
     }
     __syncthreads();  // all waves done with the K/V ring
     // wave region: 32 queries x 64 d bf16 = 4 KiB, row = query (128 B), 16-B chunk XOR-swizzled by (q&7)
@@ -357,7 +357,11 @@ int get_attn_variant() { return g_attn_variant; }
 template <bool V2, int NWAVE, bool STATIC>
 static void launch_variant(const AttnParams& p, hipStream_t stream) {
     const dim3 grid(((p.S + QW * NWAVE - 1) / (QW * NWAVE)) * p.H * p.B), block(NWAVE * 64);
-    if (p.lse) hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, true>), grid, block, 2 * STAGE_BYTES, stream, p);
+    // Two instantiations of one source may round differently (hipcc contracts / packs fp ops per instantiation: seen on the fused
+    // RMSNorm epilogue, gemm.hip), and rollout vs training-mode forward must agree bit for bit.  The deferred-rescale kernels are checked
+    // for that on the GPU (tests/test_gpu_backward.py::test_train_forward_is_bit_identical_at_full_width); the plain kernel (A/B variant 0,
+    // not performance-critical) simply always runs its LSE build.
+    if (p.lse || !V2) hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, true>), grid, block, 2 * STAGE_BYTES, stream, p);
     else hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, false>), grid, block, 2 * STAGE_BYTES, stream, p);
 }
 

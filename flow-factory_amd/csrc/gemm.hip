@@ -249,12 +249,21 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
             y[j][3] = acc[i][j][3] + (ROWB ? brow : bcol[j].w);
         }
         if constexpr (is_qk_epi(EPI)) {
-            float ss = 0.f;
+            // The rollout and the training-mode forward run DIFFERENT instantiations of this epilogue (EPI_QK_NORM / EPI_QK_NORM_RSTD) and
+            // must agree bit for bit (ratio == 1): every multiply-add below is an explicit fma and contraction is off, so that hipcc's
+            // SLP packing cannot fuse in one instantiation what it leaves unfused in the other (measured: v_pk_fma vs v_pk_mul + v_pk_add).
+            float rstd;
+            {
+#pragma clang fp contract(off)
+                float sj[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ss += y[j][0] * y[j][0] + y[j][1] * y[j][1] + y[j][2] * y[j][2] + y[j][3] * y[j][3];
-            ss += __shfl_xor(ss, 16, 64);
-            ss += __shfl_xor(ss, 32, 64);
-            const float rstd = rsqrtf(ss * (1.0f / 64.0f) + p.eps);
+                for (int j = 0; j < 4; ++j)
+                    sj[j] = __builtin_fmaf(y[j][3], y[j][3], __builtin_fmaf(y[j][2], y[j][2], __builtin_fmaf(y[j][1], y[j][1], y[j][0] * y[j][0])));
+                float ss = (sj[0] + sj[1]) + (sj[2] + sj[3]);
+                ss += __shfl_xor(ss, 16, 64);
+                ss += __shfl_xor(ss, 32, 64);
+                rstd = rsqrtf(__builtin_fmaf(ss, 1.0f / 64.0f, p.eps));
+            }
             if constexpr (EPI == EPI_QK_NORM_RSTD) {      // training-mode forward: 1/rms of this (row, head) for the RMSNorm backward
                 // (its own epilogue kind: as a runtime branch it cost the rollout kernel 13 spilled VGPRs)
                 const int m = m_base + r;

@@ -306,3 +306,41 @@ def test_full_scope_gradients_of_every_parameter(gpu):
     print("full scope:", n, "parameter gradients; worst rel-L2 per kind:", {k: f"{v[0]:.3e} ({v[1]})" for k, v in worst.items()})
     assert n >= 80 + 3 * 4 + 16 + 8 + 6 - 4
     ad.engine.close()
+
+
+@pytest.mark.parametrize("tune", [(), ((6, 0),), ((1, 0),), ((1, 2),)], ids=["static", "dynamic", "plain", "4wave"])
+def test_train_forward_is_bit_identical_at_full_width(tune):
+    """The rollout / no-grad replay and the training-mode forward run different template instantiations of the fused q/k RMSNorm epilogue
+    (EPI_QK_NORM vs EPI_QK_NORM_RSTD) and of the attention kernel (LSE output): hipcc may contract or pack floating-point operations
+    differently per instantiation (round 2: v_pk_fma in one, v_pk_mul + v_pk_add in the other -> 1-ulp bf16 differences, ratio != 1).
+    SD3.5 width (24 heads x 64), 3 blocks incl. two dual-attention ones, every attention kernel variant: outputs must be torch.equal."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mi355_flow import _lib, engine
+    from mi355_flow.weights import synthetic_state_dict
+    lib = _lib.load()
+    cfg = engine.TransformerConfig(num_layers=3, dual_layers=(0, 1))
+    e = engine.Engine(cfg)
+    e.bind_state_dict(synthetic_state_dict(cfg, device="cuda", seed=1, dtype=torch.bfloat16))
+    e.ready()
+    try:
+        for k, v in tune:
+            _lib.check(lib.mi355_tune_set(k, v), "tune_set")
+        g = torch.Generator().manual_seed(3)
+        for B, h, w, n_cfg in ((1, 32, 32, 1), (2, 48, 32, 2)):
+            x = torch.randn(B, 16, h, w, generator=g).half().cuda()
+            x1 = (x.float() + 0.1 * torch.randn(B, 16, h, w, generator=g).cuda()).half()
+            pe, pp = torch.randn(B, 333, 4096, generator=g).bfloat16().cuda(), torch.randn(B, 2048, generator=g).bfloat16().cuda()
+            ne, npl = (torch.randn(B, 333, 4096, generator=g).bfloat16().cuda(), torch.randn(B, 2048, generator=g).bfloat16().cuda()) if n_cfg == 2 else (None, None)
+            plan = e.plan(B, n_cfg, h, w, 333, 1)
+            sc = (torch.full((B,), 0.9), torch.full((B,), 0.75), torch.full((B,), 0.7))
+            a = plan.denoise_step(x, torch.full((B,), 900.0), pe, pp, ne, npl, 4.5, *sc, 0.9, "Flow-SDE", next_latents=x1, want=("noise_pred",))
+            for full in (False, True):
+                e.set_train_scope(full)
+                b = plan.denoise_step_train(x, torch.full((B,), 900.0), pe, pp, ne, npl, 4.5, *sc, 0.9, "Flow-SDE", x1)
+                assert torch.equal(a.noise_pred, b.noise_pred) and torch.equal(a.log_prob, b.log_prob), (tune, B, full)
+    finally:
+        _lib.check(lib.mi355_tune_set(6, 1), "tune_set")
+        _lib.check(lib.mi355_tune_set(1, 1), "tune_set")
+        e.set_train_scope(False)
+        e.close()
