@@ -126,6 +126,22 @@ def test_config_b_forward_1024_vs_oracle(full):
     assert _rel(y2[0:1], ref) < 3e-2 and _rel(y2[1:2], ref) < 3e-2
 
 
+def test_forward_is_bitwise_independent_of_the_batch_a_sample_sits_in(full):
+    """optimize() may replay stored transitions in micro-batches of another size than the rollout used (trainers/grpo.py:229-263).  The
+    GEMMs then run other kernels (the persistent 256x256 ping-pong kernel from 128 tiles up, the 128x128 kernel below) -- same K order, same
+    epilogue arithmetic: a sample's velocity must not depend on its batch, bit for bit, or ratio == 1 would hold only at equal batch sizes."""
+    e, sd, cfg = full
+    g = torch.Generator().manual_seed(5)
+    h = w = 64                                                             # 512^2: 1024 image tokens per sample
+    x = torch.randn(1, 16, h, w, generator=g).half().cuda()
+    pe, pp = torch.randn(1, N_TEXT, 4096, generator=g).bfloat16().cuda(), torch.randn(1, 2048, generator=g).bfloat16().cuda()
+    t = torch.tensor([900.0]).cuda()
+    y1 = e.plan(1, 1, h, w, N_TEXT, 1).transformer_forward(x, t, pe, pp)
+    for B in (2, 8):
+        yb = e.plan(B, 1, h, w, N_TEXT, 1).transformer_forward(x.repeat(B, 1, 1, 1), t.repeat(B), pe.repeat(B, 1, 1), pp.repeat(B, 1))
+        assert torch.equal(yb, y1.expand_as(yb)), B
+
+
 def test_config_a_replay_gradients_vs_oracle_autograd(full):
     """SURVEY.md 8(f) N1 at the real geometry: the differentiable replay step on full SD3.5-medium (256^2, B = 1) -- grad-mode log-prob
     bit-identical to the no-grad replay (ratio == 1), weight gradients of the attention projections of blocks 0 / 12 / 23 (the
