@@ -20,22 +20,8 @@ for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM
   tag=$(echo $C | tr ' ' '_')
   timeout 600 rocprofv3 --pmc $C --output-format csv -d $OUT/prof_pmc_$tag -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --denoise-steps 2 --no-cpu-baseline --no-kernel-timing --no-selfcheck --no-vae > $OUT/prof_pmc_$tag.log 2>&1
 done
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_qwen -o q -- python $GRAFT_REPO_ROOT/scripts/qwen_bench.py --batch 2 --denoise-steps 2 > $OUT/prof_qwen.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_wvae -o v -- python $GRAFT_REPO_ROOT/scripts/wan_vae_bench.py --iters 1 > $OUT/prof_wvae.log 2>&1
 cd $GRAFT_REPO_ROOT
 python scripts/summarize_prof.py $OUT > $OUT/prof_summary.txt 2>&1
-for T in qwen:q wvae:v; do
-  D=${T%%:*}; N=${T##*:}
-  python - "$OUT/prof_$D" "$N" > $OUT/prof_${D}_kernel_stats.txt <<'PY'
-import csv, glob, sys, re
-f = glob.glob(sys.argv[1] + "/**/" + sys.argv[2] + "_kernel_stats.csv", recursive=True)
-rows = list(csv.DictReader(open(f[0]))) if f else []
-tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
-print(f"{'kernel':70s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>9s} {'pct':>6s}")
-for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:22]:
-    name = re.sub(r"^void |mi355::\(anonymous namespace\)::", "", r["Name"])[:70]
-    print(f"{name:70s} {int(r['Calls']):7d} {float(r['TotalDurationNs'])/1e6:10.2f} {float(r['AverageNs'])/1e3:9.1f} {100*float(r['TotalDurationNs'])/tot:6.2f}")
-PY
-done
+
 head -30 $OUT/prof_summary.txt
 find $OUT -type f -size +1M -delete
