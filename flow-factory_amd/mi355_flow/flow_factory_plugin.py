@@ -1,5 +1,5 @@
 """The binding a Flow-Factory installation uses:  `model.model_type: mi355_flow.flow_factory_plugin.SD3_5NativeAdapter`
-(also `...Flux1NativeAdapter`, `...Wan2T2VNativeAdapter`).
+(also `...Flux1NativeAdapter`, `...Wan2T2VNativeAdapter`, `...QwenImageNativeAdapter`).
 
 Flow-Factory resolves an unknown `model_type` as a python path (reference src/flow_factory/models/registry.py:69-82) and
 constructs `cls(config=config, accelerator=accelerator)` (models/loader.py:61-64).  Each class below IS the reference's own
@@ -16,8 +16,11 @@ sample classes all inherited) with the rollout hot path routed to libmi355flow.s
     `use_named_parameters()` (the KL reference forward of trainers/grpo.py:281-292 sees the reference weights, not the
     rollout-time policy), with peft LoRA deltas merged (and dropped while `disable_adapter()` is active), FSDP2 shards gathered;
   * grad-mode `forward()` -- the `optimize()` replay -- runs the engine's differentiable path when the trainable
-    parameter set is supported by it (mi355_flow/autograd.py: identical forward arithmetic => ratio == 1 before any update),
-    else the reference's autograd path.
+    parameter set is supported by it (mi355_flow/autograd.py: identical forward arithmetic => ratio == 1 before any update).
+    Where the backward is not native (FLUX.1, Wan, Qwen-Image; SD3.5 trainable sets outside the engine's scope) autograd runs on
+    the reference's torch path and the VALUES of log_prob / noise_pred / next_latents_mean are the engine's (`_engine_valued`:
+    `engine + (ref - ref.detach())`), so ratio == 1 before any update and a KL term against the no-grad (engine) reference
+    forward compares like with like for every model family.
 
 Importing this module needs an importable `flow_factory`.
 """
@@ -73,6 +76,23 @@ class _LiveBinding:
     def _before_engine_call(self) -> None:     # hook of the rollout mixins (top of inference() / no-grad forward())
         self._sync_weights()
 
+    #: grad-mode forward() of the families without a native backward: value from the engine, gradient from the reference (`_engine_valued`)
+    engine_valued_replay = True
+
+    def _replay_on_reference(self, ref_forward, native_forward, args, kwargs):
+        out = ref_forward(self, *args, **kwargs)
+        if not self.engine_valued_replay or kwargs.get("next_latents") is None:
+            return out
+        try:
+            with torch.no_grad():
+                nat = native_forward(self, *args, **kwargs)
+        except NotImplementedError as e:                 # an option the engine rejects: keep the reference's values, say so once
+            if not getattr(self, "_warned_ref_value", False):
+                logger.warning("mi355_flow: grad-mode forward() keeps the reference path's values (%s)", e)
+                self._warned_ref_value = True
+            return out
+        return _engine_valued(out, nat)
+
     # mode switches (models/abc.py:351-378)
     def rollout(self, *a, **k):
         self._invalidate()
@@ -124,6 +144,28 @@ class _LiveBinding:
     @property
     def transformer_dtype(self):
         return self.pipeline.transformer.dtype
+
+
+_VALUE_FIELDS = ("log_prob", "noise_pred", "next_latents_mean")
+
+
+def _engine_valued(ref_out, native_out):
+    """Grad-mode `forward()` of a model family whose backward is not on the engine: `ref_out` comes from the reference's autograd path,
+    `native_out` from the engine's no-grad step on the same inputs.  Returns `ref_out` with every differentiable field re-valued as
+    `engine + (ref - ref.detach())`: the VALUE is the engine's, bit for bit (the bracket is exactly zero), the GRADIENT is the reference
+    path's.  `optimize()` (trainers/grpo.py:263-276) then sees ratio == exp(lp_engine - old_lp_engine) -- exactly 1 before any update,
+    which a +-1e-4 `clip_range` needs -- and its KL term (`:281-311`) compares like with like: the no-grad reference-parameter forward
+    runs on the engine too."""
+    if native_out is None:
+        return ref_out
+    new = {}
+    for f in _VALUE_FIELDS:
+        r, n = getattr(ref_out, f, None), getattr(native_out, f, None)
+        if torch.is_tensor(r) and torch.is_tensor(n) and r.requires_grad and r.shape == n.shape:
+            new[f] = n.detach().to(device=r.device, dtype=r.dtype) + (r - r.detach())
+    if not new:
+        return ref_out
+    return type(ref_out).from_dict({**ref_out.to_dict(), **new})
 
 
 def _native_vae(pipeline):
@@ -186,7 +228,8 @@ if _RefAdapter is not None:
                 logger.warning("mi355_flow: grad-mode forward() uses the reference autograd path (%s); the replay log-prob then differs "
                                "from the rollout's by the engine-vs-torch arithmetic difference", why)
                 self._warned_ref_grad = True
-            return _RefAdapter.forward(self, **kwargs)
+            # the value still comes from the engine (no-grad step on the same inputs), the gradient from the reference path
+            return self._replay_on_reference(_RefAdapter.forward, NativeRolloutMixin.forward, (), kwargs)
 
     try:
         from flow_factory.models.flux.flux1 import Flux1Adapter as _RefFlux, Flux1Sample as _RefFluxSample
@@ -224,8 +267,8 @@ if _RefAdapter is not None:
 
             @functools.wraps(FluxRolloutMixin.forward)
             def forward(self, *args, **kwargs):
-                if torch.is_grad_enabled():          # optimize(): autograd stays on the reference path for FLUX
-                    return _RefFlux.forward(self, *args, **kwargs)
+                if torch.is_grad_enabled():          # optimize(): autograd on the reference path, values from the engine
+                    return self._replay_on_reference(_RefFlux.forward, FluxRolloutMixin.forward, args, kwargs)
                 return FluxRolloutMixin.forward(self, *args, **kwargs)
 
     try:
@@ -285,8 +328,10 @@ if _RefAdapter is not None:
 
             @functools.wraps(WanRolloutMixin.forward)
             def forward(self, *args, **kwargs):
-                if torch.is_grad_enabled() or bool(getattr(self.scheduler, "is_eval", False)):
+                if bool(getattr(self.scheduler, "is_eval", False)):
                     return _RefWan.forward(self, *args, **kwargs)
+                if torch.is_grad_enabled():          # optimize(): autograd on the reference path, values from the engine
+                    return self._replay_on_reference(_RefWan.forward, WanRolloutMixin.forward, args, kwargs)
                 return WanRolloutMixin.forward(self, *args, **kwargs)
 
     try:
@@ -331,8 +376,8 @@ if _RefAdapter is not None:
 
             @functools.wraps(QwenRolloutMixin.forward)
             def forward(self, *args, **kwargs):
-                if torch.is_grad_enabled():          # optimize(): autograd stays on the reference path for Qwen-Image
-                    return _RefQwen.forward(self, *args, **kwargs)
+                if torch.is_grad_enabled():          # optimize(): autograd on the reference path, values from the engine
+                    return self._replay_on_reference(_RefQwen.forward, QwenRolloutMixin.forward, args, kwargs)
                 return QwenRolloutMixin.forward(self, *args, **kwargs)
 
 else:

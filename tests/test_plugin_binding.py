@@ -360,3 +360,86 @@ def test_qwen_image_plugin_rollout_with_ragged_prompts(ref):
         assert ad.engine.calls[-1][1]["n_cfg"] == 1 and ad.engine.calls[-1][1]["lens"] == lens
     finally:
         PM.QwenEngine, MV.WanVAEDecoder = real_engine, real_dec
+
+
+# ------------------------------------------------------------------------------------------------- grad-mode forward without a native backward
+def test_engine_valued_replay_value_is_the_engines_gradient_is_the_references(ref):
+    """FLUX / Wan / Qwen-Image (and any SD3.5 trainable set the engine's backward does not cover): `optimize()` must see the ENGINE's
+    log-prob -- ratio == 1 exactly before an update -- while autograd runs through the reference's torch path."""
+    P = ref
+    Out = P._RefOutput
+    w = torch.tensor([0.5, -0.25], requires_grad=True)
+    x = torch.tensor([[1.0, 2.0], [3.0, 4.0]])
+
+    def ref_forward(self, **kw):                  # the reference path: differentiable, slightly different arithmetic
+        npred = x * w
+        return Out(log_prob=(npred ** 2).sum(1) * 1.0001, noise_pred=npred, next_latents_mean=npred * 0.5, dt=torch.tensor([-0.1]),
+                   next_latents=kw["next_latents"])
+
+    nat = dict(log_prob=torch.tensor([1.03125, 7.0625]), noise_pred=torch.tensor([[0.5, -0.5], [1.5, -1.0]]).bfloat16().float(),
+               next_latents_mean=torch.tensor([[0.25, -0.25], [0.75, -0.5]]))
+    calls = []
+
+    def native_forward(self, **kw):
+        assert not torch.is_grad_enabled()
+        calls.append(kw)
+        return Out(dt=torch.tensor([-0.1]), next_latents=kw["next_latents"], **nat)
+
+    holder = types.SimpleNamespace(engine_valued_replay=True)
+    run = lambda **kw: P._LiveBinding._replay_on_reference(holder, ref_forward, native_forward, (), kw)   # noqa: E731
+    nl = torch.zeros(2, 2)
+    out = run(next_latents=nl, t=torch.tensor([900.0]))
+    assert len(calls) == 1 and type(out) is Out
+    for f in ("log_prob", "noise_pred", "next_latents_mean"):
+        assert torch.equal(getattr(out, f).detach(), nat[f]), f            # the engine's value, bit for bit
+        assert getattr(out, f).requires_grad
+    assert out.next_latents is nl and torch.equal(out.dt, torch.tensor([-0.1]))
+    ratio = torch.exp(out.log_prob - nat["log_prob"])                      # old_log_prob came from the engine's rollout
+    assert torch.equal(ratio.detach(), torch.ones(2))
+    (g,) = torch.autograd.grad(out.log_prob.sum() + out.noise_pred.sum(), w)
+    r = ref_forward(None, next_latents=nl)
+    (g_ref,) = torch.autograd.grad(r.log_prob.sum() + r.noise_pred.sum(), w)
+    assert torch.equal(g, g_ref)
+    # a sampling step in grad mode (no stored transition) has nothing to be consistent with: reference path only
+    run(next_latents=None)
+    assert len(calls) == 1
+    # an option the engine rejects keeps the reference's values (and says so once)
+    def rejecting(self, **kw):
+        raise NotImplementedError("joint_attention_kwargs ['ip_adapter_image_embeds']")
+    out2 = P._LiveBinding._replay_on_reference(holder, ref_forward, rejecting, (), dict(next_latents=nl))
+    assert torch.equal(out2.log_prob.detach(), r.log_prob.detach()) and holder._warned_ref_value
+    # opt-out
+    holder.engine_valued_replay = False
+    out3 = run(next_latents=nl)
+    assert len(calls) == 1 and torch.equal(out3.log_prob.detach(), r.log_prob.detach())
+
+
+def test_sd3_grad_fallback_is_engine_valued(ref):
+    """The SD3.5 plugin's own fallback (trainable parameters outside the engine's backward scope) goes through the same re-valuation:
+    the reference's `SD3_5Adapter.forward` runs WITH autograd on a differentiable torch transformer, the engine step gives the values."""
+    from mi355_flow import autograd as AG
+    ad, cfg, tr = _make(ref, YAML_FULL)
+    wq = tr.get_submodule("transformer_blocks.0.attn.to_q").weight
+    assert wq.requires_grad
+    ad.rollout()
+    ad.scheduler.set_timesteps(10)
+    e = _embeds()
+    lat = torch.randn(2, 16, 16, 16, generator=torch.Generator().manual_seed(1)).half()
+    fwd = dict(t=torch.tensor([900.0, 900.0]), t_next=torch.tensor([750.0, 750.0]), latents=lat, next_latents=(lat * 0.9).half(),
+               noise_level=0.7, compute_log_prob=True, guidance_scale=1.0, return_kwargs=["log_prob", "noise_pred", "dt"],
+               prompt_embeds=e["prompt_embeds"], pooled_prompt_embeds=e["pooled_prompt_embeds"])
+    real_reason = AG.unsupported_reason
+    try:
+        AG.unsupported_reason = lambda adapter: "test: trainable set outside the native backward"
+        # what `self.transformer(...)` does on the reference path: any differentiable function of a trainable parameter
+        tr.forward = lambda hidden_states=None, **kw: (hidden_states.float() * wq.float().mean(),)
+        with torch.enable_grad():
+            out = ad.forward(**fwd)
+        assert ad.engine.calls[-1][0] == "denoise_step" and ad.engine.calls[-1][1]["replay"]
+        assert out.log_prob.requires_grad and torch.equal(out.log_prob.detach(), torch.full((2,), -1.0))    # FakePlan's value
+        assert torch.equal(out.noise_pred.detach().float(), lat.float())                                     # FakePlan echoes the latents
+        (g,) = torch.autograd.grad(out.log_prob.sum(), wq)
+        assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
+    finally:
+        AG.unsupported_reason = real_reason
+        del tr.forward
