@@ -261,17 +261,27 @@ class NativeRolloutMixin:
         sigma_max = float(sched.sigmas[1])
         want = tuple(k for k in return_kwargs if k in ("next_latents", "next_latents_mean", "noise_pred", "std_dev_t", "dt"))
         view = (-1, 1, 1, 1)
-        if torch.is_grad_enabled() and next_latents is not None and getattr(self, "_live_weights", None) is not None:
-            # optimize() replay (trainers/grpo.py:263): the engine's differentiable step when its backward covers the trainable set
+        if torch.is_grad_enabled() and getattr(self, "_live_weights", None) is not None:
+            # Grad-mode forward.  (1) `optimize()` replay of a stored transition (trainers/grpo.py:263): log-prob of `next_latents`.
+            # (2) The matching-loss trainers -- AWM (trainers/awm.py:357-370), NFT (nft.py:297-304), DPO (dpo.py:468-469), DGPO
+            # (dgpo.py:352-364), CRD (crd.py:497-509) -- call forward() WITH autograd at an arbitrary `t`, no stored transition,
+            # `compute_log_prob=False`, and read `noise_pred`: the same differentiable engine step, whose network output, mean, std
+            # and dt do not depend on the next state (a placeholder transition is passed; its log-prob is switched off).
+            # A freshly SAMPLED next state (or its log-prob) with autograd is not a native output: reference path.
             from . import autograd as AG
+            replay = next_latents is not None
+            sampled = (not replay) and ("next_latents" in return_kwargs or (compute_log_prob and "log_prob" in return_kwargs))
             why = AG.unsupported_reason(self)
+            if why is None and sampled:
+                why = "a sampled next state (or its log-prob) was requested with autograd"
             if why is None:
+                clp = bool(compute_log_prob) and replay
                 call = dict(latents=latents, timestep=t, enc_a=enc[0], pooled_a=enc[1], enc_b=enc[2], pooled_b=enc[3], guidance=guidance_scale,
                             sigma=sigma, sigma_next=sigma_next, eta=noise_level, sigma_max=sigma_max, dynamics=dyn,
-                            next_latents=next_latents, compute_log_prob=compute_log_prob)
+                            next_latents=next_latents if replay else latents, compute_log_prob=clp)
                 lp, npred, mean, std, dtt = AG.denoise_replay(self, plan, call)
-                res = dict(noise_pred=npred, next_latents=next_latents.float(), next_latents_mean=mean, std_dev_t=std.view(view),
-                           dt=dtt.view(view), log_prob=lp if compute_log_prob else None)
+                res = dict(noise_pred=npred, next_latents=next_latents.float() if replay else None, next_latents_mean=mean,
+                           std_dev_t=std.view(view), dt=dtt.view(view), log_prob=lp if clp else None)
                 return self._output_cls.from_dict({k: res[k] for k in return_kwargs if k in res})
             if not why.startswith("the bound module has no trainable"):
                 return self._grad_fallback(why, dict(
