@@ -250,9 +250,7 @@ def main():
         lib.mi355_tune_set(3, args.pp_min_tiles)
     if os.environ.get("MI355_ATTN_STATIC") == "0":     # A/B: keep the running-max softmax even where the static bound holds
         lib.mi355_tune_set(6, 0)
-    for kv in filter(None, os.environ.get("MI355_TUNE", "").split(",")):      # A/B of kernel variants: "key=value,..." (mi355_tune_set)
-        k_, v_ = kv.split("=")
-        _lib.check(lib.mi355_tune_set(int(k_), int(v_)), "tune_set")
+    # (MI355_TUNE="key=value,..." -- A/B of kernel / launch variants -- is applied by _lib.load() itself)
     for _ in range(args.warmup):
         samples = one_rollout()
     if not args.no_selfcheck and not flux_mode:
@@ -320,6 +318,8 @@ def main():
         "world": {"backend": "nccl (RCCL)" if world > 1 else None, "world_size": world,
                   "per_rank_denoise_steps_per_s": [round(B * N * args.steps / t, 3) for t in per_rank]},
     }
+    if os.environ.get("MI355_TUNE"):
+        out["tune"] = os.environ["MI355_TUNE"]          # non-default kernel / launch variants of this run (mi355_tune_set keys)
     if timing and rank == 0:
         attn_fl, attn_launches = attention_flops(cfg, Ni, N_TEXT)
         fwd_per_timed = n_cfg * N * args.steps  # transformer forwards (batch B each) in the timed region on this rank

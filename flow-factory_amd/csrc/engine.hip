@@ -354,7 +354,10 @@ struct mi355_plan {
     hipStream_t cap_stream = nullptr;   // capture happens on a plan-owned stream: the caller's may be the legacy default stream (torch's
                                         // current stream unless the user switched), which cannot be captured; the graph is LAUNCHED on the caller's
     bool warmed = false;
-    int g_steps = -1, g_dyn = -1, g_storage = -1, g_init = -1, g_clp = -1, g_attn = -1, g_gemm = -1, g_bounds = -1;
+    int g_steps = -1, g_dyn = -1, g_storage = -1, g_init = -1, g_clp = -1, g_attn = -1, g_gemm = -1, g_bounds = -1, g_two = -1;
+    // text-stream chain of a forward on a second stream (forward_core): plan-owned, created on first use
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev_join, ev_fork;   // per block: text q|k|v ready (side -> main), attention done (main -> side); [L] = forward start
     float g_guidance = 0.f, g_sigma_max = 0.f;
 };
 
@@ -439,6 +442,9 @@ extern "C" int mi355_plan_destroy(mi355_plan* p) {
     train_release(p);
     if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
+    for (hipEvent_t ev : p->ev_join) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : p->ev_fork) (void)hipEventDestroy(ev);
+    if (p->side) (void)hipStreamDestroy(p->side);
     if (p->ws) (void)hipFree(p->ws);
     delete p;
     return 0;
@@ -576,6 +582,34 @@ static int gate_res(mi355_plan* p, hipStream_t st, const bf16_t* A, int K, const
     return 0;
 }
 
+// ---- two-stream forward ------------------------------------------------------------------------------------------------------
+// Between two joint attentions the text-stream chain of an MMDiT block (out-projection, LN-modulate, MLP, the next block's LN-modulate and
+// q|k / V^T projections) is independent of the image-stream chain.  Its grids are small (M = B'.Nt rows: 11-132 workgroups) and, in
+// small-batch configurations, so are the image grids (M <= 8192: 96-384 tiles on 256 CUs): launched back to back on one stream each of
+// them leaves most of the chip idle.  With the text chain on a plan-owned side stream (fork after every attention, join before the next
+// one) the two chains' workgroups share the CUs; inside the captured rollout the fork / join events become graph edges, so one hipGraph
+// launch replays a two-branch DAG per block.  Same kernels, same operands, same arithmetic: results are bit-identical to the
+// single-stream order.  Mode (mi355_tune_set key 8): 0 = single stream, 1 = always, 2 = when the image stream has at most
+// `g_two_stream_rows` rows (key 9).
+static int g_two_stream = 0;
+static int g_two_stream_rows = 8192;
+static bool two_stream_wanted(const mi355_plan* p) {
+    return g_two_stream == 1 || (g_two_stream == 2 && p->Mi <= g_two_stream_rows);
+}
+static int two_stream_init(mi355_plan* p) {
+    if (p->side) return 0;
+    HIPCHK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    const size_t n = (size_t)p->e->L + 1;
+    for (size_t i = 0; i < n; ++i) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        p->ev_join.push_back(a);
+        HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        p->ev_fork.push_back(b);
+    }
+    return 0;
+}
+
 // One transformer forward.  `mod` = this step's rows of mod_all; c0 / pe / conditioning prepared.
 static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int lat_dt, const bf16_t* mod, bf16_t* v_out) {
     mi355_engine* e = p->e;
@@ -594,27 +628,48 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
         HIPCHK(gemm_p(g, st));
     }
     HIPCHK(hipMemcpyAsync(p->c, p->c0, (size_t)Mc * D * 2, hipMemcpyDeviceToDevice, st));
+    // `ts` carries the text-stream chain: the caller's stream, or the plan's side stream (see above)
+    const bool two = two_stream_wanted(p);
+    hipStream_t ts = st;
+    if (two) {
+        CHK(two_stream_init(p));
+        ts = p->side;
+        HIPCHK(hipEventRecord(p->ev_fork[e->L], st));           // c, the conditioning and the previous forward are complete on `st`
+        HIPCHK(hipStreamWaitEvent(ts, p->ev_fork[e->L], 0));
+    }
+    bool text_open = false;      // the side stream holds work that `st` has not waited for yet
     for (int i = 0; i < e->L; ++i) {
         const BlockW& b = e->blk[i];
         const int mi = b.mod_img, mc = b.mod_ctx;
         // AdaLN-Zero chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp[, shift2, scale2, gate2]
         CHK(ln_mod(p, st, p->x, p->xn, b.dual ? p->xn2 : nullptr, mod, Mi, Ni, mi + 0 * D, mi + 1 * D, mi + 6 * D, mi + 7 * D));
         if (b.last)  // AdaLayerNormContinuous: scale first, then shift
-            CHK(ln_mod(p, st, p->c, p->cn, nullptr, mod, Mc, Nt, mc + 1 * D, mc + 0 * D, 0, 0));
+            CHK(ln_mod(p, ts, p->c, p->cn, nullptr, mod, Mc, Nt, mc + 1 * D, mc + 0 * D, 0, 0));
         else
-            CHK(ln_mod(p, st, p->c, p->cn, nullptr, mod, Mc, Nt, mc + 0 * D, mc + 1 * D, 0, 0));
+            CHK(ln_mod(p, ts, p->c, p->cn, nullptr, mod, Mc, Nt, mc + 0 * D, mc + 1 * D, 0, 0));
         // joint attention: image tokens first, then text
         CHK(qkv_proj(p, st, p->xn, Mi, Ni, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk, p->q, p->k, p->vT, p->S_pad, 0));
-        CHK(qkv_proj(p, st, p->cn, Mc, Nt, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck, p->q, p->k, p->vT, p->S_pad, Ni));
+        CHK(qkv_proj(p, ts, p->cn, Mc, Nt, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck, p->q, p->k, p->vT, p->S_pad, Ni));
+        if (two) {               // join: the attention reads the text rows of q / k / vT and overwrites o_ctx
+            HIPCHK(hipEventRecord(p->ev_join[i], ts));
+            HIPCHK(hipStreamWaitEvent(st, p->ev_join[i], 0));
+            text_open = false;
+        }
         {
             AttnParams a{p->q, p->k, p->vT, p->o_img, p->o_ctx, p->Bp, H, p->S, p->S_pad, Ni, get_attn_variant() >= 1,
                          g_attn_static ? b.bound_joint : 0.f};
             HIPCHK(attn_p(a, st));
         }
+        if (two && (!b.last || i + 1 < e->L)) {   // fork: text work follows (never after the final attention: nothing would join it)
+            HIPCHK(hipEventRecord(p->ev_fork[i], st));
+            HIPCHK(hipStreamWaitEvent(ts, p->ev_fork[i], 0));
+            text_open = true;
+        }
         CHK(gate_res(p, st, p->o_img, D, b.w_o, b.b_o, p->x, Mi, Ni, mod, mi + 2 * D));
-        if (!b.last) CHK(gate_res(p, st, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
+        if (!b.last) CHK(gate_res(p, ts, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
         if (b.dual) {
             CHK(qkv_proj(p, st, p->xn2, Mi, Ni, b.w_qk2, b.b_qk2, b.w_v2, b.b_v2, b.nq2, b.nk2, p->q2, p->k2, p->vT2, Ni_pad, 0));
+            // S == n_img: this launch writes o_img only, never o_ctx (which the text chain may still be reading)
             AttnParams a{p->q2, p->k2, p->vT2, p->o_img, p->o_ctx, p->Bp, H, Ni, Ni_pad, Ni, get_attn_variant() >= 1,
                          g_attn_static ? b.bound_dual : 0.f};
             HIPCHK(attn_p(a, st));
@@ -628,11 +683,15 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
         }
         CHK(gate_res(p, st, p->hid, F, b.w_ff2, b.b_ff2, p->x, Mi, Ni, mod, mi + 5 * D));
         if (!b.last) {
-            CHK(ln_mod(p, st, p->c, p->cn, nullptr, mod, Mc, Nt, mc + 3 * D, mc + 4 * D, 0, 0));
+            CHK(ln_mod(p, ts, p->c, p->cn, nullptr, mod, Mc, Nt, mc + 3 * D, mc + 4 * D, 0, 0));
             GemmParams g = gp(p->cn, D, b.w_cff1, D, Mc, F, D, EPI_BIAS_GELU, b.b_cff1, p->chid, F);
-            HIPCHK(gemm_p(g, st));
-            CHK(gate_res(p, st, p->chid, F, b.w_cff2, b.b_cff2, p->c, Mc, Nt, mod, mc + 5 * D));
+            HIPCHK(gemm_p(g, ts));
+            CHK(gate_res(p, ts, p->chid, F, b.w_cff2, b.b_cff2, p->c, Mc, Nt, mod, mc + 5 * D));
         }
+    }
+    if (two && text_open) {      // a model whose last block keeps its text stream: rejoin before the caller's stream goes on
+        HIPCHK(hipEventRecord(p->ev_join[e->L], ts));
+        HIPCHK(hipStreamWaitEvent(st, p->ev_join[e->L], 0));
     }
     // norm_out (scale first) + proj_out + unpatchify
     CHK(ln_mod(p, st, p->x, p->xn, nullptr, mod, Mi, Ni, e->mod_out + 1 * D, e->mod_out + 0 * D, 0, 0));
@@ -788,8 +847,9 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
         const bool same = p->gexec && p->g_steps == n_steps && p->g_dyn == dynamics && p->g_storage == storage_dtype &&
                           p->g_init == init_dtype && p->g_clp == clp && p->g_guidance == guidance && p->g_sigma_max == sigma_max &&
                           p->g_attn == get_attn_variant() && p->g_gemm == get_gemm_variant() &&
-                          p->g_bounds == p->e->bounds_ver * 2 + (g_attn_static != 0);
+                          p->g_bounds == p->e->bounds_ver * 2 + (g_attn_static != 0) && p->g_two == (int)two_stream_wanted(p);
         if (!same) {
+            if (two_stream_wanted(p)) CHK(two_stream_init(p));   // streams / events are created outside the capture
             if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
             hipGraph_t graph = nullptr;
             hipError_t ce = hipSuccess;
@@ -813,6 +873,7 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
                 p->g_steps = n_steps; p->g_dyn = dynamics; p->g_storage = storage_dtype; p->g_init = init_dtype; p->g_clp = clp;
                 p->g_guidance = guidance; p->g_sigma_max = sigma_max; p->g_attn = get_attn_variant(); p->g_gemm = get_gemm_variant();
                 p->g_bounds = p->e->bounds_ver * 2 + (g_attn_static != 0);
+                p->g_two = (int)two_stream_wanted(p);
             } else {
                 // no silent fallback (header convention, reference constraints.md:144-145): the caller decides whether to
                 // retry with eager launches (mi355_tune_set(2, 0))
@@ -858,6 +919,8 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 5) { set_attn128_variant(value); return 0; }
     if (key == 6) { g_attn_static = value; return 0; }
     if (key == 7) { set_raster_gm(value); return 0; }
+    if (key == 8) { g_two_stream = value; return 0; }          // text-stream chain on a side stream: 0 off, 1 on, 2 auto (rows <= key 9)
+    if (key == 9) { g_two_stream_rows = value; return 0; }
     return fail("mi355_tune_set: unknown key %d", key);
 }
 

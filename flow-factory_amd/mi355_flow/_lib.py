@@ -194,6 +194,11 @@ def load() -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # A/B of kernel / launch variants for a whole process (tests, bench, scripts): MI355_TUNE="key=value,..." -> mi355_tune_set
+    for kv in filter(None, os.environ.get("MI355_TUNE", "").split(",")):
+        k, v = kv.split("=")
+        if lib.mi355_tune_set(int(k), int(v)) != 0:
+            raise RuntimeError(f"mi355_flow: MI355_TUNE entry '{kv}' was rejected: {lib.mi355_last_error().decode()}")
     return lib
 
 

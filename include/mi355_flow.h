@@ -376,7 +376,12 @@ int mi355_profile_enable(int on);
  * key 6 = static-bound softmax (no running max when the q/k norm weights prove |score| <= 60): 1 on (default), 0 off,
  *         v >= 2: mi355_op_attention asserts the bound v itself (unit tests));
  * key 7 = GEMM tile raster: tile rows per band, walked column by column so that the tiles an XCD holds at any time form a near-square block
- *         (default 6; 0 = plain row-major order).  Results are bit-identical for every value. */
+ *         (default 6; 0 = plain row-major order).  Results are bit-identical for every value;
+ * key 8 = SD3.5 forward: the text-stream chain of every block (out-projection, LN-modulate, MLP, next q|k / V^T projections) on a
+ *         plan-owned second stream, forked after each joint attention and joined before the next (graph edges inside the captured
+ *         rollout): 0 = single stream, 1 = always, 2 = when the image stream has at most <key 9> rows (default rows 8192).  Results are
+ *         bit-identical for every value.
+ * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);
 

@@ -91,6 +91,73 @@ def test_graph_replay_equals_eager_across_epochs(ctx):
     assert not torch.equal(runs[0][0], runs[1][0])
 
 
+def _same(a, b):
+    return torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)) and bool((torch.isnan(a) == torch.isnan(b)).all())
+
+
+@pytest.mark.parametrize("n_cfg", [1, 2])
+def test_two_stream_forward_is_bit_identical(ctx, n_cfg):
+    """mi355_tune_set key 8: the text-stream chain of every block runs on a plan-owned side stream (fork after each joint attention, join
+    before the next; graph edges inside the captured rollout).  Same kernels on the same operands: the rollout must be bit-identical to the
+    single-stream order -- eagerly and as a replayed hipGraph, from the caller's default stream and from a user stream, repeatedly (a
+    missing dependency would show as run-to-run differences)."""
+    from mi355_flow import _lib
+    from oracle import scheduler_ref as S
+    cfg, e, sd = ctx
+    lib = _lib.load()
+    B, h, w, Nt, N = 3, 16, 24, 9, 5
+    ts, sig = S.make_schedule(N, shift=3.0)
+    nl = [0.0, 0.7, 0.0, 0.7, 0.0]
+    pe, pp, ne, npl, init, noise = _inputs(B, h, w, Nt, N, 900 + n_cfg)
+    gs = 4.5 if n_cfg == 2 else 1.0
+    args = (ts.tolist(), sig.tolist(), nl, "Flow-SDE", gs, init.cuda(), torch.float16, noise.cuda(), pe.cuda(), pp.cuda()) + \
+           ((ne.cuda(), npl.cuda()) if n_cfg == 2 else ())
+    plan = e.plan(B, n_cfg, h, w, Nt, N)
+    try:
+        lib.mi355_tune_set(8, 0)
+        lib.mi355_tune_set(2, 0)
+        base = plan.rollout(*args)
+        torch.cuda.synchronize()
+        lib.mi355_tune_set(8, 1)
+        for rep in range(3):                                   # eager, two streams
+            out = plan.rollout(*args)
+            assert all(_same(a, b) for a, b in zip(out, base)), ("eager", rep)
+        lib.mi355_tune_set(2, 1)
+        for rep in range(4):                                   # (re)captured with fork / join edges, then replayed
+            out = plan.rollout(*args)
+            assert all(_same(a, b) for a, b in zip(out, base)), ("graph", rep)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                          # caller on a non-default stream
+            out = plan.rollout(*args)
+            lib.mi355_tune_set(2, 0)
+            out_e = plan.rollout(*args)
+        side.synchronize()
+        assert all(_same(a, b) for a, b in zip(out, base)) and all(_same(a, b) for a, b in zip(out_e, base))
+        # auto mode: rows above the threshold keep the single stream, below take two -- same results either way
+        lib.mi355_tune_set(8, 2)
+        for rows in (1, 1 << 20):
+            lib.mi355_tune_set(9, rows)
+            lib.mi355_tune_set(2, 1)
+            out = plan.rollout(*args)
+            out2 = plan.rollout(*args)
+            assert all(_same(a, b) for a, b in zip(out, base)) and all(_same(a, b) for a, b in zip(out2, base)), rows
+        # single steps (mi355_denoise_step) take the same path
+        lib.mi355_tune_set(8, 1)
+        x = init.cuda().half()
+        kw = dict(noise=noise[0].cuda(), compute_log_prob=True, want=("next_latents_mean", "noise_pred"))
+        tt = torch.full((B,), float(ts[0]), device="cuda")
+        step_args = (x, tt, pe.cuda(), pp.cuda(), None, None, 1.0) if n_cfg == 1 else (x, tt, ne.cuda(), npl.cuda(), pe.cuda(), pp.cuda(), gs)
+        o2 = plan.denoise_step(*step_args, float(sig[0]), float(sig[1]), 0.7, float(sig[1]), "Flow-SDE", **kw)
+        lib.mi355_tune_set(8, 0)
+        o1 = plan.denoise_step(*step_args, float(sig[0]), float(sig[1]), 0.7, float(sig[1]), "Flow-SDE", **kw)
+        assert torch.equal(o1.noise_pred, o2.noise_pred) and torch.equal(o1.log_prob, o2.log_prob)
+    finally:
+        lib.mi355_tune_set(8, 0)
+        lib.mi355_tune_set(9, 8192)
+        lib.mi355_tune_set(2, 1)
+
+
 def test_adapter_error_paths(ctx):
     from mi355_flow.adapter import SD3_5NativeAdapter
     from mi355_flow.engine import TransformerConfig
