@@ -12,7 +12,7 @@ TUNE=$(cat $OUT/tune.env 2>/dev/null)
 echo "TUNE=$TUNE" >> $OUT/status
 export MI355_TUNE="$TUNE"
 timeout 420 python -m pytest tests/test_gpu_rollout_variants.py tests/test_gpu_backward.py tests/test_gpu_model.py tests/test_gpu_adapter.py \
-    tests/test_gpu_grpo_epoch.py tests/test_gpu_kernels.py tests/test_gpu_fullsize.py -m gpu -q -x 2>&1 | tail -15 > $OUT/tests_sd3.log
+    tests/test_gpu_grpo_epoch.py tests/test_gpu_kernels.py tests/test_gpu_fullsize.py -m gpu -q 2>&1 | tail -25 > $OUT/tests_sd3.log
 echo "tests_sd3 rc=${PIPESTATUS[0]}" >> $OUT/status; tail -5 $OUT/tests_sd3.log
 timeout 400 python bench.py 2>$OUT/bench.err > $OUT/bench.json; echo "bench rc=$?" >> $OUT/status; cut -c1-600 $OUT/bench.json
 export TMPDIR=/tmp

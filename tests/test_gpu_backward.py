@@ -225,11 +225,17 @@ def test_matching_loss_forward_without_a_stored_transition(gpu, guidance):
         if float(ref.norm()) < 1e-12:
             assert float(prm.grad.float().norm()) < 1e-6, name
             continue
+        if name.endswith("k.bias") or name.endswith("k_proj.bias"):
+            # a key bias shifts every score of a query equally: its gradient is zero up to rounding (softmax shift invariance);
+            # judge the error against the scale of the matching weight gradient instead of its own near-zero norm
+            wref = g_ref[name[:-4] + "weight"]
+            assert float((prm.grad.float().cpu() - ref).norm()) <= 5e-2 * max(float(ref.norm()), 1e-2 * float(wref.norm())), name
+            continue
         r = _rel(prm.grad, ref)
         worst, n = max(worst, r), n + 1
         assert r < 5e-2 and _cos(prm.grad, ref) > 0.995, (name, r)
     print(f"matching-loss forward, guidance {guidance}: {n} parameter gradients, worst rel-L2 {worst:.3e}")
-    assert n >= 60
+    assert n >= 50
     # a sampled next state with autograd is not a native output: standalone there is no reference path to fall back to
     with pytest.raises(NotImplementedError, match="sampled next state"):
         ad.forward(**{**kw, "return_kwargs": ["noise_pred", "next_latents"]})
