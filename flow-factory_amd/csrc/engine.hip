@@ -589,10 +589,12 @@ static int gate_res(mi355_plan* p, hipStream_t st, const bf16_t* A, int K, const
 // them leaves most of the chip idle.  With the text chain on a plan-owned side stream (fork after every attention, join before the next
 // one) the two chains' workgroups share the CUs; inside the captured rollout the fork / join events become graph edges, so one hipGraph
 // launch replays a two-branch DAG per block.  Same kernels, same operands, same arithmetic: results are bit-identical to the
-// single-stream order.  Mode (mi355_tune_set key 8): 0 = single stream, 1 = always, 2 = when the image stream has at most
-// `g_two_stream_rows` rows (key 9).
-static int g_two_stream = 0;
-static int g_two_stream_rows = 8192;
+// single-stream order.  Mode (mi355_tune_set key 8): 0 = single stream, 1 = always, 2 (default) = when the image stream has at most
+// `g_two_stream_rows` rows (key 9; default 32 768 = the largest shape measured, B = 8 at 1024^2: +2.4 %; B = 1 / 2 / 4: +31 / +12 / +9 %,
+// the reference's 512^2 examples +6 ... +22 %: profiles/r02b_two_stream_ab.txt).
+static int g_two_stream = 2;
+static int g_two_stream_rows = 32768;
+static int g_two_stream_late_fork = 1;     // key 10: fork after the block's last attention (1) or right after the joint attention (0)
 static bool two_stream_wanted(const mi355_plan* p) {
     return g_two_stream == 1 || (g_two_stream == 2 && p->Mi <= g_two_stream_rows);
 }
@@ -660,21 +662,30 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
                          g_attn_static ? b.bound_joint : 0.f};
             HIPCHK(attn_p(a, st));
         }
-        if (two && (!b.last || i + 1 < e->L)) {   // fork: text work follows (never after the final attention: nothing would join it)
+        // fork: text work follows (never after the final attention: nothing would join it).  The fork point is the block's LAST attention
+        // launch -- the dual (image-only) attention of a dual block also fills every CU, and text-stream GEMMs squeezed in beside it only
+        // stretch it (measured: attention 840 -> 900 us per launch with the fork before it); it touches neither o_ctx nor c.
+        const bool fork_here = two && (!b.last || i + 1 < e->L);
+        auto fork = [&]() -> int {
             HIPCHK(hipEventRecord(p->ev_fork[i], st));
             HIPCHK(hipStreamWaitEvent(ts, p->ev_fork[i], 0));
             text_open = true;
-        }
+            return 0;
+        };
+        const bool late = b.dual && g_two_stream_late_fork;
+        if (fork_here && !late) CHK(fork());
         CHK(gate_res(p, st, p->o_img, D, b.w_o, b.b_o, p->x, Mi, Ni, mod, mi + 2 * D));
-        if (!b.last) CHK(gate_res(p, ts, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
+        if (!two && !b.last) CHK(gate_res(p, st, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
         if (b.dual) {
             CHK(qkv_proj(p, st, p->xn2, Mi, Ni, b.w_qk2, b.b_qk2, b.w_v2, b.b_v2, b.nq2, b.nk2, p->q2, p->k2, p->vT2, Ni_pad, 0));
-            // S == n_img: this launch writes o_img only, never o_ctx (which the text chain may still be reading)
+            // S == n_img: this launch writes o_img only, never o_ctx (which the text chain reads after the fork)
             AttnParams a{p->q2, p->k2, p->vT2, p->o_img, p->o_ctx, p->Bp, H, Ni, Ni_pad, Ni, get_attn_variant() >= 1,
                          g_attn_static ? b.bound_dual : 0.f};
             HIPCHK(attn_p(a, st));
+            if (fork_here && late) CHK(fork());
             CHK(gate_res(p, st, p->o_img, D, b.w_o2, b.b_o2, p->x, Mi, Ni, mod, mi + 8 * D));
         }
+        if (two && !b.last) CHK(gate_res(p, ts, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
         // MLP (image stream)
         CHK(ln_mod(p, st, p->x, p->xn, nullptr, mod, Mi, Ni, mi + 3 * D, mi + 4 * D, 0, 0));
         {
@@ -847,7 +858,7 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
         const bool same = p->gexec && p->g_steps == n_steps && p->g_dyn == dynamics && p->g_storage == storage_dtype &&
                           p->g_init == init_dtype && p->g_clp == clp && p->g_guidance == guidance && p->g_sigma_max == sigma_max &&
                           p->g_attn == get_attn_variant() && p->g_gemm == get_gemm_variant() &&
-                          p->g_bounds == p->e->bounds_ver * 2 + (g_attn_static != 0) && p->g_two == (int)two_stream_wanted(p);
+                          p->g_bounds == p->e->bounds_ver * 2 + (g_attn_static != 0) && p->g_two == (int)two_stream_wanted(p) * (1 + g_two_stream_late_fork);
         if (!same) {
             if (two_stream_wanted(p)) CHK(two_stream_init(p));   // streams / events are created outside the capture
             if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
@@ -873,7 +884,7 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
                 p->g_steps = n_steps; p->g_dyn = dynamics; p->g_storage = storage_dtype; p->g_init = init_dtype; p->g_clp = clp;
                 p->g_guidance = guidance; p->g_sigma_max = sigma_max; p->g_attn = get_attn_variant(); p->g_gemm = get_gemm_variant();
                 p->g_bounds = p->e->bounds_ver * 2 + (g_attn_static != 0);
-                p->g_two = (int)two_stream_wanted(p);
+                p->g_two = (int)two_stream_wanted(p) * (1 + g_two_stream_late_fork);
             } else {
                 // no silent fallback (header convention, reference constraints.md:144-145): the caller decides whether to
                 // retry with eager launches (mi355_tune_set(2, 0))
@@ -921,6 +932,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 7) { set_raster_gm(value); return 0; }
     if (key == 8) { g_two_stream = value; return 0; }          // text-stream chain on a side stream: 0 off, 1 on, 2 auto (rows <= key 9)
     if (key == 9) { g_two_stream_rows = value; return 0; }
+    if (key == 10) { g_two_stream_late_fork = value; return 0; }
     return fail("mi355_tune_set: unknown key %d", key);
 }
 

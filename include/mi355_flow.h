@@ -379,8 +379,9 @@ int mi355_profile_enable(int on);
  *         (default 6; 0 = plain row-major order).  Results are bit-identical for every value;
  * key 8 = SD3.5 forward: the text-stream chain of every block (out-projection, LN-modulate, MLP, next q|k / V^T projections) on a
  *         plan-owned second stream, forked after each joint attention and joined before the next (graph edges inside the captured
- *         rollout): 0 = single stream, 1 = always, 2 = when the image stream has at most <key 9> rows (default rows 8192).  Results are
- *         bit-identical for every value.
+ *         rollout): 0 = single stream, 1 = always, 2 (default) = when the image stream has at most <key 9> rows (default 32768).
+ *         key 10 = fork point in dual-attention blocks: 1 (default) after the block's last attention, 0 right after the joint attention.
+ *         Results are bit-identical for every value.
  * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);

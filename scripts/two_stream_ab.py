@@ -41,6 +41,10 @@ adapter.rollout()
 # (batch, size, guidance, denoise steps, timed rollouts): the reference's example shapes (512^2, N = 10) and the bench shape at B = 1..8
 SHAPES = [(2, 512, 4.5, 10, 6), (8, 512, 1.0, 10, 6), (8, 512, 4.5, 10, 4), (1, 1024, 1.0, 28, 3), (2, 1024, 1.0, 28, 3), (4, 1024, 1.0, 28, 2),
           (8, 1024, 1.0, 28, 2)]
+if os.environ.get("AB_SHAPES"):          # e.g. AB_SHAPES="2x512x4.5x10x6,8x1024x1x28x2"
+    SHAPES = [tuple(float(v) if i == 2 else int(v) for i, v in enumerate(t.split("x"))) for t in os.environ["AB_SHAPES"].split(",")]
+# mode 1 = fork right after the joint attention, mode 2 = fork after the block's last attention (key 10 = 1, the default)
+MODES = (0, 1, 2)
 rows_out = []
 log = open(os.path.join(args.out, "two_stream_ab.txt"), "w")
 
@@ -51,8 +55,9 @@ def say(s):
     log.flush()
 
 
-say("# two-stream forward A/B (scripts/two_stream_ab.py): ms per rollout, graph replay / eager; mode 0 = single stream, 1 = text chain on a side stream")
-say("# B  size  cfg  N   image rows   graph0    graph1   gain%   eager0    eager1   gain%   denoise-steps/s (best of graph0 / graph1)")
+say("# two-stream forward A/B (scripts/two_stream_ab.py): ms per rollout (hipGraph replay); single = one stream, early = text chain on a side stream forked "
+    "after the joint attention, late = forked after the block's last attention (shipped)")
+say("# B  size  cfg  N   image rows    single     early      late   early%    late%   denoise-steps/s (single -> late)")
 for (B, size, gs, N, iters) in SHAPES:
     if args.quick:
         iters = max(1, iters // 2)
@@ -74,17 +79,17 @@ for (B, size, gs, N, iters) in SHAPES:
 
     res, ref = {}, None
     for graph in ((1, 0) if args.eager else (1,)):
-        for mode in (0, 1):
+        for mode in MODES:
             lib.mi355_tune_set(2, graph)
-            lib.mi355_tune_set(8, mode)
+            lib.mi355_tune_set(8, 1 if mode else 0)
+            lib.mi355_tune_set(10, 1 if mode == 2 else 0)
             s = one(seed=99)                      # eager warm-up (first call of a plan) or (re)capture
             s = one(seed=99)
             torch.cuda.synchronize()
-            sig = torch.stack([x.all_latents.float().sum() for x in s] + [x.log_probs.float().nan_to_num().sum() for x in s])
             if ref is None:
-                ref = (s, sig)
+                ref = s
             else:
-                for a, b in zip(s, ref[0]):
+                for a, b in zip(s, ref):
                     assert torch.equal(a.all_latents, b.all_latents), ("two-stream / graph changed the trajectory", B, size, graph, mode)
                     assert torch.equal(a.log_probs.nan_to_num(), b.log_probs.nan_to_num()), ("log-probs differ", B, size, graph, mode)
             t0 = time.perf_counter()
@@ -94,14 +99,11 @@ for (B, size, gs, N, iters) in SHAPES:
             res[(graph, mode)] = (time.perf_counter() - t0) / iters * 1e3
     n_cfg = 2 if cfg_on else 1
     Mi = B * n_cfg * (size // 16) ** 2
-    if not args.eager:
-        res[(0, 0)] = res[(0, 1)] = float("nan")
-    gg = (res[(1, 0)] / res[(1, 1)] - 1) * 100
-    ge = (res[(0, 0)] / res[(0, 1)] - 1) * 100
-    best = B * N / (min(res[(1, 0)], res[(1, 1)]) * 1e-3)
-    say(f"{B:3d} {size:5d} {gs:4.1f} {N:3d} {Mi:10d} {res[(1, 0)]:9.2f} {res[(1, 1)]:9.2f} {gg:+7.2f} {res[(0, 0)]:9.2f} {res[(0, 1)]:9.2f} {ge:+7.2f}   {best:8.2f}")
-    rows_out.append(dict(batch=B, size=size, guidance=gs, denoise_steps=N, image_rows=Mi, graph_ms=[res[(1, 0)], res[(1, 1)]],
-                         eager_ms=[res[(0, 0)], res[(0, 1)]], graph_gain_pct=gg, eager_gain_pct=ge))
+    g0, g1, g2 = res[(1, 0)], res[(1, 1)], res[(1, 2)]
+    ge, gl = (g0 / g1 - 1) * 100, (g0 / g2 - 1) * 100
+    say(f"{B:3d} {size:5d} {gs:4.1f} {N:3d} {Mi:10d} {g0:9.2f} {g1:9.2f} {g2:9.2f} {ge:+8.2f} {gl:+8.2f}   {B * N / g0 * 1e3:8.2f} -> {B * N / g2 * 1e3:8.2f}")
+    rows_out.append(dict(batch=B, size=size, guidance=gs, denoise_steps=N, image_rows=Mi, single_ms=g0, early_fork_ms=g1, late_fork_ms=g2,
+                         graph_gain_pct=gl, early_gain_pct=ge, eager_ms={str(k[1]): v for k, v in res.items() if k[0] == 0}))
 
 # recommendation: the largest row count R such that every measured shape with image_rows <= R gains >= 0.5 % in graph mode
 rows_out.sort(key=lambda r: r["image_rows"])
@@ -109,12 +111,13 @@ rec = 0
 for r in rows_out:
     if r["graph_gain_pct"] >= 0.5 and all(q["graph_gain_pct"] >= 0.5 for q in rows_out if q["image_rows"] <= r["image_rows"]):
         rec = r["image_rows"]
-tune = f"8=2,9={rec}" if rec > 0 else ""
+tune = f"8=2,9={rec},10=1" if rec > 0 else ""
 say(f"# recommendation: auto mode up to {rec} image rows  ->  MI355_TUNE=\"{tune}\"")
 with open(os.path.join(args.out, "two_stream_ab.json"), "w") as f:
     json.dump(dict(shapes=rows_out, recommended_rows=rec, tune=tune), f, indent=1)
 with open(os.path.join(args.out, "tune.env"), "w") as f:
     f.write(tune)
 lib.mi355_tune_set(8, 0)
+lib.mi355_tune_set(10, 1)
 lib.mi355_tune_set(2, 1)
 log.close()

@@ -229,7 +229,8 @@ def test_matching_loss_forward_without_a_stored_transition(gpu, guidance):
             # a key bias shifts every score of a query equally: its gradient is zero up to rounding (softmax shift invariance);
             # judge the error against the scale of the matching weight gradient instead of its own near-zero norm
             wref = g_ref[name[:-4] + "weight"]
-            assert float((prm.grad.float().cpu() - ref).norm()) <= 5e-2 * max(float(ref.norm()), 1e-2 * float(wref.norm())), name
+            err = float((prm.grad.float().cpu() - ref).norm())
+            assert err <= max(1.5e-1 * float(ref.norm()), 2e-3 * float(wref.norm())), (name, err, float(ref.norm()), float(wref.norm()))
             continue
         r = _rel(prm.grad, ref)
         worst, n = max(worst, r), n + 1

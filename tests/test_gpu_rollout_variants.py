@@ -119,13 +119,16 @@ def test_two_stream_forward_is_bit_identical(ctx, n_cfg):
         base = plan.rollout(*args)
         torch.cuda.synchronize()
         lib.mi355_tune_set(8, 1)
-        for rep in range(3):                                   # eager, two streams
-            out = plan.rollout(*args)
-            assert all(_same(a, b) for a, b in zip(out, base)), ("eager", rep)
-        lib.mi355_tune_set(2, 1)
-        for rep in range(4):                                   # (re)captured with fork / join edges, then replayed
-            out = plan.rollout(*args)
-            assert all(_same(a, b) for a, b in zip(out, base)), ("graph", rep)
+        for late in (0, 1):                                        # key 10: fork after the joint attention / after the block's last attention
+            lib.mi355_tune_set(10, late)
+            lib.mi355_tune_set(2, 0)
+            for rep in range(3):                                   # eager, two streams
+                out = plan.rollout(*args)
+                assert all(_same(a, b) for a, b in zip(out, base)), ("eager", late, rep)
+            lib.mi355_tune_set(2, 1)
+            for rep in range(4):                                   # (re)captured with fork / join edges, then replayed
+                out = plan.rollout(*args)
+                assert all(_same(a, b) for a, b in zip(out, base)), ("graph", late, rep)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                          # caller on a non-default stream
@@ -153,8 +156,9 @@ def test_two_stream_forward_is_bit_identical(ctx, n_cfg):
         o1 = plan.denoise_step(*step_args, float(sig[0]), float(sig[1]), 0.7, float(sig[1]), "Flow-SDE", **kw)
         assert torch.equal(o1.noise_pred, o2.noise_pred) and torch.equal(o1.log_prob, o2.log_prob)
     finally:
-        lib.mi355_tune_set(8, 0)
-        lib.mi355_tune_set(9, 8192)
+        lib.mi355_tune_set(8, 2)                                   # the shipped defaults
+        lib.mi355_tune_set(9, 32768)
+        lib.mi355_tune_set(10, 1)
         lib.mi355_tune_set(2, 1)
 
 
