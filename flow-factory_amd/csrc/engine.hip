@@ -594,7 +594,13 @@ static int gate_res(mi355_plan* p, hipStream_t st, const bf16_t* A, int K, const
 // the reference's 512^2 examples +6 ... +22 %: profiles/r02b_two_stream_ab.txt).
 static int g_two_stream = 2;
 static int g_two_stream_rows = 32768;
-static int g_two_stream_late_fork = 1;     // key 10: fork after the block's last attention (1) or right after the joint attention (0)
+// key 10: fork point in dual-attention blocks: 0 = right after the joint attention (the text chain also runs beside the dual attention:
+// ~1 % more at small batches), 1 = after the block's last attention (at B' = 8, 1024^2 the dual attention fills every CU and text GEMMs
+// squeezed in beside it only stretch it: 840 -> 900 us per launch), 2 (default) = 1 for plans with more than 16 384 image rows, else 0
+static int g_two_stream_late_fork = 2;
+static bool late_fork_wanted(const mi355_plan* p) {
+    return g_two_stream_late_fork == 1 || (g_two_stream_late_fork == 2 && p->Mi > 16384);
+}
 static bool two_stream_wanted(const mi355_plan* p) {
     return g_two_stream == 1 || (g_two_stream == 2 && p->Mi <= g_two_stream_rows);
 }
@@ -672,7 +678,7 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
             text_open = true;
             return 0;
         };
-        const bool late = b.dual && g_two_stream_late_fork;
+        const bool late = b.dual && late_fork_wanted(p);
         if (fork_here && !late) CHK(fork());
         CHK(gate_res(p, st, p->o_img, D, b.w_o, b.b_o, p->x, Mi, Ni, mod, mi + 2 * D));
         if (!two && !b.last) CHK(gate_res(p, st, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
@@ -858,7 +864,7 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
         const bool same = p->gexec && p->g_steps == n_steps && p->g_dyn == dynamics && p->g_storage == storage_dtype &&
                           p->g_init == init_dtype && p->g_clp == clp && p->g_guidance == guidance && p->g_sigma_max == sigma_max &&
                           p->g_attn == get_attn_variant() && p->g_gemm == get_gemm_variant() &&
-                          p->g_bounds == p->e->bounds_ver * 2 + (g_attn_static != 0) && p->g_two == (int)two_stream_wanted(p) * (1 + g_two_stream_late_fork);
+                          p->g_bounds == p->e->bounds_ver * 2 + (g_attn_static != 0) && p->g_two == (int)two_stream_wanted(p) * (1 + (int)late_fork_wanted(p));
         if (!same) {
             if (two_stream_wanted(p)) CHK(two_stream_init(p));   // streams / events are created outside the capture
             if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
@@ -884,7 +890,7 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
                 p->g_steps = n_steps; p->g_dyn = dynamics; p->g_storage = storage_dtype; p->g_init = init_dtype; p->g_clp = clp;
                 p->g_guidance = guidance; p->g_sigma_max = sigma_max; p->g_attn = get_attn_variant(); p->g_gemm = get_gemm_variant();
                 p->g_bounds = p->e->bounds_ver * 2 + (g_attn_static != 0);
-                p->g_two = (int)two_stream_wanted(p) * (1 + g_two_stream_late_fork);
+                p->g_two = (int)two_stream_wanted(p) * (1 + (int)late_fork_wanted(p));
             } else {
                 // no silent fallback (header convention, reference constraints.md:144-145): the caller decides whether to
                 // retry with eager launches (mi355_tune_set(2, 0))

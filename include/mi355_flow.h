@@ -380,7 +380,8 @@ int mi355_profile_enable(int on);
  * key 8 = SD3.5 forward: the text-stream chain of every block (out-projection, LN-modulate, MLP, next q|k / V^T projections) on a
  *         plan-owned second stream, forked after each joint attention and joined before the next (graph edges inside the captured
  *         rollout): 0 = single stream, 1 = always, 2 (default) = when the image stream has at most <key 9> rows (default 32768).
- *         key 10 = fork point in dual-attention blocks: 1 (default) after the block's last attention, 0 right after the joint attention.
+ *         key 10 = fork point in dual-attention blocks: 1 after the block's last attention, 0 right after the joint attention, 2 (default)
+ *         = 1 for plans with more than 16384 image rows, else 0.
  *         Results are bit-identical for every value.
  * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
 int mi355_tune_set(int key, int value);

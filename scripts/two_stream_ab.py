@@ -118,6 +118,6 @@ with open(os.path.join(args.out, "two_stream_ab.json"), "w") as f:
 with open(os.path.join(args.out, "tune.env"), "w") as f:
     f.write(tune)
 lib.mi355_tune_set(8, 0)
-lib.mi355_tune_set(10, 1)
+lib.mi355_tune_set(10, 2)
 lib.mi355_tune_set(2, 1)
 log.close()

@@ -158,7 +158,7 @@ def test_two_stream_forward_is_bit_identical(ctx, n_cfg):
     finally:
         lib.mi355_tune_set(8, 2)                                   # the shipped defaults
         lib.mi355_tune_set(9, 32768)
-        lib.mi355_tune_set(10, 1)
+        lib.mi355_tune_set(10, 2)
         lib.mi355_tune_set(2, 1)
 
 
