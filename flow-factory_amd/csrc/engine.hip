@@ -356,7 +356,8 @@ struct mi355_plan {
     bool warmed = false;
     int g_steps = -1, g_dyn = -1, g_storage = -1, g_init = -1, g_clp = -1, g_attn = -1, g_gemm = -1, g_bounds = -1, g_two = -1;
     // text-stream chain of a forward on a second stream (forward_core): plan-owned, created on first use
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr, side_v = nullptr;   // side_v: the image stream's V^T (and dual-attention q|k / V^T) projections
+    std::vector<hipEvent_t> ev_vfork, ev_vjoin, ev_djoin;   // per block: xn ready (main -> side_v), V^T ready, dual q|k|V^T ready (side_v -> main)
     std::vector<hipEvent_t> ev_join, ev_fork;   // per block: text q|k|v ready (side -> main), attention done (main -> side); [L] = forward start
     float g_guidance = 0.f, g_sigma_max = 0.f;
 };
@@ -444,7 +445,11 @@ extern "C" int mi355_plan_destroy(mi355_plan* p) {
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     for (hipEvent_t ev : p->ev_join) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : p->ev_fork) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : p->ev_vfork) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : p->ev_vjoin) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : p->ev_djoin) (void)hipEventDestroy(ev);
     if (p->side) (void)hipStreamDestroy(p->side);
+    if (p->side_v) (void)hipStreamDestroy(p->side_v);
     if (p->ws) (void)hipFree(p->ws);
     delete p;
     return 0;
@@ -559,7 +564,9 @@ static int ln_mod(mi355_plan* p, hipStream_t st, const bf16_t* x, bf16_t* out, b
 // q/k projection with fused bias + per-head RMSNorm + scatter, and V^T projection (operands swapped)
 static int qkv_proj(mi355_plan* p, hipStream_t st, const bf16_t* xin, int M, int rps, const bf16_t* w_qk,
                     const float* b_qk, const bf16_t* w_v, const float* b_v, const float* nq, const float* nk,
-                    bf16_t* q, bf16_t* k, bf16_t* vT, int S_pad, int s_off) {
+                    bf16_t* q, bf16_t* k, bf16_t* vT, int S_pad, int s_off, hipStream_t st_v = nullptr, bool v_only = false,
+                    bool qk_only = false) {
+    if (!st_v) st_v = st;                 // the V^T GEMM reads the same input as the q|k GEMM and may run beside it
     mi355_engine* e = p->e;
     const int D = e->D;
     GemmParams g = gp(xin, D, w_qk, D, M, 2 * D, D, EPI_QK_NORM, b_qk, nullptr, 0);
@@ -567,10 +574,10 @@ static int qkv_proj(mi355_plan* p, hipStream_t st, const bf16_t* xin, int M, int
     g.rows_per_sample = rps; g.eps = e->cfg.eps;
     // deferred-rescale attention consumes q with the softmax scale 0.125*log2(e) folded in (same single bf16 rounding)
     if (get_attn_variant() >= 1) g.q_scale = 0.125f * 1.4426950408889634f;
-    HIPCHK(gemm_p(g, st));
+    if (!v_only) HIPCHK(gemm_p(g, st));
     GemmParams gv = gp(w_v, D, xin, D, D, M, D, EPI_VT, b_v, nullptr, 0);
     gv.q = vT; gv.H = e->cfg.num_heads; gv.S_pad = S_pad; gv.s_off = s_off; gv.rows_per_sample = rps;
-    HIPCHK(gemm_p(gv, st));
+    if (!qk_only) HIPCHK(gemm_p(gv, st_v));
     return 0;
 }
 
@@ -601,6 +608,16 @@ static int g_two_stream_late_fork = 2;
 static bool late_fork_wanted(const mi355_plan* p) {
     return g_two_stream_late_fork == 1 || (g_two_stream_late_fork == 2 && p->Mi > 16384);
 }
+// key 11: a THIRD stream for the image stream's V^T projection (same input as the q|k projection) and, in dual-attention blocks, the
+// dual attention's q|k / V^T projections hoisted from behind the joint attention to beside it (xn2 comes out of the same LN-modulate
+// launch).  Small grids only: at S = 1357 (512^2) the joint attention's grid is 576 workgroups on 512 slots -- its second round leaves
+// 7/8 of the chip idle -- and a 128x128-tile GEMM at M = 4096 fills 0.75 or 1.5 rounds.  0 = off, 1 = on whenever two streams are,
+// 2 = on for plans with at most 16 384 image rows (beside a chip-filling attention the extra GEMMs only stretch it).
+static int g_three_stream = 0;
+static bool two_stream_wanted(const mi355_plan* p);
+static bool three_stream_wanted(const mi355_plan* p) {
+    return two_stream_wanted(p) && (g_three_stream == 1 || (g_three_stream == 2 && p->Mi <= 16384));
+}
 static bool two_stream_wanted(const mi355_plan* p) {
     return g_two_stream == 1 || (g_two_stream == 2 && p->Mi <= g_two_stream_rows);
 }
@@ -614,6 +631,16 @@ static int two_stream_init(mi355_plan* p) {
         p->ev_join.push_back(a);
         HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
         p->ev_fork.push_back(b);
+    }
+    HIPCHK(hipStreamCreateWithFlags(&p->side_v, hipStreamNonBlocking));
+    for (size_t i = 0; i < n; ++i) {
+        hipEvent_t a, b, c;
+        HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        p->ev_vfork.push_back(a);
+        HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        p->ev_vjoin.push_back(b);
+        HIPCHK(hipEventCreateWithFlags(&c, hipEventDisableTiming));
+        p->ev_djoin.push_back(c);
     }
     return 0;
 }
@@ -645,6 +672,8 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
         HIPCHK(hipEventRecord(p->ev_fork[e->L], st));           // c, the conditioning and the previous forward are complete on `st`
         HIPCHK(hipStreamWaitEvent(ts, p->ev_fork[e->L], 0));
     }
+    const bool three = two && three_stream_wanted(p);
+    hipStream_t vs = three ? p->side_v : st;
     bool text_open = false;      // the side stream holds work that `st` has not waited for yet
     for (int i = 0; i < e->L; ++i) {
         const BlockW& b = e->blk[i];
@@ -656,8 +685,20 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
         else
             CHK(ln_mod(p, ts, p->c, p->cn, nullptr, mod, Mc, Nt, mc + 0 * D, mc + 1 * D, 0, 0));
         // joint attention: image tokens first, then text
-        CHK(qkv_proj(p, st, p->xn, Mi, Ni, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk, p->q, p->k, p->vT, p->S_pad, 0));
+        if (three) {             // xn / xn2 are complete on `st`; the previous block's attentions (readers of q2 / k2 / vT2) are behind them
+            HIPCHK(hipEventRecord(p->ev_vfork[i], st));
+            HIPCHK(hipStreamWaitEvent(vs, p->ev_vfork[i], 0));
+        }
+        CHK(qkv_proj(p, st, p->xn, Mi, Ni, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk, p->q, p->k, p->vT, p->S_pad, 0, vs));
         CHK(qkv_proj(p, ts, p->cn, Mc, Nt, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck, p->q, p->k, p->vT, p->S_pad, Ni));
+        if (three) {
+            HIPCHK(hipEventRecord(p->ev_vjoin[i], vs));
+            HIPCHK(hipStreamWaitEvent(st, p->ev_vjoin[i], 0));
+            if (b.dual) {        // the dual attention's projections: beside the joint attention instead of behind it
+                CHK(qkv_proj(p, vs, p->xn2, Mi, Ni, b.w_qk2, b.b_qk2, b.w_v2, b.b_v2, b.nq2, b.nk2, p->q2, p->k2, p->vT2, Ni_pad, 0));
+                HIPCHK(hipEventRecord(p->ev_djoin[i], vs));
+            }
+        }
         if (two) {               // join: the attention reads the text rows of q / k / vT and overwrites o_ctx
             HIPCHK(hipEventRecord(p->ev_join[i], ts));
             HIPCHK(hipStreamWaitEvent(st, p->ev_join[i], 0));
@@ -683,7 +724,8 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
         CHK(gate_res(p, st, p->o_img, D, b.w_o, b.b_o, p->x, Mi, Ni, mod, mi + 2 * D));
         if (!two && !b.last) CHK(gate_res(p, st, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
         if (b.dual) {
-            CHK(qkv_proj(p, st, p->xn2, Mi, Ni, b.w_qk2, b.b_qk2, b.w_v2, b.b_v2, b.nq2, b.nk2, p->q2, p->k2, p->vT2, Ni_pad, 0));
+            if (three) HIPCHK(hipStreamWaitEvent(st, p->ev_djoin[i], 0));
+            else CHK(qkv_proj(p, st, p->xn2, Mi, Ni, b.w_qk2, b.b_qk2, b.w_v2, b.b_v2, b.nq2, b.nk2, p->q2, p->k2, p->vT2, Ni_pad, 0));
             // S == n_img: this launch writes o_img only, never o_ctx (which the text chain reads after the fork)
             AttnParams a{p->q2, p->k2, p->vT2, p->o_img, p->o_ctx, p->Bp, H, Ni, Ni_pad, Ni, get_attn_variant() >= 1,
                          g_attn_static ? b.bound_dual : 0.f};
@@ -864,7 +906,7 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
         const bool same = p->gexec && p->g_steps == n_steps && p->g_dyn == dynamics && p->g_storage == storage_dtype &&
                           p->g_init == init_dtype && p->g_clp == clp && p->g_guidance == guidance && p->g_sigma_max == sigma_max &&
                           p->g_attn == get_attn_variant() && p->g_gemm == get_gemm_variant() &&
-                          p->g_bounds == p->e->bounds_ver * 2 + (g_attn_static != 0) && p->g_two == (int)two_stream_wanted(p) * (1 + (int)late_fork_wanted(p));
+                          p->g_bounds == p->e->bounds_ver * 2 + (g_attn_static != 0) && p->g_two == (int)two_stream_wanted(p) * (1 + (int)late_fork_wanted(p) + 2 * (int)three_stream_wanted(p));
         if (!same) {
             if (two_stream_wanted(p)) CHK(two_stream_init(p));   // streams / events are created outside the capture
             if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
@@ -890,7 +932,7 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
                 p->g_steps = n_steps; p->g_dyn = dynamics; p->g_storage = storage_dtype; p->g_init = init_dtype; p->g_clp = clp;
                 p->g_guidance = guidance; p->g_sigma_max = sigma_max; p->g_attn = get_attn_variant(); p->g_gemm = get_gemm_variant();
                 p->g_bounds = p->e->bounds_ver * 2 + (g_attn_static != 0);
-                p->g_two = (int)two_stream_wanted(p) * (1 + (int)late_fork_wanted(p));
+                p->g_two = (int)two_stream_wanted(p) * (1 + (int)late_fork_wanted(p) + 2 * (int)three_stream_wanted(p));
             } else {
                 // no silent fallback (header convention, reference constraints.md:144-145): the caller decides whether to
                 // retry with eager launches (mi355_tune_set(2, 0))
@@ -939,6 +981,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 8) { g_two_stream = value; return 0; }          // text-stream chain on a side stream: 0 off, 1 on, 2 auto (rows <= key 9)
     if (key == 9) { g_two_stream_rows = value; return 0; }
     if (key == 10) { g_two_stream_late_fork = value; return 0; }
+    if (key == 11) { g_three_stream = value; return 0; }
     return fail("mi355_tune_set: unknown key %d", key);
 }
 

@@ -43,8 +43,10 @@ SHAPES = [(2, 512, 4.5, 10, 6), (8, 512, 1.0, 10, 6), (8, 512, 4.5, 10, 4), (1, 
           (8, 1024, 1.0, 28, 2)]
 if os.environ.get("AB_SHAPES"):          # e.g. AB_SHAPES="2x512x4.5x10x6,8x1024x1x28x2"
     SHAPES = [tuple(float(v) if i == 2 else int(v) for i, v in enumerate(t.split("x"))) for t in os.environ["AB_SHAPES"].split(",")]
-# mode 1 = fork right after the joint attention, mode 2 = fork after the block's last attention (key 10 = 1, the default)
-MODES = (0, 1, 2)
+# mode 0 = one stream; 1 = text chain on a side stream, forked right after the joint attention; 2 = forked after the block's last attention
+# (key 10 = 1); 3 = mode 1 + a third stream for the image V^T / dual-attention projections (key 11 = 1)
+MODES = tuple(int(m) for m in os.environ.get("AB_MODES", "0,1,2").split(","))
+NAMES = {0: "single", 1: "early", 2: "late", 3: "three"}
 rows_out = []
 log = open(os.path.join(args.out, "two_stream_ab.txt"), "w")
 
@@ -57,7 +59,8 @@ def say(s):
 
 say("# two-stream forward A/B (scripts/two_stream_ab.py): ms per rollout (hipGraph replay); single = one stream, early = text chain on a side stream forked "
     "after the joint attention, late = forked after the block's last attention (shipped)")
-say("# B  size  cfg  N   image rows    single     early      late   early%    late%   denoise-steps/s (single -> late)")
+say("# B  size  cfg  N   image rows " + "".join(f"{NAMES[m]:>10s}" for m in MODES) + "  " + "".join(f"{NAMES[m] + '%':>8s}" for m in MODES if m) +
+    "   denoise-steps/s (single -> best)")
 for (B, size, gs, N, iters) in SHAPES:
     if args.quick:
         iters = max(1, iters // 2)
@@ -83,6 +86,7 @@ for (B, size, gs, N, iters) in SHAPES:
             lib.mi355_tune_set(2, graph)
             lib.mi355_tune_set(8, 1 if mode else 0)
             lib.mi355_tune_set(10, 1 if mode == 2 else 0)
+            lib.mi355_tune_set(11, 1 if mode == 3 else 0)
             s = one(seed=99)                      # eager warm-up (first call of a plan) or (re)capture
             s = one(seed=99)
             torch.cuda.synchronize()
@@ -99,11 +103,13 @@ for (B, size, gs, N, iters) in SHAPES:
             res[(graph, mode)] = (time.perf_counter() - t0) / iters * 1e3
     n_cfg = 2 if cfg_on else 1
     Mi = B * n_cfg * (size // 16) ** 2
-    g0, g1, g2 = res[(1, 0)], res[(1, 1)], res[(1, 2)]
-    ge, gl = (g0 / g1 - 1) * 100, (g0 / g2 - 1) * 100
-    say(f"{B:3d} {size:5d} {gs:4.1f} {N:3d} {Mi:10d} {g0:9.2f} {g1:9.2f} {g2:9.2f} {ge:+8.2f} {gl:+8.2f}   {B * N / g0 * 1e3:8.2f} -> {B * N / g2 * 1e3:8.2f}")
-    rows_out.append(dict(batch=B, size=size, guidance=gs, denoise_steps=N, image_rows=Mi, single_ms=g0, early_fork_ms=g1, late_fork_ms=g2,
-                         graph_gain_pct=gl, early_gain_pct=ge, eager_ms={str(k[1]): v for k, v in res.items() if k[0] == 0}))
+    g0 = res[(1, 0)]
+    cols = "".join(f" {res[(1, m)]:9.2f}" for m in MODES) + "  " + "".join(f" {(g0 / res[(1, m)] - 1) * 100:+7.2f}" for m in MODES if m)
+    best = min(MODES, key=lambda m: res[(1, m)])
+    say(f"{B:3d} {size:5d} {gs:4.1f} {N:3d} {Mi:10d}{cols}   {B * N / g0 * 1e3:8.2f} -> {B * N / res[(1, best)] * 1e3:8.2f} ({NAMES[best]})")
+    rows_out.append(dict(batch=B, size=size, guidance=gs, denoise_steps=N, image_rows=Mi, ms={NAMES[m]: res[(1, m)] for m in MODES},
+                         graph_gain_pct=(g0 / min(res[(1, m)] for m in MODES if m) - 1) * 100,
+                         eager_ms={NAMES[k[1]]: v for k, v in res.items() if k[0] == 0}))
 
 # recommendation: the largest row count R such that every measured shape with image_rows <= R gains >= 0.5 % in graph mode
 rows_out.sort(key=lambda r: r["image_rows"])
@@ -119,5 +125,6 @@ with open(os.path.join(args.out, "tune.env"), "w") as f:
     f.write(tune)
 lib.mi355_tune_set(8, 0)
 lib.mi355_tune_set(10, 2)
+lib.mi355_tune_set(11, 0)
 lib.mi355_tune_set(2, 1)
 log.close()

@@ -119,16 +119,19 @@ def test_two_stream_forward_is_bit_identical(ctx, n_cfg):
         base = plan.rollout(*args)
         torch.cuda.synchronize()
         lib.mi355_tune_set(8, 1)
-        for late in (0, 1):                                        # key 10: fork after the joint attention / after the block's last attention
+        # key 10: fork after the joint attention (0) / after the block's last attention (1); key 11: third stream for the image V^T and
+        # the dual attention's projections
+        for late, third in ((0, 0), (1, 0), (0, 1), (1, 1)):
             lib.mi355_tune_set(10, late)
+            lib.mi355_tune_set(11, third)
             lib.mi355_tune_set(2, 0)
             for rep in range(3):                                   # eager, two streams
                 out = plan.rollout(*args)
-                assert all(_same(a, b) for a, b in zip(out, base)), ("eager", late, rep)
+                assert all(_same(a, b) for a, b in zip(out, base)), ("eager", late, third, rep)
             lib.mi355_tune_set(2, 1)
             for rep in range(4):                                   # (re)captured with fork / join edges, then replayed
                 out = plan.rollout(*args)
-                assert all(_same(a, b) for a, b in zip(out, base)), ("graph", late, rep)
+                assert all(_same(a, b) for a, b in zip(out, base)), ("graph", late, third, rep)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                          # caller on a non-default stream
@@ -159,6 +162,7 @@ def test_two_stream_forward_is_bit_identical(ctx, n_cfg):
         lib.mi355_tune_set(8, 2)                                   # the shipped defaults
         lib.mi355_tune_set(9, 32768)
         lib.mi355_tune_set(10, 2)
+        lib.mi355_tune_set(11, 0)
         lib.mi355_tune_set(2, 1)
 
 
