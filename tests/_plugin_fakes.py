@@ -329,3 +329,129 @@ def make_qwen_pipeline(tcfg, transformer: nn.Module):
     pipe.maybe_free_model_hooks = lambda: None
     pipe.components = {"transformer": transformer, "vae": vae, "text_encoder": pipe.text_encoder}
     return pipe
+
+
+# --------------------------------------------------------------------------------------- differentiable engine double
+class DiffFakePlan(FakePlan):
+    """FakePlan whose log-prob is one fixed function of (timestep, sample index, the weights bound NOW) in the rollout, the no-grad step and
+    the training step alike -- so `ratio == 1` holds before an update and moves after one -- with the native training-step API of
+    mi355_flow.engine.Plan (`denoise_step_train` / `denoise_step_backward`) that mi355_flow.autograd drives."""
+
+    C_W = 50.0          # large enough that an SGD step on the (1 / numel)-sized gradients survives fp32 rounding
+
+    def _lp(self, t, latents):
+        # a function of the timestep, the sample's OWN current latents and the weights bound now (no dependence on the position inside
+        # the micro-batch: optimize() shuffles the samples into other micro-batches)
+        B = latents.shape[0]
+        t = torch.as_tensor(t, dtype=torch.float32).reshape(-1)
+        t = t.expand(B) if t.numel() == 1 else t[:B]
+        m = latents.float().reshape(B, -1).mean(1)
+        return (-1.0 - 1e-4 * t + self.C_W * self.engine.weight_signal() * (1.0 + m)).float()
+
+    def rollout(self, timesteps, sigmas, noise_levels, dynamics, guidance, init_latents, storage_dtype, step_noise, prompt_embeds, pooled,
+                neg_embeds=None, neg_pooled=None, keep_positions=None, compute_log_prob=True):
+        lat, lp, fin = super().rollout(timesteps, sigmas, noise_levels, dynamics, guidance, init_latents, storage_dtype, step_noise,
+                                       prompt_embeds, pooled, neg_embeds, neg_pooled, keep_positions, compute_log_prob)
+        N = len(timesteps)
+        keep = list(range(N + 1)) if keep_positions is None else sorted(set(keep_positions))
+        for i, e in enumerate(noise_levels):
+            if e > 0 and compute_log_prob:
+                lp[i] = self._lp(timesteps[i], lat[keep.index(i)])
+        return lat, lp, fin
+
+    def denoise_step(self, latents, timestep, *a, **k):
+        o = super().denoise_step(latents, timestep, *a, **k)
+        if o.log_prob is not None:
+            o.log_prob = self._lp(timestep, latents)
+        if o.noise_pred is not None:
+            o.noise_pred = latents.float() * (1.0 + self.engine.weight_signal())
+        return o
+
+    def denoise_step_train(self, latents, timestep, enc_a, pooled_a, enc_b, pooled_b, guidance, sigma, sigma_next, eta, sigma_max, dynamics,
+                           next_latents, compute_log_prob=True, _keep=None):
+        B = latents.shape[0]
+        self.engine.calls.append(("denoise_step_train", dict(weights=self.engine.fingerprint(), eta=eta, clp=bool(compute_log_prob))))
+        o = types.SimpleNamespace()
+        o.log_prob = self._lp(timestep, latents)
+        o.noise_pred = latents.float() * (1.0 + self.engine.weight_signal())
+        o.next_latents_mean = latents.float().clone()
+        o.std_dev_t, o.dt = torch.full((B,), 0.5), torch.full((B,), -0.1)
+        if _keep is not None:
+            _keep.update(latents=latents, B=B)
+        return o
+
+    def denoise_step_backward(self, call, g_log_prob, g_noise_pred, g_mean):
+        # d lp_b / d w = C_W / numel(w) for every element of every signal tensor; d noise_pred / d w = latents / numel(w)
+        eng, lat = self.engine, call["_keep"]["latents"].float()
+        self.engine.calls.append(("denoise_step_backward", dict(has_lp=g_log_prob is not None, has_np=g_noise_pred is not None)))
+        up = 0.0
+        if g_log_prob is not None:
+            up += self.C_W * float((g_log_prob.float() * (1.0 + lat.reshape(lat.shape[0], -1).mean(1))).sum())
+        if g_noise_pred is not None:
+            up += float((g_noise_pred.float() * lat).sum())
+        for name, buf in eng.grad_bufs.items():
+            if name in eng.signal_names():
+                buf += up / (buf.numel() * len(eng.signal_names()))
+
+
+class DiffFakeEngine(FakeEngine):
+    """FakeEngine + the gradient-registration surface of mi355_flow.engine.Engine.  `weight_signal()` = mean over the attention-projection
+    weights of block 0 of what is bound now (they are in the reference's default `target_modules`, so an optimizer step moves it)."""
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.grad_bufs: Dict[str, torch.Tensor] = {}
+        self.scope_full = None
+
+    def signal_names(self):
+        return [n for n in self._names if n.startswith("transformer_blocks.0.attn.to_") and n.endswith(".weight")]
+
+    def weight_signal(self) -> float:
+        names = self.signal_names()
+        return float(sum(float(self.bound[n].double().mean()) for n in names) / len(names))
+
+    def plan(self, batch, n_cfg, h, w, n_text, max_steps):
+        key = (batch, n_cfg, h, w, n_text)
+        p = self._plans.get(key)
+        if p is None or p.max_steps < max_steps:
+            p = self._plans[key] = DiffFakePlan(self, key, max_steps)
+        return p
+
+    def grad_supported(self, name) -> int:
+        return 1 if name in self._names else 0
+
+    def set_train_scope(self, full) -> None:
+        self.scope_full = bool(full)
+
+    def set_grad(self, name, t) -> None:
+        assert name in self._names and t.dtype == torch.float32
+        self.grad_bufs[name] = t
+
+    def clear_grads(self) -> None:
+        self.grad_bufs = {}
+
+
+class TrainerAccelerator(FakeAccelerator):
+    """Single-process stand-in for what the reference's trainers / AdvantageProcessor / reduce_loss_info ask of `accelerate.Accelerator`."""
+
+    mixed_precision = "bf16"
+    is_local_main_process = True
+
+    def accumulate(self, *models):
+        from contextlib import nullcontext
+        return nullcontext()
+
+    def backward(self, loss):
+        loss.backward()
+
+    def clip_grad_norm_(self, params, max_norm):
+        return torch.nn.utils.clip_grad_norm_(list(params), max_norm)
+
+    def gather(self, t):
+        return t
+
+    def reduce(self, t, reduction="mean"):
+        return t
+
+    def wait_for_everyone(self):
+        pass

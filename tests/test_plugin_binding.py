@@ -443,3 +443,153 @@ def test_sd3_grad_fallback_is_engine_valued(ref):
     finally:
         AG.unsupported_reason = real_reason
         del tr.forward
+
+
+# ------------------------------------------------------------------------------------------------- the reference's trainer drives the plugin
+@pytest.mark.parametrize("guard", [False, True], ids=["GRPOTrainer", "GRPOGuardTrainer"])
+def test_reference_grpo_trainer_runs_an_epoch_through_the_plugin(ref, guard):
+    """the reference's OWN `GRPOTrainer.sample()` and `.optimize()` (trainers/grpo.py:141-173, :185-342), unmodified,
+    drive the plugin adapter for one epoch: kwargs built as `{**training_args, ..., **batch}` and filtered by signature, rollouts through
+    `inference()`, the reference's `AdvantageProcessor`, `BaseSample.stack`, the grad-mode replay through `mi355_flow.autograd` (engine
+    double with the native training-step API), PPO-clip + KL loss, `accelerator.backward`, optimizer steps.  Checked: the first ratio is
+    EXACTLY 1, gradients reach the torch parameters and the optimizer moves them, the KL reference forward runs on the reference weights,
+    only the updated tensors are re-bound, and the next epoch's rollout sees the new policy.  `GRPOGuardTrainer` (grpo.py:417-576) adds
+    the per-step `next_latents_mean` capture during sampling (`extra_call_back_kwargs`: step-wise engine calls) and a ratio that also
+    carries the replayed mean and std: exactly 1 as well when replay and rollout agree bit for bit."""
+    from functools import partial
+    from flow_factory.advantage.advantage_processor import AdvantageProcessor
+    from flow_factory.trainers.grpo import GRPOGuardTrainer, GRPOTrainer
+    Trainer = GRPOGuardTrainer if guard else GRPOTrainer
+    P = ref
+    real_engine = P.Engine
+    P.Engine = F.DiffFakeEngine
+    try:
+        ad, cfg, tr_mod = _make(P, YAML_FULL, kl_beta=0.05)
+    finally:
+        P.Engine = real_engine
+    ta = cfg.training_args
+    ta.num_batches_per_epoch, ta.per_device_batch_size, ta.group_size, ta.num_inner_epochs = 2, 2, 2, 1
+    ta.height, ta.width, ta.resolution, ta.num_inference_steps = 256, 256, (256, 256), 6
+    ta.clip_range, ta.adv_clip_range = (-1e-4, 1e-4), (-5.0, 5.0)
+    acc = F.TrainerAccelerator()
+    ad.accelerator = acc
+    eng = ad.engine
+    g = torch.Generator().manual_seed(3)
+    Nt, M, K = 13, 2, 2
+
+    def batch_of(i):            # what GeneralDataset.collate_fn hands over (data_utils/dataset.py:705): one prompt repeated K times
+        pe, pp = torch.randn(1, Nt, 128, generator=g).repeat(K, 1, 1), torch.randn(1, 128, generator=g).repeat(K, 1)
+        ne, npl = torch.randn(1, Nt, 128, generator=g).repeat(K, 1, 1), torch.randn(1, 128, generator=g).repeat(K, 1)
+        return dict(prompt=[f"prompt {i}"] * K, prompt_ids=torch.full((K, 4), i), prompt_embeds=pe, pooled_prompt_embeds=pp,
+                    negative_prompt_embeds=ne, negative_pooled_prompt_embeds=npl, negative_prompt_ids=torch.zeros(K, 4, dtype=torch.long))
+
+    class Buffer:
+        def __init__(self):
+            self.samples = []
+
+        def clear(self):
+            self.samples = []
+
+        def add_samples(self, s):
+            self.samples += list(s)
+
+    logged = []
+    tr = object.__new__(Trainer)
+    tr.accelerator, tr.config, tr.training_args, tr.adapter = acc, cfg, ta, ad
+    tr.log_args = types.SimpleNamespace(verbose=False)
+    tr.epoch, tr.step = 0, 0
+    # (CPU autocast cannot promote the fp16 storage tensors this double hands back; on the GPU the trainer's bf16 autocast is on)
+    tr.autocast = partial(torch.autocast, device_type="cpu", dtype=torch.bfloat16, enabled=False)
+    tr.dataloader = [batch_of(i) for i in range(M)]
+    tr.reward_buffer = Buffer()
+    tr.log_data = lambda data, step: logged.append((step, dict(data)))
+    tr.advantage_processor = AdvantageProcessor(accelerator=acc, reward_weights={"r": 1.0}, group_size=K, global_std=True,
+                                                sampler_type="group_contiguous", verbose=False)
+    trainable = ad.get_trainable_parameters()
+    before = [p_.detach().clone() for p_ in trainable]
+    # (the engine binds bf16 copies: a step must move a weight by more than its bf16 spacing to be seen -- as on the real engine)
+    tr.optimizer = torch.optim.SGD(trainable, lr=500.0)
+
+    # ---- Stage 1-3: the reference's sampling loop
+    samples = tr.sample()
+    assert len(samples) == M * K and all(type(s) is P._RefSD3Sample for s in samples)
+    if guard:        # per-step callback capture: the rollout is stepped through the single-step entry point
+        assert [c[0] for c in eng.calls].count("denoise_step") == M * 6 and "next_latents_mean" in samples[0].extra_kwargs
+    else:
+        rolls = [c for c in eng.calls if c[0] == "rollout"]
+        assert len(rolls) == M and rolls[0][1]["N"] == 6 and rolls[0][1]["guidance"] == 4.5
+    assert len({s.unique_id for s in samples}) == M
+    n_calls0 = len(eng.calls)
+    n_bound0 = len(eng.bind_log)
+    w0 = eng.fingerprint()
+    # ---- Stage 4-5: the reference's advantage computation on stand-in rewards
+    rewards = {"r": torch.tensor([0.1, 0.9, 0.4, 0.2])}
+    adv = tr.compute_advantages(samples, rewards, store_to_samples=True)
+    assert adv.shape == (M * K,) and all("advantage" in s.extra_kwargs for s in samples)
+    # ---- Stage 6: the reference's optimize()
+    tr.optimize(samples)
+    kinds = [c[0] for c in eng.calls[n_calls0:]]
+    n_train_t = len(ad.scheduler.train_timesteps)
+    assert kinds.count("denoise_step_train") == M * n_train_t and kinds.count("denoise_step_backward") == M * n_train_t
+    # KL reference forwards: no-grad engine steps on the REFERENCE weights (use_ref_parameters), one per trained timestep
+    ref_steps = [c[1] for c in eng.calls[n_calls0:] if c[0] == "denoise_step"]
+    assert len(ref_steps) == M * n_train_t and all(abs(c["weights"] - w0) <= 1e-9 * abs(w0) for c in ref_steps)
+    # the first micro-step ran before any update: ratio == 1 exactly (both min and max)
+    first = logged[0][1]
+    assert first["train/ratio_min"] == 1.0 and first["train/ratio_max"] == 1.0, first
+    assert first["train/kl_div"] == 0.0                                        # policy == reference before the first update
+    assert all(torch.isfinite(torch.as_tensor(v)).all() for _, d in logged for v in d.values())
+    assert tr.step == len(logged) == M * n_train_t
+    # the optimizer moved the trainable tensors; later micro-steps saw them (ratio left 1, KL > 0)
+    assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable))
+    later = logged[-1][1]
+    assert later["train/ratio_max"] != 1.0 or later["train/ratio_min"] != 1.0
+    assert later["train/kl_div"] > 0.0
+    # only trainable tensors were ever re-bound after the first full bind
+    rebound = set(eng.bind_log[n_bound0:])
+    assert rebound and rebound <= {n for n, p_ in tr_mod.named_parameters() if p_.requires_grad}
+    # ---- next epoch: the rollout runs on the updated policy without an explicit re-bind
+    tr.epoch = 1
+    tr.sample()
+    assert [c for c in eng.calls if c[0] in ("rollout", "denoise_step")][-1][1]["weights"] != pytest.approx(w0, rel=1e-12)
+    assert F.FakeTransformer.calls == 0
+
+
+def test_matching_loss_trainers_forward_call_reaches_the_native_backward(ref):
+    """AWM / NFT / DGPO / DPO / CRD build their training forward as `{**training_args, 't', 't_next': 0, 'latents': x_t,
+    'compute_log_prob': False, 'return_kwargs': ['noise_pred'], 'noise_level': 0.0, **batch}` filtered by the adapter's signature
+    (trainers/awm.py:357-370, dgpo.py:352-364) and call it WITH autograd: through the plugin that is the engine's differentiable step
+    (placeholder transition, log-prob off), and the loss gradient arrives at the torch parameters."""
+    from flow_factory.utils.base import filter_kwargs
+    P = ref
+    real_engine = P.Engine
+    P.Engine = F.DiffFakeEngine
+    try:
+        ad, cfg, tr_mod = _make(P, YAML_FULL)
+    finally:
+        P.Engine = real_engine
+    ad.train()
+    ad.scheduler.set_timesteps(10)
+    e = _embeds()
+    B = 2
+    x_t = torch.randn(B, 16, 16, 16, generator=torch.Generator().manual_seed(5)).half()
+    t_b = torch.tensor([437.5, 812.0])                       # continuous timesteps, off the scheduler grid
+    batch = dict(prompt=["a", "b"], prompt_ids=torch.zeros(B, 4, dtype=torch.long), all_latents=torch.zeros(B, 2, 16, 16, 16),
+                 timesteps=torch.zeros(B, 10), advantage=torch.ones(B), **e)
+    forward_kwargs = {**cfg.training_args, "t": t_b, "t_next": torch.zeros_like(t_b), "latents": x_t, "compute_log_prob": False,
+                      "return_kwargs": ["noise_pred"], "noise_level": 0.0, "guidance_scale": 1.0,
+                      **{k: v for k, v in batch.items() if k not in ("all_latents", "timesteps", "advantage")}}
+    forward_kwargs = filter_kwargs(ad.forward, **forward_kwargs)
+    assert "clip_range" not in forward_kwargs and "prompt" not in forward_kwargs
+    out = ad.forward(**forward_kwargs)
+    assert out.noise_pred is not None and out.noise_pred.requires_grad and out.log_prob is None
+    kind, call = ad.engine.calls[-1]
+    assert kind == "denoise_step_train" and call["clp"] is False and call["eta"] == 0.0
+    target = torch.randn(x_t.shape, generator=torch.Generator().manual_seed(6))
+    ((out.noise_pred - target) ** 2).mean().backward()
+    assert ad.engine.calls[-1][0] == "denoise_step_backward" and ad.engine.calls[-1][1] == dict(has_lp=False, has_np=True)
+    wq = tr_mod.get_submodule("transformer_blocks.0.attn.to_q").weight
+    assert wq.grad is not None and float(wq.grad.abs().sum()) > 0
+    frozen = [p_ for p_ in tr_mod.parameters() if not p_.requires_grad]
+    assert frozen and all(p_.grad is None for p_ in frozen)
+    assert F.FakeTransformer.calls == 0
