@@ -79,24 +79,30 @@ def rollout(
     init_latents: torch.Tensor, step_noise: torch.Tensor, timesteps: torch.Tensor, sigmas: torch.Tensor,
     noise_levels: Sequence[float], storage_dtype: torch.dtype = torch.float16,
     dynamics_type: str = "Flow-SDE", compute_log_prob: bool = True, quant: Optional[Callable] = None,
+    denoiser: Optional[Callable] = None, is_eval: bool = False,
 ):
     """sd3_5.py:258-304: N-step loop.  Returns dict(all_latents[N+1] (storage dtype), log_probs[N]
-    (nan where not computed), noise_preds[N])."""
+    (nan where not computed), noise_preds[N], next_latents_means[N]).  `denoiser` replaces the oracle network (see `forward_step`;
+    tests/test_rollout_control_flow_pin.py runs this loop and the reference's own adapter on the same stand-in)."""
     N = len(timesteps)
     lat = S.cast_latents(init_latents, storage_dtype)
     all_lat = [lat]
-    lps, vs = [], []
+    lps, vs, means = [], [], []
     sigma_max = float(sigmas[1])
     for i in range(N):
         t = timesteps[i]
         t_next = timesteps[i + 1] if i + 1 < N else torch.tensor(0.0)
         eta = float(noise_levels[i])
-        clp = compute_log_prob and eta > 0
+        clp = compute_log_prob and eta > 0                     # sd3_5.py:277: decided on the schedule's noise level ...
+        if is_eval:
+            eta = 0.0                                          # ... which step() then overrides in eval mode (flow_match_euler_discrete.py:316-317)
         out = forward_step(sd, cfg, t, t_next, lat, prompt_embeds, pooled, neg_embeds, neg_pooled, guidance_scale,
                            noise_level=eta, dynamics_type=dynamics_type, sigma_max=sigma_max,
-                           variance_noise=step_noise[i], compute_log_prob=clp, quant=quant)
+                           variance_noise=step_noise[i], compute_log_prob=clp, quant=quant, denoiser=denoiser)
         lat = S.cast_latents(out["next_latents"], storage_dtype)
         all_lat.append(lat)
         lps.append(out["log_prob"] if clp else torch.full((lat.shape[0],), float("nan")))
         vs.append(out["noise_pred"])
-    return dict(all_latents=torch.stack(all_lat, 0), log_probs=torch.stack(lps, 0), noise_preds=torch.stack(vs, 0))
+        means.append(out["next_latents_mean"])
+    return dict(all_latents=torch.stack(all_lat, 0), log_probs=torch.stack(lps, 0), noise_preds=torch.stack(vs, 0),
+                next_latents_means=torch.stack(means, 0))

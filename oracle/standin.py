@@ -1,0 +1,24 @@
+"""TEST INFRASTRUCTURE ONLY -- never imported by the product path.
+
+A closed-form stand-in for the denoiser network, used to PIN the rollout control-flow restatements (`oracle/rollout_ref.py`, ...) against
+the reference's own adapter code: the reference's `SD3_5Adapter.inference` / `.forward` (src/flow_factory/models/stable_diffusion/
+sd3_5.py:176-448) runs on CPU with this function in place of `SD3Transformer2DModel`, and the oracle's rollout runs with the same function
+as its `denoiser` -- whatever differs afterwards is control flow (RNG order, dtype casts, timestep rounding, CFG order and arithmetic, what
+the scheduler is handed, which positions and log-probs are kept), which is exactly what the restatement claims to reproduce.  The network
+BODY stays unpinned (un-vendored diffusers); this removes everything around it from that caveat.
+"""
+from __future__ import annotations
+
+import torch
+
+
+def denoiser(hidden_states: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
+             pooled_projections: torch.Tensor) -> torch.Tensor:
+    """(B, C, h, w) latents, (B,) timestep in the latents' dtype, (B, Nt, J) / (B, P) prompt tensors -> bf16 velocity (B, C, h, w).
+    Sensitive to every input (and to the batch ORDER of a CFG pair), cheap, deterministic on CPU."""
+    x = hidden_states.float()
+    t = timestep.float().reshape(-1, 1, 1, 1) / 1000.0
+    e = encoder_hidden_states.float().mean(dim=(1, 2)).reshape(-1, 1, 1, 1)
+    p = pooled_projections.float().mean(dim=1).reshape(-1, 1, 1, 1)
+    v = (0.7 * x + 0.3 * torch.roll(x, 1, dims=-1)) * torch.cos(1.3 * t) + 0.8 * torch.sin(3.0 * x) * t + 4.0 * e + 2.5 * p
+    return v.to(torch.bfloat16)            # what a bf16-autocast transformer returns

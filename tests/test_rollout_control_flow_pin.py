@@ -1,0 +1,78 @@
+"""Pins the rollout control-flow restatement `oracle/rollout_ref.py` against the REFERENCE's own adapter code.
+
+`tests/golden/rollout_control_flow.npz` holds what the reference's `SD3_5Adapter.inference()` returned on CPU
+(src/flow_factory/models/stable_diffusion/sd3_5.py:176-448, imported whole by `oracle/ref_package.py`; generator
+`oracle/make_rollout_golden.py`) with the closed-form `oracle.standin.denoiser` in place of the transformer.  The oracle's rollout runs
+on the same stand-in, the same seed and the same prompt tensors: trajectory positions, log-probs and the per-step means must agree
+BIT FOR BIT -- RNG draw order and dtypes, the timestep rounding, CFG batch order and bf16 arithmetic, the scheduler's inputs, the
+storage-dtype round trips, which positions / SDE steps are kept.  (The network body itself stays an unpinned restatement of
+un-vendored diffusers; everything around it is pinned here.)  In the build container the fixture is also re-generated live from
+/root/reference and compared with the committed file."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rollout_ref as R
+from oracle import standin
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "rollout_control_flow.npz")
+CASES = {"flow_sde_cfg_fp16": ("Flow-SDE", 4.5), "cps_nocfg_bf16": ("CPS", 1.0), "dance_cfg_native": ("Dance-SDE", 3.0),
+         "eval_ode_cfg_fp16": ("Flow-SDE", 4.5)}
+DT = {0: torch.float16, 1: torch.bfloat16, 2: torch.float32}
+
+
+def _case(blob, name):
+    return {k.split("/", 1)[1]: torch.from_numpy(np.asarray(blob[k])) for k in blob.files if k.startswith(name + "/")}
+
+
+def _check(name, ref):
+    dyn, gs = CASES[name]
+    storage = DT[int(ref["latents_dtype"])]
+    B, _, C, h, w = ref["all_latents"].shape
+    N = ref["timesteps"].numel()
+    pe, pp, ne, npl = (ref[k].bfloat16() for k in ("pe", "pp", "ne", "npl"))
+    torch.manual_seed(int(ref["seed"]))                      # the reference's draws: prepare_latents (transformer dtype), then one fp32 per step
+    init, noise = R.draw_rollout_noise(B, C, h, w, N, torch.bfloat16, None)
+    nl = [float(x) for x in ref["noise_levels"]]
+    out = R.rollout(None, None, pe, pp, ne if gs > 1 else None, npl if gs > 1 else None, gs, init, noise, ref["timesteps"], ref["sigmas"], nl,
+                    storage, dynamics_type=dyn, compute_log_prob="log_probs" in ref, denoiser=standin.denoiser, is_eval=bool(ref["is_eval"]))
+    lmap = ref["latent_index_map"].long()
+    kept = [p for p in range(N + 1) if lmap[p] >= 0]
+    assert kept, name
+    for p in kept:
+        got, want = out["all_latents"][p].float(), ref["all_latents"][:, lmap[p]]
+        assert torch.equal(got, want), (name, "latents at position", p, float((got - want).abs().max()))
+    if "log_probs" in ref:
+        pmap = ref["log_prob_index_map"].long()
+        sde = [i for i in range(N) if pmap[i] >= 0]
+        assert sde == [i for i in range(N) if nl[i] > 0] and not bool(ref["is_eval"]), (name, sde, nl)
+        for i in sde:
+            assert torch.equal(out["log_probs"][i], ref["log_probs"][:, pmap[i]]), (name, "log-prob of step", i)
+    cmap = ref["callback_index_map"].long()
+    for i in range(N):
+        if cmap[i] >= 0:
+            assert torch.equal(out["next_latents_means"][i].float(), ref["next_latents_mean"][:, cmap[i]]), (name, "mean of step", i)
+    return len(kept)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_rollout_oracle_reproduces_the_reference_adapter_bit_for_bit(name):
+    blob = np.load(GOLDEN)
+    assert _check(name, _case(blob, name)) >= 2
+
+
+def test_fixture_is_what_the_reference_produces_now():
+    from oracle import ref_package
+    if not ref_package.available():
+        pytest.skip("needs /root/reference (build container only)")
+    from oracle import make_rollout_golden as G
+    blob = np.load(GOLDEN)
+    for name in sorted(CASES):
+        live = G.run_reference(name)
+        stored = _case(blob, name)
+        assert sorted(live) == sorted(stored), name
+        for k, v in live.items():
+            assert torch.equal(v.detach().cpu().float(), stored[k].float()), (name, k)
+        _check(name, {k: v.detach().cpu() for k, v in live.items()})
