@@ -254,23 +254,31 @@ def model_scalar(value, dtype: torch.dtype) -> torch.Tensor:
 
 
 def forward_step(sd, cfg: FluxConfig, t, t_next, latents, prompt_embeds, pooled, img_ids, guidance_scale=3.5, noise_level=0.0,
-                 dynamics_type="Flow-SDE", sigma_max=None, variance_noise=None, next_latents=None, compute_log_prob=True, quant=None):
+                 dynamics_type="Flow-SDE", sigma_max=None, variance_noise=None, next_latents=None, compute_log_prob=True, quant=None,
+                 denoiser=None):
+    """flux1.py:294-346.  `denoiser` (tests/test_rollout_control_flow_pin.py) replaces the network AT THE ADAPTER'S CALL (flux1.py:323-333):
+    it receives exactly what the reference hands to `FluxTransformer2DModel`."""
     from . import scheduler_ref as S
     B = latents.shape[0]
-    tm = model_scalar(t.float() / 1000, latents.dtype).reshape(-1).expand(B)
-    gm = model_scalar(torch.full((B,), float(guidance_scale)).to(latents.dtype).float(), latents.dtype)
-    v = flux_forward(sd, cfg, latents.float(), tm, gm, pooled.float(), prompt_embeds.float(), img_ids, quant=quant, premultiplied=True)
+    if denoiser is not None:
+        v = denoiser(hidden_states=latents, timestep=torch.as_tensor(t, dtype=torch.float32).expand(B) / 1000,
+                     guidance=torch.as_tensor(guidance_scale, dtype=latents.dtype).expand(B), pooled_projections=pooled,
+                     encoder_hidden_states=prompt_embeds, txt_ids=torch.zeros(prompt_embeds.shape[1], 3).to(dtype=latents.dtype), img_ids=img_ids)
+    else:
+        tm = model_scalar(t.float() / 1000, latents.dtype).reshape(-1).expand(B)
+        gm = model_scalar(torch.full((B,), float(guidance_scale)).to(latents.dtype).float(), latents.dtype)
+        v = flux_forward(sd, cfg, latents.float(), tm, gm, pooled.float(), prompt_embeds.float(), img_ids, quant=quant, premultiplied=True)
     v = v.to(torch.bfloat16)
     return S.sde_step(v, latents, t.float() / 1000, t_next.float() / 1000, noise_level, dynamics_type=dynamics_type, sigma_max=sigma_max,
                       variance_noise=variance_noise, next_latents=next_latents, compute_log_prob=compute_log_prob)
 
 
 def rollout(sd, cfg: FluxConfig, prompt_embeds, pooled, guidance_scale, init_latents, step_noise, timesteps, sigmas, noise_levels,
-            img_ids, storage_dtype=torch.float16, dynamics_type="Flow-SDE", compute_log_prob=True, quant=None):
+            img_ids, storage_dtype=torch.float16, dynamics_type="Flow-SDE", compute_log_prob=True, quant=None, denoiser=None):
     from . import scheduler_ref as S
     N = len(timesteps)
     lat = S.cast_latents(init_latents, storage_dtype)
-    all_lat, lps, vs = [lat], [], []
+    all_lat, lps, vs, means = [lat], [], [], []
     sigma_max = float(sigmas[1])
     for i in range(N):
         t = timesteps[i]
@@ -278,9 +286,12 @@ def rollout(sd, cfg: FluxConfig, prompt_embeds, pooled, guidance_scale, init_lat
         eta = float(noise_levels[i])
         clp = compute_log_prob and eta > 0
         out = forward_step(sd, cfg, t, t_next, lat, prompt_embeds, pooled, img_ids, guidance_scale, noise_level=eta,
-                           dynamics_type=dynamics_type, sigma_max=sigma_max, variance_noise=step_noise[i], compute_log_prob=clp, quant=quant)
+                           dynamics_type=dynamics_type, sigma_max=sigma_max, variance_noise=step_noise[i], compute_log_prob=clp, quant=quant,
+                           denoiser=denoiser)
         lat = S.cast_latents(out["next_latents"], storage_dtype)
         all_lat.append(lat)
         lps.append(out["log_prob"] if clp else torch.full((lat.shape[0],), float("nan")))
         vs.append(out["noise_pred"])
-    return dict(all_latents=torch.stack(all_lat, 0), log_probs=torch.stack(lps, 0), noise_preds=torch.stack(vs, 0))
+        means.append(out["next_latents_mean"])
+    return dict(all_latents=torch.stack(all_lat, 0), log_probs=torch.stack(lps, 0), noise_preds=torch.stack(vs, 0),
+                next_latents_means=torch.stack(means, 0))

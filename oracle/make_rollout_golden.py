@@ -99,10 +99,177 @@ def run_reference(case: str):
     return out
 
 
+# ---------------------------------------------------------------------------------------------- FLUX.1 (models/flux/flux1.py:151-346)
+FLUX_CASES = {
+    "flux_flow_sde_fp16": ("Flow-SDE", 3.5, "fp16", 5, [1, 2, 3], 2, 0.7),
+    "flux_dance_native": ("Dance-SDE", 2.0, None, 4, [0, 1, 2], 1, 0.8),
+}
+
+
+def _flux_pipeline(transformer):
+    """Pseudo-pipeline with the FluxPipeline behaviours `Flux1Adapter.inference()` touches, restated from the published pipeline:
+    `prepare_latents` = one `randn_tensor` of (B, 16, 2*(H//16), 2*(W//16)) in the requested dtype, packed 2x2 -> (B, h/2*w/2, 64), plus the
+    (h/2*w/2, 3) image ids; `_unpack_latents` is its inverse."""
+    import torch.nn as nn
+    from oracle import diffusers_stub as D
+    from oracle import flux_ref as FR
+    transformer.config = types.SimpleNamespace(in_channels=64, guidance_embeds=True, num_layers=1, num_single_layers=1, num_attention_heads=1,
+                                               attention_head_dim=128, joint_attention_dim=J, pooled_projection_dim=P,
+                                               axes_dims_rope=(16, 56, 56))
+    vae = nn.Module()
+    vae.add_module("decoder", nn.Linear(2, 2))
+    vae.config = types.SimpleNamespace(scaling_factor=0.3611, shift_factor=0.1159, latent_channels=16, block_out_channels=(128, 256, 512, 512),
+                                       layers_per_block=2, norm_num_groups=32, out_channels=3)
+    vae.dtype = torch.float32
+    vae.decode = lambda lat, return_dict=False: (torch.zeros(lat.shape[0], 3, lat.shape[2] * 8, lat.shape[3] * 8),)
+    pipe = types.SimpleNamespace()
+    pipe.transformer, pipe.vae = transformer, vae
+    pipe.text_encoder, pipe.text_encoder_2 = nn.Linear(2, 2), nn.Linear(2, 2)
+    pipe.tokenizer, pipe.tokenizer_2 = object(), object()
+    pipe.vae_scale_factor = 8
+    pipe.scheduler = D.FlowMatchEulerDiscreteScheduler(num_train_timesteps=1000, shift=3.0, use_dynamic_shifting=True, base_shift=0.5,
+                                                       max_shift=1.15, base_image_seq_len=256, max_image_seq_len=4096)
+    pipe.image_processor = types.SimpleNamespace(postprocess=lambda x, output_type="pt": x)
+    pipe.maybe_free_model_hooks = lambda: None
+    pipe.components = {"transformer": transformer, "vae": vae, "text_encoder": pipe.text_encoder, "text_encoder_2": pipe.text_encoder_2}
+
+    def prepare_latents(batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        h, w = 2 * (int(height) // 16), 2 * (int(width) // 16)
+        lat = D.randn_tensor((batch_size, num_channels_latents, h, w), generator=generator, device=device, dtype=dtype)
+        return FR.pack_latents(lat), FR.prepare_img_ids(h // 2, w // 2).to(device=device, dtype=dtype)
+    pipe.prepare_latents = prepare_latents
+    pipe._unpack_latents = lambda lat, height, width, vsf: FR.unpack_latents(lat, 2 * (int(height) // (vsf * 2)), 2 * (int(width) // (vsf * 2)))
+    return pipe
+
+
+def run_reference_flux(case: str):
+    ref_package.install()
+    sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _plugin_fakes as F
+    from flow_factory.hparams import Arguments
+    from flow_factory.models.flux.flux1 import Flux1Adapter
+    from flow_factory.utils.trajectory_collector import compute_trajectory_indices
+    dyn, gs, storage, N, sde_steps, n_sde, eta = FLUX_CASES[case]
+    cfg = Arguments.load_from_yaml(os.path.join(ref_package.REF_ROOT, "examples/grpo/full/flux1/default.yaml"))
+    cfg.training_args.latent_storage_dtype = storage
+    sa = cfg.scheduler_args
+    sa.dynamics_type, sa.noise_level, sa.sde_steps, sa.num_sde_steps, sa.seed = dyn, eta, list(sde_steps), n_sde, 42
+    shapes = {"transformer_blocks.0.attn.to_q.weight": (8, 8), "transformer_blocks.0.attn.to_q.bias": (8,), "x_embedder.weight": (8, 8)}
+    tr = F.build_module_tree(shapes, buffers=(), cls=F.FakeTransformer).bfloat16()
+    tr.forward = lambda hidden_states=None, timestep=None, guidance=None, pooled_projections=None, encoder_hidden_states=None, txt_ids=None, \
+        img_ids=None, joint_attention_kwargs=None, return_dict=False: (
+            standin.flux_denoiser(hidden_states, timestep, guidance, pooled_projections, encoder_hidden_states, txt_ids, img_ids),)
+
+    class Ref(Flux1Adapter):
+        def load_pipeline(self):
+            return _flux_pipeline(tr)
+
+    ad = Ref(cfg, F.FakeAccelerator())
+    ad.post_init()
+    ad.rollout()
+    g = torch.Generator().manual_seed(21)
+    pe, pp = torch.randn(B, NT, J, generator=g).bfloat16(), torch.randn(B, P, generator=g).bfloat16()
+    seed = 2000 + sorted(FLUX_CASES).index(case)
+    torch.manual_seed(seed)
+    traj = compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N)
+    samples = ad.inference(prompt=["p0", "p1"], height=H, width=W, num_inference_steps=N, guidance_scale=gs, prompt_embeds=pe,
+                           pooled_prompt_embeds=pp, compute_log_prob=True, trajectory_indices=traj, extra_call_back_kwargs=["next_latents_mean"])
+    sched = ad.scheduler
+    return dict(seed=torch.tensor(seed), guidance=torch.tensor(gs), pe=pe.float(), pp=pp.float(), timesteps=samples[0].timesteps.float(),
+                sigmas=sched.sigmas.float(), noise_levels=torch.tensor([float(sched.get_noise_level_for_timestep(t)) for t in samples[0].timesteps]),
+                all_latents=torch.stack([s.all_latents for s in samples]).float(), img_ids=samples[0].img_ids.float(),
+                latents_dtype=torch.tensor({torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}[samples[0].all_latents.dtype]),
+                latent_index_map=samples[0].latent_index_map, callback_index_map=samples[0].extra_kwargs["callback_index_map"],
+                next_latents_mean=torch.stack([s.extra_kwargs["next_latents_mean"] for s in samples]).float(),
+                log_probs=torch.stack([s.log_probs for s in samples]).float(), log_prob_index_map=samples[0].log_prob_index_map)
+
+
+# ---------------------------------------------------------------------------------------------- Qwen-Image (models/qwen_image/qwen_image.py:288-600)
+QWEN_CASES = {
+    "qwen_flow_sde_cfg_ragged": ("Flow-SDE", 4.0, None, 5, [1, 2, 3], 2, 0.7),
+    "qwen_cps_nocfg_fp16": ("CPS", 1.0, "fp16", 4, [0, 1, 2], 1, 0.8),
+}
+QJ = 64
+
+
+def run_reference_qwen(case: str):
+    ref_package.install()
+    sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _plugin_fakes as F
+    import mi355_flow.qwen as QW
+    from contextlib import nullcontext
+    from flow_factory.hparams import Arguments
+    from flow_factory.models.qwen_image.qwen_image import QwenImageAdapter
+    from flow_factory.utils.trajectory_collector import compute_trajectory_indices
+    from oracle import diffusers_stub as D
+    from oracle import flux_ref as FR
+    dyn, gs, storage, N, sde_steps, n_sde, eta = QWEN_CASES[case]
+    cfg = Arguments.load_from_yaml(os.path.join(ref_package.REF_ROOT, "examples/grpo/full/qwen_image/default.yaml"))
+    cfg.training_args.latent_storage_dtype = storage
+    sa = cfg.scheduler_args
+    sa.dynamics_type, sa.noise_level, sa.sde_steps, sa.num_sde_steps, sa.seed = dyn, eta, list(sde_steps), n_sde, 42
+    tcfg = QW.QwenConfig(num_layers=1, num_attention_heads=1, joint_attention_dim=QJ)
+    tr = F.build_module_tree({"transformer_blocks.0.attn.to_q.weight": (8, 8), "transformer_blocks.0.attn.to_q.bias": (8,)}, buffers=(),
+                             cls=F.FakeTransformer).bfloat16()
+    tr.forward = lambda hidden_states=None, timestep=None, guidance=None, encoder_hidden_states_mask=None, encoder_hidden_states=None, \
+        img_shapes=None, txt_seq_lens=None, attention_kwargs=None, return_dict=False: (
+            standin.qwen_denoiser(hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_mask, img_shapes, txt_seq_lens),)
+    tr.cache_context = lambda name: nullcontext()
+
+    def prepare_latents(batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        # QwenImagePipeline.prepare_latents: one randn of (B, 1, 16, h, w), packed 2x2 like FLUX on the single frame
+        h, w = 2 * (int(height) // 16), 2 * (int(width) // 16)
+        lat = D.randn_tensor((batch_size, 1, num_channels_latents, h, w), generator=generator, device=device, dtype=dtype)
+        return FR.pack_latents(lat[:, 0])
+
+    class Ref(QwenImageAdapter):
+        def load_pipeline(self):
+            pipe = F.make_qwen_pipeline(tcfg, tr)
+            pipe.prepare_latents = prepare_latents
+            pipe._unpack_latents = lambda lat, height, width, vsf: FR.unpack_latents(lat, 2 * (int(height) // 16), 2 * (int(width) // 16)).unsqueeze(2)
+            pipe.vae.dtype = torch.float32
+            pipe.vae.decode = lambda lat, return_dict=False: (torch.zeros(lat.shape[0], 3, 1, lat.shape[-2] * 8, lat.shape[-1] * 8),)
+            return pipe
+
+    ad = Ref(cfg, F.FakeAccelerator())
+    ad.post_init()
+    ad.rollout()
+    g = torch.Generator().manual_seed(31)
+    lens, nlens = [5, 9], [3, 3]
+    pe = [torch.randn(n, QJ, generator=g).bfloat16() for n in lens]
+    ne = [torch.randn(n, QJ, generator=g).bfloat16() for n in nlens]
+    seed = 3000 + sorted(QWEN_CASES).index(case)
+    torch.manual_seed(seed)
+    traj = compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N)
+    samples = ad.inference(prompt=["p0", "p1"], height=H, width=W, num_inference_steps=N, guidance_scale=gs, prompt_embeds=pe,
+                           prompt_embeds_mask=[torch.ones(n, dtype=torch.long) for n in lens], prompt_ids=[torch.arange(n) for n in lens],
+                           negative_prompt_embeds=ne if gs > 1 else None,
+                           negative_prompt_embeds_mask=[torch.ones(n, dtype=torch.long) for n in nlens] if gs > 1 else None,
+                           compute_log_prob=True, trajectory_indices=traj, extra_call_back_kwargs=["next_latents_mean"])
+    sched = ad.scheduler
+    pad = lambda seq: torch.nn.utils.rnn.pad_sequence([x.float() for x in seq], batch_first=True)      # noqa: E731
+    return dict(seed=torch.tensor(seed), guidance=torch.tensor(gs), pe=pad(pe), ne=pad(ne), lens=torch.tensor(lens), nlens=torch.tensor(nlens),
+                timesteps=samples[0].timesteps.float(), sigmas=sched.sigmas.float(),
+                noise_levels=torch.tensor([float(sched.get_noise_level_for_timestep(t)) for t in samples[0].timesteps]),
+                all_latents=torch.stack([s.all_latents for s in samples]).float(), hw=torch.tensor([H // 16, W // 16]),
+                latents_dtype=torch.tensor({torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}[samples[0].all_latents.dtype]),
+                latent_index_map=samples[0].latent_index_map, callback_index_map=samples[0].extra_kwargs["callback_index_map"],
+                next_latents_mean=torch.stack([s.extra_kwargs["next_latents_mean"] for s in samples]).float(),
+                log_probs=torch.stack([s.log_probs for s in samples]).float(), log_prob_index_map=samples[0].log_prob_index_map)
+
+
 def main():
     blob = {}
     for case in CASES:
         for k, v in run_reference(case).items():
+            blob[f"{case}/{k}"] = v.detach().cpu().numpy()
+    for case in FLUX_CASES:
+        for k, v in run_reference_flux(case).items():
+            blob[f"{case}/{k}"] = v.detach().cpu().numpy()
+    for case in QWEN_CASES:
+        for k, v in run_reference_qwen(case).items():
             blob[f"{case}/{k}"] = v.detach().cpu().numpy()
     np.savez_compressed(OUT, **blob)
     print(f"wrote {OUT}: {len(blob)} arrays, {os.path.getsize(OUT)} bytes")

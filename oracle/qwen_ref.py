@@ -212,14 +212,27 @@ def cfg_rescale_bf16(neg: torch.Tensor, pos: torch.Tensor, g: float) -> torch.Te
 
 def forward_step(sd, cfg: QwenConfig, t, t_next, latents, prompt_embeds, txt_lens, hp, wp, neg_embeds=None, neg_lens=None, guidance_scale=4.0,
                  noise_level=0.0, dynamics_type="Flow-SDE", sigma_max=None, variance_noise=None, next_latents=None, compute_log_prob=True,
-                 quant=None):
+                 quant=None, denoiser=None):
+    """qwen_image.py:476-600.  `prompt_embeds` / `neg_embeds` are padded to their batch maximum, `txt_lens` / `neg_lens` the valid lengths
+    (what `_pad_batch_prompt`, :238-284, produces).  `denoiser` (tests/test_rollout_control_flow_pin.py) replaces the network AT THE
+    ADAPTER'S CALL (:553-563, :567-577): it receives what the reference hands to `QwenImageTransformer2DModel`."""
     from . import scheduler_ref as S
     B = latents.shape[0]
     timestep = torch.as_tensor(t, dtype=torch.float32).reshape(-1).expand(B).to(latents.dtype)        # :497
-    tm = (timestep / 1000).float()                                                                     # :534 (rounded in latents.dtype)
-    v = qwen_forward(sd, cfg, latents.float(), tm, prompt_embeds.float(), txt_lens, hp, wp, quant=quant).to(torch.bfloat16)
+    if denoiser is not None:
+        def net(emb, lens):
+            L = emb.shape[1]
+            mask = (torch.arange(L)[None, :] < torch.as_tensor([int(n) for n in lens])[:, None]).long()
+            return denoiser(hidden_states=latents, timestep=timestep / 1000, encoder_hidden_states=emb, encoder_hidden_states_mask=mask,
+                            img_shapes=[[(1, hp, wp)]] * B, txt_seq_lens=[int(n) for n in lens]).to(torch.bfloat16)
+    else:
+        tm = (timestep / 1000).float()                                                                 # :534 (rounded in latents.dtype)
+
+        def net(emb, lens):
+            return qwen_forward(sd, cfg, latents.float(), tm, emb.float(), lens, hp, wp, quant=quant).to(torch.bfloat16)
+    v = net(prompt_embeds, txt_lens)
     if guidance_scale > 1.0 and neg_embeds is not None:
-        vn = qwen_forward(sd, cfg, latents.float(), tm, neg_embeds.float(), neg_lens, hp, wp, quant=quant).to(torch.bfloat16)
+        vn = net(neg_embeds, neg_lens)
         v = cfg_rescale_bf16(vn, v, float(guidance_scale))
     t = torch.as_tensor(t, dtype=torch.float32)
     t_next = torch.as_tensor(t_next, dtype=torch.float32)
@@ -228,11 +241,11 @@ def forward_step(sd, cfg: QwenConfig, t, t_next, latents, prompt_embeds, txt_len
 
 
 def rollout(sd, cfg: QwenConfig, prompt_embeds, txt_lens, neg_embeds, neg_lens, guidance_scale, init_latents, step_noise, timesteps, sigmas,
-            noise_levels, hp, wp, storage_dtype=torch.bfloat16, dynamics_type="Flow-SDE", compute_log_prob=True, quant=None):
+            noise_levels, hp, wp, storage_dtype=torch.bfloat16, dynamics_type="Flow-SDE", compute_log_prob=True, quant=None, denoiser=None):
     from . import scheduler_ref as S
     N = len(timesteps)
     lat = S.cast_latents(init_latents, storage_dtype)
-    all_lat, lps, vs = [lat], [], []
+    all_lat, lps, vs, means = [lat], [], [], []
     sigma_max = float(sigmas[1])
     for i in range(N):
         t = timesteps[i]
@@ -241,9 +254,11 @@ def rollout(sd, cfg: QwenConfig, prompt_embeds, txt_lens, neg_embeds, neg_lens, 
         clp = compute_log_prob and eta > 0
         out = forward_step(sd, cfg, t, t_next, lat, prompt_embeds, txt_lens, hp, wp, neg_embeds, neg_lens, guidance_scale, noise_level=eta,
                            dynamics_type=dynamics_type, sigma_max=sigma_max, variance_noise=step_noise[i] if step_noise is not None else None,
-                           compute_log_prob=clp, quant=quant)
+                           compute_log_prob=clp, quant=quant, denoiser=denoiser)
         lat = S.cast_latents(out["next_latents"], storage_dtype)
         all_lat.append(lat)
         lps.append(out["log_prob"] if clp else torch.full((lat.shape[0],), float("nan")))
         vs.append(out["noise_pred"])
-    return dict(all_latents=torch.stack(all_lat, 0), log_probs=torch.stack(lps, 0), noise_preds=torch.stack(vs, 0))
+        means.append(out["next_latents_mean"])
+    return dict(all_latents=torch.stack(all_lat, 0), log_probs=torch.stack(lps, 0), noise_preds=torch.stack(vs, 0),
+                next_latents_means=torch.stack(means, 0))

@@ -22,3 +22,29 @@ def denoiser(hidden_states: torch.Tensor, timestep: torch.Tensor, encoder_hidden
     p = pooled_projections.float().mean(dim=1).reshape(-1, 1, 1, 1)
     v = (0.7 * x + 0.3 * torch.roll(x, 1, dims=-1)) * torch.cos(1.3 * t) + 0.8 * torch.sin(3.0 * x) * t + 4.0 * e + 2.5 * p
     return v.to(torch.bfloat16)            # what a bf16-autocast transformer returns
+
+
+def flux_denoiser(hidden_states, timestep, guidance, pooled_projections, encoder_hidden_states, txt_ids, img_ids) -> torch.Tensor:
+    """The argument list `Flux1Adapter.forward` hands to `FluxTransformer2DModel` (reference models/flux/flux1.py:323-333): packed latents
+    (B, Ni, 64), `t / 1000` in fp32, the guidance scale in the latents' dtype, pooled / T5 embeddings, zero text ids, (Ni, 3) image ids."""
+    x = hidden_states.float()
+    t = timestep.float().reshape(-1, 1, 1)
+    g = guidance.float().reshape(-1, 1, 1)
+    e = encoder_hidden_states.float().mean(dim=(1, 2)).reshape(-1, 1, 1)
+    p = pooled_projections.float().mean(dim=1).reshape(-1, 1, 1)
+    pos = (0.01 * img_ids.float()[:, 1] - 0.02 * img_ids.float()[:, 2]).reshape(1, -1, 1) + txt_ids.float().sum()
+    v = (0.7 * x + 0.3 * torch.roll(x, 1, dims=-1)) * torch.cos(1.3 * t) + 0.8 * torch.sin(3.0 * x) * t + 0.05 * g + 4.0 * e + 2.5 * p + pos
+    return v.to(torch.bfloat16)
+
+
+def qwen_denoiser(hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_mask, img_shapes, txt_seq_lens) -> torch.Tensor:
+    """The call of `QwenImageAdapter.forward` (reference models/qwen_image/qwen_image.py:553-563): packed latents, `timestep / 1000` in the
+    latents' dtype, prompt embeddings padded to the batch maximum with their mask and lengths, one (1, h/2, w/2) shape per sample."""
+    x = hidden_states.float()
+    t = timestep.float().reshape(-1, 1, 1)
+    m = encoder_hidden_states_mask.float()
+    e = (encoder_hidden_states.float().mean(-1) * m).sum(1) / m.sum(1)                       # masked mean over the valid text tokens
+    lens = torch.as_tensor([float(n) for n in txt_seq_lens]).reshape(-1, 1, 1)
+    shp = float(sum(a * b * c for (a, b, c) in img_shapes[0]))
+    v = (0.7 * x + 0.3 * torch.roll(x, 1, dims=-1)) * torch.cos(1.3 * t) + 0.8 * torch.sin(3.0 * x) * t + 4.0 * e.reshape(-1, 1, 1) + 0.01 * lens + 1e-4 * shp
+    return v.to(torch.bfloat16)

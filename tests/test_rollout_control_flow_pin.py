@@ -57,6 +57,81 @@ def _check(name, ref):
     return len(kept)
 
 
+def _compare(name, ref, out, N, nl):
+    lmap = ref["latent_index_map"].long()
+    kept = [p for p in range(N + 1) if lmap[p] >= 0]
+    for p in kept:
+        got, want = out["all_latents"][p].float(), ref["all_latents"][:, lmap[p]]
+        assert torch.equal(got, want), (name, "latents at position", p, float((got - want).abs().max()))
+    pmap = ref["log_prob_index_map"].long()
+    sde = [i for i in range(N) if pmap[i] >= 0]
+    assert sde and sde == [i for i in range(N) if nl[i] > 0], (name, sde, nl)
+    for i in sde:
+        assert torch.equal(out["log_probs"][i], ref["log_probs"][:, pmap[i]]), (name, "log-prob of step", i)
+    cmap = ref["callback_index_map"].long()
+    for i in range(N):
+        if cmap[i] >= 0:
+            assert torch.equal(out["next_latents_means"][i].float(), ref["next_latents_mean"][:, cmap[i]]), (name, "mean of step", i)
+    return len(kept)
+
+
+FLUX_CASES = {"flux_flow_sde_fp16": "Flow-SDE", "flux_dance_native": "Dance-SDE"}
+
+
+def _check_flux(name, ref):
+    """`Flux1Adapter.inference` / `.forward` (reference models/flux/flux1.py:151-346) vs `oracle.flux_ref.rollout`: the latents are drawn
+    in the PROMPT EMBEDDINGS' dtype as (B, 16, h, w) and packed, the per-step noise in fp32 with the PACKED shape, the transformer sees
+    `t / 1000` in fp32 and the guidance scale in the latents' dtype."""
+    from oracle import flux_ref as FR
+    storage = DT[int(ref["latents_dtype"])]
+    B, _, Ni, ch = ref["all_latents"].shape
+    N = ref["timesteps"].numel()
+    hp = int(ref["img_ids"][:, 1].max()) + 1
+    wp = int(ref["img_ids"][:, 2].max()) + 1
+    pe, pp = ref["pe"].bfloat16(), ref["pp"].bfloat16()
+    torch.manual_seed(int(ref["seed"]))
+    init = FR.pack_latents(torch.randn(B, ch // 4, 2 * hp, 2 * wp, dtype=pe.dtype))
+    noise = torch.stack([torch.randn(B, Ni, ch, dtype=torch.float32) for _ in range(N)])
+    nl = [float(x) for x in ref["noise_levels"]]
+    out = FR.rollout(None, None, pe, pp, float(ref["guidance"]), init, noise, ref["timesteps"], ref["sigmas"], nl, ref["img_ids"].to(pe.dtype),
+                     storage, dynamics_type=FLUX_CASES[name], denoiser=standin.flux_denoiser)
+    return _compare(name, ref, out, N, nl)
+
+
+@pytest.mark.parametrize("name", sorted(FLUX_CASES))
+def test_flux_rollout_oracle_reproduces_the_reference_adapter_bit_for_bit(name):
+    assert _check_flux(name, _case(np.load(GOLDEN), name)) >= 2
+
+
+QWEN_CASES = {"qwen_flow_sde_cfg_ragged": "Flow-SDE", "qwen_cps_nocfg_fp16": "CPS"}
+
+
+def _check_qwen(name, ref):
+    """`QwenImageAdapter.inference` / `.forward` (reference models/qwen_image/qwen_image.py:288-600) vs `oracle.qwen_ref.rollout`: ragged
+    prompt lists padded by the reference's own `_pad_batch_prompt`, `timestep / 1000` in the latents' dtype, a cond and an uncond call,
+    true CFG rescaled to the norm of the cond prediction in bf16."""
+    from oracle import flux_ref as FR
+    from oracle import qwen_ref as Q
+    storage = DT[int(ref["latents_dtype"])]
+    B, _, Ni, ch = ref["all_latents"].shape
+    N = ref["timesteps"].numel()
+    hp, wp = (int(v) for v in ref["hw"])
+    gs = float(ref["guidance"])
+    pe, ne = ref["pe"].bfloat16(), ref["ne"].bfloat16()
+    torch.manual_seed(int(ref["seed"]))
+    init = FR.pack_latents(torch.randn(B, 1, ch // 4, 2 * hp, 2 * wp, dtype=torch.bfloat16)[:, 0])      # transformer dtype
+    noise = torch.stack([torch.randn(B, Ni, ch, dtype=torch.float32) for _ in range(N)])
+    nl = [float(x) for x in ref["noise_levels"]]
+    out = Q.rollout(None, None, pe, ref["lens"].tolist(), ne if gs > 1 else None, ref["nlens"].tolist() if gs > 1 else None, gs, init, noise,
+                    ref["timesteps"], ref["sigmas"], nl, hp, wp, storage, dynamics_type=QWEN_CASES[name], denoiser=standin.qwen_denoiser)
+    return _compare(name, ref, out, N, nl)
+
+
+@pytest.mark.parametrize("name", sorted(QWEN_CASES))
+def test_qwen_rollout_oracle_reproduces_the_reference_adapter_bit_for_bit(name):
+    assert _check_qwen(name, _case(np.load(GOLDEN), name)) >= 2
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_rollout_oracle_reproduces_the_reference_adapter_bit_for_bit(name):
     blob = np.load(GOLDEN)
@@ -69,10 +144,12 @@ def test_fixture_is_what_the_reference_produces_now():
         pytest.skip("needs /root/reference (build container only)")
     from oracle import make_rollout_golden as G
     blob = np.load(GOLDEN)
-    for name in sorted(CASES):
-        live = G.run_reference(name)
-        stored = _case(blob, name)
-        assert sorted(live) == sorted(stored), name
-        for k, v in live.items():
-            assert torch.equal(v.detach().cpu().float(), stored[k].float()), (name, k)
-        _check(name, {k: v.detach().cpu() for k, v in live.items()})
+    for cases, run, check in ((CASES, G.run_reference, _check), (FLUX_CASES, G.run_reference_flux, _check_flux),
+                              (QWEN_CASES, G.run_reference_qwen, _check_qwen)):
+        for name in sorted(cases):
+            live = run(name)
+            stored = _case(blob, name)
+            assert sorted(live) == sorted(stored), name
+            for k, v in live.items():
+                assert torch.equal(v.detach().cpu().float(), stored[k].float()), (name, k)
+            check(name, {k: v.detach().cpu() for k, v in live.items()})
