@@ -179,6 +179,50 @@ class FlowMatchEulerDiscreteScheduler:
         return indices[pos].item()
 
 
+class UniPCMultistepScheduler:
+    """Restatement of diffusers' UniPCMultistepScheduler for the part the GRPO rollout uses: schedule construction with
+    `use_flow_sigmas=True` (the Wan pipelines) and `index_for_timestep`.  The multistep predictor-corrector `step()` itself (only reached by
+    the reference in evaluation mode, scheduler/unipc_multistep.py:282-285) is NOT restated: it raises."""
+
+    order = 1
+
+    def __init__(self, num_train_timesteps: int = 1000, solver_order: int = 2, prediction_type: str = "flow_prediction",
+                 use_flow_sigmas: bool = True, flow_shift: float = 3.0, final_sigmas_type: str = "zero", **unused):
+        if not use_flow_sigmas:
+            raise NotImplementedError("diffusers_stub.UniPCMultistepScheduler: only the use_flow_sigmas schedule is restated")
+        self.config = _FrozenConfig(num_train_timesteps=num_train_timesteps, solver_order=solver_order, prediction_type=prediction_type,
+                                    use_flow_sigmas=use_flow_sigmas, flow_shift=flow_shift, final_sigmas_type=final_sigmas_type)
+        self.timesteps = torch.from_numpy(np.linspace(0, num_train_timesteps - 1, num_train_timesteps, dtype=np.float32)[::-1].copy())
+        self.sigmas = torch.zeros(num_train_timesteps + 1)
+        self.num_inference_steps = None
+        self._step_index = None
+        self._begin_index = None
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        n_train, shift = self.config.num_train_timesteps, self.config.flow_shift
+        alphas = np.linspace(1, 1 / n_train, num_inference_steps + 1)
+        sigmas = 1.0 - alphas
+        sigmas = np.flip(shift * sigmas / (1 + (shift - 1) * sigmas))[:-1].copy()
+        timesteps = (sigmas * n_train).copy()
+        sigma_last = sigmas[-1] if self.config.final_sigmas_type == "sigma_min" else 0.0
+        self.sigmas = torch.from_numpy(np.concatenate([sigmas, [sigma_last]]).astype(np.float32))
+        self.timesteps = torch.from_numpy(timesteps).to(device=device, dtype=torch.int64)
+        self.num_inference_steps = len(timesteps)
+        self._step_index = None
+        self._begin_index = None
+
+    def index_for_timestep(self, timestep, schedule_timesteps=None):
+        if schedule_timesteps is None:
+            schedule_timesteps = self.timesteps
+        indices = (schedule_timesteps == timestep).nonzero()
+        if len(indices) == 0:
+            return len(self.timesteps) - 1
+        return indices[1 if len(indices) > 1 else 0].item()
+
+    def step(self, *a, **k):
+        raise NotImplementedError("diffusers_stub.UniPCMultistepScheduler.step: the multistep solver is not restated (evaluation mode only)")
+
+
 def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timesteps=None, sigmas=None, **kwargs):
     """Restatement of diffusers' pipeline helper `retrieve_timesteps` (sigmas branch)."""
     if timesteps is not None and sigmas is not None:

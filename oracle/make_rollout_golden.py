@@ -260,6 +260,97 @@ def run_reference_qwen(case: str):
                 log_probs=torch.stack([s.log_probs for s in samples]).float(), log_prob_index_map=samples[0].log_prob_index_map)
 
 
+# ---------------------------------------------------------------------------------------------- Wan2.1 / Wan2.2 T2V (models/wan/wan2_t2v.py:234-543)
+# name: (dynamics, guidance, guidance_2, boundary_ratio (None = single transformer), storage, N, sde_steps, num_sde_steps, noise_level)
+WAN_CASES = {
+    "wan21_flow_sde_cfg_fp16": ("Flow-SDE", 5.0, None, None, "fp16", 5, [1, 2, 3], 2, 0.7),
+    "wan22_two_expert_cps": ("CPS", 4.0, 3.0, 0.6, "bf16", 6, [0, 1, 2, 3, 4], 3, 0.8),
+}
+WAN_FRAMES, WAN_TD = 5, 96          # 5 frames -> 2 latent frames; text width
+
+
+def run_reference_wan(case: str):
+    ref_package.install()
+    sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _plugin_fakes as F
+    import torch.nn as nn
+    from contextlib import nullcontext
+    from flow_factory.hparams import Arguments
+    from flow_factory.models.wan.wan2_t2v import Wan2_T2V_Adapter
+    from flow_factory.utils.trajectory_collector import compute_trajectory_indices
+    from oracle import diffusers_stub as D
+    dyn, gs, gs2, ratio, storage, N, sde_steps, n_sde, eta = WAN_CASES[case]
+    cfg = Arguments.load_from_yaml(os.path.join(ref_package.REF_ROOT, "examples/grpo/full/wan21/t2v.yaml"))
+    cfg.training_args.latent_storage_dtype = storage
+    sa = cfg.scheduler_args
+    sa.dynamics_type, sa.noise_level, sa.sde_steps, sa.num_sde_steps, sa.seed = dyn, eta, list(sde_steps), n_sde, 42
+
+    def transformer(expert):
+        tr = F.build_module_tree({"blocks.0.attn1.to_q.weight": (8, 8), "blocks.0.attn1.to_q.bias": (8,)}, buffers=(), cls=F.FakeTransformer).bfloat16()
+        tr.config = types.SimpleNamespace(in_channels=16, out_channels=16, patch_size=(1, 2, 2), num_layers=1, num_attention_heads=1,
+                                          attention_head_dim=128, ffn_dim=64, text_dim=WAN_TD, freq_dim=256, eps=1e-6)
+        tr.forward = lambda hidden_states=None, timestep=None, encoder_hidden_states=None, attention_kwargs=None, return_dict=False: (
+            standin.wan_denoiser(hidden_states, timestep, encoder_hidden_states, expert),)
+        tr.cache_context = lambda name: nullcontext()
+        return tr
+
+    def pipeline():
+        vae = nn.Module()
+        vae.add_module("decoder", nn.Linear(2, 2))
+        vae.config = types.SimpleNamespace(z_dim=16, base_dim=96, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_downsample=(False, True, True),
+                                           latents_mean=[0.0] * 16, latents_std=[1.0] * 16)
+        vae.dtype = torch.float32
+        vae.decode = lambda lat, return_dict=False: (torch.zeros(lat.shape[0], 3, 1 + 4 * (lat.shape[2] - 1), lat.shape[3] * 8, lat.shape[4] * 8),)
+        pipe = types.SimpleNamespace()
+        pipe.transformer, pipe.vae = transformer(0), vae
+        pipe.transformer_2 = transformer(1) if ratio is not None else None
+        pipe.text_encoder, pipe.tokenizer = nn.Linear(2, 2), object()
+        pipe.vae_scale_factor_temporal, pipe.vae_scale_factor_spatial = 4, 8
+        pipe.config = types.SimpleNamespace(boundary_ratio=ratio, expand_timesteps=False)
+        pipe.scheduler = D.UniPCMultistepScheduler(num_train_timesteps=1000, use_flow_sigmas=True, flow_shift=3.0)
+        pipe.video_processor = types.SimpleNamespace(postprocess_video=lambda v, output_type="pt": v)
+        pipe.maybe_free_model_hooks = lambda: None
+        pipe.components = {"transformer": pipe.transformer, "vae": vae, "text_encoder": pipe.text_encoder}
+        if pipe.transformer_2 is not None:
+            pipe.components["transformer_2"] = pipe.transformer_2
+
+        def prepare_latents(batch_size, num_channels_latents, height, width, num_frames, dtype, device, generator, latents=None):
+            # WanPipeline.prepare_latents: one randn of (B, 16, (F - 1) // 4 + 1, H / 8, W / 8) in the requested dtype (fp32 here)
+            shape = (batch_size, num_channels_latents, (int(num_frames) - 1) // 4 + 1, int(height) // 8, int(width) // 8)
+            return D.randn_tensor(shape, generator=generator, device=device, dtype=dtype)
+        pipe.prepare_latents = prepare_latents
+        return pipe
+
+    class Ref(Wan2_T2V_Adapter):
+        def load_pipeline(self):
+            return pipeline()
+
+    ad = Ref(cfg, F.FakeAccelerator())
+    ad.post_init()
+    ad.rollout()
+    g = torch.Generator().manual_seed(41)
+    pe, ne = torch.randn(B, NT, WAN_TD, generator=g).bfloat16(), torch.randn(B, NT, WAN_TD, generator=g).bfloat16()
+    seed = 4000 + sorted(WAN_CASES).index(case)
+    torch.manual_seed(seed)
+    ad.scheduler.set_timesteps(N)                      # train_timesteps (the SDE-step selection) needs a schedule
+    traj = compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N)
+    samples = ad.inference(prompt=["p0", "p1"], negative_prompt=["", ""], height=H, width=W, num_frames=WAN_FRAMES, num_inference_steps=N,
+                           guidance_scale=gs, guidance_scale_2=gs2, prompt_ids=torch.zeros(B, 4, dtype=torch.long), prompt_embeds=pe,
+                           negative_prompt_ids=torch.zeros(B, 4, dtype=torch.long), negative_prompt_embeds=ne, compute_log_prob=True,
+                           trajectory_indices=traj, extra_call_back_kwargs=["next_latents_mean"])
+    sched = ad.scheduler
+    return dict(seed=torch.tensor(seed), guidance=torch.tensor(gs), guidance_2=torch.tensor(gs2 if gs2 is not None else -1.0),
+                boundary_timestep=torch.tensor(ratio * 1000.0 if ratio is not None else -1.0), pe=pe.float(), ne=ne.float(),
+                timesteps=samples[0].timesteps.long(), sigmas=sched.sigmas.float(),
+                noise_levels=torch.tensor([float(sched.get_noise_level_for_timestep(t)) for t in samples[0].timesteps]),
+                all_latents=torch.stack([s.all_latents for s in samples]).float(),
+                latents_dtype=torch.tensor({torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}[samples[0].all_latents.dtype]),
+                latent_index_map=samples[0].latent_index_map, callback_index_map=samples[0].extra_kwargs["callback_index_map"],
+                next_latents_mean=torch.stack([s.extra_kwargs["next_latents_mean"] for s in samples]).float(),
+                log_probs=torch.stack([s.log_probs for s in samples]).float(), log_prob_index_map=samples[0].log_prob_index_map)
+
+
 def main():
     blob = {}
     for case in CASES:
@@ -270,6 +361,9 @@ def main():
             blob[f"{case}/{k}"] = v.detach().cpu().numpy()
     for case in QWEN_CASES:
         for k, v in run_reference_qwen(case).items():
+            blob[f"{case}/{k}"] = v.detach().cpu().numpy()
+    for case in WAN_CASES:
+        for k, v in run_reference_wan(case).items():
             blob[f"{case}/{k}"] = v.detach().cpu().numpy()
     np.savez_compressed(OUT, **blob)
     print(f"wrote {OUT}: {len(blob)} arrays, {os.path.getsize(OUT)} bytes")

@@ -94,8 +94,10 @@ def _populate(module) -> None:
         "diffusers.pipelines.flux.pipeline_flux": {"retrieve_timesteps": D.retrieve_timesteps},
         "diffusers.pipelines.stable_diffusion_3.pipeline_stable_diffusion_3": {"retrieve_timesteps": D.retrieve_timesteps},
         "diffusers.schedulers.scheduling_flow_match_euler_discrete": {"FlowMatchEulerDiscreteScheduler": D.FlowMatchEulerDiscreteScheduler},
-        "diffusers.schedulers": {"FlowMatchEulerDiscreteScheduler": D.FlowMatchEulerDiscreteScheduler},
-        "diffusers": {"FlowMatchEulerDiscreteScheduler": D.FlowMatchEulerDiscreteScheduler},
+        "diffusers.schedulers": {"FlowMatchEulerDiscreteScheduler": D.FlowMatchEulerDiscreteScheduler,
+                                 "UniPCMultistepScheduler": D.UniPCMultistepScheduler},
+        "diffusers": {"FlowMatchEulerDiscreteScheduler": D.FlowMatchEulerDiscreteScheduler, "UniPCMultistepScheduler": D.UniPCMultistepScheduler},
+        "diffusers.schedulers.scheduling_unipc_multistep": {"UniPCMultistepScheduler": D.UniPCMultistepScheduler},
         "diffusers.utils.import_utils": {"is_torch_available": lambda: True,
                                          "is_torch_version": _is_torch_version},
     }

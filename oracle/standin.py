@@ -48,3 +48,15 @@ def qwen_denoiser(hidden_states, timestep, encoder_hidden_states, encoder_hidden
     shp = float(sum(a * b * c for (a, b, c) in img_shapes[0]))
     v = (0.7 * x + 0.3 * torch.roll(x, 1, dims=-1)) * torch.cos(1.3 * t) + 0.8 * torch.sin(3.0 * x) * t + 4.0 * e.reshape(-1, 1, 1) + 0.01 * lens + 1e-4 * shp
     return v.to(torch.bfloat16)
+
+
+def wan_denoiser(hidden_states, timestep, encoder_hidden_states, expert: int = 0) -> torch.Tensor:
+    """The call of `Wan2_T2V_Adapter.forward` (reference models/wan/wan2_t2v.py:505-523): latents (B, 16, T, h, w) cast to the transformer's
+    dtype, the scheduler's INTEGER timestep expanded to the batch, T5 embeddings.  `expert` distinguishes the two Wan2.2 transformers."""
+    x = hidden_states.float()
+    t = timestep.float().reshape(-1, 1, 1, 1, 1) / 1000.0
+    e = encoder_hidden_states.float().mean(dim=(1, 2)).reshape(-1, 1, 1, 1, 1)
+    v = (0.7 * x + 0.3 * torch.roll(x, 1, dims=2)) * torch.cos(1.3 * t) + 0.8 * torch.sin(3.0 * x) * t + 4.0 * e
+    if expert:
+        v = 0.5 * v + 0.1
+    return v.to(torch.bfloat16)

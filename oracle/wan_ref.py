@@ -218,13 +218,15 @@ def unipc_flow_schedule(num_inference_steps: int, flow_shift: float = 3.0, num_t
 
 
 def rollout(sd, cfg: WanConfig, prompt_embeds, negative_prompt_embeds, guidance_scale, init_latents, step_noise, timesteps, sigmas,
-            noise_levels, storage_dtype=torch.float16, dynamics_type="Flow-SDE", compute_log_prob=True, quant=None):
-    """N-step loop: latents (B,16,T,h,w); timesteps int64 (N,); sigma of a step = t / 1000 (unipc_multistep.py:288-291)."""
+            noise_levels, storage_dtype=torch.float16, dynamics_type="Flow-SDE", compute_log_prob=True, quant=None, denoiser=None):
+    """N-step loop: latents (B,16,T,h,w); timesteps int64 (N,); sigma of a step = t / 1000 (unipc_multistep.py:288-291).
+    `denoiser(hidden_states, timestep, encoder_hidden_states)` (tests/test_rollout_control_flow_pin.py) replaces the network AT THE
+    ADAPTER'S CALL (wan2_t2v.py:505-523): latents in the transformer dtype, the integer timestep expanded to the batch."""
     from . import scheduler_ref as S
     from .rollout_ref import cfg_combine_bf16
     N = len(timesteps)
     lat = S.cast_latents(init_latents, storage_dtype)
-    all_lat, lps = [lat], []
+    all_lat, lps, means = [lat], [], []
     sigma_max = float(sigmas[1])
     do_cfg = negative_prompt_embeds is not None and guidance_scale > 1.0
     B = lat.shape[0]
@@ -233,45 +235,54 @@ def rollout(sd, cfg: WanConfig, prompt_embeds, negative_prompt_embeds, guidance_
         t_next = timesteps[i + 1].float() if i + 1 < N else torch.tensor(0.0)
         eta = float(noise_levels[i])
         clp = compute_log_prob and eta > 0
-        x_in = lat.to(torch.bfloat16).float()
-        v = wan_forward(sd, cfg, x_in, t.expand(B), prompt_embeds.float(), quant=quant).to(torch.bfloat16)
+        if denoiser is not None:
+            net = lambda emb: denoiser(lat.to(torch.bfloat16), timesteps[i].expand(B), emb).to(torch.bfloat16)      # noqa: E731
+        else:
+            x_in = lat.to(torch.bfloat16).float()
+            net = lambda emb: wan_forward(sd, cfg, x_in, t.expand(B), emb.float(), quant=quant).to(torch.bfloat16)    # noqa: E731
+        v = net(prompt_embeds)
         if do_cfg:
-            vu = wan_forward(sd, cfg, x_in, t.expand(B), negative_prompt_embeds.float(), quant=quant).to(torch.bfloat16)
-            v = cfg_combine_bf16(vu, v, guidance_scale)
+            v = cfg_combine_bf16(net(negative_prompt_embeds), v, guidance_scale)
         out = S.sde_step(v, lat, t / 1000, t_next / 1000, eta, dynamics_type=dynamics_type, sigma_max=sigma_max,
                          variance_noise=step_noise[i], compute_log_prob=clp)
         lat = S.cast_latents(out["next_latents"], storage_dtype)
         all_lat.append(lat)
         lps.append(out["log_prob"] if clp else torch.full((B,), float("nan")))
-    return dict(all_latents=torch.stack(all_lat, 0), log_probs=torch.stack(lps, 0))
+        means.append(out["next_latents_mean"])
+    return dict(all_latents=torch.stack(all_lat, 0), log_probs=torch.stack(lps, 0), next_latents_means=torch.stack(means, 0))
 
 
 def rollout_two_expert(sd_hi, sd_lo, cfg: WanConfig, boundary_timestep, prompt_embeds, negative_prompt_embeds, guidance_scale, guidance_scale_2,
                        init_latents, step_noise, timesteps, sigmas, noise_levels, storage_dtype=torch.float16, dynamics_type="Flow-SDE",
-                       compute_log_prob=True):
+                       compute_log_prob=True, denoisers=None):
     """Wan2.2 two-expert loop (reference wan2_t2v.py:476-487 inside the loop of :344-376): the high-noise expert with `guidance_scale`
     while t >= boundary_timestep, the low-noise expert with `guidance_scale_2` below; CFG is decided per expert."""
     from . import scheduler_ref as S
     from .rollout_ref import cfg_combine_bf16
     N = len(timesteps)
     lat = S.cast_latents(init_latents, storage_dtype)
-    all_lat, lps = [lat], []
+    all_lat, lps, means = [lat], [], []
     sigma_max = float(sigmas[1])
     B = lat.shape[0]
     for i in range(N):
         t = timesteps[i].float()
         t_next = timesteps[i + 1].float() if i + 1 < N else torch.tensor(0.0)
-        sd, g = (sd_hi, guidance_scale) if float(t) >= boundary_timestep else (sd_lo, guidance_scale_2)
+        hi = float(t) >= boundary_timestep
+        sd, g = (sd_hi, guidance_scale) if hi else (sd_lo, guidance_scale_2)
         eta = float(noise_levels[i])
         clp = compute_log_prob and eta > 0
-        x_in = lat.to(torch.bfloat16).float()
-        v = wan_forward(sd, cfg, x_in, t.expand(B), prompt_embeds.float()).to(torch.bfloat16)
+        if denoisers is not None:             # (high-noise, low-noise) stand-ins at the adapter's transformer call
+            net = lambda emb: denoisers[0 if hi else 1](lat.to(torch.bfloat16), timesteps[i].expand(B), emb).to(torch.bfloat16)    # noqa: E731
+        else:
+            x_in = lat.to(torch.bfloat16).float()
+            net = lambda emb: wan_forward(sd, cfg, x_in, t.expand(B), emb.float()).to(torch.bfloat16)                            # noqa: E731
+        v = net(prompt_embeds)
         if negative_prompt_embeds is not None and g > 1.0:
-            vu = wan_forward(sd, cfg, x_in, t.expand(B), negative_prompt_embeds.float()).to(torch.bfloat16)
-            v = cfg_combine_bf16(vu, v, g)
+            v = cfg_combine_bf16(net(negative_prompt_embeds), v, g)
         out = S.sde_step(v, lat, t / 1000, t_next / 1000, eta, dynamics_type=dynamics_type, sigma_max=sigma_max,
                          variance_noise=step_noise[i], compute_log_prob=clp)
         lat = S.cast_latents(out["next_latents"], storage_dtype)
         all_lat.append(lat)
         lps.append(out["log_prob"] if clp else torch.full((B,), float("nan")))
-    return dict(all_latents=torch.stack(all_lat, 0), log_probs=torch.stack(lps, 0))
+        means.append(out["next_latents_mean"])
+    return dict(all_latents=torch.stack(all_lat, 0), log_probs=torch.stack(lps, 0), next_latents_means=torch.stack(means, 0))

@@ -132,6 +132,41 @@ def test_qwen_rollout_oracle_reproduces_the_reference_adapter_bit_for_bit(name):
     assert _check_qwen(name, _case(np.load(GOLDEN), name)) >= 2
 
 
+WAN_CASES = {"wan21_flow_sde_cfg_fp16": "Flow-SDE", "wan22_two_expert_cps": "CPS"}
+
+
+def _check_wan(name, ref):
+    """`Wan2_T2V_Adapter.inference` / `.forward` (reference models/wan/wan2_t2v.py:234-543) on the reference's own `UniPCMultistepSDEScheduler`
+    rollout branch vs `oracle.wan_ref.rollout` / `rollout_two_expert`: latents and step noise drawn in fp32, the transformer sees them in its
+    own dtype with the INTEGER timestep, cond / uncond passes combined in bf16; Wan2.2: the expert and its guidance scale chosen per step by
+    `t >= boundary_ratio * 1000`."""
+    from functools import partial
+    from oracle import wan_ref as W
+    storage = DT[int(ref["latents_dtype"])]
+    B, _, C, T, h, w = ref["all_latents"].shape
+    N = ref["timesteps"].numel()
+    pe, ne = ref["pe"].bfloat16(), ref["ne"].bfloat16()
+    torch.manual_seed(int(ref["seed"]))
+    init = torch.randn(B, C, T, h, w, dtype=torch.float32)
+    noise = torch.stack([torch.randn(B, C, T, h, w, dtype=torch.float32) for _ in range(N)])
+    nl = [float(x) for x in ref["noise_levels"]]
+    ts = ref["timesteps"].long()
+    f0, f1 = partial(standin.wan_denoiser, expert=0), partial(standin.wan_denoiser, expert=1)
+    if float(ref["boundary_timestep"]) < 0:
+        out = W.rollout(None, None, pe, ne, float(ref["guidance"]), init, noise, ts, ref["sigmas"], nl, storage, dynamics_type=WAN_CASES[name],
+                        denoiser=f0)
+    else:
+        out = W.rollout_two_expert(None, None, None, float(ref["boundary_timestep"]), pe, ne, float(ref["guidance"]), float(ref["guidance_2"]),
+                                   init, noise, ts, ref["sigmas"], nl, storage, dynamics_type=WAN_CASES[name], denoisers=(f0, f1))
+        assert any(float(t) >= float(ref["boundary_timestep"]) for t in ts) and any(float(t) < float(ref["boundary_timestep"]) for t in ts)
+    return _compare(name, ref, out, N, nl)
+
+
+@pytest.mark.parametrize("name", sorted(WAN_CASES))
+def test_wan_rollout_oracle_reproduces_the_reference_adapter_bit_for_bit(name):
+    assert _check_wan(name, _case(np.load(GOLDEN), name)) >= 2
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_rollout_oracle_reproduces_the_reference_adapter_bit_for_bit(name):
     blob = np.load(GOLDEN)
@@ -145,7 +180,7 @@ def test_fixture_is_what_the_reference_produces_now():
     from oracle import make_rollout_golden as G
     blob = np.load(GOLDEN)
     for cases, run, check in ((CASES, G.run_reference, _check), (FLUX_CASES, G.run_reference_flux, _check_flux),
-                              (QWEN_CASES, G.run_reference_qwen, _check_qwen)):
+                              (QWEN_CASES, G.run_reference_qwen, _check_qwen), (WAN_CASES, G.run_reference_wan, _check_wan)):
         for name in sorted(cases):
             live = run(name)
             stored = _case(blob, name)
