@@ -5,7 +5,9 @@ CPU fp32 restatement of the FLUX.1 transformer forward and the Flow-Factory FLUX
 :294-346 -- packed latents (B, h/2*w/2, 64), `timestep = t / 1000`, embedded guidance (no CFG), `txt_ids` zeros,
 `img_ids` from `prepare_latents`, then the same `FlowMatchEulerDiscreteSDEScheduler.step`).
 
-PARITY UNPINNED (as oracle/mmditx_ref.py): the model body is diffusers' `FluxTransformer2DModel` (un-vendored third-party
+The rollout CONTROL FLOW (`rollout`, `forward_step`) is PINNED bit for bit against the reference's own `Flux1Adapter`
+(tests/test_rollout_control_flow_pin.py, oracle/make_rollout_golden.py).
+NETWORK BODY: PARITY UNPINNED (as oracle/mmditx_ref.py): the model body is diffusers' `FluxTransformer2DModel` (un-vendored third-party
 dependency, not installed here); it is restated from the published architecture with HF state-dict names:
   x_embedder / context_embedder / time_text_embed.{timestep,guidance,text}_embedder,
   19 x FluxTransformerBlock (AdaLayerNormZero x2, joint attention with per-head RMSNorm q/k and RoPE over

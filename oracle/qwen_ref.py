@@ -6,7 +6,9 @@ CPU fp32 restatement of the Qwen-Image transformer forward and the Flow-Factory 
 per-prompt text lengths, `comb = neg + g (pos - neg)` rescaled to the norm of the cond prediction (:579-587), then the same
 `FlowMatchEulerDiscreteSDEScheduler.step`).
 
-PARITY UNPINNED (as oracle/mmditx_ref.py): the model body is diffusers' `QwenImageTransformer2DModel` (un-vendored third-party
+The rollout CONTROL FLOW (`rollout`, `forward_step`, `cfg_rescale_bf16`) is PINNED bit for bit against the reference's own
+`QwenImageAdapter` incl. ragged prompts (tests/test_rollout_control_flow_pin.py, oracle/make_rollout_golden.py).
+NETWORK BODY: PARITY UNPINNED (as oracle/mmditx_ref.py): the model body is diffusers' `QwenImageTransformer2DModel` (un-vendored third-party
 dependency, constraint diffusers>=0.36.0, not installed here); it is restated from the published architecture with HF state-dict names:
   img_in Linear(64, D) / txt_norm RMSNorm(3584) / txt_in Linear(3584, D) / time_text_embed.timestep_embedder (Timesteps(256,
   flip_sin_to_cos, scale=1000) -> Linear, SiLU, Linear), 60 x QwenImageTransformerBlock (img_mod / txt_mod = SiLU + Linear(D, 6D) chunked

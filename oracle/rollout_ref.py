@@ -11,6 +11,9 @@ CPU restatement of the rollout control flow of the reference adapter:
   4. CFG combine `u + g*(c-u)` is evaluated in bf16 op by op (sd3_5.py:431-433);
   5. step() upcasts to fp32, draws eps in fp32, rounds x' to the storage dtype (:362).
 
+PINNED: with `oracle.standin.denoiser` in place of the network this loop reproduces the reference's own `SD3_5Adapter.inference()` bit for
+bit (tests/test_rollout_control_flow_pin.py; fixture generator oracle/make_rollout_golden.py).
+
 RNG: the caller passes `init_latents` and `step_noise[N]`, drawn in the reference's
 order (prepare_latents, then one fp32 randn per step -- also on eta=0 steps) so that the
 HIP engine and this oracle consume identical numbers.

@@ -6,7 +6,9 @@ latents (B, 16, T, h, w) fp32 -> storage dtype, `timestep = t.expand(B)` with t 
 cond / uncond passes combined as `u + g (c - u)`, then `UniPCMultistepSDEScheduler.step`, whose train / rollout branch
 (scheduler/unipc_multistep.py:296-421) is the same four dynamics as the flow-match Euler SDE step with sigma = t / 1000).
 
-PARITY UNPINNED: the model body is diffusers' `WanTransformer3DModel` (un-vendored third-party dependency); restated from the
+The rollout CONTROL FLOW (`rollout`, `rollout_two_expert`) is PINNED bit for bit against the reference's own `Wan2_T2V_Adapter` and
+`UniPCMultistepSDEScheduler` (tests/test_rollout_control_flow_pin.py, oracle/make_rollout_golden.py).
+NETWORK BODY: PARITY UNPINNED: the model body is diffusers' `WanTransformer3DModel` (un-vendored third-party dependency); restated from the
 published architecture with HF state-dict names:
   patch_embedding Conv3d(16, D, k = s = (1, 2, 2)); WanRotaryPosEmbed (head_dim 128 split t/h/w = 44/42/42, adjacent pairs, float64
   angles); condition_embedder {time_embedder (sinusoidal 256 -> D -> D), time_proj Linear(D, 6D) on silu(temb), text_embedder
