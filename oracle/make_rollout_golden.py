@@ -47,8 +47,10 @@ def _pipeline(tcfg, transformer):
     return pipe
 
 
-def run_reference(case: str):
-    """-> dict of tensors: the inputs handed to the reference adapter and what its samples hold."""
+def run_reference(case: str, adapter_base=None):
+    """-> dict of tensors: the inputs handed to the reference adapter and what its samples hold.  `adapter_base`: run the SAME
+    construction and call on another adapter class (the Flow-Factory plugin class with an engine double:
+    tests/test_rollout_control_flow_pin.py::test_plugin_host_path_reproduces_the_reference_adapter)."""
     ref_package.install()
     sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -68,7 +70,7 @@ def run_reference(case: str):
     tr.forward = lambda hidden_states=None, timestep=None, encoder_hidden_states=None, pooled_projections=None, joint_attention_kwargs=None, \
         return_dict=False: (standin.denoiser(hidden_states, timestep, encoder_hidden_states, pooled_projections),)
 
-    class Ref(SD3_5Adapter):
+    class Ref(adapter_base or SD3_5Adapter):
         def load_pipeline(self):
             return _pipeline(tcfg, tr)
 

@@ -455,3 +455,59 @@ class TrainerAccelerator(FakeAccelerator):
 
     def wait_for_everyone(self):
         pass
+
+
+# --------------------------------------------------------------------------------------- engine double that computes (oracle + stand-in)
+class StandinPlan(FakePlan):
+    """Plan double whose rollout / single step ARE computed: the oracle's SDE step (`oracle.scheduler_ref`, pinned bit-exact against the
+    reference's scheduler) around `oracle.standin.denoiser` in place of the network.  With it the plugin's host path -- RNG draws, schedule,
+    noise levels, kept positions, collectors, sample construction -- can be compared with the reference adapter's results on CPU."""
+
+    def _net(self, latents, t, enc_a, pool_a, enc_b, pool_b, guidance):
+        from oracle import rollout_ref as R
+        from oracle import standin
+        B = latents.shape[0]
+        tt = torch.as_tensor(t, dtype=torch.float32).reshape(-1)
+        timestep = (tt.expand(B) if tt.numel() == 1 else tt).to(latents.dtype)
+        if enc_b is not None:                              # CFG: (enc_a, pool_a) = negative, (enc_b, pool_b) = positive; batch order [neg, pos]
+            v = standin.denoiser(torch.cat([latents, latents]), timestep.repeat(2), torch.cat([enc_a, enc_b]), torch.cat([pool_a, pool_b]))
+            vu, vt = v.chunk(2)
+            return R.cfg_combine_bf16(vu, vt, guidance)
+        return standin.denoiser(latents, timestep, enc_a, pool_a)
+
+    def rollout(self, timesteps, sigmas, noise_levels, dynamics, guidance, init_latents, storage_dtype, step_noise, prompt_embeds, pooled,
+                neg_embeds=None, neg_pooled=None, keep_positions=None, compute_log_prob=True):
+        from oracle import rollout_ref as R
+        from oracle import standin
+        N = len(timesteps)
+        self.engine.calls.append(("rollout", dict(N=N, dynamics=dynamics, guidance=guidance, noise_levels=list(noise_levels),
+                                                   keep=list(keep_positions) if keep_positions is not None else None,
+                                                   weights=self.engine.fingerprint())))
+        if step_noise is None:
+            step_noise = torch.zeros((N,) + tuple(init_latents.shape))
+        out = R.rollout(None, None, prompt_embeds, pooled, neg_embeds, neg_pooled, guidance, init_latents, step_noise,
+                        torch.tensor(timesteps, dtype=torch.float32), torch.tensor(sigmas, dtype=torch.float32), list(noise_levels), storage_dtype,
+                        dynamics_type=dynamics, compute_log_prob=compute_log_prob, denoiser=standin.denoiser)
+        keep = list(range(N + 1)) if keep_positions is None else sorted(set(keep_positions))
+        return torch.stack([out["all_latents"][p] for p in keep]), out["log_probs"], out["all_latents"][N]
+
+    def denoise_step(self, latents, timestep, enc_a, pooled_a, enc_b, pooled_b, guidance, sigma, sigma_next, eta, sigma_max, dynamics,
+                     noise=None, next_latents=None, compute_log_prob=True, want=()):
+        from oracle import scheduler_ref as S
+        self.engine.calls.append(("denoise_step", dict(replay=next_latents is not None, weights=self.engine.fingerprint(), eta=eta)))
+        v = self._net(latents, timestep, enc_a, pooled_a, enc_b, pooled_b, guidance).to(torch.bfloat16)
+        out = S.sde_step(v, latents, torch.as_tensor(sigma, dtype=torch.float32), torch.as_tensor(sigma_next, dtype=torch.float32), float(eta),
+                         dynamics_type=dynamics, sigma_max=sigma_max, variance_noise=noise, next_latents=next_latents,
+                         compute_log_prob=compute_log_prob)
+        o = types.SimpleNamespace(**{k: out.get(k) for k in ("next_latents", "next_latents_mean", "noise_pred", "log_prob", "std_dev_t", "dt")})
+        o.next_storage = S.cast_latents(out["next_latents"], latents.dtype)
+        return o
+
+
+class StandinEngine(FakeEngine):
+    def plan(self, batch, n_cfg, h, w, n_text, max_steps):
+        key = (batch, n_cfg, h, w, n_text)
+        p = self._plans.get(key)
+        if p is None or p.max_steps < max_steps:
+            p = self._plans[key] = StandinPlan(self, key, max_steps)
+        return p

@@ -188,3 +188,36 @@ def test_fixture_is_what_the_reference_produces_now():
             for k, v in live.items():
                 assert torch.equal(v.detach().cpu().float(), stored[k].float()), (name, k)
             check(name, {k: v.detach().cpu() for k, v in live.items()})
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_plugin_host_path_reproduces_the_reference_adapter(name):
+    """The PRODUCT's host path against the reference adapter: the Flow-Factory plugin class (`mi355_flow.flow_factory_plugin.
+    SD3_5NativeAdapter` = reference adapter + rollout mixin) is built and called exactly like the reference adapter was for the fixture,
+    with an engine double that computes (oracle SDE step around the same stand-in network) where libmi355flow.so would.  Everything the
+    mixin does on the host -- the RNG draws and their dtypes, the schedule, the per-step noise levels, which positions / SDE steps are
+    kept, the per-step callback capture, the reference sample class and its index maps -- must reproduce the reference's samples bit for
+    bit; the torch transformer is never called."""
+    import sys
+    import types
+    from oracle import ref_package
+    if not ref_package.available():
+        pytest.skip("needs /root/reference (build container only)")
+    ref_package.install()
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _plugin_fakes as F
+    import mi355_flow.flow_factory_plugin as P
+    from oracle import make_rollout_golden as G
+    if P._RefAdapter is None:
+        import importlib
+        P = importlib.reload(P)
+    saved = (P.Engine, P.VAEDecoder, P.VAEConfig)
+    P.Engine, P.VAEDecoder, P.VAEConfig = F.StandinEngine, F.FakeVAEDecoder, types.SimpleNamespace(from_hf=lambda c: c)
+    try:
+        live = G.run_reference(name, adapter_base=P.SD3_5NativeAdapter)
+    finally:
+        P.Engine, P.VAEDecoder, P.VAEConfig = saved
+    stored = _case(np.load(GOLDEN), name)
+    assert sorted(live) == sorted(stored), name
+    for k, v in live.items():
+        assert torch.equal(v.detach().cpu().float(), stored[k].float()), (name, k)
