@@ -144,7 +144,7 @@ def _flux_pipeline(transformer):
     return pipe
 
 
-def run_reference_flux(case: str):
+def run_reference_flux(case: str, adapter_base=None, callbacks=True):
     ref_package.install()
     sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -163,7 +163,7 @@ def run_reference_flux(case: str):
         img_ids=None, joint_attention_kwargs=None, return_dict=False: (
             standin.flux_denoiser(hidden_states, timestep, guidance, pooled_projections, encoder_hidden_states, txt_ids, img_ids),)
 
-    class Ref(Flux1Adapter):
+    class Ref(adapter_base or Flux1Adapter):
         def load_pipeline(self):
             return _flux_pipeline(tr)
 
@@ -176,8 +176,12 @@ def run_reference_flux(case: str):
     torch.manual_seed(seed)
     traj = compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N)
     samples = ad.inference(prompt=["p0", "p1"], height=H, width=W, num_inference_steps=N, guidance_scale=gs, prompt_embeds=pe,
-                           pooled_prompt_embeds=pp, compute_log_prob=True, trajectory_indices=traj, extra_call_back_kwargs=["next_latents_mean"])
+                           pooled_prompt_embeds=pp, compute_log_prob=True, trajectory_indices=traj,
+                           extra_call_back_kwargs=["next_latents_mean"] if callbacks else [])
     sched = ad.scheduler
+    if not callbacks:
+        for s_ in samples:
+            s_.extra_kwargs["next_latents_mean"] = torch.zeros(0)
     return dict(seed=torch.tensor(seed), guidance=torch.tensor(gs), pe=pe.float(), pp=pp.float(), timesteps=samples[0].timesteps.float(),
                 sigmas=sched.sigmas.float(), noise_levels=torch.tensor([float(sched.get_noise_level_for_timestep(t)) for t in samples[0].timesteps]),
                 all_latents=torch.stack([s.all_latents for s in samples]).float(), img_ids=samples[0].img_ids.float(),
@@ -195,7 +199,7 @@ QWEN_CASES = {
 QJ = 64
 
 
-def run_reference_qwen(case: str):
+def run_reference_qwen(case: str, adapter_base=None, callbacks=True):
     ref_package.install()
     sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -226,7 +230,7 @@ def run_reference_qwen(case: str):
         lat = D.randn_tensor((batch_size, 1, num_channels_latents, h, w), generator=generator, device=device, dtype=dtype)
         return FR.pack_latents(lat[:, 0])
 
-    class Ref(QwenImageAdapter):
+    class Ref(adapter_base or QwenImageAdapter):
         def load_pipeline(self):
             pipe = F.make_qwen_pipeline(tcfg, tr)
             pipe.prepare_latents = prepare_latents
@@ -249,8 +253,11 @@ def run_reference_qwen(case: str):
                            prompt_embeds_mask=[torch.ones(n, dtype=torch.long) for n in lens], prompt_ids=[torch.arange(n) for n in lens],
                            negative_prompt_embeds=ne if gs > 1 else None,
                            negative_prompt_embeds_mask=[torch.ones(n, dtype=torch.long) for n in nlens] if gs > 1 else None,
-                           compute_log_prob=True, trajectory_indices=traj, extra_call_back_kwargs=["next_latents_mean"])
+                           compute_log_prob=True, trajectory_indices=traj, extra_call_back_kwargs=["next_latents_mean"] if callbacks else [])
     sched = ad.scheduler
+    if not callbacks:
+        for s_ in samples:
+            s_.extra_kwargs["next_latents_mean"] = torch.zeros(0)
     pad = lambda seq: torch.nn.utils.rnn.pad_sequence([x.float() for x in seq], batch_first=True)      # noqa: E731
     return dict(seed=torch.tensor(seed), guidance=torch.tensor(gs), pe=pad(pe), ne=pad(ne), lens=torch.tensor(lens), nlens=torch.tensor(nlens),
                 timesteps=samples[0].timesteps.float(), sigmas=sched.sigmas.float(),
@@ -271,7 +278,7 @@ WAN_CASES = {
 WAN_FRAMES, WAN_TD = 5, 96          # 5 frames -> 2 latent frames; text width
 
 
-def run_reference_wan(case: str):
+def run_reference_wan(case: str, adapter_base=None, callbacks=True):
     ref_package.install()
     sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -324,7 +331,7 @@ def run_reference_wan(case: str):
         pipe.prepare_latents = prepare_latents
         return pipe
 
-    class Ref(Wan2_T2V_Adapter):
+    class Ref(adapter_base or Wan2_T2V_Adapter):
         def load_pipeline(self):
             return pipeline()
 
@@ -340,8 +347,11 @@ def run_reference_wan(case: str):
     samples = ad.inference(prompt=["p0", "p1"], negative_prompt=["", ""], height=H, width=W, num_frames=WAN_FRAMES, num_inference_steps=N,
                            guidance_scale=gs, guidance_scale_2=gs2, prompt_ids=torch.zeros(B, 4, dtype=torch.long), prompt_embeds=pe,
                            negative_prompt_ids=torch.zeros(B, 4, dtype=torch.long), negative_prompt_embeds=ne, compute_log_prob=True,
-                           trajectory_indices=traj, extra_call_back_kwargs=["next_latents_mean"])
+                           trajectory_indices=traj, extra_call_back_kwargs=["next_latents_mean"] if callbacks else [])
     sched = ad.scheduler
+    if not callbacks:
+        for s_ in samples:
+            s_.extra_kwargs["next_latents_mean"] = torch.zeros(0)
     return dict(seed=torch.tensor(seed), guidance=torch.tensor(gs), guidance_2=torch.tensor(gs2 if gs2 is not None else -1.0),
                 boundary_timestep=torch.tensor(ratio * 1000.0 if ratio is not None else -1.0), pe=pe.float(), ne=ne.float(),
                 timesteps=samples[0].timesteps.long(), sigmas=sched.sigmas.float(),

@@ -511,3 +511,98 @@ class StandinEngine(FakeEngine):
         if p is None or p.max_steps < max_steps:
             p = self._plans[key] = StandinPlan(self, key, max_steps)
         return p
+
+
+class _StandinFamilyEngine(FakeEngine):
+    """Computing engine double for the FLUX.1 / Qwen-Image / Wan plugin classes: parameter names = whatever tiny module tree the test
+    binds (`NAMES`), `plan(...).rollout(...)` = the family's ORACLE rollout around its stand-in network."""
+
+    NAMES: List[str] = []
+    PLAN = None
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self._names = list(type(self).NAMES)
+        self.bound, self.bind_log, self.calls, self._plans = {}, [], [], {}
+
+    def plan(self, *key):
+        p = self._plans.get(key)
+        if p is None:
+            p = self._plans[key] = type(self).PLAN(self, key)
+        return p
+
+
+def _keep_rows(out, N, keep_positions):
+    keep = list(range(N + 1)) if keep_positions is None else sorted(set(keep_positions))
+    return torch.stack([out["all_latents"][p] for p in keep]), out["log_probs"], out["all_latents"][N]
+
+
+class FluxStandinPlan:
+    def __init__(self, engine, key):
+        self.engine = engine
+        self.batch, self.h, self.w, self.n_text, self.max_steps = key
+
+    def rollout(self, timesteps, sigmas, noise_levels, dynamics, guidance_scale, init_latents, storage_dtype, step_noise, prompt_embeds, pooled,
+                keep_positions=None, compute_log_prob=True):
+        from oracle import flux_ref as FR
+        from oracle import standin
+        self.engine.calls.append(("rollout", dict(N=len(timesteps))))
+        out = FR.rollout(None, None, prompt_embeds, pooled, guidance_scale, init_latents, step_noise, torch.tensor(timesteps, dtype=torch.float32),
+                         torch.tensor(sigmas, dtype=torch.float32), list(noise_levels),
+                         FR.prepare_img_ids(self.h // 2, self.w // 2).to(init_latents.dtype), storage_dtype, dynamics_type=dynamics,
+                         compute_log_prob=compute_log_prob, denoiser=standin.flux_denoiser)
+        return _keep_rows(out, len(timesteps), keep_positions)
+
+
+class FluxStandinEngine(_StandinFamilyEngine):
+    PLAN = FluxStandinPlan
+
+
+class QwenStandinPlan:
+    def __init__(self, engine, key):
+        self.engine = engine
+        self.batch, self.n_cfg, self.h, self.w, self.n_text, self.max_steps = key
+
+    def rollout(self, timesteps, sigmas, noise_levels, dynamics, guidance_scale, init_latents, storage_dtype, step_noise, embeds, lens=None,
+                keep_positions=None, compute_log_prob=True):
+        from oracle import qwen_ref as Q
+        from oracle import standin
+        B = self.batch
+        self.engine.calls.append(("rollout", dict(N=len(timesteps), lens=list(lens), n_cfg=self.n_cfg)))
+        lens = [int(n) for n in lens]
+        # the plugin hands over [negative | positive] halves padded to the plan's text length; the reference pads each call to its own
+        # batch maximum (`_pad_batch_prompt`): cut back so that the stand-in sees tensors of the reference's shapes
+        if self.n_cfg == 2:
+            nl_, pl_ = lens[:B], lens[B:]
+            neg, pos = embeds[:B, :max(nl_)], embeds[B:, :max(pl_)]
+        else:
+            nl_, pl_, neg, pos = None, lens, None, embeds[:, :max(lens)]
+        out = Q.rollout(None, None, pos, pl_, neg, nl_, guidance_scale, init_latents, step_noise, torch.tensor(timesteps, dtype=torch.float32),
+                        torch.tensor(sigmas, dtype=torch.float32), list(noise_levels), self.h // 2, self.w // 2, storage_dtype,
+                        dynamics_type=dynamics, compute_log_prob=compute_log_prob, denoiser=standin.qwen_denoiser)
+        return _keep_rows(out, len(timesteps), keep_positions)
+
+
+class QwenStandinEngine(_StandinFamilyEngine):
+    PLAN = QwenStandinPlan
+
+
+class WanStandinPlan:
+    def __init__(self, engine, key):
+        self.engine = engine
+        self.batch, self.n_cfg, self.T, self.h, self.w, self.n_text, self.max_steps = key
+
+    def rollout(self, timesteps, sigmas, noise_levels, dynamics, guidance, init_latents, storage_dtype, step_noise, prompt_embeds,
+                neg_embeds=None, keep_positions=None, compute_log_prob=True):
+        from functools import partial
+        from oracle import standin
+        from oracle import wan_ref as W
+        self.engine.calls.append(("rollout", dict(N=len(timesteps), n_cfg=self.n_cfg)))
+        out = W.rollout(None, None, prompt_embeds, neg_embeds, guidance, init_latents, step_noise, torch.tensor(timesteps).long(),
+                        torch.tensor(sigmas, dtype=torch.float32), list(noise_levels), storage_dtype, dynamics_type=dynamics,
+                        compute_log_prob=compute_log_prob, denoiser=partial(standin.wan_denoiser, expert=0))
+        return _keep_rows(out, len(timesteps), keep_positions)
+
+
+class WanStandinEngine(_StandinFamilyEngine):
+    PLAN = WanStandinPlan

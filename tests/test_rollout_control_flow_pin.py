@@ -221,3 +221,48 @@ def test_plugin_host_path_reproduces_the_reference_adapter(name):
     assert sorted(live) == sorted(stored), name
     for k, v in live.items():
         assert torch.equal(v.detach().cpu().float(), stored[k].float()), (name, k)
+
+
+@pytest.mark.parametrize("family,name", [("flux", "flux_flow_sde_fp16"), ("flux", "flux_dance_native"), ("qwen", "qwen_flow_sde_cfg_ragged"),
+                                         ("qwen", "qwen_cps_nocfg_fp16"), ("wan", "wan21_flow_sde_cfg_fp16")])
+def test_family_plugin_host_paths_reproduce_the_reference_adapters(family, name):
+    """Same as above for `Flux1NativeAdapter`, `QwenImageNativeAdapter` and `Wan2T2VNativeAdapter` (single transformer): the reference
+    adapter and the plugin class are built and called identically (fused rollouts: no per-step callback tensors), the plugin on an engine
+    double whose `rollout` is the family's oracle loop around the stand-in network.  Samples must agree bit for bit -- packed / 5-D latent
+    draws in the right dtype and order, dynamic shift / UniPC schedules, text padding and lengths, kept positions, sample fields."""
+    import sys
+    import types
+    from oracle import ref_package
+    if not ref_package.available():
+        pytest.skip("needs /root/reference (build container only)")
+    ref_package.install()
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _plugin_fakes as F
+    import mi355_flow.flow_factory_plugin as P
+    import mi355_flow.vae as MV
+    from oracle import make_rollout_golden as G
+    if P._RefAdapter is None:
+        import importlib
+        P = importlib.reload(P)
+    run, attr, eng, names, plug = {
+        "flux": (G.run_reference_flux, "FluxEngine", F.FluxStandinEngine,
+                 ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias", "x_embedder.weight"], "Flux1NativeAdapter"),
+        "qwen": (G.run_reference_qwen, "QwenEngine", F.QwenStandinEngine,
+                 ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias"], "QwenImageNativeAdapter"),
+        "wan": (G.run_reference_wan, "WanEngine", F.WanStandinEngine, ["blocks.0.attn1.to_q.weight", "blocks.0.attn1.to_q.bias"],
+                "Wan2T2VNativeAdapter"),
+    }[family]
+    want = run(name, callbacks=False)                           # the reference's own adapter, live
+    saved = (getattr(P, attr), P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder)
+    eng.NAMES = names
+    setattr(P, attr, eng)
+    P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = F.FakeVAEDecoder, types.SimpleNamespace(from_hf=lambda c: c), F.FakeVideoVAEDecoder
+    try:
+        got = run(name, adapter_base=getattr(P, plug), callbacks=False)
+    finally:
+        setattr(P, attr, saved[0])
+        P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = saved[1:]
+    assert sorted(got) == sorted(want), name
+    for k, v in want.items():
+        assert torch.equal(got[k].detach().cpu().float(), v.detach().cpu().float()), (name, k)
+    assert want["all_latents"].shape[1] >= 2 and want["log_probs"].numel() > 0
