@@ -98,6 +98,22 @@ def run_reference(case: str, adapter_base=None):
     if not is_eval:
         out["log_probs"] = torch.stack([s.log_probs for s in samples]).float()
         out["log_prob_index_map"] = samples[0].log_prob_index_map
+        # the optimize() replay of every trained step (trainers/grpo.py:229-263): `t`, `t_next` as (B,) tensors, the stored (x_i, x_{i+1}),
+        # `noise_level = scheduler.noise_level`; no-grad here (the values are what matters: ratio == exp(replay - rollout) must be 1)
+        lat = torch.stack([s.all_latents for s in samples])
+        lmap, ts = samples[0].latent_index_map, samples[0].timesteps
+        rep = {k: [] for k in ("log_prob", "noise_pred", "next_latents_mean", "std_dev_t", "dt")}
+        with torch.no_grad():
+            for i in [int(j) for j in range(N) if samples[0].log_prob_index_map[j] >= 0]:
+                t_next = ts[i + 1] if i + 1 < N else torch.tensor(0.0)
+                o = ad.forward(t=ts[i].expand(B), t_next=t_next.expand(B), latents=lat[:, lmap[i]], next_latents=lat[:, lmap[i + 1]],
+                               prompt_embeds=pe, pooled_prompt_embeds=pp, negative_prompt_embeds=ne if gs > 1 else None,
+                               negative_pooled_prompt_embeds=npl if gs > 1 else None, guidance_scale=gs, noise_level=sched.noise_level,
+                               compute_log_prob=True, return_kwargs=list(rep))
+                for k in rep:
+                    rep[k].append(getattr(o, k).float())
+        for k, v in rep.items():
+            out["replay_" + k] = torch.stack(v)
     return out
 
 

@@ -54,6 +54,20 @@ def _check(name, ref):
     for i in range(N):
         if cmap[i] >= 0:
             assert torch.equal(out["next_latents_means"][i].float(), ref["next_latents_mean"][:, cmap[i]]), (name, "mean of step", i)
+    if "replay_log_prob" in ref:
+        # optimize()'s replay of the stored transitions (trainers/grpo.py:229-263): the reference's own replay reproduces its rollout
+        # log-probs exactly (train_inference_consistency.md), and the oracle's replay step reproduces every replay output
+        pmap = ref["log_prob_index_map"].long()
+        for j, i in enumerate(i for i in range(N) if pmap[i] >= 0):
+            assert torch.equal(ref["replay_log_prob"][j], ref["log_probs"][:, pmap[i]]), (name, "the reference's own replay ratio != 1", i)
+            x_i, x_n = ref["all_latents"][:, lmap[i]].to(storage), ref["all_latents"][:, lmap[i + 1]].to(storage)
+            t_next = ref["timesteps"][i + 1] if i + 1 < N else torch.tensor(0.0)
+            o = R.forward_step(None, None, ref["timesteps"][i].expand(B), t_next.expand(B), x_i, pe, pp, ne if gs > 1 else None,
+                               npl if gs > 1 else None, gs, noise_level=nl[i], dynamics_type=dyn, sigma_max=float(ref["sigmas"][1]),
+                               next_latents=x_n, compute_log_prob=True, denoiser=standin.denoiser)
+            for k in ("log_prob", "noise_pred", "next_latents_mean", "std_dev_t", "dt"):
+                want = ref["replay_" + k][j]
+                assert torch.equal(o[k].float().reshape(want.shape), want), (name, "replay", k, i)
     return len(kept)
 
 
