@@ -9,6 +9,7 @@ weight liveness across optimizer steps / `use_ref_parameters` / LoRA `disable_ad
 /root/reference does not exist on the GPU box: everything here skips there.
 """
 import inspect
+import os
 import types
 
 import pytest
@@ -592,4 +593,239 @@ def test_matching_loss_trainers_forward_call_reaches_the_native_backward(ref):
     assert wq.grad is not None and float(wq.grad.abs().sum()) > 0
     frozen = [p_ for p_ in tr_mod.parameters() if not p_.requires_grad]
     assert frozen and all(p_.grad is None for p_ in frozen)
+    assert F.FakeTransformer.calls == 0
+
+
+def test_reference_nft_trainer_runs_an_epoch_through_the_plugin(ref):
+    """The reference's own `DiffusionNFTTrainer.sample()` / `.optimize()` (trainers/nft.py:239-471), unmodified, on the SD3.5 plugin:
+    rollouts keep only the final latents (`trajectory_indices=[-1]`, no log-probs), the old-policy predictions are no-grad engine steps at
+    continuous timesteps under `rollout()` mode, the training forward is the engine's differentiable step without a stored transition
+    (`noise_pred` WITH autograd), the KL reference forward runs on the reference weights, gradients reach the torch parameters."""
+    from functools import partial
+    from flow_factory.advantage.advantage_processor import AdvantageProcessor
+    from flow_factory.hparams import Arguments
+    from flow_factory.trainers.nft import DiffusionNFTTrainer
+    from mi355_flow.weights import expected_shapes
+    P = ref
+    cfg = Arguments.load_from_yaml("/root/reference/examples/nft/full/flux1/default.yaml")      # NFT hyper-parameters (no SD3.5 NFT example ships)
+    ta = cfg.training_args
+    ta.kl_beta = 0.05
+    ta.num_batches_per_epoch, ta.per_device_batch_size, ta.group_size, ta.num_inner_epochs = 2, 2, 2, 1
+    ta.height, ta.width, ta.resolution, ta.num_inference_steps, ta.guidance_scale = 256, 256, (256, 256), 6, 1.0
+    ta.num_train_timesteps, ta.off_policy = 2, False
+    tcfg = _tiny_cfg()
+    tr_mod = F.build_module_tree(expected_shapes(tcfg), cls=F.FakeTransformer)
+    real_engine = P.Engine
+    P.Engine = F.DiffFakeEngine
+    try:
+        class Plug(P.SD3_5NativeAdapter):
+            def load_pipeline(self):
+                return F.make_pipeline(tcfg, tr_mod)
+        acc = F.TrainerAccelerator()
+        ad = Plug(cfg, acc)
+        ad.post_init()
+    finally:
+        P.Engine = real_engine
+    eng = ad.engine
+    g = torch.Generator().manual_seed(3)
+    Nt, M, K = 13, 2, 2
+
+    def batch_of(i):
+        pe, pp = torch.randn(1, Nt, 128, generator=g).repeat(K, 1, 1), torch.randn(1, 128, generator=g).repeat(K, 1)
+        return dict(prompt=[f"prompt {i}"] * K, prompt_ids=torch.full((K, 4), i), prompt_embeds=pe, pooled_prompt_embeds=pp)
+
+    class Buffer:
+        def clear(self):
+            pass
+
+        def add_samples(self, s):
+            pass
+
+    logged = []
+    tr = object.__new__(DiffusionNFTTrainer)
+    tr.accelerator, tr.config, tr.training_args, tr.adapter = acc, cfg, ta, ad
+    tr.log_args = types.SimpleNamespace(verbose=False)
+    tr.epoch, tr.step = 0, 0
+    tr.autocast = partial(torch.autocast, device_type="cpu", dtype=torch.bfloat16, enabled=False)
+    tr.dataloader = [batch_of(i) for i in range(M)]
+    tr.reward_buffer = Buffer()
+    tr.log_data = lambda data, step: logged.append((step, dict(data)))
+    tr.advantage_processor = AdvantageProcessor(accelerator=acc, reward_weights={"r": 1.0}, group_size=K, global_std=True,
+                                                sampler_type="group_contiguous", verbose=False)
+    tr.nft_beta, tr.off_policy, tr.kl_type = ta.nft_beta, ta.off_policy, ta.kl_type
+    tr.time_sampling_strategy, tr.time_shift = ta.time_sampling_strategy, ta.time_shift
+    tr.num_train_timesteps, tr.timestep_range = ta.num_train_timesteps, ta.timestep_range
+    trainable = ad.get_trainable_parameters()
+    before = [p_.detach().clone() for p_ in trainable]
+    tr.optimizer = torch.optim.SGD(trainable, lr=500.0)
+
+    samples = tr.sample()
+    assert len(samples) == M * K
+    rolls = [c[1] for c in eng.calls if c[0] == "rollout"]
+    assert len(rolls) == M and rolls[0]["keep"] == [6]                      # trajectory_indices=[-1]: only the final position leaves the engine
+    assert samples[0].all_latents.shape[0] == 1 and samples[0].log_probs is None
+    tr.compute_advantages(samples, {"r": torch.tensor([0.1, 0.9, 0.4, 0.2])}, store_to_samples=True)
+    n0 = len(eng.calls)
+    tr.optimize(samples)
+    kinds = [c[0] for c in eng.calls[n0:]]
+    T = tr.num_train_timesteps
+    # per micro-batch: T old-policy no-grad steps, then per trained timestep one differentiable step + backward + one KL reference step
+    assert kinds.count("denoise_step_train") == M * T and kinds.count("denoise_step_backward") == M * T
+    assert kinds.count("denoise_step") == M * T * 2
+    train_calls = [c[1] for c in eng.calls[n0:] if c[0] == "denoise_step_train"]
+    assert all(c["clp"] is False and c["eta"] == 0.0 for c in train_calls)
+    assert all(c[1] == dict(has_lp=False, has_np=True) for c in eng.calls[n0:] if c[0] == "denoise_step_backward")
+    assert tr.step == len(logged) == M * T
+    assert all(torch.isfinite(torch.as_tensor(v)).all() for _, d in logged for v in d.values())
+    assert logged[0][1]["train/kl_div_max"] == 0.0 and logged[-1][1]["train/kl_div_max"] > 0.0       # policy == reference only before the first step
+    assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable))
+    assert F.FakeTransformer.calls == 0
+
+
+# ------------------------------------------------------------------------------------------------- generic harness: a REAL trainer object
+def _real_trainer(P, trainer_cls, yaml, tweak, batches, K, lr=500.0, engine=None):
+    """Constructs `trainer_cls(accelerator, config, adapter)` through the reference's own `__init__` chain; only `BaseTrainer`'s
+    environment set-up (`_initialization`: dataset / dataloader / reward models / accelerator.prepare, and the logging backend) is
+    replaced by test objects.  Returns (trainer, adapter, torch module, log list)."""
+    from flow_factory.advantage.advantage_processor import AdvantageProcessor
+    from flow_factory.hparams import Arguments
+    from flow_factory.trainers.abc import BaseTrainer
+    from functools import partial
+    from mi355_flow.weights import expected_shapes
+    import tempfile
+    import yaml as Y
+    raw = Y.safe_load(open(yaml))
+    # sizes that validate on one process (the example files are written for 8 GPUs); everything else stays the example's
+    raw["train"].update(per_device_batch_size=2, group_size=2, unique_sample_num_per_epoch=2, resolution=256, num_inference_steps=6)
+    raw["train"].pop("gradient_accumulation_steps", None)
+    raw["model"]["finetune_type"] = "full"                       # (peft is absent here; LoRA binding has its own test)
+    raw["train"]["ema_device"] = raw["train"].get("ref_param_device", "cpu") and "cpu"
+    with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+        Y.safe_dump(raw, f)
+    cfg = Arguments.load_from_yaml(f.name)
+    os.unlink(f.name)
+    tweak(cfg)
+    tcfg = _tiny_cfg()
+    tr_mod = F.build_module_tree(expected_shapes(tcfg), cls=F.FakeTransformer)
+    real_engine = P.Engine
+    P.Engine = engine or F.DiffFakeEngine
+    try:
+        class Plug(P.SD3_5NativeAdapter):
+            def load_pipeline(self):
+                return F.make_pipeline(tcfg, tr_mod)
+        acc = F.TrainerAccelerator()
+        ad = Plug(cfg, acc)
+    finally:
+        P.Engine = real_engine
+
+    class Buffer:
+        def clear(self):
+            pass
+
+        def add_samples(self, s):
+            pass
+
+    logged = []
+
+    def init(self):
+        self.dataloader, self.test_dataloader = list(batches), None
+        self.optimizer = torch.optim.SGD(self.adapter.get_trainable_parameters(), lr=lr)
+        self.reward_buffer = Buffer()
+        self.advantage_processor = AdvantageProcessor(accelerator=self.accelerator, reward_weights={"r": 1.0}, group_size=K, global_std=True,
+                                                      sampler_type="group_contiguous", verbose=False)
+
+    saved = (BaseTrainer._initialization, BaseTrainer._init_logging_backend, BaseTrainer.log_data)
+    BaseTrainer._initialization, BaseTrainer._init_logging_backend = init, lambda self: None
+    BaseTrainer.log_data = lambda self, data, step: logged.append((step, dict(data)))
+    try:
+        tr = trainer_cls(accelerator=acc, config=cfg, adapter=ad)
+    finally:
+        BaseTrainer._initialization, BaseTrainer._init_logging_backend = saved[0], saved[1]
+    tr.log_data = lambda data, step: logged.append((step, dict(data)))
+    BaseTrainer.log_data = saved[2]
+    # (CPU autocast cannot promote the fp16 storage tensors the engine double hands back; on the GPU the trainer's bf16 autocast is on)
+    tr.autocast = partial(torch.autocast, device_type="cpu", dtype=torch.bfloat16, enabled=False)
+    return tr, ad, tr_mod, logged
+
+
+def _prompt_batches(M, K, Nt=13, cfg_pair=False, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(M):
+        b = dict(prompt=[f"prompt {i}"] * K, prompt_ids=torch.full((K, 4), i),
+                 prompt_embeds=torch.randn(1, Nt, 128, generator=g).repeat(K, 1, 1), pooled_prompt_embeds=torch.randn(1, 128, generator=g).repeat(K, 1))
+        if cfg_pair:
+            b.update(negative_prompt_embeds=torch.randn(1, Nt, 128, generator=g).repeat(K, 1, 1),
+                     negative_pooled_prompt_embeds=torch.randn(1, 128, generator=g).repeat(K, 1),
+                     negative_prompt_ids=torch.zeros(K, 4, dtype=torch.long))
+        out.append(b)
+    return out
+
+
+def _small(ta, **extra):
+    ta.num_batches_per_epoch, ta.per_device_batch_size, ta.group_size, ta.num_inner_epochs = 2, 2, 2, 1
+    ta.height, ta.width, ta.resolution, ta.num_inference_steps = 256, 256, (256, 256), 6
+    for k, v in extra.items():
+        setattr(ta, k, v)
+
+
+def test_reference_awm_trainer_runs_an_epoch_through_the_plugin(ref):
+    """The reference's own AWM trainer (trainers/awm.py; examples/awm/lora/sd3_5) constructed through its real `__init__` and run for an
+    epoch on the SD3.5 plugin: final-latent rollouts, matching-loss training forward WITH autograd at sampled timesteps, KL terms."""
+    from flow_factory.trainers.awm import AWMTrainer
+    M, K = 2, 2
+
+    def tweak(cfg):
+        cfg.model_args.finetune_type = "full"                     # (peft is absent here; LoRA binding has its own test)
+        _small(cfg.training_args, guidance_scale=1.0, num_train_timesteps=2, off_policy=False, kl_beta=0.05, ema_kl_beta=0.0)
+    tr, ad, tr_mod, logged = _real_trainer(ref, AWMTrainer, "/root/reference/examples/awm/lora/sd3_5/default.yaml", tweak, _prompt_batches(M, K), K)
+    eng = ad.engine
+    trainable = ad.get_trainable_parameters()
+    before = [p_.detach().clone() for p_ in trainable]
+    samples = tr.sample()
+    assert len(samples) == M * K
+    tr.compute_advantages(samples, {"r": torch.tensor([0.1, 0.9, 0.4, 0.2])}, store_to_samples=True)
+    n0 = len(eng.calls)
+    tr.optimize(samples)
+    kinds = [c[0] for c in eng.calls[n0:]]
+    assert kinds.count("denoise_step_train") >= M and kinds.count("denoise_step_train") == kinds.count("denoise_step_backward")
+    assert all(c[1]["clp"] is False for c in eng.calls[n0:] if c[0] == "denoise_step_train")
+    assert logged and all(torch.isfinite(torch.as_tensor(v)).all() for _, d in logged for v in d.values())
+    assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable))
+    assert F.FakeTransformer.calls == 0
+
+
+@pytest.mark.parametrize("which", ["dgpo", "dpo"])
+def test_reference_dgpo_and_dpo_trainers_run_an_epoch_through_the_plugin(ref, which):
+    """The reference's own DGPO trainer (trainers/dgpo.py -- the trainer of BASELINE.json configs[4]; examples/dgpo/lora/sd3_5) and DPO
+    trainer (trainers/dpo.py; examples/dpo/lora/sd3_5), real `__init__`, one epoch on the SD3.5 plugin."""
+    if which == "dgpo":
+        from flow_factory.trainers.dgpo import DGPOTrainer as Trainer
+        yaml = "/root/reference/examples/dgpo/lora/sd3_5/default.yaml"
+    else:
+        from flow_factory.trainers.dpo import DPOTrainer as Trainer
+        yaml = "/root/reference/examples/dpo/lora/sd3_5/default.yaml"
+    M, K = 2, 2
+
+    def tweak(cfg):
+        cfg.model_args.finetune_type = "full"
+        _small(cfg.training_args, guidance_scale=1.0)
+        for k, v in (("num_train_timesteps", 2), ("off_policy", False)):
+            if hasattr(cfg.training_args, k):
+                setattr(cfg.training_args, k, v)
+    tr, ad, tr_mod, logged = _real_trainer(ref, Trainer, yaml, tweak, _prompt_batches(M, K), K)
+    eng = ad.engine
+    trainable = ad.get_trainable_parameters()
+    before = [p_.detach().clone() for p_ in trainable]
+    samples = tr.sample()
+    assert len(samples) == M * K
+    for s, r in zip(samples, [0.1, 0.9, 0.4, 0.2]):
+        s.extra_kwargs["reward"] = torch.tensor(r)
+    tr.compute_advantages(samples, {"r": torch.tensor([0.1, 0.9, 0.4, 0.2])}, store_to_samples=True) if hasattr(tr, "compute_advantages") else None
+    n0 = len(eng.calls)
+    tr.optimize(samples)
+    kinds = [c[0] for c in eng.calls[n0:]]
+    assert kinds.count("denoise_step_train") >= 1 and kinds.count("denoise_step_train") == kinds.count("denoise_step_backward")
+    assert logged and all(torch.isfinite(torch.as_tensor(v)).all() for _, d in logged for v in d.values() if torch.is_tensor(v) or isinstance(v, float))
+    assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable))
     assert F.FakeTransformer.calls == 0
