@@ -666,6 +666,7 @@ def test_reference_nft_trainer_runs_an_epoch_through_the_plugin(ref):
     assert samples[0].all_latents.shape[0] == 1 and samples[0].log_probs is None
     tr.compute_advantages(samples, {"r": torch.tensor([0.1, 0.9, 0.4, 0.2])}, store_to_samples=True)
     n0 = len(eng.calls)
+    torch.manual_seed(1234)            # timesteps / noise are drawn on the global generator
     tr.optimize(samples)
     kinds = [c[0] for c in eng.calls[n0:]]
     T = tr.num_train_timesteps
@@ -786,6 +787,7 @@ def test_reference_awm_trainer_runs_an_epoch_through_the_plugin(ref):
     assert len(samples) == M * K
     tr.compute_advantages(samples, {"r": torch.tensor([0.1, 0.9, 0.4, 0.2])}, store_to_samples=True)
     n0 = len(eng.calls)
+    torch.manual_seed(1234)            # timesteps / noise are drawn on the global generator
     tr.optimize(samples)
     kinds = [c[0] for c in eng.calls[n0:]]
     assert kinds.count("denoise_step_train") >= M and kinds.count("denoise_step_train") == kinds.count("denoise_step_backward")
@@ -823,9 +825,10 @@ def test_reference_dgpo_and_dpo_trainers_run_an_epoch_through_the_plugin(ref, wh
         s.extra_kwargs["reward"] = torch.tensor(r)
     tr.compute_advantages(samples, {"r": torch.tensor([0.1, 0.9, 0.4, 0.2])}, store_to_samples=True) if hasattr(tr, "compute_advantages") else None
     n0 = len(eng.calls)
+    torch.manual_seed(1234)            # the trainers draw timesteps / noise on the global generator: make the epoch reproducible
     tr.optimize(samples)
     kinds = [c[0] for c in eng.calls[n0:]]
     assert kinds.count("denoise_step_train") >= 1 and kinds.count("denoise_step_train") == kinds.count("denoise_step_backward")
     assert logged and all(torch.isfinite(torch.as_tensor(v)).all() for _, d in logged for v in d.values() if torch.is_tensor(v) or isinstance(v, float))
-    assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable))
+    assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable)), logged
     assert F.FakeTransformer.calls == 0
