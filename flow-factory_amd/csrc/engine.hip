@@ -996,6 +996,14 @@ extern "C" int mi355_op_linear(void* stream, const void* A, const void* W, const
     return 0;
 }
 
+// A/B candidate for the GEMM main loop (gemm_w4.hip; not on the rollout path): bias epilogue only
+extern "C" int mi355_op_linear_w4(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K) {
+    if (!A || !W || !bias || !out) return fail("mi355_op_linear_w4: null argument");
+    if (M % 256 || N % 256 || K % 64) return fail("mi355_op_linear_w4: M %% 256, N %% 256 and K %% 64 must be 0");
+    HIPCHK(launch_gemm_w4((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)out, M, N, K, (hipStream_t)stream));
+    return 0;
+}
+
 // debug: same as mi355_op_linear (act 0) with an s_memtime trace buffer (device, >= 256*16*2*4 int64)
 extern "C" int mi355_op_linear_trace(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                                      void* trace) {

@@ -75,6 +75,8 @@ struct GemmParams {
 };
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);
+// experimental 4-wave / 128x128-per-wave / 32x32x16-MFMA main loop (gemm_w4.hip): out = A . W^T + bias, M % 256 == N % 256 == K % 64 == 0
+hipError_t launch_gemm_w4(const bf16_t* A, const bf16_t* W, const float* bias, bf16_t* out, int M, int N, int K, hipStream_t stream);
 void set_gemm_variant(int v);
 int get_gemm_variant();
 void set_pp_min_tiles(int v);

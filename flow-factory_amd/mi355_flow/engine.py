@@ -407,6 +407,18 @@ def op_linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, act: int = 0
     return out
 
 
+def op_linear_w4(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """A/B candidate for the GEMM main loop (csrc/gemm_w4.hip; unit tests / microbenchmarks only): x @ w.T + bias."""
+    lib = _lib.load()
+    x, w = _bf16c(x), _bf16c(w)
+    bias = bias.to(torch.float32).contiguous()
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty((M, N), device=x.device, dtype=torch.bfloat16)
+    _lib.check(lib.mi355_op_linear_w4(_stream(), _ptr(x), _ptr(w), _ptr(bias), _ptr(out), M, N, K), "op_linear_w4")
+    return out
+
+
 def op_attention(q: torch.Tensor, k: torch.Tensor, vT: torch.Tensor, S: int, n_img: int):
     """q,k: [B,H,S_pad,64] bf16; vT: [B,H,64,S_pad] bf16 -> (o_img [B*n_img, H*64], o_ctx [B*(S-n_img), H*64])."""
     lib = _lib.load()
