@@ -700,7 +700,8 @@ def _real_trainer(P, trainer_cls, yaml, tweak, batches, K, lr=500.0, engine=None
     raw["train"].update(per_device_batch_size=2, group_size=2, unique_sample_num_per_epoch=2, resolution=256, num_inference_steps=6)
     raw["train"].pop("gradient_accumulation_steps", None)
     raw["model"]["finetune_type"] = "full"                       # (peft is absent here; LoRA binding has its own test)
-    raw["train"]["ema_device"] = raw["train"].get("ref_param_device", "cpu") and "cpu"
+    raw["train"]["ema_device"] = "cpu"                             # (the example files say 'cuda')
+    raw["train"]["ref_param_device"] = "cpu"
     with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
         Y.safe_dump(raw, f)
     cfg = Arguments.load_from_yaml(f.name)
@@ -797,16 +798,20 @@ def test_reference_awm_trainer_runs_an_epoch_through_the_plugin(ref):
     assert F.FakeTransformer.calls == 0
 
 
-@pytest.mark.parametrize("which", ["dgpo", "dpo"])
-def test_reference_dgpo_and_dpo_trainers_run_an_epoch_through_the_plugin(ref, which):
+@pytest.mark.parametrize("which", ["dgpo", "dpo", "crd"])
+def test_reference_dgpo_dpo_and_crd_trainers_run_an_epoch_through_the_plugin(ref, which):
     """The reference's own DGPO trainer (trainers/dgpo.py -- the trainer of BASELINE.json configs[4]; examples/dgpo/lora/sd3_5) and DPO
-    trainer (trainers/dpo.py; examples/dpo/lora/sd3_5), real `__init__`, one epoch on the SD3.5 plugin."""
+    trainer (trainers/dpo.py; examples/dpo/lora/sd3_5) and CRD trainer (trainers/crd.py; examples/crd/lora/sd3_5: `old` / `sampling`
+    parameter snapshots swapped in through `use_named_parameters`), real `__init__`, one epoch on the SD3.5 plugin."""
     if which == "dgpo":
         from flow_factory.trainers.dgpo import DGPOTrainer as Trainer
         yaml = "/root/reference/examples/dgpo/lora/sd3_5/default.yaml"
-    else:
+    elif which == "dpo":
         from flow_factory.trainers.dpo import DPOTrainer as Trainer
         yaml = "/root/reference/examples/dpo/lora/sd3_5/default.yaml"
+    else:
+        from flow_factory.trainers.crd import CRDTrainer as Trainer
+        yaml = "/root/reference/examples/crd/lora/sd3_5/default.yaml"
     M, K = 2, 2
 
     def tweak(cfg):
