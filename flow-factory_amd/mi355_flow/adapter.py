@@ -126,16 +126,18 @@ class NativeRolloutMixin:
         h, w = int(height) // VAE_SCALE_FACTOR, int(width) // VAE_SCALE_FACTOR
         N = int(num_inference_steps)
 
-        # RNG, in the reference's order on `generator` (None = the global device generator; a CPU generator draws on the host like
-        # diffusers' randn_tensor): prepare_latents (transformer dtype), then one fp32 draw per step -- also when noise_level == 0,
-        # but none at all under ODE dynamics (flow_match_euler_discrete.py:329-340 draws nothing)
+        # RNG, in the reference's order: prepare_latents on `generator` (transformer dtype; None = the global device generator, a CPU
+        # generator draws on the host like diffusers' randn_tensor), then one fp32 draw per step -- also when noise_level == 0, but none
+        # at all under ODE dynamics (flow_match_euler_discrete.py:329-340 draws nothing).  The step draws ALWAYS come from the global
+        # generator: the reference hands `generator` to `prepare_latents` only (sd3_5.py:242-250), never to `scheduler.step` (:436-446)
+        # (found by tests/test_rollout_control_flow_pin.py::test_differential_sweep_plugin_vs_reference_adapter)
         dyn = self.scheduler.dynamics_type
         latents = randn_tensor((B, C, h, w), generator=generator, device=device, dtype=dtype)
         step_noise = None
         if dyn != "ODE":
             step_noise = torch.empty((N, B, C, h, w), device=device, dtype=torch.float32)
             for i in range(N):
-                step_noise[i] = randn_tensor((B, C, h, w), generator=generator, device=device, dtype=torch.float32)
+                step_noise[i] = randn_tensor((B, C, h, w), generator=None, device=device, dtype=torch.float32)
 
         ps = self.engine.cfg.patch_size
         timesteps = self._set_timesteps(self.scheduler, N, seq_len=(h // ps) * (w // ps), device=device)

@@ -263,7 +263,7 @@ class FluxRolloutMixin:
         if dyn != "ODE":
             step_noise = torch.empty((N, B, Ni, Cl * 4), device=device, dtype=torch.float32)
             for i in range(N):
-                step_noise[i] = randn_tensor((B, Ni, Cl * 4), generator=generator, device=device, dtype=torch.float32)
+                step_noise[i] = randn_tensor((B, Ni, Cl * 4), generator=None, device=device, dtype=torch.float32)
 
         timesteps = self._set_timesteps(self.scheduler, N, seq_len=latents.shape[1], device=device)
         ts_host = [float(t) for t in timesteps.tolist()]

@@ -288,7 +288,7 @@ class WanRolloutMixin:
         if self.scheduler.dynamics_type != "ODE":
             step_noise = torch.empty((N, B, Cl, T, h, w), device=device, dtype=torch.float32)
             for i in range(N):
-                step_noise[i] = randn_tensor((B, Cl, T, h, w), generator=generator, device=device, dtype=torch.float32)
+                step_noise[i] = randn_tensor((B, Cl, T, h, w), generator=None, device=device, dtype=torch.float32)
         ts_host = [float(t) for t in timesteps.tolist()]
         sig_host = [float(s) for s in self.scheduler.sigmas.tolist()]
         eta_host = host_noise_levels(self.scheduler, N)

@@ -47,24 +47,21 @@ def _pipeline(tcfg, transformer):
     return pipe
 
 
-def run_reference(case: str, adapter_base=None):
-    """-> dict of tensors: the inputs handed to the reference adapter and what its samples hold.  `adapter_base`: run the SAME
-    construction and call on another adapter class (the Flow-Factory plugin class with an engine double:
-    tests/test_rollout_control_flow_pin.py::test_plugin_host_path_reproduces_the_reference_adapter)."""
+def build_sd3(adapter_base=None, dyn="Flow-SDE", storage="fp16", sde_steps=(1, 2, 3), n_sde=1, eta=0.7, is_eval=False, seed=42):
+    """The reference's `SD3_5Adapter` (or `adapter_base`: the Flow-Factory plugin class) constructed the way Flow-Factory does, on the
+    pseudo-pipeline with the stand-in transformer, in rollout (or eval) mode."""
     ref_package.install()
     sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _plugin_fakes as F
     from flow_factory.hparams import Arguments
     from flow_factory.models.stable_diffusion.sd3_5 import SD3_5Adapter
-    from flow_factory.utils.trajectory_collector import compute_trajectory_indices
     from mi355_flow.engine import TransformerConfig
     from mi355_flow.weights import expected_shapes
-    dyn, gs, storage, N, sde_steps, n_sde, eta, is_eval = CASES[case]
     cfg = Arguments.load_from_yaml(os.path.join(ref_package.REF_ROOT, "examples/grpo/full/sd3_5/default.yaml"))
     cfg.training_args.latent_storage_dtype = storage
     sa = cfg.scheduler_args
-    sa.dynamics_type, sa.noise_level, sa.sde_steps, sa.num_sde_steps, sa.seed = dyn, eta, list(sde_steps), n_sde, 42
+    sa.dynamics_type, sa.noise_level, sa.sde_steps, sa.num_sde_steps, sa.seed = dyn, eta, list(sde_steps), n_sde, seed
     tcfg = TransformerConfig(num_layers=1, num_heads=1, joint_attention_dim=J, pooled_projection_dim=P, pos_embed_max_size=24, dual_layers=())
     tr = F.build_module_tree(expected_shapes(tcfg), cls=F.FakeTransformer).bfloat16()
     tr.forward = lambda hidden_states=None, timestep=None, encoder_hidden_states=None, pooled_projections=None, joint_attention_kwargs=None, \
@@ -77,13 +74,24 @@ def run_reference(case: str, adapter_base=None):
     ad = Ref(cfg, F.FakeAccelerator())
     ad.post_init()
     ad.eval() if is_eval else ad.rollout()
+    return ad
+
+
+def run_reference(case: str, adapter_base=None, explicit_generator=False):
+    """-> dict of tensors: the inputs handed to the reference adapter and what its samples hold.  `adapter_base`: run the SAME
+    construction and call on another adapter class (the Flow-Factory plugin class with an engine double:
+    tests/test_rollout_control_flow_pin.py::test_plugin_host_path_reproduces_the_reference_adapter)."""
+    ref_package.install()
+    from flow_factory.utils.trajectory_collector import compute_trajectory_indices
+    dyn, gs, storage, N, sde_steps, n_sde, eta, is_eval = CASES[case]
+    ad = build_sd3(adapter_base, dyn, storage, sde_steps, n_sde, eta, is_eval)
     g = torch.Generator().manual_seed(11)
     mk = lambda *s: torch.randn(*s, generator=g).bfloat16()
     pe, pp, ne, npl = mk(B, NT, J), mk(B, P), mk(B, NT, J), mk(B, P)
     seed = 1000 + sorted(CASES).index(case)
     torch.manual_seed(seed)                                  # the reference draws on the global generator (generator=None)
     traj = "all" if is_eval else compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N)
-    samples = ad.inference(prompt=["p0", "p1"], height=H, width=W, num_inference_steps=N, guidance_scale=gs, prompt_embeds=pe,
+    samples = ad.inference(prompt=["p0", "p1"], generator=torch.Generator().manual_seed(77) if explicit_generator else None, height=H, width=W, num_inference_steps=N, guidance_scale=gs, prompt_embeds=pe,
                            pooled_prompt_embeds=pp, negative_prompt_embeds=ne if gs > 1 else None,
                            negative_pooled_prompt_embeds=npl if gs > 1 else None, compute_log_prob=not is_eval, trajectory_indices=traj,
                            extra_call_back_kwargs=["next_latents_mean"])
@@ -160,7 +168,7 @@ def _flux_pipeline(transformer):
     return pipe
 
 
-def run_reference_flux(case: str, adapter_base=None, callbacks=True):
+def run_reference_flux(case: str, adapter_base=None, callbacks=True, explicit_generator=False):
     ref_package.install()
     sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -191,7 +199,7 @@ def run_reference_flux(case: str, adapter_base=None, callbacks=True):
     seed = 2000 + sorted(FLUX_CASES).index(case)
     torch.manual_seed(seed)
     traj = compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N)
-    samples = ad.inference(prompt=["p0", "p1"], height=H, width=W, num_inference_steps=N, guidance_scale=gs, prompt_embeds=pe,
+    samples = ad.inference(prompt=["p0", "p1"], generator=torch.Generator().manual_seed(77) if explicit_generator else None, height=H, width=W, num_inference_steps=N, guidance_scale=gs, prompt_embeds=pe,
                            pooled_prompt_embeds=pp, compute_log_prob=True, trajectory_indices=traj,
                            extra_call_back_kwargs=["next_latents_mean"] if callbacks else [])
     sched = ad.scheduler
@@ -215,7 +223,7 @@ QWEN_CASES = {
 QJ = 64
 
 
-def run_reference_qwen(case: str, adapter_base=None, callbacks=True):
+def run_reference_qwen(case: str, adapter_base=None, callbacks=True, explicit_generator=False):
     ref_package.install()
     sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -265,7 +273,7 @@ def run_reference_qwen(case: str, adapter_base=None, callbacks=True):
     seed = 3000 + sorted(QWEN_CASES).index(case)
     torch.manual_seed(seed)
     traj = compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N)
-    samples = ad.inference(prompt=["p0", "p1"], height=H, width=W, num_inference_steps=N, guidance_scale=gs, prompt_embeds=pe,
+    samples = ad.inference(prompt=["p0", "p1"], generator=torch.Generator().manual_seed(77) if explicit_generator else None, height=H, width=W, num_inference_steps=N, guidance_scale=gs, prompt_embeds=pe,
                            prompt_embeds_mask=[torch.ones(n, dtype=torch.long) for n in lens], prompt_ids=[torch.arange(n) for n in lens],
                            negative_prompt_embeds=ne if gs > 1 else None,
                            negative_prompt_embeds_mask=[torch.ones(n, dtype=torch.long) for n in nlens] if gs > 1 else None,
@@ -294,7 +302,7 @@ WAN_CASES = {
 WAN_FRAMES, WAN_TD = 5, 96          # 5 frames -> 2 latent frames; text width
 
 
-def run_reference_wan(case: str, adapter_base=None, callbacks=True):
+def run_reference_wan(case: str, adapter_base=None, callbacks=True, explicit_generator=False):
     ref_package.install()
     sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -360,7 +368,7 @@ def run_reference_wan(case: str, adapter_base=None, callbacks=True):
     torch.manual_seed(seed)
     ad.scheduler.set_timesteps(N)                      # train_timesteps (the SDE-step selection) needs a schedule
     traj = compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N)
-    samples = ad.inference(prompt=["p0", "p1"], negative_prompt=["", ""], height=H, width=W, num_frames=WAN_FRAMES, num_inference_steps=N,
+    samples = ad.inference(prompt=["p0", "p1"], generator=torch.Generator().manual_seed(77) if explicit_generator else None, negative_prompt=["", ""], height=H, width=W, num_frames=WAN_FRAMES, num_inference_steps=N,
                            guidance_scale=gs, guidance_scale_2=gs2, prompt_ids=torch.zeros(B, 4, dtype=torch.long), prompt_embeds=pe,
                            negative_prompt_ids=torch.zeros(B, 4, dtype=torch.long), negative_prompt_embeds=ne, compute_log_prob=True,
                            trajectory_indices=traj, extra_call_back_kwargs=["next_latents_mean"] if callbacks else [])

@@ -239,7 +239,8 @@ def test_plugin_host_path_reproduces_the_reference_adapter(name):
 
 @pytest.mark.parametrize("family,name", [("flux", "flux_flow_sde_fp16"), ("flux", "flux_dance_native"), ("qwen", "qwen_flow_sde_cfg_ragged"),
                                          ("qwen", "qwen_cps_nocfg_fp16"), ("wan", "wan21_flow_sde_cfg_fp16")])
-def test_family_plugin_host_paths_reproduce_the_reference_adapters(family, name):
+@pytest.mark.parametrize("explicit_generator", [False, True], ids=["global-rng", "explicit-generator"])
+def test_family_plugin_host_paths_reproduce_the_reference_adapters(family, name, explicit_generator):
     """Same as above for `Flux1NativeAdapter`, `QwenImageNativeAdapter` and `Wan2T2VNativeAdapter` (single transformer): the reference
     adapter and the plugin class are built and called identically (fused rollouts: no per-step callback tensors), the plugin on an engine
     double whose `rollout` is the family's oracle loop around the stand-in network.  Samples must agree bit for bit -- packed / 5-D latent
@@ -266,13 +267,14 @@ def test_family_plugin_host_paths_reproduce_the_reference_adapters(family, name)
         "wan": (G.run_reference_wan, "WanEngine", F.WanStandinEngine, ["blocks.0.attn1.to_q.weight", "blocks.0.attn1.to_q.bias"],
                 "Wan2T2VNativeAdapter"),
     }[family]
-    want = run(name, callbacks=False)                           # the reference's own adapter, live
+    # (an explicit `generator` only feeds `prepare_latents` in the reference; the per-step noise stays on the global generator)
+    want = run(name, callbacks=False, explicit_generator=explicit_generator)      # the reference's own adapter, live
     saved = (getattr(P, attr), P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder)
     eng.NAMES = names
     setattr(P, attr, eng)
     P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = F.FakeVAEDecoder, types.SimpleNamespace(from_hf=lambda c: c), F.FakeVideoVAEDecoder
     try:
-        got = run(name, adapter_base=getattr(P, plug), callbacks=False)
+        got = run(name, adapter_base=getattr(P, plug), callbacks=False, explicit_generator=explicit_generator)
     finally:
         setattr(P, attr, saved[0])
         P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = saved[1:]
@@ -280,3 +282,104 @@ def test_family_plugin_host_paths_reproduce_the_reference_adapters(family, name)
     for k, v in want.items():
         assert torch.equal(got[k].detach().cpu().float(), v.detach().cpu().float()), (name, k)
     assert want["all_latents"].shape[1] >= 2 and want["log_probs"].numel() > 0
+
+
+def _sample_fields(samples):
+    """Every tensor a sample carries (incl. extra_kwargs), stacked over the batch, plus the scalar / list fields."""
+    import dataclasses
+    out = {}
+    for f in dataclasses.fields(samples[0]):
+        vals = [getattr(s, f.name) for s in samples]
+        if f.name == "extra_kwargs":
+            for k in sorted(vals[0]):
+                out["extra." + k] = [v[k] for v in vals]
+        else:
+            out[f.name] = vals
+    return out
+
+
+def _assert_same_samples(got, want, ctx):
+    a, b = _sample_fields(got), _sample_fields(want)
+    assert sorted(a) == sorted(b), (ctx, sorted(set(a) ^ set(b)))
+    for k in a:
+        for x, y in zip(a[k], b[k]):
+            if torch.is_tensor(y):
+                assert torch.is_tensor(x) and x.dtype == y.dtype and x.shape == y.shape, (ctx, k, getattr(x, "dtype", None), y.dtype)
+                assert torch.equal(torch.nan_to_num(x.float()), torch.nan_to_num(y.float())), (ctx, k)
+            else:
+                assert x == y, (ctx, k, x, y)
+
+
+@pytest.mark.parametrize("trial", range(24))
+def test_differential_sweep_plugin_vs_reference_adapter(trial):
+    """Differential sweep over the options of `inference()`: dynamics, CFG on / off / requested-without-negatives, storage dtype, step
+    count, SDE-step windows, trajectory selections ('all', None, explicit lists with negative indices), log-probs on / off, callback keys,
+    global vs explicit CPU generator, eval mode.  For every drawn combination the reference's `SD3_5Adapter` and the plugin class (engine
+    double computing the oracle step around the stand-in network) are built and called identically; EVERY field of every returned sample
+    -- tensors with dtype and shape, index maps, extra_kwargs, prompts, sizes -- must be equal."""
+    import random
+    import sys
+    import types
+    from oracle import ref_package
+    if not ref_package.available():
+        pytest.skip("needs /root/reference (build container only)")
+    ref_package.install()
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _plugin_fakes as F
+    import mi355_flow.flow_factory_plugin as P
+    from oracle import make_rollout_golden as G
+    if P._RefAdapter is None:
+        import importlib
+        P = importlib.reload(P)
+    rnd = random.Random(7700 + trial)
+    dyn = rnd.choice(["Flow-SDE", "Dance-SDE", "CPS", "ODE"])
+    storage = rnd.choice(["fp16", "bf16", None])
+    N = rnd.choice([3, 4, 6, 7])
+    window = sorted(rnd.sample(range(N - 1), rnd.randint(1, N - 1)))
+    n_sde = rnd.randint(1, len(window))
+    is_eval = rnd.random() < 0.2
+    cfg_mode = rnd.choice(["cfg", "nocfg", "cfg_without_negatives"])
+    gs = 1.0 if cfg_mode == "nocfg" else rnd.choice([2.0, 4.5])
+    clp = (not is_eval) and dyn != "ODE" and rnd.random() < 0.8
+    # (log-probs with a selection that keeps no SDE step make the reference's own collector stack an empty list: not drawn)
+    traj = rnd.choice(["all", "train"]) if clp else rnd.choice(["all", None, [0, -1], [-1], [1, 2, -2]])
+    callbacks = rnd.choice([[], ["noise_level"], ["next_latents_mean"], ["noise_pred", "std_dev_t", "dt", "noise_level"]])
+    explicit_gen = rnd.random() < 0.4
+    ctx = dict(trial=trial, dyn=dyn, storage=storage, N=N, window=window, n_sde=n_sde, is_eval=is_eval, cfg=cfg_mode, gs=gs, clp=clp,
+               traj=traj, callbacks=callbacks, explicit_gen=explicit_gen)
+    g = torch.Generator().manual_seed(100 + trial)
+    Bq = rnd.choice([1, 2, 3])
+    mk = lambda *s: torch.randn(*s, generator=g).bfloat16()     # noqa: E731
+    pe, pp, ne, npl = mk(Bq, 7, 128), mk(Bq, 128), mk(Bq, 7, 128), mk(Bq, 128)
+
+    def run(base):
+        from flow_factory.utils.trajectory_collector import compute_trajectory_indices
+        ad = G.build_sd3(base, dyn, storage, window, n_sde, 0.7, is_eval, seed=trial)
+        ti = compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N) if traj == "train" else traj
+        torch.manual_seed(4242 + trial)
+        kw = dict(prompt=[f"p{i}" for i in range(Bq)], prompt_ids=torch.arange(Bq * 3).reshape(Bq, 3), height=64, width=96,
+                  num_inference_steps=N, guidance_scale=gs, prompt_embeds=pe, pooled_prompt_embeds=pp, compute_log_prob=clp,
+                  trajectory_indices=ti, extra_call_back_kwargs=list(callbacks),
+                  generator=torch.Generator().manual_seed(9 + trial) if explicit_gen else None)
+        if cfg_mode == "cfg":
+            kw.update(negative_prompt_embeds=ne, negative_pooled_prompt_embeds=npl, negative_prompt_ids=torch.zeros(Bq, 3, dtype=torch.long))
+        return ad.inference(**kw)
+
+    try:
+        want, ref_error = run(None), None
+    except Exception as e:          # noqa: BLE001 -- an option combination the reference itself cannot serve
+        want, ref_error = None, e
+    saved = (P.Engine, P.VAEDecoder, P.VAEConfig)
+    P.Engine, P.VAEDecoder, P.VAEConfig = F.StandinEngine, F.FakeVAEDecoder, types.SimpleNamespace(from_hf=lambda c: c)
+    try:
+        if ref_error is not None:
+            # e.g. log-probs requested while the trajectory selection keeps no SDE step: the reference's collector stacks an empty
+            # list (RuntimeError); the plugin returns no log-probs instead.  Nothing to compare.
+            pytest.skip(f"the reference itself cannot serve this combination: {ref_error!r}")
+        got = run(P.SD3_5NativeAdapter)
+    finally:
+        P.Engine, P.VAEDecoder, P.VAEConfig = saved
+    # (the decoded image comes from a VAE double on both sides: compare everything else)
+    for s_ in list(got) + list(want):
+        s_.image = None
+    _assert_same_samples(got, want, ctx)
