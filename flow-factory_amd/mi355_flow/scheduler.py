@@ -77,14 +77,16 @@ def set_scheduler_timesteps(scheduler, num_inference_steps: int, seq_len: Option
     return scheduler.timesteps
 
 
-def host_noise_levels(scheduler, num_steps: Optional[int] = None) -> List[float]:
+def host_noise_levels(scheduler, num_steps: Optional[int] = None, effective: bool = True) -> List[float]:
     """Per-step noise levels of a rollout as host floats (what `mi355_rollout` consumes: no `.item()` sync per step), derived from
     the PUBLIC SDE-scheduler contract only -- `current_sde_steps`, `noise_level`, `is_eval`, `dynamics_type` (reference
     scheduler/abc.py:76-153, flow_match_euler_discrete.py:126-198) -- so it works on the reference's own scheduler classes under
     the Flow-Factory plugin as well as on the mirrors in this package.  Equals `get_noise_level_for_timestep(t_i)` per step, with
-    the `is_eval` / ODE override of `step()` (:316-317) applied."""
+    the `is_eval` / ODE override of `step()` (:316-317) applied -- `effective=False` leaves that override out: the SCHEDULE's value, which is
+    what the reference's rollout loop hands to its callback collector (`capturable={'noise_level': ...}`, sd3_5.py:274,300) even in
+    evaluation mode."""
     n = int(num_steps) if num_steps is not None else len(scheduler.timesteps)
-    if bool(getattr(scheduler, "is_eval", False)) or getattr(scheduler, "dynamics_type", None) == "ODE":
+    if effective and (bool(getattr(scheduler, "is_eval", False)) or getattr(scheduler, "dynamics_type", None) == "ODE"):
         return [0.0] * n
     cur = {int(i) for i in torch.as_tensor(scheduler.current_sde_steps).reshape(-1).tolist()}
     eta = float(scheduler.noise_level)

@@ -196,7 +196,7 @@ class CollectedRollout:
 
 
 def collect_rollout(trajectory_indices: TrajectoryIndicesType, num_steps: int, latent_at, log_probs, noise_levels, compute_log_prob: bool,
-                    step_outputs=None, extra_keys=()) -> CollectedRollout:
+                    step_outputs=None, extra_keys=(), captured_noise_levels=None) -> CollectedRollout:
     """`latent_at(pos)` -> the stored latents (B, ...) at trajectory position pos (only asked for collected positions);
     `log_probs[i]` (B,) for SDE steps; `step_outputs[i]` the per-step scheduler outputs when callback tensors were requested."""
     N = num_steps
@@ -211,7 +211,7 @@ def collect_rollout(trajectory_indices: TrajectoryIndicesType, num_steps: int, l
         if compute_log_prob and noise_levels[i] > 0:
             lp_c.collect(log_probs[i], i)
         cb_c.collect_step(step_idx=i, output=step_outputs[i] if step_outputs is not None else None, keys=list(extra_keys),
-                          capturable={"noise_level": noise_levels[i]})
+                          capturable={"noise_level": (captured_noise_levels if captured_noise_levels is not None else noise_levels)[i]})
     out = CollectedRollout()
     lats = lat_c.get_result()
     lps = lp_c.get_result() if compute_log_prob else None

@@ -313,7 +313,8 @@ class WanRolloutMixin:
             final = lat_kept[N]
             pos_to_slot = {p: p for p in range(N + 1)}
         traj = collect_rollout(trajectory_indices, N, lambda pos: lat_kept[pos_to_slot[pos]], log_probs, eta_host, compute_log_prob,
-                               step_outputs, extra_call_back_kwargs)
+                               step_outputs, extra_call_back_kwargs,
+                               captured_noise_levels=host_noise_levels(self.scheduler, N, effective=False))
         videos = self.decode_latents(final, output_type="pt")
         return [
             self._sample_cls(

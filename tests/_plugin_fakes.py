@@ -489,13 +489,17 @@ class StandinPlan(FakePlan):
                         torch.tensor(timesteps, dtype=torch.float32), torch.tensor(sigmas, dtype=torch.float32), list(noise_levels), storage_dtype,
                         dynamics_type=dynamics, compute_log_prob=compute_log_prob, denoiser=standin.denoiser)
         keep = list(range(N + 1)) if keep_positions is None else sorted(set(keep_positions))
-        return torch.stack([out["all_latents"][p] for p in keep]), out["log_probs"], out["all_latents"][N]
+        kept = torch.stack([out["all_latents"][p] for p in keep]) if keep else out["all_latents"][:0]
+        return kept, out["log_probs"], out["all_latents"][N]
 
     def denoise_step(self, latents, timestep, enc_a, pooled_a, enc_b, pooled_b, guidance, sigma, sigma_next, eta, sigma_max, dynamics,
                      noise=None, next_latents=None, compute_log_prob=True, want=()):
         from oracle import scheduler_ref as S
         self.engine.calls.append(("denoise_step", dict(replay=next_latents is not None, weights=self.engine.fingerprint(), eta=eta)))
         v = self._net(latents, timestep, enc_a, pooled_a, enc_b, pooled_b, guidance).to(torch.bfloat16)
+        if torch.is_tensor(eta):                          # a per-sample noise level inferred from per-sample sigmas: one value in practice
+            assert bool((eta == eta.reshape(-1)[0]).all()), "the double serves one noise level per call"
+            eta = eta.reshape(-1)[0]
         out = S.sde_step(v, latents, torch.as_tensor(sigma, dtype=torch.float32), torch.as_tensor(sigma_next, dtype=torch.float32), float(eta),
                          dynamics_type=dynamics, sigma_max=sigma_max, variance_noise=noise, next_latents=next_latents,
                          compute_log_prob=compute_log_prob)

@@ -310,7 +310,7 @@ def _assert_same_samples(got, want, ctx):
                 assert x == y, (ctx, k, x, y)
 
 
-@pytest.mark.parametrize("trial", range(24))
+@pytest.mark.parametrize("trial", range(40))
 def test_differential_sweep_plugin_vs_reference_adapter(trial):
     """Differential sweep over the options of `inference()`: dynamics, CFG on / off / requested-without-negatives, storage dtype, step
     count, SDE-step windows, trajectory selections ('all', None, explicit lists with negative indices), log-probs on / off, callback keys,
@@ -383,3 +383,92 @@ def test_differential_sweep_plugin_vs_reference_adapter(trial):
     for s_ in list(got) + list(want):
         s_.image = None
     _assert_same_samples(got, want, ctx)
+
+
+@pytest.mark.parametrize("trial", range(40))
+def test_differential_sweep_forward_plugin_vs_reference_adapter(trial):
+    """The single-step API, `forward()` (no-grad; the rollout step, the KL / old-policy forwards of the trainers, the replay's value path):
+    scalar or per-sample `t`, `t_next` given or derived from the schedule, `noise_level` given or inferred from sigma, a sampling step
+    (fresh noise from the global generator) or the replay of a stored transition, any subset of `return_kwargs`, CFG on / off / without
+    negatives, eval mode -- every returned field must equal the reference adapter's, with dtype and shape."""
+    import random
+    import sys
+    import types
+    from oracle import ref_package
+    if not ref_package.available():
+        pytest.skip("needs /root/reference (build container only)")
+    ref_package.install()
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _plugin_fakes as F
+    import mi355_flow.flow_factory_plugin as P
+    from oracle import make_rollout_golden as G
+    if P._RefAdapter is None:
+        import importlib
+        P = importlib.reload(P)
+    rnd = random.Random(9100 + trial)
+    dyn = rnd.choice(["Flow-SDE", "Dance-SDE", "CPS", "ODE"])
+    storage = rnd.choice(["fp16", "bf16", None])
+    N = rnd.choice([4, 6, 8])
+    window = sorted(rnd.sample(range(N - 1), rnd.randint(1, N - 1)))
+    is_eval = rnd.random() < 0.15
+    cfg_mode = rnd.choice(["cfg", "nocfg", "cfg_without_negatives"])
+    gs = 1.0 if cfg_mode == "nocfg" else rnd.choice([2.0, 4.5])
+    Bq = rnd.choice([1, 2, 3])
+    step = rnd.randrange(N - 1) if dyn == "CPS" else rnd.randrange(N)          # (CPS at the last step: sigma_next = 0, a delta)
+    per_sample_t = rnd.random() < 0.5
+    give_t_next = rnd.random() < 0.6
+    noise_level = rnd.choice([None, 0.0, 0.7])
+    replay = rnd.random() < 0.5
+    clp = dyn != "ODE" and not is_eval and rnd.random() < 0.7 and (noise_level is None or noise_level > 0)
+    keys = ["noise_pred", "next_latents", "next_latents_mean", "std_dev_t", "dt", "log_prob"]
+    return_kwargs = rnd.sample(keys, rnd.randint(1, len(keys)))
+    ctx = dict(trial=trial, dyn=dyn, storage=storage, N=N, window=window, is_eval=is_eval, cfg=cfg_mode, gs=gs, B=Bq, step=step,
+               per_sample_t=per_sample_t, give_t_next=give_t_next, noise_level=noise_level, replay=replay, clp=clp, return_kwargs=return_kwargs)
+    g = torch.Generator().manual_seed(300 + trial)
+    mk = lambda *s: torch.randn(*s, generator=g).bfloat16()     # noqa: E731
+    pe, pp, ne, npl = mk(Bq, 7, 128), mk(Bq, 128), mk(Bq, 7, 128), mk(Bq, 128)
+    sdt = {"fp16": torch.float16, "bf16": torch.bfloat16, None: torch.bfloat16}[storage]
+    x = torch.randn(Bq, 16, 8, 12, generator=g).to(sdt)
+    x_next = (x.float() * 0.9 + 0.1 * torch.randn(Bq, 16, 8, 12, generator=g)).to(sdt)
+
+    def run(base):
+        ad = G.build_sd3(base, dyn, storage, window, 1, 0.7, is_eval, seed=trial)
+        ad.scheduler.set_timesteps(N) if not hasattr(ad.scheduler, "_mi355") else None
+        from flow_factory.scheduler import set_scheduler_timesteps
+        ts = set_scheduler_timesteps(scheduler=ad.scheduler, num_inference_steps=N, seq_len=24, device=torch.device("cpu"))
+        t = ts[step].expand(Bq).clone() if per_sample_t else ts[step]
+        t_next = (ts[step + 1] if step + 1 < N else torch.tensor(0.0))
+        if per_sample_t:
+            t_next = t_next.expand(Bq).clone()
+        kw = dict(t=t, latents=x, prompt_embeds=pe, pooled_prompt_embeds=pp, guidance_scale=gs, compute_log_prob=clp,
+                  return_kwargs=list(return_kwargs), noise_level=noise_level)
+        if give_t_next:
+            kw["t_next"] = t_next
+        if replay:
+            kw["next_latents"] = x_next
+        if cfg_mode == "cfg":
+            kw.update(negative_prompt_embeds=ne, negative_pooled_prompt_embeds=npl)
+        torch.manual_seed(777 + trial)
+        with torch.no_grad():
+            return ad.forward(**kw)
+
+    try:
+        want, ref_error = run(None), None
+    except Exception as e:          # noqa: BLE001
+        want, ref_error = None, e
+    if ref_error is not None:
+        pytest.skip(f"the reference itself cannot serve this combination: {ref_error!r}")
+    saved = (P.Engine, P.VAEDecoder, P.VAEConfig)
+    P.Engine, P.VAEDecoder, P.VAEConfig = F.StandinEngine, F.FakeVAEDecoder, types.SimpleNamespace(from_hf=lambda c: c)
+    try:
+        got = run(P.SD3_5NativeAdapter)
+    finally:
+        P.Engine, P.VAEDecoder, P.VAEConfig = saved
+    for k in keys:
+        a, b = getattr(got, k, None), getattr(want, k, None)
+        if b is None:
+            assert a is None, (ctx, k, "the plugin returns a field the reference leaves out")
+            continue
+        assert a is not None, (ctx, k, "missing")
+        assert a.dtype == b.dtype and a.shape == b.shape, (ctx, k, a.dtype, b.dtype, tuple(a.shape), tuple(b.shape))
+        assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), (ctx, k, float((a.float() - b.float()).abs().max()))
