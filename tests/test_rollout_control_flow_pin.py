@@ -472,3 +472,71 @@ def test_differential_sweep_forward_plugin_vs_reference_adapter(trial):
         assert a is not None, (ctx, k, "missing")
         assert a.dtype == b.dtype and a.shape == b.shape, (ctx, k, a.dtype, b.dtype, tuple(a.shape), tuple(b.shape))
         assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), (ctx, k, float((a.float() - b.float()).abs().max()))
+
+
+@pytest.mark.parametrize("trial", range(24))
+def test_differential_sweep_standalone_adapter_vs_reference_adapter(trial):
+    """The STANDALONE adapter (`mi355_flow.adapter.SD3_5NativeAdapter`: the mixin on this package's own scheduler / collector / sample
+    mirrors -- what bench.py and the GPU tests drive) against the reference's `SD3_5Adapter`, same sweep as above.  The engine is the
+    computing double; the adapter object is assembled without its constructor (which insists on a GPU)."""
+    import random
+    import sys
+    from oracle import ref_package
+    if not ref_package.available():
+        pytest.skip("needs /root/reference (build container only)")
+    ref_package.install()
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _plugin_fakes as F
+    from mi355_flow.adapter import SD3_5NativeAdapter
+    from mi355_flow.engine import TransformerConfig
+    from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
+    from mi355_flow.trajectory import compute_trajectory_indices as mirror_traj
+    from oracle import make_rollout_golden as G
+    rnd = random.Random(5500 + trial)
+    dyn = rnd.choice(["Flow-SDE", "Dance-SDE", "CPS", "ODE"])
+    storage = rnd.choice(["fp16", "bf16", None])
+    N = rnd.choice([3, 4, 6, 7])
+    window = sorted(rnd.sample(range(N - 1), rnd.randint(1, N - 1)))
+    n_sde = rnd.randint(1, len(window))
+    is_eval = rnd.random() < 0.2
+    cfg_mode = rnd.choice(["cfg", "nocfg", "cfg_without_negatives"])
+    gs = 1.0 if cfg_mode == "nocfg" else rnd.choice([2.0, 4.5])
+    clp = (not is_eval) and dyn != "ODE" and rnd.random() < 0.8
+    traj = rnd.choice(["all", "train"]) if clp else rnd.choice(["all", None, [0, -1], [-1], [1, 2, -2]])
+    callbacks = rnd.choice([[], ["noise_level"], ["next_latents_mean"], ["noise_pred", "std_dev_t", "dt", "noise_level"]])
+    explicit_gen = rnd.random() < 0.4
+    ctx = dict(trial=trial, dyn=dyn, storage=storage, N=N, window=window, n_sde=n_sde, is_eval=is_eval, cfg=cfg_mode, gs=gs, clp=clp,
+               traj=traj, callbacks=callbacks, explicit_gen=explicit_gen)
+    g = torch.Generator().manual_seed(100 + trial)
+    Bq = rnd.choice([1, 2, 3])
+    mk = lambda *s: torch.randn(*s, generator=g).bfloat16()     # noqa: E731
+    pe, pp, ne, npl = mk(Bq, 7, 128), mk(Bq, 128), mk(Bq, 7, 128), mk(Bq, 128)
+
+    def call(ad, traj_fn):
+        ti = traj_fn(ad.scheduler.train_timesteps, N) if traj == "train" else traj
+        torch.manual_seed(4242 + trial)
+        kw = dict(prompt=[f"p{i}" for i in range(Bq)], prompt_ids=torch.arange(Bq * 3).reshape(Bq, 3), height=64, width=96,
+                  num_inference_steps=N, guidance_scale=gs, prompt_embeds=pe, pooled_prompt_embeds=pp, compute_log_prob=clp,
+                  trajectory_indices=ti, extra_call_back_kwargs=list(callbacks),
+                  generator=torch.Generator().manual_seed(9 + trial) if explicit_gen else None)
+        if cfg_mode == "cfg":
+            kw.update(negative_prompt_embeds=ne, negative_pooled_prompt_embeds=npl, negative_prompt_ids=torch.zeros(Bq, 3, dtype=torch.long))
+        return ad.inference(**kw)
+
+    from flow_factory.utils.trajectory_collector import compute_trajectory_indices as ref_traj
+    try:
+        want = call(G.build_sd3(None, dyn, storage, window, n_sde, 0.7, is_eval, seed=trial),
+                    lambda tt, n: ref_traj(train_timestep_indices=tt, num_inference_steps=n))
+    except Exception as e:          # noqa: BLE001
+        pytest.skip(f"the reference itself cannot serve this combination: {e!r}")
+    tcfg = TransformerConfig(num_layers=1, num_heads=1, joint_attention_dim=128, pooled_projection_dim=128, pos_embed_max_size=24, dual_layers=())
+    ad = object.__new__(SD3_5NativeAdapter)
+    ad.device, ad.transformer_dtype, ad._latent_storage = torch.device("cpu"), torch.bfloat16, storage
+    ad.scheduler = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=window, num_sde_steps=n_sde, seed=trial, dynamics_type=dyn, shift=3.0)
+    ad.engine, ad._live_weights = F.StandinEngine(tcfg), None
+    ad._vae_decode, ad.vae_decoder, ad.vae_max_batch = None, None, 4
+    ad.eval() if is_eval else ad.rollout()
+    got = call(ad, lambda tt, n: mirror_traj(tt, n))
+    for s_ in want:
+        s_.image = None
+    _assert_same_samples(got, want, ctx)
