@@ -99,9 +99,9 @@ def run_reference(case: str, adapter_base=None, explicit_generator=False):
     out = dict(seed=torch.tensor(seed), is_eval=torch.tensor(int(is_eval)), pe=pe.float(), pp=pp.float(), ne=ne.float(), npl=npl.float(),
                timesteps=samples[0].timesteps.float(), sigmas=sched.sigmas.float(),
                noise_levels=torch.tensor([float(sched.get_noise_level_for_timestep(t)) for t in samples[0].timesteps]),
-               all_latents=torch.stack([s.all_latents for s in samples]).float(),
-               latents_dtype=torch.tensor({torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}[samples[0].all_latents.dtype]),
-               latent_index_map=samples[0].latent_index_map, callback_index_map=samples[0].extra_kwargs["callback_index_map"],
+               all_latents=(torch.stack([s.all_latents for s in samples]).float() if samples[0].all_latents is not None else torch.zeros(0)),
+               latents_dtype=torch.tensor({torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}[samples[0].all_latents.dtype] if samples[0].all_latents is not None else -1),
+               latent_index_map=(samples[0].latent_index_map if samples[0].latent_index_map is not None else torch.zeros(0)), callback_index_map=samples[0].extra_kwargs["callback_index_map"],
                next_latents_mean=torch.stack([s.extra_kwargs["next_latents_mean"] for s in samples]).float())
     if not is_eval:
         out["log_probs"] = torch.stack([s.log_probs for s in samples]).float()
@@ -168,7 +168,7 @@ def _flux_pipeline(transformer):
     return pipe
 
 
-def run_reference_flux(case: str, adapter_base=None, callbacks=True, explicit_generator=False):
+def run_reference_flux(case, adapter_base=None, callbacks=True, explicit_generator=False, traj="train", clp=True, seed=None):
     ref_package.install()
     sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -176,7 +176,7 @@ def run_reference_flux(case: str, adapter_base=None, callbacks=True, explicit_ge
     from flow_factory.hparams import Arguments
     from flow_factory.models.flux.flux1 import Flux1Adapter
     from flow_factory.utils.trajectory_collector import compute_trajectory_indices
-    dyn, gs, storage, N, sde_steps, n_sde, eta = FLUX_CASES[case]
+    dyn, gs, storage, N, sde_steps, n_sde, eta = FLUX_CASES[case] if isinstance(case, str) else case
     cfg = Arguments.load_from_yaml(os.path.join(ref_package.REF_ROOT, "examples/grpo/full/flux1/default.yaml"))
     cfg.training_args.latent_storage_dtype = storage
     sa = cfg.scheduler_args
@@ -196,11 +196,12 @@ def run_reference_flux(case: str, adapter_base=None, callbacks=True, explicit_ge
     ad.rollout()
     g = torch.Generator().manual_seed(21)
     pe, pp = torch.randn(B, NT, J, generator=g).bfloat16(), torch.randn(B, P, generator=g).bfloat16()
-    seed = 2000 + sorted(FLUX_CASES).index(case)
+    seed = (2000 + sorted(FLUX_CASES).index(case)) if seed is None else seed
     torch.manual_seed(seed)
-    traj = compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N)
+    if traj == "train":
+        traj = compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N)
     samples = ad.inference(prompt=["p0", "p1"], generator=torch.Generator().manual_seed(77) if explicit_generator else None, height=H, width=W, num_inference_steps=N, guidance_scale=gs, prompt_embeds=pe,
-                           pooled_prompt_embeds=pp, compute_log_prob=True, trajectory_indices=traj,
+                           pooled_prompt_embeds=pp, compute_log_prob=clp, trajectory_indices=traj,
                            extra_call_back_kwargs=["next_latents_mean"] if callbacks else [])
     sched = ad.scheduler
     if not callbacks:
@@ -208,11 +209,12 @@ def run_reference_flux(case: str, adapter_base=None, callbacks=True, explicit_ge
             s_.extra_kwargs["next_latents_mean"] = torch.zeros(0)
     return dict(seed=torch.tensor(seed), guidance=torch.tensor(gs), pe=pe.float(), pp=pp.float(), timesteps=samples[0].timesteps.float(),
                 sigmas=sched.sigmas.float(), noise_levels=torch.tensor([float(sched.get_noise_level_for_timestep(t)) for t in samples[0].timesteps]),
-                all_latents=torch.stack([s.all_latents for s in samples]).float(), img_ids=samples[0].img_ids.float(),
-                latents_dtype=torch.tensor({torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}[samples[0].all_latents.dtype]),
-                latent_index_map=samples[0].latent_index_map, callback_index_map=samples[0].extra_kwargs["callback_index_map"],
+                all_latents=(torch.stack([s.all_latents for s in samples]).float() if samples[0].all_latents is not None else torch.zeros(0)), img_ids=samples[0].img_ids.float(),
+                latents_dtype=torch.tensor({torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}[samples[0].all_latents.dtype] if samples[0].all_latents is not None else -1),
+                latent_index_map=(samples[0].latent_index_map if samples[0].latent_index_map is not None else torch.zeros(0)), callback_index_map=samples[0].extra_kwargs["callback_index_map"],
                 next_latents_mean=torch.stack([s.extra_kwargs["next_latents_mean"] for s in samples]).float(),
-                log_probs=torch.stack([s.log_probs for s in samples]).float(), log_prob_index_map=samples[0].log_prob_index_map)
+                **({} if samples[0].log_probs is None else dict(log_probs=torch.stack([s.log_probs for s in samples]).float(),
+                                                                 log_prob_index_map=samples[0].log_prob_index_map)))
 
 
 # ---------------------------------------------------------------------------------------------- Qwen-Image (models/qwen_image/qwen_image.py:288-600)
@@ -223,7 +225,7 @@ QWEN_CASES = {
 QJ = 64
 
 
-def run_reference_qwen(case: str, adapter_base=None, callbacks=True, explicit_generator=False):
+def run_reference_qwen(case, adapter_base=None, callbacks=True, explicit_generator=False, traj="train", clp=True, seed=None):
     ref_package.install()
     sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -235,7 +237,7 @@ def run_reference_qwen(case: str, adapter_base=None, callbacks=True, explicit_ge
     from flow_factory.utils.trajectory_collector import compute_trajectory_indices
     from oracle import diffusers_stub as D
     from oracle import flux_ref as FR
-    dyn, gs, storage, N, sde_steps, n_sde, eta = QWEN_CASES[case]
+    dyn, gs, storage, N, sde_steps, n_sde, eta = QWEN_CASES[case] if isinstance(case, str) else case
     cfg = Arguments.load_from_yaml(os.path.join(ref_package.REF_ROOT, "examples/grpo/full/qwen_image/default.yaml"))
     cfg.training_args.latent_storage_dtype = storage
     sa = cfg.scheduler_args
@@ -270,14 +272,15 @@ def run_reference_qwen(case: str, adapter_base=None, callbacks=True, explicit_ge
     lens, nlens = [5, 9], [3, 3]
     pe = [torch.randn(n, QJ, generator=g).bfloat16() for n in lens]
     ne = [torch.randn(n, QJ, generator=g).bfloat16() for n in nlens]
-    seed = 3000 + sorted(QWEN_CASES).index(case)
+    seed = (3000 + sorted(QWEN_CASES).index(case)) if seed is None else seed
     torch.manual_seed(seed)
-    traj = compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N)
+    if traj == "train":
+        traj = compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N)
     samples = ad.inference(prompt=["p0", "p1"], generator=torch.Generator().manual_seed(77) if explicit_generator else None, height=H, width=W, num_inference_steps=N, guidance_scale=gs, prompt_embeds=pe,
                            prompt_embeds_mask=[torch.ones(n, dtype=torch.long) for n in lens], prompt_ids=[torch.arange(n) for n in lens],
                            negative_prompt_embeds=ne if gs > 1 else None,
                            negative_prompt_embeds_mask=[torch.ones(n, dtype=torch.long) for n in nlens] if gs > 1 else None,
-                           compute_log_prob=True, trajectory_indices=traj, extra_call_back_kwargs=["next_latents_mean"] if callbacks else [])
+                           compute_log_prob=clp, trajectory_indices=traj, extra_call_back_kwargs=["next_latents_mean"] if callbacks else [])
     sched = ad.scheduler
     if not callbacks:
         for s_ in samples:
@@ -286,11 +289,12 @@ def run_reference_qwen(case: str, adapter_base=None, callbacks=True, explicit_ge
     return dict(seed=torch.tensor(seed), guidance=torch.tensor(gs), pe=pad(pe), ne=pad(ne), lens=torch.tensor(lens), nlens=torch.tensor(nlens),
                 timesteps=samples[0].timesteps.float(), sigmas=sched.sigmas.float(),
                 noise_levels=torch.tensor([float(sched.get_noise_level_for_timestep(t)) for t in samples[0].timesteps]),
-                all_latents=torch.stack([s.all_latents for s in samples]).float(), hw=torch.tensor([H // 16, W // 16]),
-                latents_dtype=torch.tensor({torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}[samples[0].all_latents.dtype]),
-                latent_index_map=samples[0].latent_index_map, callback_index_map=samples[0].extra_kwargs["callback_index_map"],
+                all_latents=(torch.stack([s.all_latents for s in samples]).float() if samples[0].all_latents is not None else torch.zeros(0)), hw=torch.tensor([H // 16, W // 16]),
+                latents_dtype=torch.tensor({torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}[samples[0].all_latents.dtype] if samples[0].all_latents is not None else -1),
+                latent_index_map=(samples[0].latent_index_map if samples[0].latent_index_map is not None else torch.zeros(0)), callback_index_map=samples[0].extra_kwargs["callback_index_map"],
                 next_latents_mean=torch.stack([s.extra_kwargs["next_latents_mean"] for s in samples]).float(),
-                log_probs=torch.stack([s.log_probs for s in samples]).float(), log_prob_index_map=samples[0].log_prob_index_map)
+                **({} if samples[0].log_probs is None else dict(log_probs=torch.stack([s.log_probs for s in samples]).float(),
+                                                                 log_prob_index_map=samples[0].log_prob_index_map)))
 
 
 # ---------------------------------------------------------------------------------------------- Wan2.1 / Wan2.2 T2V (models/wan/wan2_t2v.py:234-543)
@@ -302,7 +306,7 @@ WAN_CASES = {
 WAN_FRAMES, WAN_TD = 5, 96          # 5 frames -> 2 latent frames; text width
 
 
-def run_reference_wan(case: str, adapter_base=None, callbacks=True, explicit_generator=False):
+def run_reference_wan(case, adapter_base=None, callbacks=True, explicit_generator=False, traj="train", clp=True, seed=None):
     ref_package.install()
     sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -313,7 +317,7 @@ def run_reference_wan(case: str, adapter_base=None, callbacks=True, explicit_gen
     from flow_factory.models.wan.wan2_t2v import Wan2_T2V_Adapter
     from flow_factory.utils.trajectory_collector import compute_trajectory_indices
     from oracle import diffusers_stub as D
-    dyn, gs, gs2, ratio, storage, N, sde_steps, n_sde, eta = WAN_CASES[case]
+    dyn, gs, gs2, ratio, storage, N, sde_steps, n_sde, eta = WAN_CASES[case] if isinstance(case, str) else case
     cfg = Arguments.load_from_yaml(os.path.join(ref_package.REF_ROOT, "examples/grpo/full/wan21/t2v.yaml"))
     cfg.training_args.latent_storage_dtype = storage
     sa = cfg.scheduler_args
@@ -364,13 +368,14 @@ def run_reference_wan(case: str, adapter_base=None, callbacks=True, explicit_gen
     ad.rollout()
     g = torch.Generator().manual_seed(41)
     pe, ne = torch.randn(B, NT, WAN_TD, generator=g).bfloat16(), torch.randn(B, NT, WAN_TD, generator=g).bfloat16()
-    seed = 4000 + sorted(WAN_CASES).index(case)
+    seed = (4000 + sorted(WAN_CASES).index(case)) if seed is None else seed
     torch.manual_seed(seed)
     ad.scheduler.set_timesteps(N)                      # train_timesteps (the SDE-step selection) needs a schedule
-    traj = compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N)
+    if traj == "train":
+        traj = compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N)
     samples = ad.inference(prompt=["p0", "p1"], generator=torch.Generator().manual_seed(77) if explicit_generator else None, negative_prompt=["", ""], height=H, width=W, num_frames=WAN_FRAMES, num_inference_steps=N,
                            guidance_scale=gs, guidance_scale_2=gs2, prompt_ids=torch.zeros(B, 4, dtype=torch.long), prompt_embeds=pe,
-                           negative_prompt_ids=torch.zeros(B, 4, dtype=torch.long), negative_prompt_embeds=ne, compute_log_prob=True,
+                           negative_prompt_ids=torch.zeros(B, 4, dtype=torch.long), negative_prompt_embeds=ne, compute_log_prob=clp,
                            trajectory_indices=traj, extra_call_back_kwargs=["next_latents_mean"] if callbacks else [])
     sched = ad.scheduler
     if not callbacks:
@@ -380,11 +385,12 @@ def run_reference_wan(case: str, adapter_base=None, callbacks=True, explicit_gen
                 boundary_timestep=torch.tensor(ratio * 1000.0 if ratio is not None else -1.0), pe=pe.float(), ne=ne.float(),
                 timesteps=samples[0].timesteps.long(), sigmas=sched.sigmas.float(),
                 noise_levels=torch.tensor([float(sched.get_noise_level_for_timestep(t)) for t in samples[0].timesteps]),
-                all_latents=torch.stack([s.all_latents for s in samples]).float(),
-                latents_dtype=torch.tensor({torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}[samples[0].all_latents.dtype]),
-                latent_index_map=samples[0].latent_index_map, callback_index_map=samples[0].extra_kwargs["callback_index_map"],
+                all_latents=(torch.stack([s.all_latents for s in samples]).float() if samples[0].all_latents is not None else torch.zeros(0)),
+                latents_dtype=torch.tensor({torch.float16: 0, torch.bfloat16: 1, torch.float32: 2}[samples[0].all_latents.dtype] if samples[0].all_latents is not None else -1),
+                latent_index_map=(samples[0].latent_index_map if samples[0].latent_index_map is not None else torch.zeros(0)), callback_index_map=samples[0].extra_kwargs["callback_index_map"],
                 next_latents_mean=torch.stack([s.extra_kwargs["next_latents_mean"] for s in samples]).float(),
-                log_probs=torch.stack([s.log_probs for s in samples]).float(), log_prob_index_map=samples[0].log_prob_index_map)
+                **({} if samples[0].log_probs is None else dict(log_probs=torch.stack([s.log_probs for s in samples]).float(),
+                                                                 log_prob_index_map=samples[0].log_prob_index_map)))
 
 
 def main():

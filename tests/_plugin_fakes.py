@@ -551,6 +551,8 @@ class FluxStandinPlan:
         from oracle import flux_ref as FR
         from oracle import standin
         self.engine.calls.append(("rollout", dict(N=len(timesteps))))
+        if step_noise is None:                               # ODE dynamics: the plugin draws (and the step uses) no noise
+            step_noise = torch.zeros((len(timesteps),) + tuple(init_latents.shape))
         out = FR.rollout(None, None, prompt_embeds, pooled, guidance_scale, init_latents, step_noise, torch.tensor(timesteps, dtype=torch.float32),
                          torch.tensor(sigmas, dtype=torch.float32), list(noise_levels),
                          FR.prepare_img_ids(self.h // 2, self.w // 2).to(init_latents.dtype), storage_dtype, dynamics_type=dynamics,
@@ -602,6 +604,8 @@ class WanStandinPlan:
         from oracle import standin
         from oracle import wan_ref as W
         self.engine.calls.append(("rollout", dict(N=len(timesteps), n_cfg=self.n_cfg)))
+        if step_noise is None:
+            step_noise = torch.zeros((len(timesteps),) + tuple(init_latents.shape))
         out = W.rollout(None, None, prompt_embeds, neg_embeds, guidance, init_latents, step_noise, torch.tensor(timesteps).long(),
                         torch.tensor(sigmas, dtype=torch.float32), list(noise_levels), storage_dtype, dynamics_type=dynamics,
                         compute_log_prob=compute_log_prob, denoiser=partial(standin.wan_denoiser, expert=0))

@@ -540,3 +540,66 @@ def test_differential_sweep_standalone_adapter_vs_reference_adapter(trial):
     for s_ in want:
         s_.image = None
     _assert_same_samples(got, want, ctx)
+
+
+@pytest.mark.parametrize("family", ["flux", "qwen", "wan"])
+@pytest.mark.parametrize("trial", range(10))
+def test_differential_sweep_family_plugins_vs_reference_adapters(family, trial):
+    """Random option combinations (dynamics, guidance / true CFG on-off, storage dtype, steps, SDE windows, trajectory selections, log-probs,
+    explicit vs global generator) through the reference's `Flux1Adapter` / `QwenImageAdapter` / `Wan2_T2V_Adapter` and through the
+    corresponding plugin class on its computing engine double (fused rollouts): every recorded tensor must be equal."""
+    import random
+    import sys
+    import types
+    from oracle import ref_package
+    if not ref_package.available():
+        pytest.skip("needs /root/reference (build container only)")
+    ref_package.install()
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _plugin_fakes as F
+    import mi355_flow.flow_factory_plugin as P
+    import mi355_flow.vae as MV
+    from oracle import make_rollout_golden as G
+    if P._RefAdapter is None:
+        import importlib
+        P = importlib.reload(P)
+    rnd = random.Random(31000 + 100 * ["flux", "qwen", "wan"].index(family) + trial)
+    dyn = rnd.choice(["Flow-SDE", "Dance-SDE", "CPS", "ODE"])
+    storage = rnd.choice(["fp16", "bf16", None])
+    N = rnd.choice([3, 4, 6])
+    window = sorted(rnd.sample(range(N - 1), rnd.randint(1, N - 1)))
+    n_sde = rnd.randint(1, len(window))
+    eta = rnd.choice([0.5, 0.7])
+    clp = dyn != "ODE" and rnd.random() < 0.7
+    traj = rnd.choice(["train", "all"]) if clp else rnd.choice(["all", [-1], [0, -1]])
+    gs = rnd.choice([1.0, 3.5]) if family != "flux" else rnd.choice([1.0, 3.5, 7.0])
+    explicit_gen = rnd.random() < 0.5
+    case = {"flux": (dyn, gs, storage, N, window, n_sde, eta), "qwen": (dyn, gs, storage, N, window, n_sde, eta),
+            "wan": (dyn, gs, None, None, storage, N, window, n_sde, eta)}[family]
+    run, attr, eng, names, plug = {
+        "flux": (G.run_reference_flux, "FluxEngine", F.FluxStandinEngine,
+                 ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias", "x_embedder.weight"], "Flux1NativeAdapter"),
+        "qwen": (G.run_reference_qwen, "QwenEngine", F.QwenStandinEngine,
+                 ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias"], "QwenImageNativeAdapter"),
+        "wan": (G.run_reference_wan, "WanEngine", F.WanStandinEngine, ["blocks.0.attn1.to_q.weight", "blocks.0.attn1.to_q.bias"],
+                "Wan2T2VNativeAdapter"),
+    }[family]
+    kw = dict(callbacks=False, explicit_generator=explicit_gen, traj=traj, clp=clp, seed=777 + trial)
+    ctx = dict(family=family, trial=trial, case=case, **kw)
+    try:
+        want = run(case, **kw)
+    except Exception as e:          # noqa: BLE001
+        pytest.skip(f"the reference itself cannot serve this combination: {e!r}")
+    saved = (getattr(P, attr), P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder)
+    eng.NAMES = names
+    setattr(P, attr, eng)
+    P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = F.FakeVAEDecoder, types.SimpleNamespace(from_hf=lambda c: c), F.FakeVideoVAEDecoder
+    try:
+        got = run(case, adapter_base=getattr(P, plug), **kw)
+    finally:
+        setattr(P, attr, saved[0])
+        P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = saved[1:]
+    assert sorted(got) == sorted(want), ctx
+    for k, v in want.items():
+        a, b = got[k].detach().cpu().float(), v.detach().cpu().float()
+        assert a.shape == b.shape and torch.equal(torch.nan_to_num(a), torch.nan_to_num(b)), (ctx, k)
