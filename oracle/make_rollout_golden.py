@@ -306,7 +306,9 @@ WAN_CASES = {
 WAN_FRAMES, WAN_TD = 5, 96          # 5 frames -> 2 latent frames; text width
 
 
-def run_reference_wan(case, adapter_base=None, callbacks=True, explicit_generator=False, traj="train", clp=True, seed=None):
+def build_wan(case, adapter_base=None):
+    """The reference's `Wan2_T2V_Adapter` (or the plugin class) on the Wan pseudo-pipeline with the stand-in transformer(s), in rollout mode;
+    returns (adapter, N)."""
     ref_package.install()
     sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -366,6 +368,14 @@ def run_reference_wan(case, adapter_base=None, callbacks=True, explicit_generato
     ad = Ref(cfg, F.FakeAccelerator())
     ad.post_init()
     ad.rollout()
+    return ad, N
+
+
+def run_reference_wan(case, adapter_base=None, callbacks=True, explicit_generator=False, traj="train", clp=True, seed=None):
+    ref_package.install()
+    from flow_factory.utils.trajectory_collector import compute_trajectory_indices
+    dyn, gs, gs2, ratio, storage, N, sde_steps, n_sde, eta = WAN_CASES[case] if isinstance(case, str) else case
+    ad, N = build_wan(case, adapter_base)
     g = torch.Generator().manual_seed(41)
     pe, ne = torch.randn(B, NT, WAN_TD, generator=g).bfloat16(), torch.randn(B, NT, WAN_TD, generator=g).bfloat16()
     seed = (4000 + sorted(WAN_CASES).index(case)) if seed is None else seed

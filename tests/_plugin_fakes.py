@@ -614,3 +614,48 @@ class WanStandinPlan:
 
 class WanStandinEngine(_StandinFamilyEngine):
     PLAN = WanStandinPlan
+
+
+# --------------------------------------------------------------------------------------- CPU stand-in for the fused step kernel
+def oracle_sde_step(v_text, v_uncond, guidance, latents, sigma, sigma_next, eta, sigma_max, dynamics: str, noise=None, next_latents=None,
+                    compute_log_prob=True, want=("next_latents", "next_latents_mean", "noise_pred", "std_dev_t", "dt")):
+    """Signature of `mi355_flow.engine.sde_step` (the fused CFG + SDE-step + log-prob kernel, mi355_sde_step) computed by the ORACLE step
+    (`oracle.scheduler_ref.sde_step`, bit-exact against the reference scheduler's fixtures; the HIP kernel is pinned against the same
+    fixtures on the GPU).  Lets the per-step host paths of the FLUX / Qwen / Wan mixins run on a CPU-only box."""
+    from oracle import rollout_ref as R
+    from oracle import scheduler_ref as S
+    v = v_text if v_uncond is None else R.cfg_combine_bf16(v_uncond, v_text, float(guidance))
+    if torch.is_tensor(eta):
+        eta = float(eta.reshape(-1)[0])
+    out = S.sde_step(v.to(torch.bfloat16) if v.dtype != torch.float32 else v, latents, torch.as_tensor(sigma, dtype=torch.float32),
+                     torch.as_tensor(sigma_next, dtype=torch.float32), float(eta), dynamics_type=dynamics, sigma_max=sigma_max,
+                     variance_noise=noise, next_latents=next_latents, compute_log_prob=compute_log_prob)
+    o = types.SimpleNamespace(**{k: out.get(k) for k in ("next_latents", "next_latents_mean", "noise_pred", "log_prob", "std_dev_t", "dt")})
+    o.next_storage = S.cast_latents(out["next_latents"], latents.dtype)
+    return o
+
+
+class WanStandinPlanStepwise(WanStandinPlan):
+    """+ `transformer_forward` (what the per-step paths call): [negative | positive] halves through the stand-in of THIS engine's expert."""
+
+    @property
+    def engine_expert(self):
+        return getattr(self.engine, "expert", 0)
+
+    def transformer_forward(self, latents, t, enc_a, enc_b=None):
+        from oracle import standin
+        B = latents.shape[0]
+        self.engine.calls.append(("transformer_forward", dict(expert=self.engine_expert, n_cfg=1 if enc_b is None else 2, t=float(t.reshape(-1)[0]))))
+        tt = t.reshape(-1)[0].long().expand(B)
+        halves = [standin.wan_denoiser(latents.to(torch.bfloat16), tt, e, self.engine_expert) for e in ([enc_a] if enc_b is None else [enc_a, enc_b])]
+        return torch.cat(halves)
+
+
+class WanStandinEngineStepwise(_StandinFamilyEngine):
+    PLAN = WanStandinPlanStepwise
+    _count = 0
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.expert = type(self)._count % 2          # the plugin builds the high-noise expert's engine first, then the low-noise one
+        type(self)._count += 1
