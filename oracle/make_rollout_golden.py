@@ -168,14 +168,14 @@ def _flux_pipeline(transformer):
     return pipe
 
 
-def run_reference_flux(case, adapter_base=None, callbacks=True, explicit_generator=False, traj="train", clp=True, seed=None):
+def build_flux(case, adapter_base=None, model_level=False):
+    """The reference's `Flux1Adapter` (or the plugin class) on the FLUX pseudo-pipeline with the stand-in transformer, in rollout mode."""
     ref_package.install()
     sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _plugin_fakes as F
     from flow_factory.hparams import Arguments
     from flow_factory.models.flux.flux1 import Flux1Adapter
-    from flow_factory.utils.trajectory_collector import compute_trajectory_indices
     dyn, gs, storage, N, sde_steps, n_sde, eta = FLUX_CASES[case] if isinstance(case, str) else case
     cfg = Arguments.load_from_yaml(os.path.join(ref_package.REF_ROOT, "examples/grpo/full/flux1/default.yaml"))
     cfg.training_args.latent_storage_dtype = storage
@@ -185,7 +185,8 @@ def run_reference_flux(case, adapter_base=None, callbacks=True, explicit_generat
     tr = F.build_module_tree(shapes, buffers=(), cls=F.FakeTransformer).bfloat16()
     tr.forward = lambda hidden_states=None, timestep=None, guidance=None, pooled_projections=None, encoder_hidden_states=None, txt_ids=None, \
         img_ids=None, joint_attention_kwargs=None, return_dict=False: (
-            standin.flux_denoiser(hidden_states, timestep, guidance, pooled_projections, encoder_hidden_states, txt_ids, img_ids),)
+            (standin.flux_transformer_call if model_level else standin.flux_denoiser)(
+                hidden_states, timestep, guidance, pooled_projections, encoder_hidden_states, txt_ids, img_ids),)
 
     class Ref(adapter_base or Flux1Adapter):
         def load_pipeline(self):
@@ -194,6 +195,14 @@ def run_reference_flux(case, adapter_base=None, callbacks=True, explicit_generat
     ad = Ref(cfg, F.FakeAccelerator())
     ad.post_init()
     ad.rollout()
+    return ad
+
+
+def run_reference_flux(case, adapter_base=None, callbacks=True, explicit_generator=False, traj="train", clp=True, seed=None, model_level=False):
+    ref_package.install()
+    from flow_factory.utils.trajectory_collector import compute_trajectory_indices
+    dyn, gs, storage, N, sde_steps, n_sde, eta = FLUX_CASES[case] if isinstance(case, str) else case
+    ad = build_flux(case, adapter_base, model_level)
     g = torch.Generator().manual_seed(21)
     pe, pp = torch.randn(B, NT, J, generator=g).bfloat16(), torch.randn(B, P, generator=g).bfloat16()
     seed = (2000 + sorted(FLUX_CASES).index(case)) if seed is None else seed
@@ -225,7 +234,8 @@ QWEN_CASES = {
 QJ = 64
 
 
-def run_reference_qwen(case, adapter_base=None, callbacks=True, explicit_generator=False, traj="train", clp=True, seed=None):
+def build_qwen(case, adapter_base=None, model_level=False):
+    """The reference's `QwenImageAdapter` (or the plugin class) on the Qwen pseudo-pipeline with the stand-in transformer, in rollout mode."""
     ref_package.install()
     sys.path.insert(0, os.path.join(ROOT, "flow-factory_amd"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -234,7 +244,6 @@ def run_reference_qwen(case, adapter_base=None, callbacks=True, explicit_generat
     from contextlib import nullcontext
     from flow_factory.hparams import Arguments
     from flow_factory.models.qwen_image.qwen_image import QwenImageAdapter
-    from flow_factory.utils.trajectory_collector import compute_trajectory_indices
     from oracle import diffusers_stub as D
     from oracle import flux_ref as FR
     dyn, gs, storage, N, sde_steps, n_sde, eta = QWEN_CASES[case] if isinstance(case, str) else case
@@ -247,7 +256,8 @@ def run_reference_qwen(case, adapter_base=None, callbacks=True, explicit_generat
                              cls=F.FakeTransformer).bfloat16()
     tr.forward = lambda hidden_states=None, timestep=None, guidance=None, encoder_hidden_states_mask=None, encoder_hidden_states=None, \
         img_shapes=None, txt_seq_lens=None, attention_kwargs=None, return_dict=False: (
-            standin.qwen_denoiser(hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_mask, img_shapes, txt_seq_lens),)
+            (standin.qwen_transformer_call if model_level else standin.qwen_denoiser)(
+                hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_mask, img_shapes, txt_seq_lens),)
     tr.cache_context = lambda name: nullcontext()
 
     def prepare_latents(batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
@@ -268,6 +278,14 @@ def run_reference_qwen(case, adapter_base=None, callbacks=True, explicit_generat
     ad = Ref(cfg, F.FakeAccelerator())
     ad.post_init()
     ad.rollout()
+    return ad
+
+
+def run_reference_qwen(case, adapter_base=None, callbacks=True, explicit_generator=False, traj="train", clp=True, seed=None, model_level=False):
+    ref_package.install()
+    from flow_factory.utils.trajectory_collector import compute_trajectory_indices
+    dyn, gs, storage, N, sde_steps, n_sde, eta = QWEN_CASES[case] if isinstance(case, str) else case
+    ad = build_qwen(case, adapter_base, model_level)
     g = torch.Generator().manual_seed(31)
     lens, nlens = [5, 9], [3, 3]
     pe = [torch.randn(n, QJ, generator=g).bfloat16() for n in lens]

@@ -60,3 +60,45 @@ def wan_denoiser(hidden_states, timestep, encoder_hidden_states, expert: int = 0
     if expert:
         v = 0.5 * v + 0.1
     return v.to(torch.bfloat16)
+
+
+# ---- stand-ins at the MODEL-internal level: what the network embeds after its own first arithmetic on the adapter's arguments ----------
+# The engines take the values the network embeds (`t_model`, `guidance_model`), computed by the product's host code; diffusers computes the
+# same values INSIDE the model (`FluxTransformer2DModel.forward`: `timestep.to(hidden_states.dtype) * 1000`, likewise guidance;
+# `QwenImageTransformer2DModel`: `Timesteps(scale=1000)` on the timestep it receives).  `*_transformer_call` restates that first line and
+# hands over to the model-level stand-in, so that the reference side and the engine double meet at the same quantity -- and the product's
+# host arithmetic for it is what gets compared.
+def flux_denoiser_model(hidden_states, t_model, guidance_model, pooled_projections, encoder_hidden_states, hp: int, wp: int) -> torch.Tensor:
+    x = hidden_states.float()
+    B = x.shape[0]
+    t = t_model.float().reshape(-1).expand(B).reshape(-1, 1, 1) / 1000.0
+    g = (guidance_model.float().reshape(-1).expand(B).reshape(-1, 1, 1) / 1000.0) if guidance_model is not None else 0.0
+    e = encoder_hidden_states.float().mean(dim=(1, 2)).reshape(-1, 1, 1)
+    p = pooled_projections.float().mean(dim=1).reshape(-1, 1, 1)
+    rows = torch.arange(hp, dtype=torch.float32).repeat_interleave(wp)
+    cols = torch.arange(wp, dtype=torch.float32).repeat(hp)
+    pos = (0.01 * rows - 0.02 * cols).reshape(1, -1, 1)
+    v = (0.7 * x + 0.3 * torch.roll(x, 1, dims=-1)) * torch.cos(1.3 * t) + 0.8 * torch.sin(3.0 * x) * t + 0.05 * g + 4.0 * e + 2.5 * p + pos
+    return v.to(torch.bfloat16)
+
+
+def flux_transformer_call(hidden_states, timestep, guidance, pooled_projections, encoder_hidden_states, txt_ids, img_ids) -> torch.Tensor:
+    dt = hidden_states.dtype
+    hp, wp = int(img_ids[:, 1].max()) + 1, int(img_ids[:, 2].max()) + 1
+    return flux_denoiser_model(hidden_states, (timestep.to(dt) * 1000).float(), (guidance.to(dt) * 1000).float() if guidance is not None else None,
+                               pooled_projections, encoder_hidden_states, hp, wp)
+
+
+def qwen_denoiser_model(hidden_states, t_model, encoder_hidden_states, lens) -> torch.Tensor:
+    """`encoder_hidden_states` padded to at least max(lens); only the first lens[b] rows of sample b count."""
+    x = hidden_states.float()
+    B = x.shape[0]
+    t = t_model.float().reshape(-1).expand(B).reshape(-1, 1, 1) / 1000.0
+    e = torch.stack([encoder_hidden_states[b, :int(n)].float().mean() for b, n in enumerate(lens)]).reshape(-1, 1, 1)
+    ln = torch.as_tensor([float(n) for n in lens]).reshape(-1, 1, 1)
+    v = (0.7 * x + 0.3 * torch.roll(x, 1, dims=-1)) * torch.cos(1.3 * t) + 0.8 * torch.sin(3.0 * x) * t + 4.0 * e + 0.01 * ln
+    return v.to(torch.bfloat16)
+
+
+def qwen_transformer_call(hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_mask, img_shapes, txt_seq_lens) -> torch.Tensor:
+    return qwen_denoiser_model(hidden_states, timestep.float() * 1000.0, encoder_hidden_states, [int(n) for n in txt_seq_lens])

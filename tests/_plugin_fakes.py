@@ -659,3 +659,69 @@ class WanStandinEngineStepwise(_StandinFamilyEngine):
         super().__init__(cfg)
         self.expert = type(self)._count % 2          # the plugin builds the high-noise expert's engine first, then the low-noise one
         type(self)._count += 1
+
+
+class FluxStandinPlanModel(FluxStandinPlan):
+    """FLUX plan double at the MODEL level: `transformer_forward(latents, t_model, guidance_model, pe, pp)` receives the values the product's
+    host code computed for the network (`oracle.standin.flux_denoiser_model`); the fused rollout goes through the oracle loop with
+    `flux_transformer_call` (the adapter-level arguments -> the model's own first arithmetic -> the same stand-in)."""
+
+    def transformer_forward(self, latents, t_model, guidance_model, prompt_embeds, pooled):
+        from oracle import standin
+        self.engine.calls.append(("transformer_forward", dict(t=float(t_model.reshape(-1)[0]))))
+        return standin.flux_denoiser_model(latents, t_model, guidance_model, pooled, prompt_embeds, self.h // 2, self.w // 2)
+
+    def rollout(self, timesteps, sigmas, noise_levels, dynamics, guidance_scale, init_latents, storage_dtype, step_noise, prompt_embeds, pooled,
+                keep_positions=None, compute_log_prob=True):
+        from oracle import flux_ref as FR
+        from oracle import standin
+        self.engine.calls.append(("rollout", dict(N=len(timesteps))))
+        if step_noise is None:
+            step_noise = torch.zeros((len(timesteps),) + tuple(init_latents.shape))
+        out = FR.rollout(None, None, prompt_embeds, pooled, guidance_scale, init_latents, step_noise, torch.tensor(timesteps, dtype=torch.float32),
+                         torch.tensor(sigmas, dtype=torch.float32), list(noise_levels),
+                         FR.prepare_img_ids(self.h // 2, self.w // 2).to(init_latents.dtype), storage_dtype, dynamics_type=dynamics,
+                         compute_log_prob=compute_log_prob, denoiser=standin.flux_transformer_call)
+        return _keep_rows(out, len(timesteps), keep_positions)
+
+
+class FluxStandinEngineModel(_StandinFamilyEngine):
+    PLAN = FluxStandinPlanModel
+
+
+class QwenStandinPlanModel(QwenStandinPlan):
+    """Qwen-Image plan double at the MODEL level: `transformer_forward(latents, t_model, embeds, lens, guidance)` = the prediction the
+    scheduler sees (norm-rescaled true CFG over the [negative | positive] halves when n_cfg == 2)."""
+
+    def transformer_forward(self, latents, t_model, embeds, lens=None, guidance_scale=1.0, return_raw=False):
+        from oracle import qwen_ref as Q
+        from oracle import standin
+        B = self.batch
+        lens = [int(n) for n in lens]
+        self.engine.calls.append(("transformer_forward", dict(t=float(t_model.reshape(-1)[0]), n_cfg=self.n_cfg)))
+        if self.n_cfg == 2:
+            neg = standin.qwen_denoiser_model(latents, t_model, embeds[:B], lens[:B])
+            pos = standin.qwen_denoiser_model(latents, t_model, embeds[B:], lens[B:])
+            return Q.cfg_rescale_bf16(neg, pos, float(guidance_scale))
+        return standin.qwen_denoiser_model(latents, t_model, embeds, lens)
+
+    def rollout(self, timesteps, sigmas, noise_levels, dynamics, guidance_scale, init_latents, storage_dtype, step_noise, embeds, lens=None,
+                keep_positions=None, compute_log_prob=True):
+        from oracle import qwen_ref as Q
+        from oracle import standin
+        B = self.batch
+        self.engine.calls.append(("rollout", dict(N=len(timesteps), lens=list(lens), n_cfg=self.n_cfg)))
+        lens = [int(n) for n in lens]
+        if self.n_cfg == 2:
+            nl_, pl_ = lens[:B], lens[B:]
+            neg, pos = embeds[:B, :max(nl_)], embeds[B:, :max(pl_)]
+        else:
+            nl_, pl_, neg, pos = None, lens, None, embeds[:, :max(lens)]
+        out = Q.rollout(None, None, pos, pl_, neg, nl_, guidance_scale, init_latents, step_noise, torch.tensor(timesteps, dtype=torch.float32),
+                        torch.tensor(sigmas, dtype=torch.float32), list(noise_levels), self.h // 2, self.w // 2, storage_dtype,
+                        dynamics_type=dynamics, compute_log_prob=compute_log_prob, denoiser=standin.qwen_transformer_call)
+        return _keep_rows(out, len(timesteps), keep_positions)
+
+
+class QwenStandinEngineModel(_StandinFamilyEngine):
+    PLAN = QwenStandinPlanModel

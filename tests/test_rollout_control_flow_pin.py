@@ -723,3 +723,153 @@ def test_differential_sweep_wan_forward_plugin_vs_reference_adapter(trial):
         assert a is not None, (ctx, k, "missing")
         assert a.dtype == b.dtype and a.shape == b.shape, (ctx, k, a.dtype, b.dtype, tuple(a.shape), tuple(b.shape))
         assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), (ctx, k, float((a.float() - b.float()).abs().max()))
+
+
+@pytest.mark.parametrize("family,name", [("flux", "flux_flow_sde_fp16"), ("flux", "flux_dance_native"), ("qwen", "qwen_flow_sde_cfg_ragged"),
+                                         ("qwen", "qwen_cps_nocfg_fp16")])
+@pytest.mark.parametrize("callbacks", [False, True], ids=["fused", "stepwise-callbacks"])
+def test_flux_and_qwen_plugin_paths_at_the_model_level(family, name, callbacks):
+    """FLUX.1 / Qwen-Image plugin rollouts -- fused and the per-step path (callback capture) -- against the reference adapters with the
+    stand-in placed INSIDE the model boundary (`oracle.standin.*_transformer_call`: diffusers' own first arithmetic on the adapter's
+    `timestep` / `guidance`, then the stand-in), so that the engine double receives the values the PRODUCT's host code computes for the
+    network (`t_model` = round_storage(t / 1000) * 1000, guidance likewise; Qwen: `model_timestep`).  Per-step paths run on the CPU
+    stand-in of the fused step kernel."""
+    import sys
+    import types
+    from oracle import ref_package
+    if not ref_package.available():
+        pytest.skip("needs /root/reference (build container only)")
+    ref_package.install()
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _plugin_fakes as F
+    import mi355_flow.flow_factory_plugin as P
+    import mi355_flow.flux as MF
+    import mi355_flow.qwen as MQ
+    import mi355_flow.vae as MV
+    from oracle import make_rollout_golden as G
+    if P._RefAdapter is None:
+        import importlib
+        P = importlib.reload(P)
+    run, attr, eng, names, plug = {
+        "flux": (G.run_reference_flux, "FluxEngine", F.FluxStandinEngineModel,
+                 ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias", "x_embedder.weight"], "Flux1NativeAdapter"),
+        "qwen": (G.run_reference_qwen, "QwenEngine", F.QwenStandinEngineModel,
+                 ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias"], "QwenImageNativeAdapter"),
+    }[family]
+    want = run(name, callbacks=callbacks, model_level=True)
+    saved = (getattr(P, attr), P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder, MF.sde_step, MQ.sde_step)
+    eng.NAMES = names
+    setattr(P, attr, eng)
+    P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = F.FakeVAEDecoder, types.SimpleNamespace(from_hf=lambda c: c), F.FakeVideoVAEDecoder
+    MF.sde_step = MQ.sde_step = F.oracle_sde_step
+    try:
+        got = run(name, adapter_base=getattr(P, plug), callbacks=callbacks, model_level=True)
+    finally:
+        setattr(P, attr, saved[0])
+        P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder, MF.sde_step, MQ.sde_step = saved[1:]
+    assert sorted(got) == sorted(want), name
+    for k, v in want.items():
+        assert torch.equal(got[k].detach().cpu().float(), v.detach().cpu().float()), (name, k)
+
+
+@pytest.mark.parametrize("family", ["flux", "qwen"])
+@pytest.mark.parametrize("trial", range(16))
+def test_differential_sweep_flux_qwen_forward_plugin_vs_reference_adapter(family, trial):
+    """`forward()` of the FLUX.1 / Qwen-Image plugins against the reference adapters' `forward` (stand-in inside the model boundary, CPU
+    stand-in of the fused step kernel): scalar or (B,) timesteps on and off the schedule grid's storage rounding, `t_next` given or
+    derived, inferred / explicit noise level, sampling step or replay, `return_kwargs` subsets, guidance values; Qwen: ragged prompt lists,
+    true CFG on / off."""
+    import random
+    import sys
+    import types
+    from oracle import ref_package
+    if not ref_package.available():
+        pytest.skip("needs /root/reference (build container only)")
+    ref_package.install()
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _plugin_fakes as F
+    import mi355_flow.flow_factory_plugin as P
+    import mi355_flow.flux as MF
+    import mi355_flow.qwen as MQ
+    import mi355_flow.vae as MV
+    from oracle import make_rollout_golden as G
+    if P._RefAdapter is None:
+        import importlib
+        P = importlib.reload(P)
+    rnd = random.Random(81000 + 100 * (family == "qwen") + trial)
+    dyn = rnd.choice(["Flow-SDE", "Dance-SDE", "CPS", "ODE"])
+    storage = rnd.choice(["fp16", "bf16"])
+    N = rnd.choice([4, 6, 8])
+    window = sorted(rnd.sample(range(N - 1), rnd.randint(1, N - 1)))
+    gs = rnd.choice([1.0, 3.5, 7.0]) if family == "flux" else rnd.choice([1.0, 4.0])
+    case = (dyn, gs, storage, N, window, 1, 0.7)
+    step = rnd.randrange(N - 1) if dyn == "CPS" else rnd.randrange(N)
+    per_sample_t, give_t_next = rnd.random() < 0.5, rnd.random() < 0.6
+    noise_level = rnd.choice([None, 0.0, 0.7])
+    replay = rnd.random() < 0.5
+    clp = dyn != "ODE" and rnd.random() < 0.7 and (noise_level is None or noise_level > 0)
+    keys = ["noise_pred", "next_latents", "next_latents_mean", "std_dev_t", "dt", "log_prob"]
+    return_kwargs = rnd.sample(keys, rnd.randint(1, len(keys)))
+    ctx = dict(family=family, trial=trial, case=case, step=step, per_sample_t=per_sample_t, give_t_next=give_t_next, noise_level=noise_level,
+               replay=replay, clp=clp, return_kwargs=return_kwargs)
+    g = torch.Generator().manual_seed(600 + trial)
+    Bq, hp, wp = 2, 4, 6
+    sdt = {"fp16": torch.float16, "bf16": torch.bfloat16}[storage]
+    x = torch.randn(Bq, hp * wp, 64, generator=g).to(sdt)
+    x_next = (x.float() * 0.9 + 0.1 * torch.randn(Bq, hp * wp, 64, generator=g)).to(sdt)
+    if family == "flux":
+        from oracle import flux_ref as FR
+        extra = dict(prompt_embeds=torch.randn(Bq, 7, 128, generator=g).bfloat16(), pooled_prompt_embeds=torch.randn(Bq, 128, generator=g).bfloat16(),
+                     img_ids=FR.prepare_img_ids(hp, wp).to(sdt))
+        build, attr, eng, names, plug = (G.build_flux, "FluxEngine", F.FluxStandinEngineModel,
+                                         ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias", "x_embedder.weight"],
+                                         "Flux1NativeAdapter")
+    else:
+        lens, nlens = [5, 9], [3, 4]
+        extra = dict(prompt_embeds=[torch.randn(n, G.QJ, generator=g).bfloat16() for n in lens],
+                     prompt_embeds_mask=[torch.ones(n, dtype=torch.long) for n in lens], img_shapes=[[(1, hp, wp)]] * Bq)
+        if gs > 1:
+            extra.update(negative_prompt_embeds=[torch.randn(n, G.QJ, generator=g).bfloat16() for n in nlens],
+                         negative_prompt_embeds_mask=[torch.ones(n, dtype=torch.long) for n in nlens])
+        build, attr, eng, names, plug = (G.build_qwen, "QwenEngine", F.QwenStandinEngineModel,
+                                         ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias"], "QwenImageNativeAdapter")
+
+    def run(base):
+        from flow_factory.scheduler import set_scheduler_timesteps
+        ad = build(case, base, model_level=True)
+        ts = set_scheduler_timesteps(scheduler=ad.scheduler, num_inference_steps=N, seq_len=hp * wp, device=torch.device("cpu"))
+        t = ts[step].expand(Bq).clone() if per_sample_t else ts[step]
+        t_next = ts[step + 1] if step + 1 < N else torch.tensor(0.0)
+        if per_sample_t:
+            t_next = t_next.expand(Bq).clone()
+        kw = dict(t=t, latents=x, guidance_scale=gs, compute_log_prob=clp, return_kwargs=list(return_kwargs), noise_level=noise_level, **extra)
+        if give_t_next:
+            kw["t_next"] = t_next
+        if replay:
+            kw["next_latents"] = x_next
+        torch.manual_seed(999 + trial)
+        with torch.no_grad():
+            return ad.forward(**kw)
+
+    try:
+        want = run(None)
+    except Exception as e:          # noqa: BLE001
+        pytest.skip(f"the reference itself cannot serve this combination: {e!r}")
+    saved = (getattr(P, attr), P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder, MF.sde_step, MQ.sde_step)
+    eng.NAMES = names
+    setattr(P, attr, eng)
+    P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = F.FakeVAEDecoder, types.SimpleNamespace(from_hf=lambda c: c), F.FakeVideoVAEDecoder
+    MF.sde_step = MQ.sde_step = F.oracle_sde_step
+    try:
+        got = run(getattr(P, plug))
+    finally:
+        setattr(P, attr, saved[0])
+        P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder, MF.sde_step, MQ.sde_step = saved[1:]
+    for k in keys:
+        a, b = getattr(got, k, None), getattr(want, k, None)
+        if b is None:
+            assert a is None, (ctx, k, "the plugin returns a field the reference leaves out")
+            continue
+        assert a is not None, (ctx, k, "missing")
+        assert a.dtype == b.dtype and a.shape == b.shape, (ctx, k, a.dtype, b.dtype, tuple(a.shape), tuple(b.shape))
+        assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), (ctx, k, float((a.float() - b.float()).abs().max()))
