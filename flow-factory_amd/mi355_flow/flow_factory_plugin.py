@@ -27,6 +27,7 @@ Importing this module needs an importable `flow_factory`.
 from __future__ import annotations
 
 import functools
+import inspect
 import logging
 from contextlib import contextmanager
 
@@ -80,7 +81,14 @@ class _LiveBinding:
     engine_valued_replay = True
 
     def _replay_on_reference(self, ref_forward, native_forward, args, kwargs):
-        out = ref_forward(self, *args, **kwargs)
+        # the trainer filters its kwargs by THIS class's forward() signature (utils/base.py:38-63), which may carry parameters the
+        # reference's forward does not know (FLUX: `height` / `width` to recover the latent grid without img_ids): drop those
+        accepted = inspect.signature(ref_forward).parameters
+        if not any(p.kind == inspect.Parameter.VAR_KEYWORD for p in accepted.values()):
+            ref_kwargs = {k: v for k, v in kwargs.items() if k in accepted}
+        else:
+            ref_kwargs = kwargs
+        out = ref_forward(self, *args, **ref_kwargs)
         if not self.engine_valued_replay or kwargs.get("next_latents") is None:
             return out
         try:

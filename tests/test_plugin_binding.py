@@ -684,7 +684,7 @@ def test_reference_nft_trainer_runs_an_epoch_through_the_plugin(ref):
 
 
 # ------------------------------------------------------------------------------------------------- generic harness: a REAL trainer object
-def _real_trainer(P, trainer_cls, yaml, tweak, batches, K, lr=500.0, engine=None):
+def _real_trainer(P, trainer_cls, yaml, tweak, batches, K, lr=500.0, engine=None, make_adapter=None):
     """Constructs `trainer_cls(accelerator, config, adapter)` through the reference's own `__init__` chain; only `BaseTrainer`'s
     environment set-up (`_initialization`: dataset / dataloader / reward models / accelerator.prepare, and the logging backend) is
     replaced by test objects.  Returns (trainer, adapter, torch module, log list)."""
@@ -707,18 +707,21 @@ def _real_trainer(P, trainer_cls, yaml, tweak, batches, K, lr=500.0, engine=None
     cfg = Arguments.load_from_yaml(f.name)
     os.unlink(f.name)
     tweak(cfg)
-    tcfg = _tiny_cfg()
-    tr_mod = F.build_module_tree(expected_shapes(tcfg), cls=F.FakeTransformer)
-    real_engine = P.Engine
-    P.Engine = engine or F.DiffFakeEngine
-    try:
-        class Plug(P.SD3_5NativeAdapter):
-            def load_pipeline(self):
-                return F.make_pipeline(tcfg, tr_mod)
-        acc = F.TrainerAccelerator()
-        ad = Plug(cfg, acc)
-    finally:
-        P.Engine = real_engine
+    acc = F.TrainerAccelerator()
+    if make_adapter is not None:                 # another model family: the caller builds the plugin adapter (and its torch module)
+        ad, tr_mod = make_adapter(cfg, acc)
+    else:
+        tcfg = _tiny_cfg()
+        tr_mod = F.build_module_tree(expected_shapes(tcfg), cls=F.FakeTransformer)
+        real_engine = P.Engine
+        P.Engine = engine or F.DiffFakeEngine
+        try:
+            class Plug(P.SD3_5NativeAdapter):
+                def load_pipeline(self):
+                    return F.make_pipeline(tcfg, tr_mod)
+            ad = Plug(cfg, acc)
+        finally:
+            P.Engine = real_engine
 
     class Buffer:
         def clear(self):
@@ -837,3 +840,155 @@ def test_reference_dgpo_dpo_and_crd_trainers_run_an_epoch_through_the_plugin(ref
     assert logged and all(torch.isfinite(torch.as_tensor(v)).all() for _, d in logged for v in d.values() if torch.is_tensor(v) or isinstance(v, float))
     assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable)), logged
     assert F.FakeTransformer.calls == 0
+
+
+@pytest.mark.parametrize("family", ["flux", "wan", "qwen"])
+def test_reference_grpo_trainer_on_the_family_plugins_replays_engine_valued(ref, family):
+    """FLUX.1 / Wan / Qwen-Image have no native backward: `optimize()` differentiates through the reference's torch forward while the
+    VALUES of log_prob / noise_pred come from the engine (`flow_factory_plugin._engine_valued`).  Here the reference's own `GRPOTrainer`
+    runs an epoch on each plugin with a torch transformer whose arithmetic is deliberately ~1e-3 off the engine's (as bf16 torch vs the
+    HIP kernels are): the very first ratio is still EXACTLY 1 and the KL term exactly 0 (both sides of it are engine values), while the
+    gradient -- taken through the torch path -- reaches the parameters and the optimizer moves them.  With `engine_valued_replay = False`
+    the same epoch starts with ratio != 1 (what the default +-1e-4 clip range would then clip from the first step on).  (This test also
+    caught the FLUX plugin handing `height` / `width` -- parameters of ITS forward() only -- to the reference's forward.)"""
+    import mi355_flow.flux as MF
+    import mi355_flow.qwen as MQ
+    import mi355_flow.vae as MV
+    import mi355_flow.wan as MW
+    from contextlib import nullcontext
+    from flow_factory.trainers.grpo import GRPOTrainer
+    from oracle import make_rollout_golden as G
+    from oracle import standin
+    P = ref
+    M, K, Nt = 2, 2, 7
+    yaml = {"flux": "/root/reference/examples/grpo/full/flux1/default.yaml", "wan": "/root/reference/examples/grpo/full/wan21/t2v.yaml",
+            "qwen": "/root/reference/examples/grpo/full/qwen_image/default.yaml"}[family]
+
+    def run(engine_valued):
+        def make_adapter(cfg, acc):
+            names = {"flux": ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias", "x_embedder.weight"],
+                     "wan": ["blocks.0.attn1.to_q.weight", "blocks.0.attn1.to_q.bias"],
+                     "qwen": ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias"]}[family]
+            tr = F.build_module_tree({n: ((8, 8) if n.endswith("weight") else (8,)) for n in names}, buffers=(), cls=F.FakeTransformer).bfloat16()
+            wq = tr.get_submodule(names[0].rsplit(".", 1)[0]).weight
+            off = lambda v: ((v.float() * (1.001 + wq.float().mean())).to(torch.bfloat16),)      # noqa: E731 -- differentiable, ~1e-3 off the engine
+            tr.cache_context = lambda name: nullcontext()
+            saved = (P.FluxEngine, P.WanEngine, P.QwenEngine, P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder)
+            P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = F.FakeVAEDecoder, types.SimpleNamespace(from_hf=lambda c: c), F.FakeVideoVAEDecoder
+            try:
+                if family == "flux":
+                    tr.forward = lambda hidden_states=None, timestep=None, guidance=None, pooled_projections=None, encoder_hidden_states=None, \
+                        txt_ids=None, img_ids=None, joint_attention_kwargs=None, return_dict=False: off(
+                            standin.flux_transformer_call(hidden_states, timestep, guidance, pooled_projections, encoder_hidden_states, txt_ids, img_ids))
+                    F.FluxStandinEngineModel.NAMES = names
+                    P.FluxEngine = F.FluxStandinEngineModel
+
+                    class Plug(P.Flux1NativeAdapter):
+                        def load_pipeline(self):
+                            return G._flux_pipeline(tr)
+                elif family == "wan":
+                    tr.config = types.SimpleNamespace(in_channels=16, out_channels=16, patch_size=(1, 2, 2), num_layers=1, num_attention_heads=1,
+                                                      attention_head_dim=128, ffn_dim=64, text_dim=G.WAN_TD, freq_dim=256, eps=1e-6)
+                    tr.forward = lambda hidden_states=None, timestep=None, encoder_hidden_states=None, attention_kwargs=None, return_dict=False: off(
+                        standin.wan_denoiser(hidden_states, timestep, encoder_hidden_states, 0))
+                    F.WanStandinEngineStepwise.NAMES, F.WanStandinEngineStepwise._count = names, 0
+                    P.WanEngine = F.WanStandinEngineStepwise
+
+                    class Plug(P.Wan2T2VNativeAdapter):
+                        def load_pipeline(self):
+                            return _wan_pipeline(tr)
+                else:
+                    import mi355_flow.qwen as QW
+                    tcfg = QW.QwenConfig(num_layers=1, num_attention_heads=1, joint_attention_dim=G.QJ)
+                    tr.forward = lambda hidden_states=None, timestep=None, guidance=None, encoder_hidden_states_mask=None, encoder_hidden_states=None, \
+                        img_shapes=None, txt_seq_lens=None, attention_kwargs=None, return_dict=False: off(
+                            standin.qwen_transformer_call(hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_mask, img_shapes, txt_seq_lens))
+                    F.QwenStandinEngineModel.NAMES = names
+                    P.QwenEngine = F.QwenStandinEngineModel
+
+                    class Plug(P.QwenImageNativeAdapter):
+                        def load_pipeline(self):
+                            return _qwen_pipeline(tcfg, tr)
+                ad = Plug(cfg, acc)
+            finally:
+                P.FluxEngine, P.WanEngine, P.QwenEngine, P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = saved
+            ad.engine_valued_replay = engine_valued
+            return ad, tr
+
+        def tweak(cfg):
+            _small(cfg.training_args, guidance_scale=3.5 if family == "flux" else 1.0, kl_beta=0.05, kl_type="v-based", clip_range=(-1e-4, 1e-4),
+                   adv_clip_range=(-5.0, 5.0))
+            cfg.training_args.height = cfg.training_args.width = 64
+            cfg.training_args.resolution = (64, 64)
+            if family == "wan":
+                cfg.training_args.extra_kwargs = {**getattr(cfg.training_args, "extra_kwargs", {}), "num_frames": 5}
+        g = torch.Generator().manual_seed(3)
+        J = {"flux": 128, "wan": G.WAN_TD, "qwen": G.QJ}[family]
+        batches = []
+        for i in range(M):
+            b = dict(prompt=[f"prompt {i}"] * K, prompt_ids=torch.full((K, 4), i), prompt_embeds=torch.randn(1, Nt, J, generator=g).bfloat16().repeat(K, 1, 1))
+            if family == "flux":
+                b["pooled_prompt_embeds"] = torch.randn(1, 128, generator=g).bfloat16().repeat(K, 1)
+            if family == "qwen":
+                b["prompt_embeds_mask"] = torch.ones(K, Nt, dtype=torch.long)
+            batches.append(b)
+        real = (MF.sde_step, MW.sde_step, MQ.sde_step, MV.WanVAEDecoder)
+        MF.sde_step = MW.sde_step = MQ.sde_step = F.oracle_sde_step
+        MV.WanVAEDecoder = F.FakeVideoVAEDecoder             # (the video VAE decoder is created lazily, at the first decode_latents)
+        try:
+            tr, ad, tr_mod, logged = _real_trainer(P, GRPOTrainer, yaml, tweak, batches, K, lr=50.0, make_adapter=make_adapter)
+            trainable = ad.get_trainable_parameters()
+            before = [p_.detach().clone() for p_ in trainable]
+            torch.manual_seed(99)
+            samples = tr.sample()
+            assert len(samples) == M * K
+            tr.compute_advantages(samples, {"r": torch.tensor([0.1, 0.9, 0.4, 0.2])}, store_to_samples=True)
+            torch.manual_seed(1234)
+            tr.optimize(samples)
+        finally:
+            MF.sde_step, MW.sde_step, MQ.sde_step, MV.WanVAEDecoder = real
+        moved = any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable))
+        return logged, moved
+
+    logged, moved = run(True)
+    first = logged[0][1]
+    assert first["train/ratio_min"] == 1.0 and first["train/ratio_max"] == 1.0, first          # exactly 1 although the torch path is 1e-3 off
+    assert float(first["train/kl_div"]) == 0.0
+    assert moved and all(torch.isfinite(torch.as_tensor(v)).all() for _, d in logged for v in d.values())
+    logged_off, _ = run(False)
+    first_off = logged_off[0][1]
+    assert first_off["train/ratio_min"] != 1.0 or first_off["train/ratio_max"] != 1.0          # the hazard the engine-valued replay removes
+
+
+def _wan_pipeline(transformer):
+    """Wan pseudo-pipeline (single transformer) for the trainer-level test: as oracle/make_rollout_golden.build_wan's."""
+    import torch.nn as nn
+    from oracle import diffusers_stub as D
+    vae = nn.Module()
+    vae.add_module("decoder", nn.Linear(2, 2))
+    vae.config = types.SimpleNamespace(z_dim=16, base_dim=96, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_downsample=(False, True, True),
+                                       latents_mean=[0.0] * 16, latents_std=[1.0] * 16)
+    vae.dtype = torch.float32
+    pipe = types.SimpleNamespace()
+    pipe.transformer, pipe.vae, pipe.transformer_2 = transformer, vae, None
+    pipe.text_encoder, pipe.tokenizer = nn.Linear(2, 2), object()
+    pipe.vae_scale_factor_temporal, pipe.vae_scale_factor_spatial = 4, 8
+    pipe.config = types.SimpleNamespace(boundary_ratio=None, expand_timesteps=False)
+    pipe.scheduler = D.UniPCMultistepScheduler(num_train_timesteps=1000, use_flow_sigmas=True, flow_shift=3.0)
+    pipe.video_processor = types.SimpleNamespace(postprocess_video=lambda v, output_type="pt": v)
+    pipe.maybe_free_model_hooks = lambda: None
+    pipe.components = {"transformer": transformer, "vae": vae, "text_encoder": pipe.text_encoder}
+    pipe.prepare_latents = lambda batch_size, num_channels_latents, height, width, num_frames, dtype, device, generator, latents=None: D.randn_tensor(
+        (batch_size, num_channels_latents, (int(num_frames) - 1) // 4 + 1, int(height) // 8, int(width) // 8), generator=generator, device=device, dtype=dtype)
+    return pipe
+
+
+def _qwen_pipeline(tcfg, transformer):
+    from oracle import diffusers_stub as D
+    from oracle import flux_ref as FR
+    pipe = F.make_qwen_pipeline(tcfg, transformer)
+    pipe.prepare_latents = lambda batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None: FR.pack_latents(
+        D.randn_tensor((batch_size, 1, num_channels_latents, 2 * (int(height) // 16), 2 * (int(width) // 16)), generator=generator, device=device,
+                       dtype=dtype)[:, 0])
+    pipe.vae.dtype = torch.float32
+    return pipe
