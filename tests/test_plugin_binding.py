@@ -842,6 +842,66 @@ def test_reference_dgpo_dpo_and_crd_trainers_run_an_epoch_through_the_plugin(ref
     assert F.FakeTransformer.calls == 0
 
 
+def _family_adapter_factory(P, family, engine_valued=True):
+    """-> make_adapter(cfg, accelerator) for `_real_trainer`: the FLUX.1 / Wan / Qwen-Image plugin class on its computing engine double, with a
+    torch transformer that is differentiable in a trainable parameter and ~1e-3 away from the engine's arithmetic."""
+    import mi355_flow.vae as MV
+    from contextlib import nullcontext
+    from oracle import make_rollout_golden as G
+    from oracle import standin
+
+    def make_adapter(cfg, acc):
+        names = {"flux": ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias", "x_embedder.weight"],
+                 "wan": ["blocks.0.attn1.to_q.weight", "blocks.0.attn1.to_q.bias"],
+                 "qwen": ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias"]}[family]
+        tr = F.build_module_tree({n: ((8, 8) if n.endswith("weight") else (8,)) for n in names}, buffers=(), cls=F.FakeTransformer).bfloat16()
+        wq = tr.get_submodule(names[0].rsplit(".", 1)[0]).weight
+        off = lambda v: ((v.float() * (1.001 + wq.float().mean())).to(torch.bfloat16),)      # noqa: E731 -- differentiable, ~1e-3 off the engine
+        tr.cache_context = lambda name: nullcontext()
+        saved = (P.FluxEngine, P.WanEngine, P.QwenEngine, P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder)
+        P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = F.FakeVAEDecoder, types.SimpleNamespace(from_hf=lambda c: c), F.FakeVideoVAEDecoder
+        try:
+            if family == "flux":
+                tr.forward = lambda hidden_states=None, timestep=None, guidance=None, pooled_projections=None, encoder_hidden_states=None, \
+                    txt_ids=None, img_ids=None, joint_attention_kwargs=None, return_dict=False: off(
+                        standin.flux_transformer_call(hidden_states, timestep, guidance, pooled_projections, encoder_hidden_states, txt_ids, img_ids))
+                F.FluxStandinEngineModel.NAMES = names
+                P.FluxEngine = F.FluxStandinEngineModel
+
+                class Plug(P.Flux1NativeAdapter):
+                    def load_pipeline(self):
+                        return G._flux_pipeline(tr)
+            elif family == "wan":
+                tr.config = types.SimpleNamespace(in_channels=16, out_channels=16, patch_size=(1, 2, 2), num_layers=1, num_attention_heads=1,
+                                                  attention_head_dim=128, ffn_dim=64, text_dim=G.WAN_TD, freq_dim=256, eps=1e-6)
+                tr.forward = lambda hidden_states=None, timestep=None, encoder_hidden_states=None, attention_kwargs=None, return_dict=False: off(
+                    standin.wan_denoiser(hidden_states, timestep, encoder_hidden_states, 0))
+                F.WanStandinEngineStepwise.NAMES, F.WanStandinEngineStepwise._count = names, 0
+                P.WanEngine = F.WanStandinEngineStepwise
+
+                class Plug(P.Wan2T2VNativeAdapter):
+                    def load_pipeline(self):
+                        return _wan_pipeline(tr)
+            else:
+                import mi355_flow.qwen as QW
+                tcfg = QW.QwenConfig(num_layers=1, num_attention_heads=1, joint_attention_dim=G.QJ)
+                tr.forward = lambda hidden_states=None, timestep=None, guidance=None, encoder_hidden_states_mask=None, encoder_hidden_states=None, \
+                    img_shapes=None, txt_seq_lens=None, attention_kwargs=None, return_dict=False: off(
+                        standin.qwen_transformer_call(hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_mask, img_shapes, txt_seq_lens))
+                F.QwenStandinEngineModel.NAMES = names
+                P.QwenEngine = F.QwenStandinEngineModel
+
+                class Plug(P.QwenImageNativeAdapter):
+                    def load_pipeline(self):
+                        return _qwen_pipeline(tcfg, tr)
+            ad = Plug(cfg, acc)
+        finally:
+            P.FluxEngine, P.WanEngine, P.QwenEngine, P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = saved
+        ad.engine_valued_replay = engine_valued
+        return ad, tr
+    return make_adapter
+
+
 @pytest.mark.parametrize("family", ["flux", "wan", "qwen"])
 def test_reference_grpo_trainer_on_the_family_plugins_replays_engine_valued(ref, family):
     """FLUX.1 / Wan / Qwen-Image have no native backward: `optimize()` differentiates through the reference's torch forward while the
@@ -865,55 +925,7 @@ def test_reference_grpo_trainer_on_the_family_plugins_replays_engine_valued(ref,
             "qwen": "/root/reference/examples/grpo/full/qwen_image/default.yaml"}[family]
 
     def run(engine_valued):
-        def make_adapter(cfg, acc):
-            names = {"flux": ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias", "x_embedder.weight"],
-                     "wan": ["blocks.0.attn1.to_q.weight", "blocks.0.attn1.to_q.bias"],
-                     "qwen": ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias"]}[family]
-            tr = F.build_module_tree({n: ((8, 8) if n.endswith("weight") else (8,)) for n in names}, buffers=(), cls=F.FakeTransformer).bfloat16()
-            wq = tr.get_submodule(names[0].rsplit(".", 1)[0]).weight
-            off = lambda v: ((v.float() * (1.001 + wq.float().mean())).to(torch.bfloat16),)      # noqa: E731 -- differentiable, ~1e-3 off the engine
-            tr.cache_context = lambda name: nullcontext()
-            saved = (P.FluxEngine, P.WanEngine, P.QwenEngine, P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder)
-            P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = F.FakeVAEDecoder, types.SimpleNamespace(from_hf=lambda c: c), F.FakeVideoVAEDecoder
-            try:
-                if family == "flux":
-                    tr.forward = lambda hidden_states=None, timestep=None, guidance=None, pooled_projections=None, encoder_hidden_states=None, \
-                        txt_ids=None, img_ids=None, joint_attention_kwargs=None, return_dict=False: off(
-                            standin.flux_transformer_call(hidden_states, timestep, guidance, pooled_projections, encoder_hidden_states, txt_ids, img_ids))
-                    F.FluxStandinEngineModel.NAMES = names
-                    P.FluxEngine = F.FluxStandinEngineModel
-
-                    class Plug(P.Flux1NativeAdapter):
-                        def load_pipeline(self):
-                            return G._flux_pipeline(tr)
-                elif family == "wan":
-                    tr.config = types.SimpleNamespace(in_channels=16, out_channels=16, patch_size=(1, 2, 2), num_layers=1, num_attention_heads=1,
-                                                      attention_head_dim=128, ffn_dim=64, text_dim=G.WAN_TD, freq_dim=256, eps=1e-6)
-                    tr.forward = lambda hidden_states=None, timestep=None, encoder_hidden_states=None, attention_kwargs=None, return_dict=False: off(
-                        standin.wan_denoiser(hidden_states, timestep, encoder_hidden_states, 0))
-                    F.WanStandinEngineStepwise.NAMES, F.WanStandinEngineStepwise._count = names, 0
-                    P.WanEngine = F.WanStandinEngineStepwise
-
-                    class Plug(P.Wan2T2VNativeAdapter):
-                        def load_pipeline(self):
-                            return _wan_pipeline(tr)
-                else:
-                    import mi355_flow.qwen as QW
-                    tcfg = QW.QwenConfig(num_layers=1, num_attention_heads=1, joint_attention_dim=G.QJ)
-                    tr.forward = lambda hidden_states=None, timestep=None, guidance=None, encoder_hidden_states_mask=None, encoder_hidden_states=None, \
-                        img_shapes=None, txt_seq_lens=None, attention_kwargs=None, return_dict=False: off(
-                            standin.qwen_transformer_call(hidden_states, timestep, encoder_hidden_states, encoder_hidden_states_mask, img_shapes, txt_seq_lens))
-                    F.QwenStandinEngineModel.NAMES = names
-                    P.QwenEngine = F.QwenStandinEngineModel
-
-                    class Plug(P.QwenImageNativeAdapter):
-                        def load_pipeline(self):
-                            return _qwen_pipeline(tcfg, tr)
-                ad = Plug(cfg, acc)
-            finally:
-                P.FluxEngine, P.WanEngine, P.QwenEngine, P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = saved
-            ad.engine_valued_replay = engine_valued
-            return ad, tr
+        make_adapter = _family_adapter_factory(P, family, engine_valued)
 
         def tweak(cfg):
             _small(cfg.training_args, guidance_scale=3.5 if family == "flux" else 1.0, kl_beta=0.05, kl_type="v-based", clip_range=(-1e-4, 1e-4),
@@ -992,3 +1004,49 @@ def _qwen_pipeline(tcfg, transformer):
                        dtype=dtype)[:, 0])
     pipe.vae.dtype = torch.float32
     return pipe
+
+
+def test_reference_dgpo_trainer_on_the_qwen_image_plugin(ref):
+    """BASELINE.json configs[4]: Qwen-Image under the DGPO trainer (trainers/dgpo.py; examples/dgpo is written for SD3.5, its
+    hyper-parameters are used here).  The reference's own `DGPOTrainer` -- real `__init__` -- runs an epoch on the Qwen-Image plugin: ODE /
+    SDE rollouts on the engine double, the DSM training forward WITHOUT a stored transition through the reference's torch path (no native
+    Qwen backward), old-policy / reference predictions as no-grad engine forwards."""
+    import mi355_flow.qwen as MQ
+    import mi355_flow.vae as MV
+    from flow_factory.trainers.dgpo import DGPOTrainer
+    from oracle import make_rollout_golden as G
+    P = ref
+    M, K, Nt = 2, 2, 7
+    g = torch.Generator().manual_seed(3)
+    batches = [dict(prompt=[f"prompt {i}"] * K, prompt_ids=torch.full((K, 4), i), prompt_embeds=torch.randn(1, Nt, G.QJ, generator=g).bfloat16().repeat(K, 1, 1),
+                    prompt_embeds_mask=torch.ones(K, Nt, dtype=torch.long)) for i in range(M)]
+
+    def tweak(cfg):
+        _small(cfg.training_args, guidance_scale=1.0)
+        cfg.training_args.height = cfg.training_args.width = 64
+        cfg.training_args.resolution = (64, 64)
+        for k, v in (("num_train_timesteps", 2), ("off_policy", False)):
+            if hasattr(cfg.training_args, k):
+                setattr(cfg.training_args, k, v)
+    real = (MQ.sde_step, MV.WanVAEDecoder)
+    MQ.sde_step, MV.WanVAEDecoder = F.oracle_sde_step, F.FakeVideoVAEDecoder
+    try:
+        tr, ad, tr_mod, logged = _real_trainer(P, DGPOTrainer, "/root/reference/examples/dgpo/lora/sd3_5/default.yaml", tweak, batches, K, lr=50.0,
+                                               make_adapter=_family_adapter_factory(P, "qwen"))
+        trainable = ad.get_trainable_parameters()
+        before = [p_.detach().clone() for p_ in trainable]
+        torch.manual_seed(99)
+        samples = tr.sample()
+        assert len(samples) == M * K and type(samples[0]).__name__ == "QwenImageSample"
+        for s_, r in zip(samples, [0.1, 0.9, 0.4, 0.2]):
+            s_.extra_kwargs["reward"] = torch.tensor(r)
+        tr.compute_advantages(samples, {"r": torch.tensor([0.1, 0.9, 0.4, 0.2])}, store_to_samples=True)
+        n0 = len(ad.engine.calls)
+        torch.manual_seed(1234)
+        tr.optimize(samples)
+    finally:
+        MQ.sde_step, MV.WanVAEDecoder = real
+    kinds = [c[0] for c in ad.engine.calls[n0:]]
+    assert "transformer_forward" in kinds                                  # the no-grad old-policy / reference predictions ran on the engine
+    assert logged and all(torch.isfinite(torch.as_tensor(v)).all() for _, d in logged for v in d.values() if torch.is_tensor(v) or isinstance(v, float))
+    assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable)), logged
