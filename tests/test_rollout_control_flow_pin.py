@@ -344,7 +344,7 @@ def test_differential_sweep_plugin_vs_reference_adapter(trial):
     # (log-probs with a selection that keeps no SDE step make the reference's own collector stack an empty list: not drawn)
     traj = rnd.choice(["all", "train"]) if clp else rnd.choice(["all", None, [0, -1], [-1], [1, 2, -2]])
     callbacks = rnd.choice([[], ["noise_level"], ["next_latents_mean"], ["noise_pred", "std_dev_t", "dt", "noise_level"]])
-    explicit_gen = rnd.random() < 0.4
+    explicit_gen = rnd.choice([None, None, "one", "per-sample list"])      # evaluate() passes one CPU generator per prompt
     ctx = dict(trial=trial, dyn=dyn, storage=storage, N=N, window=window, n_sde=n_sde, is_eval=is_eval, cfg=cfg_mode, gs=gs, clp=clp,
                traj=traj, callbacks=callbacks, explicit_gen=explicit_gen)
     g = torch.Generator().manual_seed(100 + trial)
@@ -360,7 +360,8 @@ def test_differential_sweep_plugin_vs_reference_adapter(trial):
         kw = dict(prompt=[f"p{i}" for i in range(Bq)], prompt_ids=torch.arange(Bq * 3).reshape(Bq, 3), height=64, width=96,
                   num_inference_steps=N, guidance_scale=gs, prompt_embeds=pe, pooled_prompt_embeds=pp, compute_log_prob=clp,
                   trajectory_indices=ti, extra_call_back_kwargs=list(callbacks),
-                  generator=torch.Generator().manual_seed(9 + trial) if explicit_gen else None)
+                  generator=(None if explicit_gen is None else torch.Generator().manual_seed(9 + trial) if explicit_gen == "one" else
+                             [torch.Generator().manual_seed(9 + trial + 17 * i) for i in range(Bq)]))
         if cfg_mode == "cfg":
             kw.update(negative_prompt_embeds=ne, negative_pooled_prompt_embeds=npl, negative_prompt_ids=torch.zeros(Bq, 3, dtype=torch.long))
         return ad.inference(**kw)
@@ -504,7 +505,7 @@ def test_differential_sweep_standalone_adapter_vs_reference_adapter(trial):
     clp = (not is_eval) and dyn != "ODE" and rnd.random() < 0.8
     traj = rnd.choice(["all", "train"]) if clp else rnd.choice(["all", None, [0, -1], [-1], [1, 2, -2]])
     callbacks = rnd.choice([[], ["noise_level"], ["next_latents_mean"], ["noise_pred", "std_dev_t", "dt", "noise_level"]])
-    explicit_gen = rnd.random() < 0.4
+    explicit_gen = rnd.choice([None, None, "one", "per-sample list"])      # evaluate() passes one CPU generator per prompt
     ctx = dict(trial=trial, dyn=dyn, storage=storage, N=N, window=window, n_sde=n_sde, is_eval=is_eval, cfg=cfg_mode, gs=gs, clp=clp,
                traj=traj, callbacks=callbacks, explicit_gen=explicit_gen)
     g = torch.Generator().manual_seed(100 + trial)
@@ -518,7 +519,8 @@ def test_differential_sweep_standalone_adapter_vs_reference_adapter(trial):
         kw = dict(prompt=[f"p{i}" for i in range(Bq)], prompt_ids=torch.arange(Bq * 3).reshape(Bq, 3), height=64, width=96,
                   num_inference_steps=N, guidance_scale=gs, prompt_embeds=pe, pooled_prompt_embeds=pp, compute_log_prob=clp,
                   trajectory_indices=ti, extra_call_back_kwargs=list(callbacks),
-                  generator=torch.Generator().manual_seed(9 + trial) if explicit_gen else None)
+                  generator=(None if explicit_gen is None else torch.Generator().manual_seed(9 + trial) if explicit_gen == "one" else
+                             [torch.Generator().manual_seed(9 + trial + 17 * i) for i in range(Bq)]))
         if cfg_mode == "cfg":
             kw.update(negative_prompt_embeds=ne, negative_pooled_prompt_embeds=npl, negative_prompt_ids=torch.zeros(Bq, 3, dtype=torch.long))
         return ad.inference(**kw)
