@@ -1118,3 +1118,45 @@ def test_reference_evaluate_loop_runs_on_the_plugins(ref, family):
     assert any(k.startswith("eval/reward_r") for _, d in logged for k in d)
     assert not ad.scheduler.is_eval or True
     assert F.FakeTransformer.calls == 0
+
+
+def test_reference_training_loop_start_runs_two_epochs_on_the_plugin(ref):
+    """`GRPOTrainer.start()` itself (trainers/grpo.py:60-90): per-epoch scheduler re-seeding (a new SDE-step selection each epoch), sample ->
+    prepare_feedback -> optimize -> `adapter.ema_step`, twice, on the SD3.5 plugin with the engine double -- the second epoch's rollouts run
+    on the weights the first epoch produced, and the SDE step the rollout trains on follows the reference's per-epoch seed."""
+    from flow_factory.trainers.grpo import GRPOTrainer
+    P = ref
+    M, K = 2, 2
+
+    def tweak(cfg):
+        _small(cfg.training_args, guidance_scale=1.0, kl_beta=0.0, max_epochs=2, clip_range=(-1e-4, 1e-4), adv_clip_range=(-5.0, 5.0))
+        cfg.log_args.save_freq = 0
+        cfg.eval_args.eval_freq = 0
+    tr, ad, tr_mod, logged = _real_trainer(P, GRPOTrainer, YAML_FULL, tweak, _prompt_batches(M, K), K)
+    seen = []
+
+    class Buffer:
+        def clear(self):
+            seen.clear()
+
+        def add_samples(self, s):
+            seen.extend(s)
+
+        def finalize(self, store_to_samples=True, split="all"):
+            r = torch.linspace(0.1, 0.9, len(seen))
+            for s_, v in zip(seen, r):
+                s_.extra_kwargs["reward"] = v
+            return {"r": r}
+    tr.reward_buffer = Buffer()
+    torch.manual_seed(5)
+    tr.start()
+    assert tr.epoch == 2
+    rolls = [c[1] for c in ad.engine.calls if c[0] == "rollout"]
+    assert len(rolls) == 2 * M
+    assert rolls[0]["weights"] == rolls[1]["weights"] != rolls[2]["weights"]                 # epoch 2 samples on the updated policy
+    sde = [tuple(i for i, e in enumerate(r["noise_levels"]) if e > 0) for r in rolls]
+    assert sde[0] == sde[1] and sde[2] == sde[3] and all(len(x) == 1 for x in sde)            # one SDE step per epoch (num_sde_steps 1) ...
+    from flow_factory.scheduler.flow_match_euler_discrete import FlowMatchEulerDiscreteSDEScheduler as RefSched
+    assert isinstance(ad.scheduler, RefSched)                                                  # ... chosen by the reference's own scheduler
+    assert any(k.startswith("train/") for _, d in logged for k in d)
+    assert F.FakeTransformer.calls == 0
