@@ -19,6 +19,7 @@ Missing names raise unless `partial=True` (a stale weight must never be used sil
 """
 from __future__ import annotations
 
+import weakref
 from typing import Callable, Dict, Iterable, List, Optional, Tuple
 
 import torch
@@ -154,13 +155,20 @@ class LiveWeights:
         self.engine, self.get_module, self.partial = engine, get_module, partial
         self.epoch = 1
         self.lora_scale = 1.0      # joint_attention_kwargs['scale'] (diffusers scale_lora_layers): extra factor on every LoRA delta
-        self._root_id: Optional[int] = None
+        self._root_ref = None      # weak reference to the unwrapped module the sources were resolved against (an `id()` could be reused
+                                   # by a NEW module allocated at a freed one's address: the sources would silently stay on the old tensors)
         self._sources: Dict[str, object] = {}
         self._bound: Dict[str, object] = {}
         self.last_rebinds = 0
 
     def invalidate(self) -> None:
         self.epoch += 1
+
+    def reset(self) -> None:
+        """Re-resolve every source at the next `sync()`: the module TREE was changed in place (e.g. linear layers wrapped into LoRA layers
+        after the first sync), which neither version counters nor the root's identity can show."""
+        self._root_ref = None
+        self._bound.clear()
 
     def set_lora_scale(self, scale: float) -> None:
         self.lora_scale = float(scale)
@@ -172,9 +180,9 @@ class LiveWeights:
     def sync(self) -> int:
         root = self.get_module()
         inner = unwrap_module(root)
-        if id(inner) != self._root_id:
+        if self._root_ref is None or self._root_ref() is not inner:
             self._sources = resolve_sources(inner, self.engine.param_names(), partial=self.partial)
-            self._root_id = id(inner)
+            self._root_ref = weakref.ref(inner)
             self._bound.clear()
         n = 0
         for name, src in self._sources.items():

@@ -286,8 +286,7 @@ def test_lora_gradients_flow_through_the_merged_weight(gpu):
     mod.cuda()
     for n, prm in mod.named_parameters():
         prm.requires_grad_("lora_" in n)
-    ad._live_weights.invalidate()
-    ad._live_weights._root_id = None            # the module tree changed: re-resolve
+    ad._live_weights.reset()                    # the module tree changed in place: re-resolve the sources
     B, h, w, Nt = 2, 16, 16, 13
     inp = _inputs(B, h, w, Nt, seed=2)
     ad.scheduler.set_timesteps(4)

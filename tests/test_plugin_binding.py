@@ -1148,12 +1148,17 @@ def test_reference_training_loop_start_runs_two_epochs_on_the_plugin(ref):
                 s_.extra_kwargs["reward"] = v
             return {"r": r}
     tr.reward_buffer = Buffer()
+    trainable = ad.get_trainable_parameters()
+    before = [p_.detach().clone() for p_ in trainable]
     torch.manual_seed(5)
     tr.start()
     assert tr.epoch == 2
     rolls = [c[1] for c in ad.engine.calls if c[0] == "rollout"]
     assert len(rolls) == 2 * M
-    assert rolls[0]["weights"] == rolls[1]["weights"] != rolls[2]["weights"]                 # epoch 2 samples on the updated policy
+    assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable))          # the optimizer moved the policy ...
+    assert rolls[0]["weights"] == rolls[1]["weights"] and rolls[2]["weights"] == rolls[3]["weights"]   # ... between, not within, epochs
+    names = [n for n, p_ in tr_mod.named_parameters() if p_.requires_grad]
+    assert set(ad.engine.bind_log[len(ad.engine.param_names()):]) <= set(names)               # and only those tensors were re-bound
     sde = [tuple(i for i, e in enumerate(r["noise_levels"]) if e > 0) for r in rolls]
     assert sde[0] == sde[1] and sde[2] == sde[3] and all(len(x) == 1 for x in sde)            # one SDE step per epoch (num_sde_steps 1) ...
     from flow_factory.scheduler.flow_match_euler_discrete import FlowMatchEulerDiscreteSDEScheduler as RefSched
