@@ -728,3 +728,44 @@ class QwenStandinPlanModel(QwenStandinPlan):
 
 class QwenStandinEngineModel(_StandinFamilyEngine):
     PLAN = QwenStandinPlanModel
+
+
+# --------------------------------------------------------------------------------------- a miniature `peft` for the reference's apply_lora()
+class MiniLoraConfig:
+    def __init__(self, r=8, lora_alpha=16, init_lora_weights=True, target_modules=(), **unused):
+        self.r, self.lora_alpha, self.target_modules = int(r), float(lora_alpha), list(target_modules)
+
+
+class MiniPeftModel(FakePeftModel):
+    """What the reference's `apply_lora` / `use_ref_parameters` ask of `peft.PeftModel` (models/abc.py:856-950, :556-583): adapter registry,
+    `set_adapter`, `disable_adapter()`; every non-LoRA parameter frozen, B = 0 at initialisation (the delta starts at zero, as peft's)."""
+
+    def __init__(self, inner, cfg: "MiniLoraConfig"):
+        wrapped = []
+        for path, mod in list(inner.named_modules()):
+            if any(path.endswith(t) for t in cfg.target_modules) and hasattr(mod, "weight") and not hasattr(mod, "base_layer"):
+                parent = inner.get_submodule(path.rsplit(".", 1)[0])
+                lay = FakeLoraLinear(mod, r=cfg.r, alpha=cfg.lora_alpha, seed=len(wrapped))
+                with torch.no_grad():
+                    lay.lora_B["default"].weight.zero_()
+                setattr(parent, path.rsplit(".", 1)[1], lay)
+                wrapped.append(path)
+        assert wrapped, f"no module matches {cfg.target_modules}"
+        super().__init__(inner)
+        self.wrapped = wrapped
+        for n, p in self.named_parameters():
+            p.requires_grad_("lora_" in n)
+        self.active_adapter = "default"
+
+    def set_adapter(self, name):
+        self.active_adapter = name
+
+    def add_adapter(self, name, cfg):
+        raise NotImplementedError
+
+    def delete_adapter(self, name):
+        raise NotImplementedError
+
+
+def mini_get_peft_model(model, cfg):
+    return MiniPeftModel(model, cfg)

@@ -1165,3 +1165,57 @@ def test_reference_training_loop_start_runs_two_epochs_on_the_plugin(ref):
     assert isinstance(ad.scheduler, RefSched)                                                  # ... chosen by the reference's own scheduler
     assert any(k.startswith("train/") for _, d in logged for k in d)
     assert F.FakeTransformer.calls == 0
+
+
+def test_reference_grpo_trainer_with_lora_through_the_plugin(ref):
+    """The reference's flagship configuration -- `finetune_type: lora` (examples/grpo/lora/sd3_5) -- at the trainer level: the reference's own
+    `apply_lora` wraps the transformer through a miniature `peft` (LoraConfig / get_peft_model / PeftModel with `disable_adapter()`), the
+    plugin binds MERGED weights `W + s B A`, `optimize()` differentiates through the merged weight into A and B (only LoRA tensors are
+    trainable), the KL reference forward runs with the adapters disabled (`use_ref_parameters` -> `disable_adapter()`): first ratio exactly
+    1, KL exactly 0 while B = 0, A / B move, the base weights do not, and the next rollout runs on the new merged weights."""
+    import flow_factory.models.abc as RA
+    from flow_factory.trainers.grpo import GRPOTrainer
+    P = ref
+    M, K = 2, 2
+    saved = (RA.get_peft_model, RA.LoraConfig, RA.PeftModel)
+    RA.get_peft_model, RA.LoraConfig, RA.PeftModel = F.mini_get_peft_model, F.MiniLoraConfig, F.MiniPeftModel
+    try:
+        import tempfile
+        import yaml as Y
+        from flow_factory.hparams import Arguments
+
+        def tweak(cfg):
+            _small(cfg.training_args, guidance_scale=1.0, kl_beta=0.05, kl_type="v-based", clip_range=(-1e-4, 1e-4), adv_clip_range=(-5.0, 5.0))
+            cfg.model_args.finetune_type = "lora"
+            cfg.model_args.lora_rank, cfg.model_args.lora_alpha = 4, 8
+        tr, ad, tr_mod, logged = _real_trainer(P, GRPOTrainer, YAML_LORA, tweak, _prompt_batches(M, K), K, lr=50.0)
+        peft_model = ad.transformer
+        assert isinstance(peft_model, F.MiniPeftModel) and peft_model.wrapped
+        trainable = ad.get_trainable_parameters()
+        names = {n for n, p_ in peft_model.named_parameters() if p_.requires_grad}
+        assert trainable and all("lora_" in n for n in names) and len(trainable) == len(names)
+        base_before = {n: p_.detach().clone() for n, p_ in peft_model.named_parameters() if "lora_" not in n}
+        lora_before = {n: p_.detach().clone() for n, p_ in peft_model.named_parameters() if "lora_" in n}
+        eng = ad.engine
+        torch.manual_seed(99)
+        samples = tr.sample()
+        w_rollout = eng.fingerprint()
+        tr.compute_advantages(samples, {"r": torch.tensor([0.1, 0.9, 0.4, 0.2])}, store_to_samples=True)
+        n0 = len(eng.calls)
+        torch.manual_seed(1234)
+        tr.optimize(samples)
+    finally:
+        RA.get_peft_model, RA.LoraConfig, RA.PeftModel = saved
+    first = logged[0][1]
+    assert first["train/ratio_min"] == 1.0 and first["train/ratio_max"] == 1.0, first
+    assert float(first["train/kl_div"]) == 0.0                                          # B = 0: policy == reference before the first step
+    ref_steps = [c[1] for c in eng.calls[n0:] if c[0] == "denoise_step"]
+    assert ref_steps and all(abs(c["weights"] - w_rollout) <= 1e-9 * abs(w_rollout) for c in ref_steps)   # adapters disabled = base weights
+    moved = {n for n, p_ in peft_model.named_parameters() if "lora_" in n and not torch.equal(p_.detach(), lora_before[n])}
+    assert any("lora_B" in n for n in moved), sorted(moved)                             # d/dB = s * dW A^T is non-zero from the first step
+    assert all(torch.equal(p_.detach(), base_before[n]) for n, p_ in peft_model.named_parameters() if "lora_" not in n)
+    assert float(logged[-1][1]["train/kl_div"]) > 0.0 or len(logged) == 1
+    tr.epoch = 1
+    tr.sample()
+    assert [c for c in eng.calls if c[0] == "rollout"][-1][1]["weights"] != pytest.approx(w_rollout, rel=1e-12)   # new merged weights
+    assert F.FakeTransformer.calls == 0
