@@ -165,6 +165,7 @@ def main():
     ap.add_argument("--model", choices=["sd3_5", "flux1"], default="sd3_5",
                     help="sd3_5 = BASELINE.json configs[1] (the metric's config); flux1 = FLUX.1-dev geometry (configs[2], SURVEY 8(f) N3)")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed w.r.t. `value`) VAE-decode leg")
+    ap.add_argument("--no-small-batch", action="store_true", help="skip the (untimed w.r.t. `value`) small-batch legs")
     ap.add_argument("--no-graph", action="store_true", help="launch the rollout eagerly instead of replaying the hipGraph")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test without a GPU: gloo backend, the rollout replaced by a fixed sleep per micro-batch "
@@ -381,6 +382,43 @@ def main():
         out["graph_vs_eager"] = {"graph_ms_per_rollout": round(g_s * 1e3, 2), "eager_ms_per_rollout": round(e_s * 1e3, 2),
                                  "graph_denoise_steps_per_s": round(B * N / g_s, 3), "eager_denoise_steps_per_s": round(B * N / e_s, 3),
                                  "note": "untimed w.r.t. `value`; one hipGraph launch replays the whole N-step loop (~7 850 kernels)"}
+    if rank == 0 and world == 1 and not flux_mode and not args.no_small_batch:
+        # Small-batch configurations of the same engine (hipGraph replay; the text-stream chain of every block on a second stream): the
+        # reference's own example shape (examples/grpo/full/sd3_5: 512^2, N = 10, B = 2 with CFG) and B = 2 at the bench resolution.
+        # Reported beside the metric, never inside `value`; a failure here is recorded, not raised.
+        try:
+            legs = {}
+            lib.mi355_tune_set(2, 1)
+            for tag, (b2, size2, gs2, n2) in (("b2_1024_nocfg_28", (2, 1024, 1.0, 28)), ("b2_512_cfg4.5_10", (2, 512, 4.5, 10))):
+                cfg2 = gs2 > 1.0
+                pe2 = torch.randn(b2, N_TEXT, cfg.joint_attention_dim, device=dev, generator=g).bfloat16()
+                pp2 = torch.randn(b2, cfg.pooled_projection_dim, device=dev, generator=g).bfloat16()
+                ne2 = torch.randn(b2, N_TEXT, cfg.joint_attention_dim, device=dev, generator=g).bfloat16() if cfg2 else None
+                np2 = torch.randn(b2, cfg.pooled_projection_dim, device=dev, generator=g).bfloat16() if cfg2 else None
+                traj2 = compute_trajectory_indices(sched.train_timesteps, n2)
+
+                def roll2():
+                    return adapter.inference(prompt=None, height=size2, width=size2, num_inference_steps=n2, guidance_scale=gs2,
+                                             prompt_embeds=pe2, pooled_prompt_embeds=pp2, negative_prompt_embeds=ne2,
+                                             negative_pooled_prompt_embeds=np2, compute_log_prob=True, trajectory_indices=traj2)
+                roll2(); roll2()                                  # eager warm-up of the new plan, then capture
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    s2 = roll2()
+                torch.cuda.synchronize()
+                dt2 = (time.perf_counter() - t1) / 3
+                assert len(s2) == b2 and torch.isfinite(s2[0].log_probs).all()
+                n_cfg2 = 2 if cfg2 else 1
+                F2 = forward_flops(cfg, (size2 // 16) ** 2, N_TEXT)
+                tf2 = n_cfg2 * F2 * b2 * n2 / dt2 / 1e12
+                legs[tag] = {"batch": b2, "size": size2, "guidance": gs2, "denoise_steps": n2, "ms_per_rollout": round(dt2 * 1e3, 2),
+                             "denoise_steps_per_s": round(b2 * n2 / dt2, 2), "forward_tflops": round(tf2, 1),
+                             "forward_frac": round(tf2 / PEAK_BF16_TFLOPS, 4)}
+            out["small_batch"] = {**legs, "note": "hipGraph replay, two-stream forward; untimed w.r.t. `value`"}
+        except Exception as e:  # noqa: BLE001 -- never let an extra leg take the headline line down
+            out["small_batch"] = {"error": repr(e)}
+        lib.mi355_tune_set(2, 0 if args.no_graph else 1)
     if flux_mode and rank == 0:
         out["roofline"] = {"bound": "mfma", "kernel": "whole FLUX.1 forward (MFMA GEMMs + head_dim-128 attention), wall-clock of the rollout",
                            "achieved": round(fwd_tflops, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fwd_tflops / PEAK_BF16_TFLOPS, 4),
