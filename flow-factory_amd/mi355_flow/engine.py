@@ -59,6 +59,30 @@ class TransformerConfig:
     def dim(self) -> int:
         return self.num_heads * self.head_dim
 
+    @classmethod
+    def from_hf(cls, config) -> "TransformerConfig":
+        """From a diffusers `SD3Transformer2DModel.config` (what `SD3_5Adapter` loads, reference sd3_5.py:60-66).  The engine implements
+        the SD3.5 block (RMS q/k norm per head, head_dim 64, caption projection to the model width); any other member of the SD3 family
+        -- e.g. SD3.0-medium, which has no q/k norm -- is refused HERE, by name, instead of failing later on a missing weight."""
+        g = (lambda k, d=None: getattr(config, k, d)) if not isinstance(config, dict) else (lambda k, d=None: config.get(k, d))
+        heads, hd = int(g("num_attention_heads", 24)), int(g("attention_head_dim", 64))
+        qk = g("qk_norm", "rms_norm")
+        if qk != "rms_norm":
+            raise NotImplementedError(f"mi355_flow: SD3 transformer with qk_norm={qk!r}: the engine implements the SD3.5 block (qk_norm='rms_norm')")
+        if hd != 64:
+            raise NotImplementedError(f"mi355_flow: attention_head_dim={hd}: the SD3.5 engine's attention kernel is built for head_dim 64")
+        cap = g("caption_projection_dim", heads * hd)
+        if int(cap) != heads * hd:
+            raise NotImplementedError(f"mi355_flow: caption_projection_dim={cap} differs from the model width {heads * hd}")
+        dual = tuple(int(i) for i in (g("dual_attention_layers", ()) or ()))
+        layers = int(g("num_layers", 24))
+        if any(i < 0 or i >= layers for i in dual):
+            raise ValueError(f"mi355_flow: dual_attention_layers {dual} outside [0, {layers})")
+        return cls(in_channels=int(g("in_channels", 16)), out_channels=int(g("out_channels", None) or g("in_channels", 16)),
+                   patch_size=int(g("patch_size", 2)), num_layers=layers, num_heads=heads, head_dim=hd,
+                   joint_attention_dim=int(g("joint_attention_dim", 4096)), pooled_projection_dim=int(g("pooled_projection_dim", 2048)),
+                   pos_embed_max_size=int(g("pos_embed_max_size", 384)), dual_layers=dual)
+
     def to_c(self) -> ModelCfg:
         mask = 0
         for i in self.dual_layers:

@@ -211,12 +211,7 @@ if _RefAdapter is not None:
 
         def __init__(self, config, accelerator):
             _RefAdapter.__init__(self, config, accelerator)
-            tc = self.pipeline.transformer.config
-            self._init_live(Engine(TransformerConfig(
-                in_channels=tc.in_channels, out_channels=tc.out_channels, patch_size=tc.patch_size,
-                num_layers=tc.num_layers, num_heads=tc.num_attention_heads, head_dim=tc.attention_head_dim,
-                joint_attention_dim=tc.joint_attention_dim, pooled_projection_dim=tc.pooled_projection_dim,
-                pos_embed_max_size=tc.pos_embed_max_size, dual_layers=tuple(getattr(tc, "dual_attention_layers", ()) or ()))))
+            self._init_live(Engine(TransformerConfig.from_hf(self.pipeline.transformer.config)))
             self.vae_decoder = _native_vae(self.pipeline)
 
         @torch.no_grad()
