@@ -159,6 +159,25 @@ hipError_t launch_time_proj(const float* t, int rows, int dim, int t_round_dt, b
     return hipGetLastError();
 }
 
+// One wave that samples {s_memtime (core clocks, slows down with the power throttle), s_memrealtime (100 MHz wall clock)} every
+// ~sleep_iters * 8 k core clocks: launched on a side stream it sits in one wave slot beside the kernels under test and shows the core
+// clock they are actually delivered (profiles/r02_power_clock_notes.txt: 1.44 GHz inside the bf16 GEMM at the 1.35 kW cap, not the 2.4 GHz
+// the roofline peaks are quoted at).  Measurement tool (scripts/clock_under_load.py), never on the product path.
+__global__ void clock_probe_kernel(long long* out, int n, int sleep_iters) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < n; ++i) {
+        const long long c = clock64(), w = wall_clock64();
+        out[2 * i] = c;
+        out[2 * i + 1] = w;
+        for (int k = 0; k < sleep_iters; ++k) __builtin_amdgcn_s_sleep(127);
+    }
+}
+
+hipError_t launch_clock_probe(long long* out, int n, int sleep_iters, hipStream_t stream) {
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, stream, out, n, sleep_iters);
+    return hipGetLastError();
+}
+
 hipError_t launch_convert(const void* src, int src_dt, void* dst, int dst_dt, long n, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(convert_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, src, src_dt, dst, dst_dt, n);

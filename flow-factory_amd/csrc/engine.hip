@@ -1016,6 +1016,13 @@ extern "C" int mi355_op_linear_trace(void* stream, const void* A, const void* W,
     return 0;
 }
 
+// measurement tool: n samples of {s_memtime, s_memrealtime} (int64 pairs) taken by one wave, ~sleep_iters * 8 k core clocks apart
+extern "C" int mi355_clock_probe(void* stream, void* out, int n, int sleep_iters) {
+    if (!out || n <= 0 || sleep_iters < 0) return fail("mi355_clock_probe: bad argument");
+    HIPCHK(launch_clock_probe((long long*)out, n, sleep_iters, (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int mi355_op_attention(void* stream, const void* q, const void* k, const void* vT, void* o_img, void* o_ctx, int B,
                                   int H, int S, int S_pad, int n_img) {
     if (!q || !k || !vT || !o_img) return fail("mi355_op_attention: null argument");

@@ -170,6 +170,7 @@ hipError_t launch_pos_crop(const bf16_t* pos, bf16_t* out, int max_size, int hp,
 hipError_t launch_time_proj(const float* t, int rows, int dim, int t_round_dt, bf16_t* out, hipStream_t stream);
 // generic dtype conversion (weights binding); n elements
 hipError_t launch_convert(const void* src, int src_dt, void* dst, int dst_dt, long n, hipStream_t stream);
+hipError_t launch_clock_probe(long long* out, int n, int sleep_iters, hipStream_t stream);   // measurement tool: {core clock, wall clock} samples
 
 // ------------------------------------------------------------------------------ VAE decode (vae.hip)
 // latents [B][C][HW] (storage dtype) -> NHWC bf16 [B*HW][Cpad] = bf16(lat / scale + shift), channels >= C zero

@@ -104,6 +104,7 @@ SIGNATURES = {
     "mi355_op_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I]),
     "mi355_op_linear_w4": (_I, [_P, _P, _P, _P, _P, _I, _I, _I]),
     "mi355_op_linear_trace": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "mi355_clock_probe": (_I, [_P, _P, _I, _I]),
     "mi355_op_attention": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "mi355_op_ln_modulate": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F]),
     "mi355_vae_create": (_I, [C.POINTER(VaeCfg), C.POINTER(_P)]),

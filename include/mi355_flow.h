@@ -169,6 +169,10 @@ int mi355_op_linear_w4(void* stream, const void* A, const void* W, const float* 
  * trace[((wg*16 + tile_iter)*2 + group)*4 + {0: tile start, 1: main loop start, 2: main loop end, 3: stores drained}] */
 int mi355_op_linear_trace(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                           void* trace);
+/* measurement tool (scripts/clock_under_load.py): one wave writes n {s_memtime core-clock count, s_memrealtime 100 MHz count} int64 pairs to
+ * `out`, ~sleep_iters * 8 k core clocks apart; launched on a side stream beside the kernels under test it shows the core clock they are
+ * delivered under the package power cap */
+int mi355_clock_probe(void* stream, void* out, int n, int sleep_iters);
 /* q,k : [B][H][S_pad][64] bf16, vT : [B][H][64][S_pad] bf16 -> o_img [B*n_img][H*64], o_ctx [B*(S-n_img)][H*64] */
 int mi355_op_attention(void* stream, const void* q, const void* k, const void* vT, void* o_img, void* o_ctx, int B,
                        int H, int S, int S_pad, int n_img);

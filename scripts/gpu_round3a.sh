@@ -1,0 +1,15 @@
+# First GPU call of round 3 (everything here was written after round 2's GPU budget was spent and has NOT run on an MI355X yet):
+#   1. the gated checks (tests/test_gpu_next_round.py): SD3.5-large width forward vs the oracle; bench.py's small-batch legs
+#   2. the delivered-clock probe beside the hot kernels (scripts/clock_under_load.py) -> which kernel still has headroom at ITS clock
+#   3. the whole -m gpu suite at HEAD
+# usage: gpurun --timeout 900 -- 'bash scripts/gpu_round3a.sh'
+set -x
+cd $GRAFT_REPO_ROOT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r3a
+mkdir -p $OUT; rm -rf $OUT/*
+MI355_NEXT=1 timeout 600 python -m pytest tests/test_gpu_next_round.py -q 2>&1 | tail -15 > $OUT/next_round_tests.log; echo "next rc=$?" >> $OUT/status
+cat $OUT/next_round_tests.log
+timeout 120 python scripts/clock_under_load.py --ms 30 > $OUT/clock_under_load.txt 2>&1; echo "clock rc=$?" >> $OUT/status
+cat $OUT/clock_under_load.txt
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > $OUT/tests.log; echo "tests rc=$?" >> $OUT/status
+cat $OUT/tests.log
