@@ -28,7 +28,6 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from .binding import LiveWeights, _LoraWeight, _Plain, _full, unwrap_module
-from .engine import DYNAMICS, _bf16c, _scalars
 
 
 # --------------------------------------------------------------------------------------------- trainable sources

@@ -20,7 +20,7 @@ Missing names raise unless `partial=True` (a stale weight must never be used sil
 from __future__ import annotations
 
 import weakref
-from typing import Callable, Dict, Iterable, List, Optional, Tuple
+from typing import Callable, Dict, Iterable, List, Tuple
 
 import torch
 

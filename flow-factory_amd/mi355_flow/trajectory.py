@@ -9,7 +9,7 @@ The engine consumes the same selection as a `keep_slot` table (see `keep_slots`)
 from __future__ import annotations
 
 from collections import defaultdict
-from typing import Any, Dict, List, Literal, Optional, Sequence, Set, Union
+from typing import Any, Dict, List, Literal, Optional, Set, Union
 
 import torch
 

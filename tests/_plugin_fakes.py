@@ -459,6 +459,42 @@ class TrainerAccelerator(FakeAccelerator):
         pass
 
 
+class DistTrainerAccelerator(TrainerAccelerator):
+    """`TrainerAccelerator` over an initialised `torch.distributed` group (gloo on CPU): what accelerate's gather / reduce / barrier do on
+    N processes, for world-size-2 runs of the reference's trainers through the plugin (tests/test_dist_gloo.py)."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        super().__init__()
+        self.process_index, self.num_processes = dist.get_rank(), dist.get_world_size()
+        self.is_main_process = self.is_local_main_process = self.process_index == 0
+        self.distributed_type = "MULTI_CPU"
+
+    def gather(self, t):
+        import torch.distributed as dist
+        t = t.contiguous()
+        out = [torch.empty_like(t) for _ in range(self.num_processes)]
+        dist.all_gather(out, t)
+        return torch.cat(out, 0)
+
+    def reduce(self, t, reduction="mean"):
+        import torch.distributed as dist
+        if isinstance(t, dict):                                   # accelerate reduces nested structures leaf by leaf
+            return {k: self.reduce(v, reduction) for k, v in t.items()}
+        if isinstance(t, (list, tuple)):
+            return type(t)(self.reduce(v, reduction) for v in t)
+        t = t.clone()
+        dist.all_reduce(t)
+        return t / self.num_processes if reduction == "mean" else t
+
+    def wait_for_everyone(self):
+        import torch.distributed as dist
+        dist.barrier()
+
+    def unwrap_model(self, m, **k):
+        return m.module if type(m).__name__ == "DistributedDataParallel" else m
+
+
 # --------------------------------------------------------------------------------------- engine double that computes (oracle + stand-in)
 class StandinPlan(FakePlan):
     """Plan double whose rollout / single step ARE computed: the oracle's SDE step (`oracle.scheduler_ref`, pinned bit-exact against the

@@ -204,3 +204,107 @@ def test_fsdp2_sharded_module_binds_whole_tensors_and_tracks_optimizer_steps(tmp
     for r in range(2):
         ok, n0, n1 = np.load(tmp_path / f"fsdp_{r}.npy")
         assert ok == 1 and n0 == n1 > 0, (r, ok, n0, n1)
+
+
+def _trainer_worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from oracle import ref_package
+    ref_package.install()
+    import _plugin_fakes as F
+    import mi355_flow.flow_factory_plugin as P
+    import test_plugin_binding as T
+    from flow_factory.advantage.advantage_processor import AdvantageProcessor
+    from flow_factory.trainers.grpo import GRPOTrainer
+    P.Engine, P.VAEDecoder = F.FakeEngine, F.FakeVAEDecoder
+    P.VAEConfig = types.SimpleNamespace(from_hf=lambda c: c)
+    M_total, K = 4, 2
+    M = M_total // world
+    mine = T._prompt_batches(M_total, K, cfg_pair=True)[rank * M:(rank + 1) * M]       # GroupContiguousSampler: rank r owns whole groups
+
+    def tweak(cfg):
+        T._small(cfg.training_args, kl_beta=0.05, clip_range=(-1e-4, 1e-4), adv_clip_range=(-5.0, 5.0))
+    acc = F.DistTrainerAccelerator()
+    tr, ad, tr_mod, logged = T._real_trainer(P, GRPOTrainer, T.YAML_FULL, tweak, mine, K, accelerator=acc)
+    # what BaseTrainer._initialization does with accelerator.prepare (trainers/abc.py:255-263): the trainable component becomes the DDP module
+    ad.set_component("transformer", DDP(tr_mod))
+    trainable = ad.get_trainable_parameters()
+    before = torch.cat([p_.detach().reshape(-1) for p_ in trainable]).clone()
+    torch.manual_seed(100 + rank)                     # device-specific seeding (trainers/loader.py:70): the ranks draw different noise
+    samples = tr.sample()
+    ok = len(samples) == M * K and len({s.unique_id for s in samples}) == M
+    # ---- advantages: 2-rank result of the reference's processor == its single-process result on the union of the samples
+    # K = 2: group-normalised advantages are (-1, +1) or (+1, -1).  One group has the same pattern on both ranks, the other MIRRORED ones:
+    # the engine double's d(log-prob)/dW depends (almost only) on the sample's position in the batch, so the local gradients of the mirrored
+    # micro-batch are non-zero and opposite -- their DDP average all but vanishes.  A collapsed all-reduced gradient norm there (next to a
+    # full-size one for the other micro-batch) is the evidence that the reducer really averaged across ranks.
+    all_r = torch.tensor([0.1, 0.9, 0.4, 0.2, 0.3, 0.7, 0.5, 0.8])
+    adv = tr.compute_advantages(samples, {"r": all_r[rank * M * K:(rank + 1) * M * K]}, store_to_samples=True)
+    ids = acc.gather(torch.tensor([s.unique_id for s in samples], dtype=torch.int64))
+    union = [types.SimpleNamespace(unique_id=int(i), extra_kwargs={}) for i in ids]
+    solo = AdvantageProcessor(accelerator=F.TrainerAccelerator(), reward_weights={"r": 1.0}, group_size=K, global_std=True,
+                              sampler_type="group_contiguous", verbose=False)
+    want = solo.compute_advantages(samples=union, rewards={"r": all_r}, store_to_samples=False,
+                                   aggregation_func=tr.training_args.advantage_aggregation)
+    ok_adv = bool(torch.allclose(adv.float().cpu(), torch.as_tensor(want).float()[rank * M * K:(rank + 1) * M * K], rtol=1e-5, atol=1e-6))
+    # ---- optimize(): DDP averages the gradients the engine's autograd node returns; every rank takes the same steps
+    n0 = len(ad.engine.calls)
+    if os.environ.get("MI355_TEST_DEBUG"):
+        _step = tr.optimizer.step
+        def step(*a, **k):
+            gs = [p_.grad for g_ in tr.optimizer.param_groups for p_ in g_["params"]]
+            print(f"[rank {rank}] optimizer.step: {sum(g is not None for g in gs)}/{len(gs)} grads, max |g| = "
+                  f"{max((float(g.abs().max()) for g in gs if g is not None), default=-1):.3e}; same objects as trainable: "
+                  f"{all(a is b for a, b in zip([p_ for g_ in tr.optimizer.param_groups for p_ in g_['params']], trainable))}", flush=True)
+            return _step(*a, **k)
+        tr.optimizer.step = step
+    tr.optimize(samples)
+    kinds = [c[0] for c in ad.engine.calls[n0:]]
+    first = logged[0][1]
+    ok_ratio = first["train/ratio_min"] == 1.0 and first["train/ratio_max"] == 1.0
+    after = torch.cat([p_.detach().reshape(-1) for p_ in trainable])
+    both = acc.gather(after.reshape(1, -1))
+    ok_same = bool(torch.equal(both[0], both[1])) and not torch.equal(after, before)
+    if os.environ.get("MI355_TEST_DEBUG"):
+        print(f"[rank {rank}] adv = {adv.tolist()} logged[0] = { {k: float(v) for k, v in logged[0][1].items()} }", flush=True)
+        print(f"[rank {rank}] max |w0 - w1| = {float((both[0] - both[1]).abs().max()):.3e}, moved {float((after - before).abs().max()):.3e}, "
+              f"ddp = {type(ad.transformer).__name__}, kinds = {kinds}", flush=True)
+    ok_calls = kinds.count("denoise_step_train") == kinds.count("denoise_step_backward") >= M
+    gn = sorted(float(d["train/grad_norm"]) for _, d in logged[:2])       # (optimize() shuffles with a seeded generator: same order on both ranks)
+    ok_reduced = gn[1] > 0.0 and gn[0] < 0.05 * gn[1]
+    # the next rollout of BOTH ranks runs on the same updated policy (no explicit re-bind)
+    tr.epoch = 1
+    tr.sample()
+    fp = torch.tensor([[c for c in ad.engine.calls if c[0] in ("rollout", "denoise_step")][-1][1]["weights"]], dtype=torch.float64)
+    fps = acc.gather(fp)
+    ok_fp = bool(fps[0] == fps[1])
+    np.save(os.path.join(out_dir, f"trainer_{rank}.npy"), np.array([int(ok), int(ok_adv), int(ok_ratio), int(ok_same), int(ok_calls), int(ok_fp),
+                                                                    int(F.FakeTransformer.calls == 0), int(ok_reduced)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reference_grpo_trainer_on_two_ranks_through_the_plugin(tmp_path):
+    """SURVEY.md 8(e) at the trainer level: the reference's own `GRPOTrainer` (sample -> compute_advantages -> optimize), one process per
+    rank on gloo, each rank rolling out ITS prompt groups through the plugin (no data-path collective), the reference's AdvantageProcessor
+    gathering rewards across ranks (== its single-process result on the union), and the policy update all-reduced by DDP around the
+    engine's autograd node: first ratio exactly 1 on every rank, bit-identical weights on both ranks after the epoch, the next rollout on
+    the same new policy.  (Engine = the differentiable double; on the GPUs the same code runs with backend `nccl` = RCCL.)"""
+    import socket
+    import pytest
+    from oracle import ref_package
+    if not ref_package.available():
+        pytest.skip("needs /root/reference (build container only)")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    mp.spawn(_trainer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        flags = np.load(tmp_path / f"trainer_{r}.npy").tolist()
+        assert flags == [1] * 8, (r, dict(zip(["samples", "advantages", "ratio", "same_weights", "calls", "next_policy", "no_torch_forward",
+                                               "gradients_all_reduced"], flags)))

@@ -684,7 +684,7 @@ def test_reference_nft_trainer_runs_an_epoch_through_the_plugin(ref):
 
 
 # ------------------------------------------------------------------------------------------------- generic harness: a REAL trainer object
-def _real_trainer(P, trainer_cls, yaml, tweak, batches, K, lr=500.0, engine=None, make_adapter=None):
+def _real_trainer(P, trainer_cls, yaml, tweak, batches, K, lr=500.0, engine=None, make_adapter=None, accelerator=None):
     """Constructs `trainer_cls(accelerator, config, adapter)` through the reference's own `__init__` chain; only `BaseTrainer`'s
     environment set-up (`_initialization`: dataset / dataloader / reward models / accelerator.prepare, and the logging backend) is
     replaced by test objects.  Returns (trainer, adapter, torch module, log list)."""
@@ -707,7 +707,7 @@ def _real_trainer(P, trainer_cls, yaml, tweak, batches, K, lr=500.0, engine=None
     cfg = Arguments.load_from_yaml(f.name)
     os.unlink(f.name)
     tweak(cfg)
-    acc = F.TrainerAccelerator()
+    acc = accelerator or F.TrainerAccelerator()
     if make_adapter is not None:                 # another model family: the caller builds the plugin adapter (and its torch module)
         ad, tr_mod = make_adapter(cfg, acc)
     else:
