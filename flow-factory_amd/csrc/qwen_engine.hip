@@ -216,6 +216,12 @@ struct mi355_qwen_plan {
     bf16_t* io_pe;
     std::vector<float> host_t, host_sc;
     std::vector<int> host_len;
+    // two-stream forward (opt-in, mi355_tune_set key 12): the text chain of every block on a plan-owned side stream with its own q|k
+    // staging and MLP-hidden buffers (the single-stream path shares `qkbuf` / `big` between the two chains)
+    hipStream_t side = nullptr;
+    char* ws_side = nullptr;
+    bf16_t *qkbuf_c = nullptr, *big_c = nullptr;
+    std::vector<hipEvent_t> ev_join, ev_fork;   // per block: text q|k|v ready (side -> main), attention done (main -> side); [L] = forward start / end
 };
 
 extern "C" int mi355_qwen_plan_create(mi355_qwen* e, int batch, int n_cfg, int latent_h, int latent_w, int n_text, int max_steps,
@@ -314,6 +320,10 @@ extern "C" int mi355_qwen_plan_create(mi355_qwen* e, int batch, int n_cfg, int l
 
 extern "C" int mi355_qwen_plan_destroy(mi355_qwen_plan* p) {
     if (!p) return 0;
+    for (hipEvent_t ev : p->ev_join) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : p->ev_fork) (void)hipEventDestroy(ev);
+    if (p->side) (void)hipStreamDestroy(p->side);
+    if (p->ws_side) (void)hipFree(p->ws_side);
     if (p->ws) (void)hipFree(p->ws);
     delete p;
     return 0;
@@ -385,14 +395,14 @@ int ln_mod(mi355_qwen_plan* p, hipStream_t st, const bf16_t* x, bf16_t* out, con
 
 // q|k projection (one GEMM) -> per-head RMSNorm + RoPE + scatter; V^T projection with the scatter fused (operands swapped)
 int qkv(mi355_qwen_plan* p, hipStream_t st, const bf16_t* xin, int M, int rps, int s_off, const bf16_t* w_qk, const float* b_qk,
-        const bf16_t* w_v, const float* b_v, const float* nq, const float* nk) {
+        const bf16_t* w_v, const float* b_v, const float* nq, const float* nk, bf16_t* qkb) {
     mi355_qwen* e = p->e;
     const int D = e->D;
-    GemmParams g = make_gemm(xin, D, w_qk, D, M, 2 * D, D, EPI_BIAS, b_qk, p->qkbuf, 2 * D);
+    GemmParams g = make_gemm(xin, D, w_qk, D, M, 2 * D, D, EPI_BIAS, b_qk, qkb, 2 * D);
     HIPCHK(launch_gemm(g, st));
     RopeNormParams r;
     memset(&r, 0, sizeof(r));
-    r.src = p->qkbuf; r.src_ld = 2 * D; r.q_col = 0; r.k_col = D; r.nw_q = nq; r.nw_k = nk; r.cs = p->cs;
+    r.src = qkb; r.src_ld = 2 * D; r.q_col = 0; r.k_col = D; r.nw_q = nq; r.nw_k = nk; r.cs = p->cs;
     r.q_out = p->q; r.k_out = p->k; r.M = M; r.H = e->H; r.rows_per_sample = rps; r.s_off = s_off; r.S_pad = p->S_pad;
     r.eps = e->cfg.eps; r.q_scale = 0.08838834764831845f * 1.4426950408889634f;
     HIPCHK(launch_rope_norm(r, st));
@@ -412,10 +422,47 @@ int gate_res(mi355_qwen_plan* p, hipStream_t st, const bf16_t* A, long lda, int 
 
 // one transformer forward over the FB = n_cfg * B samples: packed latents (storage dtype, B samples, replicated per CFG branch) ->
 // packed velocity v2 [FB][Ni][C] bf16.  `mod` = this call's first modulation row; c0 / kvlen prepared.
+// Two-stream forward (tune key 12; OFF by default -- written after round 2's GPU budget was spent, to be A/B-ed in round 3): the text
+// chain of a block (LN-modulate -> q|k|v projections ... out-projection -> LN-modulate -> MLP, M = FB * Nt rows: a fraction of a wave of
+// workgroups) runs on a plan-owned side stream beside the image chain, as in the SD3.5 engine (engine.hip, keys 8-10: +6 ... +31 % on
+// small forward batches).  Join before the joint attention (it reads the text rows of q / k / vT), fork after it (the text out-projection
+// reads o_ctx; the NEXT block's text projections overwrite the text rows of q / k / vT, so they must also come after this attention).
+// Results are bit-identical to the single-stream order: the kernels and their inputs are the same, only `qkbuf` / `big` are not shared.
+int g_qwen_two_stream = 0;          // 0 off, 1 on, 2 on for plans with at most g_qwen_two_stream_rows image rows
+int g_qwen_two_stream_rows = 16384;
+
+bool qwen_two_stream_wanted(const mi355_qwen_plan* p) {
+    return g_qwen_two_stream == 1 || (g_qwen_two_stream == 2 && p->Mi <= g_qwen_two_stream_rows);
+}
+
+int qwen_two_stream_init(mi355_qwen_plan* p) {
+    if (p->side) return 0;
+    const size_t qkb = (((size_t)p->Mc * 2 * p->e->D * 2) + 255) & ~(size_t)255, big = (((size_t)p->Mc * p->e->F * 2) + 255) & ~(size_t)255;
+    HIPCHK(hipMalloc((void**)&p->ws_side, qkb + big));
+    p->qkbuf_c = (bf16_t*)p->ws_side;
+    p->big_c = (bf16_t*)(p->ws_side + qkb);
+    for (int i = 0; i <= p->e->L; ++i) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        p->ev_join.push_back(a);
+        HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        p->ev_fork.push_back(b);
+    }
+    HIPCHK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    return 0;
+}
+
 int forward_core(mi355_qwen_plan* p, hipStream_t st, const void* latents, int lat_dt, const bf16_t* mod) {
     mi355_qwen* e = p->e;
     const int D = e->D, F = e->F, C = e->cfg.in_channels;
     const int Ni = p->Ni, Nt = p->Nt;
+    const bool two = qwen_two_stream_wanted(p);
+    hipStream_t ts = st;                               // carries the text chain
+    bf16_t *qkb_c = p->qkbuf, *big_c = p->big;
+    if (two) {
+        CHK(qwen_two_stream_init(p));
+        ts = p->side; qkb_c = p->qkbuf_c; big_c = p->big_c;
+    }
     const bf16_t* lat = (const bf16_t*)latents;
     if (lat_dt != DT_BF16) {
         HIPCHK(launch_convert(latents, lat_dt, p->lat16, DT_BF16, (long)p->B * p->n_lat, st));
@@ -427,31 +474,48 @@ int forward_core(mi355_qwen_plan* p, hipStream_t st, const void* latents, int la
     if (p->ncfg == 2)
         HIPCHK(hipMemcpyAsync(p->x + (size_t)p->B * Ni * D, p->x, (size_t)p->B * Ni * D * 2, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpyAsync(p->c, p->c0, (size_t)p->Mc * D * 2, hipMemcpyDeviceToDevice, st));
+    if (two) {          // c, the conditioning (modulation table, prompt, key lengths) and the previous forward are complete on `st`
+        HIPCHK(hipEventRecord(p->ev_fork[e->L], st));
+        HIPCHK(hipStreamWaitEvent(ts, p->ev_fork[e->L], 0));
+    }
     for (int i = 0; i < e->L; ++i) {
         const QBlockW& b = e->blk[i];
         const int mi = b.mod_img, mc = b.mod_ctx;     // chunks: shift1, scale1, gate1, shift2, scale2, gate2
-        CHK(ln_mod(p, st, p->c, p->cn, mod, p->Mc, Nt, mc, mc + D));
-        CHK(qkv(p, st, p->cn, p->Mc, Nt, Ni, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck));
+        CHK(ln_mod(p, ts, p->c, p->cn, mod, p->Mc, Nt, mc, mc + D));
+        CHK(qkv(p, ts, p->cn, p->Mc, Nt, Ni, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck, qkb_c));
         CHK(ln_mod(p, st, p->x, p->xn, mod, p->Mi, Ni, mi, mi + D));
-        CHK(qkv(p, st, p->xn, p->Mi, Ni, 0, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk));
+        CHK(qkv(p, st, p->xn, p->Mi, Ni, 0, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk, p->qkbuf));
+        if (two) {      // join: the attention reads the text rows of q / k / vT
+            HIPCHK(hipEventRecord(p->ev_join[i], ts));
+            HIPCHK(hipStreamWaitEvent(st, p->ev_join[i], 0));
+        }
         Attn128Params a;
         memset(&a, 0, sizeof(a));
         a.q = p->q; a.k = p->k; a.vT = p->vT; a.o_first = p->o_img; a.ld_first = D; a.n_first = Ni;
         a.o_rest = p->o_ctx; a.ld_rest = D; a.B = p->FB; a.H = e->H; a.S = p->S; a.S_pad = p->S_pad; a.q_prescaled = 1;
         a.score_bound = b.bound; a.kv_len = p->kvlen;
         HIPCHK(launch_attention128(a, st));
+        if (two) {      // fork: o_ctx is written, and the text rows of q / k / vT are free for the next block's text projections
+            HIPCHK(hipEventRecord(p->ev_fork[i], st));
+            HIPCHK(hipStreamWaitEvent(ts, p->ev_fork[i], 0));
+        }
         CHK(gate_res(p, st, p->o_img, D, D, b.w_o, b.b_o, p->x, p->Mi, Ni, mod, mi + 2 * D));
-        CHK(gate_res(p, st, p->o_ctx, D, D, b.w_co, b.b_co, p->c, p->Mc, Nt, mod, mc + 2 * D));
+        CHK(gate_res(p, ts, p->o_ctx, D, D, b.w_co, b.b_co, p->c, p->Mc, Nt, mod, mc + 2 * D));
         CHK(ln_mod(p, st, p->x, p->xn, mod, p->Mi, Ni, mi + 3 * D, mi + 4 * D));
         GemmParams f1 = make_gemm(p->xn, D, b.w_ff1, D, p->Mi, F, D, EPI_BIAS_GELU, b.b_ff1, p->big, F);
         HIPCHK(launch_gemm(f1, st));
         CHK(gate_res(p, st, p->big, F, F, b.w_ff2, b.b_ff2, p->x, p->Mi, Ni, mod, mi + 5 * D));
         if (i + 1 < e->L) {       // the text stream of the last block feeds nothing
-            CHK(ln_mod(p, st, p->c, p->cn, mod, p->Mc, Nt, mc + 3 * D, mc + 4 * D));
-            GemmParams c1 = make_gemm(p->cn, D, b.w_cff1, D, p->Mc, F, D, EPI_BIAS_GELU, b.b_cff1, p->big, F);
-            HIPCHK(launch_gemm(c1, st));
-            CHK(gate_res(p, st, p->big, F, F, b.w_cff2, b.b_cff2, p->c, p->Mc, Nt, mod, mc + 5 * D));
+            CHK(ln_mod(p, ts, p->c, p->cn, mod, p->Mc, Nt, mc + 3 * D, mc + 4 * D));
+            GemmParams c1 = make_gemm(p->cn, D, b.w_cff1, D, p->Mc, F, D, EPI_BIAS_GELU, b.b_cff1, big_c, F);
+            HIPCHK(launch_gemm(c1, ts));
+            CHK(gate_res(p, ts, big_c, F, F, b.w_cff2, b.b_cff2, p->c, p->Mc, Nt, mod, mc + 5 * D));
         }
+    }
+    if (two) {          // the side stream's tail (last block's text out-projection) completes before `st` goes on: the next forward's
+                        // conditioning and its copy into `c` are ordered behind it
+        HIPCHK(hipEventRecord(p->ev_join[e->L], ts));
+        HIPCHK(hipStreamWaitEvent(st, p->ev_join[e->L], 0));
     }
     // AdaLayerNormContinuous (scale first), proj_out
     CHK(ln_mod(p, st, p->x, p->xn, mod, p->Mi, Ni, e->mod_out + D, e->mod_out));
@@ -484,6 +548,11 @@ int sde_call(hipStream_t st, int batch, int64_t n, const bf16_t* v, const void* 
 }
 
 }  // namespace
+
+namespace mi355 {
+void set_qwen_two_stream(int mode) { g_qwen_two_stream = mode; }
+void set_qwen_two_stream_rows(int rows) { g_qwen_two_stream_rows = rows; }
+}  // namespace mi355
 
 // One transformer evaluation incl. the CFG combine (replay / tests).  t_model [B] device fp32 = the angle base of the sinusoidal
 // projection = 1000 * (the value the network receives, t / 1000 rounded to the latents' dtype): Timesteps(scale=1000).  prompt_embeds bf16 [n_cfg*B][n_text][J]

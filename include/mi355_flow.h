@@ -390,6 +390,8 @@ int mi355_profile_enable(int on);
  *         key 10 = fork point in dual-attention blocks: 1 after the block's last attention, 0 right after the joint attention, 2 (default)
  *         = 1 for plans with more than 16384 image rows, else 0.
  *         Results are bit-identical for every value.
+ *  12/13  the same for the Qwen-Image engine (mi355_qwen_*): 0 (default) = single stream, 1 = text chain of every block on a plan-owned
+ *         side stream, 2 = when the image stream has at most <key 13> rows (default 16384).  Opt-in until measured on the GPU.
  * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);

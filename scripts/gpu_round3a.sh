@@ -2,6 +2,7 @@
 #   1. the gated checks (tests/test_gpu_next_round.py): SD3.5-large width forward vs the oracle; bench.py's small-batch legs
 #   2. the delivered-clock probe beside the hot kernels (scripts/clock_under_load.py) -> which kernel still has headroom at ITS clock
 #   3. the whole -m gpu suite at HEAD
+#   4. A/B of the Qwen-Image two-stream forward (key 12)
 # usage: gpurun --timeout 900 -- 'bash scripts/gpu_round3a.sh'
 set -x
 cd $GRAFT_REPO_ROOT
@@ -13,3 +14,6 @@ timeout 120 python scripts/clock_under_load.py --ms 30 > $OUT/clock_under_load.t
 cat $OUT/clock_under_load.txt
 timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > $OUT/tests.log; echo "tests rc=$?" >> $OUT/status
 cat $OUT/tests.log
+# Qwen-Image two-stream forward (key 12, opt-in): A/B in one process at the bench shape and at B = 1 (41 GB of synthetic weights: ~1 min to bind)
+timeout 400 python scripts/qwen_bench.py --batch 2 --denoise-steps 2 --iters 2 --ab-two-stream 2>&1 | tail -2 > $OUT/qwen_two_stream_ab.txt; echo "qwen ab rc=$?" >> $OUT/status
+cat $OUT/qwen_two_stream_ab.txt

@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--layers", type=int, default=60)
     ap.add_argument("--iters", type=int, default=1)
     ap.add_argument("--dynamics", default="Flow-SDE", help="Flow-SDE | Dance-SDE | CPS | ODE (DGPO samples with ODE)")
+    ap.add_argument("--ab-two-stream", action="store_true",
+                    help="A/B of the text chain on a side stream (mi355_tune_set key 12) in ONE process: same seeded rollout under 0 / 1, "
+                         "bit-identity asserted, seconds per rollout of both (not yet run on the GPU)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     cfg = qwen.QwenConfig(num_layers=a.layers)
@@ -75,6 +78,30 @@ def main():
     run = lambda: ad.inference(prompt=None, height=a.size, width=a.size, num_inference_steps=N, guidance_scale=a.guidance, prompt_embeds=pe,
                                prompt_embeds_mask=pm, negative_prompt_embeds=ne, negative_prompt_embeds_mask=nm, compute_log_prob=a.dynamics != "ODE")
     s = run(); torch.cuda.synchronize()
+    if a.ab_two_stream:
+        from mi355_flow import _lib
+        lib = _lib.load()
+        res, secs = {}, {}
+        for mode in (0, 1, 0, 1):
+            lib.mi355_tune_set(12, mode)
+            torch.cuda.manual_seed(5)
+            o = run(); torch.cuda.synchronize()                 # (the first run under mode 1 creates the side stream and its buffers)
+            torch.cuda.manual_seed(5)
+            t0 = time.perf_counter()
+            for _ in range(a.iters): o = run()
+            torch.cuda.synchronize()
+            secs.setdefault(mode, []).append((time.perf_counter() - t0) / a.iters)
+            lat = torch.stack([x.all_latents for x in o])
+            if mode in res:
+                assert torch.equal(res[mode], lat), f"mode {mode}: run-to-run difference"
+            res[mode] = lat
+        lib.mi355_tune_set(12, 0)
+        same = bool(torch.equal(res[0], res[1]))
+        t_a, t_b = min(secs[0]), min(secs[1])
+        print(json.dumps({"ab": "qwen two-stream (key 12)", "batch": B, "image": f"{a.size}x{a.size}", "denoise_steps": N, "bit_identical": same,
+                          "s_per_rollout_single": round(t_a, 4), "s_per_rollout_two_stream": round(t_b, 4), "gain_pct": round((t_a / t_b - 1) * 100, 2)}))
+        assert same
+        return
     t0 = time.perf_counter()
     for _ in range(a.iters): s = run()
     torch.cuda.synchronize()

@@ -65,3 +65,67 @@ def test_bench_small_batch_legs_report_numbers():
     assert "error" not in sb, sb
     for tag in ("b2_1024_nocfg_28", "b2_512_cfg4.5_10"):
         assert sb[tag]["denoise_steps_per_s"] > 0 and 0 < sb[tag]["forward_frac"] < 1
+
+
+def test_qwen_two_stream_forward_and_rollout_are_bit_identical():
+    """Qwen-Image engine with the text chain of every block on a side stream (mi355_tune_set key 12 = 1; default 0): the raw network
+    outputs of both CFG branches of a ragged-prompt forward and a whole true-CFG rollout (latents, log-probs) equal the single-stream
+    results bit for bit, repeatedly (a missing fork / join edge shows up as a run-to-run difference)."""
+    from mi355_flow import _lib, qwen as qw
+    from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
+    from oracle import qwen_ref as R
+    lib = _lib.load()
+    cfg_o = R.tiny_config()
+    sd = {k: v.bfloat16().float() for k, v in R.make_synthetic_state_dict(cfg_o, seed=3, std=0.03).items()}
+    cfg = qw.QwenConfig(num_layers=cfg_o.num_layers, num_attention_heads=cfg_o.num_attention_heads,
+                        joint_attention_dim=cfg_o.joint_attention_dim, scale_rope=cfg_o.scale_rope)
+    J = cfg_o.joint_attention_dim
+    g = torch.Generator().manual_seed(5)
+    try:
+        # ---- single forwards: a small and a chip-filling token count, ragged text, both CFG branches
+        eng = qw.QwenEngine(cfg)
+        eng.bind_state_dict({k: v.cuda() for k, v in sd.items()})
+        eng.ready()
+        for (B, h, w, Nt) in ((2, 8, 12, 19), (2, 64, 64, 77)):
+            x = torch.randn(B, (h // 2) * (w // 2), 64, generator=g).bfloat16()
+            lens = [Nt, max(1, Nt - 5)] * 2
+            emb = torch.randn(2 * B, Nt, J, generator=g).bfloat16()
+            for b, n in enumerate(lens):
+                emb[b, n:] = 0
+            tm = qw.model_timestep(torch.tensor([875.0, 500.0][:B]), torch.bfloat16)
+            outs = {}
+            for mode in (0, 1, 1, 0, 1):
+                lib.mi355_tune_set(12, mode)
+                plan = eng.plan(B, 2, h, w, Nt, 1)
+                v, raw = plan.transformer_forward(x.cuda(), tm, emb.cuda(), lens, guidance_scale=4.0, return_raw=True)
+                torch.cuda.synchronize()
+                outs.setdefault(mode, []).append((v.clone(), raw.clone()))
+            ref_v, ref_raw = outs[0][0]
+            assert torch.isfinite(ref_raw.float()).all()
+            for mode, runs in outs.items():
+                for v, raw in runs:
+                    assert torch.equal(v, ref_v) and torch.equal(raw, ref_raw), (mode, B, h, w, Nt)
+        eng.close()
+        # ---- a whole rollout through the adapter
+        res = {}
+        for mode in (0, 1):
+            lib.mi355_tune_set(12, mode)
+            sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[0, 1, 2, 3], num_sde_steps=2, seed=42, dynamics_type="Flow-SDE",
+                                                       shift=1.0, use_dynamic_shifting=True, base_shift=0.5, max_shift=0.9, max_image_seq_len=8192,
+                                                       shift_terminal=0.02)
+            ad = qw.QwenImageNativeAdapter({k: v.cuda() for k, v in sd.items()}, cfg, sched, latent_storage_dtype="bf16")
+            ad.rollout()
+            gg = torch.Generator().manual_seed(9)
+            pe = [torch.randn(n, J, generator=gg).bfloat16().cuda() for n in (21, 17)]
+            pm = [torch.ones(n, dtype=torch.long).cuda() for n in (21, 17)]
+            ne = torch.randn(2, 6, J, generator=gg).bfloat16().cuda()
+            nm = torch.ones(2, 6, dtype=torch.long).cuda()
+            torch.cuda.manual_seed(77)
+            s = ad.inference(prompt=["a", "b"], negative_prompt=None, height=128, width=192, num_inference_steps=5, guidance_scale=4.0,
+                             prompt_embeds=pe, prompt_embeds_mask=pm, negative_prompt_embeds=ne, negative_prompt_embeds_mask=nm,
+                             compute_log_prob=True, trajectory_indices="all")
+            res[mode] = (torch.stack([o.all_latents for o in s]).clone(), torch.stack([o.log_probs for o in s]).clone())
+            ad.engine.close()
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    finally:
+        lib.mi355_tune_set(12, 0)
