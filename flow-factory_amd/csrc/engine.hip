@@ -984,6 +984,8 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 11) { g_three_stream = value; return 0; }
     if (key == 12) { set_qwen_two_stream(value); return 0; }   // Qwen-Image engine: text chain on a side stream (0 off = default, 1 on, 2 auto)
     if (key == 13) { set_qwen_two_stream_rows(value); return 0; }
+    if (key == 14) { set_flux_two_stream(value); return 0; }   // FLUX.1 engine, double blocks: the same
+    if (key == 15) { set_flux_two_stream_rows(value); return 0; }
     return fail("mi355_tune_set: unknown key %d", key);
 }
 

@@ -241,6 +241,12 @@ struct mi355_flux_plan {
     float *io_noise, *io_lp;
     bf16_t *io_pe, *io_pp;
     std::vector<float> host_t, host_sc;
+    // two-stream double blocks (opt-in, mi355_tune_set key 14): the text chain on a plan-owned side stream with its own q|k staging and
+    // MLP-hidden buffers (the single-stream path shares `qkbuf` / `big` between the two chains)
+    hipStream_t side = nullptr;
+    char* ws_side = nullptr;
+    bf16_t *qkbuf_c = nullptr, *big_c = nullptr;
+    std::vector<hipEvent_t> ev_join, ev_fork;   // per double block: text q|k|v ready (side -> main), attention done (main -> side); [L] = start / end
 };
 
 extern "C" int mi355_flux_plan_create(mi355_flux* e, int batch, int latent_h, int latent_w, int n_text, int max_steps,
@@ -327,6 +333,10 @@ extern "C" int mi355_flux_plan_create(mi355_flux* e, int batch, int latent_h, in
 
 extern "C" int mi355_flux_plan_destroy(mi355_flux_plan* p) {
     if (!p) return 0;
+    for (hipEvent_t ev : p->ev_join) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : p->ev_fork) (void)hipEventDestroy(ev);
+    if (p->side) (void)hipStreamDestroy(p->side);
+    if (p->ws_side) (void)hipFree(p->ws_side);
     if (p->ws) (void)hipFree(p->ws);
     delete p;
     return 0;
@@ -407,14 +417,15 @@ int ln_mod(mi355_flux_plan* p, hipStream_t st, const bf16_t* x, bf16_t* out, con
 
 // q|k projection (one GEMM) -> RMSNorm + RoPE + scatter; V^T projection with the scatter fused (operands swapped)
 int qkv(mi355_flux_plan* p, hipStream_t st, const bf16_t* xin, int M, int rps, int s_off, const bf16_t* w_qk, const float* b_qk,
-        const bf16_t* w_v, const float* b_v, const float* nq, const float* nk) {
+        const bf16_t* w_v, const float* b_v, const float* nq, const float* nk, bf16_t* qkb = nullptr) {
     mi355_flux* e = p->e;
     const int D = e->D;
-    GemmParams g = make_gemm(xin, D, w_qk, D, M, 2 * D, D, EPI_BIAS, b_qk, p->qkbuf, 2 * D);
+    if (!qkb) qkb = p->qkbuf;
+    GemmParams g = make_gemm(xin, D, w_qk, D, M, 2 * D, D, EPI_BIAS, b_qk, qkb, 2 * D);
     HIPCHK(launch_gemm(g, st));
     RopeNormParams r;
     memset(&r, 0, sizeof(r));
-    r.src = p->qkbuf; r.src_ld = 2 * D; r.q_col = 0; r.k_col = D; r.nw_q = nq; r.nw_k = nk; r.cs = p->cs;
+    r.src = qkb; r.src_ld = 2 * D; r.q_col = 0; r.k_col = D; r.nw_q = nq; r.nw_k = nk; r.cs = p->cs;
     r.q_out = p->q; r.k_out = p->k; r.M = M; r.H = e->H; r.rows_per_sample = rps; r.s_off = s_off; r.S_pad = p->S_pad;
     r.eps = e->cfg.eps; r.q_scale = 0.08838834764831845f * 1.4426950408889634f;
     HIPCHK(launch_rope_norm(r, st));
@@ -444,10 +455,46 @@ int attention(mi355_flux_plan* p, hipStream_t st, bf16_t* o_first, long ld_first
 
 // one transformer forward: packed latents (storage dtype) -> packed velocity v_out [B][Ni][C] bf16.  `mod` = this step's
 // rows of mod_all; c0 / conditioning prepared.
+// Two-stream double blocks (tune key 14; OFF by default -- written after round 2's GPU budget was spent, to be A/B-ed in round 3): as in the
+// SD3.5 and Qwen-Image engines, the text chain of a double block runs on a plan-owned side stream beside the image chain (the reference's
+// own FLUX.1 examples sample at B = 1-2 and 384^2 / 512^2: 576-1024 image tokens next to 512 text tokens, every grid a fraction of the
+// chip).  Join before the joint attention, fork after it, last join before the two streams are concatenated for the single blocks.
+// Bit-identical to the single-stream order.
+int g_flux_two_stream = 0;          // 0 off, 1 on, 2 on for plans with at most g_flux_two_stream_rows image rows
+int g_flux_two_stream_rows = 16384;
+
+bool flux_two_stream_wanted(const mi355_flux_plan* p) {
+    return g_flux_two_stream == 1 || (g_flux_two_stream == 2 && p->Mi <= g_flux_two_stream_rows);
+}
+
+int flux_two_stream_init(mi355_flux_plan* p) {
+    if (p->side) return 0;
+    const size_t qkb = (((size_t)p->Mc * 2 * p->e->D * 2) + 255) & ~(size_t)255, big = (((size_t)p->Mc * p->e->F * 2) + 255) & ~(size_t)255;
+    HIPCHK(hipMalloc((void**)&p->ws_side, qkb + big));
+    p->qkbuf_c = (bf16_t*)p->ws_side;
+    p->big_c = (bf16_t*)(p->ws_side + qkb);
+    for (int i = 0; i <= p->e->L; ++i) {
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        p->ev_join.push_back(a);
+        HIPCHK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        p->ev_fork.push_back(b);
+    }
+    HIPCHK(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    return 0;
+}
+
 int forward_core(mi355_flux_plan* p, hipStream_t st, const void* latents, int lat_dt, const bf16_t* mod, bf16_t* v_out) {
     mi355_flux* e = p->e;
     const int D = e->D, F = e->F, C = e->cfg.in_channels;
     const int Ni = p->Ni, Nt = p->Nt, S = p->S;
+    const bool two = flux_two_stream_wanted(p) && e->L > 0;
+    hipStream_t ts = st;                               // carries the text chain of the double blocks
+    bf16_t *qkb_c = p->qkbuf, *big_c = p->big;
+    if (two) {
+        CHK(flux_two_stream_init(p));
+        ts = p->side; qkb_c = p->qkbuf_c; big_c = p->big_c;
+    }
     const bf16_t* lat = (const bf16_t*)latents;
     if (lat_dt != DT_BF16) {
         HIPCHK(launch_convert(latents, lat_dt, p->lat16, DT_BF16, (long)p->B * p->n_lat, st));
@@ -456,24 +503,40 @@ int forward_core(mi355_flux_plan* p, hipStream_t st, const void* latents, int la
     GemmParams gx = make_gemm(lat, C, e->w_x, C, p->Mi, D, C, EPI_BIAS, e->b_x, p->x, D);
     HIPCHK(launch_gemm(gx, st));
     HIPCHK(hipMemcpyAsync(p->c, p->c0, (size_t)p->Mc * D * 2, hipMemcpyDeviceToDevice, st));
+    if (two) {          // c, the conditioning (modulation table, prompt) and the previous forward are complete on `st`
+        HIPCHK(hipEventRecord(p->ev_fork[e->L], st));
+        HIPCHK(hipStreamWaitEvent(ts, p->ev_fork[e->L], 0));
+    }
     for (int i = 0; i < e->L; ++i) {
         const DoubleW& b = e->dbl[i];
         const int mi = b.mod_img, mc = b.mod_ctx;     // chunks: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-        CHK(ln_mod(p, st, p->c, p->cn, mod, p->Mc, Nt, mc, mc + D));
-        CHK(qkv(p, st, p->cn, p->Mc, Nt, 0, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck));
+        CHK(ln_mod(p, ts, p->c, p->cn, mod, p->Mc, Nt, mc, mc + D));
+        CHK(qkv(p, ts, p->cn, p->Mc, Nt, 0, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck, qkb_c));
         CHK(ln_mod(p, st, p->x, p->xn, mod, p->Mi, Ni, mi, mi + D));
         CHK(qkv(p, st, p->xn, p->Mi, Ni, Nt, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk));
+        if (two) {      // join: the attention reads the text rows of q / k / vT
+            HIPCHK(hipEventRecord(p->ev_join[i], ts));
+            HIPCHK(hipStreamWaitEvent(st, p->ev_join[i], 0));
+        }
         CHK(attention(p, st, p->o_ctx, D, Nt, p->o_img, D, b.bound));
+        if (two) {      // fork: o_ctx is written, and the text rows of q / k / vT are free for the next block's text projections
+            HIPCHK(hipEventRecord(p->ev_fork[i], st));
+            HIPCHK(hipStreamWaitEvent(ts, p->ev_fork[i], 0));
+        }
         CHK(gate_res(p, st, p->o_img, D, D, b.w_o, b.b_o, p->x, p->Mi, Ni, mod, mi + 2 * D));
-        CHK(gate_res(p, st, p->o_ctx, D, D, b.w_co, b.b_co, p->c, p->Mc, Nt, mod, mc + 2 * D));
+        CHK(gate_res(p, ts, p->o_ctx, D, D, b.w_co, b.b_co, p->c, p->Mc, Nt, mod, mc + 2 * D));
         CHK(ln_mod(p, st, p->x, p->xn, mod, p->Mi, Ni, mi + 3 * D, mi + 4 * D));
         GemmParams f1 = make_gemm(p->xn, D, b.w_ff1, D, p->Mi, F, D, EPI_BIAS_GELU, b.b_ff1, p->big, F);
         HIPCHK(launch_gemm(f1, st));
         CHK(gate_res(p, st, p->big, F, F, b.w_ff2, b.b_ff2, p->x, p->Mi, Ni, mod, mi + 5 * D));
-        CHK(ln_mod(p, st, p->c, p->cn, mod, p->Mc, Nt, mc + 3 * D, mc + 4 * D));
-        GemmParams c1 = make_gemm(p->cn, D, b.w_cff1, D, p->Mc, F, D, EPI_BIAS_GELU, b.b_cff1, p->big, F);
-        HIPCHK(launch_gemm(c1, st));
-        CHK(gate_res(p, st, p->big, F, F, b.w_cff2, b.b_cff2, p->c, p->Mc, Nt, mod, mc + 5 * D));
+        CHK(ln_mod(p, ts, p->c, p->cn, mod, p->Mc, Nt, mc + 3 * D, mc + 4 * D));
+        GemmParams c1 = make_gemm(p->cn, D, b.w_cff1, D, p->Mc, F, D, EPI_BIAS_GELU, b.b_cff1, big_c, F);
+        HIPCHK(launch_gemm(c1, ts));
+        CHK(gate_res(p, ts, big_c, F, F, b.w_cff2, b.b_cff2, p->c, p->Mc, Nt, mod, mc + 5 * D));
+    }
+    if (two) {          // the text stream is complete before it is concatenated with the image stream
+        HIPCHK(hipEventRecord(p->ev_join[e->L], ts));
+        HIPCHK(hipStreamWaitEvent(st, p->ev_join[e->L], 0));
     }
     // joint stream y = cat([c, x], dim=1) per sample
     const size_t rowb = (size_t)D * 2;
@@ -514,6 +577,11 @@ int sde_call(hipStream_t st, int batch, int64_t n, const bf16_t* v, const void* 
 }
 
 }  // namespace
+
+namespace mi355 {
+void set_flux_two_stream(int mode) { g_flux_two_stream = mode; }
+void set_flux_two_stream_rows(int rows) { g_flux_two_stream_rows = rows; }
+}  // namespace mi355
 
 // transformer only (replay / tests): t_model[B] and guidance_model[B] are the values the network embeds (device fp32):
 // the adapter passes t/1000 and the model multiplies by 1000 in the latents' dtype (see mi355_flux_rollout)

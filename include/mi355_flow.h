@@ -392,6 +392,7 @@ int mi355_profile_enable(int on);
  *         Results are bit-identical for every value.
  *  12/13  the same for the Qwen-Image engine (mi355_qwen_*): 0 (default) = single stream, 1 = text chain of every block on a plan-owned
  *         side stream, 2 = when the image stream has at most <key 13> rows (default 16384).  Opt-in until measured on the GPU.
+ *  14/15  the same for the double blocks of the FLUX.1 engine (mi355_flux_*).  Opt-in until measured on the GPU.
  * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);

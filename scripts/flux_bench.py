@@ -16,6 +16,9 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=4)
     ap.add_argument("--iters", type=int, default=2)
     ap.add_argument("--attn-only", action="store_true")
+    ap.add_argument("--ab-two-stream", default=None, metavar="BxSIZE,...",
+                    help="A/B of the double blocks' text chain on a side stream (mi355_tune_set key 14) in ONE process over a list of shapes, "
+                         "e.g. 1x384,2x512,1x1024,8x1024 (the reference's examples sample at 1x384 / 2x512); bit-identity asserted (not yet run on the GPU)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     if a.attn_only:
@@ -45,6 +48,38 @@ def main():
     torch.cuda.empty_cache()
     print(f"weights bound in {time.time() - t0:.1f} s", file=sys.stderr)
     ad.rollout()
+    if a.ab_two_stream:
+        from mi355_flow import _lib
+        lib = _lib.load()
+        N = a.denoise_steps
+        for shape in a.ab_two_stream.split(","):
+            B, size = (int(v) for v in shape.split("x"))
+            g = torch.Generator(device=dev).manual_seed(1)
+            pe = torch.randn(B, a.n_text, cfg.joint_attention_dim, device=dev, generator=g).bfloat16()
+            pp = torch.randn(B, cfg.pooled_projection_dim, device=dev, generator=g).bfloat16()
+            run = lambda: ad.inference(prompt=None, height=size, width=size, num_inference_steps=N, guidance_scale=3.5, prompt_embeds=pe,
+                                       pooled_prompt_embeds=pp, compute_log_prob=True, trajectory_indices="all")
+            res, secs = {}, {}
+            for mode in (0, 1, 0, 1):
+                lib.mi355_tune_set(14, mode)
+                torch.cuda.manual_seed(5)
+                o = run(); torch.cuda.synchronize()
+                torch.cuda.manual_seed(5)
+                t0 = time.perf_counter()
+                for _ in range(a.iters): o = run()
+                torch.cuda.synchronize()
+                secs.setdefault(mode, []).append((time.perf_counter() - t0) / a.iters)
+                lat = torch.stack([x.all_latents for x in o])
+                assert mode not in res or torch.equal(res[mode], lat), f"mode {mode}: run-to-run difference"
+                res[mode] = lat
+            lib.mi355_tune_set(14, 0)
+            same = bool(torch.equal(res[0], res[1]))
+            t_a, t_b = min(secs[0]), min(secs[1])
+            print(json.dumps({"ab": "flux two-stream double blocks (key 14)", "batch": B, "size": size, "denoise_steps": N, "bit_identical": same,
+                              "s_per_rollout_single": round(t_a, 4), "s_per_rollout_two_stream": round(t_b, 4),
+                              "denoise_steps_per_s": [round(B * N / t_a, 2), round(B * N / t_b, 2)], "gain_pct": round((t_a / t_b - 1) * 100, 2)}), flush=True)
+            assert same
+        return
     B, N = a.batch, a.denoise_steps
     g = torch.Generator(device=dev).manual_seed(1)
     pe = torch.randn(B, a.n_text, cfg.joint_attention_dim, device=dev, generator=g).bfloat16()

@@ -129,3 +129,57 @@ def test_qwen_two_stream_forward_and_rollout_are_bit_identical():
         assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     finally:
         lib.mi355_tune_set(12, 0)
+
+
+def test_flux_two_stream_double_blocks_are_bit_identical():
+    """FLUX.1 engine with the text chain of the double blocks on a side stream (mi355_tune_set key 14 = 1; default 0): single forwards
+    (small and chip-filling token counts, text length not a multiple of 64 so that text and image columns of V^T share cache lines) and a
+    whole rollout equal the single-stream results bit for bit, repeatedly."""
+    from mi355_flow import _lib, flux as fx
+    from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
+    from oracle import flux_ref as R
+    lib = _lib.load()
+    cfg_o = R.tiny_config()
+    sd = {k: v.bfloat16().float() for k, v in R.make_synthetic_state_dict(cfg_o, 77).items()}
+    cfg = fx.FluxConfig(num_layers=cfg_o.num_layers, num_single_layers=cfg_o.num_single_layers, num_attention_heads=cfg_o.num_attention_heads,
+                        joint_attention_dim=cfg_o.joint_attention_dim, pooled_projection_dim=cfg_o.pooled_projection_dim,
+                        guidance_embeds=cfg_o.guidance_embeds)
+    g = torch.Generator().manual_seed(5)
+    try:
+        eng = fx.FluxEngine(cfg)
+        eng.bind_state_dict({k: v.cuda() for k, v in sd.items()})
+        eng.ready()
+        for (B, h, w, Nt) in ((2, 8, 8, 13), (2, 64, 64, 77), (1, 48, 48, 512)):
+            x = R.pack_latents(torch.randn(B, 16, h, w, generator=g)).half()
+            enc = torch.randn(B, Nt, cfg_o.joint_attention_dim, generator=g).bfloat16()
+            pool = torch.randn(B, cfg_o.pooled_projection_dim, generator=g).bfloat16()
+            tm = torch.tensor([900.0, 412.5][:B])
+            gm = torch.full((B,), 3500.0) if cfg_o.guidance_embeds else None
+            outs = []
+            for mode in (0, 1, 1, 0, 1):
+                lib.mi355_tune_set(14, mode)
+                plan = eng.plan(B, h, w, Nt, 1)
+                y = plan.transformer_forward(x.cuda(), tm, gm, enc.cuda(), pool.cuda())
+                torch.cuda.synchronize()
+                outs.append(y.clone())
+            assert torch.isfinite(outs[0].float()).all()
+            assert all(torch.equal(o, outs[0]) for o in outs[1:]), (B, h, w, Nt)
+        eng.close()
+        res = {}
+        for mode in (0, 1):
+            lib.mi355_tune_set(14, mode)
+            sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[0, 1, 2, 3], num_sde_steps=2, seed=42, dynamics_type="Flow-SDE",
+                                                       shift=3.0, use_dynamic_shifting=True)
+            ad = fx.Flux1NativeAdapter({k: v.cuda() for k, v in sd.items()}, cfg, sched, latent_storage_dtype="fp16")
+            ad.rollout()
+            gg = torch.Generator().manual_seed(9)
+            pe = torch.randn(2, 16, cfg_o.joint_attention_dim, generator=gg).bfloat16().cuda()
+            pp = torch.randn(2, cfg_o.pooled_projection_dim, generator=gg).bfloat16().cuda()
+            torch.cuda.manual_seed(77)
+            s = ad.inference(prompt=["a", "b"], height=128, width=128, num_inference_steps=5, guidance_scale=3.5, prompt_embeds=pe,
+                             pooled_prompt_embeds=pp, trajectory_indices="all")
+            res[mode] = (torch.stack([o.all_latents for o in s]).clone(), torch.stack([o.log_probs for o in s]).clone())
+            ad.engine.close()
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    finally:
+        lib.mi355_tune_set(14, 0)
