@@ -249,6 +249,7 @@ hipError_t launch128(const Attn128Params& p, hipStream_t stream) {
 }  // namespace
 
 void set_attn128_variant(int v) { g_attn128_variant = v; }
+int get_attn128_variant() { return g_attn128_variant; }
 
 hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream) {
     if (p.S <= 0 || p.S_pad < p.S || p.n_first < 0 || p.n_first > p.S) return hipErrorInvalidValue;

@@ -72,6 +72,7 @@ struct mi355_flux {
     std::map<std::string, FSlot> slots;
     std::vector<std::string> names;
     bool bounds_dirty = true;
+    int bounds_ver = 0;          // bumped whenever the per-block score bounds are recomputed (they are baked into a captured graph)
 
     bf16_t* a16(int64_t n) {
         size_t bytes = ((size_t)n * 2 + 255) & ~(size_t)255;
@@ -247,6 +248,12 @@ struct mi355_flux_plan {
     char* ws_side = nullptr;
     bf16_t *qkbuf_c = nullptr, *big_c = nullptr;
     std::vector<hipEvent_t> ev_join, ev_fork;   // per double block: text q|k|v ready (side -> main), attention done (main -> side); [L] = start / end
+    // hipGraph of the N-step loop (opt-in, mi355_tune_set key 16): captured on a plan-owned stream on the second call of a configuration
+    hipGraphExec_t gexec = nullptr;
+    hipStream_t cap_stream = nullptr;
+    bool warmed = false;
+    int g_steps = -1, g_dyn = -1, g_storage = -1, g_init = -1, g_clp = -1, g_noise = -1, g_bounds = -1, g_two = -1, g_gemm = -1, g_attn = -1;
+    float g_sigma_max = 0.f;
 };
 
 extern "C" int mi355_flux_plan_create(mi355_flux* e, int batch, int latent_h, int latent_w, int n_text, int max_steps,
@@ -333,6 +340,8 @@ extern "C" int mi355_flux_plan_create(mi355_flux* e, int batch, int latent_h, in
 
 extern "C" int mi355_flux_plan_destroy(mi355_flux_plan* p) {
     if (!p) return 0;
+    if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
+    if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     for (hipEvent_t ev : p->ev_join) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : p->ev_fork) (void)hipEventDestroy(ev);
     if (p->side) (void)hipStreamDestroy(p->side);
@@ -362,6 +371,7 @@ int update_score_bounds(mi355_flux* e, hipStream_t st) {
     for (auto& b : e->dbl) b.bound = c * fmaxf(amax(b.nq), amax(b.ncq)) * fmaxf(amax(b.nk), amax(b.nck));
     for (auto& b : e->sgl) b.bound = c * amax(b.nq) * amax(b.nk);
     e->bounds_dirty = false;
+    ++e->bounds_ver;
     return 0;
 }
 
@@ -462,6 +472,11 @@ int attention(mi355_flux_plan* p, hipStream_t st, bf16_t* o_first, long ld_first
 // Bit-identical to the single-stream order.
 int g_flux_two_stream = 0;          // 0 off, 1 on, 2 on for plans with at most g_flux_two_stream_rows image rows
 int g_flux_two_stream_rows = 16384;
+
+// key 16: replay the N-step loop of mi355_flux_rollout as ONE hipGraph (OFF by default -- also written after round 2's GPU budget was
+// spent): at the reference's example shapes (B = 1-2, 384^2 / 512^2) the ~700 launches of a forward are 5-15 us kernels and the loop is
+// bound by launch overhead; the SD3.5 engine's captured rollout is the model (engine.hip, key 2).
+int g_flux_graph = 0;
 
 bool flux_two_stream_wanted(const mi355_flux_plan* p) {
     return g_flux_two_stream == 1 || (g_flux_two_stream == 2 && p->Mi <= g_flux_two_stream_rows);
@@ -581,6 +596,7 @@ int sde_call(hipStream_t st, int batch, int64_t n, const bf16_t* v, const void* 
 namespace mi355 {
 void set_flux_two_stream(int mode) { g_flux_two_stream = mode; }
 void set_flux_two_stream_rows(int rows) { g_flux_two_stream_rows = rows; }
+void set_flux_graph(int on) { g_flux_graph = on; }
 }  // namespace mi355
 
 // transformer only (replay / tests): t_model[B] and guidance_model[B] are the values the network embeds (device fp32):
@@ -646,19 +662,65 @@ extern "C" int mi355_flux_rollout(mi355_flux_plan* p, void* stream, int n_steps,
     HIPCHK(hipMemcpyAsync(p->io_pp, pooled, (size_t)B * p->e->cfg.pooled_projection_dim * 2, hipMemcpyDeviceToDevice, st));
     const float sigma_max = sigmas_host[1];
     const int clp = compute_log_prob && out_log_probs;
-    CHK(prepare_prompt(p, st, p->io_pe, p->io_pp));
-    CHK(prepare_conditioning(p, st, n_steps));
     const size_t esz = storage_dtype == MI355_F32 ? 4 : 2;
     const size_t lat_bytes = (size_t)nl * esz;
-    HIPCHK(launch_convert(p->io_init, init_dtype, p->io_traj, storage_dtype, (long)nl, st));      // cast_latents(init)
-    for (int i = 0; i < n_steps; ++i) {
-        const bf16_t* mod = p->mod_all + (int64_t)i * B * p->e->mod_cols;
-        char* cur = p->io_traj + (size_t)i * lat_bytes;
-        char* nxt = p->io_traj + (size_t)(i + 1) * lat_bytes;
-        CHK(forward_core(p, st, cur, storage_dtype, mod, p->v));
-        CHK(sde_call(st, B, p->n_lat, p->v, cur, storage_dtype, step_noise ? p->io_noise + (int64_t)i * nl : nullptr, p->scal + i,
-                     p->scal + p->max_steps + i, p->scal + 2 * p->max_steps + i, sigma_max, dynamics, clp ? 2 : 0, nxt,
-                     clp ? p->io_lp + (int64_t)i * B : nullptr));
+    // everything below reads / writes plan-owned buffers at fixed addresses (staged inputs, t_dev / g_dev / scal, io_traj, io_lp)
+    auto body = [&](hipStream_t s) -> int {
+        CHK(prepare_prompt(p, s, p->io_pe, p->io_pp));
+        CHK(prepare_conditioning(p, s, n_steps));
+        HIPCHK(launch_convert(p->io_init, init_dtype, p->io_traj, storage_dtype, (long)nl, s));      // cast_latents(init)
+        for (int i = 0; i < n_steps; ++i) {
+            const bf16_t* mod = p->mod_all + (int64_t)i * B * p->e->mod_cols;
+            char* cur = p->io_traj + (size_t)i * lat_bytes;
+            char* nxt = p->io_traj + (size_t)(i + 1) * lat_bytes;
+            CHK(forward_core(p, s, cur, storage_dtype, mod, p->v));
+            CHK(sde_call(s, B, p->n_lat, p->v, cur, storage_dtype, step_noise ? p->io_noise + (int64_t)i * nl : nullptr, p->scal + i,
+                         p->scal + p->max_steps + i, p->scal + 2 * p->max_steps + i, sigma_max, dynamics, clp ? 2 : 0, nxt,
+                         clp ? p->io_lp + (int64_t)i * B : nullptr));
+        }
+        return 0;
+    };
+    bool launched = false;
+    if (g_flux_graph && p->warmed) {
+        const int two = (int)flux_two_stream_wanted(p);
+        const bool same = p->gexec && p->g_steps == n_steps && p->g_dyn == dynamics && p->g_storage == storage_dtype && p->g_init == init_dtype &&
+                          p->g_clp == clp && p->g_noise == (int)(step_noise != nullptr) && p->g_sigma_max == sigma_max &&
+                          p->g_bounds == p->e->bounds_ver && p->g_two == two && p->g_gemm == get_gemm_variant() && p->g_attn == get_attn128_variant();
+        if (!same) {
+            if (two) CHK(flux_two_stream_init(p));              // streams / events / buffers are created outside the capture
+            if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
+            hipGraph_t graph = nullptr;
+            hipError_t ce = hipSuccess;
+            if (!p->cap_stream) ce = hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking);
+            if (ce == hipSuccess) ce = hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed);
+            if (ce == hipSuccess) {
+                const int rc = body(p->cap_stream);             // nothing executes: launches / D2D copies become graph nodes
+                ce = hipStreamEndCapture(p->cap_stream, &graph);
+                if (rc != 0 || ce != hipSuccess || !graph) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    graph = nullptr;
+                }
+            }
+            if (graph) {
+                ce = hipGraphInstantiate(&p->gexec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (ce != hipSuccess) p->gexec = nullptr;
+            }
+            if (!p->gexec) {                                    // no silent fallback: the caller chooses eager launches with key 16 = 0
+                const hipError_t last = hipGetLastError();
+                return errorf("mi355_flux_rollout: hipGraph capture / instantiation of the %d-step loop failed (%s); mi355_tune_set(16, 0) "
+                              "selects eager launches", n_steps, hipGetErrorString(ce != hipSuccess ? ce : last));
+            }
+            p->g_steps = n_steps; p->g_dyn = dynamics; p->g_storage = storage_dtype; p->g_init = init_dtype; p->g_clp = clp;
+            p->g_noise = (int)(step_noise != nullptr); p->g_sigma_max = sigma_max; p->g_bounds = p->e->bounds_ver; p->g_two = two;
+            p->g_gemm = get_gemm_variant(); p->g_attn = get_attn128_variant();
+        }
+        HIPCHK(hipGraphLaunch(p->gexec, st));
+        launched = true;
+    }
+    if (!launched) {
+        CHK(body(st));
+        p->warmed = true;
     }
     if (keep_slot_host && out_latents)
         for (int i = 0; i <= n_steps; ++i)

@@ -113,10 +113,13 @@ struct Attn128Params {
 };
 hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream);
 void set_attn128_variant(int v);   // 0: 8-wave workgroups (default), 1: 4-wave workgroups
+int get_attn128_variant();
 void set_qwen_two_stream(int mode);        // qwen_engine.hip: text chain on a side stream (0 off = default, 1 on, 2 auto by image rows)
 void set_qwen_two_stream_rows(int rows);
+void set_qwen_graph(int on);               // qwen_engine.hip: replay the N-step loop of mi355_qwen_rollout as one hipGraph (0 = default: eager)
 void set_flux_two_stream(int mode);        // flux_engine.hip: the same for the FLUX.1 double blocks
 void set_flux_two_stream_rows(int rows);
+void set_flux_graph(int on);               // flux_engine.hip: replay the N-step loop of mi355_flux_rollout as one hipGraph (0 = default: eager)
 
 // per-head RMSNorm (weight, eps) + rotary embedding of the q and k projections (flux_ops.hip):
 //   src rows [M][src_ld]: q at column q_col + h*128, k at k_col + h*128 (bf16, bias already added);

@@ -65,6 +65,7 @@ struct mi355_qwen {
     std::map<std::string, QSlot> slots;
     std::vector<std::string> names;
     bool bounds_dirty = true;
+    int bounds_ver = 0;          // bumped whenever the per-block score bounds are recomputed (they are baked into a captured graph)
 
     bf16_t* a16(int64_t n) {
         size_t bytes = ((size_t)n * 2 + 255) & ~(size_t)255;
@@ -222,6 +223,12 @@ struct mi355_qwen_plan {
     char* ws_side = nullptr;
     bf16_t *qkbuf_c = nullptr, *big_c = nullptr;
     std::vector<hipEvent_t> ev_join, ev_fork;   // per block: text q|k|v ready (side -> main), attention done (main -> side); [L] = forward start / end
+    // hipGraph of the N-step loop (opt-in, mi355_tune_set key 17): captured on a plan-owned stream on the second call of a configuration
+    hipGraphExec_t gexec = nullptr;
+    hipStream_t cap_stream = nullptr;
+    bool warmed = false;
+    int g_steps = -1, g_dyn = -1, g_storage = -1, g_init = -1, g_clp = -1, g_noise = -1, g_bounds = -1, g_two = -1, g_gemm = -1, g_attn = -1;
+    float g_sigma_max = 0.f, g_guidance = 0.f;
 };
 
 extern "C" int mi355_qwen_plan_create(mi355_qwen* e, int batch, int n_cfg, int latent_h, int latent_w, int n_text, int max_steps,
@@ -320,6 +327,8 @@ extern "C" int mi355_qwen_plan_create(mi355_qwen* e, int batch, int n_cfg, int l
 
 extern "C" int mi355_qwen_plan_destroy(mi355_qwen_plan* p) {
     if (!p) return 0;
+    if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
+    if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     for (hipEvent_t ev : p->ev_join) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : p->ev_fork) (void)hipEventDestroy(ev);
     if (p->side) (void)hipStreamDestroy(p->side);
@@ -348,6 +357,7 @@ int update_score_bounds(mi355_qwen* e, hipStream_t st) {
     const float c = 11.313708f * 1.4426950408889634f * 1.02f;
     for (auto& b : e->blk) b.bound = c * fmaxf(amax(b.nq), amax(b.ncq)) * fmaxf(amax(b.nk), amax(b.nck));
     e->bounds_dirty = false;
+    ++e->bounds_ver;
     return 0;
 }
 
@@ -430,6 +440,11 @@ int gate_res(mi355_qwen_plan* p, hipStream_t st, const bf16_t* A, long lda, int 
 // Results are bit-identical to the single-stream order: the kernels and their inputs are the same, only `qkbuf` / `big` are not shared.
 int g_qwen_two_stream = 0;          // 0 off, 1 on, 2 on for plans with at most g_qwen_two_stream_rows image rows
 int g_qwen_two_stream_rows = 16384;
+
+// key 17: replay the N-step loop of mi355_qwen_rollout as ONE hipGraph (OFF by default; same status): 60 blocks x ~14 launches per forward,
+// 5-15 us each at the reference's example shapes (B = 1, 384^2 / 512^2), are bound by launch overhead.  The prompt preparation (it uploads
+// the per-sample key lengths from host memory) stays in front of the graph.
+int g_qwen_graph = 0;
 
 bool qwen_two_stream_wanted(const mi355_qwen_plan* p) {
     return g_qwen_two_stream == 1 || (g_qwen_two_stream == 2 && p->Mi <= g_qwen_two_stream_rows);
@@ -552,6 +567,7 @@ int sde_call(hipStream_t st, int batch, int64_t n, const bf16_t* v, const void* 
 namespace mi355 {
 void set_qwen_two_stream(int mode) { g_qwen_two_stream = mode; }
 void set_qwen_two_stream_rows(int rows) { g_qwen_two_stream_rows = rows; }
+void set_qwen_graph(int on) { g_qwen_graph = on; }
 }  // namespace mi355
 
 // One transformer evaluation incl. the CFG combine (replay / tests).  t_model [B] device fp32 = the angle base of the sinusoidal
@@ -623,21 +639,67 @@ extern "C" int mi355_qwen_rollout(mi355_qwen_plan* p, void* stream, int n_steps,
     const int clp = compute_log_prob && out_log_probs;
     CHK(prepare_prompt(p, st, p->io_pe, txt_lens_host));
     p->mod_ld = 0;                                    // every sample of a step shares its one modulation row
-    CHK(prepare_conditioning(p, st, n_steps));
     const size_t esz = storage_dtype == MI355_F32 ? 4 : 2;
     const size_t lat_bytes = (size_t)nl * esz;
-    HIPCHK(launch_convert(p->io_init, init_dtype, p->io_traj, storage_dtype, (long)nl, st));      // cast_latents(init)
-    for (int i = 0; i < n_steps; ++i) {
-        const bf16_t* mod = p->mod_all + (int64_t)i * p->e->mod_cols;
-        char* cur = p->io_traj + (size_t)i * lat_bytes;
-        char* nxt = p->io_traj + (size_t)(i + 1) * lat_bytes;
-        CHK(forward_core(p, st, cur, storage_dtype, mod));
-        int rc = 0;
-        const bf16_t* v = combine(p, st, guidance_scale, p->v, &rc);
-        CHK(rc);
-        CHK(sde_call(st, B, p->n_lat, v, cur, storage_dtype, step_noise ? p->io_noise + (int64_t)i * nl : nullptr, p->scal + i,
-                     p->scal + p->max_steps + i, p->scal + 2 * p->max_steps + i, sigma_max, dynamics, clp ? 2 : 0, nxt,
-                     clp ? p->io_lp + (int64_t)i * B : nullptr));
+    // everything below reads / writes plan-owned buffers at fixed addresses (staged inputs, c0 / kvlen, t_dev / scal, io_traj, io_lp)
+    auto body = [&](hipStream_t s) -> int {
+        CHK(prepare_conditioning(p, s, n_steps));
+        HIPCHK(launch_convert(p->io_init, init_dtype, p->io_traj, storage_dtype, (long)nl, s));      // cast_latents(init)
+        for (int i = 0; i < n_steps; ++i) {
+            const bf16_t* mod = p->mod_all + (int64_t)i * p->e->mod_cols;
+            char* cur = p->io_traj + (size_t)i * lat_bytes;
+            char* nxt = p->io_traj + (size_t)(i + 1) * lat_bytes;
+            CHK(forward_core(p, s, cur, storage_dtype, mod));
+            int rc = 0;
+            const bf16_t* v = combine(p, s, guidance_scale, p->v, &rc);
+            CHK(rc);
+            CHK(sde_call(s, B, p->n_lat, v, cur, storage_dtype, step_noise ? p->io_noise + (int64_t)i * nl : nullptr, p->scal + i,
+                         p->scal + p->max_steps + i, p->scal + 2 * p->max_steps + i, sigma_max, dynamics, clp ? 2 : 0, nxt,
+                         clp ? p->io_lp + (int64_t)i * B : nullptr));
+        }
+        return 0;
+    };
+    bool launched = false;
+    if (g_qwen_graph && p->warmed) {
+        const int two = (int)qwen_two_stream_wanted(p);
+        const bool same = p->gexec && p->g_steps == n_steps && p->g_dyn == dynamics && p->g_storage == storage_dtype && p->g_init == init_dtype &&
+                          p->g_clp == clp && p->g_noise == (int)(step_noise != nullptr) && p->g_sigma_max == sigma_max && p->g_guidance == guidance_scale &&
+                          p->g_bounds == p->e->bounds_ver && p->g_two == two && p->g_gemm == get_gemm_variant() && p->g_attn == get_attn128_variant();
+        if (!same) {
+            if (two) CHK(qwen_two_stream_init(p));              // streams / events / buffers are created outside the capture
+            if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
+            hipGraph_t graph = nullptr;
+            hipError_t ce = hipSuccess;
+            if (!p->cap_stream) ce = hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking);
+            if (ce == hipSuccess) ce = hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed);
+            if (ce == hipSuccess) {
+                const int rc = body(p->cap_stream);             // nothing executes: launches / D2D copies become graph nodes
+                ce = hipStreamEndCapture(p->cap_stream, &graph);
+                if (rc != 0 || ce != hipSuccess || !graph) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    graph = nullptr;
+                }
+            }
+            if (graph) {
+                ce = hipGraphInstantiate(&p->gexec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (ce != hipSuccess) p->gexec = nullptr;
+            }
+            if (!p->gexec) {                                    // no silent fallback: the caller chooses eager launches with key 17 = 0
+                const hipError_t last = hipGetLastError();
+                return errorf("mi355_qwen_rollout: hipGraph capture / instantiation of the %d-step loop failed (%s); mi355_tune_set(17, 0) "
+                              "selects eager launches", n_steps, hipGetErrorString(ce != hipSuccess ? ce : last));
+            }
+            p->g_steps = n_steps; p->g_dyn = dynamics; p->g_storage = storage_dtype; p->g_init = init_dtype; p->g_clp = clp;
+            p->g_noise = (int)(step_noise != nullptr); p->g_sigma_max = sigma_max; p->g_guidance = guidance_scale; p->g_bounds = p->e->bounds_ver;
+            p->g_two = two; p->g_gemm = get_gemm_variant(); p->g_attn = get_attn128_variant();
+        }
+        HIPCHK(hipGraphLaunch(p->gexec, st));
+        launched = true;
+    }
+    if (!launched) {
+        CHK(body(st));
+        p->warmed = true;
     }
     if (keep_slot_host && out_latents)
         for (int i = 0; i <= n_steps; ++i)

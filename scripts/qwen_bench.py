@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--layers", type=int, default=60)
     ap.add_argument("--iters", type=int, default=1)
     ap.add_argument("--dynamics", default="Flow-SDE", help="Flow-SDE | Dance-SDE | CPS | ODE (DGPO samples with ODE)")
+    ap.add_argument("--ab-shapes", default=None, metavar="BxSIZE,...", help="shapes of the --ab-two-stream run (default: --batch x --size)")
     ap.add_argument("--ab-two-stream", action="store_true",
                     help="A/B of the text chain on a side stream (mi355_tune_set key 12) in ONE process: same seeded rollout under 0 / 1, "
                          "bit-identity asserted, seconds per rollout of both (not yet run on the GPU)")
@@ -81,26 +82,36 @@ def main():
     if a.ab_two_stream:
         from mi355_flow import _lib
         lib = _lib.load()
-        res, secs = {}, {}
-        for mode in (0, 1, 0, 1):
-            lib.mi355_tune_set(12, mode)
-            torch.cuda.manual_seed(5)
-            o = run(); torch.cuda.synchronize()                 # (the first run under mode 1 creates the side stream and its buffers)
-            torch.cuda.manual_seed(5)
-            t0 = time.perf_counter()
-            for _ in range(a.iters): o = run()
-            torch.cuda.synchronize()
-            secs.setdefault(mode, []).append((time.perf_counter() - t0) / a.iters)
-            lat = torch.stack([x.all_latents for x in o])
-            if mode in res:
-                assert torch.equal(res[mode], lat), f"mode {mode}: run-to-run difference"
-            res[mode] = lat
-        lib.mi355_tune_set(12, 0)
-        same = bool(torch.equal(res[0], res[1]))
-        t_a, t_b = min(secs[0]), min(secs[1])
-        print(json.dumps({"ab": "qwen two-stream (key 12)", "batch": B, "image": f"{a.size}x{a.size}", "denoise_steps": N, "bit_identical": same,
-                          "s_per_rollout_single": round(t_a, 4), "s_per_rollout_two_stream": round(t_b, 4), "gain_pct": round((t_a / t_b - 1) * 100, 2)}))
-        assert same
+        for shape in (a.ab_shapes or f"{B}x{a.size}").split(","):
+            B, size = (int(v) for v in shape.split("x"))
+            pe = torch.randn(B, a.n_text, J, device=dev, generator=g).bfloat16()
+            pm = torch.ones(B, a.n_text, dtype=torch.long, device=dev)
+            ne = torch.randn(B, n_neg, J, device=dev, generator=g).bfloat16() if a.guidance > 1 else None
+            nm = torch.ones(B, n_neg, dtype=torch.long, device=dev) if a.guidance > 1 else None
+            run = lambda: ad.inference(prompt=None, height=size, width=size, num_inference_steps=N, guidance_scale=a.guidance, prompt_embeds=pe,
+                                       prompt_embeds_mask=pm, negative_prompt_embeds=ne, negative_prompt_embeds_mask=nm, compute_log_prob=a.dynamics != "ODE")
+            res, secs = {}, {}
+            modes = ((0, 0), (1, 0), (0, 1), (1, 1))                  # (two-stream: key 12, hipGraph replay of the loop: key 17)
+            for mode in modes + modes:
+                lib.mi355_tune_set(12, mode[0]); lib.mi355_tune_set(17, mode[1])
+                torch.cuda.manual_seed(5)
+                o = run(); torch.cuda.synchronize()                 # (creates the side stream / captures the graph of this configuration)
+                torch.cuda.manual_seed(5)
+                t0 = time.perf_counter()
+                for _ in range(a.iters): o = run()
+                torch.cuda.synchronize()
+                secs.setdefault(mode, []).append((time.perf_counter() - t0) / a.iters)
+                lat = torch.stack([x.all_latents for x in o])
+                if mode in res:
+                    assert torch.equal(res[mode], lat), f"mode {mode}: run-to-run difference"
+                res[mode] = lat
+            lib.mi355_tune_set(12, 0); lib.mi355_tune_set(17, 0)
+            same = all(bool(torch.equal(res[modes[0]], res[m])) for m in modes[1:])
+            best = {m: min(v) for m, v in secs.items()}
+            print(json.dumps({"ab": "qwen (two-stream key 12, graph key 17)", "batch": B, "image": f"{size}x{size}", "denoise_steps": N, "bit_identical": same,
+                              "s_per_rollout": {f"two{m[0]}_graph{m[1]}": round(t, 4) for m, t in best.items()},
+                              "gain_pct_vs_single_eager": {f"two{m[0]}_graph{m[1]}": round((best[modes[0]] / t - 1) * 100, 2) for m, t in best.items()}}), flush=True)
+            assert same
         return
     t0 = time.perf_counter()
     for _ in range(a.iters): s = run()

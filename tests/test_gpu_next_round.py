@@ -67,10 +67,11 @@ def test_bench_small_batch_legs_report_numbers():
         assert sb[tag]["denoise_steps_per_s"] > 0 and 0 < sb[tag]["forward_frac"] < 1
 
 
-def test_qwen_two_stream_forward_and_rollout_are_bit_identical():
-    """Qwen-Image engine with the text chain of every block on a side stream (mi355_tune_set key 12 = 1; default 0): the raw network
-    outputs of both CFG branches of a ragged-prompt forward and a whole true-CFG rollout (latents, log-probs) equal the single-stream
-    results bit for bit, repeatedly (a missing fork / join edge shows up as a run-to-run difference)."""
+def test_qwen_two_stream_and_graph_replay_are_bit_identical():
+    """Qwen-Image engine with the text chain of every block on a side stream (mi355_tune_set key 12 = 1; default 0) and / or the N-step
+    loop replayed as one hipGraph (key 17 = 1; default 0): the raw network outputs of both CFG branches of a ragged-prompt forward and whole
+    true-CFG rollouts (latents, log-probs) equal the single-stream eager results bit for bit, repeatedly (a missing fork / join edge shows
+    up as a run-to-run difference); a replayed graph sees new prompt lengths."""
     from mi355_flow import _lib, qwen as qw
     from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
     from oracle import qwen_ref as R
@@ -106,35 +107,49 @@ def test_qwen_two_stream_forward_and_rollout_are_bit_identical():
                 for v, raw in runs:
                     assert torch.equal(v, ref_v) and torch.equal(raw, ref_raw), (mode, B, h, w, Nt)
         eng.close()
-        # ---- a whole rollout through the adapter
+        # ---- whole rollouts through the adapter: single / two-stream x eager / hipGraph replay of the loop (key 17; captured on the second
+        #      call of a configuration: eager warm-up, capture + launch, replay).  The third run changes the prompts' lengths: the key
+        #      lengths are uploaded in front of the graph, so a replay must see them.
         res = {}
-        for mode in (0, 1):
-            lib.mi355_tune_set(12, mode)
+        for mode in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            lib.mi355_tune_set(12, mode[0])
+            lib.mi355_tune_set(17, mode[1])
             sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[0, 1, 2, 3], num_sde_steps=2, seed=42, dynamics_type="Flow-SDE",
                                                        shift=1.0, use_dynamic_shifting=True, base_shift=0.5, max_shift=0.9, max_image_seq_len=8192,
                                                        shift_terminal=0.02)
             ad = qw.QwenImageNativeAdapter({k: v.cuda() for k, v in sd.items()}, cfg, sched, latent_storage_dtype="bf16")
             ad.rollout()
             gg = torch.Generator().manual_seed(9)
-            pe = [torch.randn(n, J, generator=gg).bfloat16().cuda() for n in (21, 17)]
-            pm = [torch.ones(n, dtype=torch.long).cuda() for n in (21, 17)]
             ne = torch.randn(2, 6, J, generator=gg).bfloat16().cuda()
             nm = torch.ones(2, 6, dtype=torch.long).cuda()
-            torch.cuda.manual_seed(77)
-            s = ad.inference(prompt=["a", "b"], negative_prompt=None, height=128, width=192, num_inference_steps=5, guidance_scale=4.0,
-                             prompt_embeds=pe, prompt_embeds_mask=pm, negative_prompt_embeds=ne, negative_prompt_embeds_mask=nm,
-                             compute_log_prob=True, trajectory_indices="all")
-            res[mode] = (torch.stack([o.all_latents for o in s]).clone(), torch.stack([o.log_probs for o in s]).clone())
+            full = [torch.randn(21, J, generator=gg).bfloat16().cuda() for _ in range(2)]
+            runs = []
+            for lens in ((21, 17), (21, 17), (21, 17), (21, 9)):
+                pe = [full[b][:n] for b, n in enumerate(lens)]
+                pm = [torch.ones(n, dtype=torch.long).cuda() for n in lens]
+                torch.cuda.manual_seed(77)
+                s = ad.inference(prompt=["a", "b"], negative_prompt=None, height=128, width=192, num_inference_steps=5, guidance_scale=4.0,
+                                 prompt_embeds=pe, prompt_embeds_mask=pm, negative_prompt_embeds=ne, negative_prompt_embeds_mask=nm,
+                                 compute_log_prob=True, trajectory_indices="all")
+                runs.append((torch.stack([o.all_latents for o in s]).clone(), torch.stack([o.log_probs for o in s]).clone()))
+            assert all(torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]) for r in runs[1:3]), mode
+            assert not torch.equal(runs[3][0][1], runs[0][0][1])          # the shorter second prompt changed sample 1 ...
+            assert torch.equal(runs[3][0][0], runs[0][0][0])              # ... and only sample 1
+            res[mode] = (runs[0][0], runs[0][1], runs[3][0], runs[3][1])
             ad.engine.close()
-        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        ref = res[(0, 0)]
+        for mode, r in res.items():
+            assert all(torch.equal(a, b) for a, b in zip(r, ref)), mode
     finally:
         lib.mi355_tune_set(12, 0)
+        lib.mi355_tune_set(17, 0)
 
 
-def test_flux_two_stream_double_blocks_are_bit_identical():
-    """FLUX.1 engine with the text chain of the double blocks on a side stream (mi355_tune_set key 14 = 1; default 0): single forwards
-    (small and chip-filling token counts, text length not a multiple of 64 so that text and image columns of V^T share cache lines) and a
-    whole rollout equal the single-stream results bit for bit, repeatedly."""
+def test_flux_two_stream_and_graph_replay_are_bit_identical():
+    """FLUX.1 engine with the text chain of the double blocks on a side stream (mi355_tune_set key 14 = 1; default 0) and / or the N-step
+    loop replayed as one hipGraph (key 16 = 1; default 0): single forwards (small and chip-filling token counts, text length not a multiple
+    of 64 so that text and image columns of V^T share cache lines) and whole rollouts equal the single-stream eager results bit for bit,
+    repeatedly; a changed step count re-captures."""
     from mi355_flow import _lib, flux as fx
     from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
     from oracle import flux_ref as R
@@ -165,9 +180,12 @@ def test_flux_two_stream_double_blocks_are_bit_identical():
             assert torch.isfinite(outs[0].float()).all()
             assert all(torch.equal(o, outs[0]) for o in outs[1:]), (B, h, w, Nt)
         eng.close()
+        # ---- whole rollouts: single / two-stream x eager / hipGraph replay of the loop (key 16; the graph is captured on the second call
+        #      of a configuration, so every mode runs three times: eager warm-up, capture + launch, replay)
         res = {}
-        for mode in (0, 1):
-            lib.mi355_tune_set(14, mode)
+        for mode in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            lib.mi355_tune_set(14, mode[0])
+            lib.mi355_tune_set(16, mode[1])
             sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[0, 1, 2, 3], num_sde_steps=2, seed=42, dynamics_type="Flow-SDE",
                                                        shift=3.0, use_dynamic_shifting=True)
             ad = fx.Flux1NativeAdapter({k: v.cuda() for k, v in sd.items()}, cfg, sched, latent_storage_dtype="fp16")
@@ -175,11 +193,22 @@ def test_flux_two_stream_double_blocks_are_bit_identical():
             gg = torch.Generator().manual_seed(9)
             pe = torch.randn(2, 16, cfg_o.joint_attention_dim, generator=gg).bfloat16().cuda()
             pp = torch.randn(2, cfg_o.pooled_projection_dim, generator=gg).bfloat16().cuda()
-            torch.cuda.manual_seed(77)
-            s = ad.inference(prompt=["a", "b"], height=128, width=128, num_inference_steps=5, guidance_scale=3.5, prompt_embeds=pe,
-                             pooled_prompt_embeds=pp, trajectory_indices="all")
-            res[mode] = (torch.stack([o.all_latents for o in s]).clone(), torch.stack([o.log_probs for o in s]).clone())
+            runs = []
+            for _ in range(3):
+                torch.cuda.manual_seed(77)
+                s = ad.inference(prompt=["a", "b"], height=128, width=128, num_inference_steps=5, guidance_scale=3.5, prompt_embeds=pe,
+                                 pooled_prompt_embeds=pp, trajectory_indices="all")
+                runs.append((torch.stack([o.all_latents for o in s]).clone(), torch.stack([o.log_probs for o in s]).clone()))
+            assert all(torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]) for r in runs[1:]), mode
+            # a different step count / dynamics re-captures instead of replaying a stale graph
+            torch.cuda.manual_seed(78)
+            s4 = ad.inference(prompt=["a", "b"], height=128, width=128, num_inference_steps=4, guidance_scale=3.5, prompt_embeds=pe,
+                              pooled_prompt_embeds=pp, trajectory_indices="all")
+            res[mode] = (runs[0][0], runs[0][1], torch.stack([o.all_latents for o in s4]).clone())
             ad.engine.close()
-        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        ref = res[(0, 0)]
+        for mode, r in res.items():
+            assert all(torch.equal(a, b) for a, b in zip(r, ref)), mode
     finally:
         lib.mi355_tune_set(14, 0)
+        lib.mi355_tune_set(16, 0)
