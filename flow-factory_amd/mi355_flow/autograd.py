@@ -87,15 +87,50 @@ def unsupported_reason(host) -> Optional[str]:
 grad_forward_supported = unsupported_reason      # name used by the Flow-Factory plugin
 
 
+# --------------------------------------------------------------------------------------------- FSDP2 (sharded DTensor parameters)
+def _is_sharded(t) -> bool:
+    return hasattr(t, "full_tensor") and hasattr(t, "device_mesh")
+
+
+class _ShardGradBridge(torch.autograd.Function):
+    """FSDP2 parameter (a sharded DTensor) -> a stand-in of its GLOBAL shape for the engine's autograd node, which needs the parameter as a
+    graph edge only (the values are the engine's own bound copy): no all-gather in the forward.  Backward: the engine hands back the WHOLE
+    gradient of this rank's micro-batch; declared a partial value and redistributed to the parameter's placements it is reduce-scattered
+    with averaging over the data-parallel mesh -- what FSDP2's own post-backward does for gradients computed by `module.forward`, which the
+    engine bypasses (so FSDP2's hooks never fire and nothing is reduced twice)."""
+
+    @staticmethod
+    def forward(ctx, p):
+        ctx.mesh, ctx.placements = p.device_mesh, p.placements
+        return p._local_tensor.new_zeros(()).expand(p.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        from torch.distributed.tensor import DTensor, Partial
+        if g is None:
+            return None
+        part = DTensor.from_local(g.contiguous(), ctx.mesh, [Partial("avg")] * ctx.mesh.ndim, run_check=False)
+        return part.redistribute(ctx.mesh, ctx.placements)
+
+
+def _full_with_grad(t: torch.Tensor) -> torch.Tensor:
+    """Whole tensor WITH autograd (LoRA factors, whose values enter the merged weight): for an FSDP2 shard the backward averages the
+    per-rank gradients over the mesh (`full_tensor()`'s default backward would just chunk this rank's gradient)."""
+    if _is_sharded(t) and t.requires_grad:
+        from torch.distributed.tensor import Partial
+        return t.full_tensor(grad_placements=[Partial("avg")] * t.device_mesh.ndim)
+    return _full(t)
+
+
 def _materialise_with_grad(src, lora_scale: float) -> torch.Tensor:
     """The tensor the engine binds for this source, connected to the trainable leaves by autograd."""
     if isinstance(src, _Plain):
-        return src.t
+        return _ShardGradBridge.apply(src.t) if _is_sharded(src.t) else src.t
     lay = src.layer
-    w = _full(lay.base_layer.weight)
+    w = _full_with_grad(lay.base_layer.weight)
     out = w.float() if w.requires_grad else w.detach().float()
     for a in src._active():
-        A, B = _full(lay.lora_A[a].weight).float(), _full(lay.lora_B[a].weight).float()
+        A, B = _full_with_grad(lay.lora_A[a].weight).float(), _full_with_grad(lay.lora_B[a].weight).float()
         delta = (B @ A) * (float(lay.scaling[a]) * float(lora_scale))
         out = out + (delta.t() if getattr(lay, "fan_in_fan_out", False) else delta)
     return out

@@ -308,3 +308,92 @@ def test_reference_grpo_trainer_on_two_ranks_through_the_plugin(tmp_path):
         flags = np.load(tmp_path / f"trainer_{r}.npy").tolist()
         assert flags == [1] * 8, (r, dict(zip(["samples", "advantages", "ratio", "same_weights", "calls", "next_policy", "no_torch_forward",
                                                "gradients_all_reduced"], flags)))
+
+
+def _fsdp2_grad_worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    from torch.distributed.device_mesh import init_device_mesh
+    from torch.distributed.fsdp import fully_shard
+    import _plugin_fakes as F
+    from mi355_flow import autograd as AG
+    from mi355_flow.binding import LiveWeights
+    from mi355_flow.engine import TransformerConfig
+    from mi355_flow.weights import expected_shapes
+    tcfg = TransformerConfig(num_layers=2, num_heads=1, joint_attention_dim=64, pooled_projection_dim=64, pos_embed_max_size=8, dual_layers=(0,))
+    mod = F.build_module_tree(expected_shapes(tcfg), seed=3)                # same seed on both ranks = the unsharded model
+    for n, p_ in mod.named_parameters():                                    # the reference's default target: the attention projections
+        p_.requires_grad_(".attn.to_" in n or ".attn.add_" in n)
+    mesh = init_device_mesh("cpu", (world,))
+    for blk in mod.transformer_blocks.children():
+        fully_shard(blk, mesh=mesh)
+    fully_shard(mod, mesh=mesh)
+    eng = F.DiffFakeEngine(tcfg)
+    host = types.SimpleNamespace(engine=eng, _live_weights=LiveWeights(eng, lambda: mod))
+    host._sync_weights = host._live_weights.sync
+    assert AG.unsupported_reason(host) is None
+    plan = eng.plan(2, 1, 8, 8, 5, 4)
+    g = torch.Generator().manual_seed(10 + rank)                             # every rank has its own micro-batch
+    lat = torch.randn(2, 16, 8, 8, generator=g).half()
+    call = dict(latents=lat, timestep=torch.tensor([500.0, 500.0]), enc_a=torch.zeros(2, 5, 64), pooled_a=torch.zeros(2, 64), enc_b=None,
+                pooled_b=None, guidance=1.0, sigma=0.5, sigma_next=0.4, eta=0.7, sigma_max=0.98, dynamics="Flow-SDE",
+                next_latents=lat, compute_log_prob=True)
+    lp, npred, mean, std, dtt = AG.denoise_replay(host, plan, call)
+    wgt = torch.tensor([1.0, -3.0]) * (rank + 1)
+    (wgt * lp).sum().backward()
+    # what the engine double returns on THIS rank for every element of a signal tensor (see DiffFakePlan.denoise_step_backward)
+    sig = eng.signal_names()
+    m = lat.float().reshape(2, -1).mean(1)
+    local_up = F.DiffFakePlan.C_W * float((wgt * (1.0 + m)).sum())
+    ups = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(ups, torch.tensor([local_up], dtype=torch.float64))
+    mean_up = float(sum(u.item() for u in ups) / world)                     # FSDP2 averages gradients over the data-parallel mesh
+    ok, n_sig, n_sharded = True, 0, 0
+    for name, p_ in mod.named_parameters():
+        if not p_.requires_grad:
+            ok = ok and p_.grad is None
+            continue
+        gshard = p_.grad
+        ok = ok and gshard is not None and type(gshard).__name__ == "DTensor" and gshard.placements == p_.placements
+        if not ok:
+            break
+        loc = gshard.to_local()
+        n_sharded += int(loc.numel() < p_.numel())
+        if name in sig:
+            want = mean_up / (p_.numel() * len(sig))
+            ok = ok and bool(torch.allclose(loc.double(), torch.full_like(loc, want, dtype=torch.float64), rtol=1e-5, atol=1e-12))
+            n_sig += 1
+        else:
+            ok = ok and float(loc.abs().max()) == 0.0
+    # an optimizer step on the shards is seen by the next sync (and both ranks hold the same model again)
+    before = eng.weight_signal()
+    torch.optim.SGD([p_ for p_ in mod.parameters() if p_.requires_grad], lr=1e4).step()
+    host._live_weights.sync()
+    after = eng.weight_signal()
+    sigs = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(sigs, torch.tensor([after], dtype=torch.float64))
+    ok = ok and after != before and float(sigs[0]) == float(sigs[1])
+    np.save(os.path.join(out_dir, f"fsdpgrad_{rank}.npy"), np.array([int(ok), n_sig, n_sharded]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fsdp2_sharded_parameters_receive_averaged_gradients_from_the_engine_autograd_node(tmp_path):
+    """The reference's full fine-tuning example for SD3.5 runs under FSDP2 (examples/grpo/full/sd3_5/default.yaml): the trainable parameters
+    are sharded DTensors, and the engine's autograd node -- which bypasses `module.forward`, so FSDP2's own reduce-scatter hooks never
+    fire -- hands back WHOLE gradients of the local micro-batch.  `mi355_flow.autograd` bridges them: no all-gather in the forward, and in
+    the backward the whole gradient is declared a partial value and redistributed to the parameter's placements (reduce-scatter with
+    averaging).  Checked on 2 ranks with different micro-batches: every trainable shard's `.grad` is a DTensor with the parameter's
+    placements holding the MEAN of the ranks' gradients; frozen parameters get none; an optimizer step on the shards reaches the engine."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    mp.spawn(_fsdp2_grad_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        ok, n_sig, n_sharded = np.load(tmp_path / f"fsdpgrad_{r}.npy").tolist()
+        assert ok == 1 and n_sig >= 4 and n_sharded > 0, (r, ok, n_sig, n_sharded)
