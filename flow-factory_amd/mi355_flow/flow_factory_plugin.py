@@ -54,6 +54,14 @@ class _LiveBinding:
     swaps parameters behind the engine's back (`param.data.copy_` does not bump autograd version counters)."""
 
     def _init_live(self, engine) -> None:
+        # the engine's arithmetic is the reference's DEFAULT run: bf16 autocast over bf16 weights (hparams/args.py:63, model_args.py:49)
+        mp = getattr(getattr(self, "config", None), "mixed_precision", "bf16")
+        if mp == "fp16":
+            raise NotImplementedError("mi355_flow: mixed_precision='fp16' -- the native engine computes in bf16 (the reference's default); "
+                                      "set mixed_precision: bf16 or use the reference adapter")
+        if mp not in (None, "bf16"):
+            logger.warning("mi355_flow: mixed_precision=%r -- the native engine always computes like the reference's bf16 autocast run "
+                           "(bf16 GEMM inputs, fp32 LayerNorm / softmax / accumulation)", mp)
         self.engine = engine
         self._live_weights = LiveWeights(engine, lambda: self.transformer)
 
@@ -70,7 +78,9 @@ class _LiveBinding:
         return n
 
     def _invalidate(self) -> None:
-        self._live_weights.invalidate()
+        live = getattr(self, "_live_weights", None)          # (None while the reference's __init__ is still running: nothing bound yet)
+        if live is not None:
+            live.invalidate()
         if getattr(self, "_live_weights_2", None) is not None:
             self._live_weights_2.invalidate()
 

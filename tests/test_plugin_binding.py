@@ -300,6 +300,40 @@ def test_missing_parameters_fail_fast(ref):
         LiveWeights(F.FakeEngine(tcfg), lambda: tr).sync()
 
 
+def test_plugin_refuses_what_the_engine_does_not_compute(ref, caplog):
+    """Construction-time guards of the plugin (fail fast, no silent fallback -- constraints.md:144-145): fp16 mixed precision (the engine
+    computes like the reference's default bf16 autocast run), and SD3-family members the engine does not implement (SD3.0 has no q/k norm)."""
+    import logging
+    from flow_factory.hparams import Arguments
+    from mi355_flow.weights import expected_shapes
+    P = ref
+    tcfg = _tiny_cfg()
+
+    def build(mixed_precision="bf16", **tc_extra):
+        cfg = Arguments.load_from_yaml(YAML_FULL)
+        cfg.mixed_precision = mixed_precision
+        tr = F.build_module_tree(expected_shapes(tcfg), cls=F.FakeTransformer)
+
+        class Plug(P.SD3_5NativeAdapter):
+            def load_pipeline(self):
+                pipe = F.make_pipeline(tcfg, tr)
+                for k, v in tc_extra.items():
+                    setattr(pipe.transformer.config, k, v)
+                return pipe
+        return Plug(cfg, F.FakeAccelerator())
+
+    assert build().engine is not None
+    with pytest.raises(NotImplementedError, match="fp16"):
+        build(mixed_precision="fp16")
+    with caplog.at_level(logging.WARNING):
+        assert build(mixed_precision="no").engine is not None
+    assert any("bf16 autocast" in r.getMessage() for r in caplog.records)
+    with pytest.raises(NotImplementedError, match="qk_norm=None"):
+        build(qk_norm=None)
+    with pytest.raises(NotImplementedError, match="caption_projection_dim"):
+        build(caption_projection_dim=4096)
+
+
 # ------------------------------------------------------------------------------------------------- Qwen-Image (config E)
 def test_qwen_image_plugin_rollout_with_ragged_prompts(ref):
     """`QwenImageNativeAdapter(config, accelerator)` built as Flow-Factory does from the reference's own example YAML
