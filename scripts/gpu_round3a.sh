@@ -12,6 +12,9 @@ MI355_NEXT=1 timeout 600 python -m pytest tests/test_gpu_next_round.py -q 2>&1 |
 cat $OUT/next_round_tests.log
 timeout 120 python scripts/clock_under_load.py --ms 30 > $OUT/clock_under_load.txt 2>&1; echo "clock rc=$?" >> $OUT/status
 cat $OUT/clock_under_load.txt
+# d = 64 attention variants incl. 3 = row sums on the matrix pipe (MSUM): parity vs fp32 and TFLOP/s at the bench shapes
+timeout 120 python scripts/attn_ab.py > $OUT/attn_ab.txt 2>&1; echo "attn ab rc=$?" >> $OUT/status
+cat $OUT/attn_ab.txt
 timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 > $OUT/tests.log; echo "tests rc=$?" >> $OUT/status
 cat $OUT/tests.log
 # Qwen-Image two-stream forward (key 12) and hipGraph replay of the loop (key 17), both opt-in: A/B in one process (41 GB of synthetic weights: ~1 min to bind)

@@ -213,3 +213,38 @@ def test_flux_two_stream_and_graph_replay_are_bit_identical():
     finally:
         lib.mi355_tune_set(14, 0)
         lib.mi355_tune_set(16, 0)
+
+
+@pytest.mark.parametrize("B,H,S,n_img", [(1, 2, 300, 256), (2, 3, 333, 77), (1, 4, 4429, 4096)])
+def test_attention_row_sums_on_the_matrix_pipe_match_fp32(B, H, S, n_img):
+    """A/B variant 3 of the d = 64 attention (static-bound softmax; row sums from one more MFMA per 16-key step with an all-ones A operand
+    instead of v_dot2c on the VALU port): against fp32 torch attention, same tolerance as the shipped variants (tests/test_gpu_kernels.py),
+    and within bf16 rounding of variant 1 on the same inputs; ragged S exercises the masked last tile and the inactive tail waves."""
+    import torch.nn.functional as Fn
+    from mi355_flow import _lib, engine
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(S + H)
+    S_pad = (S + 63) // 64 * 64
+    q = torch.zeros(B, H, S_pad, 64)
+    k = torch.zeros_like(q)
+    v = torch.zeros_like(q)
+    q[:, :, :S] = torch.randn(B, H, S, 64, generator=g).bfloat16().float()
+    k[:, :, :S] = torch.randn(B, H, S, 64, generator=g).bfloat16().float()
+    v[:, :, :S] = torch.randn(B, H, S, 64, generator=g).bfloat16().float()
+    ref = Fn.scaled_dot_product_attention(q[:, :, :S], k[:, :, :S], v[:, :, :S]).transpose(1, 2).reshape(B, S, H * 64)
+    qd, kd, vT = q.bfloat16().cuda(), k.bfloat16().cuda(), v.transpose(2, 3).contiguous().bfloat16().cuda()
+    outs = {}
+    try:
+        lib.mi355_tune_set(6, 40)                       # |score| <= 40 holds by a wide margin for unit-variance q, k (log2 domain ~ +-10)
+        for var in (1, 3):
+            lib.mi355_tune_set(1, var)
+            oi, oc = engine.op_attention(qd, kd, vT, S, n_img)
+            torch.cuda.synchronize()
+            outs[var] = torch.cat([oi.view(B, n_img, H * 64), oc.view(B, S - n_img, H * 64)], 1).float().cpu()
+    finally:
+        lib.mi355_tune_set(1, 1)
+        lib.mi355_tune_set(6, 1)
+    for var, got in outs.items():
+        rel = float((got - ref).norm() / ref.norm())
+        assert torch.isfinite(got).all() and rel < 6e-3, (var, rel)
+    assert float((outs[3] - outs[1]).abs().max()) <= 2.0 ** -6 * float(ref.abs().max())
