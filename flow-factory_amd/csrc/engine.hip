@@ -988,6 +988,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 15) { set_flux_two_stream_rows(value); return 0; }
     if (key == 16) { set_flux_graph(value); return 0; }        // FLUX.1 engine: hipGraph replay of the rollout loop (0 = default: eager)
     if (key == 17) { set_qwen_graph(value); return 0; }        // Qwen-Image engine: the same
+    if (key == 18) { set_wan_graph(value); return 0; }         // Wan engine: the same
     return fail("mi355_tune_set: unknown key %d", key);
 }
 

@@ -120,6 +120,7 @@ void set_qwen_graph(int on);               // qwen_engine.hip: replay the N-step
 void set_flux_two_stream(int mode);        // flux_engine.hip: the same for the FLUX.1 double blocks
 void set_flux_two_stream_rows(int rows);
 void set_flux_graph(int on);               // flux_engine.hip: replay the N-step loop of mi355_flux_rollout as one hipGraph (0 = default: eager)
+void set_wan_graph(int on);                // wan_engine.hip: the same for mi355_wan_rollout
 
 // per-head RMSNorm (weight, eps) + rotary embedding of the q and k projections (flux_ops.hip):
 //   src rows [M][src_ld]: q at column q_col + h*128, k at k_col + h*128 (bf16, bias already added);

@@ -50,6 +50,7 @@ struct mi355_wan {
     std::map<std::string, WSlot> slots;
     std::vector<std::string> names;
     bool derived_dirty = true;   // ln2_mod tables / score bounds need a rebuild after a (re)bind
+    int derived_ver = 0;         // bumped by every rebuild (the bounds are baked into a captured graph)
     std::vector<float> bound_self, bound_cross;
 
     bf16_t* a16(int64_t n) {
@@ -195,6 +196,12 @@ struct mi355_wan_plan {
     bf16_t *io_pe, *io_ne;
     std::vector<float> host_t, host_sc;
     int mod_cols;
+    // hipGraph of the N-step loop (opt-in, mi355_tune_set key 18): captured on a plan-owned stream on the second call of a configuration
+    hipGraphExec_t gexec = nullptr;
+    hipStream_t cap_stream = nullptr;
+    bool warmed = false;
+    int g_steps = -1, g_dyn = -1, g_storage = -1, g_init = -1, g_clp = -1, g_noise = -1, g_derived = -1, g_gemm = -1, g_attn = -1;
+    float g_sigma_max = 0.f, g_guidance = 0.f;
 };
 
 extern "C" int mi355_wan_plan_create(mi355_wan* e, int batch, int n_cfg, int latent_t, int latent_h, int latent_w, int n_text,
@@ -280,6 +287,8 @@ extern "C" int mi355_wan_plan_create(mi355_wan* e, int batch, int n_cfg, int lat
 
 extern "C" int mi355_wan_plan_destroy(mi355_wan_plan* p) {
     if (!p) return 0;
+    if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
+    if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     if (p->ws) (void)hipFree(p->ws);
     delete p;
     return 0;
@@ -312,6 +321,7 @@ int refresh_derived(mi355_wan* e, hipStream_t st) {
         e->bound_cross[i] = c * amax(e->blk[i].nq2) * amax(e->blk[i].nk2);
     }
     e->derived_dirty = false;
+    ++e->derived_ver;
     return 0;
 }
 
@@ -468,6 +478,13 @@ extern "C" int mi355_wan_forward(mi355_wan_plan* p, void* stream, const void* la
     return forward_core(p, st, latents, lat_dtype, p->mod_all, (bf16_t*)v_out);
 }
 
+// key 18: replay the N-step loop of mi355_wan_rollout as ONE hipGraph (OFF by default; written after round 2's GPU budget was spent): the
+// reference's Wan examples sample 240 x 240 x 5-frame clips at B = 1 (a few hundred tokens) -- launch-bound, like its FLUX.1 / Qwen examples.
+static int g_wan_graph = 0;
+namespace mi355 {
+void set_wan_graph(int on) { g_wan_graph = on; }
+}  // namespace mi355
+
 // the whole N-step loop; timesteps_host: the scheduler's (integer-valued) timesteps; sigma of a step = t / 1000
 // (scheduler/unipc_multistep.py:288-291); neg_embeds == NULL <=> the plan has n_cfg == 1.
 extern "C" int mi355_wan_rollout(mi355_wan_plan* p, void* stream, int n_steps, const float* timesteps_host, const float* sigmas_host,
@@ -508,27 +525,71 @@ extern "C" int mi355_wan_rollout(mi355_wan_plan* p, void* stream, int n_steps, c
     if (p->ncfg == 2) HIPCHK(hipMemcpyAsync(p->io_ne, neg_embeds, emb_bytes, hipMemcpyDeviceToDevice, st));
     const float sigma_max = sigmas_host[1];
     const int clp = compute_log_prob && out_log_probs;
-    if (p->ncfg == 2) CHK(prepare_prompt(p, st, p->io_ne, p->io_pe));
-    else CHK(prepare_prompt(p, st, p->io_pe, nullptr));
-    CHK(prepare_conditioning(p, st, n_steps));
     const size_t esz = storage_dtype == MI355_F32 ? 4 : 2;
     const size_t lat_bytes = (size_t)nl * esz;
-    HIPCHK(launch_convert(p->io_init, init_dtype, p->io_traj, storage_dtype, (long)nl, st));      // cast_latents(init)
-    for (int i = 0; i < n_steps; ++i) {
-        const bf16_t* mod = p->mod_all + (int64_t)i * Bp * p->mod_cols;
-        char* cur = p->io_traj + (size_t)i * lat_bytes;
-        char* nxt = p->io_traj + (size_t)(i + 1) * lat_bytes;
-        CHK(forward_core(p, st, cur, storage_dtype, mod, p->v));
-        SdeStepParams s;
-        memset(&s, 0, sizeof(s));
-        s.v_uncond = p->ncfg == 2 ? p->v : nullptr;
-        s.v_text = p->ncfg == 2 ? p->v + nl : p->v;
-        s.v_dt = DT_BF16; s.guidance = guidance; s.latents = cur; s.lat_dt = storage_dtype;
-        s.noise = step_noise ? p->io_noise + (int64_t)i * nl : nullptr;
-        s.sigma = p->scal + i; s.sigma_next = p->scal + p->max_steps + i; s.eta = p->scal + 2 * p->max_steps + i; s.scalar_stride = 0;
-        s.sigma_max = sigma_max; s.dynamics = dynamics; s.compute_log_prob = clp ? 2 : 0; s.B = B; s.n = p->n_lat;
-        s.next_out = nxt; s.next_out_dt = storage_dtype; s.log_prob = clp ? p->io_lp + (int64_t)i * B : nullptr;
-        HIPCHK(launch_sde_step(s, st));
+    // everything below reads / writes plan-owned buffers at fixed addresses (staged inputs, t_dev / scal, io_traj, io_lp)
+    auto body = [&](hipStream_t sx) -> int {
+        if (p->ncfg == 2) CHK(prepare_prompt(p, sx, p->io_ne, p->io_pe));
+        else CHK(prepare_prompt(p, sx, p->io_pe, nullptr));
+        CHK(prepare_conditioning(p, sx, n_steps));
+        HIPCHK(launch_convert(p->io_init, init_dtype, p->io_traj, storage_dtype, (long)nl, sx));      // cast_latents(init)
+        for (int i = 0; i < n_steps; ++i) {
+            const bf16_t* mod = p->mod_all + (int64_t)i * Bp * p->mod_cols;
+            char* cur = p->io_traj + (size_t)i * lat_bytes;
+            char* nxt = p->io_traj + (size_t)(i + 1) * lat_bytes;
+            CHK(forward_core(p, sx, cur, storage_dtype, mod, p->v));
+            SdeStepParams s;
+            memset(&s, 0, sizeof(s));
+            s.v_uncond = p->ncfg == 2 ? p->v : nullptr;
+            s.v_text = p->ncfg == 2 ? p->v + nl : p->v;
+            s.v_dt = DT_BF16; s.guidance = guidance; s.latents = cur; s.lat_dt = storage_dtype;
+            s.noise = step_noise ? p->io_noise + (int64_t)i * nl : nullptr;
+            s.sigma = p->scal + i; s.sigma_next = p->scal + p->max_steps + i; s.eta = p->scal + 2 * p->max_steps + i; s.scalar_stride = 0;
+            s.sigma_max = sigma_max; s.dynamics = dynamics; s.compute_log_prob = clp ? 2 : 0; s.B = B; s.n = p->n_lat;
+            s.next_out = nxt; s.next_out_dt = storage_dtype; s.log_prob = clp ? p->io_lp + (int64_t)i * B : nullptr;
+            HIPCHK(launch_sde_step(s, sx));
+        }
+        return 0;
+    };
+    bool launched = false;
+    if (g_wan_graph && p->warmed) {
+        const bool same = p->gexec && p->g_steps == n_steps && p->g_dyn == dynamics && p->g_storage == storage_dtype && p->g_init == init_dtype &&
+                          p->g_clp == clp && p->g_noise == (int)(step_noise != nullptr) && p->g_sigma_max == sigma_max && p->g_guidance == guidance &&
+                          p->g_derived == p->e->derived_ver && p->g_gemm == get_gemm_variant() && p->g_attn == get_attn128_variant();
+        if (!same) {
+            if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
+            hipGraph_t graph = nullptr;
+            hipError_t ce = hipSuccess;
+            if (!p->cap_stream) ce = hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking);
+            if (ce == hipSuccess) ce = hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed);
+            if (ce == hipSuccess) {
+                const int rc = body(p->cap_stream);             // nothing executes: launches / D2D copies become graph nodes
+                ce = hipStreamEndCapture(p->cap_stream, &graph);
+                if (rc != 0 || ce != hipSuccess || !graph) {
+                    if (graph) (void)hipGraphDestroy(graph);
+                    graph = nullptr;
+                }
+            }
+            if (graph) {
+                ce = hipGraphInstantiate(&p->gexec, graph, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(graph);
+                if (ce != hipSuccess) p->gexec = nullptr;
+            }
+            if (!p->gexec) {                                    // no silent fallback: the caller chooses eager launches with key 18 = 0
+                const hipError_t last = hipGetLastError();
+                return errorf("mi355_wan_rollout: hipGraph capture / instantiation of the %d-step loop failed (%s); mi355_tune_set(18, 0) "
+                              "selects eager launches", n_steps, hipGetErrorString(ce != hipSuccess ? ce : last));
+            }
+            p->g_steps = n_steps; p->g_dyn = dynamics; p->g_storage = storage_dtype; p->g_init = init_dtype; p->g_clp = clp;
+            p->g_noise = (int)(step_noise != nullptr); p->g_sigma_max = sigma_max; p->g_guidance = guidance; p->g_derived = p->e->derived_ver;
+            p->g_gemm = get_gemm_variant(); p->g_attn = get_attn128_variant();
+        }
+        HIPCHK(hipGraphLaunch(p->gexec, st));
+        launched = true;
+    }
+    if (!launched) {
+        CHK(body(st));
+        p->warmed = true;
     }
     if (keep_slot_host && out_latents)
         for (int i = 0; i <= n_steps; ++i)

@@ -396,6 +396,7 @@ int mi355_profile_enable(int on);
  *  16     FLUX.1 engine: 1 = mi355_flux_rollout replays its N-step loop as one hipGraph (captured on the second call of a configuration,
  *         like key 2 for the SD3.5 engine); 0 (default) = eager launches.  A failed capture is an error, not a fallback.  Opt-in until measured.
  *  17     the same for mi355_qwen_rollout (the prompt preparation, which uploads the per-sample key lengths, stays in front of the graph).
+ *  18     the same for mi355_wan_rollout.
  * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);

@@ -1,5 +1,6 @@
 # First GPU call of round 3 (everything here was written after round 2's GPU budget was spent and has NOT run on an MI355X yet):
-#   1. the gated checks (tests/test_gpu_next_round.py): SD3.5-large width forward vs the oracle; bench.py's small-batch legs
+#   1. the gated checks (tests/test_gpu_next_round.py): SD3.5-large width forward vs the oracle; bench.py's small-batch legs; two-stream /
+#      graph-replay bit-identity for FLUX.1, Qwen-Image, Wan; attention variant 3
 #   2. the delivered-clock probe beside the hot kernels (scripts/clock_under_load.py) -> which kernel still has headroom at ITS clock
 #   3. the whole -m gpu suite at HEAD
 #   4. A/B of the Qwen-Image (keys 12, 17) and FLUX.1 (keys 14, 16) two-stream forwards and graph-replayed rollouts

@@ -248,3 +248,43 @@ def test_attention_row_sums_on_the_matrix_pipe_match_fp32(B, H, S, n_img):
         rel = float((got - ref).norm() / ref.norm())
         assert torch.isfinite(got).all() and rel < 6e-3, (var, rel)
     assert float((outs[3] - outs[1]).abs().max()) <= 2.0 ** -6 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("guidance", [1.0, 5.0])
+def test_wan_graph_replay_is_bit_identical(guidance):
+    """Wan engine with the N-step loop replayed as one hipGraph (mi355_tune_set key 18 = 1; default 0): rollouts (latents, log-probs) with
+    and without CFG equal the eager results bit for bit over warm-up / capture / replay, a replay sees new prompts, and a changed step
+    count re-captures."""
+    from mi355_flow import _lib, wan as wn
+    from oracle import wan_ref as R
+    lib = _lib.load()
+    cfg_o = R.tiny_config()
+    sd = {k: v.bfloat16().float() for k, v in R.make_synthetic_state_dict(cfg_o, 12).items()}
+    cfg = wn.WanConfig(num_layers=cfg_o.num_layers, num_attention_heads=cfg_o.num_attention_heads, ffn_dim=cfg_o.ffn_dim, text_dim=cfg_o.text_dim)
+    B, Nt = 2, 12
+    g = torch.Generator().manual_seed(4)
+    pes = [torch.randn(B, Nt, cfg_o.text_dim, generator=g).bfloat16().cuda() for _ in range(2)]
+    ne = torch.randn(B, Nt, cfg_o.text_dim, generator=g).bfloat16().cuda()
+    res = {}
+    try:
+        for mode in (0, 1):
+            lib.mi355_tune_set(18, mode)
+            sched = wn.UniPCMultistepSDEScheduler(flow_shift=3.0, noise_level=0.7, sde_steps=[0, 1, 2, 3], num_sde_steps=2, seed=42,
+                                                  dynamics_type="Flow-SDE")
+            ad = wn.Wan2T2VNativeAdapter({k: v.cuda() for k, v in sd.items()}, cfg, sched, latent_storage_dtype="fp16")
+            ad.rollout()
+            runs = []
+            for pe, N in ((pes[0], 5), (pes[0], 5), (pes[0], 5), (pes[1], 5), (pes[0], 4)):
+                torch.cuda.manual_seed(31)
+                s = ad.inference(prompt=["a", "b"], height=64, width=96, num_frames=9, num_inference_steps=N, guidance_scale=guidance,
+                                 prompt_embeds=pe, negative_prompt_embeds=ne if guidance > 1.0 else None, compute_log_prob=True,
+                                 trajectory_indices="all")
+                runs.append((torch.stack([o.all_latents for o in s]).clone(), torch.stack([o.log_probs for o in s]).clone()))
+            assert all(torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]) for r in runs[1:3]), mode
+            assert not torch.equal(runs[3][0], runs[0][0])                    # other prompts: other trajectory
+            res[mode] = runs
+            ad.engine.close()
+        for a, b in zip(res[0], res[1]):
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    finally:
+        lib.mi355_tune_set(18, 0)
