@@ -25,3 +25,7 @@ cat $OUT/qwen_two_stream_ab.txt
 # FLUX.1 double blocks two-stream (key 14) and hipGraph replay of the loop (key 16), both opt-in: the reference's example shapes (B = 1 at 384^2, B = 2 at 512^2) and the bench shapes
 timeout 400 python scripts/flux_bench.py --denoise-steps 4 --iters 2 --ab-two-stream 1x384,2x512,1x1024,2x1024,8x1024 2>&1 | grep '^{' > $OUT/flux_two_stream_ab.txt; echo "flux ab rc=$?" >> $OUT/status
 cat $OUT/flux_two_stream_ab.txt
+# Wan2.1-1.3B: hipGraph replay of the loop (key 18) at the reference's example shape (240 x 240 x 5 frames, B = 1, CFG 5) and a mid-size clip
+timeout 200 python scripts/wan_bench.py --batch 1 --height 240 --width 240 --frames 5 --denoise-steps 10 --iters 3 --ab-graph 2>&1 | grep '^{' > $OUT/wan_graph_ab.txt
+timeout 200 python scripts/wan_bench.py --batch 1 --height 480 --width 832 --frames 17 --denoise-steps 4 --iters 2 --ab-graph 2>&1 | grep '^{' >> $OUT/wan_graph_ab.txt; echo "wan ab rc=$?" >> $OUT/status
+cat $OUT/wan_graph_ab.txt
