@@ -191,3 +191,101 @@ def test_the_checker_sees_every_edge_that_is_needed(family, missing):
         else:
             flux_forward(s, L=3, LS=2, two=True, tag=f"f{f}", skip=(missing,))
     assert s.races() != []
+
+
+def sd3_forward(s, L, dual, two, late, three, tag, skip=()):
+    """csrc/engine.hip forward_core (the SHIPPED default is two = True; `late` above 16 384 image rows; `three` is opt-in): image chain on
+    'st', text chain on 'ts', the image V^T / dual-attention projections on 'vs' in the three-stream variant.  `dual` = indices of the
+    dual-attention blocks; the last block has no text out-projection / MLP (context_pre_only)."""
+    st = "st"
+    ts = "side" if two else "st"
+    three = three and two
+    vs = "side_v" if three else "st"
+    s.launch(st, f"{tag}:patch_embed", ["lat", "w", "pe"], ["patches", "x"])
+    s.launch(st, f"{tag}:c<-c0", ["c0"], ["c"])
+    if two and "fork_start" not in skip:
+        s.record(f"{tag}:fork[L]", st)
+        s.wait(ts, f"{tag}:fork[L]")
+    text_open = False
+    for i in range(L):
+        last, is_dual = i == L - 1, i in dual
+        s.launch(st, f"{tag}:{i}:ln_x", ["x", "mod"], ["xn"] + (["xn2"] if is_dual else []))
+        s.launch(ts, f"{tag}:{i}:ln_c", ["c", "mod"], ["cn"])
+        if three:
+            s.record(f"{tag}:vfork[{i}]", st)
+            s.wait(vs, f"{tag}:vfork[{i}]")
+        s.launch(st, f"{tag}:{i}:qk_x", ["xn", "w"], ["q.img", "k.img"])
+        s.launch(vs, f"{tag}:{i}:vT_x", ["xn", "w"], ["vT.img"])
+        s.launch(ts, f"{tag}:{i}:qk_c", ["cn", "w"], ["q.txt", "k.txt"])
+        s.launch(ts, f"{tag}:{i}:vT_c", ["cn", "w"], ["vT.txt"])
+        if three:
+            s.record(f"{tag}:vjoin[{i}]", vs)
+            s.wait(st, f"{tag}:vjoin[{i}]")
+            if is_dual:
+                s.launch(vs, f"{tag}:{i}:qk2", ["xn2", "w"], ["q2", "k2"])
+                s.launch(vs, f"{tag}:{i}:vT2", ["xn2", "w"], ["vT2"])
+                s.record(f"{tag}:djoin[{i}]", vs)
+        if two and "join" not in skip:
+            s.record(f"{tag}:join[{i}]", ts)
+            s.wait(st, f"{tag}:join[{i}]")
+            text_open = False
+        s.launch(st, f"{tag}:{i}:attn", ["q.img", "q.txt", "k.img", "k.txt", "vT.img", "vT.txt"], ["o_img", "o_ctx"])
+        fork_here = two and (not last or i + 1 < L)
+
+        def fork():
+            nonlocal text_open
+            if "fork" not in skip:
+                s.record(f"{tag}:fork[{i}]", st)
+                s.wait(ts, f"{tag}:fork[{i}]")
+            text_open = True
+        is_late = is_dual and late
+        if fork_here and not is_late:
+            fork()
+        s.launch(st, f"{tag}:{i}:out_x", ["o_img", "w", "mod", "x"], ["x"])
+        if not two and not last:
+            s.launch(st, f"{tag}:{i}:out_c", ["o_ctx", "w", "mod", "c"], ["c"])
+        if is_dual:
+            if three:
+                s.wait(st, f"{tag}:djoin[{i}]")
+            else:
+                s.launch(st, f"{tag}:{i}:qk2", ["xn2", "w"], ["q2", "k2"])
+                s.launch(st, f"{tag}:{i}:vT2", ["xn2", "w"], ["vT2"])
+            s.launch(st, f"{tag}:{i}:attn2", ["q2", "k2", "vT2"], ["o_img"])          # S == n_img: never writes o_ctx
+            if fork_here and is_late:
+                fork()
+            s.launch(st, f"{tag}:{i}:out2_x", ["o_img", "w", "mod", "x"], ["x"])
+        if two and not last:
+            s.launch(ts, f"{tag}:{i}:out_c", ["o_ctx", "w", "mod", "c"], ["c"])
+        s.launch(st, f"{tag}:{i}:ln2_x", ["x", "mod"], ["xn"])
+        s.launch(st, f"{tag}:{i}:ff1_x", ["xn", "w"], ["hid"])
+        s.launch(st, f"{tag}:{i}:ff2_x", ["hid", "w", "mod", "x"], ["x"])
+        if not last:
+            s.launch(ts, f"{tag}:{i}:ln2_c", ["c", "mod"], ["cn"])
+            s.launch(ts, f"{tag}:{i}:ff1_c", ["cn", "w"], ["chid"])
+            s.launch(ts, f"{tag}:{i}:ff2_c", ["chid", "w", "mod", "c"], ["c"])
+    if two and text_open and "join_end" not in skip:
+        s.record(f"{tag}:join[L]", ts)
+        s.wait(st, f"{tag}:join[L]")
+    s.launch(st, f"{tag}:ln_out", ["x", "mod"], ["xn"])
+    s.launch(st, f"{tag}:proj_out", ["xn", "w"], ["v"])
+    s.launch(st, f"{tag}:cfg+sde", ["v", "lat"], ["lat"])
+
+
+@pytest.mark.parametrize("two,late,three", [(False, False, False), (True, False, False), (True, True, False), (True, False, True), (True, True, True)])
+def test_sd3_schedule_has_no_race(two, late, three):
+    """The SHIPPED SD3.5 schedule (bit-identity was measured on the GPU, which cannot prove the absence of a race): single stream, two
+    streams with the early / late fork, and the opt-in three-stream variant -- 4 blocks, the first two with dual attention, two forwards."""
+    s = Sched()
+    _prepare(s)
+    for f in range(2):
+        sd3_forward(s, L=4, dual=(0, 1), two=two, late=late, three=three, tag=f"f{f}")
+    assert s.races() == []
+
+
+@pytest.mark.parametrize("missing", ["fork_start", "join", "fork"])
+def test_sd3_checker_sensitivity(missing):
+    s = Sched()
+    _prepare(s)
+    for f in range(2):
+        sd3_forward(s, L=4, dual=(0, 1), two=True, late=True, three=False, tag=f"f{f}", skip=(missing,))
+    assert s.races() != []
