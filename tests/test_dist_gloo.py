@@ -397,3 +397,81 @@ def test_fsdp2_sharded_parameters_receive_averaged_gradients_from_the_engine_aut
     for r in range(2):
         ok, n_sig, n_sharded = np.load(tmp_path / f"fsdpgrad_{r}.npy").tolist()
         assert ok == 1 and n_sig >= 4 and n_sharded > 0, (r, ok, n_sig, n_sharded)
+
+
+def _fsdp2_lora_worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    from torch.distributed.device_mesh import init_device_mesh
+    from torch.distributed.fsdp import fully_shard
+    import _plugin_fakes as F
+    from mi355_flow import autograd as AG
+    from mi355_flow.binding import LiveWeights
+    from mi355_flow.engine import TransformerConfig
+    from mi355_flow.weights import expected_shapes
+    tcfg = TransformerConfig(num_layers=2, num_heads=1, joint_attention_dim=64, pooled_projection_dim=64, pos_embed_max_size=8, dual_layers=(0,))
+
+    def build():
+        m = F.build_module_tree(expected_shapes(tcfg), seed=3)
+        F.wrap_lora(m)
+        for n, p_ in m.named_parameters():
+            p_.requires_grad_("lora_" in n)
+        return m
+    mod, twin = build(), build()                                            # twin: the same model, unsharded, for the expected gradients
+    mesh = init_device_mesh("cpu", (world,))
+    for blk in mod.transformer_blocks.children():
+        fully_shard(blk, mesh=mesh)
+    fully_shard(mod, mesh=mesh)
+
+    def run(m):
+        eng = F.DiffFakeEngine(tcfg)
+        host = types.SimpleNamespace(engine=eng, _live_weights=LiveWeights(eng, lambda: m))
+        host._sync_weights = host._live_weights.sync
+        assert AG.unsupported_reason(host) is None
+        plan = eng.plan(2, 1, 8, 8, 5, 4)
+        return host, plan
+
+    def loss_of(host, plan, r):
+        g = torch.Generator().manual_seed(10 + r)
+        lat = torch.randn(2, 16, 8, 8, generator=g).half()
+        call = dict(latents=lat, timestep=torch.tensor([500.0, 500.0]), enc_a=torch.zeros(2, 5, 64), pooled_a=torch.zeros(2, 64), enc_b=None,
+                    pooled_b=None, guidance=1.0, sigma=0.5, sigma_next=0.4, eta=0.7, sigma_max=0.98, dynamics="Flow-SDE",
+                    next_latents=lat, compute_log_prob=True)
+        lp = AG.denoise_replay(host, plan, call)[0]
+        return (torch.tensor([1.0, -3.0]) * (r + 1) * lp).sum()
+
+    host, plan = run(mod)
+    loss_of(host, plan, rank).backward()                                    # this rank's micro-batch on the SHARDED model
+    thost, tplan = run(twin)
+    for r in range(world):                                                  # every rank's micro-batch on the unsharded twin: the mean is expected
+        (loss_of(thost, tplan, r) / world).backward()
+    ok, n = True, 0
+    want = dict(twin.named_parameters())
+    for name, p_ in mod.named_parameters():
+        if not p_.requires_grad:
+            ok = ok and p_.grad is None
+            continue
+        gfull = p_.grad.full_tensor()
+        ok = ok and type(p_.grad).__name__ == "DTensor" and bool(torch.allclose(gfull, want[name].grad, rtol=1e-5, atol=1e-9))
+        n += int(float(want[name].grad.abs().max()) > 0)
+    np.save(os.path.join(out_dir, f"fsdplora_{rank}.npy"), np.array([int(ok), n]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_fsdp2_sharded_lora_factors_receive_averaged_gradients(tmp_path):
+    """LoRA under FSDP2: the A / B factors are sharded DTensors whose VALUES enter the merged weight, so they are gathered with autograd
+    (`full_tensor(grad_placements=[Partial("avg")])`): on 2 ranks with different micro-batches every factor's gradient equals the mean of
+    the per-rank gradients computed on an unsharded twin of the model; the frozen base weights get none."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    mp.spawn(_fsdp2_lora_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        ok, n = np.load(tmp_path / f"fsdplora_{r}.npy").tolist()
+        assert ok == 1 and n >= 4, (r, ok, n)
