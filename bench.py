@@ -165,7 +165,9 @@ def main():
     ap.add_argument("--model", choices=["sd3_5", "flux1"], default="sd3_5",
                     help="sd3_5 = BASELINE.json configs[1] (the metric's config); flux1 = FLUX.1-dev geometry (configs[2], SURVEY 8(f) N3)")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed w.r.t. `value`) VAE-decode leg")
-    ap.add_argument("--no-small-batch", action="store_true", help="skip the (untimed w.r.t. `value`) small-batch legs")
+    ap.add_argument("--small-batch", action="store_true",
+                    help="also run the (untimed w.r.t. `value`) small-batch legs: B = 2 at 1024^2 and the reference's 512^2 B = 2 CFG example shape "
+                         "(opt-in until they have run on the GPU once: tests/test_gpu_next_round.py)")
     ap.add_argument("--no-graph", action="store_true", help="launch the rollout eagerly instead of replaying the hipGraph")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test without a GPU: gloo backend, the rollout replaced by a fixed sleep per micro-batch "
@@ -382,7 +384,7 @@ def main():
         out["graph_vs_eager"] = {"graph_ms_per_rollout": round(g_s * 1e3, 2), "eager_ms_per_rollout": round(e_s * 1e3, 2),
                                  "graph_denoise_steps_per_s": round(B * N / g_s, 3), "eager_denoise_steps_per_s": round(B * N / e_s, 3),
                                  "note": "untimed w.r.t. `value`; one hipGraph launch replays the whole N-step loop (~7 850 kernels)"}
-    if rank == 0 and world == 1 and not flux_mode and not args.no_small_batch:
+    if rank == 0 and world == 1 and not flux_mode and args.small_batch:
         # Small-batch configurations of the same engine (hipGraph replay; the text-stream chain of every block on a second stream): the
         # reference's own example shape (examples/grpo/full/sd3_5: 512^2, N = 10, B = 2 with CFG) and B = 2 at the bench resolution.
         # Reported beside the metric, never inside `value`; a failure here is recorded, not raised.
