@@ -1,5 +1,5 @@
 """GPU checks written while no GPU time was left in the round: NOT yet run on an MI355X, therefore kept out of the
-driver's `-m gpu` run (every test here is skipped unless `MI355_NEXT=1`).  First thing to run on the next box:
+driver's `-m gpu` run (every test here is DESELECTED unless `MI355_NEXT=1`: tests/conftest.py).  First thing to run on the next box:
 
     MI355_NEXT=1 python -m pytest tests/test_gpu_next_round.py -x -q
 
@@ -10,7 +10,7 @@ import os
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("MI355_NEXT") != "1", reason="unverified on the GPU: set MI355_NEXT=1")]
+pytestmark = [pytest.mark.gpu, pytest.mark.gpu_next]          # gpu_next: deselected unless MI355_NEXT=1 (tests/conftest.py)
 
 
 def _rel(a, b):
