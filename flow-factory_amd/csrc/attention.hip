@@ -48,10 +48,10 @@ int g_attn_variant = 1;
 // LSE: also write the per-query log-sum-exp (training-mode forward).  A template parameter, not a runtime test of p.lse: the dynamic
 // 8-wave kernel sits at its 128-VGPR / ~102-SGPR budget, and keeping the extra pointer and row index live across the key loop spilled
 // 14 VGPRs to scratch (measured in round 2: 1046 -> 911 TFLOP/s) -- the rollout instantiations must not pay for the training output.
-// MSUM (A/B variant 3, not yet run on the GPU): the softmax row sums come out of the matrix pipe -- one more MFMA per 16-key step with an
-// all-ones A operand (every row of its 32x32 result is sum_k P[k][q]) instead of 16 v_dot2c + adds per tile on the VALU port, which is the
-// port that bounds this kernel (32 quarter-rate v_exp per 16 MFMA: profiles/r01_mfma_valu_mix_microbench.txt).
-template <bool V2, int NWAVE, bool STATIC = false, bool LSE = false, bool MSUM = false>
+// (Measured and dropped in round 3, profiles/r03a_attn_ab_variants.txt: row sums on the matrix pipe -- one more MFMA per 16-key step with an
+// all-ones A operand instead of the 16 v_dot2c per tile -- 998 vs 1029 TFLOP/s at S = 4429, 1028 vs 1094 at S = 4096: the fifth MFMA per
+// step costs more matrix-pipe time than the dot2s cost on the VALU port.)
+template <bool V2, int NWAVE, bool STATIC = false, bool LSE = false>
 __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
     constexpr int QB = QW * NWAVE;  // queries per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -220,9 +220,6 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
     constexpr float THR = 6.0f;
     float m_run = 0.f;
     f32x16 negm = (f32x16){0};
-    f32x16 lsum = (f32x16){0};          // MSUM: every register = this lane's query's partial row sum (16-key steps of its half-wave)
-    typedef __attribute__((ext_vector_type(4))) unsigned ones_u32x4;
-    const bf16x8 ones = __builtin_bit_cast(bf16x8, (ones_u32x4){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
     // a wave whose 32 queries all lie beyond S (tail of the last query block: 179 of its 256 rows at S = 4429) only helps staging
     const bool wave_active = (qblk * QB + wave * QW) < p.S;
     for (int t = 0; t < nt; ++t) {
@@ -278,10 +275,6 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) negm[r] = -m_run;
             l_run *= alpha;
-            if constexpr (MSUM) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) lsum[r] *= alpha;
-            }
 #pragma unroll
             for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -299,11 +292,10 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
                 const float p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
                 const unsigned u = pack_bf16(p0, p1);
                 pk[kb][r >> 1] = u;
-                if constexpr (!MSUM)
-                    ps[(r >> 1) & 3] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2, u), __builtin_bit_cast(bf16v2, 0x3f803f80u),
-                                                                       ps[(r >> 1) & 3], false);
+                ps[(r >> 1) & 3] = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16v2, u), __builtin_bit_cast(bf16v2, 0x3f803f80u),
+                                                                   ps[(r >> 1) & 3], false);
             }
-        if constexpr (!MSUM) l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int kb = c >> 1, sh = (c & 1) * 4;
@@ -315,12 +307,8 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
                 const bf16x8 vf = *(const bf16x8*)(sb + offV[c] + db * 4096);
                 o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
             }
-            if constexpr (MSUM) lsum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lsum, 0, 0, 0);
         }
     }
-    // MSUM: an all-ones A operand sums over ALL 16 keys of the step (both half-waves' 8), so register 0 already holds the whole row sum
-    // of this lane's query; the xor-32 exchange of the finalisation must not double it
-    if constexpr (MSUM) l_run = 0.5f * lsum[0];
     m_fin = m_run;
     }
 
@@ -369,15 +357,15 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
 void set_attn_variant(int v) { g_attn_variant = v; }
 int get_attn_variant() { return g_attn_variant; }
 
-template <bool V2, int NWAVE, bool STATIC, bool MSUM = false>
+template <bool V2, int NWAVE, bool STATIC>
 static void launch_variant(const AttnParams& p, hipStream_t stream) {
     const dim3 grid(((p.S + QW * NWAVE - 1) / (QW * NWAVE)) * p.H * p.B), block(NWAVE * 64);
     // Two instantiations of one source may round differently (hipcc contracts / packs fp ops per instantiation: seen on the fused
     // RMSNorm epilogue, gemm.hip), and rollout vs training-mode forward must agree bit for bit.  The deferred-rescale kernels are checked
     // for that on the GPU (tests/test_gpu_backward.py::test_train_forward_is_bit_identical_at_full_width); the plain kernel (A/B variant 0,
     // not performance-critical) simply always runs its LSE build.
-    if (p.lse || !V2) hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, true, MSUM>), grid, block, 2 * STAGE_BYTES, stream, p);
-    else hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, false, MSUM>), grid, block, 2 * STAGE_BYTES, stream, p);
+    if (p.lse || !V2) hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, true>), grid, block, 2 * STAGE_BYTES, stream, p);
+    else hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, false>), grid, block, 2 * STAGE_BYTES, stream, p);
 }
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
@@ -386,10 +374,6 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (g_attn_variant == 0) launch_variant<false, 8, false>(p, stream);
     else if (g_attn_variant == 1) {
         if (stat) launch_variant<true, 8, true>(p, stream);
-        else launch_variant<true, 8, false>(p, stream);
-    } else if (g_attn_variant == 3) {
-        // row sums on the matrix pipe (MSUM), static-bound softmax only (the running-max kernel has no registers to spare); else variant 1
-        if (stat) launch_variant<true, 8, true, true>(p, stream);
         else launch_variant<true, 8, false>(p, stream);
     } else {
         // 4-wave workgroups (128 queries): twice the workgroups at half the size (A/B: profiles/r02_small_batch_attention_ab.txt)

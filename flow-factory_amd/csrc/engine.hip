@@ -988,7 +988,6 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 15) { set_flux_two_stream_rows(value); return 0; }
     if (key == 16) { set_flux_graph(value); return 0; }        // FLUX.1 engine: hipGraph replay of the rollout loop (0 = default: eager)
     if (key == 17) { set_qwen_graph(value); return 0; }        // Qwen-Image engine: the same
-    if (key == 18) { set_wan_graph(value); return 0; }         // Wan engine: the same
     return fail("mi355_tune_set: unknown key %d", key);
 }
 
@@ -1000,14 +999,6 @@ extern "C" int mi355_op_linear(void* stream, const void* A, const void* W, const
     GemmParams g = gp((const bf16_t*)A, K, (const bf16_t*)W, K, M, N, K, act == 1 ? EPI_BIAS_SILU : act == 2 ? EPI_BIAS_GELU : EPI_BIAS,
                       bias, (bf16_t*)out, N);
     HIPCHK(gemm_p(g, (hipStream_t)stream));
-    return 0;
-}
-
-// A/B candidate for the GEMM main loop (gemm_w4.hip; not on the rollout path): bias epilogue only
-extern "C" int mi355_op_linear_w4(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K) {
-    if (!A || !W || !bias || !out) return fail("mi355_op_linear_w4: null argument");
-    if (M % 256 || N % 256 || K % 64) return fail("mi355_op_linear_w4: M %% 256, N %% 256 and K %% 64 must be 0");
-    HIPCHK(launch_gemm_w4((const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)out, M, N, K, (hipStream_t)stream));
     return 0;
 }
 

@@ -465,18 +465,20 @@ int attention(mi355_flux_plan* p, hipStream_t st, bf16_t* o_first, long ld_first
 
 // one transformer forward: packed latents (storage dtype) -> packed velocity v_out [B][Ni][C] bf16.  `mod` = this step's
 // rows of mod_all; c0 / conditioning prepared.
-// Two-stream double blocks (tune key 14; OFF by default -- written after round 2's GPU budget was spent, to be A/B-ed in round 3): as in the
+// Two-stream double blocks (tune key 14; ON by default for plans of up to 16 384 image rows since round 3): as in the
 // SD3.5 and Qwen-Image engines, the text chain of a double block runs on a plan-owned side stream beside the image chain (the reference's
 // own FLUX.1 examples sample at B = 1-2 and 384^2 / 512^2: 576-1024 image tokens next to 512 text tokens, every grid a fraction of the
 // chip).  Join before the joint attention, fork after it, last join before the two streams are concatenated for the single blocks.
-// Bit-identical to the single-stream order.
-int g_flux_two_stream = 0;          // 0 off, 1 on, 2 on for plans with at most g_flux_two_stream_rows image rows
+// Bit-identical to the single-stream order.  Measured on MI355X (profiles/r03a_flux_two_stream_ab.txt, hipGraph replay, denoise-steps/s single ->
+// two streams): 384^2 B = 1 30.9 -> 37.7 (+22 %), 512^2 B = 2 37.6 -> 39.8 (+6 %), 1024^2 B = 1 13.2 -> 13.9 (+5 %), B = 2 14.1 -> 14.5 (+3 %),
+// B = 8 15.39 -> 15.39 (32 768 rows: above the threshold, single stream).
+int g_flux_two_stream = 2;          // 0 off, 1 on, 2 (default) on for plans with at most g_flux_two_stream_rows image rows
 int g_flux_two_stream_rows = 16384;
 
-// key 16: replay the N-step loop of mi355_flux_rollout as ONE hipGraph (OFF by default -- also written after round 2's GPU budget was
-// spent): at the reference's example shapes (B = 1-2, 384^2 / 512^2) the ~700 launches of a forward are 5-15 us kernels and the loop is
-// bound by launch overhead; the SD3.5 engine's captured rollout is the model (engine.hip, key 2).
-int g_flux_graph = 0;
+// key 16: replay the N-step loop of mi355_flux_rollout as ONE hipGraph, like the SD3.5 engine's captured rollout (engine.hip, key 2).  ON by
+// default since round 3; measured bit-identical and +0.1 ... +0.8 % over eager launches at the reference's example shapes, +-0.1 % at
+// B = 8 (same file): the host keeps up with ~700 launches of 5-15 us, the graph mainly takes the CPU out of the loop.
+int g_flux_graph = 1;
 
 bool flux_two_stream_wanted(const mi355_flux_plan* p) {
     return g_flux_two_stream == 1 || (g_flux_two_stream == 2 && p->Mi <= g_flux_two_stream_rows);

@@ -75,8 +75,6 @@ struct GemmParams {
 };
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);
-// experimental 4-wave / 128x128-per-wave / 32x32x16-MFMA main loop (gemm_w4.hip): out = A . W^T + bias, M % 256 == N % 256 == K % 64 == 0
-hipError_t launch_gemm_w4(const bf16_t* A, const bf16_t* W, const float* bias, bf16_t* out, int M, int N, int K, hipStream_t stream);
 void set_gemm_variant(int v);
 int get_gemm_variant();
 void set_pp_min_tiles(int v);
@@ -120,7 +118,6 @@ void set_qwen_graph(int on);               // qwen_engine.hip: replay the N-step
 void set_flux_two_stream(int mode);        // flux_engine.hip: the same for the FLUX.1 double blocks
 void set_flux_two_stream_rows(int rows);
 void set_flux_graph(int on);               // flux_engine.hip: replay the N-step loop of mi355_flux_rollout as one hipGraph (0 = default: eager)
-void set_wan_graph(int on);                // wan_engine.hip: the same for mi355_wan_rollout
 
 // per-head RMSNorm (weight, eps) + rotary embedding of the q and k projections (flux_ops.hip):
 //   src rows [M][src_ld]: q at column q_col + h*128, k at k_col + h*128 (bf16, bias already added);

@@ -432,19 +432,21 @@ int gate_res(mi355_qwen_plan* p, hipStream_t st, const bf16_t* A, long lda, int 
 
 // one transformer forward over the FB = n_cfg * B samples: packed latents (storage dtype, B samples, replicated per CFG branch) ->
 // packed velocity v2 [FB][Ni][C] bf16.  `mod` = this call's first modulation row; c0 / kvlen prepared.
-// Two-stream forward (tune key 12; OFF by default -- written after round 2's GPU budget was spent, to be A/B-ed in round 3): the text
+// Two-stream forward (tune key 12; ON by default for plans of up to 16 384 image rows since round 3): the text
 // chain of a block (LN-modulate -> q|k|v projections ... out-projection -> LN-modulate -> MLP, M = FB * Nt rows: a fraction of a wave of
 // workgroups) runs on a plan-owned side stream beside the image chain, as in the SD3.5 engine (engine.hip, keys 8-10: +6 ... +31 % on
 // small forward batches).  Join before the joint attention (it reads the text rows of q / k / vT), fork after it (the text out-projection
 // reads o_ctx; the NEXT block's text projections overwrite the text rows of q / k / vT, so they must also come after this attention).
 // Results are bit-identical to the single-stream order: the kernels and their inputs are the same, only `qkbuf` / `big` are not shared.
-int g_qwen_two_stream = 0;          // 0 off, 1 on, 2 on for plans with at most g_qwen_two_stream_rows image rows
+// Measured on MI355X (profiles/r03a_qwen_two_stream_ab.txt, full 60-layer geometry, true CFG, s per 2-step rollout single -> two streams):
+// 512^2 B = 1 0.1191 -> 0.0785 (+52 %), 384^2 B = 1 0.1015 -> 0.0705 (+44 %), 1024^2 B = 2 0.5243 -> 0.5083 (+3 %).
+int g_qwen_two_stream = 2;          // 0 off, 1 on, 2 (default) on for plans with at most g_qwen_two_stream_rows image rows
 int g_qwen_two_stream_rows = 16384;
 
-// key 17: replay the N-step loop of mi355_qwen_rollout as ONE hipGraph (OFF by default; same status): 60 blocks x ~14 launches per forward,
-// 5-15 us each at the reference's example shapes (B = 1, 384^2 / 512^2), are bound by launch overhead.  The prompt preparation (it uploads
-// the per-sample key lengths from host memory) stays in front of the graph.
-int g_qwen_graph = 0;
+// key 17: replay the N-step loop of mi355_qwen_rollout as ONE hipGraph (ON by default since round 3: bit-identical, +0.9 % at 512^2 and +2 % at
+// 384^2 on top of the two-stream forward, +-0.1 % at 1024^2; same file).  The prompt preparation (it uploads the per-sample key lengths from
+// host memory) stays in front of the graph.
+int g_qwen_graph = 1;
 
 bool qwen_two_stream_wanted(const mi355_qwen_plan* p) {
     return g_qwen_two_stream == 1 || (g_qwen_two_stream == 2 && p->Mi <= g_qwen_two_stream_rows);

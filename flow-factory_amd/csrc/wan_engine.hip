@@ -196,12 +196,6 @@ struct mi355_wan_plan {
     bf16_t *io_pe, *io_ne;
     std::vector<float> host_t, host_sc;
     int mod_cols;
-    // hipGraph of the N-step loop (opt-in, mi355_tune_set key 18): captured on a plan-owned stream on the second call of a configuration
-    hipGraphExec_t gexec = nullptr;
-    hipStream_t cap_stream = nullptr;
-    bool warmed = false;
-    int g_steps = -1, g_dyn = -1, g_storage = -1, g_init = -1, g_clp = -1, g_noise = -1, g_derived = -1, g_gemm = -1, g_attn = -1;
-    float g_sigma_max = 0.f, g_guidance = 0.f;
 };
 
 extern "C" int mi355_wan_plan_create(mi355_wan* e, int batch, int n_cfg, int latent_t, int latent_h, int latent_w, int n_text,
@@ -287,8 +281,6 @@ extern "C" int mi355_wan_plan_create(mi355_wan* e, int batch, int n_cfg, int lat
 
 extern "C" int mi355_wan_plan_destroy(mi355_wan_plan* p) {
     if (!p) return 0;
-    if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
-    if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     if (p->ws) (void)hipFree(p->ws);
     delete p;
     return 0;
@@ -478,13 +470,10 @@ extern "C" int mi355_wan_forward(mi355_wan_plan* p, void* stream, const void* la
     return forward_core(p, st, latents, lat_dtype, p->mod_all, (bf16_t*)v_out);
 }
 
-// key 18: replay the N-step loop of mi355_wan_rollout as ONE hipGraph (OFF by default; written after round 2's GPU budget was spent): the
-// reference's Wan examples sample 240 x 240 x 5-frame clips at B = 1 (a few hundred tokens) -- launch-bound, like its FLUX.1 / Qwen examples.
-static int g_wan_graph = 0;
-namespace mi355 {
-void set_wan_graph(int on) { g_wan_graph = on; }
-}  // namespace mi355
-
+// The loop runs as eager launches: replaying it as ONE hipGraph (the SD3.5 / FLUX.1 / Qwen-Image engines do) was measured in round 3 at the
+// reference's example shape (240 x 240 x 5 frames, B = 1, CFG) and at 480 x 832 x 17 -- bit-identical, -0.1 % / -0.3 %
+// (profiles/r03a_wan_graph_ab.txt): even the smallest Wan clip is not launch-bound (per-step cross-attention K / V are cached, 30 blocks of
+// ~10 launches each).  Removed rather than kept as a dead option.
 // the whole N-step loop; timesteps_host: the scheduler's (integer-valued) timesteps; sigma of a step = t / 1000
 // (scheduler/unipc_multistep.py:288-291); neg_embeds == NULL <=> the plan has n_cfg == 1.
 extern "C" int mi355_wan_rollout(mi355_wan_plan* p, void* stream, int n_steps, const float* timesteps_host, const float* sigmas_host,
@@ -551,46 +540,7 @@ extern "C" int mi355_wan_rollout(mi355_wan_plan* p, void* stream, int n_steps, c
         }
         return 0;
     };
-    bool launched = false;
-    if (g_wan_graph && p->warmed) {
-        const bool same = p->gexec && p->g_steps == n_steps && p->g_dyn == dynamics && p->g_storage == storage_dtype && p->g_init == init_dtype &&
-                          p->g_clp == clp && p->g_noise == (int)(step_noise != nullptr) && p->g_sigma_max == sigma_max && p->g_guidance == guidance &&
-                          p->g_derived == p->e->derived_ver && p->g_gemm == get_gemm_variant() && p->g_attn == get_attn128_variant();
-        if (!same) {
-            if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
-            hipGraph_t graph = nullptr;
-            hipError_t ce = hipSuccess;
-            if (!p->cap_stream) ce = hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking);
-            if (ce == hipSuccess) ce = hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeRelaxed);
-            if (ce == hipSuccess) {
-                const int rc = body(p->cap_stream);             // nothing executes: launches / D2D copies become graph nodes
-                ce = hipStreamEndCapture(p->cap_stream, &graph);
-                if (rc != 0 || ce != hipSuccess || !graph) {
-                    if (graph) (void)hipGraphDestroy(graph);
-                    graph = nullptr;
-                }
-            }
-            if (graph) {
-                ce = hipGraphInstantiate(&p->gexec, graph, nullptr, nullptr, 0);
-                (void)hipGraphDestroy(graph);
-                if (ce != hipSuccess) p->gexec = nullptr;
-            }
-            if (!p->gexec) {                                    // no silent fallback: the caller chooses eager launches with key 18 = 0
-                const hipError_t last = hipGetLastError();
-                return errorf("mi355_wan_rollout: hipGraph capture / instantiation of the %d-step loop failed (%s); mi355_tune_set(18, 0) "
-                              "selects eager launches", n_steps, hipGetErrorString(ce != hipSuccess ? ce : last));
-            }
-            p->g_steps = n_steps; p->g_dyn = dynamics; p->g_storage = storage_dtype; p->g_init = init_dtype; p->g_clp = clp;
-            p->g_noise = (int)(step_noise != nullptr); p->g_sigma_max = sigma_max; p->g_guidance = guidance; p->g_derived = p->e->derived_ver;
-            p->g_gemm = get_gemm_variant(); p->g_attn = get_attn128_variant();
-        }
-        HIPCHK(hipGraphLaunch(p->gexec, st));
-        launched = true;
-    }
-    if (!launched) {
-        CHK(body(st));
-        p->warmed = true;
-    }
+    CHK(body(st));
     if (keep_slot_host && out_latents)
         for (int i = 0; i <= n_steps; ++i)
             if (keep_slot_host[i] >= 0)

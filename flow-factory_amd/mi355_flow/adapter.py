@@ -170,7 +170,7 @@ class NativeRolloutMixin:
 
         # collectors: exactly the reference's bookkeeping (sd3_5.py:265-304) over the engine outputs
         traj = collect_rollout(trajectory_indices, N, get_lat, log_probs, eta_host, compute_log_prob, step_outputs, extra_call_back_kwargs,
-                               captured_noise_levels=host_noise_levels(self.scheduler, N, effective=False))
+                               captured_noise_levels=host_noise_levels(self.scheduler, N, effective=False), dynamics=dyn)
         images = self.decode_latents(latents=final, output_type="pt")
         samples = []
         for b in range(B):

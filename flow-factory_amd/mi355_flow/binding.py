@@ -42,6 +42,19 @@ def unwrap_module(m):
     return m
 
 
+def _deepspeed_step(m):
+    """Optimizer-step counter of a DeepSpeedEngine wrapper anywhere in the wrapper chain (None without DeepSpeed).  `global_steps` advances
+    at every gradient-accumulation boundary (`DeepSpeedEngine._take_model_step`), i.e. whenever the parameters may have been rewritten."""
+    for _ in range(8):
+        if type(m).__name__ == "DeepSpeedEngine":
+            return (int(getattr(m, "global_steps", 0)), int(getattr(m, "skipped_steps", 0)))
+        nxt = getattr(m, "_orig_mod", None) or (getattr(m, "module", None) if type(m).__name__ in ("DistributedDataParallel",) else None)
+        if nxt is None:
+            return None
+        m = nxt
+    return None
+
+
 def _is_lora_layer(mod) -> bool:
     return hasattr(mod, "base_layer") and hasattr(mod, "lora_A") and hasattr(mod, "lora_B")
 
@@ -160,6 +173,7 @@ class LiveWeights:
         self._sources: Dict[str, object] = {}
         self._bound: Dict[str, object] = {}
         self.last_rebinds = 0
+        self._ds_step = None       # (global_steps, micro_steps of the last optimizer boundary) of a DeepSpeedEngine wrapper, if any
 
     def invalidate(self) -> None:
         self.epoch += 1
@@ -180,6 +194,13 @@ class LiveWeights:
     def sync(self) -> int:
         root = self.get_module()
         inner = unwrap_module(root)
+        # DeepSpeed ZeRO-1/2 and its BF16_Optimizer write updated parameters through `.data.copy_()` into views of a flat buffer: neither the
+        # storage pointer nor the version counter moves (reference config/deepspeed/*.yaml).  Its engine counts optimizer steps: a new count
+        # re-binds every trainable tensor.
+        step = _deepspeed_step(root)
+        if step != self._ds_step:
+            self._ds_step = step
+            self.invalidate()
         if self._root_ref is None or self._root_ref() is not inner:
             self._sources = resolve_sources(inner, self.engine.param_names(), partial=self.partial)
             self._root_ref = weakref.ref(inner)

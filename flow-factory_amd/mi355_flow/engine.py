@@ -98,6 +98,7 @@ class WeightHolder:
 
     _ABI = "engine"      # C symbol infix
     _WHAT = "transformer"
+    KEEPALIVE_FLUSH_BYTES = 1 << 30
 
     def _fn(self, suffix: str):
         return getattr(self.lib, f"mi355_{self._ABI}_{suffix}")
@@ -121,11 +122,17 @@ class WeightHolder:
                    f"{self._ABI}_bind_weight({name})")
         self._keepalive = getattr(self, "_keepalive", [])
         self._keepalive.append(t)
+        # temporaries (gathered FSDP2 shards, merged fp32 LoRA weights) must outlive their asynchronous conversion kernel, but not each
+        # other: drain every ~1 GiB so that a 41 GB model never sits next to a whole un-sharded copy of itself during a re-bind
+        self._keepalive_bytes = getattr(self, "_keepalive_bytes", 0) + t.numel() * t.element_size()
+        if self._keepalive_bytes >= self.KEEPALIVE_FLUSH_BYTES:
+            torch.cuda.current_stream().synchronize()
+            self._keepalive, self._keepalive_bytes = [], 0
 
     def finish_binding(self) -> None:
         # conversion kernels read the (possibly temporary) source tensors asynchronously
         torch.cuda.current_stream().synchronize()
-        self._keepalive = []
+        self._keepalive, self._keepalive_bytes = [], 0
 
     def bind_state_dict(self, state_dict: Dict[str, torch.Tensor], partial: bool = False, strict: Optional[bool] = None) -> None:
         """Copy / re-pack torch Parameters (HF names) into the engine.  Call again after every optimizer step, EMA swap or LoRA
@@ -160,6 +167,7 @@ class Engine(WeightHolder):
         _lib.check(self.lib.mi355_engine_create(C.byref(c), C.byref(h)), "engine_create")
         self._h = h
         self._plans: Dict[tuple, "Plan"] = {}
+        self.train_scope = False
 
     # ---------------------------------------------------------------- weight gradients (mi355_flow/autograd.py)
     def grad_supported(self, name: str) -> int:
@@ -168,6 +176,7 @@ class Engine(WeightHolder):
 
     def set_train_scope(self, full: bool) -> None:
         _lib.check(self.lib.mi355_engine_set_train_scope(self._h, int(bool(full))), "set_train_scope")
+        self.train_scope = bool(full)
 
     def set_grad(self, name: str, grad: torch.Tensor) -> None:
         """Register the fp32 buffer the next backward writes d loss / d `name` into (same shape as the parameter)."""
@@ -296,20 +305,36 @@ class Plan:
         enc_b = _bf16c(enc_b) if enc_b is not None else None
         pooled_b = _bf16c(pooled_b) if pooled_b is not None else None
         nxt = next_latents.contiguous()
-        _lib.check(self.lib.mi355_denoise_step_train(
-            self._h, _stream(), _ptr(latents), dtype_code(latents.dtype), _ptr(t), _ptr(enc_a), _ptr(pooled_a), _ptr(enc_b), _ptr(pooled_b),
-            float(guidance), _ptr(nxt), dtype_code(nxt.dtype), _ptr(sig), _ptr(sig_n), _ptr(et), stride, float(sigma_max),
-            DYNAMICS[dynamics], int(bool(compute_log_prob)), None, _ptr(outs.next_latents_mean), _ptr(outs.noise_pred),
-            _ptr(outs.log_prob), _ptr(outs.std_dev_t), _ptr(outs.dt)), "denoise_step_train")
+        k = dict(latents=latents, t=t, enc_a=enc_a, pooled_a=pooled_a, enc_b=enc_b, pooled_b=pooled_b, nxt=nxt, sig=sig, sig_n=sig_n, et=et,
+                 stride=stride, guidance=float(guidance), sigma_max=float(sigma_max), dynamics=DYNAMICS[dynamics],
+                 clp=int(bool(compute_log_prob)), scope=self.engine.train_scope)
+        self._train_forward(k, outs)
         if _keep is not None:
-            _keep.update(latents=latents, nxt=nxt, sig=sig, sig_n=sig_n, et=et, stride=stride, guidance=float(guidance),
-                         sigma_max=float(sigma_max), dynamics=DYNAMICS[dynamics], clp=int(bool(compute_log_prob)))
+            _keep.update(k)
         return outs
+
+    def _train_forward(self, k: dict, outs) -> None:
+        """One launch of mi355_denoise_step_train on prepared tensors.  The plan owns ONE activation stash (per-block buffers, modulation
+        rows, LSE, ...), overwritten by every training forward: each forward takes a serial number that the matching backward checks."""
+        _lib.check(self.lib.mi355_denoise_step_train(
+            self._h, _stream(), _ptr(k["latents"]), dtype_code(k["latents"].dtype), _ptr(k["t"]), _ptr(k["enc_a"]), _ptr(k["pooled_a"]),
+            _ptr(k["enc_b"]), _ptr(k["pooled_b"]), k["guidance"], _ptr(k["nxt"]), dtype_code(k["nxt"].dtype), _ptr(k["sig"]), _ptr(k["sig_n"]),
+            _ptr(k["et"]), k["stride"], k["sigma_max"], k["dynamics"], k["clp"], None, _ptr(outs.next_latents_mean), _ptr(outs.noise_pred),
+            _ptr(outs.log_prob), _ptr(outs.std_dev_t), _ptr(outs.dt)), "denoise_step_train")
+        self._train_serial = getattr(self, "_train_serial", 0) + 1
+        k["serial"] = self._train_serial
 
     def denoise_step_backward(self, call: dict, g_log_prob, g_noise_pred, g_mean) -> None:
         """mi355_denoise_step_backward for the step recorded in `call['_keep']`; gradients go to the buffers registered with
         `Engine.set_grad`."""
         k = call["_keep"]
+        if k["serial"] != getattr(self, "_train_serial", 0):
+            # another training forward ran on this plan since (DPO's chosen / rejected pair, trainers/dpo.py:587-588; any loss that sums
+            # several grad forwards before one backward): the stash holds ITS activations.  Re-run this step's forward on the kept
+            # inputs -- same kernels, same weights (the caller re-bound them), bit-identical stash -- then differentiate it.
+            self.engine.set_train_scope(k["scope"])
+            self.recomputed_forwards = getattr(self, "recomputed_forwards", 0) + 1
+            self._train_forward(k, _StepOutputs(self.batch, k["latents"], ("next_latents_mean", "noise_pred", "std_dev_t", "dt"), True))
         f32 = lambda g: None if g is None else g.to(torch.float32).contiguous()
         g_lp, g_np, g_mn = f32(g_log_prob), f32(g_noise_pred), f32(g_mean)
         _lib.check(self.lib.mi355_denoise_step_backward(
@@ -428,38 +453,4 @@ def op_linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, act: int = 0
     N = w.shape[0]
     out = torch.empty((M, N), device=x.device, dtype=torch.bfloat16)
     _lib.check(lib.mi355_op_linear(_stream(), _ptr(x), _ptr(w), _ptr(bias), _ptr(out), M, N, K, act), "op_linear")
-    return out
-
-
-def op_linear_w4(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
-    """A/B candidate for the GEMM main loop (csrc/gemm_w4.hip; unit tests / microbenchmarks only): x @ w.T + bias."""
-    lib = _lib.load()
-    x, w = _bf16c(x), _bf16c(w)
-    bias = bias.to(torch.float32).contiguous()
-    M, K = x.shape
-    N = w.shape[0]
-    out = torch.empty((M, N), device=x.device, dtype=torch.bfloat16)
-    _lib.check(lib.mi355_op_linear_w4(_stream(), _ptr(x), _ptr(w), _ptr(bias), _ptr(out), M, N, K), "op_linear_w4")
-    return out
-
-
-def op_attention(q: torch.Tensor, k: torch.Tensor, vT: torch.Tensor, S: int, n_img: int):
-    """q,k: [B,H,S_pad,64] bf16; vT: [B,H,64,S_pad] bf16 -> (o_img [B*n_img, H*64], o_ctx [B*(S-n_img), H*64])."""
-    lib = _lib.load()
-    B, H, S_pad, hd = q.shape
-    assert hd == 64 and vT.shape == (B, H, 64, S_pad)
-    o_img = torch.empty((B * n_img, H * 64), device=q.device, dtype=torch.bfloat16)
-    o_ctx = torch.empty((max(B * (S - n_img), 1), H * 64), device=q.device, dtype=torch.bfloat16)
-    _lib.check(lib.mi355_op_attention(_stream(), _ptr(q.contiguous()), _ptr(k.contiguous()), _ptr(vT.contiguous()),
-                                      _ptr(o_img), _ptr(o_ctx), B, H, S, S_pad, n_img), "op_attention")
-    return o_img, o_ctx[: B * (S - n_img)]
-
-
-def op_ln_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, rows_per_sample: int, eps: float = 1e-6):
-    lib = _lib.load()
-    M, D = x.shape
-    mod = torch.stack([_bf16c(shift), _bf16c(scale)], 0).contiguous()  # [2][nb][D]: one allocation
-    out = torch.empty_like(x)
-    _lib.check(lib.mi355_op_ln_modulate(_stream(), _ptr(_bf16c(x)), _ptr(mod[0]), _ptr(mod[1]), _ptr(out), M, D,
-                                        rows_per_sample, eps), "op_ln_modulate")
     return out

@@ -313,14 +313,15 @@ if _RefAdapter is not None:
                                      text_dim=tc.text_dim, freq_dim=tc.freq_dim, patch_size=tuple(tc.patch_size), eps=tc.eps)
                 ratio = getattr(self.pipeline.config, "boundary_ratio", None)
                 second = getattr(self.pipeline, "transformer_2", None)
-                if second is not None and ratio is not None and 0 < ratio < 1:
+                if second is not None and ratio is not None and 0 < ratio <= 1:     # (ratio == 1: t == 1000 still picks the high-noise expert)
                     self._init_live(WanEngine(wcfg(self.pipeline.transformer.config)))
                     self.engine_2 = WanEngine(wcfg(second.config))
                     self._live_weights_2 = LiveWeights(self.engine_2, lambda: self.transformer_2)
                     self.boundary_ratio = float(ratio)
-                elif second is not None and ratio is not None and ratio >= 1:        # only the low-noise expert is ever used
-                    self._init_live(WanEngine(wcfg(second.config)))
+                elif second is not None and ratio is not None and ratio > 1:         # every t is below the boundary: only the low-noise expert,
+                    self._init_live(WanEngine(wcfg(second.config)))                  # with ITS guidance scale (wan2_t2v.py:482-485)
                     self._live_weights = LiveWeights(self.engine, lambda: self.transformer_2)
+                    self.low_noise_only = True
                 else:
                     self._init_live(WanEngine(wcfg(self.pipeline.transformer.config)))
 

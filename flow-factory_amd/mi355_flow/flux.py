@@ -290,7 +290,7 @@ class FluxRolloutMixin:
 
         traj = collect_rollout(trajectory_indices, N, lambda pos: lat_kept[pos_to_slot[pos]], log_probs, eta_host, compute_log_prob,
                                step_outputs, extra_call_back_kwargs,
-                               captured_noise_levels=host_noise_levels(self.scheduler, N, effective=False))
+                               captured_noise_levels=host_noise_levels(self.scheduler, N, effective=False), dynamics=dyn)
         images = self.decode_latents(final, height, width, output_type="pt")
         return [
             self._sample_cls(

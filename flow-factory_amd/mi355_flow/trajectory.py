@@ -196,7 +196,7 @@ class CollectedRollout:
 
 
 def collect_rollout(trajectory_indices: TrajectoryIndicesType, num_steps: int, latent_at, log_probs, noise_levels, compute_log_prob: bool,
-                    step_outputs=None, extra_keys=(), captured_noise_levels=None) -> CollectedRollout:
+                    step_outputs=None, extra_keys=(), captured_noise_levels=None, dynamics: Optional[str] = None) -> CollectedRollout:
     """`latent_at(pos)` -> the stored latents (B, ...) at trajectory position pos (only asked for collected positions);
     `log_probs[i]` (B,) for SDE steps; `step_outputs[i]` the per-step scheduler outputs when callback tensors were requested."""
     N = num_steps
@@ -208,8 +208,21 @@ def collect_rollout(trajectory_indices: TrajectoryIndicesType, num_steps: int, l
     for i in range(N):
         if lat_c.should_collect(i + 1):
             lat_c.collect(latent_at(i + 1), i + 1)
-        if compute_log_prob and noise_levels[i] > 0:
-            lp_c.collect(log_probs[i], i)
+        # the reference gates on the SCHEDULE's noise level (`get_noise_level_for_timestep(t) > 0`, sd3_5.py:275-278), not on the effective
+        # one.  In evaluation mode (effective level 0 on every step) `step()` still evaluates its log-prob expression: under Flow-SDE /
+        # Dance-SDE that is -(x' - mean)^2 / (2 * 0) - log(0) = NaN in fp32 (flow_match_euler_discrete.py:363-398), under ODE dynamics
+        # `zeros(B)` (:337-340) -- and that value IS collected, so `log_probs` / `log_prob_index_map` exist in the sample.
+        sched_level = (captured_noise_levels if captured_noise_levels is not None else noise_levels)[i]
+        if compute_log_prob and sched_level > 0:
+            if noise_levels[i] > 0:
+                lp_c.collect(log_probs[i], i)
+            else:
+                if dynamics == "CPS":
+                    raise NotImplementedError("mi355_flow: log-probs of an evaluation-mode CPS step (the reference reports the storage-rounding "
+                                              "residual -mean((round(mu) - mu)^2)) are not produced by the engine")
+                like = log_probs[i]
+                fill = 0.0 if dynamics == "ODE" else float("nan")
+                lp_c.collect(torch.full((like.shape[0],), fill, dtype=torch.float32, device=like.device), i)
         cb_c.collect_step(step_idx=i, output=step_outputs[i] if step_outputs is not None else None, keys=list(extra_keys),
                           capturable={"noise_level": (captured_noise_levels if captured_noise_levels is not None else noise_levels)[i]})
     out = CollectedRollout()

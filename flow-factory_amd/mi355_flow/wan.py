@@ -194,6 +194,7 @@ class WanRolloutMixin:
     # `guidance_scale_2`).  None = single-transformer Wan2.1.  Per-token timesteps (`expand_timesteps`, TI2V-5B) are not supported.
     engine_2 = None
     boundary_ratio: Optional[float] = None
+    low_noise_only = False      # a Wan2.2 pipeline whose boundary lies above every timestep: `engine` holds transformer_2, guidance_scale_2 applies
 
     def _boundary_timestep(self, boundary_timestep: Optional[float] = None) -> Optional[float]:
         if boundary_timestep is None and self.boundary_ratio is not None:
@@ -202,6 +203,8 @@ class WanRolloutMixin:
 
     def _expert(self, t: float, guidance_scale: float, guidance_scale_2: Optional[float], boundary_timestep: Optional[float]):
         """(engine, guidance) for a step at timestep t: the reference's selection rule."""
+        if self.low_noise_only:
+            return self.engine, (guidance_scale_2 if guidance_scale_2 is not None else guidance_scale)
         bt = self._boundary_timestep(boundary_timestep)
         if self.engine_2 is None or bt is None or t >= bt:
             return self.engine, guidance_scale
@@ -257,6 +260,10 @@ class WanRolloutMixin:
         self._before_engine_call()
         if attention_kwargs:
             raise NotImplementedError("mi355_flow: attention_kwargs are not supported by the native engine")
+        if self.low_noise_only:
+            if guidance_scale_2 is not None:
+                guidance_scale = guidance_scale_2          # every step runs the low-noise expert with its own scale
+            guidance_scale_2 = None
         if guidance_scale_2 is not None and guidance_scale_2 != guidance_scale and self.engine_2 is None:
             raise ValueError("mi355_flow: guidance_scale_2 needs a two-expert (Wan2.2) adapter: no second transformer is bound")
         if (num_frames - 1) % VAE_SCALE_TEMPORAL != 0:
@@ -314,7 +321,7 @@ class WanRolloutMixin:
             pos_to_slot = {p: p for p in range(N + 1)}
         traj = collect_rollout(trajectory_indices, N, lambda pos: lat_kept[pos_to_slot[pos]], log_probs, eta_host, compute_log_prob,
                                step_outputs, extra_call_back_kwargs,
-                               captured_noise_levels=host_noise_levels(self.scheduler, N, effective=False))
+                               captured_noise_levels=host_noise_levels(self.scheduler, N, effective=False), dynamics=self.scheduler.dynamics_type)
         videos = self.decode_latents(final, output_type="pt")
         return [
             self._sample_cls(

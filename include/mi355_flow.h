@@ -162,9 +162,6 @@ int mi355_op_attention_fwd_bwd(void* stream, const void* q, const void* k, const
 /* out[M][N] (bf16, ld = N) = A[M][K] . W[N][K]^T + bias[N] (fp32 bias); act: 0 none, 1 silu, 2 gelu-tanh */
 int mi355_op_linear(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                     int act);
-/* A/B candidate for the GEMM main loop (csrc/gemm_w4.hip: 4 waves x 128x128 register tiles, 32x32x16 MFMA; unit tests / microbenchmarks only,
- * not on the rollout path): out = A . W^T + bias; M % 256 == 0, N % 256 == 0, K % 64 == 0 */
-int mi355_op_linear_w4(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K);
 /* debug: mi355_op_linear (act 0) that also records s_memtime stamps per workgroup / tile / wave-group:
  * trace[((wg*16 + tile_iter)*2 + group)*4 + {0: tile start, 1: main loop start, 2: main loop end, 3: stores drained}] */
 int mi355_op_linear_trace(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,

@@ -396,3 +396,50 @@ def test_train_forward_is_bit_identical_at_full_width(tune):
         _lib.check(lib.mi355_tune_set(1, 1), "tune_set")
         e.set_train_scope(False)
         e.close()
+
+
+def test_two_grad_forwards_on_one_plan_before_a_single_backward(gpu):
+    """DPO (reference trainers/dpo.py:587-588) runs the chosen and the rejected forward -- same shape, hence the same plan and the same
+    activation stash -- BEFORE one `backward()` of the summed loss.  Each forward's backward node must differentiate ITS OWN forward: the
+    plan stamps every training forward with a serial and re-runs a forward whose stash has been overwritten.  Compared against the two
+    losses back-propagated one at a time (each right after its forward, the path every other test takes): bit-identical is not promised
+    (accumulation order into `.grad`), equal to fp32 rounding is."""
+    targets = (".to_q.", ".to_k.", ".to_v.", ".to_out.0.", ".ff.net.0.proj.")
+    ad, mod, cfg_o = _build(lambda n: any(k in n for k in targets), seed=31)
+    B, h, w, Nt = 2, 16, 16, 13
+    ad.scheduler.set_timesteps(4)
+
+    def kwargs(seed, t):
+        inp = _inputs(B, h, w, Nt, seed=seed)
+        return inp, dict(t=torch.full((B,), t), t_next=torch.zeros(B), latents=inp["x"].cuda(), prompt_embeds=inp["pe"].cuda(),
+                         pooled_prompt_embeds=inp["pp"].cuda(), guidance_scale=1.0, noise_level=0.0, compute_log_prob=False,
+                         return_kwargs=["noise_pred"])
+
+    (inp_w, kw_w), (inp_l, kw_l) = kwargs(41, 437.5), kwargs(43, 812.5)
+    loss_of = lambda inp, out: (inp["wnp"].cuda() * out.noise_pred).mean()
+
+    def grads():
+        g = {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}
+        for p in mod.parameters():
+            p.grad = None
+        return g
+
+    # reference: one forward, one backward, twice (gradients accumulate in .grad)
+    loss_of(inp_w, ad.forward(**kw_w)).backward()
+    (-0.5 * loss_of(inp_l, ad.forward(**kw_l))).backward()
+    g_seq = grads()
+    plan = next(iter(ad.engine._plans.values()))
+    assert getattr(plan, "recomputed_forwards", 0) == 0
+    # DPO order: both forwards first, then ONE backward
+    out_w, out_l = ad.forward(**kw_w), ad.forward(**kw_l)
+    (loss_of(inp_w, out_w) - 0.5 * loss_of(inp_l, out_l)).backward()
+    g_joint = grads()
+    assert plan.recomputed_forwards == 1                 # the first forward's stash had been overwritten and was rebuilt
+    assert g_seq.keys() == g_joint.keys() and len(g_seq) >= 20
+    for n in g_seq:
+        assert _rel(g_joint[n], g_seq[n]) < 1e-5, (n, _rel(g_joint[n], g_seq[n]))
+    # and the stale-stash failure this guards against is real: the two forwards' gradients differ by far more than that
+    loss_of(inp_w, ad.forward(**kw_w)).backward()
+    g_w = grads()
+    assert max(_rel(g_w[n], g_seq[n]) for n in g_seq) > 1e-2
+    ad.engine.close()

@@ -190,23 +190,3 @@ def test_sde_step_cfg_and_large(eng):
     assert torch.equal(o.noise_pred.cpu(), v.float())
     assert torch.equal(o.next_latents.cpu(), ref["next_latents"])
     np.testing.assert_allclose(o.log_prob.cpu().numpy(), ref["log_prob"].numpy(), rtol=1e-5)
-
-
-@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 512, 128), (512, 768, 192), (1024, 512, 1536)])
-def test_gemm_w4_candidate_matches_fp32(M, N, K):
-    """csrc/gemm_w4.hip -- the experimental 4-wave / 128x128-per-wave / 32x32x16-MFMA main loop (A/B candidate, not on the rollout path):
-    K = 64 (prologue only), 128 (both stages), odd tile counts, a long K; vs fp32 torch on the same bf16 operands; run-to-run identical."""
-    if not torch.cuda.is_available():
-        pytest.skip("needs a GPU")
-    import math
-    from mi355_flow import engine
-    g = torch.Generator(device="cuda").manual_seed(M + N + K)
-    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
-    w = (torch.randn(N, K, device="cuda", generator=g) / math.sqrt(K)).bfloat16()
-    b = torch.randn(N, device="cuda", generator=g)
-    y = engine.op_linear_w4(x, w, b)
-    ref = x.float() @ w.float().t() + b
-    assert float((y.float() - ref).norm() / ref.norm()) < 4e-3
-    assert torch.equal(y, engine.op_linear_w4(x, w, b))
-    with pytest.raises(RuntimeError, match="M % 256"):
-        engine.op_linear_w4(x[:100], w, b)

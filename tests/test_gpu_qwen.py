@@ -248,6 +248,38 @@ def test_qwen_full_width_blocks_at_1024(qw):
     eng.close()
 
 
+def test_qwen_full_width_blocks_at_config_e_1328(qw):
+    """BASELINE.json configs[4] at ITS OWN shape (reference qwen_image.py:476-600): 1328^2 = a 166 x 166 latent grid = 83 * 83 = 6889 image
+    tokens (odd grid: the centred RoPE rows / columns are asymmetric; 6889 is not a multiple of 64, so the ragged text tail starts
+    mid-tile), true CFG with ragged prompts, Qwen-Image width, 2 blocks, vs the fp32 oracle (model body unpinned)."""
+    from oracle import qwen_ref as R
+    cfg_o = R.QwenConfig(num_layers=2)
+    sd, cfg = _setup(qw, cfg_o, seed=14, std=0.02)
+    eng = _engine(qw, sd, cfg)
+    B, h, w, Nt = 1, 166, 166, 96
+    Ni = (h // 2) * (w // 2)
+    g = torch.Generator().manual_seed(18)
+    x = _bf(torch.randn(B, Ni, 64, generator=g))
+    pos_lens, neg_lens = [91], [5]
+    pe, ne = _text(B, Nt, 3584, pos_lens, g), _text(B, Nt, 3584, neg_lens, g)
+    t = torch.tensor([640.0])
+    v, raw = eng.plan(B, 2, h, w, Nt, 1).transformer_forward(x.bfloat16().cuda(), qw.model_timestep(t, torch.bfloat16), torch.cat([ne, pe]).cuda(),
+                                                              neg_lens + pos_lens, guidance_scale=4.0, return_raw=True)
+    assert torch.isfinite(v.float()).all()
+    tq = (t.to(torch.bfloat16) / 1000).float()
+    with torch.no_grad():
+        rp = R.qwen_forward(sd, cfg_o, x, tq, pe, pos_lens, h // 2, w // 2)
+        rn = R.qwen_forward(sd, cfg_o, x, tq, ne, neg_lens, h // 2, w // 2)
+    r1, r2 = _rel(raw[1:], rp), _rel(raw[:1], rn)
+    r3 = _rel(v, R.cfg_rescale_bf16(rn, rp, 4.0))
+    rows = raw[1].float().cpu().reshape(h // 2, w // 2, 64)
+    rrows = rp[0].reshape(h // 2, w // 2, 64)
+    worst_row = max(float((rows[i] - rrows[i]).norm() / rrows[i].norm()) for i in range(h // 2))
+    print(f"Qwen-Image full-width 2 blocks, 1328^2 (S = 6889 + 96): rel-L2 cond {r1:.3e} uncond {r2:.3e} cfg {r3:.3e}, worst image row {worst_row:.3e}")
+    assert r1 < 2e-2 and r2 < 2e-2 and r3 < 4e-2 and worst_row < 3e-2
+    eng.close()
+
+
 def test_qwen_errors(qw):
     from oracle import qwen_ref as R
     cfg_o = R.tiny_config()

@@ -1,16 +1,13 @@
-"""GPU checks written while no GPU time was left in the round: NOT yet run on an MI355X, therefore kept out of the
-driver's `-m gpu` run (every test here is DESELECTED unless `MI355_NEXT=1`: tests/conftest.py).  First thing to run on the next box:
-
-    MI355_NEXT=1 python -m pytest tests/test_gpu_next_round.py -x -q
-
-A test that passes there moves to its family's file (and loses the gate); one that fails names a gap to close.
-"""
+"""GPU checks of the launch SCHEDULES (side streams, hipGraph replay) of the FLUX.1 and Qwen-Image engines -- bit-identity of every
+combination against single-stream eager launches, whole rollouts included -- plus two checks that were written without GPU time at the end
+of round 2 and first ran (and passed) in round 3's first GPU call: the SD3.5-large width forward and bench.py's small-batch legs.
+Measured gains of the schedules: profiles/r03a_*_two_stream_ab.txt."""
 import os
 
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu, pytest.mark.gpu_next]          # gpu_next: deselected unless MI355_NEXT=1 (tests/conftest.py)
+pytestmark = pytest.mark.gpu
 
 
 def _rel(a, b):
@@ -53,13 +50,12 @@ def test_forward_at_sd3_5_large_width_vs_oracle():
 
 def test_bench_small_batch_legs_report_numbers():
     """bench.py's untimed small-batch legs (`--small-batch`: B = 2 at 1024^2; the reference's 512^2 B = 2 CFG example shape) produce finite
-    figures and do not disturb the headline line (added after the last GPU run of round 2, hence opt-in: once this passes they can become
-    the default)."""
+    figures and do not disturb the headline line (`--no-small-batch` switches them off)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--no-vae", "--no-cpu-baseline", "--small-batch"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--no-vae", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -70,7 +66,7 @@ def test_bench_small_batch_legs_report_numbers():
 
 
 def test_qwen_two_stream_and_graph_replay_are_bit_identical():
-    """Qwen-Image engine with the text chain of every block on a side stream (mi355_tune_set key 12 = 1; default 0) and / or the N-step
+    """Qwen-Image engine with the text chain of every block on a side stream (mi355_tune_set key 12; default 2 = plans of up to 16 384 image rows) and / or the N-step
     loop replayed as one hipGraph (key 17 = 1; default 0): the raw network outputs of both CFG branches of a ragged-prompt forward and whole
     true-CFG rollouts (latents, log-probs) equal the single-stream eager results bit for bit, repeatedly (a missing fork / join edge shows
     up as a run-to-run difference); a replayed graph sees new prompt lengths."""
@@ -143,12 +139,12 @@ def test_qwen_two_stream_and_graph_replay_are_bit_identical():
         for mode, r in res.items():
             assert all(torch.equal(a, b) for a, b in zip(r, ref)), mode
     finally:
-        lib.mi355_tune_set(12, 0)
-        lib.mi355_tune_set(17, 0)
+        lib.mi355_tune_set(12, 2)                       # the defaults
+        lib.mi355_tune_set(17, 1)
 
 
 def test_flux_two_stream_and_graph_replay_are_bit_identical():
-    """FLUX.1 engine with the text chain of the double blocks on a side stream (mi355_tune_set key 14 = 1; default 0) and / or the N-step
+    """FLUX.1 engine with the text chain of the double blocks on a side stream (mi355_tune_set key 14; default 2 = plans of up to 16 384 image rows) and / or the N-step
     loop replayed as one hipGraph (key 16 = 1; default 0): single forwards (small and chip-filling token counts, text length not a multiple
     of 64 so that text and image columns of V^T share cache lines) and whole rollouts equal the single-stream eager results bit for bit,
     repeatedly; a changed step count re-captures."""
@@ -212,80 +208,5 @@ def test_flux_two_stream_and_graph_replay_are_bit_identical():
         for mode, r in res.items():
             assert all(torch.equal(a, b) for a, b in zip(r, ref)), mode
     finally:
-        lib.mi355_tune_set(14, 0)
-        lib.mi355_tune_set(16, 0)
-
-
-@pytest.mark.parametrize("B,H,S,n_img", [(1, 2, 300, 256), (2, 3, 333, 77), (1, 4, 4429, 4096)])
-def test_attention_row_sums_on_the_matrix_pipe_match_fp32(B, H, S, n_img):
-    """A/B variant 3 of the d = 64 attention (static-bound softmax; row sums from one more MFMA per 16-key step with an all-ones A operand
-    instead of v_dot2c on the VALU port): against fp32 torch attention, same tolerance as the shipped variants (tests/test_gpu_kernels.py),
-    and within bf16 rounding of variant 1 on the same inputs; ragged S exercises the masked last tile and the inactive tail waves."""
-    import torch.nn.functional as Fn
-    from mi355_flow import _lib, engine
-    lib = _lib.load()
-    g = torch.Generator().manual_seed(S + H)
-    S_pad = (S + 63) // 64 * 64
-    q = torch.zeros(B, H, S_pad, 64)
-    k = torch.zeros_like(q)
-    v = torch.zeros_like(q)
-    q[:, :, :S] = torch.randn(B, H, S, 64, generator=g).bfloat16().float()
-    k[:, :, :S] = torch.randn(B, H, S, 64, generator=g).bfloat16().float()
-    v[:, :, :S] = torch.randn(B, H, S, 64, generator=g).bfloat16().float()
-    ref = Fn.scaled_dot_product_attention(q[:, :, :S], k[:, :, :S], v[:, :, :S]).transpose(1, 2).reshape(B, S, H * 64)
-    qd, kd, vT = q.bfloat16().cuda(), k.bfloat16().cuda(), v.transpose(2, 3).contiguous().bfloat16().cuda()
-    outs = {}
-    try:
-        lib.mi355_tune_set(6, 40)                       # |score| <= 40 holds by a wide margin for unit-variance q, k (log2 domain ~ +-10)
-        for var in (1, 3):
-            lib.mi355_tune_set(1, var)
-            oi, oc = engine.op_attention(qd, kd, vT, S, n_img)
-            torch.cuda.synchronize()
-            outs[var] = torch.cat([oi.view(B, n_img, H * 64), oc.view(B, S - n_img, H * 64)], 1).float().cpu()
-    finally:
-        lib.mi355_tune_set(1, 1)
-        lib.mi355_tune_set(6, 1)
-    for var, got in outs.items():
-        rel = float((got - ref).norm() / ref.norm())
-        assert torch.isfinite(got).all() and rel < 6e-3, (var, rel)
-    assert float((outs[3] - outs[1]).abs().max()) <= 2.0 ** -6 * float(ref.abs().max())
-
-
-@pytest.mark.parametrize("guidance", [1.0, 5.0])
-def test_wan_graph_replay_is_bit_identical(guidance):
-    """Wan engine with the N-step loop replayed as one hipGraph (mi355_tune_set key 18 = 1; default 0): rollouts (latents, log-probs) with
-    and without CFG equal the eager results bit for bit over warm-up / capture / replay, a replay sees new prompts, and a changed step
-    count re-captures."""
-    from mi355_flow import _lib, wan as wn
-    from oracle import wan_ref as R
-    lib = _lib.load()
-    cfg_o = R.tiny_config()
-    sd = {k: v.bfloat16().float() for k, v in R.make_synthetic_state_dict(cfg_o, 12).items()}
-    cfg = wn.WanConfig(num_layers=cfg_o.num_layers, num_attention_heads=cfg_o.num_attention_heads, ffn_dim=cfg_o.ffn_dim, text_dim=cfg_o.text_dim)
-    B, Nt = 2, 12
-    g = torch.Generator().manual_seed(4)
-    pes = [torch.randn(B, Nt, cfg_o.text_dim, generator=g).bfloat16().cuda() for _ in range(2)]
-    ne = torch.randn(B, Nt, cfg_o.text_dim, generator=g).bfloat16().cuda()
-    res = {}
-    try:
-        for mode in (0, 1):
-            lib.mi355_tune_set(18, mode)
-            sched = wn.UniPCMultistepSDEScheduler(flow_shift=3.0, noise_level=0.7, sde_steps=[0, 1, 2, 3], num_sde_steps=2, seed=42,
-                                                  dynamics_type="Flow-SDE")
-            ad = wn.Wan2T2VNativeAdapter({k: v.cuda() for k, v in sd.items()}, cfg, sched, latent_storage_dtype="fp16")
-            ad.rollout()
-            runs = []
-            for pe, N in ((pes[0], 5), (pes[0], 5), (pes[0], 5), (pes[1], 5), (pes[0], 4)):
-                torch.cuda.manual_seed(31)
-                s = ad.inference(prompt=["a", "b"], height=64, width=96, num_frames=9, num_inference_steps=N, guidance_scale=guidance,
-                                 prompt_embeds=pe, negative_prompt_embeds=ne if guidance > 1.0 else None, compute_log_prob=True,
-                                 trajectory_indices="all")
-                runs.append((torch.stack([o.all_latents for o in s]).clone(), torch.stack([o.log_probs for o in s]).clone()))
-            assert all(torch.equal(r[0], runs[0][0]) and torch.equal(r[1], runs[0][1]) for r in runs[1:3]), mode
-            assert not torch.equal(runs[3][0], runs[0][0])                    # other prompts: other trajectory
-            res[mode] = runs
-            ad.engine.close()
-        for a, b in zip(res[0], res[1]):
-            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-    finally:
-        lib.mi355_tune_set(18, 0)
+        lib.mi355_tune_set(14, 2)                       # the defaults
+        lib.mi355_tune_set(16, 1)

@@ -160,6 +160,34 @@ def test_wan_full_width_blocks_at_4608_tokens(wn):
     eng.close()
 
 
+def test_wan_full_width_blocks_at_config_d_20280_tokens(wn):
+    """BASELINE.json configs[3] at ITS OWN shape (reference wan2_t2v.py:426-543): 480 x 832 x 49 frames = a 13 x 60 x 104 latent grid =
+    13 * 30 * 52 = 20 280 video tokens (not a multiple of 64: the last key tile is masked; operand offsets beyond 2^31 bytes in the
+    q / k / V^T scatter at forward batch 2), Wan2.1-1.3B width, 2 blocks, CFG on, vs the fp32 oracle (model body unpinned)."""
+    from oracle import wan_ref as R
+    cfg_o = R.WanConfig(num_layers=2)
+    sd, cfg = _setup(wn, cfg_o, seed=78)
+    eng = wn.WanEngine(cfg)
+    eng.bind_state_dict({k: v.cuda() for k, v in sd.items()})
+    eng.ready()
+    B, T, h, w, Nt = 1, 13, 60, 104, 226
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B, 16, T, h, w, generator=g).half()
+    pe = _bf(torch.randn(B, Nt, cfg_o.text_dim, generator=g))
+    ne = _bf(torch.randn(B, Nt, cfg_o.text_dim, generator=g))
+    t = torch.tensor([601.0])
+    got = eng.plan(B, 2, T, h, w, Nt, 1).transformer_forward(x.cuda(), t, ne.cuda(), pe.cuda()).float().cpu()
+    assert torch.isfinite(got).all()
+    with torch.no_grad():
+        ref = torch.cat([R.wan_forward(sd, cfg_o, x.float(), t.expand(B), ne), R.wan_forward(sd, cfg_o, x.float(), t.expand(B), pe)])
+    rel = ((got - ref).norm() / ref.norm()).item()
+    # per-frame: an indexing slip that only hits the far end of the 20 280-token axis must not hide in the global norm
+    per_frame = [((got[:, :, f] - ref[:, :, f]).norm() / ref[:, :, f].norm()).item() for f in range(T)]
+    print(f"Wan full-width 2 blocks, S = 20280 (config D): rel-L2 {rel:.3e}, worst frame {max(per_frame):.3e}")
+    assert rel < 2e-2 and max(per_frame) < 3e-2, (rel, per_frame)
+    eng.close()
+
+
 def test_wan22_two_expert_rollout_matches_oracle_and_replays(wn):
     """Wan2.2 two-expert pipelines (reference wan2_t2v.py:476-487): high-noise expert + `guidance_scale` while t >= boundary_ratio * 1000,
     low-noise expert + `guidance_scale_2` below (here <= 1: that expert runs without CFG).  Latents / log-probs vs the oracle's
