@@ -968,7 +968,8 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
     return 0;
 }
 
-// A/B knob for kernel variants (key 0: GEMM 256x256 schedule, 0 = simple 2-stage, 1 = ping-pong)
+// A/B knob for kernel variants (key 0: large-grid GEMM kernel, 0 = simple 2-stage, 1 = default (4-wave hand-scheduled loop up to K = key 19,
+// else ping-pong), 2 = 4-wave wherever it applies, 3 = ping-pong only)
 extern "C" int mi355_tune_set(int key, int value) {
     if (key == 0) { set_gemm_variant(value); return 0; }
     if (key == 1) { set_attn_variant(value); return 0; }
@@ -988,6 +989,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 15) { set_flux_two_stream_rows(value); return 0; }
     if (key == 16) { set_flux_graph(value); return 0; }        // FLUX.1 engine: hipGraph replay of the rollout loop (0 = default: eager)
     if (key == 17) { set_qwen_graph(value); return 0; }        // Qwen-Image engine: the same
+    if (key == 19) { set_w4_max_k(value); return 0; }          // default GEMM dispatch: largest K for the 4-wave hand-scheduled kernel
     return fail("mi355_tune_set: unknown key %d", key);
 }
 
@@ -999,6 +1001,18 @@ extern "C" int mi355_op_linear(void* stream, const void* A, const void* W, const
     GemmParams g = gp((const bf16_t*)A, K, (const bf16_t*)W, K, M, N, K, act == 1 ? EPI_BIAS_SILU : act == 2 ? EPI_BIAS_GELU : EPI_BIAS,
                       bias, (bf16_t*)out, N);
     HIPCHK(gemm_p(g, (hipStream_t)stream));
+    return 0;
+}
+
+// x[M][N] += gate[m / rows_per_sample][N] * (A . W^T + bias), in place: the gated-residual epilogue of the out-projections / second MLP
+// linears (K8 / K11 of SURVEY.md 2.3) as an operator, for unit tests and the GEMM A/B scripts
+extern "C" int mi355_op_linear_gate_res(void* stream, const void* A, const void* W, const float* bias, const void* gate, void* x, int M, int N,
+                                        int K, int rows_per_sample) {
+    if (!A || !W || !bias || !gate || !x) return fail("mi355_op_linear_gate_res: null argument");
+    if (K % 64 || N % 8 || rows_per_sample < 1) return fail("mi355_op_linear_gate_res: K %% 64, N %% 8 must be 0 and rows_per_sample >= 1");
+    GemmParams g = gp((const bf16_t*)A, K, (const bf16_t*)W, K, M, N, K, EPI_GATE_RES, bias, (bf16_t*)x, N);
+    g.aux = (const bf16_t*)gate; g.ld_aux = N; g.rows_per_sample = rows_per_sample;
+    HIPCHK(launch_gemm(g, (hipStream_t)stream));
     return 0;
 }
 

@@ -40,7 +40,10 @@ __device__ __forceinline__ void tile_coords(int tile, int ntm, int ntn, int gm, 
     tn = r / rows;
     tm = first + (r - tn * rows);
 }
-int g_gemm_variant = 1;  // large grids: 0 simple 2-stage kernel, 1 persistent ping-pong kernel
+int g_gemm_variant = 1;  // large grids: 0 simple 2-stage kernel; 1 (default) the 4-wave kernel with the hand-scheduled loop where it applies and
+                         // K <= g_w4_max_k, else the persistent ping-pong kernel; 2 the 4-wave kernel wherever it applies; 3 ping-pong only
+int g_w4_max_k = 3072;   // measured (profiles/r03e_gemm_w4_ab.txt): w4 +5 ... +10 % at K = 1536, -8 % at K = 6144 (16 loads per wave and K-tile
+                         // concentrated in half an interval: too little flight time for rows 12 KiB apart streaming from HBM)
 // (a 32x32x16-MFMA / 2-phases-per-K-tile ping-pong variant was measured 6-10 % SLOWER than the 16x16x32 / 4-phase one
 //  on every shape of this model and was dropped: profiles/r01_gemm_variants.txt)
 
@@ -153,14 +156,15 @@ __device__ __forceinline__ void store_row8(const GemmParams& p, int m, int n, in
             if (vec) {
                 const uint4 g = *(const uint4*)gp;
                 const uint4 x = *(const uint4*)op;
-                y[0] = bf_lo(x.x) + bf_lo(g.x) * y[0]; y[1] = bf_hi(x.x) + bf_hi(g.x) * y[1];
-                y[2] = bf_lo(x.y) + bf_lo(g.y) * y[2]; y[3] = bf_hi(x.y) + bf_hi(g.y) * y[3];
-                y[4] = bf_lo(x.z) + bf_lo(g.z) * y[4]; y[5] = bf_hi(x.z) + bf_hi(g.z) * y[5];
-                y[6] = bf_lo(x.w) + bf_lo(g.w) * y[6]; y[7] = bf_hi(x.w) + bf_hi(g.w) * y[7];
+                // explicit fma: every path that forms x + g * y (this one, the ragged one, the batched one of epilogue_part) must round alike
+                y[0] = __builtin_fmaf(bf_lo(g.x), y[0], bf_lo(x.x)); y[1] = __builtin_fmaf(bf_hi(g.x), y[1], bf_hi(x.x));
+                y[2] = __builtin_fmaf(bf_lo(g.y), y[2], bf_lo(x.y)); y[3] = __builtin_fmaf(bf_hi(g.y), y[3], bf_hi(x.y));
+                y[4] = __builtin_fmaf(bf_lo(g.z), y[4], bf_lo(x.z)); y[5] = __builtin_fmaf(bf_hi(g.z), y[5], bf_hi(x.z));
+                y[6] = __builtin_fmaf(bf_lo(g.w), y[6], bf_lo(x.w)); y[7] = __builtin_fmaf(bf_hi(g.w), y[7], bf_hi(x.w));
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
-                    if (n + e < p.N) y[e] = bf2f(op[e]) + bf2f(gp[e]) * y[e];
+                    if (n + e < p.N) y[e] = __builtin_fmaf(bf2f(gp[e]), y[e], bf2f(op[e]));
             }
         }
         if (vec) {
@@ -179,9 +183,13 @@ __device__ __forceinline__ void store_row8(const GemmParams& p, int m, int n, in
 // acc: NR*16 rows x 64 columns of the wave's tile, acc[i][j][e] = C[m_base + 16 i + (lane&15)][n_base + 16 j + 4 (lane>>4) + e];
 // stg: NR*2 KiB of wave-private LDS
 // FULL: the whole 256-wide tile lies inside [0,M) x [0,N) and rows are 16-byte aligned (no guards)
-template <int EPI, int NR, bool FULL = false>
+// bpre: the 4 bias float4 of this lane's columns (n_base + 16 j + 4 (lane >> 4)), loaded ONCE per output tile by the caller -- the compiler
+//       cannot hoist these loads out of the per-chunk calls itself (the chunks' global stores may alias p.bias for all it knows), and each
+//       call then pays one L2 round trip before its first arithmetic
+struct BiasPre { float4 v[4]; };      // by value: a pointer to a caller's array keeps that array in scratch memory
+template <int EPI, int NR, bool FULL = false, bool PRE = false>
 __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (&acc)[NR][4], int m_base, int n_base,
-                                              char* stg, int lane) {
+                                              char* stg, int lane, BiasPre bpre = BiasPre()) {
     const int frow = lane & 15, fkg = lane >> 4;
     float4 bcol[4];
     float4 nw[4];
@@ -223,7 +231,8 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
         const int n = n_base + j * 16 + 4 * fkg;
         bcol[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (EPI != EPI_VT && EPI != EPI_BIAS_ROW) {
-            if (FULL || n < p.N) bcol[j] = *(const float4*)(p.bias + n);
+            if constexpr (PRE) bcol[j] = bpre.v[j];
+            else if (FULL || n < p.N) bcol[j] = *(const float4*)(p.bias + n);
         }
         if constexpr (is_qk_epi(EPI)) {
             const bool is_k = n_base >= p.H * 64;
@@ -294,12 +303,52 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
         }
     }
     // wave-private region: a wave's LDS operations execute in order, no barrier needed
+    if constexpr (FULL && EPI == EPI_GATE_RES) {
+        // x += gate * y in place.  All LDS reads, then all global loads (the residual rows and the gate vectors), then arithmetic + stores:
+        // written as one loop the compiler keeps load -> store -> load order (a row's store may alias the next row's load for all it
+        // knows), i.e. NR * 2 exposed L2 round trips per call with nothing else to run on a SIMD whose waves are all in their epilogue.
+        uint4 val[NR * 2], xr[NR * 2], gr[NR * 2];
+        const int c = lane & 7;
 #pragma unroll
-    for (int it = 0; it < NR * 2; ++it) {
-        const int r = it * 8 + (lane >> 3), c = lane & 7;
-        const uint4 val = *(const uint4*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
-        const int m = m_base + r;
-        if (FULL || m < p.M) store_row8<EPI, FULL>(p, m, n_base + c * 8, n_base, val);
+        for (int it = 0; it < NR * 2; ++it) {
+            const int r = it * 8 + (lane >> 3);
+            val[it] = *(const uint4*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
+        }
+#pragma unroll
+        for (int it = 0; it < NR * 2; ++it) {
+            const int m = m_base + it * 8 + (lane >> 3), n = n_base + c * 8;
+            xr[it] = *(const uint4*)(p.out + (long)m * p.ldo + n);
+            gr[it] = *(const uint4*)(p.aux + (long)(m / p.rows_per_sample) * p.ld_aux + n);
+        }
+#pragma unroll
+        for (int it = 0; it < NR * 2; ++it) {
+            const int m = m_base + it * 8 + (lane >> 3), n = n_base + c * 8;
+            const uint4 v = val[it], x = xr[it], g = gr[it];
+            // (same operations, in the same order, as store_row8's vector path)
+            const float y0 = __builtin_fmaf(bf_lo(g.x), bf_lo(v.x), bf_lo(x.x)), y1 = __builtin_fmaf(bf_hi(g.x), bf_hi(v.x), bf_hi(x.x));
+            const float y2 = __builtin_fmaf(bf_lo(g.y), bf_lo(v.y), bf_lo(x.y)), y3 = __builtin_fmaf(bf_hi(g.y), bf_hi(v.y), bf_hi(x.y));
+            const float y4 = __builtin_fmaf(bf_lo(g.z), bf_lo(v.z), bf_lo(x.z)), y5 = __builtin_fmaf(bf_hi(g.z), bf_hi(v.z), bf_hi(x.z));
+            const float y6 = __builtin_fmaf(bf_lo(g.w), bf_lo(v.w), bf_lo(x.w)), y7 = __builtin_fmaf(bf_hi(g.w), bf_hi(v.w), bf_hi(x.w));
+            *(uint4*)(p.out + (long)m * p.ldo + n) = make_uint4(pack_bf16(y0, y1), pack_bf16(y2, y3), pack_bf16(y4, y5), pack_bf16(y6, y7));
+        }
+    } else if constexpr (FULL && !is_qk_epi(EPI)) {      // (the q / k scatter epilogues sit at their register limit in the ping-pong kernel)
+        uint4 val[NR * 2];                   // every LDS read in flight before the first store needs its data
+#pragma unroll
+        for (int it = 0; it < NR * 2; ++it) {
+            const int r = it * 8 + (lane >> 3), c = lane & 7;
+            val[it] = *(const uint4*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
+        }
+#pragma unroll
+        for (int it = 0; it < NR * 2; ++it)
+            store_row8<EPI, FULL>(p, m_base + it * 8 + (lane >> 3), n_base + (lane & 7) * 8, n_base, val[it]);
+    } else {
+#pragma unroll
+        for (int it = 0; it < NR * 2; ++it) {
+            const int r = it * 8 + (lane >> 3), c = lane & 7;
+            const uint4 val = *(const uint4*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
+            const int m = m_base + r;
+            if (FULL || m < p.M) store_row8<EPI, FULL>(p, m, n_base + c * 8, n_base, val);
+        }
     }
 }
 
@@ -759,6 +808,156 @@ hipError_t launch_pp(const GemmParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256x256x64 kernel with 4 waves, one per SIMD, each a 128x128 register tile (256 AGPR accumulators), and a HAND-SCHEDULED main loop
+// (gemm_w4_asm.inc, generated by gen_gemm_w4.py: its docstring has the schedule).  Against the 8-wave ping-pong kernel: LDS bytes read per
+// MFMA -33 % (a wave's fragment feeds 8 MFMAs instead of 4 / 8), one barrier per K-tile instead of eight, 16 LDS-DMA instructions per wave and
+// K-tile interleaved one per four MFMAs.  This is the structure hipBLASLt's own gfx950 bf16 kernels use (MT256x256x64, MIWaveTile 8x8, 256
+// threads), which were 10 % ahead of the ping-pong kernel on every model shape (profiles/r03a_clock_under_load.txt).
+// The C++ shell owns tile scheduling, addressing and the shared fused epilogues; the asm statement owns a[0:255], v[120:247], s[80:91]
+// (clobber lists) -- hipcc's register allocator does not terminate on 64 "+a" operands, so the accumulators are handed over by register
+// NUMBER: v_accvgpr_read statements right behind the loop.  The shell must therefore never make hipcc touch an AGPR itself (it has no MFMA
+// and stays far below 248 VGPRs; `make check-w4` greps the ISA for stray AGPR writes).
+// Requirements (launcher): M % 256 == 0, N % 256 == 0, K % 128 == 0.  ABL: ablation builds for the microbenchmark only (results garbage).
+#include "gemm_w4_asm.inc"
+
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(256) void gemm_w4_kernel(GemmParams p) {
+    constexpr int BM = 256, BN = 256;
+    constexpr int STAGE = 65536;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // persistent tile schedule (as gemm_pp_kernel)
+    const int ntm = p.M / BM, ntn = p.N / BN;
+    const int nblk = ntm * ntn;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per_xcd = (int)(gridDim.x >> 3);
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int chunk_lo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int chunk_n = q8 + (xcd < r8 ? 1 : 0);
+    if (slot >= chunk_n) return;
+    const int my_tiles = (chunk_n - slot + per_xcd - 1) / per_xcd;
+
+    // LDS-DMA: wave w fills rows [64 w, 64 w + 64) of both operands, 8 rows (1 KiB) per instruction; lane -> (row = l >> 3, LDS chunk
+    // position l & 7); the position holds source chunk  pos ^ ((row >> 1) & 7)
+    unsigned ga[8], gw[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int row = wave * 64 + g * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        ga[g] = ((unsigned)row * (unsigned)p.lda + (unsigned)(c * 8)) * 2u;
+        gw[g] = ((unsigned)row * (unsigned)p.ldw + (unsigned)(c * 8)) * 2u;
+    }
+    // fragment reads: lane -> (row l & 15 of a 16-row block, k-chunk kk * 4 + (l >> 4)), position = chunk ^ ((row >> 1) & 7)
+    const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem);
+    unsigned lx[2][2], lw[2][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const unsigned in_blk = (unsigned)((lane & 15) * 128 + (((kk * 4 + (lane >> 4)) ^ ((lane & 15) >> 1)) << 4));
+            lx[st][kk] = lds0 + st * STAGE + wm * 16384 + in_blk;
+            lw[st][kk] = lds0 + st * STAGE + 32768 + wn * 16384 + in_blk;
+        }
+    const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * 8192);       // this wave's LDS-DMA destination inside a region
+
+    auto tile_bases = [&](int tile, unsigned long long& a, unsigned long long& w, int& m0, int& n0) {
+        int tm, tn;
+        tile_coords(tile, ntm, ntn, p.raster_gm, tm, tn);
+        m0 = tm * BM; n0 = tn * BN;
+        a = (unsigned long long)p.A + (unsigned long long)m0 * (unsigned long long)p.lda * 2ull;
+        w = (unsigned long long)p.W + (unsigned long long)n0 * (unsigned long long)p.ldw * 2ull;
+    };
+    unsigned long long cA, cW, nA, nW;
+    int m0, n0, m0n, n0n;
+    tile_bases(chunk_lo + slot, cA, cW, m0, n0);
+    {   // K-tile 0 of the first tile -> stage 0
+        char* dst = smem + wave * 8192;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            glds16((const char*)cA + ga[g], dst + g * 1024);
+            glds16((const char*)cW + gw[g], dst + 32768 + g * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const int pairs = p.K / 128 - 1;
+    char* stg = smem + 2 * STAGE + wave * 8192;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        if (ti + 1 < my_tiles) tile_bases(chunk_lo + slot + (ti + 1) * per_xcd, nA, nW, m0n, n0n);
+        else { nA = cA; nW = cW; m0n = m0; n0n = n0; }       // nothing follows: the last prefetch re-reads this tile's first K-tile (unused)
+#define W4_OPERANDS                                                                                                                      \
+        : : [ga0] "v"(ga[0]), [ga1] "v"(ga[1]), [ga2] "v"(ga[2]), [ga3] "v"(ga[3]), [ga4] "v"(ga[4]), [ga5] "v"(ga[5]), [ga6] "v"(ga[6]),    \
+            [ga7] "v"(ga[7]), [gw0] "v"(gw[0]), [gw1] "v"(gw[1]), [gw2] "v"(gw[2]), [gw3] "v"(gw[3]), [gw4] "v"(gw[4]), [gw5] "v"(gw[5]),    \
+            [gw6] "v"(gw[6]), [gw7] "v"(gw[7]), [lx00] "v"(lx[0][0]), [lx01] "v"(lx[0][1]), [lx10] "v"(lx[1][0]), [lx11] "v"(lx[1][1]),      \
+            [lw00] "v"(lw[0][0]), [lw01] "v"(lw[0][1]), [lw10] "v"(lw[1][0]), [lw11] "v"(lw[1][1]), [cA] "s"(cA), [cW] "s"(cW), [nA] "s"(nA), \
+            [nW] "s"(nW), [pairs] "s"(pairs), [ldsw] "s"(ldsw)                                                                             \
+        : W4_CLOBBERS
+        if constexpr (ABL == 0) asm volatile(W4_LOOP_ASM W4_OPERANDS);
+        else if constexpr (ABL == 1) asm volatile(W4_LOOP_ASM_NOLOAD W4_OPERANDS);
+        else if constexpr (ABL == 2) asm volatile(W4_LOOP_ASM_NOREAD W4_OPERANDS);
+        else if constexpr (ABL == 3) asm volatile(W4_LOOP_ASM_MFMA_ONLY W4_OPERANDS);
+        else if constexpr (ABL == 4) asm volatile(W4_LOOP_ASM_S1 W4_OPERANDS);
+        else asm volatile(W4_LOOP_ASM_S3 W4_OPERANDS);
+#undef W4_OPERANDS
+        // ---- epilogue: eight 32x64 chunks of the wave's 128x128 tile through the shared fused epilogues (wave-private LDS staging)
+#define W4_CHUNK(Q, C)                                                                                         \
+        {                                                                                                      \
+            f32x4 a2[2][4];                                                                                    \
+            W4_READ_CHUNK_##Q##_##C(a2)                                                                        \
+            const int mb = m0 + wm * 128 + Q * 32, nb = n0 + wn * 128 + C * 64;                                \
+            epilogue_part<EPI, 2, true, HAS_COLB>(p, a2, mb, nb, stg, lane_e, bpre);                         \
+        }
+        if constexpr (ABL == 0 || ABL >= 4) {
+            // Everything the epilogue derives from the lane id is recomputed per tile from an OPAQUE copy of it: hipcc would otherwise hoist
+            // that address arithmetic out of the tile loop and keep it alive across the asm statement, where only v0-v119 are free -- measured:
+            // 176-320 bytes of scratch per lane, every reload followed by s_waitcnt vmcnt(0) with no second wave on the SIMD to hide it
+            // (w4 1113 vs ping-pong 1302 TFLOP/s; profiles/r03d_gemm_w4_second_ab.txt).
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            constexpr bool HAS_COLB = EPI != EPI_VT && EPI != EPI_BIAS_ROW;
+#define W4_COLUMN_HALF(C)                                                                                                \
+            {                                                                                                            \
+                BiasPre bpre;           /* one bias load per tile and column half: its four row chunks share it */       \
+                if constexpr (HAS_COLB)                                                                                   \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
+                        bpre.v[j] = *(const float4*)(p.bias + n0 + wn * 128 + C * 64 + j * 16 + 4 * (lane_e >> 4));        \
+                W4_CHUNK(0, C) W4_CHUNK(1, C) W4_CHUNK(2, C) W4_CHUNK(3, C)                                              \
+            }
+            W4_COLUMN_HALF(0) W4_COLUMN_HALF(1)
+#undef W4_COLUMN_HALF
+        }
+#undef W4_CHUNK
+        cA = nA; cW = nW; m0 = m0n; n0 = n0n;
+    }
+}
+
+template <int EPI, int ABL = 0>
+hipError_t launch_w4(const GemmParams& p, hipStream_t stream) {
+    auto kern = gemm_w4_kernel<EPI, ABL>;
+    constexpr int smem = 2 * 65536 + 4 * 8192;            // operand stages + epilogue staging = 160 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int grid = (p.M / 256) * (p.N / 256);
+    if (grid > 256) grid = 256;
+    grid = (grid + 7) / 8 * 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, p);
+    return hipGetLastError();
+}
+template <int EPI>
+inline bool w4_ok(const GemmParams& p) {      // whole tiles only (the kernel has the guard-free epilogue path alone)
+    return p.M % 256 == 0 && p.N % 256 == 0 && p.K % 128 == 0 && p.K >= 128 && ((p.ldo & 7) == 0 || is_qk_epi(EPI) || EPI == EPI_VT) &&
+           (EPI != EPI_VT || ((p.rows_per_sample | p.s_off) & 7) == 0);
+}
+
 template <int BM, int BN, int WM, int WN, int EPI, bool CONV = false>
 hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
     using C = Cfg<BM, BN, WM, WN>;
@@ -795,6 +994,19 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     const double cost_pp = 4.0 * (double)((big + 255) / 256), cost_128 = 2.78 * (double)((t128 + 511) / 512);
     if constexpr (EPI != EPI_UNPATCH) {   // (proj_out, N = 64: scalar-scatter epilogue, always the 128x128 kernel)
+        if ((g_gemm_variant == 2 || (g_gemm_variant == 1 && p.K <= g_w4_max_k)) && big >= g_pp_min_tiles && w4_ok<EPI>(p) && cost_pp <= cost_128) {
+            if constexpr (EPI == EPI_BIAS) {      // ablation builds of the hand-scheduled loop (scripts/gemm_ab.py): 33 no loads, 34 no fragment reads, 35 MFMA only
+                switch (p.dbg_skip_prefetch) {
+                    case 33: return launch_w4<EPI, 1>(p, stream);
+                    case 34: return launch_w4<EPI, 2>(p, stream);
+                    case 35: return launch_w4<EPI, 3>(p, stream);
+                    case 36: return launch_w4<EPI, 4>(p, stream);      // schedule s1 (valid results)
+                    case 37: return launch_w4<EPI, 5>(p, stream);      // schedule s3 (valid results)
+                    default: break;
+                }
+            }
+            return launch_w4<EPI>(p, stream);
+        }
         if (big >= g_pp_min_tiles && fits32 && cost_pp <= cost_128) {
             if constexpr (EPI == EPI_BIAS) {      // ablation builds (scripts/gemm_ablate.py)
                 switch (p.dbg_skip_prefetch) {
@@ -837,6 +1049,7 @@ hipError_t launch_simple(const GemmParams& p, hipStream_t stream) {
 
 void set_conv_cfg(int v) { g_conv_cfg = v; }
 void set_gemm_variant(int v) { g_gemm_variant = v; }
+void set_w4_max_k(int v) { g_w4_max_k = v; }
 void set_pp_min_tiles(int v) { g_pp_min_tiles = v; }
 int get_gemm_variant() { return g_gemm_variant; }
 

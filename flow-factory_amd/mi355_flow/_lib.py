@@ -103,6 +103,7 @@ SIGNATURES = {
     "mi355_op_attention_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
     "mi355_op_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I]),
     "mi355_op_linear_trace": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "mi355_op_linear_gate_res": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
     "mi355_clock_probe": (_I, [_P, _P, _I, _I]),
     "mi355_op_attention": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "mi355_op_ln_modulate": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F]),

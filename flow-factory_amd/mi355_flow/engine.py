@@ -454,3 +454,38 @@ def op_linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, act: int = 0
     out = torch.empty((M, N), device=x.device, dtype=torch.bfloat16)
     _lib.check(lib.mi355_op_linear(_stream(), _ptr(x), _ptr(w), _ptr(bias), _ptr(out), M, N, K, act), "op_linear")
     return out
+
+
+def op_linear_gate_res(x: torch.Tensor, a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, gate: torch.Tensor, rows_per_sample: int) -> torch.Tensor:
+    """x (bf16 [M, N], updated IN PLACE and returned) += gate[m // rows_per_sample] * (a @ w.T + bias)."""
+    lib = _lib.load()
+    a, w, gate = _bf16c(a), _bf16c(w), _bf16c(gate)
+    bias = bias.to(torch.float32).contiguous()
+    M, K = a.shape
+    N = w.shape[0]
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.shape == (M, N) and gate.shape == ((M + rows_per_sample - 1) // rows_per_sample, N)
+    _lib.check(lib.mi355_op_linear_gate_res(_stream(), _ptr(a), _ptr(w), _ptr(bias), _ptr(gate), _ptr(x), M, N, K, rows_per_sample),
+               "op_linear_gate_res")
+    return x
+
+
+def op_attention(q: torch.Tensor, k: torch.Tensor, vT: torch.Tensor, S: int, n_img: int):
+    """q,k: [B,H,S_pad,64] bf16; vT: [B,H,64,S_pad] bf16 -> (o_img [B*n_img, H*64], o_ctx [B*(S-n_img), H*64])."""
+    lib = _lib.load()
+    B, H, S_pad, hd = q.shape
+    assert hd == 64 and vT.shape == (B, H, 64, S_pad)
+    o_img = torch.empty((B * n_img, H * 64), device=q.device, dtype=torch.bfloat16)
+    o_ctx = torch.empty((max(B * (S - n_img), 1), H * 64), device=q.device, dtype=torch.bfloat16)
+    _lib.check(lib.mi355_op_attention(_stream(), _ptr(q.contiguous()), _ptr(k.contiguous()), _ptr(vT.contiguous()),
+                                      _ptr(o_img), _ptr(o_ctx), B, H, S, S_pad, n_img), "op_attention")
+    return o_img, o_ctx[: B * (S - n_img)]
+
+
+def op_ln_modulate(x: torch.Tensor, shift: torch.Tensor, scale: torch.Tensor, rows_per_sample: int, eps: float = 1e-6):
+    lib = _lib.load()
+    M, D = x.shape
+    mod = torch.stack([_bf16c(shift), _bf16c(scale)], 0).contiguous()  # [2][nb][D]: one allocation
+    out = torch.empty_like(x)
+    _lib.check(lib.mi355_op_ln_modulate(_stream(), _ptr(_bf16c(x)), _ptr(mod[0]), _ptr(mod[1]), _ptr(out), M, D,
+                                        rows_per_sample, eps), "op_ln_modulate")
+    return out

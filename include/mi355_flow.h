@@ -162,6 +162,11 @@ int mi355_op_attention_fwd_bwd(void* stream, const void* q, const void* k, const
 /* out[M][N] (bf16, ld = N) = A[M][K] . W[N][K]^T + bias[N] (fp32 bias); act: 0 none, 1 silu, 2 gelu-tanh */
 int mi355_op_linear(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                     int act);
+/* x[M][N] (bf16, in place) += gate[m / rows_per_sample][N] (bf16) * (A . W^T + bias): the gated-residual GEMM epilogue of the attention
+ * out-projections and the second MLP linears (reference: the `hidden_states + gate.unsqueeze(1) * attn_output` lines of diffusers'
+ * JointTransformerBlock.forward, reached from models/stable_diffusion/sd3_5.py:421-428) as an operator */
+int mi355_op_linear_gate_res(void* stream, const void* A, const void* W, const float* bias, const void* gate, void* x, int M, int N, int K,
+                             int rows_per_sample);
 /* debug: mi355_op_linear (act 0) that also records s_memtime stamps per workgroup / tile / wave-group:
  * trace[((wg*16 + tile_iter)*2 + group)*4 + {0: tile start, 1: main loop start, 2: main loop end, 3: stores drained}] */
 int mi355_op_linear_trace(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
@@ -371,7 +376,9 @@ int mi355_op_group_norm(void* stream, const void* x, const float* gamma, const f
  * enable(1) starts recording every launch of {attention, gemm, ln_modulate, sde_step, misc};
  * collect() waits for the events and returns summed elapsed milliseconds and launch counts (5 each). */
 int mi355_profile_enable(int on);
-/* A/B knob for kernel variants (key 0 = schedule of the 256x256 GEMM: 0 simple 2-stage, 1 ping-pong (default);
+/* A/B knob for kernel variants (key 0 = large-grid 256x256 GEMM kernel: 0 simple 2-stage; 1 (default) the 4-wave kernel with the
+ *         hand-scheduled main loop where it applies (whole 256x256 tiles, K % 128 == 0) up to K = <key 19> (default 3072), else the 8-wave
+ *         ping-pong kernel; 2 the 4-wave kernel wherever it applies; 3 the ping-pong kernel only.  Results are bit-identical for 1, 2, 3;
  * key 1 = attention softmax: 0 plain online softmax, 1 deferred rescale (default);
  * key 2 = hipGraph replay of the rollout loop: 0 eager launches, 1 captured graph (default);
  * key 3 = smallest 256x256-tile grid that takes the ping-pong kernel (default 128);
@@ -387,13 +394,13 @@ int mi355_profile_enable(int on);
  *         key 10 = fork point in dual-attention blocks: 1 after the block's last attention, 0 right after the joint attention, 2 (default)
  *         = 1 for plans with more than 16384 image rows, else 0.
  *         Results are bit-identical for every value.
- *  12/13  the same for the Qwen-Image engine (mi355_qwen_*): 0 (default) = single stream, 1 = text chain of every block on a plan-owned
- *         side stream, 2 = when the image stream has at most <key 13> rows (default 16384).  Opt-in until measured on the GPU.
- *  14/15  the same for the double blocks of the FLUX.1 engine (mi355_flux_*).  Opt-in until measured on the GPU.
- *  16     FLUX.1 engine: 1 = mi355_flux_rollout replays its N-step loop as one hipGraph (captured on the second call of a configuration,
- *         like key 2 for the SD3.5 engine); 0 (default) = eager launches.  A failed capture is an error, not a fallback.  Opt-in until measured.
+ *  12/13  the same for the Qwen-Image engine (mi355_qwen_*): 0 = single stream, 1 = text chain of every block on a plan-owned side stream,
+ *         2 (default) = when the image stream has at most <key 13> rows (default 16384).  Measured +3 ... +52 % (profiles/r03a_*).
+ *  14/15  the same for the double blocks of the FLUX.1 engine (mi355_flux_*); default 2.  Measured +3 ... +22 %.
+ *  16     FLUX.1 engine: 1 (default) = mi355_flux_rollout replays its N-step loop as one hipGraph (captured on the second call of a
+ *         configuration, like key 2 for the SD3.5 engine); 0 = eager launches.  A failed capture is an error, not a fallback.
  *  17     the same for mi355_qwen_rollout (the prompt preparation, which uploads the per-sample key lengths, stays in front of the graph).
- *  18     the same for mi355_wan_rollout.
+ *  19     largest K that key 0 = 1 gives to the 4-wave GEMM kernel (default 3072).
  * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);
