@@ -42,8 +42,8 @@ __device__ __forceinline__ void tile_coords(int tile, int ntm, int ntn, int gm, 
 }
 int g_gemm_variant = 1;  // large grids: 0 simple 2-stage kernel; 1 (default) the 4-wave kernel with the hand-scheduled loop where it applies and
                          // K <= g_w4_max_k, else the persistent ping-pong kernel; 2 the 4-wave kernel wherever it applies; 3 ping-pong only
-int g_w4_max_k = 3072;   // measured (profiles/r03e_gemm_w4_ab.txt): w4 +5 ... +10 % at K = 1536, -8 % at K = 6144 (16 loads per wave and K-tile
-                         // concentrated in half an interval: too little flight time for rows 12 KiB apart streaming from HBM)
+int g_w4_max_k = 3072;   // microbenchmark (profiles/r03e_gemm_w4_ab.txt): w4 +5 ... +10 % at K = 1536, -8 % at K = 6144 (16 loads per wave and
+                         // K-tile concentrated in half an interval: too little flight time for rows 12 KiB apart streaming from HBM)
 // (a 32x32x16-MFMA / 2-phases-per-K-tile ping-pong variant was measured 6-10 % SLOWER than the 16x16x32 / 4-phase one
 //  on every shape of this model and was dropped: profiles/r01_gemm_variants.txt)
 
@@ -190,6 +190,7 @@ struct BiasPre { float4 v[4]; };      // by value: a pointer to a caller's array
 template <int EPI, int NR, bool FULL = false, bool PRE = false>
 __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (&acc)[NR][4], int m_base, int n_base,
                                               char* stg, int lane, BiasPre bpre = BiasPre()) {
+
     const int frow = lane & 15, fkg = lane >> 4;
     float4 bcol[4];
     float4 nw[4];
@@ -994,7 +995,11 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     const double cost_pp = 4.0 * (double)((big + 255) / 256), cost_128 = 2.78 * (double)((t128 + 511) / 512);
     if constexpr (EPI != EPI_UNPATCH) {   // (proj_out, N = 64: scalar-scatter epilogue, always the 128x128 kernel)
-        if ((g_gemm_variant == 2 || (g_gemm_variant == 1 && p.K <= g_w4_max_k)) && big >= g_pp_min_tiles && w4_ok<EPI>(p) && cost_pp <= cost_128) {
+        // default dispatch, from IN-MODEL per-kernel durations (profiles/r03g_*: the rollout runs at the package power cap, where the 4-wave
+        // kernel's +5 ... +10 % of the back-to-back microbenchmark shrink to -2.8 % time on the wide MLP projection, +-0 on q|k, and turn into
+        // +2 ... +4 % on the N = 1536 gated-residual and V^T shapes, whose read-modify-write / scatter epilogues its single wave per SIMD exposes)
+        const bool w4_default = p.K <= g_w4_max_k && p.N >= 3072 && EPI != EPI_VT && EPI != EPI_GATE_RES;
+        if ((g_gemm_variant == 2 || (g_gemm_variant == 1 && w4_default)) && big >= g_pp_min_tiles && w4_ok<EPI>(p) && cost_pp <= cost_128) {
             if constexpr (EPI == EPI_BIAS) {      // ablation builds of the hand-scheduled loop (scripts/gemm_ab.py): 33 no loads, 34 no fragment reads, 35 MFMA only
                 switch (p.dbg_skip_prefetch) {
                     case 33: return launch_w4<EPI, 1>(p, stream);

@@ -10,7 +10,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    for key, tag in (("attn_kernel", "attn_kernel"), ("gemm_pp_kernel", None), ("gemm_kernel", None), ("ln_mod_kernel", "ln_mod_kernel"),
+    for key, tag in (("attn_kernel", "attn_kernel"), ("gemm_w4_kernel", None), ("gemm_pp_kernel", None), ("gemm_kernel", None), ("ln_mod_kernel", "ln_mod_kernel"),
                      ("sde_step_kernel", "sde_step_kernel"), ("patchify", "patchify_kernel"), ("time_proj", "time_proj_kernel"),
                      ("convert_kernel", "convert_kernel"), ("pos_crop", "pos_crop_kernel"), ("gn_partial", "gn_partial_kernel"),
                      ("gn_finalize", "gn_finalize_kernel"), ("gn_apply", "gn_apply_kernel"), ("softmax_rows", "softmax_rows_kernel"),
@@ -22,6 +22,9 @@ def short(name):
             import re
             epi = ["bias", "bias_silu", "bias_gelu", "posadd", "addsrc_silu", "gate_res", "qk_norm", "vT", "unpatch", "bias_row",
                    "f32", "img", "dgelu", "qk_norm_rstd"]
+            m4 = re.search(r"gemm_w4_kernel<(\d+)(?:, \d+)?>", name)
+            if m4:
+                return f"gemm_w4<256x256,{epi[int(m4.group(1))]}>"
             mp = re.search(r"gemm_pp_kernel<(\d+)(?:, \d+)?>", name)
             if mp:
                 return f"gemm_pp<256x256,{epi[int(mp.group(1))]}>"
@@ -72,7 +75,7 @@ if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
     except Exception:
         sha = ""
     sha = sha or os.environ.get("MI355_COMMIT", "unknown")
-    json.dump({"round": 2, "commit": sha, "kernel": "mi355::attn_kernel (mean over the joint S=4429 and dual S=4096 launches of a forward, forward batch 8)",
+    json.dump({"round": int(os.environ.get("MI355_ROUND", "3")), "commit": sha, "kernel": "mi355::attn_kernel (mean over the joint S=4429 and dual S=4096 launches of a forward, forward batch 8)",
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 0 --denoise-steps 2",
                "FETCH_SIZE_kb_per_launch": a["FETCH_SIZE"], "WRITE_SIZE_kb_per_launch": a["WRITE_SIZE"],
                "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> doubled; WRITE_SIZE as is",
