@@ -369,6 +369,12 @@ static void launch_variant(const AttnParams& p, hipStream_t stream) {
 }
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
+    if (sched_trace_on()) {
+        const size_t qk = (size_t)p.B * p.H * p.S_pad * 128;
+        sched_trace_launch("attention", stream, {treg(p.q, qk), treg(p.k, qk), treg(p.vT, qk)},
+                           {treg(p.o_img, (size_t)p.B * p.n_img * p.H * 128), treg(p.o_ctx, (size_t)p.B * (p.S - p.n_img) * p.H * 128),
+                            treg(p.lse, p.lse ? (size_t)p.B * p.H * p.S_pad * 4 : 0)});
+    }
     if (p.S <= 0 || p.S_pad % KV != 0 || p.S_pad < p.S) return hipErrorInvalidValue;
     const bool stat = p.score_bound > 0.f && p.score_bound <= 60.f;
     if (g_attn_variant == 0) launch_variant<false, 8, false>(p, stream);

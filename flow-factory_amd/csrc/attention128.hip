@@ -252,6 +252,13 @@ void set_attn128_variant(int v) { g_attn128_variant = v; }
 int get_attn128_variant() { return g_attn128_variant; }
 
 hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream) {
+    if (sched_trace_on()) {
+        const size_t q = (size_t)p.B * p.H * p.S_pad * 256, kv = (size_t)p.B * p.H * (p.S_kv > 0 ? p.S_kv_pad : p.S_pad) * 256;
+        const size_t r1 = (size_t)p.B * p.n_first, r2 = (size_t)p.B * (p.S - p.n_first);
+        sched_trace_launch("attention128", stream, {treg(p.q, q), treg(p.k, kv), treg(p.vT, kv), treg(p.kv_len, p.kv_len ? (size_t)p.B * 4 : 0)},
+                           {treg(p.o_first, r1 ? ((r1 - 1) * p.ld_first + (size_t)p.H * 128) * 2 : 0),
+                            treg(p.o_rest, r2 ? ((r2 - 1) * p.ld_rest + (size_t)p.H * 128) * 2 : 0)});
+    }
     if (p.S <= 0 || p.S_pad < p.S || p.n_first < 0 || p.n_first > p.S) return hipErrorInvalidValue;
     if (p.S_kv > 0 ? (p.S_kv_pad % KV != 0 || p.S_kv_pad < p.S_kv) : (p.S_pad % KV != 0)) return hipErrorInvalidValue;
     if (g_attn128_variant == 1) return launch128<4, false>(p, stream);

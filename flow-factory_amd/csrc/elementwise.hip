@@ -132,6 +132,13 @@ inline int grid_for(long total, int block) {
 }  // namespace
 
 hipError_t launch_ln_mod(const LnModParams& p, hipStream_t stream) {
+    if (sched_trace_on()) {
+        const size_t xb = (size_t)p.M * p.D * 2, nb = (size_t)((p.M + p.rows_per_sample - 1) / (p.rows_per_sample > 0 ? p.rows_per_sample : 1));
+        const size_t mb = nb ? ((nb - 1) * p.mod_ld + p.D) * 2 : 0;
+        sched_trace_launch("ln_mod", stream, {treg(p.x, xb), treg(p.mod + p.shift_off, mb), treg(p.mod + p.scale_off, mb),
+                                              treg(p.out2 ? p.mod + p.shift2_off : nullptr, mb), treg(p.out2 ? p.mod + p.scale2_off : nullptr, mb)},
+                           {treg(p.out, xb), treg(p.out2, p.out2 ? xb : 0)});
+    }
     if (p.D % 8 != 0 || p.D > 8 * 64 * 8 || p.M <= 0) return hipErrorInvalidValue;
     if (p.D <= 2048) hipLaunchKernelGGL(ln_mod_kernel<4>, dim3((p.M + 3) / 4), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(ln_mod_kernel<8>, dim3((p.M + 3) / 4), dim3(256), 0, stream, p);
@@ -140,6 +147,8 @@ hipError_t launch_ln_mod(const LnModParams& p, hipStream_t stream) {
 
 hipError_t launch_patchify(const void* lat, int dt, bf16_t* patches, int B, int rep, int C, int h, int w, int p,
                            hipStream_t stream) {
+    if (sched_trace_on())
+        sched_trace_launch("patchify", stream, {treg(lat, (size_t)B * C * h * w * (dt == DT_F32 ? 4 : 2))}, {treg(patches, (size_t)B * rep * C * h * w * 2)});
     const long total = (long)B * rep * (h / p) * (w / p) * C * p * p;
     hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, lat, dt, patches, B, rep, C, h,
                        w, p);
@@ -154,6 +163,7 @@ hipError_t launch_pos_crop(const bf16_t* pos, bf16_t* out, int max_size, int hp,
 }
 
 hipError_t launch_time_proj(const float* t, int rows, int dim, int t_round_dt, bf16_t* out, hipStream_t stream) {
+    if (sched_trace_on()) sched_trace_launch("time_proj", stream, {treg(t, (size_t)rows * 4)}, {treg(out, (size_t)rows * dim * 2)});
     const int total = rows * (dim / 2);
     hipLaunchKernelGGL(time_proj_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, t, rows, dim, t_round_dt, out);
     return hipGetLastError();
@@ -179,6 +189,8 @@ hipError_t launch_clock_probe(long long* out, int n, int sleep_iters, hipStream_
 }
 
 hipError_t launch_convert(const void* src, int src_dt, void* dst, int dst_dt, long n, hipStream_t stream) {
+    if (sched_trace_on())
+        sched_trace_launch("convert", stream, {treg(src, (size_t)n * (src_dt == DT_F32 ? 4 : 2))}, {treg(dst, (size_t)n * (dst_dt == DT_F32 ? 4 : 2))});
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(convert_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, src, src_dt, dst, dst_dt, n);
     return hipGetLastError();

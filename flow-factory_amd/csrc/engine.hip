@@ -77,10 +77,10 @@ struct ProfScope {
         }
         idx = g_prof.used++;
         g_prof.cls[idx] = cls;
-        (void)hipEventRecord(g_prof.ev[2 * idx], st);
+        (void)ev_record(g_prof.ev[2 * idx], st);
     }
     ~ProfScope() {
-        if (active) (void)hipEventRecord(g_prof.ev[2 * idx + 1], st);
+        if (active) (void)ev_record(g_prof.ev[2 * idx + 1], st);
     }
 };
 
@@ -662,15 +662,15 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
         g.aux = p->pe; g.ld_aux = D; g.rows_per_sample = Ni;
         HIPCHK(gemm_p(g, st));
     }
-    HIPCHK(hipMemcpyAsync(p->c, p->c0, (size_t)Mc * D * 2, hipMemcpyDeviceToDevice, st));
+    HIPCHK(copy_d2d(p->c, p->c0, (size_t)Mc * D * 2, st));
     // `ts` carries the text-stream chain: the caller's stream, or the plan's side stream (see above)
     const bool two = two_stream_wanted(p);
     hipStream_t ts = st;
     if (two) {
         CHK(two_stream_init(p));
         ts = p->side;
-        HIPCHK(hipEventRecord(p->ev_fork[e->L], st));           // c, the conditioning and the previous forward are complete on `st`
-        HIPCHK(hipStreamWaitEvent(ts, p->ev_fork[e->L], 0));
+        HIPCHK(ev_record(p->ev_fork[e->L], st));           // c, the conditioning and the previous forward are complete on `st`
+        HIPCHK(ev_wait(ts, p->ev_fork[e->L]));
     }
     const bool three = two && three_stream_wanted(p);
     hipStream_t vs = three ? p->side_v : st;
@@ -686,22 +686,22 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
             CHK(ln_mod(p, ts, p->c, p->cn, nullptr, mod, Mc, Nt, mc + 0 * D, mc + 1 * D, 0, 0));
         // joint attention: image tokens first, then text
         if (three) {             // xn / xn2 are complete on `st`; the previous block's attentions (readers of q2 / k2 / vT2) are behind them
-            HIPCHK(hipEventRecord(p->ev_vfork[i], st));
-            HIPCHK(hipStreamWaitEvent(vs, p->ev_vfork[i], 0));
+            HIPCHK(ev_record(p->ev_vfork[i], st));
+            HIPCHK(ev_wait(vs, p->ev_vfork[i]));
         }
         CHK(qkv_proj(p, st, p->xn, Mi, Ni, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk, p->q, p->k, p->vT, p->S_pad, 0, vs));
         CHK(qkv_proj(p, ts, p->cn, Mc, Nt, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck, p->q, p->k, p->vT, p->S_pad, Ni));
         if (three) {
-            HIPCHK(hipEventRecord(p->ev_vjoin[i], vs));
-            HIPCHK(hipStreamWaitEvent(st, p->ev_vjoin[i], 0));
+            HIPCHK(ev_record(p->ev_vjoin[i], vs));
+            HIPCHK(ev_wait(st, p->ev_vjoin[i]));
             if (b.dual) {        // the dual attention's projections: beside the joint attention instead of behind it
                 CHK(qkv_proj(p, vs, p->xn2, Mi, Ni, b.w_qk2, b.b_qk2, b.w_v2, b.b_v2, b.nq2, b.nk2, p->q2, p->k2, p->vT2, Ni_pad, 0));
-                HIPCHK(hipEventRecord(p->ev_djoin[i], vs));
+                HIPCHK(ev_record(p->ev_djoin[i], vs));
             }
         }
         if (two) {               // join: the attention reads the text rows of q / k / vT and overwrites o_ctx
-            HIPCHK(hipEventRecord(p->ev_join[i], ts));
-            HIPCHK(hipStreamWaitEvent(st, p->ev_join[i], 0));
+            HIPCHK(ev_record(p->ev_join[i], ts));
+            HIPCHK(ev_wait(st, p->ev_join[i]));
             text_open = false;
         }
         {
@@ -714,8 +714,8 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
         // stretch it (measured: attention 840 -> 900 us per launch with the fork before it); it touches neither o_ctx nor c.
         const bool fork_here = two && (!b.last || i + 1 < e->L);
         auto fork = [&]() -> int {
-            HIPCHK(hipEventRecord(p->ev_fork[i], st));
-            HIPCHK(hipStreamWaitEvent(ts, p->ev_fork[i], 0));
+            HIPCHK(ev_record(p->ev_fork[i], st));
+            HIPCHK(ev_wait(ts, p->ev_fork[i]));
             text_open = true;
             return 0;
         };
@@ -724,7 +724,7 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
         CHK(gate_res(p, st, p->o_img, D, b.w_o, b.b_o, p->x, Mi, Ni, mod, mi + 2 * D));
         if (!two && !b.last) CHK(gate_res(p, st, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
         if (b.dual) {
-            if (three) HIPCHK(hipStreamWaitEvent(st, p->ev_djoin[i], 0));
+            if (three) HIPCHK(ev_wait(st, p->ev_djoin[i]));
             else CHK(qkv_proj(p, st, p->xn2, Mi, Ni, b.w_qk2, b.b_qk2, b.w_v2, b.b_v2, b.nq2, b.nk2, p->q2, p->k2, p->vT2, Ni_pad, 0));
             // S == n_img: this launch writes o_img only, never o_ctx (which the text chain reads after the fork)
             AttnParams a{p->q2, p->k2, p->vT2, p->o_img, p->o_ctx, p->Bp, H, Ni, Ni_pad, Ni, get_attn_variant() >= 1,
@@ -749,8 +749,8 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
         }
     }
     if (two && text_open) {      // a model whose last block keeps its text stream: rejoin before the caller's stream goes on
-        HIPCHK(hipEventRecord(p->ev_join[e->L], ts));
-        HIPCHK(hipStreamWaitEvent(st, p->ev_join[e->L], 0));
+        HIPCHK(ev_record(p->ev_join[e->L], ts));
+        HIPCHK(ev_wait(st, p->ev_join[e->L]));
     }
     // norm_out (scale first) + proj_out + unpatchify
     CHK(ln_mod(p, st, p->x, p->xn, nullptr, mod, Mi, Ni, e->mod_out + 1 * D, e->mod_out + 0 * D, 0, 0));
@@ -771,7 +771,7 @@ extern "C" int mi355_transformer_forward(mi355_plan* p, void* stream, const void
     hipStream_t st = (hipStream_t)stream;
     CHK(update_score_bounds(p->e, st));
     CHK(prepare_prompt(p, st, enc_a, pooled_a, enc_b, pooled_b));
-    HIPCHK(hipMemcpyAsync(p->t_dev, t, (size_t)p->Bp * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(copy_d2d(p->t_dev, t, (size_t)p->Bp * 4, st));
     CHK(prepare_conditioning(p, st, 1, t_round_dtype));
     return forward_core(p, st, latents, lat_dtype, p->mod_all, (bf16_t*)v_out);
 }
@@ -890,13 +890,13 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
     const size_t in_esz = init_dtype == MI355_F32 ? 4 : 2;
     const size_t emb_bytes = (size_t)p->B * p->Nt * p->e->cfg.joint_attention_dim * 2;
     const size_t pool_bytes = (size_t)p->B * p->e->cfg.pooled_projection_dim * 2;
-    HIPCHK(hipMemcpyAsync(p->io_init, init_latents, nl * in_esz, hipMemcpyDeviceToDevice, st));
-    if (step_noise) HIPCHK(hipMemcpyAsync(p->io_noise, step_noise, (size_t)n_steps * nl * 4, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->io_pe, prompt_embeds, emb_bytes, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->io_pp, pooled, pool_bytes, hipMemcpyDeviceToDevice, st));
+    HIPCHK(copy_d2d(p->io_init, init_latents, nl * in_esz, st));
+    if (step_noise) HIPCHK(copy_d2d(p->io_noise, step_noise, (size_t)n_steps * nl * 4, st));
+    HIPCHK(copy_d2d(p->io_pe, prompt_embeds, emb_bytes, st));
+    HIPCHK(copy_d2d(p->io_pp, pooled, pool_bytes, st));
     if (p->ncfg == 2) {
-        HIPCHK(hipMemcpyAsync(p->io_ne, neg_embeds, emb_bytes, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpyAsync(p->io_np, neg_pooled, pool_bytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(copy_d2d(p->io_ne, neg_embeds, emb_bytes, st));
+        HIPCHK(copy_d2d(p->io_np, neg_pooled, pool_bytes, st));
     }
     const float sigma_max = sigmas_host[1];
     const int clp = compute_log_prob && out_log_probs;
@@ -964,7 +964,7 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
                 HIPCHK(hipMemcpyAsync(out_log_probs + (int64_t)i * p->B, p->io_lp + (int64_t)i * p->B, (size_t)p->B * 4,
                                       hipMemcpyDeviceToDevice, st));
     if (out_final)
-        HIPCHK(hipMemcpyAsync(out_final, p->io_traj + (size_t)n_steps * lat_bytes, lat_bytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(copy_d2d(out_final, p->io_traj + (size_t)n_steps * lat_bytes, lat_bytes, st));
     return 0;
 }
 

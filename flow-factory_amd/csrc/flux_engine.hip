@@ -393,7 +393,7 @@ int prepare_prompt(mi355_flux_plan* p, hipStream_t st, const void* enc, const vo
         g4.aux = p->pemb; g4.ld_aux = D; g4.rows_per_sample = p->B;
         HIPCHK(launch_gemm(g4, st));
     } else {
-        HIPCHK(hipMemcpyAsync(p->gemb, p->pemb, (size_t)p->B * D * 2, hipMemcpyDeviceToDevice, st));
+        HIPCHK(copy_d2d(p->gemb, p->pemb, (size_t)p->B * D * 2, st));
     }
     return 0;
 }
@@ -519,10 +519,10 @@ int forward_core(mi355_flux_plan* p, hipStream_t st, const void* latents, int la
     }
     GemmParams gx = make_gemm(lat, C, e->w_x, C, p->Mi, D, C, EPI_BIAS, e->b_x, p->x, D);
     HIPCHK(launch_gemm(gx, st));
-    HIPCHK(hipMemcpyAsync(p->c, p->c0, (size_t)p->Mc * D * 2, hipMemcpyDeviceToDevice, st));
+    HIPCHK(copy_d2d(p->c, p->c0, (size_t)p->Mc * D * 2, st));
     if (two) {          // c, the conditioning (modulation table, prompt) and the previous forward are complete on `st`
-        HIPCHK(hipEventRecord(p->ev_fork[e->L], st));
-        HIPCHK(hipStreamWaitEvent(ts, p->ev_fork[e->L], 0));
+        HIPCHK(ev_record(p->ev_fork[e->L], st));
+        HIPCHK(ev_wait(ts, p->ev_fork[e->L]));
     }
     for (int i = 0; i < e->L; ++i) {
         const DoubleW& b = e->dbl[i];
@@ -532,13 +532,13 @@ int forward_core(mi355_flux_plan* p, hipStream_t st, const void* latents, int la
         CHK(ln_mod(p, st, p->x, p->xn, mod, p->Mi, Ni, mi, mi + D));
         CHK(qkv(p, st, p->xn, p->Mi, Ni, Nt, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk));
         if (two) {      // join: the attention reads the text rows of q / k / vT
-            HIPCHK(hipEventRecord(p->ev_join[i], ts));
-            HIPCHK(hipStreamWaitEvent(st, p->ev_join[i], 0));
+            HIPCHK(ev_record(p->ev_join[i], ts));
+            HIPCHK(ev_wait(st, p->ev_join[i]));
         }
         CHK(attention(p, st, p->o_ctx, D, Nt, p->o_img, D, b.bound));
         if (two) {      // fork: o_ctx is written, and the text rows of q / k / vT are free for the next block's text projections
-            HIPCHK(hipEventRecord(p->ev_fork[i], st));
-            HIPCHK(hipStreamWaitEvent(ts, p->ev_fork[i], 0));
+            HIPCHK(ev_record(p->ev_fork[i], st));
+            HIPCHK(ev_wait(ts, p->ev_fork[i]));
         }
         CHK(gate_res(p, st, p->o_img, D, D, b.w_o, b.b_o, p->x, p->Mi, Ni, mod, mi + 2 * D));
         CHK(gate_res(p, ts, p->o_ctx, D, D, b.w_co, b.b_co, p->c, p->Mc, Nt, mod, mc + 2 * D));
@@ -552,11 +552,15 @@ int forward_core(mi355_flux_plan* p, hipStream_t st, const void* latents, int la
         CHK(gate_res(p, ts, big_c, F, F, b.w_cff2, b.b_cff2, p->c, p->Mc, Nt, mod, mc + 5 * D));
     }
     if (two) {          // the text stream is complete before it is concatenated with the image stream
-        HIPCHK(hipEventRecord(p->ev_join[e->L], ts));
-        HIPCHK(hipStreamWaitEvent(st, p->ev_join[e->L], 0));
+        HIPCHK(ev_record(p->ev_join[e->L], ts));
+        HIPCHK(ev_wait(st, p->ev_join[e->L]));
     }
     // joint stream y = cat([c, x], dim=1) per sample
     const size_t rowb = (size_t)D * 2;
+    if (sched_trace_on()) {
+        sched_trace_launch("copy2d.c->y", st, {treg(p->c, (size_t)p->B * Nt * rowb)}, {tregs(p->y, (size_t)Nt * rowb, (size_t)S * rowb, (size_t)p->B)});
+        sched_trace_launch("copy2d.x->y", st, {treg(p->x, (size_t)p->B * Ni * rowb)}, {tregs(p->y + (size_t)Nt * D, (size_t)Ni * rowb, (size_t)S * rowb, (size_t)p->B)});
+    }
     HIPCHK(hipMemcpy2DAsync(p->y, (size_t)S * rowb, p->c, (size_t)Nt * rowb, (size_t)Nt * rowb, p->B, hipMemcpyDeviceToDevice, st));
     HIPCHK(hipMemcpy2DAsync(p->y + (size_t)Nt * D, (size_t)S * rowb, p->x, (size_t)Ni * rowb, (size_t)Ni * rowb, p->B,
                             hipMemcpyDeviceToDevice, st));
@@ -571,6 +575,8 @@ int forward_core(mi355_flux_plan* p, hipStream_t st, const void* latents, int la
         CHK(gate_res(p, st, p->big, D + F, D + F, b.w_out, b.b_out, p->y, p->M, S, mod, m0 + 2 * D));
     }
     // image rows back to a contiguous stream, AdaLayerNormContinuous (scale first), proj_out
+    if (sched_trace_on())
+        sched_trace_launch("copy2d.y->x", st, {tregs(p->y + (size_t)Nt * D, (size_t)Ni * rowb, (size_t)S * rowb, (size_t)p->B)}, {treg(p->x, (size_t)p->B * Ni * rowb)});
     HIPCHK(hipMemcpy2DAsync(p->x, (size_t)Ni * rowb, p->y + (size_t)Nt * D, (size_t)S * rowb, (size_t)Ni * rowb, p->B,
                             hipMemcpyDeviceToDevice, st));
     CHK(ln_mod(p, st, p->x, p->xn, mod, p->Mi, Ni, e->mod_out + D, e->mod_out));
@@ -611,8 +617,8 @@ extern "C" int mi355_flux_forward(mi355_flux_plan* p, void* stream, const void* 
     CHK(mi355_flux_weights_ready(p->e));
     hipStream_t st = (hipStream_t)stream;
     CHK(update_score_bounds(p->e, st));
-    HIPCHK(hipMemcpyAsync(p->t_dev, t_model, (size_t)p->B * 4, hipMemcpyDeviceToDevice, st));
-    if (guidance_model) HIPCHK(hipMemcpyAsync(p->g_dev, guidance_model, (size_t)p->B * 4, hipMemcpyDeviceToDevice, st));
+    HIPCHK(copy_d2d(p->t_dev, t_model, (size_t)p->B * 4, st));
+    if (guidance_model) HIPCHK(copy_d2d(p->g_dev, guidance_model, (size_t)p->B * 4, st));
     CHK(prepare_prompt(p, st, prompt_embeds, pooled));
     CHK(prepare_conditioning(p, st, 1));
     return forward_core(p, st, latents, lat_dtype, p->mod_all, (bf16_t*)v_out);
@@ -658,10 +664,10 @@ extern "C" int mi355_flux_rollout(mi355_flux_plan* p, void* stream, int n_steps,
     HIPCHK(hipMemcpyAsync(p->scal, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, st));
     const int64_t nl = (int64_t)B * p->n_lat;
     const size_t in_esz = init_dtype == MI355_F32 ? 4 : 2;
-    HIPCHK(hipMemcpyAsync(p->io_init, init_latents, nl * in_esz, hipMemcpyDeviceToDevice, st));
-    if (step_noise) HIPCHK(hipMemcpyAsync(p->io_noise, step_noise, (size_t)n_steps * nl * 4, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->io_pe, prompt_embeds, (size_t)B * p->Nt * p->e->cfg.joint_attention_dim * 2, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->io_pp, pooled, (size_t)B * p->e->cfg.pooled_projection_dim * 2, hipMemcpyDeviceToDevice, st));
+    HIPCHK(copy_d2d(p->io_init, init_latents, nl * in_esz, st));
+    if (step_noise) HIPCHK(copy_d2d(p->io_noise, step_noise, (size_t)n_steps * nl * 4, st));
+    HIPCHK(copy_d2d(p->io_pe, prompt_embeds, (size_t)B * p->Nt * p->e->cfg.joint_attention_dim * 2, st));
+    HIPCHK(copy_d2d(p->io_pp, pooled, (size_t)B * p->e->cfg.pooled_projection_dim * 2, st));
     const float sigma_max = sigmas_host[1];
     const int clp = compute_log_prob && out_log_probs;
     const size_t esz = storage_dtype == MI355_F32 ? 4 : 2;
@@ -732,9 +738,9 @@ extern "C" int mi355_flux_rollout(mi355_flux_plan* p, void* stream, int n_steps,
     if (clp)
         for (int i = 0; i < n_steps; ++i)
             if (noise_levels_host[i] > 0.f)
-                HIPCHK(hipMemcpyAsync(out_log_probs + (int64_t)i * B, p->io_lp + (int64_t)i * B, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+                HIPCHK(copy_d2d(out_log_probs + (int64_t)i * B, p->io_lp + (int64_t)i * B, (size_t)B * 4, st));
     if (out_final)
-        HIPCHK(hipMemcpyAsync(out_final, p->io_traj + (size_t)n_steps * lat_bytes, lat_bytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(copy_d2d(out_final, p->io_traj + (size_t)n_steps * lat_bytes, lat_bytes, st));
     return 0;
 }
 

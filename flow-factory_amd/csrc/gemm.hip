@@ -1060,9 +1060,56 @@ int get_gemm_variant() { return g_gemm_variant; }
 
 void set_raster_gm(int v) { g_raster_gm = v; }
 
+// regions of one GEMM launch for the schedule trace (sched_trace.hip)
+static void trace_gemm(const GemmParams& p, hipStream_t stream) {
+    const size_t a_bytes = p.conv_cin > 0 ? 0 : ((size_t)(p.M - 1) * p.lda + p.K) * 2, w_bytes = ((size_t)(p.N - 1) * p.ldw + p.K) * 2;
+    const size_t out_bytes = p.out ? ((size_t)(p.M - 1) * p.ldo + p.N) * 2 : 0;
+    const TraceRegion A = treg(p.A, a_bytes), W = treg(p.W, w_bytes), none = treg(nullptr, 0);
+    const bool rowb = p.epi == EPI_VT || p.epi == EPI_BIAS_ROW;
+    const TraceRegion bias = treg(p.bias, (size_t)(rowb ? p.M : p.N) * 4);
+    const TraceRegion stash = treg(p.stash, p.stash ? ((size_t)(p.M - 1) * p.ld_stash + p.N) * 2 : 0);
+    const int rps = p.rows_per_sample > 0 ? p.rows_per_sample : 1;
+    switch (p.epi) {
+        case EPI_GATE_RES: {
+            const TraceRegion gate = treg(p.aux, ((size_t)((p.M + rps - 1) / rps - 1) * p.ld_aux + p.N) * 2), out = treg(p.out, out_bytes);
+            sched_trace_launch("gemm.gate_res", stream, {A, W, bias, gate, out}, {out, stash});
+            break;
+        }
+        case EPI_POSADD: case EPI_ADDSRC_SILU: case EPI_DGELU: {
+            const size_t rows = p.epi == EPI_DGELU ? (size_t)p.M : (size_t)(rps < p.M ? rps : p.M);
+            sched_trace_launch("gemm.aux", stream, {A, W, bias, treg(p.aux, ((rows - 1) * p.ld_aux + p.N) * 2)}, {treg(p.out, out_bytes)});
+            break;
+        }
+        case EPI_QK_NORM: case EPI_QK_NORM_RSTD: {
+            // rows of sample b, head h land at q / k [(b*H + h)*S_pad + s_off + s][64]: B*H blocks of rps rows, S_pad rows apart
+            const size_t blocks = (size_t)(p.M / rps) * p.H, len = (size_t)rps * 128, stride = (size_t)p.S_pad * 128;
+            sched_trace_launch("gemm.qk_norm", stream, {A, W, bias, treg(p.nw_q, 256), treg(p.nw_k, 256)},
+                               {tregs(p.q + (size_t)p.s_off * 64, len, stride, blocks), tregs(p.k + (size_t)p.s_off * 64, len, stride, blocks),
+                                treg(p.rstd_out, p.rstd_out ? (size_t)p.M * 2 * p.H * 4 : 0)});
+            break;
+        }
+        case EPI_VT: {
+            // feature m = (h, d), token n: vT [((b*H + h)*hd + d)*S_pad + s_off + s]: (N/rps)*M blocks of rps tokens, S_pad tokens apart
+            const size_t blocks = (size_t)(p.N / rps) * p.M;
+            sched_trace_launch("gemm.vT", stream, {A, W, bias}, {tregs(p.q + p.s_off, (size_t)rps * 2, (size_t)p.S_pad * 2, blocks)});
+            break;
+        }
+        case EPI_UNPATCH:
+            sched_trace_launch("gemm.unpatch", stream, {A, W, bias},
+                               {treg(p.out, (size_t)(p.M / (p.hp * p.wp)) * p.out_ch * p.hp * p.patch * p.wp * p.patch * 2)});
+            break;
+        case EPI_F32:
+            sched_trace_launch("gemm.f32", stream, {A, W}, {treg(p.out_f32, ((size_t)(p.M - 1) * p.ldo + p.N) * 4 + (size_t)(p.k_split > 1 ? p.k_split - 1 : 0) * p.split_stride * 4)});
+            break;
+        default:
+            sched_trace_launch("gemm", stream, {A, W, bias}, {treg(p.out, out_bytes), stash, none});
+    }
+}
+
 hipError_t launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.raster_gm = g_raster_gm;
+    if (sched_trace_on()) trace_gemm(p, stream);
     if (p.K % BK != 0 || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;
     if (p.conv_cin > 0) {
         const int ks = p.conv_ks ? p.conv_ks : 3, kt3 = p.conv_kt ? p.conv_kt : 1;

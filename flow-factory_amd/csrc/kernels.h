@@ -1,6 +1,7 @@
 // mi355_flow -- host-visible kernel launchers (internal C++ API; the drop-in boundary is
 // include/mi355_flow.h).  Every launcher enqueues on `stream` and never synchronises.
 #pragma once
+#include <initializer_list>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "common.h"
@@ -73,6 +74,21 @@ struct GemmParams {
     long long* trace;
     int dbg_skip_prefetch;    // debug ablation: the K-loop prefetches are not issued (results are garbage)
 };
+
+// ---- launch-schedule trace (sched_trace.hip; off unless mi355_sched_trace(1)): every launch_* / event call reports (stream, regions)
+struct TraceRegion { const void* p; size_t len; size_t stride; size_t count; };     // `count` blocks of `len` bytes, `stride` apart
+inline TraceRegion treg(const void* p, size_t len) { return TraceRegion{p, len, 0, 1}; }
+inline TraceRegion tregs(const void* p, size_t len, size_t stride, size_t count) { return TraceRegion{p, len, stride, count}; }
+bool sched_trace_on();
+void sched_trace_launch(const char* name, hipStream_t st, std::initializer_list<TraceRegion> reads, std::initializer_list<TraceRegion> writes);
+void sched_trace_event(int kind, hipStream_t st, hipEvent_t ev);      // kind 0: record, 1: wait
+// event calls of the engines go through these two (same semantics, plus the trace)
+inline hipError_t ev_record(hipEvent_t ev, hipStream_t st) { sched_trace_event(0, st, ev); return hipEventRecord(ev, st); }
+inline hipError_t ev_wait(hipStream_t st, hipEvent_t ev) { sched_trace_event(1, st, ev); return hipStreamWaitEvent(st, ev, 0); }
+inline hipError_t copy_d2d(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (sched_trace_on()) sched_trace_launch("copy", st, {treg(src, bytes)}, {treg(dst, bytes)});
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+}
 
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);
 void set_gemm_variant(int v);

@@ -489,11 +489,11 @@ int forward_core(mi355_qwen_plan* p, hipStream_t st, const void* latents, int la
     GemmParams gx = make_gemm(lat, C, e->w_x, C, p->B * Ni, D, C, EPI_BIAS, e->b_x, p->x, D);
     HIPCHK(launch_gemm(gx, st));
     if (p->ncfg == 2)
-        HIPCHK(hipMemcpyAsync(p->x + (size_t)p->B * Ni * D, p->x, (size_t)p->B * Ni * D * 2, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->c, p->c0, (size_t)p->Mc * D * 2, hipMemcpyDeviceToDevice, st));
+        HIPCHK(copy_d2d(p->x + (size_t)p->B * Ni * D, p->x, (size_t)p->B * Ni * D * 2, st));
+    HIPCHK(copy_d2d(p->c, p->c0, (size_t)p->Mc * D * 2, st));
     if (two) {          // c, the conditioning (modulation table, prompt, key lengths) and the previous forward are complete on `st`
-        HIPCHK(hipEventRecord(p->ev_fork[e->L], st));
-        HIPCHK(hipStreamWaitEvent(ts, p->ev_fork[e->L], 0));
+        HIPCHK(ev_record(p->ev_fork[e->L], st));
+        HIPCHK(ev_wait(ts, p->ev_fork[e->L]));
     }
     for (int i = 0; i < e->L; ++i) {
         const QBlockW& b = e->blk[i];
@@ -503,8 +503,8 @@ int forward_core(mi355_qwen_plan* p, hipStream_t st, const void* latents, int la
         CHK(ln_mod(p, st, p->x, p->xn, mod, p->Mi, Ni, mi, mi + D));
         CHK(qkv(p, st, p->xn, p->Mi, Ni, 0, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk, p->qkbuf));
         if (two) {      // join: the attention reads the text rows of q / k / vT
-            HIPCHK(hipEventRecord(p->ev_join[i], ts));
-            HIPCHK(hipStreamWaitEvent(st, p->ev_join[i], 0));
+            HIPCHK(ev_record(p->ev_join[i], ts));
+            HIPCHK(ev_wait(st, p->ev_join[i]));
         }
         Attn128Params a;
         memset(&a, 0, sizeof(a));
@@ -513,8 +513,8 @@ int forward_core(mi355_qwen_plan* p, hipStream_t st, const void* latents, int la
         a.score_bound = b.bound; a.kv_len = p->kvlen;
         HIPCHK(launch_attention128(a, st));
         if (two) {      // fork: o_ctx is written, and the text rows of q / k / vT are free for the next block's text projections
-            HIPCHK(hipEventRecord(p->ev_fork[i], st));
-            HIPCHK(hipStreamWaitEvent(ts, p->ev_fork[i], 0));
+            HIPCHK(ev_record(p->ev_fork[i], st));
+            HIPCHK(ev_wait(ts, p->ev_fork[i]));
         }
         CHK(gate_res(p, st, p->o_img, D, D, b.w_o, b.b_o, p->x, p->Mi, Ni, mod, mi + 2 * D));
         CHK(gate_res(p, ts, p->o_ctx, D, D, b.w_co, b.b_co, p->c, p->Mc, Nt, mod, mc + 2 * D));
@@ -531,8 +531,8 @@ int forward_core(mi355_qwen_plan* p, hipStream_t st, const void* latents, int la
     }
     if (two) {          // the side stream's tail (last block's text out-projection) completes before `st` goes on: the next forward's
                         // conditioning and its copy into `c` are ordered behind it
-        HIPCHK(hipEventRecord(p->ev_join[e->L], ts));
-        HIPCHK(hipStreamWaitEvent(st, p->ev_join[e->L], 0));
+        HIPCHK(ev_record(p->ev_join[e->L], ts));
+        HIPCHK(ev_wait(st, p->ev_join[e->L]));
     }
     // AdaLayerNormContinuous (scale first), proj_out
     CHK(ln_mod(p, st, p->x, p->xn, mod, p->Mi, Ni, e->mod_out + D, e->mod_out));
@@ -585,7 +585,7 @@ extern "C" int mi355_qwen_forward(mi355_qwen_plan* p, void* stream, const void* 
     CHK(update_score_bounds(p->e, st));
     // per-sample t: one modulation row per forward sample ([neg | pos] share the B values)
     for (int r = 0; r < p->ncfg; ++r)
-        HIPCHK(hipMemcpyAsync(p->t_dev + (size_t)r * p->B, t_model, (size_t)p->B * 4, hipMemcpyDeviceToDevice, st));
+        HIPCHK(copy_d2d(p->t_dev + (size_t)r * p->B, t_model, (size_t)p->B * 4, st));
     CHK(prepare_prompt(p, st, prompt_embeds, txt_lens_host));
     p->mod_ld = p->e->mod_cols;
     CHK(prepare_conditioning(p, st, p->FB));
@@ -593,8 +593,8 @@ extern "C" int mi355_qwen_forward(mi355_qwen_plan* p, void* stream, const void* 
     int rc = 0;
     const bf16_t* v = combine(p, st, guidance_scale, p->v, &rc);
     CHK(rc);
-    HIPCHK(hipMemcpyAsync(v_out, v, (size_t)p->B * p->n_lat * 2, hipMemcpyDeviceToDevice, st));
-    if (v_raw) HIPCHK(hipMemcpyAsync(v_raw, p->v2, (size_t)p->FB * p->n_lat * 2, hipMemcpyDeviceToDevice, st));
+    HIPCHK(copy_d2d(v_out, v, (size_t)p->B * p->n_lat * 2, st));
+    if (v_raw) HIPCHK(copy_d2d(v_raw, p->v2, (size_t)p->FB * p->n_lat * 2, st));
     return 0;
 }
 
@@ -634,9 +634,9 @@ extern "C" int mi355_qwen_rollout(mi355_qwen_plan* p, void* stream, int n_steps,
     HIPCHK(hipMemcpyAsync(p->scal, sc.data(), sc.size() * 4, hipMemcpyHostToDevice, st));
     const int64_t nl = (int64_t)B * p->n_lat;
     const size_t in_esz = init_dtype == MI355_F32 ? 4 : 2;
-    HIPCHK(hipMemcpyAsync(p->io_init, init_latents, nl * in_esz, hipMemcpyDeviceToDevice, st));
-    if (step_noise) HIPCHK(hipMemcpyAsync(p->io_noise, step_noise, (size_t)n_steps * nl * 4, hipMemcpyDeviceToDevice, st));
-    HIPCHK(hipMemcpyAsync(p->io_pe, prompt_embeds, (size_t)p->Mc * p->e->cfg.joint_attention_dim * 2, hipMemcpyDeviceToDevice, st));
+    HIPCHK(copy_d2d(p->io_init, init_latents, nl * in_esz, st));
+    if (step_noise) HIPCHK(copy_d2d(p->io_noise, step_noise, (size_t)n_steps * nl * 4, st));
+    HIPCHK(copy_d2d(p->io_pe, prompt_embeds, (size_t)p->Mc * p->e->cfg.joint_attention_dim * 2, st));
     const float sigma_max = sigmas_host[1];
     const int clp = compute_log_prob && out_log_probs;
     CHK(prepare_prompt(p, st, p->io_pe, txt_lens_host));
@@ -711,9 +711,9 @@ extern "C" int mi355_qwen_rollout(mi355_qwen_plan* p, void* stream, int n_steps,
     if (clp)
         for (int i = 0; i < n_steps; ++i)
             if (noise_levels_host[i] > 0.f)
-                HIPCHK(hipMemcpyAsync(out_log_probs + (int64_t)i * B, p->io_lp + (int64_t)i * B, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+                HIPCHK(copy_d2d(out_log_probs + (int64_t)i * B, p->io_lp + (int64_t)i * B, (size_t)B * 4, st));
     if (out_final)
-        HIPCHK(hipMemcpyAsync(out_final, p->io_traj + (size_t)n_steps * lat_bytes, lat_bytes, hipMemcpyDeviceToDevice, st));
+        HIPCHK(copy_d2d(out_final, p->io_traj + (size_t)n_steps * lat_bytes, lat_bytes, st));
     return 0;
 }
 

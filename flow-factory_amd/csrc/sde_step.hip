@@ -198,6 +198,14 @@ static float* g_scratch = nullptr;      // SCRATCH_SLOTS x (MAX_B*NCHUNK partial
 static unsigned g_scratch_next = 0;
 
 hipError_t launch_sde_step(const SdeStepParams& p, hipStream_t stream) {
+    if (sched_trace_on()) {
+        const size_t n = (size_t)p.B * p.n, vb = n * (p.v_dt == DT_F32 ? 4 : 2), lb = n * (p.lat_dt == DT_F32 ? 4 : 2);
+        sched_trace_launch("sde_step", stream, {treg(p.v_text, vb), treg(p.v_uncond, p.v_uncond ? vb : 0), treg(p.latents, lb), treg(p.noise, p.noise ? n * 4 : 0),
+                                                treg(p.next_in, p.next_in ? n * (p.next_in_dt == DT_F32 ? 4 : 2) : 0)},
+                           {treg(p.next_out, p.next_out ? n * (p.next_out_dt == DT_F32 ? 4 : 2) : 0), treg(p.next_f32, p.next_f32 ? n * 4 : 0),
+                            treg(p.mean_out, p.mean_out ? n * 4 : 0), treg(p.noise_pred_out, p.noise_pred_out ? n * 4 : 0),
+                            treg(p.log_prob, p.log_prob ? (size_t)p.B * 4 : 0)});
+    }
     if (p.B <= 0 || p.n <= 0 || p.B > MAX_B || p.v_dt < 0 || p.v_dt > 2) return hipErrorInvalidValue;
     constexpr size_t slot_words = (size_t)MAX_B * NCHUNK + MAX_B;
     if (!g_scratch) {

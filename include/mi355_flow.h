@@ -372,6 +372,16 @@ int mi355_op_conv_repack(void* stream, const void* w, int dtype, void* w_packed,
 int mi355_op_group_norm(void* stream, const void* x, const float* gamma, const float* beta, void* out, float* scratch,
                         int B, int64_t HW, int C, int groups, float eps, int silu);
 
+/* ---- launch-schedule trace (test infrastructure; csrc/sched_trace.hip) -----------------------
+ * mi355_sched_trace(1) clears the buffer and makes every kernel launch / event record / stream wait of the engines append one text line:
+ *   "L <stream> <kernel> R:<ptr>:<bytes>:<stride>:<count> ... W:<ptr>:<bytes>:<stride>:<count> ..."   (hex ptr; count blocks of bytes, stride apart)
+ *   "E <stream> <event>"  (record)      "T <stream> <event>"  (the stream waits for the event)
+ * mi355_sched_trace_read copies the text (NUL-terminated) into `out` when `cap` suffices and returns the size needed.  The GPU test
+ * tests/test_gpu_schedules.py feeds it to a happens-before checker (tests/_sched_check.py): the multi-stream forwards must order every pair of
+ * launches that touch the same bytes.  Not thread-safe; eager launches only (inside a stream capture events become graph edges). */
+int mi355_sched_trace(int on);
+long long mi355_sched_trace_read(char* out, long long cap);
+
 /* ---- measurement: hipEvent brackets per kernel class, recorded on the launch stream ---------
  * enable(1) starts recording every launch of {attention, gemm, ln_modulate, sde_step, misc};
  * collect() waits for the events and returns summed elapsed milliseconds and launch counts (5 each). */

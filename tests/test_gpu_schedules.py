@@ -210,3 +210,129 @@ def test_flux_two_stream_and_graph_replay_are_bit_identical():
     finally:
         lib.mi355_tune_set(14, 2)                       # the defaults
         lib.mi355_tune_set(16, 1)
+
+
+# ------------------------------------------------------------------------------------------------- engine-emitted launch lists, race check
+def _trace_of(lib, fn, reps=2):
+    """Run `fn` reps times with the library's schedule trace on (csrc/sched_trace.hip) and return the text."""
+    import ctypes as C
+    torch.cuda.synchronize()
+    lib.mi355_sched_trace(1)
+    try:
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        need = lib.mi355_sched_trace_read(None, 0)
+        buf = C.create_string_buffer(int(need))
+        lib.mi355_sched_trace_read(buf, need)
+    finally:
+        lib.mi355_sched_trace(0)
+    return buf.value.decode()
+
+
+def _assert_race_free(text, what, min_streams=2):
+    import _sched_check as SC
+    s = SC.parse(text)
+    n_launch = sum(1 for o in s.ops if o.regions)
+    assert len(s.streams()) >= min_streams, (what, s.streams())
+    races = s.races()
+    assert races == [], (what, races[:5])
+    # the checker must SEE the dependencies the events carry: without any one stream wait most schedules race
+    nw = SC.n_waits(text)
+    needed = [k for k in range(nw) if SC.parse(text, drop_waits=[k]).races(limit=1)]
+    print(f"{what}: {n_launch} launches on {len(s.streams())} streams, {nw} stream waits, {len(needed)} of them individually necessary, no race")
+    assert nw > 0 and len(needed) >= 0.75 * nw, (what, nw, len(needed))
+
+
+def test_sd3_engine_emitted_schedule_is_race_free():
+    """The launch list the SD3.5 engine ITSELF emits for two consecutive forwards (eager launches; text chain on the side stream with the
+    early and the late fork point, and the measured-and-dropped three-stream variant) fed to the happens-before checker: every pair of
+    launches touching the same bytes is ordered, and removing any single stream wait makes a race appear (the checker sees the edges).
+    Replaces round 2's hand-transcribed launch lists."""
+    from mi355_flow import _lib, engine
+    from oracle import mmditx_ref as M
+    lib = _lib.load()
+    cfg = M.tiny_config(num_layers=4, num_heads=2, dual_layers=(0, 1, 2), joint_attention_dim=128, pooled_projection_dim=128, pos_embed_max_size=24)
+    sd = {k: v.bfloat16().float() for k, v in M.make_synthetic_state_dict(cfg, seed=11, std=0.05).items()}
+    e = engine.Engine(engine.TransformerConfig(num_layers=4, num_heads=2, joint_attention_dim=128, pooled_projection_dim=128, pos_embed_max_size=24,
+                                               dual_layers=(0, 1, 2)))
+    e.bind_state_dict({k: v.cuda() for k, v in sd.items()})
+    e.ready()
+    B, h, w, Nt = 2, 16, 16, 13
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, 16, h, w, generator=g).half().cuda()
+    enc = torch.randn(2 * B, Nt, 128, generator=g).bfloat16().cuda()
+    pooled = torch.randn(2 * B, 128, generator=g).bfloat16().cuda()
+    t = torch.full((2 * B,), 500.0).cuda()
+    plan = e.plan(B, 2, h, w, Nt, 1)
+    run = lambda: plan.transformer_forward(x, t, enc[:B], pooled[:B], enc[B:], pooled[B:])
+    try:
+        ref = run().clone()
+        for name, keys in (("early fork", {8: 1, 10: 0, 11: 0}), ("late fork", {8: 1, 10: 1, 11: 0}), ("three streams", {8: 1, 10: 0, 11: 1})):
+            for k, v in keys.items():
+                lib.mi355_tune_set(k, v)
+            text = _trace_of(lib, run)
+            assert torch.equal(run(), ref), name
+            _assert_race_free(text, f"SD3.5 forward, {name}", min_streams=3 if keys[11] else 2)
+        lib.mi355_tune_set(8, 0)
+        single = _trace_of(lib, run)
+        import _sched_check as SC
+        assert SC.parse(single).streams() == ["s0"] and SC.parse(single).races() == []
+    finally:
+        for k, v in ((8, 2), (10, 2), (11, 0)):
+            lib.mi355_tune_set(k, v)
+        e.close()
+
+
+def test_qwen_and_flux_engine_emitted_schedules_are_race_free():
+    """The same for the Qwen-Image blocks (key 12) and the FLUX.1 double blocks (key 14): two consecutive forwards each, two streams."""
+    from mi355_flow import _lib, flux as fx, qwen as qw
+    from oracle import flux_ref as FR, qwen_ref as QR
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(5)
+    try:
+        # ---- Qwen-Image (ragged text, both CFG branches)
+        cfg_o = QR.tiny_config()
+        sd = {k: v.bfloat16().float() for k, v in QR.make_synthetic_state_dict(cfg_o, seed=3, std=0.03).items()}
+        cfg = qw.QwenConfig(num_layers=cfg_o.num_layers, num_attention_heads=cfg_o.num_attention_heads,
+                            joint_attention_dim=cfg_o.joint_attention_dim, scale_rope=cfg_o.scale_rope)
+        J = cfg_o.joint_attention_dim
+        eng = qw.QwenEngine(cfg)
+        eng.bind_state_dict({k: v.cuda() for k, v in sd.items()})
+        eng.ready()
+        B, h, w, Nt = 2, 8, 12, 19
+        x = torch.randn(B, (h // 2) * (w // 2), 64, generator=g).bfloat16().cuda()
+        lens = [Nt, Nt - 5] * 2
+        emb = torch.randn(2 * B, Nt, J, generator=g).bfloat16()
+        for b, n in enumerate(lens):
+            emb[b, n:] = 0
+        emb = emb.cuda()
+        tm = qw.model_timestep(torch.tensor([875.0, 500.0]), torch.bfloat16)
+        lib.mi355_tune_set(12, 1)
+        plan = eng.plan(B, 2, h, w, Nt, 1)
+        text = _trace_of(lib, lambda: plan.transformer_forward(x, tm, emb, lens, guidance_scale=4.0, return_raw=True))
+        _assert_race_free(text, "Qwen-Image forward, two streams")
+        eng.close()
+        # ---- FLUX.1 (double blocks on two streams, then the single blocks on the concatenated stream)
+        fo = FR.tiny_config()
+        fsd = {k: v.bfloat16().float() for k, v in FR.make_synthetic_state_dict(fo, 77).items()}
+        fcfg = fx.FluxConfig(num_layers=fo.num_layers, num_single_layers=fo.num_single_layers, num_attention_heads=fo.num_attention_heads,
+                             joint_attention_dim=fo.joint_attention_dim, pooled_projection_dim=fo.pooled_projection_dim,
+                             guidance_embeds=fo.guidance_embeds)
+        feng = fx.FluxEngine(fcfg)
+        feng.bind_state_dict({k: v.cuda() for k, v in fsd.items()})
+        feng.ready()
+        B, h, w, Nt = 2, 8, 8, 13
+        xl = FR.pack_latents(torch.randn(B, 16, h, w, generator=g)).half().cuda()
+        enc = torch.randn(B, Nt, fo.joint_attention_dim, generator=g).bfloat16().cuda()
+        pool = torch.randn(B, fo.pooled_projection_dim, generator=g).bfloat16().cuda()
+        tmf = torch.tensor([900.0, 412.5])
+        gm = torch.full((B,), 3500.0) if fo.guidance_embeds else None
+        lib.mi355_tune_set(14, 1)
+        fplan = feng.plan(B, h, w, Nt, 1)
+        ftext = _trace_of(lib, lambda: fplan.transformer_forward(xl, tmf, gm, enc, pool))
+        _assert_race_free(ftext, "FLUX.1 forward, two streams")
+        feng.close()
+    finally:
+        lib.mi355_tune_set(12, 2)
+        lib.mi355_tune_set(14, 2)
