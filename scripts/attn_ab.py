@@ -20,10 +20,10 @@ for (S, n_img, scale) in [(4429, 4096, 1.0), (4096, 4096, 1.0), (4429, 4096, 3.0
     vT = v.transpose(2, 3).contiguous()
     ref = torch.nn.functional.scaled_dot_product_attention(q[:1, :4, :S].float(), k[:1, :4, :S].float(), v[:1, :4, :S].float()).transpose(1, 2).reshape(1, S, 256)
     fl = 4.0 * B * H * S * S * 64
-    # op-level entry: key 6 >= 2 = the proven |score| bound -> static-softmax kernels (variant 3 needs them); the scaled inputs exceed any
-    # such bound and run the running-max kernels (variant 3 then falls back to variant 1's)
+    # op-level entry: key 6 >= 2 = the proven |score| bound -> static-softmax kernels; the scaled inputs exceed any such bound and run the
+    # running-max kernels.  (variant 3 = row sums on the matrix pipe was measured here in round 3 and deleted: profiles/r03a_attn_ab_variants.txt)
     lib.mi355_tune_set(6, 40 if scale == 1.0 else 0)
-    for var in (0, 1, 2, 3):             # 3 = row sums on the matrix pipe (MSUM; written after round 2's GPU budget was spent)
+    for var in (0, 1, 2):                # 0 plain online softmax, 1 deferred rescale / static (shipped), 2 the same on 4-wave workgroups
         lib.mi355_tune_set(1, var)
         oi, oc = engine.op_attention(q, k, vT, S, n_img)
         got = torch.cat([oi.view(B, n_img, H * 64), oc.view(B, S - n_img, H * 64)], 1)[:1, :, :256].float()

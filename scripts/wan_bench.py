@@ -17,8 +17,6 @@ def main():
     ap.add_argument("--guidance", type=float, default=5.0)
     ap.add_argument("--denoise-steps", type=int, default=4)
     ap.add_argument("--iters", type=int, default=1)
-    ap.add_argument("--ab-graph", action="store_true", help="A/B of the hipGraph replay of the rollout loop (mi355_tune_set key 18) in ONE process: "
-                                                            "same seeded rollout eager / graph, bit-identity asserted (not yet run on the GPU)")
     a = ap.parse_args()
     dev = torch.device("cuda")
     cfg = wan.WanConfig()
@@ -32,29 +30,6 @@ def main():
     run = lambda: ad.inference(prompt=None, height=a.height, width=a.width, num_frames=a.frames, num_inference_steps=N, guidance_scale=a.guidance,
                                prompt_embeds=pe, negative_prompt_embeds=ne, compute_log_prob=True, trajectory_indices="all")
     s = run(); torch.cuda.synchronize()
-    if a.ab_graph:
-        from mi355_flow import _lib
-        lib = _lib.load()
-        res, secs = {}, {}
-        for mode in (0, 1, 0, 1):
-            lib.mi355_tune_set(18, mode)
-            torch.cuda.manual_seed(5)
-            o = run(); torch.cuda.synchronize()                   # (the first graph-mode run of a configuration captures)
-            torch.cuda.manual_seed(5)
-            t0 = time.perf_counter()
-            for _ in range(a.iters): o = run()
-            torch.cuda.synchronize()
-            secs.setdefault(mode, []).append((time.perf_counter() - t0) / a.iters)
-            lat = torch.stack([x.all_latents for x in o])
-            assert mode not in res or torch.equal(res[mode], lat), f"mode {mode}: run-to-run difference"
-            res[mode] = lat
-        lib.mi355_tune_set(18, 0)
-        same = bool(torch.equal(res[0], res[1]))
-        t_a, t_b = min(secs[0]), min(secs[1])
-        print(json.dumps({"ab": "wan graph replay (key 18)", "batch": B, "clip": f"{a.height}x{a.width}x{a.frames}", "denoise_steps": N, "bit_identical": same,
-                          "s_per_rollout_eager": round(t_a, 4), "s_per_rollout_graph": round(t_b, 4), "gain_pct": round((t_a / t_b - 1) * 100, 2)}), flush=True)
-        assert same
-        return
     t0 = time.perf_counter()
     for _ in range(a.iters): s = run()
     torch.cuda.synchronize()
