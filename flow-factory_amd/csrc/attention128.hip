@@ -230,7 +230,165 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn128_kernel(Attn128Params p)
     }
 }
 
-int g_attn128_variant = 0;   // 0: 8 waves x 32 queries, 1 workgroup / CU; 1: 4 waves, 2 workgroups / CU (independent barrier domains)
+// ---------------------------------------------------------------------------------------------------------------------------------
+// 4-wave kernel with a HAND-SCHEDULED key loop (attn128_w4_asm.inc, generated by gen_attn128_w4.py: its docstring has the schedule): one
+// wave per SIMD, TWO chains of 32 queries per wave, the softmax of one chain on the VALU under the MFMAs of the other; static softmax
+// only (score_bound <= 60), self-attention only (S_kv == 0; per-sample key counts `kv_len` supported).  Same LDS images, same K-row
+// permutation, same arithmetic per element as attn128_kernel<8, true> (row sums are formed in another order: results agree to fp32
+// rounding of l, not bit for bit).  The shell owns addressing, Q fragments (written to AGPRs before the loop), finalisation and stores.
+#include "attn128_w4_asm.inc"
+
+template <int RG>
+__global__ __launch_bounds__(256) void attn128_w4_kernel(Attn128Params p) {
+    constexpr int QB = 256;                         // 4 waves x 2 chains x 32 queries
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, lg = lane >> 5;
+    const int nqb = (p.S + QB - 1) / QB;
+    const int nwg = nqb * p.H * p.B;
+    int wid = blockIdx.x;
+    {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = wid & 7;
+        wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (wid >> 3);
+    }
+    const int qblk = wid % nqb;
+    const int bhi = wid / nqb;
+    const int h = bhi % p.H, b = bhi / p.H;
+    const long bh = (long)b * p.H + h;
+    int Skv = p.S;
+    if (p.kv_len) Skv = min(Skv, max(1, __builtin_amdgcn_readfirstlane(p.kv_len[b])));
+    const bf16_t* Qg = p.q + bh * p.S_pad * HD;
+    const bf16_t* Kg = p.k + bh * p.S_pad * HD;
+    const bf16_t* Vg = p.vT + bh * HD * p.S_pad;
+    const int nt = (Skv + KV - 1) / KV;
+
+    // ---- K(0), V^T(0) -> stage 0 of their rings (V ring at LDS 0, K ring at 64 KiB); wave w stages groups w, w + 4, w + 8, w + 12
+    unsigned gk[4], gv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = wave + 4 * i;
+        const int krow = (g & 7) * 8 + (lane >> 3);
+        const int kc = (lane & 7) ^ ((krow >> 1) & 7);
+        gk[i] = (unsigned)((krow * HD + (g >> 3) * 64 + kc * 8) * 2);
+        const int vrow = g * 8 + (lane >> 3);
+        const int vc = (lane & 7) ^ ((vrow >> 1) & 7);
+        gv[i] = (unsigned)(((long)vrow * p.S_pad + vc * 8) * 2);
+        __builtin_amdgcn_global_load_lds((gptr_t)((const char*)Kg + gk[i]), (lptr_t)(smem + 65536 + g * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)((const char*)Vg + gv[i]), (lptr_t)(smem + g * 1024), 16, 0, 0);
+        if (nt > 1) {                           // tile 1 -> stage 1 (the loop loads two tiles ahead)
+            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)Kg + gk[i] + KV * HD * 2), (lptr_t)(smem + 65536 + 16384 + g * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)((const char*)Vg + gv[i] + KV * 2), (lptr_t)(smem + 16384 + g * 1024), 16, 0, 0);
+        }
+    }
+    // ---- Q fragments -> a[128:191] (the MFMA B operand of the S^T products)
+    {
+#define A128_LOADQ(C, KK)                                                                                           \
+        {                                                                                                          \
+            const int q_row = qblk * QB + wave * 64 + C * 32 + lq;                                                \
+            const int q_ld = q_row < p.S ? q_row : p.S - 1;                                                        \
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4;                                            \
+            u32x4 u = *(const u32x4*)(Qg + (long)q_ld * HD + KK * 16 + lg * 8);                                    \
+            if (!p.q_prescaled)                                                                                    \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) u[e] = pack_bf16(bf_lo(u[e]) * SCALE_LOG2E, bf_hi(u[e]) * SCALE_LOG2E); \
+            A128_WRITE_Q_##C##_##KK(u);                                                                            \
+        }
+        A128_LOADQ(0, 0) A128_LOADQ(0, 1) A128_LOADQ(0, 2) A128_LOADQ(0, 3) A128_LOADQ(0, 4) A128_LOADQ(0, 5) A128_LOADQ(0, 6) A128_LOADQ(0, 7)
+        A128_LOADQ(1, 0) A128_LOADQ(1, 1) A128_LOADQ(1, 2) A128_LOADQ(1, 3) A128_LOADQ(1, 4) A128_LOADQ(1, 5) A128_LOADQ(1, 6) A128_LOADQ(1, 7)
+#undef A128_LOADQ
+    }
+    // ---- fragment read bases (lane part; stage and block offsets are immediates / rotated inside the loop)
+    const int krow = key_perm(lq);
+    unsigned vk0, vk1, vk2, vk3, vc0, vc1, vc2, vc3, vp0 = 0, vp1 = 0, vp2 = 0, vp3 = 0;
+    {
+        unsigned t[4], u[4];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) t[k4] = 65536u + (unsigned)(krow * 128 + (((2 * k4 + lg) ^ ((krow >> 1) & 7)) << 4));
+#pragma unroll
+        for (int c = 0; c < 4; ++c) u[c] = (unsigned)(lq * 128 + (((2 * c + lg) ^ ((lq >> 1) & 7)) << 4));
+        vk0 = t[0]; vk1 = t[1]; vk2 = t[2]; vk3 = t[3]; vc0 = u[0]; vc1 = u[1]; vc2 = u[2]; vc3 = u[3];
+    }
+    const int rem = Skv - (nt - 1) * KV;                           // valid keys of the last tile, 1 .. 64
+    const int vrem = rem - 8 * lg;
+    const float vneg = -1e30f;
+    // loads inside the loop start with tile 2: sources two tiles ahead, destinations stage 2
+    const unsigned long long ksrc = (unsigned long long)Kg + 2ull * KV * HD * 2, vsrc = (unsigned long long)Vg + 2ull * KV * 2;
+    const unsigned mk = __builtin_amdgcn_readfirstlane(65536u + 32768u + wave * 1024u), mv = __builtin_amdgcn_readfirstlane(32768u + wave * 1024u);
+    const int mid = nt - 3;
+    float l00, l01, l10, l11;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#define A128_OPERANDS                                                                                                                       \
+        : [l00] "=&v"(l00), [l01] "=&v"(l01), [l10] "=&v"(l10), [l11] "=&v"(l11), [vk0] "+v"(vk0), [vk1] "+v"(vk1), [vk2] "+v"(vk2),        \
+          [vk3] "+v"(vk3), [vc0] "+v"(vc0), [vc1] "+v"(vc1), [vc2] "+v"(vc2), [vc3] "+v"(vc3), [vp0] "+v"(vp0), [vp1] "+v"(vp1),            \
+          [vp2] "+v"(vp2), [vp3] "+v"(vp3)                                                                                                  \
+        : [gk0] "v"(gk[0]), [gk1] "v"(gk[1]), [gk2] "v"(gk[2]), [gk3] "v"(gk[3]), [gv0] "v"(gv[0]), [gv1] "v"(gv[1]), [gv2] "v"(gv[2]),     \
+          [gv3] "v"(gv[3]), [vrem] "v"(vrem), [vneg] "v"(vneg), [ksrc] "s"(ksrc), [vsrc] "s"(vsrc), [mk] "s"(mk), [mv] "s"(mv), [mid] "s"(mid) \
+        : A128_CLOBBERS
+    if (nt == 1) asm volatile(A128_BODY_SINGLE A128_OPERANDS);
+    else if (nt == 2) asm volatile(A128_BODY_TWO A128_OPERANDS);
+    else if constexpr (RG == 101) asm volatile(A128_BODY_MULTI_NOVALU A128_OPERANDS);       // ablations: timing only
+    else if constexpr (RG == 102) asm volatile(A128_BODY_MULTI_NOREAD A128_OPERANDS);
+    else if constexpr (RG == 103) asm volatile(A128_BODY_MULTI_MFMA A128_OPERANDS);
+    else if constexpr (RG == 104) asm volatile(A128_BODY_MULTI_MFMA_NOSYNC A128_OPERANDS);
+    else asm volatile(A128_BODY_MULTI A128_OPERANDS);
+#undef A128_OPERANDS
+    // ---- finalize per chain: 1 / l, O through LDS (row = query, 256 B, chunks XOR-swizzled by q & 7; the V ring is free: every wave is
+    //      past the loop's last barrier-protected read only after this barrier) for full-row stores
+    __syncthreads();
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int lqe = lane_e & 31, lge = lane_e >> 5;
+#define A128_FINISH(C)                                                                                              \
+    {                                                                                                              \
+        float l = l##C##0 + l##C##1;                                                                               \
+        l += __shfl_xor(l, 32, 64);                                                                                \
+        const float inv = 1.0f / l;                                                                                \
+        char* ob = smem + (wave * 2 + C) * (32 * HD * 2);                                                          \
+        f32x16 o;                                                                                                  \
+        A128_STORE_DB(C, 0) A128_STORE_DB(C, 1) A128_STORE_DB(C, 2) A128_STORE_DB(C, 3)                            \
+        __builtin_amdgcn_wave_barrier();                                                                           \
+        _Pragma("unroll") for (int it = 0; it < 8; ++it) {                                                         \
+            const int r = it * 4 + (lane_e >> 4), c = lane_e & 15;                                                 \
+            const uint4 val = *(const uint4*)(ob + r * 256 + ((c ^ (r & 7)) << 4));                                \
+            const int qi = qblk * QB + wave * 64 + C * 32 + r;                                                     \
+            if (qi < p.S) {                                                                                        \
+                bf16_t* dst = (qi < p.n_first) ? p.o_first + ((long)b * p.n_first + qi) * p.ld_first                \
+                                               : p.o_rest + ((long)b * (p.S - p.n_first) + (qi - p.n_first)) * p.ld_rest; \
+                *(uint4*)(dst + h * HD + c * 8) = val;                                                             \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+#define A128_STORE_DB(C, DB)                                                                                        \
+        A128_READ_O_##C##_##DB(o)                                                                                  \
+        _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                            \
+            const int d0 = 32 * DB + 8 * a + 4 * lge;                                                              \
+            uint2 w = {pack_bf16(o[4 * a] * inv, o[4 * a + 1] * inv), pack_bf16(o[4 * a + 2] * inv, o[4 * a + 3] * inv)}; \
+            const int chunk = (d0 >> 3) ^ (lqe & 7);                                                               \
+            *(uint2*)(ob + lqe * 256 + chunk * 16 + (d0 & 7) * 2) = w;                                             \
+        }
+    A128_FINISH(0)
+    A128_FINISH(1)
+#undef A128_STORE_DB
+#undef A128_FINISH
+}
+
+template <int RG>
+static hipError_t launch128_w4(const Attn128Params& p, hipStream_t stream) {
+    constexpr int smem = 131072;                    // V ring 64 KiB + K ring 64 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn128_w4_kernel<RG>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(attn128_w4_kernel<RG>, dim3(((p.S + 255) / 256) * p.H * p.B), dim3(256), smem, stream, p);
+    return hipGetLastError();
+}
+
+int g_attn128_variant = 0;   // 0 (default): the 4-wave hand-scheduled kernel where it applies (static softmax, self-attention), else 8 waves x 32
+                             // queries, 1 workgroup / CU; 1: 4 compiler-scheduled waves, 2 workgroups / CU; 5: never the hand-scheduled kernel (A/B)
 
 template <int NWAVE, bool STATIC>
 hipError_t launch128(const Attn128Params& p, hipStream_t stream) {
@@ -248,7 +406,10 @@ hipError_t launch128(const Attn128Params& p, hipStream_t stream) {
 
 }  // namespace
 
+int g_attn128_op_bound = 0;   // operator-level entry (unit tests, A/B): the |score| bound it asserts (0 = none: running-max kernel)
 void set_attn128_variant(int v) { g_attn128_variant = v; }
+void set_attn128_op_bound(int v) { g_attn128_op_bound = v; }
+int get_attn128_op_bound() { return g_attn128_op_bound; }
 int get_attn128_variant() { return g_attn128_variant; }
 
 hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream) {
@@ -262,7 +423,15 @@ hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream) {
     if (p.S <= 0 || p.S_pad < p.S || p.n_first < 0 || p.n_first > p.S) return hipErrorInvalidValue;
     if (p.S_kv > 0 ? (p.S_kv_pad % KV != 0 || p.S_kv_pad < p.S_kv) : (p.S_pad % KV != 0)) return hipErrorInvalidValue;
     if (g_attn128_variant == 1) return launch128<4, false>(p, stream);
-    if (p.score_bound > 0.f && p.score_bound <= 60.f) return launch128<8, true>(p, stream);
+    const bool stat = p.score_bound > 0.f && p.score_bound <= 60.f;
+    if (stat && p.S_kv == 0 && g_attn128_variant != 5) {         // the 4-wave hand-scheduled kernel wherever it applies (default)
+        if (g_attn128_variant == 101) return launch128_w4<101>(p, stream);      // (ablation builds: timing only)
+        if (g_attn128_variant == 102) return launch128_w4<102>(p, stream);
+        if (g_attn128_variant == 103) return launch128_w4<103>(p, stream);
+        if (g_attn128_variant == 104) return launch128_w4<104>(p, stream);
+        return launch128_w4<16>(p, stream);
+    }
+    if (stat) return launch128<8, true>(p, stream);
     return launch128<8, false>(p, stream);
 }
 

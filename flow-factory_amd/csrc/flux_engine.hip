@@ -754,6 +754,7 @@ extern "C" int mi355_op_attention128(void* stream, const void* q, const void* k,
     a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.vT = (const bf16_t*)vT; a.o_first = (bf16_t*)o_first; a.ld_first = ld_first;
     a.n_first = n_first; a.o_rest = (bf16_t*)o_rest; a.ld_rest = ld_rest; a.B = B; a.H = H; a.S = S; a.S_pad = S_pad;
     a.q_prescaled = q_prescaled;
+    a.score_bound = (float)get_attn128_op_bound();
     HIPCHK(launch_attention128(a, (hipStream_t)stream));
     return 0;
 }

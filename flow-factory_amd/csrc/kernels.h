@@ -127,8 +127,10 @@ struct Attn128Params {
     const int* kv_len;  // optional device [B]: sample b attends to keys [0, kv_len[b]) only (ragged text at the END of the joint sequence)
 };
 hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream);
-void set_attn128_variant(int v);   // 0: 8-wave workgroups (default), 1: 4-wave workgroups
+void set_attn128_variant(int v);   // 0 (default): 4-wave hand-scheduled kernel where it applies, else 8-wave workgroups; 1: 4-wave compiler-scheduled; 5: never hand-scheduled
 int get_attn128_variant();
+void set_attn128_op_bound(int v);  // mi355_op_attention128 passes this as the proven |score| bound (0 = none); mi355_tune_set(21, v)
+int get_attn128_op_bound();
 void set_qwen_two_stream(int mode);        // qwen_engine.hip: text chain on a side stream (0 off = default, 1 on, 2 auto by image rows)
 void set_qwen_two_stream_rows(int rows);
 void set_qwen_graph(int on);               // qwen_engine.hip: replay the N-step loop of mi355_qwen_rollout as one hipGraph (0 = default: eager)

@@ -393,7 +393,9 @@ int mi355_profile_enable(int on);
  * key 2 = hipGraph replay of the rollout loop: 0 eager launches, 1 captured graph (default);
  * key 3 = smallest 256x256-tile grid that takes the ping-pong kernel (default 128);
  * key 4 = VAE conv tile shape: 0 auto (default), 1 128x128, 2 256x128, 3 256x256, 4 512x128;
- * key 5 = head_dim-128 attention workgroup: 0 = 8 waves (default), 1 = 4 waves;
+ * key 5 = head_dim-128 attention: 0 (default) = the 4-wave kernel with the hand-scheduled key loop where it applies (static softmax,
+ *         self-attention), else 8-wave workgroups; 1 = 4-wave compiler-scheduled workgroups; 5 = never the hand-scheduled kernel (A/B);
+ *         key 21 = the |score| bound mi355_op_attention128 asserts (0 = none: running-max kernel; unit tests and A/B);
  * key 6 = static-bound softmax (no running max when the q/k norm weights prove |score| <= 60): 1 on (default), 0 off,
  *         v >= 2: mi355_op_attention asserts the bound v itself (unit tests));
  * key 7 = GEMM tile raster: tile rows per band, walked column by column so that the tiles an XCD holds at any time form a near-square block
