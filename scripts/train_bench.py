@@ -23,6 +23,7 @@ ap.add_argument("--size", type=int, default=1024)
 ap.add_argument("--train", choices=["attn", "blocks"], default="attn")
 ap.add_argument("--guidance", type=float, default=1.0)
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--only-step", action="store_true", help="run 1 + iters forward+backward steps and nothing else (for rocprofv3)")
 args = ap.parse_args()
 
 from mi355_flow.adapter import SD3_5NativeAdapter  # noqa: E402
@@ -86,6 +87,9 @@ def fwd_bwd():
         p.grad = None
 
 
+if args.only_step:
+    print(json.dumps({"ms_forward_backward": round(timed(fwd_bwd, args.iters) * 1e3, 2), "steps_profiled": args.iters + 1}))
+    sys.exit(0)
 t_ng, t_f, t_fb = timed(nograd, args.iters), timed(fwd, args.iters), timed(fwd_bwd, args.iters)
 lp_a, lp_b = nograd().log_prob, ad.forward(**kw).log_prob.detach()
 assert torch.equal(lp_a, lp_b), "grad-mode replay log-prob differs from the no-grad replay"
