@@ -420,12 +420,32 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* dy, l
         part[(long)blockIdx.y * N + n] = t;
     }
 }
+// 32 columns x 8 slab lanes per workgroup: a lane sums every 8th partial (4 independent chains), the 8 lanes of a column combine in a
+// fixed order through LDS.  (One thread per column walking all partials was a chain of `nslab` dependent L2 round trips: 31 us for the
+// 128 row tiles of an 8192-row dY, 148 times per optimize() step.)
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* part, int nslab, int N, float* out, int accumulate) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int i = 0; i < nslab; ++i) s += part[(long)i * N + n];
-    out[n] = accumulate ? out[n] + s : s;
+    __shared__ float red[8][32];
+    const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (n < N) {
+        int i = r;
+        for (; i + 24 < nslab; i += 32) {
+            s0 += part[(long)i * N + n];
+            s1 += part[(long)(i + 8) * N + n];
+            s2 += part[(long)(i + 16) * N + n];
+            s3 += part[(long)(i + 24) * N + n];
+        }
+        for (; i < nslab; i += 8) s0 += part[(long)i * N + n];
+    }
+    red[r][c] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (r == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][c];
+        out[n] = accumulate ? out[n] + t : t;
+    }
 }
 
 // split-K second stage: out[i] (+)= sum_s part[s][i], fixed order
@@ -596,7 +616,7 @@ hipError_t launch_transpose_colsum(const bf16_t* in, long ld_in, bf16_t* out, lo
     else
         hipLaunchKernelGGL(transpose_kernel<false>, dim3(ntile, (cols + 63) / 64, 1), dim3(256), 0, st, in, ld_in, 0L, out, ld_out, 0L, rows, cols,
                            rows_pad, scratch);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, scratch, ntile, cols, colsum, 0);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, scratch, ntile, cols, colsum, 0);
     return hipGetLastError();
 }
 
@@ -622,7 +642,7 @@ hipError_t launch_rms_dw_finish(const float* part, int nwg, float q_scale, float
 hipError_t launch_colsum(const bf16_t* dy, long ld, long M, int N, float* scratch, float* out, int accumulate, hipStream_t st) {
     const int nslab = (int)(M >= 8192 ? 64 : (M + 127) / 128);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, nslab), dim3(256), 0, st, dy, ld, M, N, scratch, nslab);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 255) / 256), dim3(256), 0, st, scratch, nslab, N, out, accumulate);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 31) / 32), dim3(256), 0, st, scratch, nslab, N, out, accumulate);
     return hipGetLastError();
 }
 

@@ -119,6 +119,7 @@ static hipError_t lnmod_p(const LnModParams& l, hipStream_t st) { ProfScope ps(P
 static hipError_t sde_p(const SdeStepParams& s, hipStream_t st) { ProfScope ps(PC_SDE, st); return launch_sde_step(s, st); }
 
 // training-mode state (engine_train.inc, included at the end of this file)
+static int g_train_two_stream = 1;   // key 22, see engine_train.inc
 struct mi355_engine;
 struct mi355_plan;
 static void train_release(mi355_plan* p);
@@ -990,6 +991,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 16) { set_flux_graph(value); return 0; }        // FLUX.1 engine: hipGraph replay of the rollout loop (0 = default: eager)
     if (key == 17) { set_qwen_graph(value); return 0; }        // Qwen-Image engine: the same
     if (key == 19) { set_w4_max_k(value); return 0; }
+    if (key == 22) { g_train_two_stream = value; return 0; }   // optimize() replay: the context-stream chain of the training forward / backward on a side stream (1 = default)
     if (key == 21) { set_attn128_op_bound(value); return 0; }  // mi355_op_attention128: the |score| bound the caller asserts (0 = none)          // default GEMM dispatch: largest K for the 4-wave hand-scheduled kernel
     return fail("mi355_tune_set: unknown key %d", key);
 }

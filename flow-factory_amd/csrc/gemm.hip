@@ -332,6 +332,30 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
             const float y6 = __builtin_fmaf(bf_lo(g.w), bf_lo(v.w), bf_lo(x.w)), y7 = __builtin_fmaf(bf_hi(g.w), bf_hi(v.w), bf_hi(x.w));
             *(uint4*)(p.out + (long)m * p.ldo + n) = make_uint4(pack_bf16(y0, y1), pack_bf16(y2, y3), pack_bf16(y4, y5), pack_bf16(y6, y7));
         }
+    } else if constexpr (FULL && EPI == EPI_DGELU) {
+        // dpre = dy * gelu'(pre): all LDS reads, then all loads of the stashed pre-activation, then arithmetic + stores (as above: inside
+        // store_row8 every row's load waits behind the previous row's store)
+        uint4 val[NR * 2], ar[NR * 2];
+        const int c = lane & 7;
+#pragma unroll
+        for (int it = 0; it < NR * 2; ++it) {
+            const int r = it * 8 + (lane >> 3);
+            val[it] = *(const uint4*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
+        }
+#pragma unroll
+        for (int it = 0; it < NR * 2; ++it)
+            ar[it] = *(const uint4*)(p.aux + (long)(m_base + it * 8 + (lane >> 3)) * p.ld_aux + n_base + c * 8);
+#pragma unroll
+        for (int it = 0; it < NR * 2; ++it) {
+            const uint4 v = val[it], a = ar[it];
+            // (same operations as store_row8's path: y * gelu'(pre) on the bf16-rounded product sum)
+            const float y0 = bf_lo(v.x) * gelu_tanh_grad_f(bf_lo(a.x)), y1 = bf_hi(v.x) * gelu_tanh_grad_f(bf_hi(a.x));
+            const float y2 = bf_lo(v.y) * gelu_tanh_grad_f(bf_lo(a.y)), y3 = bf_hi(v.y) * gelu_tanh_grad_f(bf_hi(a.y));
+            const float y4 = bf_lo(v.z) * gelu_tanh_grad_f(bf_lo(a.z)), y5 = bf_hi(v.z) * gelu_tanh_grad_f(bf_hi(a.z));
+            const float y6 = bf_lo(v.w) * gelu_tanh_grad_f(bf_lo(a.w)), y7 = bf_hi(v.w) * gelu_tanh_grad_f(bf_hi(a.w));
+            *(uint4*)(p.out + (long)(m_base + it * 8 + (lane >> 3)) * p.ldo + n_base + c * 8) =
+                make_uint4(pack_bf16(y0, y1), pack_bf16(y2, y3), pack_bf16(y4, y5), pack_bf16(y6, y7));
+        }
     } else if constexpr (FULL && !is_qk_epi(EPI)) {      // (the q / k scatter epilogues sit at their register limit in the ping-pong kernel)
         uint4 val[NR * 2];                   // every LDS read in flight before the first store needs its data
 #pragma unroll

@@ -280,6 +280,43 @@ def test_gradients_ragged_shapes_and_partial_trainable_set(gpu):
     ad.engine.close()
 
 
+def test_side_stream_training_schedule_is_bit_identical_to_the_serial_one(gpu):
+    """mi355_tune_set(22, .): the context-stream chain of the training forward / backward on a side stream (default) vs in line.  Same
+    kernels on the same operands, all deterministic in the default scope: log-prob and every gradient must be torch.equal -- any
+    missing join / fork edge shows up here as a difference (repeated: a race need not fire every time)."""
+    from mi355_flow import _lib
+    lib = _lib.load()
+    targets = (".to_q.", ".to_k.", ".to_v.", ".to_out.0.")
+    ad, mod, _ = _build(lambda n: any(k in n for k in targets), seed=21)
+    B, h, w, Nt = 4, 16, 16, 77
+    inp = _inputs(B, h, w, Nt, seed=5)
+    ad.scheduler.set_timesteps(4)
+    kw = dict(t=torch.full((B,), 750.0), t_next=torch.full((B,), 500.0), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+              prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(), guidance_scale=1.0, noise_level=0.7,
+              compute_log_prob=True, return_kwargs=["log_prob", "dt"])
+
+    def step():
+        for prm in mod.parameters():
+            prm.grad = None
+        out = ad.forward(**kw)
+        (inp["wlp"].cuda() * out.log_prob).sum().backward()
+        torch.cuda.synchronize()
+        return out.log_prob.detach().clone(), {n: prm.grad.clone() for n, prm in mod.named_parameters() if prm.requires_grad}
+
+    try:
+        _lib.check(lib.mi355_tune_set(22, 0), "tune_set")
+        lp0, g0 = step()
+        _lib.check(lib.mi355_tune_set(22, 1), "tune_set")
+        for _ in range(4):
+            lp1, g1 = step()
+            assert torch.equal(lp0, lp1)
+            for n in g0:
+                assert torch.equal(g0[n], g1[n]), n
+    finally:
+        _lib.check(lib.mi355_tune_set(22, 1), "tune_set")
+    ad.engine.close()
+
+
 def test_lora_gradients_flow_through_the_merged_weight(gpu):
     ad, mod, cfg_o = _build(lambda n: False, seed=21)
     PF.wrap_lora(mod)
