@@ -468,16 +468,21 @@ static int update_score_bounds(mi355_engine* e, hipStream_t st) {
     std::vector<float> host(e->used32 / 4);
     HIPCHK(hipMemcpyAsync(host.data(), e->arena32, e->used32, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    auto amax = [&](const float* dev) {
-        const float* h = host.data() + (dev - (const float*)e->arena32);
+    // |q . k| = |sum_d qn_d a_d kn_d b_d| <= max_d |a_d b_d| * sum_d |qn_d kn_d| <= max_d |a_d b_d| * |qn| |kn|, and an RMS-normalised head has
+    // |qn| <= sqrt(64): the bound needs the largest PRODUCT of the two norm weights at one channel, not the product of their largest entries
+    // (a checkpoint whose q and k weights peak at different channels keeps the static kernel)
+    auto pmax = [&](const float* dq, const float* dk) {
+        const float* a = host.data() + (dq - (const float*)e->arena32);
+        const float* b = host.data() + (dk - (const float*)e->arena32);
         float m = 0.f;
-        for (int i = 0; i < 64; ++i) m = fmaxf(m, fabsf(h[i]));
+        for (int i = 0; i < 64; ++i) m = fmaxf(m, fabsf(a[i] * b[i]));
         return m;
     };
     const float c = 64.0f * 0.125f * 1.4426950408889634f * 1.02f;
     for (auto& b : e->blk) {
-        b.bound_joint = c * fmaxf(amax(b.nq), amax(b.ncq)) * fmaxf(amax(b.nk), amax(b.nck));
-        b.bound_dual = b.dual ? c * amax(b.nq2) * amax(b.nk2) : 0.f;
+        // joint attention: image / text queries against image / text keys
+        b.bound_joint = c * fmaxf(fmaxf(pmax(b.nq, b.nk), pmax(b.nq, b.nck)), fmaxf(pmax(b.ncq, b.nk), pmax(b.ncq, b.nck)));
+        b.bound_dual = b.dual ? c * pmax(b.nq2, b.nk2) : 0.f;
     }
     e->bounds_dirty = false;
     ++e->bounds_ver;

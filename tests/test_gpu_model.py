@@ -260,6 +260,46 @@ def test_large_norm_weights_fall_back_to_running_max():
         e.close()
 
 
+def test_large_norm_weights_at_different_channels_keep_the_static_kernel():
+    """The proven bound is 64 * max_d |w_q[d] * w_k[d]| (Cauchy-Schwarz on the weighted heads), not 64 * max|w_q| * max|w_k|: q weights of 4
+    at even channels and k weights of 4 at odd channels (0.5 elsewhere) give products of 2 -- every launch stays on the static-softmax
+    kernel -- and the forward, run on inputs scaled so that single channels dominate the heads, still matches the oracle."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mi355_flow import engine
+    from oracle import mmditx_ref as M
+    cfg = M.tiny_config(num_layers=2, num_heads=2, dual_layers=(0,), joint_attention_dim=128, pooled_projection_dim=128,
+                        pos_embed_max_size=24)
+    sd = M.make_synthetic_state_dict(cfg, seed=7, std=0.08)
+    even = (torch.arange(64) % 2 == 0).float()
+    for k_ in sd:
+        if ".norm_" in k_:
+            is_q = "norm_q" in k_ or "norm_added_q" in k_
+            big = even if is_q else 1.0 - even
+            sd[k_] = (4.0 * big + 0.5 * (1.0 - big)) * torch.sign(sd[k_] + 1e-3)
+    sd = {k_: v.bfloat16().float() for k_, v in sd.items()}
+    e = engine.Engine(engine.TransformerConfig(num_layers=2, num_heads=2, joint_attention_dim=128, pooled_projection_dim=128,
+                                               pos_embed_max_size=24, dual_layers=(0,)))
+    e.bind_state_dict({k_: v.cuda() for k_, v in sd.items()})
+    e.ready()
+    try:
+        info = e.attention_info()
+        assert info["static"] == info["total"] == 3, info
+        assert info["max_bound"] < 60.0 * 0.5, info
+        g = torch.Generator().manual_seed(3)
+        B, h, w, Nt = 2, 16, 16, 13
+        x = (torch.randn(B, 16, h, w, generator=g) * 3.0).half()
+        enc = (torch.randn(B, Nt, 128, generator=g) * 3.0).bfloat16()
+        pooled = torch.randn(B, 128, generator=g).bfloat16()
+        t = torch.tensor([800.0, 300.0])
+        y = e.plan(B, 1, h, w, Nt, 1).transformer_forward(x.cuda(), t.cuda(), enc.cuda(), pooled.cuda())
+        ref = M.mmdit_forward(sd, cfg, x.float(), t, enc.float(), pooled.float())
+        assert torch.isfinite(y.float()).all()
+        assert _rel(y, ref) < 3e-2
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("B,h,w,Nt", [(1, 2, 2, 1), (1, 2, 4, 3), (5, 6, 2, 2)])
 def test_forward_degenerate_sizes(tiny, B, h, w, Nt):
     """Smallest legal shapes: one image token (2x2 latent), one text token, odd batch -- every kernel on its ragged / scalar tail path."""
