@@ -23,7 +23,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int TB = 64;                     // rows of the streamed dimension per tile
 constexpr int TILE = TB * 64 * 2;          // 8 KiB
-constexpr int NWAVE = 4;                   // 4 waves x 32 lanes-of-interest = 128 keys (pass 1) / queries (pass 2) per workgroup
+// NWAVE waves x 32 lanes-of-interest = 128 or 256 keys (pass 1) / queries (pass 2) per workgroup.  Every workgroup streams ALL query (key)
+// tiles of its (b, h) through LDS -- 4 (3) tiles of 8 KiB per 64 rows -- so the L2 -> LDS traffic of a launch is S / (32 NWAVE) x the
+// operand bytes: at S = 4429, B H = 48, 4 waves: 3.8 GB (dK/dV pass) + 2.9 GB (dQ pass) per attention, ~7 TB/s at the measured
+// durations; 8 waves halve it (one workgroup of 8 waves per CU instead of two of 4: the same two waves per SIMD).
 constexpr float LN2 = 0.6931471805599453f;
 
 __device__ __forceinline__ int row_perm(int i) {     // MFMA output row i (0..31) -> row offset inside the 32-row block (attention.hip key_perm)
@@ -32,6 +35,7 @@ __device__ __forceinline__ int row_perm(int i) {     // MFMA output row i (0..31
 }
 
 // stage one 64-row x 128-byte tile (rows `row_stride` elements apart in HBM) into LDS at `dst`; wave w copies 8-row groups w, w + NWAVE
+template <int NWAVE>
 __device__ __forceinline__ void stage_tile(const bf16_t* src, long row_stride, char* dst, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < 8 / NWAVE; ++i) {
@@ -74,6 +78,7 @@ __device__ __forceinline__ bf16x8 frag4(unsigned a, unsigned b, unsigned c, unsi
 // ----------------------------------------------------------------------------------------------- pass 1: dK, dV
 // LDS stage: Q [64 q][64 d] | dO [64 q][64 d] | Q^T [64 d][64 q] | dO^T [64 d][64 q] | L[64], Delta[64]
 constexpr int ST1 = 4 * TILE + 512;
+template <int NWAVE>
 __global__ __launch_bounds__(NWAVE * 64, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -108,10 +113,10 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn_bwd_dkv_kernel(AttnBwdPara
 
     auto stage = [&](int t, int buf) {
         char* base = smem + buf * ST1;
-        stage_tile(Qg + (long)t * TB * 64, 64, base, wave, lane);
-        stage_tile(Og + (long)t * TB * 64, 64, base + TILE, wave, lane);
-        stage_tile(QTg + (long)t * TB, p.S_pad, base + 2 * TILE, wave, lane);
-        stage_tile(OTg + (long)t * TB, p.S_pad, base + 3 * TILE, wave, lane);
+        stage_tile<NWAVE>(Qg + (long)t * TB * 64, 64, base, wave, lane);
+        stage_tile<NWAVE>(Og + (long)t * TB * 64, 64, base + TILE, wave, lane);
+        stage_tile<NWAVE>(QTg + (long)t * TB, p.S_pad, base + 2 * TILE, wave, lane);
+        stage_tile<NWAVE>(OTg + (long)t * TB, p.S_pad, base + 3 * TILE, wave, lane);
     };
     // L / Delta of a query tile (2 x 64 floats): loaded into a register early, written to LDS after the tile's MFMA work
     const float* ldsrc = tid < 64 ? Lg + tid : Dg + (tid - 64);
@@ -129,21 +134,32 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn_bwd_dkv_kernel(AttnBwdPara
     dk[0] = (f32x16){0}; dk[1] = (f32x16){0}; dv[0] = (f32x16){0}; dv[1] = (f32x16){0};
     const int nt = (p.S + TB - 1) / TB;
     stage(0, 0);
-    if (tid < 128) ((float*)(smem + 4 * TILE))[tid] = ldsrc[0];
+    if (tid < 128) ((float*)(smem + 4 * TILE))[tid] = -ldsrc[0];      // LDS holds -L and -Delta: they enter the MFMA chains as their C operand
     for (int t = 0; t < nt; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         float ld_next = 0.f;
         if (t + 1 < nt) {
             stage(t + 1, (t + 1) & 1);
-            if (tid < 128) ld_next = ldsrc[(t + 1) * TB];
+            if (tid < 128) ld_next = -ldsrc[(t + 1) * TB];
         }
         const char* sb = smem + (t & 1) * ST1;
         const float* sL = (const float*)(sb + 4 * TILE);
         const float* sD = sL + 64;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            f32x16 s = (f32x16){0}, dp = (f32x16){0};
+            // register r <-> query t*64 + 32*qb + 16*(r>>3) + 8*lg + (r&7): the accumulators start at -L[query] / -Delta[query] (8 consecutive
+            // floats per half: four 16-byte LDS reads each), so the chains deliver s - L and dP - Delta and no subtraction is issued
+            f32x16 s, dp;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const float4 a0 = *(const float4*)(sL + 32 * qb + 16 * hh + 8 * lg), a1 = *(const float4*)(sL + 32 * qb + 16 * hh + 8 * lg + 4);
+                const float4 b0 = *(const float4*)(sD + 32 * qb + 16 * hh + 8 * lg), b1 = *(const float4*)(sD + 32 * qb + 16 * hh + 8 * lg + 4);
+                s[8 * hh + 0] = a0.x; s[8 * hh + 1] = a0.y; s[8 * hh + 2] = a0.z; s[8 * hh + 3] = a0.w;
+                s[8 * hh + 4] = a1.x; s[8 * hh + 5] = a1.y; s[8 * hh + 6] = a1.z; s[8 * hh + 7] = a1.w;
+                dp[8 * hh + 0] = b0.x; dp[8 * hh + 1] = b0.y; dp[8 * hh + 2] = b0.z; dp[8 * hh + 3] = b0.w;
+                dp[8 * hh + 4] = b1.x; dp[8 * hh + 5] = b1.y; dp[8 * hh + 6] = b1.z; dp[8 * hh + 7] = b1.w;
+            }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const bf16x8 qa = *(const bf16x8*)(sb + offR[kk] + qb * 4096);
@@ -151,19 +167,17 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn_bwd_dkv_kernel(AttnBwdPara
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[kk], dp, 0, 0, 0);
             }
-            // register r <-> query t*64 + 32*qb + 16*(r>>3) + 8*lg + (r&7)
             unsigned pk[8], zk[8];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                const int ql = 32 * qb + 16 * (r >> 3) + 8 * lg + (r & 7);
-                const float l0 = sL[ql], l1 = sL[ql + 1], d0 = sD[ql], d1 = sD[ql + 1];
-                float p0 = __builtin_amdgcn_exp2f(s[r] - l0), p1 = __builtin_amdgcn_exp2f(s[r + 1] - l1);
+                float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
                 if (t == nt - 1) {
+                    const int ql = 32 * qb + 16 * (r >> 3) + 8 * lg + (r & 7);
                     if (t * TB + ql >= p.S) p0 = 0.f;
                     if (t * TB + ql + 1 >= p.S) p1 = 0.f;
                 }
                 pk[r >> 1] = pack_bf16(p0, p1);
-                zk[r >> 1] = pack_bf16(p0 * (dp[r] - d0), p1 * (dp[r + 1] - d1));
+                zk[r >> 1] = pack_bf16(p0 * dp[r], p1 * dp[r + 1]);
             }
 #pragma unroll
             for (int hs = 0; hs < 2; ++hs) {          // two k-steps of 16 queries: c = 2*qb + hs
@@ -192,7 +206,8 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn_bwd_dkv_kernel(AttnBwdPara
 // ----------------------------------------------------------------------------------------------- pass 2: dQ
 // LDS stage: K [64 keys][64 d] | V [64 keys][64 d] | K^T [64 d][64 keys]
 constexpr int ST2 = 3 * TILE;
-__global__ __launch_bounds__(NWAVE * 64, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
+template <int NWAVE>
+__global__ __launch_bounds__(NWAVE * 64, NWAVE == 8 ? 4 : 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -223,9 +238,9 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn_bwd_dq_kernel(AttnBwdParam
 
     auto stage = [&](int t, int buf) {
         char* base = smem + buf * ST2;
-        stage_tile(Kg + (long)t * TB * 64, 64, base, wave, lane);
-        stage_tile(Vg + (long)t * TB * 64, 64, base + TILE, wave, lane);
-        stage_tile(KTg + (long)t * TB, p.S_pad, base + 2 * TILE, wave, lane);
+        stage_tile<NWAVE>(Kg + (long)t * TB * 64, 64, base, wave, lane);
+        stage_tile<NWAVE>(Vg + (long)t * TB * 64, 64, base + TILE, wave, lane);
+        stage_tile<NWAVE>(KTg + (long)t * TB, p.S_pad, base + 2 * TILE, wave, lane);
     };
     const int prow = row_perm(lq);
     int offR[4], offT[4];
@@ -284,18 +299,33 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn_bwd_dq_kernel(AttnBwdParam
 
 }  // namespace
 
-hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream) {
-    if (p.S <= 0 || p.S_pad % TB != 0 || p.S_pad < p.S) return hipErrorInvalidValue;
+static int g_attn_bwd_waves = 8, g_attn_bwd_waves_dq = 8;
+void set_attn_bwd_waves(int pass, int v) { (pass == 0 ? g_attn_bwd_waves : g_attn_bwd_waves_dq) = v == 4 ? 4 : 8; }
+
+template <int NWAVE>
+static hipError_t launch_dkv(const AttnBwdParams& p, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST1);
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NWAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST1);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int nb = (p.S + 32 * NWAVE - 1) / (32 * NWAVE);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(nb * p.H * p.B), dim3(NWAVE * 64), 2 * ST1, stream, p);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(nb * p.H * p.B), dim3(NWAVE * 64), 2 * ST2, stream, p);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NWAVE>, dim3(nb * p.H * p.B), dim3(NWAVE * 64), 2 * ST1, stream, p);
     return hipGetLastError();
+}
+template <int NWAVE>
+static hipError_t launch_dq(const AttnBwdParams& p, hipStream_t stream) {
+    const int nb = (p.S + 32 * NWAVE - 1) / (32 * NWAVE);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<NWAVE>, dim3(nb * p.H * p.B), dim3(NWAVE * 64), 2 * ST2, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream) {
+    if (p.S <= 0 || p.S_pad % TB != 0 || p.S_pad < p.S) return hipErrorInvalidValue;
+    hipError_t e = g_attn_bwd_waves == 4 ? launch_dkv<4>(p, stream) : launch_dkv<8>(p, stream);
+    if (e != hipSuccess) return e;
+    return g_attn_bwd_waves_dq == 4 ? launch_dq<4>(p, stream) : launch_dq<8>(p, stream);
 }
 
 }  // namespace mi355
