@@ -23,10 +23,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int TB = 64;                     // rows of the streamed dimension per tile
 constexpr int TILE = TB * 64 * 2;          // 8 KiB
-// NWAVE waves x 32 lanes-of-interest = 128 or 256 keys (pass 1) / queries (pass 2) per workgroup.  Every workgroup streams ALL query (key)
-// tiles of its (b, h) through LDS -- 4 (3) tiles of 8 KiB per 64 rows -- so the L2 -> LDS traffic of a launch is S / (32 NWAVE) x the
-// operand bytes: at S = 4429, B H = 48, 4 waves: 3.8 GB (dK/dV pass) + 2.9 GB (dQ pass) per attention, ~7 TB/s at the measured
-// durations; 8 waves halve it (one workgroup of 8 waves per CU instead of two of 4: the same two waves per SIMD).
+// NWAVE waves x 32 lanes-of-interest keys (pass 1) / queries (pass 2) per workgroup.  4 waves, two workgroups per CU: 8-wave workgroups
+// (one per CU, half the L2 -> LDS operand traffic: every workgroup streams ALL tiles of its (b, h)) measured 4-8 % SLOWER
+// (profiles/r03u_attn_bwd_waves_ab.txt) -- two independent barriers per CU overlap better than one, and the traffic is not the bound.
+constexpr int NWAVES = 4;
 constexpr float LN2 = 0.6931471805599453f;
 
 __device__ __forceinline__ int row_perm(int i) {     // MFMA output row i (0..31) -> row offset inside the 32-row block (attention.hip key_perm)
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn_bwd_dkv_kernel(AttnBwdPara
 // LDS stage: K [64 keys][64 d] | V [64 keys][64 d] | K^T [64 d][64 keys]
 constexpr int ST2 = 3 * TILE;
 template <int NWAVE>
-__global__ __launch_bounds__(NWAVE * 64, NWAVE == 8 ? 4 : 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
+__global__ __launch_bounds__(NWAVE * 64, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -299,33 +299,18 @@ __global__ __launch_bounds__(NWAVE * 64, NWAVE == 8 ? 4 : 2) void attn_bwd_dq_ke
 
 }  // namespace
 
-static int g_attn_bwd_waves = 8, g_attn_bwd_waves_dq = 8;
-void set_attn_bwd_waves(int pass, int v) { (pass == 0 ? g_attn_bwd_waves : g_attn_bwd_waves_dq) = v == 4 ? 4 : 8; }
-
-template <int NWAVE>
-static hipError_t launch_dkv(const AttnBwdParams& p, hipStream_t stream) {
+hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream) {
+    if (p.S <= 0 || p.S_pad % TB != 0 || p.S_pad < p.S) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NWAVE>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST1);
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST1);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int nb = (p.S + 32 * NWAVE - 1) / (32 * NWAVE);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NWAVE>, dim3(nb * p.H * p.B), dim3(NWAVE * 64), 2 * ST1, stream, p);
+    const int nb = (p.S + 32 * NWAVES - 1) / (32 * NWAVES);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel<NWAVES>, dim3(nb * p.H * p.B), dim3(NWAVES * 64), 2 * ST1, stream, p);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<NWAVES>, dim3(nb * p.H * p.B), dim3(NWAVES * 64), 2 * ST2, stream, p);
     return hipGetLastError();
-}
-template <int NWAVE>
-static hipError_t launch_dq(const AttnBwdParams& p, hipStream_t stream) {
-    const int nb = (p.S + 32 * NWAVE - 1) / (32 * NWAVE);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<NWAVE>, dim3(nb * p.H * p.B), dim3(NWAVE * 64), 2 * ST2, stream, p);
-    return hipGetLastError();
-}
-
-hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream) {
-    if (p.S <= 0 || p.S_pad % TB != 0 || p.S_pad < p.S) return hipErrorInvalidValue;
-    hipError_t e = g_attn_bwd_waves == 4 ? launch_dkv<4>(p, stream) : launch_dkv<8>(p, stream);
-    if (e != hipSuccess) return e;
-    return g_attn_bwd_waves_dq == 4 ? launch_dq<4>(p, stream) : launch_dq<8>(p, stream);
 }
 
 }  // namespace mi355

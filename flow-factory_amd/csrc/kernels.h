@@ -293,7 +293,6 @@ struct AttnBwdParams {
     int B, H, S, S_pad;
 };
 hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream);
-void set_attn_bwd_waves(int pass, int v);      // pass 0 = dK/dV, 1 = dQ: 8 (default) or 4 waves per workgroup (A/B)
 
 // --------------------------------------------------------------------------- SDE step (K15)
 enum Dynamics : int { DYN_ODE = 0, DYN_FLOW_SDE = 1, DYN_DANCE_SDE = 2, DYN_CPS = 3 };
