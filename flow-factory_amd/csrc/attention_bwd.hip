@@ -297,10 +297,331 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn_bwd_dq_kernel(AttnBwdParam
     store_rows(dq, LN2, ob, p.dq + bh * p.S_pad * 64, qblk * QB + wave * 32, p.S, lane);
 }
 
+// =============================================================================================== transposed-read kernels (round 3)
+// The same two passes without the transposed operand copies.  The second product of each pass contracts over the STREAMED dimension
+// (dV^T += dO^T . P and dK^T += Q^T . dZ over queries; dQ^T += K^T . dZ^T over keys), so its A operand is a column walk through a
+// row-major tile: `ds_read_b64_tr_b16` delivers exactly that (per 16-lane group: a [4 rows][16 columns] block, lane i receives column
+// i; checked lane by lane in scripts/mb/tr_b16_probe.hip).  What that removes: the Q^T / dO^T (K^T) tiles of every stage -- half (a
+// third) of the L2 -> LDS traffic and of the LDS footprint, which pays for a 4-stage (3-stage) ring with loads two tiles ahead and counted
+// waits instead of `vmcnt(0)` per tile -- and, on the host side, the q^T / k^T / dO^T transpose launches and their buffers.
+// Swizzle: physical 16-byte chunk = logical ^ swz2(row), swz2 = f ^ ((f & 1) << 2) with f = (row >> 1) & 7: still a permutation of the 8
+// even (odd) rows a ds_read_b128 lane group touches (conflict-free as before), and rows r, r + 2 of a transposed read's 4-row block now
+// sit in different 64-byte halves of their 128-byte rows (4 rows x 64 bytes = 64 distinct banks).
+typedef short v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4s* lds_v4s_t;
+
+__device__ __forceinline__ int swz2(int row) {
+    const int f = (row >> 1) & 7;
+    return f ^ ((f & 1) << 2);
+}
+
+template <int NWAVE>
+__device__ __forceinline__ void stage_tile2(const bf16_t* src, long row_stride, char* dst, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 8 / NWAVE; ++i) {
+        const int grp = wave + i * NWAVE;
+        const int row = grp * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ swz2(row);
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + (long)row * row_stride + c * 8), (lptr_t)(dst + grp * 1024), 16, 0, 0);
+    }
+}
+
+// The transposed reads and the MFMAs they feed are one inline-assembly block per 32-row half tile, with the fragments in FIXED registers:
+//  * hipcc guards every C-level LDS read it knows to be an LDS read (the `ds_read_tr16_b64` builtin, address-space-3 pointers) with
+//    `s_waitcnt vmcnt(0)` while any LDS-DMA is in flight -- it cannot tell the ring stages apart -- which would drain the tiles just put in
+//    flight (the plain fragment reads go through generic pointers and are not guarded);
+//  * a fragment is two 64-bit reads into the halves of one 4-register MFMA operand: as separate asm outputs they would need packing moves.
+// Per-lane addresses a0..a3 = piece (db, jj) = (0,0), (0,1), (1,0), (1,1) of the 16-row block at the tile's row 32 half (+ hs * 2048 bytes).
+// LDS returns in order, so `lgkmcnt(n)` retires all but the last n reads (compiler-issued fragment reads in flight only make it wait longer).
+#define TR_RD(dst, a, off) "ds_read_b64_tr_b16 " dst ", " a " offset:" #off "\n\t"
+#define MFMA32(acc, afrag, b) "v_mfma_f32_32x32x16_bf16 " acc ", " afrag ", " b ", " acc "\n\t"
+
+__device__ __forceinline__ void wait_tiles_ahead(int ahead, int per_tile) {
+    // `ahead` tiles were issued after the one about to be read, `per_tile` VM operations each (vmcnt retires in order)
+    if (per_tile == 5) {
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// ---- pass 1: dK, dV.  LDS stage: Q [64 q][64 d] | dO [64 q][64 d] | -L[64] | -Delta[64]; ring of 4
+constexpr int ST1T = 2 * TILE + 512;
+constexpr int NST1 = 4;
+__global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dkv_tr_kernel(AttnBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane & 31, lg = lane >> 5;
+    constexpr int KB = 32 * NWAVES;
+    const int nkb = (p.S + KB - 1) / KB;
+    const int nwg = nkb * p.H * p.B;
+    int wid = blockIdx.x;
+    {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = wid & 7;
+        wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (wid >> 3);
+    }
+    const int kblk = wid % nkb;
+    const long bh = wid / nkb;
+    const bf16_t* Qg = p.q + bh * p.S_pad * 64;
+    const bf16_t* Og = p.doh + bh * p.S_pad * 64;
+    // -L | -Delta of a 64-query tile are 128 contiguous floats in p.nld ([b h][tile][2][64]): wave w moves floats 32 w .. 32 w + 31 with
+    // the first 8 lanes of one 16-byte LDS-DMA instruction (every wave: the same VM-operation count per tile, 5)
+    const float* NLg = p.nld + bh * p.S_pad * 2 + wave * 32 + (lane & 7) * 4;
+    const int key = kblk * KB + wave * 32 + lk;
+    const int key_ld = key < p.S ? key : p.S - 1;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        kf[kk] = *(const bf16x8*)(p.k + (bh * p.S_pad + key_ld) * 64 + kk * 16 + lg * 8);
+        vf[kk] = *(const bf16x8*)(p.v + (bh * p.S_pad + key_ld) * 64 + kk * 16 + lg * 8);
+    }
+    auto stage = [&](int t, int buf) {
+        char* base = smem + buf * ST1T;
+        stage_tile2<NWAVES>(Qg + (long)t * TB * 64, 64, base, wave, lane);
+        stage_tile2<NWAVES>(Og + (long)t * TB * 64, 64, base + TILE, wave, lane);
+        if (lane < 8) __builtin_amdgcn_global_load_lds((gptr_t)(NLg + (long)t * 2 * TB), (lptr_t)(base + 2 * TILE + wave * 128), 16, 0, 0);
+    };
+    // row-major tiles as A operand: row = 32*qb + perm(lk), logical chunk = 2*kk + lg
+    const int prow = row_perm(lk);
+    int offR[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) offR[kk] = prow * 128 + (((2 * kk + lg) ^ swz2(prow)) << 4);
+    // transposed reads: this lane supplies the 8-byte piece (row 8 lg + 4 jj + (i >> 2), columns 32 db + 16 g1 + 4 (i & 3) ..) of the block
+    int trb[2][2];
+    {
+        const int i = lane & 15, g1 = (lane >> 4) & 1;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int ql = 8 * lg + 4 * jj + (i >> 2);
+                const int ch = 4 * db + 2 * g1 + ((i & 3) >> 1);
+                trb[db][jj] = ql * 128 + ((ch ^ swz2(ql)) << 4) + (i & 1) * 8;
+            }
+    }
+    f32x16 dk[2], dv[2];
+    dk[0] = (f32x16){0}; dk[1] = (f32x16){0}; dv[0] = (f32x16){0}; dv[1] = (f32x16){0};
+    const int nt = (p.S + TB - 1) / TB;
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    if (nt > 2) stage(2, 2);
+    for (int t = 0; t < nt; ++t) {
+        wait_tiles_ahead(nt - 1 - t, 5);
+        if (t + 3 < nt) stage(t + 3, (t + 3) & (NST1 - 1));      // its buffer held tile t - 1: every wave is past it (the barrier above)
+        const char* sb = smem + (t & (NST1 - 1)) * ST1T;
+        // -L / -Delta reads as inline assembly: hipcc guards every C-level read of an LDS range that an in-flight LDS-DMA may alias with
+        // `s_waitcnt vmcnt(0)` (it cannot tell the ring stages apart) -- which would drain the two tiles just put in flight
+        const unsigned stg = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + (t & (NST1 - 1)) * ST1T);
+        const unsigned sLa = stg + 2 * TILE + 32 * lg;
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 s, dp;
+            {
+                f32x4 a[4], b[4];
+                if (qb == 0) {
+                    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:64\n\tds_read_b128 %3, %8 offset:80\n\t"
+                                 "ds_read_b128 %4, %8 offset:256\n\tds_read_b128 %5, %8 offset:272\n\tds_read_b128 %6, %8 offset:320\n\t"
+                                 "ds_read_b128 %7, %8 offset:336\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]) : "v"(sLa) : "memory");
+                } else {
+                    asm volatile("ds_read_b128 %0, %8 offset:128\n\tds_read_b128 %1, %8 offset:144\n\tds_read_b128 %2, %8 offset:192\n\tds_read_b128 %3, %8 offset:208\n\t"
+                                 "ds_read_b128 %4, %8 offset:384\n\tds_read_b128 %5, %8 offset:400\n\tds_read_b128 %6, %8 offset:448\n\t"
+                                 "ds_read_b128 %7, %8 offset:464\n\ts_waitcnt lgkmcnt(0)"
+                                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]) : "v"(sLa) : "memory");
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s[4 * j + e] = a[j][e]; dp[4 * j + e] = b[j][e]; }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 qa = *(const bf16x8*)(sb + offR[kk] + qb * 4096);
+                const bf16x8 oa = *(const bf16x8*)(sb + TILE + offR[kk] + qb * 4096);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[kk], dp, 0, 0, 0);
+            }
+            unsigned pk[8], zk[8];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
+                if (t == nt - 1) {
+                    const int ql = 32 * qb + 16 * (r >> 3) + 8 * lg + (r & 7);
+                    if (t * TB + ql >= p.S) p0 = 0.f;
+                    if (t * TB + ql + 1 >= p.S) p1 = 0.f;
+                }
+                pk[r >> 1] = pack_bf16(p0, p1);
+                zk[r >> 1] = pack_bf16(p0 * dp[r], p1 * dp[r + 1]);
+            }
+            // dV^T += dO^T . P and dK^T += Q^T . dZ over this half tile's 32 queries (two k-steps hs of 16): A fragments = transposed reads of the
+            // dO tile (offset 8192) and the Q tile, v[224:239] for hs = 0, v[240:255] for hs = 1: [dO db0 | dO db1 | Q db0 | Q db1] x 4 registers
+            {
+                const bf16x8 pf0 = frag4(pk[0], pk[1], pk[2], pk[3]), pf1 = frag4(pk[4], pk[5], pk[6], pk[7]);
+                const bf16x8 zf0 = frag4(zk[0], zk[1], zk[2], zk[3]), zf1 = frag4(zk[4], zk[5], zk[6], zk[7]);
+                const unsigned a0 = stg + qb * 4096 + trb[0][0], a1 = stg + qb * 4096 + trb[0][1];
+                const unsigned a2 = stg + qb * 4096 + trb[1][0], a3 = stg + qb * 4096 + trb[1][1];
+                asm volatile(
+                    TR_RD("v[224:225]", "%[a0]", 8192) TR_RD("v[226:227]", "%[a1]", 8192) TR_RD("v[228:229]", "%[a2]", 8192) TR_RD("v[230:231]", "%[a3]", 8192)
+                    TR_RD("v[232:233]", "%[a0]", 0) TR_RD("v[234:235]", "%[a1]", 0) TR_RD("v[236:237]", "%[a2]", 0) TR_RD("v[238:239]", "%[a3]", 0)
+                    TR_RD("v[240:241]", "%[a0]", 10240) TR_RD("v[242:243]", "%[a1]", 10240) TR_RD("v[244:245]", "%[a2]", 10240) TR_RD("v[246:247]", "%[a3]", 10240)
+                    "s_waitcnt lgkmcnt(4)\n\t"
+                    MFMA32("%[dv0]", "v[224:227]", "%[pf0]") MFMA32("%[dk0]", "v[232:235]", "%[zf0]")
+                    TR_RD("v[248:249]", "%[a0]", 2048) TR_RD("v[250:251]", "%[a1]", 2048) TR_RD("v[252:253]", "%[a2]", 2048) TR_RD("v[254:255]", "%[a3]", 2048)
+                    MFMA32("%[dv1]", "v[228:231]", "%[pf0]") MFMA32("%[dk1]", "v[236:239]", "%[zf0]")
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    MFMA32("%[dv0]", "v[240:243]", "%[pf1]") MFMA32("%[dk0]", "v[248:251]", "%[zf1]")
+                    MFMA32("%[dv1]", "v[244:247]", "%[pf1]") MFMA32("%[dk1]", "v[252:255]", "%[zf1]")
+                    : [dv0] "+v"(dv[0]), [dv1] "+v"(dv[1]), [dk0] "+v"(dk[0]), [dk1] "+v"(dk[1])
+                    : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [pf0] "v"(pf0), [pf1] "v"(pf1), [zf0] "v"(zf0), [zf1] "v"(zf1)
+                    : "memory", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
+                      "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+            }
+        }
+    }
+    __syncthreads();     // every wave is done with the ring: reuse it for the output transposes (4 KiB per wave)
+    char* ob = smem + wave * 4096;
+    const int row0 = kblk * KB + wave * 32;
+    store_rows(dk, LN2, ob, p.dk + bh * p.S_pad * 64, row0, p.S, lane);
+    store_rows(dv, 1.0f, ob, p.dv + bh * p.S_pad * 64, row0, p.S, lane);
+}
+
+// ---- pass 2: dQ.  LDS stage: K [64 keys][64 d] | V [64 keys][64 d]; ring of 3 (three workgroups per CU as before)
+constexpr int ST2T = 2 * TILE;
+constexpr int NST2 = 3;
+__global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dq_tr_kernel(AttnBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, lg = lane >> 5;
+    constexpr int QB = 32 * NWAVES;
+    const int nqb = (p.S + QB - 1) / QB;
+    const int nwg = nqb * p.H * p.B;
+    int wid = blockIdx.x;
+    {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = wid & 7;
+        wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (wid >> 3);
+    }
+    const int qblk = wid % nqb;
+    const long bh = wid / nqb;
+    const bf16_t* Kg = p.k + bh * p.S_pad * 64;
+    const bf16_t* Vg = p.v + bh * p.S_pad * 64;
+    const int q_row = qblk * QB + wave * 32 + lq;
+    const int q_ld = q_row < p.S ? q_row : p.S - 1;
+    bf16x8 qf[4], of[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        qf[kk] = *(const bf16x8*)(p.q + (bh * p.S_pad + q_ld) * 64 + kk * 16 + lg * 8);
+        of[kk] = *(const bf16x8*)(p.doh + (bh * p.S_pad + q_ld) * 64 + kk * 16 + lg * 8);
+    }
+    const float L = p.lse[bh * p.S_pad + q_ld], Dl = p.delta[bh * p.S_pad + q_ld];
+    auto stage = [&](int t, int buf) {
+        char* base = smem + buf * ST2T;
+        stage_tile2<NWAVES>(Kg + (long)t * TB * 64, 64, base, wave, lane);
+        stage_tile2<NWAVES>(Vg + (long)t * TB * 64, 64, base + TILE, wave, lane);
+    };
+    const int prow = row_perm(lq);
+    int offR[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) offR[kk] = prow * 128 + (((2 * kk + lg) ^ swz2(prow)) << 4);
+    int trb[2][2];
+    {
+        const int i = lane & 15, g1 = (lane >> 4) & 1;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int kl = 8 * lg + 4 * jj + (i >> 2);
+                const int ch = 4 * db + 2 * g1 + ((i & 3) >> 1);
+                trb[db][jj] = kl * 128 + ((ch ^ swz2(kl)) << 4) + (i & 1) * 8;
+            }
+    }
+    f32x16 dq[2];
+    dq[0] = (f32x16){0}; dq[1] = (f32x16){0};
+    const int nt = (p.S + TB - 1) / TB;
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    for (int t = 0; t < nt; ++t) {
+        wait_tiles_ahead(nt - 1 - t >= 1 ? 1 : 0, 4);
+        if (t + 2 < nt) stage(t + 2, (t + 2) % NST2);
+        const char* sb = smem + (t % NST2) * ST2T;
+        const unsigned stg = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + (t % NST2) * ST2T);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 s = (f32x16){0}, dp = (f32x16){0};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 ka = *(const bf16x8*)(sb + offR[kk] + kb * 4096);
+                const bf16x8 va = *(const bf16x8*)(sb + TILE + offR[kk] + kb * 4096);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, of[kk], dp, 0, 0, 0);
+            }
+            unsigned zk[8];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                float p0 = __builtin_amdgcn_exp2f(s[r] - L), p1 = __builtin_amdgcn_exp2f(s[r + 1] - L);
+                if (t == nt - 1) {
+                    const int kl = t * TB + 32 * kb + 16 * (r >> 3) + 8 * lg + (r & 7);
+                    if (kl >= p.S) p0 = 0.f;
+                    if (kl + 1 >= p.S) p1 = 0.f;
+                }
+                zk[r >> 1] = pack_bf16(p0 * (dp[r] - Dl), p1 * (dp[r + 1] - Dl));
+            }
+            // dQ^T += K^T . dZ^T over this half tile's 32 keys: A fragments = transposed reads of the K tile, v[152:159] (hs = 0), v[160:167] (hs = 1)
+            {
+                const bf16x8 zf0 = frag4(zk[0], zk[1], zk[2], zk[3]), zf1 = frag4(zk[4], zk[5], zk[6], zk[7]);
+                const unsigned a0 = stg + kb * 4096 + trb[0][0], a1 = stg + kb * 4096 + trb[0][1];
+                const unsigned a2 = stg + kb * 4096 + trb[1][0], a3 = stg + kb * 4096 + trb[1][1];
+                asm volatile(
+                    TR_RD("v[152:153]", "%[a0]", 0) TR_RD("v[154:155]", "%[a1]", 0) TR_RD("v[156:157]", "%[a2]", 0) TR_RD("v[158:159]", "%[a3]", 0)
+                    TR_RD("v[160:161]", "%[a0]", 2048) TR_RD("v[162:163]", "%[a1]", 2048) TR_RD("v[164:165]", "%[a2]", 2048) TR_RD("v[166:167]", "%[a3]", 2048)
+                    "s_waitcnt lgkmcnt(4)\n\t"
+                    MFMA32("%[dq0]", "v[152:155]", "%[zf0]") MFMA32("%[dq1]", "v[156:159]", "%[zf0]")
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    MFMA32("%[dq0]", "v[160:163]", "%[zf1]") MFMA32("%[dq1]", "v[164:167]", "%[zf1]")
+                    : [dq0] "+v"(dq[0]), [dq1] "+v"(dq[1])
+                    : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [zf0] "v"(zf0), [zf1] "v"(zf1)
+                    : "memory", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167");
+            }
+        }
+    }
+    __syncthreads();
+    char* ob = smem + wave * 4096;
+    store_rows(dq, LN2, ob, p.dq + bh * p.S_pad * 64, qblk * QB + wave * 32, p.S, lane);
+}
+
+}  // namespace
+
+static int g_attn_bwd_tr = 1;
+void set_attn_bwd_tr(int v) { g_attn_bwd_tr = v != 0; }
+int get_attn_bwd_tr() { return g_attn_bwd_tr; }
+
+namespace {
+hipError_t launch_attention_bwd_tr(const AttnBwdParams& p, hipStream_t stream) {
+    if (!p.nld) return hipErrorInvalidValue;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkv_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NST1 * ST1T);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nb = (p.S + 32 * NWAVES - 1) / (32 * NWAVES);
+    hipLaunchKernelGGL(attn_bwd_dkv_tr_kernel, dim3(nb * p.H * p.B), dim3(NWAVES * 64), NST1 * ST1T, stream, p);
+    hipLaunchKernelGGL(attn_bwd_dq_tr_kernel, dim3(nb * p.H * p.B), dim3(NWAVES * 64), NST2 * ST2T, stream, p);
+    return hipGetLastError();
+}
 }  // namespace
 
 hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream) {
     if (p.S <= 0 || p.S_pad % TB != 0 || p.S_pad < p.S) return hipErrorInvalidValue;
+    if (g_attn_bwd_tr) return launch_attention_bwd_tr(p, stream);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkv_kernel<NWAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * ST1);

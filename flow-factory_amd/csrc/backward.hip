@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* in, long l
 
 // ------------------------------------------------------------------ attention backward: prologue
 // token-major o / do (image rows, then context rows, as the forward wrote o) -> per (b, h):
-//   doh [B][H][S_pad][64] = do rows, doT [B][H][64][S_pad], delta [B][H][S_pad] = sum_d do * o   (fp32)
+//   doh [B][H][S_pad][64] = do rows, doT [B][H][64][S_pad] (optional), delta [B][H][S_pad] = sum_d do * o   (fp32) [, -delta, -lse]
 // one workgroup = 64 tokens of one (b, h); padded rows (s >= S) are left untouched (zero-initialised buffers)
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnBwdPrepParams p) {
     __shared__ bf16_t tile[64][66];
@@ -316,10 +316,18 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnBwdPrepParams p)
             ov = bf2f(op[row * D + h * 64 + lane]);
             p.doh[(bh * p.S_pad + s) * 64 + lane] = f2bf(dov);
             const float dl = wave_sum(dov * ov);
-            if (lane == 0) p.delta[bh * p.S_pad + s] = dl;
+            if (lane == 0) {
+                p.delta[bh * p.S_pad + s] = dl;
+                if (p.nld) {
+                    float* nl = p.nld + (bh * p.S_pad + (s & ~63)) * 2 + (s & 63);
+                    nl[0] = -p.lse[bh * p.S_pad + s];
+                    nl[64] = -dl;
+                }
+            }
         }
         tile[r][lane] = f2bf(dov);
     }
+    if (!p.doT) return;                   // (the transposed-read kernels take dO row-major only)
     __syncthreads();
     for (int d = w; d < 64; d += 4) {
         const int s = s0 + lane;

@@ -252,6 +252,7 @@ struct AttnBwdPrepParams {
     const bf16_t* o_img; const bf16_t* o_ctx; const bf16_t* do_img; const bf16_t* do_ctx;   // token-major [.][H*64]; do_ctx may be null (zeros)
     bf16_t* doh; bf16_t* doT; float* delta;                                               // [B][H][S_pad][64], [B][H][64][S_pad], [B][H][S_pad]
     int B, H, S, S_pad, n_img;
+    const float* lse; float* nld;      // optional: [B][H][S_pad / 64][2][64] = -lse | -delta per 64-query tile; doT may then be null
 };
 hipError_t launch_attn_bwd_prep(const AttnBwdPrepParams& p, hipStream_t stream);
 struct RmsBwdParams {
@@ -291,8 +292,11 @@ struct AttnBwdParams {
     const float* lse; const float* delta;
     bf16_t* dq; bf16_t* dk; bf16_t* dv;
     int B, H, S, S_pad;
+    const float* nld;      // transposed-read kernels (qT / kT / doT are not read then): [B][H][S_pad / 64][2][64] = -lse | -delta per 64-query tile
 };
 hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream);
+void set_attn_bwd_tr(int v);       // 1 (default) = the transposed-read kernels (no q^T / k^T / dO^T copies), 0 = the round-2 kernels
+int get_attn_bwd_tr();
 
 // --------------------------------------------------------------------------- SDE step (K15)
 enum Dynamics : int { DYN_ODE = 0, DYN_FLOW_SDE = 1, DYN_DANCE_SDE = 2, DYN_CPS = 3 };
