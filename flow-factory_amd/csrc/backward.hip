@@ -296,10 +296,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* in, long l
 
 // ------------------------------------------------------------------ attention backward: prologue
 // token-major o / do (image rows, then context rows, as the forward wrote o) -> per (b, h):
-//   doh [B][H][S_pad][64] = do rows, doT [B][H][64][S_pad] (optional), delta [B][H][S_pad] = sum_d do * o   (fp32) [, -delta, -lse]
+//   doh [B][H][S_pad][64] = do rows, delta [B][H][S_pad] = sum_d do * o (fp32), nld = -lse | -delta per 64-query tile (the dK/dV pass
+//   moves a tile's 128 floats into LDS with one LDS-DMA instruction per wave and feeds them to its MFMA chains as C operands)
 // one workgroup = 64 tokens of one (b, h); padded rows (s >= S) are left untouched (zero-initialised buffers)
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnBwdPrepParams p) {
-    __shared__ bf16_t tile[64][66];
     const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
     const int D = p.H * 64, n_ctx = p.S - p.n_img;
     const long bh = (long)b * p.H + h;
@@ -307,31 +307,20 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnBwdPrepParams p)
     // 4 waves x 16 tokens: lane = d
     for (int r = w; r < 64; r += 4) {
         const int s = s0 + r;
-        float dov = 0.f, ov = 0.f;
-        if (s < p.S) {
-            const long row = (s < p.n_img) ? ((long)b * p.n_img + s) : ((long)b * n_ctx + (s - p.n_img));
-            const bf16_t* dop = (s < p.n_img) ? p.do_img : p.do_ctx;
-            const bf16_t* op = (s < p.n_img) ? p.o_img : p.o_ctx;
-            if (dop) dov = bf2f(dop[row * D + h * 64 + lane]);      // do_ctx == nullptr: the context output is unused (last block)
-            ov = bf2f(op[row * D + h * 64 + lane]);
-            p.doh[(bh * p.S_pad + s) * 64 + lane] = f2bf(dov);
-            const float dl = wave_sum(dov * ov);
-            if (lane == 0) {
-                p.delta[bh * p.S_pad + s] = dl;
-                if (p.nld) {
-                    float* nl = p.nld + (bh * p.S_pad + (s & ~63)) * 2 + (s & 63);
-                    nl[0] = -p.lse[bh * p.S_pad + s];
-                    nl[64] = -dl;
-                }
-            }
+        if (s >= p.S) continue;
+        const long row = (s < p.n_img) ? ((long)b * p.n_img + s) : ((long)b * n_ctx + (s - p.n_img));
+        const bf16_t* dop = (s < p.n_img) ? p.do_img : p.do_ctx;
+        const bf16_t* op = (s < p.n_img) ? p.o_img : p.o_ctx;
+        const float dov = dop ? bf2f(dop[row * D + h * 64 + lane]) : 0.f;      // do_ctx == nullptr: the context output is unused (last block)
+        const float ov = bf2f(op[row * D + h * 64 + lane]);
+        p.doh[(bh * p.S_pad + s) * 64 + lane] = f2bf(dov);
+        const float dl = wave_sum(dov * ov);
+        if (lane == 0) {
+            p.delta[bh * p.S_pad + s] = dl;
+            float* nl = p.nld + (bh * p.S_pad + (s & ~63)) * 2 + (s & 63);
+            nl[0] = -p.lse[bh * p.S_pad + s];
+            nl[64] = -dl;
         }
-        tile[r][lane] = f2bf(dov);
-    }
-    if (!p.doT) return;                   // (the transposed-read kernels take dO row-major only)
-    __syncthreads();
-    for (int d = w; d < 64; d += 4) {
-        const int s = s0 + lane;
-        if (s < p.S) p.doT[(bh * 64 + d) * p.S_pad + s] = tile[lane][d];
     }
 }
 

@@ -250,9 +250,9 @@ hipError_t launch_transpose_colsum(const bf16_t* in, long ld_in, bf16_t* out, lo
                                    float* colsum, hipStream_t stream);
 struct AttnBwdPrepParams {
     const bf16_t* o_img; const bf16_t* o_ctx; const bf16_t* do_img; const bf16_t* do_ctx;   // token-major [.][H*64]; do_ctx may be null (zeros)
-    bf16_t* doh; bf16_t* doT; float* delta;                                               // [B][H][S_pad][64], [B][H][64][S_pad], [B][H][S_pad]
+    const float* lse;                                                                     // [B][H][S_pad] from the forward
+    bf16_t* doh; float* delta; float* nld;                                                // [B][H][S_pad][64], [B][H][S_pad], [B][H][S_pad/64][2][64]
     int B, H, S, S_pad, n_img;
-    const float* lse; float* nld;      // optional: [B][H][S_pad / 64][2][64] = -lse | -delta per 64-query tile; doT may then be null
 };
 hipError_t launch_attn_bwd_prep(const AttnBwdPrepParams& p, hipStream_t stream);
 struct RmsBwdParams {
@@ -284,19 +284,15 @@ struct SdeBwdParams {
 };
 hipError_t launch_sde_step_bwd(const SdeBwdParams& p, hipStream_t stream);
 // flash-attention backward, head_dim 64 (attention_bwd.hip).  q (pre-scaled by log2(e)/8), k, v, doh: [B][H][S_pad][64];
-// qT, kT, doT: [B][H][64][S_pad]; lse (log2 domain), delta: [B][H][S_pad] fp32.  Outputs dq (w.r.t. the stored, pre-scaled q), dk, dv
-// [B][H][S_pad][64] bf16.  Two deterministic passes: key-block-outer (dk, dv) and query-block-outer (dq).
+// lse (log2 domain), delta: [B][H][S_pad] fp32.  Outputs dq (w.r.t. the stored, pre-scaled q), dk, dv [B][H][S_pad][64] bf16.  Two deterministic passes: key-block-outer (dk, dv) and query-block-outer (dq).
 struct AttnBwdParams {
-    const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* doh;
-    const bf16_t* qT; const bf16_t* kT; const bf16_t* doT;
-    const float* lse; const float* delta;
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* doh;     // [B][H][S_pad][64] each (q pre-scaled; v row-major; doh = dO head-major)
+    const float* lse; const float* delta;                                     // [B][H][S_pad]
+    const float* nld;                                                         // [B][H][S_pad / 64][2][64] = -lse | -delta per 64-query tile
     bf16_t* dq; bf16_t* dk; bf16_t* dv;
     int B, H, S, S_pad;
-    const float* nld;      // transposed-read kernels (qT / kT / doT are not read then): [B][H][S_pad / 64][2][64] = -lse | -delta per 64-query tile
 };
 hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream);
-void set_attn_bwd_tr(int v);       // 1 (default) = the transposed-read kernels (no q^T / k^T / dO^T copies), 0 = the round-2 kernels
-int get_attn_bwd_tr();
 
 // --------------------------------------------------------------------------- SDE step (K15)
 enum Dynamics : int { DYN_ODE = 0, DYN_FLOW_SDE = 1, DYN_DANCE_SDE = 2, DYN_CPS = 3 };

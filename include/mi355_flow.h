@@ -416,8 +416,6 @@ int mi355_profile_enable(int on);
  *  22     optimize() replay (mi355_denoise_step_train / _backward): 1 (default) = the context-stream chain of every block on a side stream owned
  *         by the training state (the backward: only in the default scope with no context-stream weight gradient registered), 0 = in line.
  *         Results are bit-identical for either value.
- *  23     flash-attention backward (head_dim 64): 1 (default) = the kernels that read the streamed tiles transposed out of LDS
- *         (ds_read_b64_tr_b16: no q^T / k^T / dO^T copies, 4- / 3-stage operand rings), 0 = the round-2 kernels (A/B).
  * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);
