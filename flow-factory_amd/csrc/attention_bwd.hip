@@ -73,8 +73,8 @@ __device__ __forceinline__ bf16x8 frag4(unsigned a, unsigned b, unsigned c, unsi
 // i; checked lane by lane in scripts/mb/tr_b16_probe.hip).  Against round 2's kernels, which staged Q^T / dO^T (K^T) tiles from transposed
 // copies in HBM: half (a third) of the L2 -> LDS traffic and of the LDS footprint, which pays for a 4-stage (3-stage) ring with loads two
 // tiles ahead and counted waits instead of `vmcnt(0)` per tile, and no q^T / k^T / dO^T transpose launches.  Measured inside the
-// optimize() step (profiles/r03v_attn_bwd_tr_ab.txt, joint + dual average): dK/dV pass 558 -> 492 us, dQ pass 383 -> 380 us (that pass is
-// VALU-bound: 32 v_exp + 96 other VALU per 24 MFMAs).
+// optimize() step (profiles/r03v_attn_bwd_tr_ab.txt, joint + dual average): dK/dV pass 558 -> 492 us, dQ pass 383 -> 380 us (that pass was
+// VALU-bound: see its C-operand splats below).
 // Swizzle: physical 16-byte chunk = logical ^ swz2(row), swz2 = f ^ ((f & 1) << 2) with f = (row >> 1) & 7: still a permutation of the 8
 // even (odd) rows a ds_read_b128 lane group touches (conflict-free as before), and rows r, r + 2 of a transposed read's 4-row block now
 // sit in different 64-byte halves of their 128-byte rows (4 rows x 64 bytes = 64 distinct banks).
@@ -264,9 +264,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dkv_tr_kernel(AttnBwd
     store_rows(dv, 1.0f, ob, p.dv + bh * p.S_pad * 64, row0, p.S, lane);
 }
 
-// ---- pass 2: dQ.  LDS stage: K [64 keys][64 d] | V [64 keys][64 d]; ring of 3 (three workgroups per CU as before)
+// ---- pass 2: dQ.  LDS stage: K [64 keys][64 d] | V [64 keys][64 d]; ring of 4, two workgroups per CU
 constexpr int ST2T = 2 * TILE;
-constexpr int NST2 = 3;
+constexpr int NST2 = 4;
 __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dq_tr_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -292,7 +292,15 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dq_tr_kernel(AttnBwdP
         qf[kk] = *(const bf16x8*)(p.q + (bh * p.S_pad + q_ld) * 64 + kk * 16 + lg * 8);
         of[kk] = *(const bf16x8*)(p.doh + (bh * p.S_pad + q_ld) * 64 + kk * 16 + lg * 8);
     }
-    const float L = p.lse[bh * p.S_pad + q_ld], Dl = p.delta[bh * p.S_pad + q_ld];
+    // -L and -Delta of this lane's query as 16-register splats: the C operand of the first MFMA of every S^T / dP^T chain (vdst != src2),
+    // so the chains deliver s - L and dP - Delta and the pass issues no subtraction (it is VALU-bound: 32 v_exp + 96 other VALU per 24 MFMAs
+    // before, 32 + 32 now; the 32 registers cost the third wave per SIMD, which the VALU port could not feed anyway)
+    f32x16 nL, nD;
+    {
+        const float l = -p.lse[bh * p.S_pad + q_ld], d = -p.delta[bh * p.S_pad + q_ld];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { nL[r] = l; nD[r] = d; }
+    }
     auto stage = [&](int t, int buf) {
         char* base = smem + buf * ST2T;
         stage_tile2<NWAVES>(Kg + (long)t * TB * 64, 64, base, wave, lane);
@@ -319,47 +327,48 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dq_tr_kernel(AttnBwdP
     const int nt = (p.S + TB - 1) / TB;
     stage(0, 0);
     if (nt > 1) stage(1, 1);
+    if (nt > 2) stage(2, 2);
     for (int t = 0; t < nt; ++t) {
-        wait_tiles_ahead(nt - 1 - t >= 1 ? 1 : 0, 4);
-        if (t + 2 < nt) stage(t + 2, (t + 2) % NST2);
+        wait_tiles_ahead(nt - 1 - t, 4);
+        if (t + 3 < nt) stage(t + 3, (t + 3) % NST2);
         const char* sb = smem + (t % NST2) * ST2T;
         const unsigned stg = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + (t % NST2) * ST2T);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            f32x16 s = (f32x16){0}, dp = (f32x16){0};
+            f32x16 s, dp;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const bf16x8 ka = *(const bf16x8*)(sb + offR[kk] + kb * 4096);
                 const bf16x8 va = *(const bf16x8*)(sb + TILE + offR[kk] + kb * 4096);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[kk], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, of[kk], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[kk], kk == 0 ? nL : s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, of[kk], kk == 0 ? nD : dp, 0, 0, 0);
             }
             unsigned zk[8];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                float p0 = __builtin_amdgcn_exp2f(s[r] - L), p1 = __builtin_amdgcn_exp2f(s[r + 1] - L);
+                float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
                 if (t == nt - 1) {
                     const int kl = t * TB + 32 * kb + 16 * (r >> 3) + 8 * lg + (r & 7);
                     if (kl >= p.S) p0 = 0.f;
                     if (kl + 1 >= p.S) p1 = 0.f;
                 }
-                zk[r >> 1] = pack_bf16(p0 * (dp[r] - Dl), p1 * (dp[r + 1] - Dl));
+                zk[r >> 1] = pack_bf16(p0 * dp[r], p1 * dp[r + 1]);
             }
-            // dQ^T += K^T . dZ^T over this half tile's 32 keys: A fragments = transposed reads of the K tile, v[152:159] (hs = 0), v[160:167] (hs = 1)
+            // dQ^T += K^T . dZ^T over this half tile's 32 keys: A fragments = transposed reads of the K tile, v[224:231] (hs = 0), v[232:239] (hs = 1)
             {
                 const bf16x8 zf0 = frag4(zk[0], zk[1], zk[2], zk[3]), zf1 = frag4(zk[4], zk[5], zk[6], zk[7]);
                 const unsigned a0 = stg + kb * 4096 + trb[0][0], a1 = stg + kb * 4096 + trb[0][1];
                 const unsigned a2 = stg + kb * 4096 + trb[1][0], a3 = stg + kb * 4096 + trb[1][1];
                 asm volatile(
-                    TR_RD("v[152:153]", "%[a0]", 0) TR_RD("v[154:155]", "%[a1]", 0) TR_RD("v[156:157]", "%[a2]", 0) TR_RD("v[158:159]", "%[a3]", 0)
-                    TR_RD("v[160:161]", "%[a0]", 2048) TR_RD("v[162:163]", "%[a1]", 2048) TR_RD("v[164:165]", "%[a2]", 2048) TR_RD("v[166:167]", "%[a3]", 2048)
+                    TR_RD("v[224:225]", "%[a0]", 0) TR_RD("v[226:227]", "%[a1]", 0) TR_RD("v[228:229]", "%[a2]", 0) TR_RD("v[230:231]", "%[a3]", 0)
+                    TR_RD("v[232:233]", "%[a0]", 2048) TR_RD("v[234:235]", "%[a1]", 2048) TR_RD("v[236:237]", "%[a2]", 2048) TR_RD("v[238:239]", "%[a3]", 2048)
                     "s_waitcnt lgkmcnt(4)\n\t"
-                    MFMA32("%[dq0]", "v[152:155]", "%[zf0]") MFMA32("%[dq1]", "v[156:159]", "%[zf0]")
+                    MFMA32("%[dq0]", "v[224:227]", "%[zf0]") MFMA32("%[dq1]", "v[228:231]", "%[zf0]")
                     "s_waitcnt lgkmcnt(0)\n\t"
-                    MFMA32("%[dq0]", "v[160:163]", "%[zf1]") MFMA32("%[dq1]", "v[164:167]", "%[zf1]")
+                    MFMA32("%[dq0]", "v[232:235]", "%[zf1]") MFMA32("%[dq1]", "v[236:239]", "%[zf1]")
                     : [dq0] "+v"(dq[0]), [dq1] "+v"(dq[1])
                     : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [zf0] "v"(zf0), [zf1] "v"(zf1)
-                    : "memory", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167");
+                    : "memory", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239");
             }
         }
     }
