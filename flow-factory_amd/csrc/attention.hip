@@ -48,6 +48,8 @@ int g_attn_variant = 1;
 // LSE: also write the per-query log-sum-exp (training-mode forward).  A template parameter, not a runtime test of p.lse: the dynamic
 // 8-wave kernel sits at its 128-VGPR / ~102-SGPR budget, and keeping the extra pointer and row index live across the key loop spilled
 // 14 VGPRs to scratch (measured in round 2: 1046 -> 911 TFLOP/s) -- the rollout instantiations must not pay for the training output.
+// (Measured and dropped in round 3, profiles/r03x_attn_ring_ab.txt: a 4-stage K / V^T ring with loads two tiles ahead and counted waits -- what
+// bought the backward's dK/dV pass 12 % at two waves per SIMD -- is 1-2 % SLOWER here: with four waves per SIMD the load latency is already hidden.)
 // (Measured and dropped in round 3, profiles/r03a_attn_ab_variants.txt: row sums on the matrix pipe -- one more MFMA per 16-key step with an
 // all-ones A operand instead of the 16 v_dot2c per tile -- 998 vs 1029 TFLOP/s at S = 4429, 1028 vs 1094 at S = 4096: the fifth MFMA per
 // step costs more matrix-pipe time than the dot2s cost on the VALU port.)
