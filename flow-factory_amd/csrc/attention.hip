@@ -53,9 +53,7 @@ int g_attn_variant = 1;
 // (Measured and dropped in round 3, profiles/r03a_attn_ab_variants.txt: row sums on the matrix pipe -- one more MFMA per 16-key step with an
 // all-ones A operand instead of the 16 v_dot2c per tile -- 998 vs 1029 TFLOP/s at S = 4429, 1028 vs 1094 at S = 4096: the fifth MFMA per
 // step costs more matrix-pipe time than the dot2s cost on the VALU port.)
-// RING: stages of the K / V^T ring.  2 = tile t+1 put in flight after tile t's barrier, `vmcnt(0)` before the next barrier; 4 = loads TWO tiles
-// ahead with counted waits (the deferred-rescale kernels with 8 waves only: 64 KiB per workgroup, still two workgroups per CU).
-template <bool V2, int NWAVE, bool STATIC = false, bool LSE = false, int RING = 2>
+template <bool V2, int NWAVE, bool STATIC = false, bool LSE = false>
 __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
     constexpr int QB = QW * NWAVE;  // queries per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -226,29 +224,12 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
     f32x16 negm = (f32x16){0};
     // a wave whose 32 queries all lie beyond S (tail of the last query block: 179 of its 256 rows at S = 4429) only helps staging
     const bool wave_active = (qblk * QB + wave * QW) < p.S;
-    if constexpr (RING == 4) {
-        if (nt > 1) stage(1, 1);
-        if (nt > 2) stage(2, 2);
-    }
     for (int t = 0; t < nt; ++t) {
-        if constexpr (RING == 4) {
-            static_assert(RING == 2 || NG == 1, "the counted waits below assume 2 LDS-DMA instructions per wave and tile");
-            // tiles t+1, t+2 (2 VM operations per wave each) were issued after tile t: vmcnt retires in order
-            const int ahead = nt - 1 - t;
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 3 < nt) stage(t + 3, (t + 3) & 3);      // its buffer held tile t - 1: every wave is past it
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
         if (!wave_active) continue;
-        const char* sb = smem + (t & (RING - 1)) * STAGE_BYTES;
+        const char* sb = smem + (t & 1) * STAGE_BYTES;
         f32x16 s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -375,8 +356,6 @@ __global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
 
 }  // namespace
 
-static int g_attn_ring = 2;
-void set_attn_ring(int v) { g_attn_ring = v == 4 ? 4 : 2; }
 void set_attn_variant(int v) { g_attn_variant = v; }
 int get_attn_variant() { return g_attn_variant; }
 
@@ -387,13 +366,6 @@ static void launch_variant(const AttnParams& p, hipStream_t stream) {
     // RMSNorm epilogue, gemm.hip), and rollout vs training-mode forward must agree bit for bit.  The deferred-rescale kernels are checked
     // for that on the GPU (tests/test_gpu_backward.py::test_train_forward_is_bit_identical_at_full_width); the plain kernel (A/B variant 0,
     // not performance-critical) simply always runs its LSE build.
-    if constexpr (V2 && NWAVE == 8) {
-        if (g_attn_ring == 4) {
-            if (p.lse) hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, true, 4>), grid, block, 4 * STAGE_BYTES, stream, p);
-            else hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, false, 4>), grid, block, 4 * STAGE_BYTES, stream, p);
-            return;
-        }
-    }
     if (p.lse || !V2) hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, true>), grid, block, 2 * STAGE_BYTES, stream, p);
     else hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, false>), grid, block, 2 * STAGE_BYTES, stream, p);
 }

@@ -98,8 +98,7 @@ void set_pp_min_tiles(int v);
 void set_raster_gm(int v);      // GEMM tile raster: tile rows per band (0 = row-major)
 void set_conv_cfg(int v);       // VAE conv tile shape A/B knob (0 auto)
 void set_attn_variant(int v);  // 0 = plain online softmax, 1 = deferred-rescale (default)
-int get_attn_variant();
-void set_attn_ring(int v);     // K / V^T ring of the 8-wave head_dim-64 kernels: 2 or 4 stages
+int get_attn_variant();  // tuning / A-B knob: 0 = simple 2-stage 256x256 kernel, 1 = ping-pong (default)
 
 // ------------------------------------------------------------------------------- attention
 // Non-causal softmax(q k^T / 8) v over S keys, head_dim 64.  q,k: [B][H][S_pad][64],
