@@ -414,8 +414,8 @@ int mi355_profile_enable(int on);
  *  17     the same for mi355_qwen_rollout (the prompt preparation, which uploads the per-sample key lengths, stays in front of the graph).
  *  19     largest K that key 0 = 1 gives to the 4-wave GEMM kernel (default 3072).
  *  22     optimize() replay (mi355_denoise_step_train / _backward): 1 (default) = the context-stream chain of every block on a side stream owned
- *         by the training state (the backward: only in the default scope with no context-stream weight gradient registered), 0 = in line.
- *         Results are bit-identical for either value.
+ *         by the training state (the backward: in the default gradient scope; the context stream's weight gradients run there too, on
+ *         their own scratch), 0 = in line.  Results are bit-identical for either value.
  * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);
