@@ -53,12 +53,8 @@ int g_attn_variant = 1;
 // (Measured and dropped in round 3, profiles/r03a_attn_ab_variants.txt: row sums on the matrix pipe -- one more MFMA per 16-key step with an
 // all-ones A operand instead of the 16 v_dot2c per tile -- 998 vs 1029 TFLOP/s at S = 4429, 1028 vs 1094 at S = 4096: the fifth MFMA per
 // step costs more matrix-pipe time than the dot2s cost on the VALU port.)
-// OCC: waves per SIMD the register allocator must leave room for.  4 everywhere except the small-grid instantiations (4 waves, OCC = 5:
-// 96 VGPRs, 18-50 dwords of scratch, five 32-KiB workgroups = all 160 KiB of a CU's LDS), which exist for one reason: a launch takes
-// ceil(workgroups / slots) rounds of one key loop each, and at the reference's 512^2 example shapes (S = 1357) the grid is 1.03-2.06 x the
-// 4-waves-per-SIMD slots -- 1280 instead of 1024 workgroup slots remove a whole round (launch_attention picks; bit-identical results).
-template <bool V2, int NWAVE, bool STATIC = false, bool LSE = false, int OCC = 4>
-__global__ __launch_bounds__(NWAVE * 64, OCC) void attn_kernel(AttnParams p) {
+template <bool V2, int NWAVE, bool STATIC = false, bool LSE = false>
+__global__ __launch_bounds__(NWAVE * 64, 4) void attn_kernel(AttnParams p) {
     constexpr int QB = QW * NWAVE;  // queries per workgroup
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -363,35 +359,15 @@ __global__ __launch_bounds__(NWAVE * 64, OCC) void attn_kernel(AttnParams p) {
 void set_attn_variant(int v) { g_attn_variant = v; }
 int get_attn_variant() { return g_attn_variant; }
 
-template <bool V2, int NWAVE, bool STATIC, int OCC = 4>
+template <bool V2, int NWAVE, bool STATIC>
 static void launch_variant(const AttnParams& p, hipStream_t stream) {
     const dim3 grid(((p.S + QW * NWAVE - 1) / (QW * NWAVE)) * p.H * p.B), block(NWAVE * 64);
     // Two instantiations of one source may round differently (hipcc contracts / packs fp ops per instantiation: seen on the fused
     // RMSNorm epilogue, gemm.hip), and rollout vs training-mode forward must agree bit for bit.  The deferred-rescale kernels are checked
     // for that on the GPU (tests/test_gpu_backward.py::test_train_forward_is_bit_identical_at_full_width); the plain kernel (A/B variant 0,
     // not performance-critical) simply always runs its LSE build.
-    if (p.lse || !V2) hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, true, OCC>), grid, block, 2 * STAGE_BYTES, stream, p);
-    else hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, false, OCC>), grid, block, 2 * STAGE_BYTES, stream, p);
-}
-
-// key 23: workgroup shape of the deferred-rescale / static kernels: 0 (default) = by rounds (below), 1 = 8 waves, 2 = 4 waves, 3 = 4 waves at five
-// waves per SIMD
-static int g_attn_shape = 0;
-void set_attn_shape(int v) { g_attn_shape = v; }
-
-// Rounds of one key loop a launch takes on 256 CUs: 8-wave workgroups have 512 slots, 4-wave ones 1024 (four waves per SIMD) or 1280
-// (five: the spilling instantiation, ~`SPILL` x the time per round).  Large grids stay on the 8-wave kernel.
-static int pick_attn_shape(const AttnParams& p) {
-    if (g_attn_shape >= 1 && g_attn_shape <= 3) return g_attn_shape;
-    const long bh = (long)p.B * p.H;
-    const long w8 = bh * ((p.S + 255) / 256), w4 = bh * ((p.S + 127) / 128);
-    if (w8 > 2560) return 1;
-    const long r8 = (w8 + 511) / 512, r4 = (w4 + 1023) / 1024, r5 = (w4 + 1279) / 1280;
-    const float SPILL = 1.12f;
-    float best = (float)r8; int shape = 1;
-    if ((float)r4 < best) { best = (float)r4; shape = 2; }
-    if ((float)r5 * SPILL < best) { best = (float)r5 * SPILL; shape = 3; }
-    return shape;
+    if (p.lse || !V2) hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, true>), grid, block, 2 * STAGE_BYTES, stream, p);
+    else hipLaunchKernelGGL((attn_kernel<V2, NWAVE, STATIC, false>), grid, block, 2 * STAGE_BYTES, stream, p);
 }
 
 hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
@@ -404,19 +380,13 @@ hipError_t launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.S <= 0 || p.S_pad % KV != 0 || p.S_pad < p.S) return hipErrorInvalidValue;
     const bool stat = p.score_bound > 0.f && p.score_bound <= 60.f;
     if (g_attn_variant == 0) launch_variant<false, 8, false>(p, stream);
-    else {
-        // (variant 2 = the 4-wave workgroups everywhere: A/B, profiles/r02_small_batch_attention_ab.txt)
-        const int shape = g_attn_variant == 2 ? 2 : pick_attn_shape(p);
-        if (shape == 1) {
-            if (stat) launch_variant<true, 8, true>(p, stream);
-            else launch_variant<true, 8, false>(p, stream);
-        } else if (shape == 2) {
-            if (stat) launch_variant<true, 4, true>(p, stream);
-            else launch_variant<true, 4, false>(p, stream);
-        } else {
-            if (stat) launch_variant<true, 4, true, 5>(p, stream);
-            else launch_variant<true, 4, false, 5>(p, stream);
-        }
+    else if (g_attn_variant == 1) {
+        if (stat) launch_variant<true, 8, true>(p, stream);
+        else launch_variant<true, 8, false>(p, stream);
+    } else {
+        // 4-wave workgroups (128 queries): twice the workgroups at half the size (A/B: profiles/r02_small_batch_attention_ab.txt)
+        if (stat) launch_variant<true, 4, true>(p, stream);
+        else launch_variant<true, 4, false>(p, stream);
     }
     return hipGetLastError();
 }

@@ -98,8 +98,7 @@ void set_pp_min_tiles(int v);
 void set_raster_gm(int v);      // GEMM tile raster: tile rows per band (0 = row-major)
 void set_conv_cfg(int v);       // VAE conv tile shape A/B knob (0 auto)
 void set_attn_variant(int v);  // 0 = plain online softmax, 1 = deferred-rescale (default)
-int get_attn_variant();
-void set_attn_shape(int v);    // workgroup shape of the head_dim-64 kernels: 0 auto (by rounds), 1 = 8 waves, 2 = 4 waves, 3 = 4 waves at five waves per SIMD  // tuning / A-B knob: 0 = simple 2-stage 256x256 kernel, 1 = ping-pong (default)
+int get_attn_variant();  // tuning / A-B knob: 0 = simple 2-stage 256x256 kernel, 1 = ping-pong (default)
 
 // ------------------------------------------------------------------------------- attention
 // Non-causal softmax(q k^T / 8) v over S keys, head_dim 64.  q,k: [B][H][S_pad][64],

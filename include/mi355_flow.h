@@ -416,8 +416,6 @@ int mi355_profile_enable(int on);
  *  22     optimize() replay (mi355_denoise_step_train / _backward): 1 (default) = the context-stream chain of every block on a side stream owned
  *         by the training state (the backward: in the default gradient scope; the context stream's weight gradients run there too, on
  *         their own scratch), 0 = in line.  Results are bit-identical for either value.
- *  23     head_dim-64 attention, workgroup shape: 0 (default) = chosen per launch by how many rounds of one key loop the grid takes (8-wave
- *         workgroups: 512 slots; 4-wave: 1024; 4-wave at five waves per SIMD: 1280 -- small grids only), 1 / 2 / 3 force one.  Bit-identical.
  * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);
