@@ -48,6 +48,10 @@ int g_attn_variant = 1;
 // LSE: also write the per-query log-sum-exp (training-mode forward).  A template parameter, not a runtime test of p.lse: the dynamic
 // 8-wave kernel sits at its 128-VGPR / ~102-SGPR budget, and keeping the extra pointer and row index live across the key loop spilled
 // 14 VGPRs to scratch (measured in round 2: 1046 -> 911 TFLOP/s) -- the rollout instantiations must not pay for the training output.
+// (Measured and dropped in round 3, profiles/r03z_attn_shape_occupancy5_ab.txt: 4-wave instantiations squeezed to 96 VGPRs for FIVE waves per
+// SIMD -- 1280 instead of 1024 workgroup slots, which would take a whole round off the small grids of the reference's 512^2 examples
+// (S = 1357: 1056 workgroups) -- spill 18-50 dwords into the key loop: 1.5 x (static) to 3.5 x (running max) slower.  Nor do rounds cost what
+// the count suggests: B' = 4 / 8 / 16 at S = 1357 take 69 / 110 / 203 us.)
 // (Measured and dropped in round 3, profiles/r03x_attn_ring_ab.txt: a 4-stage K / V^T ring with loads two tiles ahead and counted waits -- what
 // bought the backward's dK/dV pass 12 % at two waves per SIMD -- is 1-2 % SLOWER here: with four waves per SIMD the load latency is already hidden.)
 // (Measured and dropped in round 3, profiles/r03a_attn_ab_variants.txt: row sums on the matrix pipe -- one more MFMA per 16-key step with an
