@@ -50,6 +50,10 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn128_kernel(Attn128Params p)
     const int bhi = wid / nqb;
     const int h = bhi % p.H, b = bhi / p.H;
     const long bh = (long)b * p.H + h;
+    if (p.mode) {       // data-dependent static / running-max split: every workgroup decides by its own (b, h) (wave-uniform loads)
+        const float bound = sqrtf(__uint_as_float(p.qmax2[bh]) * __uint_as_float(p.kmax2[bh])) * 1.01f;
+        if ((bound <= 60.f) != (p.mode == 1)) return;
+    }
     // keys / values may be a different sequence (cross-attention): S_kv == 0 means self-attention over the S queries
     int Skv = p.S_kv > 0 ? p.S_kv : p.S;
     if (p.kv_len) Skv = min(Skv, max(1, __builtin_amdgcn_readfirstlane(p.kv_len[b])));
@@ -257,6 +261,10 @@ __global__ __launch_bounds__(256) void attn128_w4_kernel(Attn128Params p) {
     const int bhi = wid / nqb;
     const int h = bhi % p.H, b = bhi / p.H;
     const long bh = (long)b * p.H + h;
+    if (p.mode) {       // data-dependent static / running-max split: every workgroup decides by its own (b, h) (wave-uniform loads)
+        const float bound = sqrtf(__uint_as_float(p.qmax2[bh]) * __uint_as_float(p.kmax2[bh])) * 1.01f;
+        if ((bound <= 60.f) != (p.mode == 1)) return;
+    }
     int Skv = p.S;
     if (p.kv_len) Skv = min(Skv, max(1, __builtin_amdgcn_readfirstlane(p.kv_len[b])));
     const bf16_t* Qg = p.q + bh * p.S_pad * HD;
@@ -423,7 +431,18 @@ hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream) {
     if (p.S <= 0 || p.S_pad < p.S || p.n_first < 0 || p.n_first > p.S) return hipErrorInvalidValue;
     if (p.S_kv > 0 ? (p.S_kv_pad % KV != 0 || p.S_kv_pad < p.S_kv) : (p.S_pad % KV != 0)) return hipErrorInvalidValue;
     if (g_attn128_variant == 1) return launch128<4, false>(p, stream);
-    const bool stat = p.score_bound > 0.f && p.score_bound <= 60.f;
+    bool stat = p.score_bound > 0.f && p.score_bound <= 60.f;
+    if (!stat && p.qmax2 && p.kmax2 && p.S_kv == 0 && g_attn128_variant == 0) {
+        // no weight-side proof (Wan: RMSNorm across heads), but the producers of q and k measured their row norms: both kernels are launched and
+        // every workgroup runs or exits by its own (b, h).  (b, h) pairs whose scores can exceed 60 keep the running max; the others -- all of
+        // them for ordinary activations -- take the hand-scheduled static kernel.  The exiting workgroups cost a few microseconds per launch.
+        Attn128Params a = p;
+        a.mode = 1; a.score_bound = 60.f;
+        hipError_t e = launch128_w4<16>(a, stream);
+        if (e != hipSuccess) return e;
+        a.mode = 2; a.score_bound = 0.f;
+        return launch128<8, false>(a, stream);
+    }
     if (stat && p.S_kv == 0 && g_attn128_variant != 5) {         // the 4-wave hand-scheduled kernel wherever it applies (default)
         if (g_attn128_variant == 101) return launch128_w4<101>(p, stream);      // (ablation builds: timing only)
         if (g_attn128_variant == 102) return launch128_w4<102>(p, stream);

@@ -60,7 +60,14 @@ __global__ __launch_bounds__(256) void norm_rope_full_kernel(NormRopeFullParams 
             const float2 w = *(const float2*)(p.weight + h * 128 + 2 * lane);
             const float a = x0[h] * rstd * w.x, bb = x1[h] * rstd * w.y;
             const float ra = (a * c - bb * sn) * p.out_scale, rb = (bb * c + a * sn) * p.out_scale;
-            *(unsigned*)(p.out + (((long)b * p.H + h) * p.S_pad + s) * 128 + 2 * lane) = pack_bf16(ra, rb);
+            const unsigned u = pack_bf16(ra, rb);
+            *(unsigned*)(p.out + (((long)b * p.H + h) * p.S_pad + s) * 128 + 2 * lane) = u;
+            if (p.max2) {       // squared norm of the row AS STORED: the attention's data-dependent score bound (non-negative floats order like their bits)
+                const float n2 = wave_sum(bf_lo(u) * bf_lo(u) + bf_hi(u) * bf_hi(u));
+                // (the maximum only grows: a plain -- possibly stale, i.e. smaller -- read can only cause a redundant atomic, never skip a needed
+                // one; after the first rows of a (b, h) almost every row skips, so 40 000 rows do not queue on 24 addresses)
+                if (lane == 0 && __float_as_uint(n2) > p.max2[(long)b * p.H + h]) atomicMax(p.max2 + (long)b * p.H + h, __float_as_uint(n2));
+            }
         }
 }
 

@@ -125,12 +125,18 @@ struct Attn128Params {
     float score_bound; // > 0: proven bound on |score| (log2 domain); <= 60 selects the no-running-max kernel
     int S_kv, S_kv_pad; // cross-attention: keys / values are a different sequence (k [B][H][S_kv_pad][128], vT [B][H][128][S_kv_pad]); 0 = self
     const int* kv_len;  // optional device [B]: sample b attends to keys [0, kv_len[b]) only (ragged text at the END of the joint sequence)
+    // optional device [B*H] each: the largest squared row norm of this launch's stored q (k) per (batch, head), as its producer measured it
+    // (norm_rope_full).  |score| <= |q| |k| then bounds every score of a (b, h) from the DATA: launch_attention128 launches the static-softmax
+    // kernel and the running-max kernel, and each workgroup runs or exits by its own (b, h)'s bound (`mode` below).
+    const unsigned* qmax2; const unsigned* kmax2;
+    int mode;           // set by launch_attention128: 0 = always run, 1 = run only where the measured bound <= 60, 2 = only where it is larger
 };
 hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream);
 void set_attn128_variant(int v);   // 0 (default): 4-wave hand-scheduled kernel where it applies, else 8-wave workgroups; 1: 4-wave compiler-scheduled; 5: never hand-scheduled
 int get_attn128_variant();
 void set_attn128_op_bound(int v);  // mi355_op_attention128 passes this as the proven |score| bound (0 = none); mi355_tune_set(21, v)
 int get_attn128_op_bound();
+void set_wan_data_bound(int v);            // wan_engine.hip: data-dependent static / running-max split of the self-attention (1 = default)
 void set_qwen_two_stream(int mode);        // qwen_engine.hip: text chain on a side stream (0 off = default, 1 on, 2 auto by image rows)
 void set_qwen_two_stream_rows(int rows);
 void set_qwen_graph(int on);               // qwen_engine.hip: replay the N-step loop of mi355_qwen_rollout as one hipGraph (0 = default: eager)
@@ -162,6 +168,7 @@ struct NormRopeFullParams {
     bf16_t* out;
     int M, H, rows_per_sample, s_off, S_pad;
     float eps, out_scale;
+    unsigned* max2;                           // optional [B*H]: atomic max of the squared norm of every stored (bf16-rounded) output row, as float bits
 };
 hipError_t launch_norm_rope_full(const NormRopeFullParams& p, hipStream_t stream);
 // Qwen-Image: RMSNorm over whole rows (weight fp32 [D]) and the norm-rescaled true-CFG combine over C = 64 channel tokens (flux_ops.hip)

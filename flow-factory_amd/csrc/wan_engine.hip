@@ -194,6 +194,7 @@ struct mi355_wan_plan {
     char *io_init, *io_traj;
     float *io_noise, *io_lp;
     bf16_t *io_pe, *io_ne;
+    unsigned* max2;            // [2][Bp*H]: largest squared stored row norm of q / k per (batch, head) of the current self-attention (float bits)
     std::vector<float> host_t, host_sc;
     int mod_cols;
 };
@@ -233,6 +234,7 @@ extern "C" int mi355_wan_plan_create(mi355_wan* e, int batch, int n_cfg, int lat
     size_t o_ii = take(nl, 4), o_it = take((int64_t)(max_steps + 1) * nl, 4), o_in = take((int64_t)max_steps * nl, 4);
     size_t o_il = take((int64_t)max_steps * batch, 4);
     size_t o_ipe = take((int64_t)batch * n_text * e->cfg.text_dim, 2), o_ine = take((int64_t)batch * n_text * e->cfg.text_dim, 2);
+    size_t o_max2 = take((int64_t)2 * p->Bp * e->H, 4);
     p->ws_bytes = off;
     if (hipMalloc((void**)&p->ws, off) != hipSuccess) {
         int r = errorf("mi355_wan_plan_create: hipMalloc of %zu bytes failed", off);
@@ -254,6 +256,7 @@ extern "C" int mi355_wan_plan_create(mi355_wan* e, int batch, int n_cfg, int lat
     p->cs = (float2*)(w + o_cs); p->t_dev = (float*)(w + o_t); p->scal = (float*)(w + o_sc);
     p->io_init = w + o_ii; p->io_traj = w + o_it; p->io_noise = (float*)(w + o_in); p->io_lp = (float*)(w + o_il);
     p->io_pe = (bf16_t*)(w + o_ipe); p->io_ne = (bf16_t*)(w + o_ine);
+    p->max2 = (unsigned*)(w + o_max2);
     // rotary table (WanRotaryPosEmbed): head_dim 128 -> t / h / w axes of 44 / 42 / 42 features, float64 angles, adjacent pairs
     {
         const int hw = 2 * (128 / 6), ax[3] = {128 - 2 * hw, hw, hw};
@@ -292,6 +295,12 @@ namespace {
 
 constexpr float kScale = 0.08838834764831845f * 1.4426950408889634f;   // log2(e) / sqrt(128)
 
+// key 24: self-attention score bound from the data where the weights prove none (1 = default).  Wan's q / k RMSNorm runs ACROSS heads, so the
+// weight-side bound is 200 * max|w_q| * max|w_k| -- never <= 60 -- and every self-attention ran the running-max kernel.  The kernel that
+// stores q and k now also measures them (largest squared row norm per (batch, head), one atomic max per row and head); |q . k| <= |q| |k| then
+// bounds the scores of each (b, h) from what is actually there, and the static-softmax 4-wave kernel takes every (b, h) that passes.
+int g_wan_data_bound = 1;
+
 // after a (re)bind: LayerNorm-affine rows for ln_mod, and the |score| bounds from the across-head norm weights:
 // ||q_hat|| <= sqrt(H*128) * max|w| for the whole row, so per head |q_h . k_h| <= ||q_hat|| ||k_hat|| (Cauchy-Schwarz on the sub-vectors)
 int refresh_derived(mi355_wan* e, hipStream_t st) {
@@ -328,11 +337,11 @@ int ln_mod(mi355_wan_plan* p, hipStream_t st, const bf16_t* x, bf16_t* out, cons
 }
 
 int norm_rope(mi355_wan_plan* p, hipStream_t st, const bf16_t* src, long ld, int col, const float* w, bool rope, bf16_t* out, int M, int rps,
-              int S_pad, float scale) {
+              int S_pad, float scale, unsigned* max2 = nullptr) {
     NormRopeFullParams r;
     memset(&r, 0, sizeof(r));
     r.src = src; r.src_ld = ld; r.col = col; r.weight = w; r.cs = rope ? p->cs : nullptr; r.out = out; r.M = M; r.H = p->e->H;
-    r.rows_per_sample = rps; r.s_off = 0; r.S_pad = S_pad; r.eps = p->e->cfg.eps; r.out_scale = scale;
+    r.rows_per_sample = rps; r.s_off = 0; r.S_pad = S_pad; r.eps = p->e->cfg.eps; r.out_scale = scale; r.max2 = max2;
     HIPCHK(launch_norm_rope_full(r, st));
     return 0;
 }
@@ -412,14 +421,18 @@ int forward_core(mi355_wan_plan* p, hipStream_t st, const void* latents, int lat
         CHK(ln_mod(p, st, p->x, p->xn, mod, p->mod_cols, M, S, m0, m0 + D));
         GemmParams gq = make_gemm(p->xn, D, b.w_qk, D, M, 2 * D, D, EPI_BIAS, b.b_qk, p->qkbuf, 2 * D);
         HIPCHK(launch_gemm(gq, st));
-        CHK(norm_rope(p, st, p->qkbuf, 2 * D, 0, b.nq, true, p->q, M, S, p->S_pad, kScale));
-        CHK(norm_rope(p, st, p->qkbuf, 2 * D, D, b.nk, true, p->k, M, S, p->S_pad, 1.0f));
+        // self-attention score bound from the data (the weights prove none: RMSNorm across heads): largest stored row norm per (b, h)
+        const bool dyn_bound = g_wan_data_bound && !(e->bound_self[i] > 0.f && e->bound_self[i] <= 60.f);
+        if (dyn_bound) HIPCHK(hipMemsetAsync(p->max2, 0, (size_t)2 * p->Bp * e->H * 4, st));
+        CHK(norm_rope(p, st, p->qkbuf, 2 * D, 0, b.nq, true, p->q, M, S, p->S_pad, kScale, dyn_bound ? p->max2 : nullptr));
+        CHK(norm_rope(p, st, p->qkbuf, 2 * D, D, b.nk, true, p->k, M, S, p->S_pad, 1.0f, dyn_bound ? p->max2 + p->Bp * e->H : nullptr));
         CHK(vt_proj(p, st, b.w_v, b.b_v, p->xn, M, S, p->vT, p->S_pad));
         {
             Attn128Params a;
             memset(&a, 0, sizeof(a));
             a.q = p->q; a.k = p->k; a.vT = p->vT; a.o_first = p->o; a.ld_first = D; a.n_first = S; a.o_rest = p->o; a.ld_rest = D;
             a.B = p->Bp; a.H = e->H; a.S = S; a.S_pad = p->S_pad; a.q_prescaled = 1; a.score_bound = e->bound_self[i];
+            if (dyn_bound) { a.qmax2 = p->max2; a.kmax2 = p->max2 + p->Bp * e->H; }
             HIPCHK(launch_attention128(a, st));
         }
         CHK(gate_res(p, st, p->o, D, b.w_o, b.b_o, p->x, M, S, mod, m0 + 2 * D));
@@ -454,6 +467,8 @@ int forward_core(mi355_wan_plan* p, hipStream_t st, const void* latents, int lat
 }
 
 }  // namespace
+
+namespace mi355 { void set_wan_data_bound(int v) { g_wan_data_bound = v != 0; } }
 
 // transformer only (tests / replay): t[Bp] device fp32 = the timestep values the network embeds; enc_b == NULL when n_cfg == 1.
 // With n_cfg == 2 the forward batch is [enc_a (negative), enc_b (positive)] on replicated latents, v_out holds both halves.

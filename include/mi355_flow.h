@@ -416,6 +416,9 @@ int mi355_profile_enable(int on);
  *  22     optimize() replay (mi355_denoise_step_train / _backward): 1 (default) = the context-stream chain of every block on a side stream owned
  *         by the training state (the backward: in the default gradient scope; the context stream's weight gradients run there too, on
  *         their own scratch), 0 = in line.  Results are bit-identical for either value.
+ *  24     Wan self-attention: 1 (default) = the kernel that stores q and k also measures their largest row norm per (batch, head), and every
+ *         (batch, head) whose |q| |k| bound stays <= 60 runs the static-softmax hand-scheduled kernel (the others keep the running max);
+ *         0 = the weight-side bound only (never satisfied by Wan's across-head RMSNorm: running-max kernel everywhere).
  * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);

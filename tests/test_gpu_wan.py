@@ -53,6 +53,46 @@ def test_wan_forward_matches_oracle(wn, B, T, h, w, Nt, n_cfg):
     eng.close()
 
 
+def test_wan_self_attention_splits_static_and_running_max_by_the_measured_norms(wn):
+    """mi355_tune_set(24, .): the kernel that stores q / k measures their largest row norm per (batch, head); (batch, head) pairs whose
+    |q| |k| stays <= 60 run the static-softmax kernel, the others the running-max kernel -- inside ONE launch pair.  Here head 1's q / k norm
+    weights are 8 x larger (its scores reach the hundreds: exp2 would overflow without a running max) while head 0 stays ordinary: the
+    forward must match the oracle, and the all-running-max forward (key 24 = 0), to bf16 accuracy."""
+    from mi355_flow import _lib
+    from oracle import wan_ref as R
+    lib = _lib.load()
+    cfg_o = R.tiny_config()
+    sd, cfg = _setup(wn, cfg_o, seed=77)
+    H = cfg_o.num_attention_heads
+    assert H >= 2
+    for k_ in list(sd):
+        if k_.endswith("attn1.norm_q.weight") or k_.endswith("attn1.norm_k.weight"):
+            w = sd[k_].clone()
+            w[128:256] *= 8.0
+            sd[k_] = _bf(w)
+    B, T, h, w_, Nt = 2, 2, 8, 12, 9
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 16, T, h, w_, generator=g).half()
+    pe = _bf(torch.randn(B, Nt, cfg_o.text_dim, generator=g))
+    t = torch.tensor([500.0])
+    ref = R.wan_forward(sd, cfg_o, x.float(), t.expand(B), pe)
+    outs = {}
+    try:
+        for key in (1, 0):
+            _lib.check(lib.mi355_tune_set(24, key), "tune_set")
+            eng = wn.WanEngine(cfg)
+            eng.bind_state_dict({k: v.cuda() for k, v in sd.items()})
+            eng.ready()
+            outs[key] = eng.plan(B, 1, T, h, w_, Nt, 1).transformer_forward(x.cuda(), t, pe.cuda()).float().cpu()
+            eng.close()
+            assert torch.isfinite(outs[key]).all()
+            rel = ((outs[key] - ref).norm() / ref.norm()).item()
+            assert rel < 3e-2, (key, rel)
+    finally:
+        _lib.check(lib.mi355_tune_set(24, 1), "tune_set")
+    assert ((outs[1] - outs[0]).norm() / outs[0].norm()).item() < 1e-2
+
+
 @pytest.mark.parametrize("guidance", [1.0, 5.0])
 def test_wan_rollout_matches_oracle_and_replays(wn, guidance):
     from oracle import wan_ref as R
