@@ -771,3 +771,16 @@ extern "C" int mi355_op_rope_norm(void* stream, const void* src, int64_t src_ld,
     HIPCHK(launch_rope_norm(r, (hipStream_t)stream));
     return 0;
 }
+
+// Wan q / k producer (across-head RMSNorm, optional 3-D RoPE, head-major scatter) as an operator: unit tests of the row-norm output
+extern "C" int mi355_op_norm_rope_full(void* stream, const void* src, int64_t src_ld, int col, const float* weight, const float* cos_sin,
+                                       void* out, int M, int H, int rows_per_sample, int S_pad, float eps, float out_scale, void* max2) {
+    if (!src || !weight || !out) return errorf("mi355_op_norm_rope_full: null argument");
+    NormRopeFullParams r;
+    memset(&r, 0, sizeof(r));
+    r.src = (const bf16_t*)src; r.src_ld = src_ld; r.col = col; r.weight = weight; r.cs = (const float2*)cos_sin; r.out = (bf16_t*)out;
+    r.M = M; r.H = H; r.rows_per_sample = rows_per_sample; r.s_off = 0; r.S_pad = S_pad; r.eps = eps; r.out_scale = out_scale;
+    r.max2 = (unsigned*)max2;
+    HIPCHK(launch_norm_rope_full(r, (hipStream_t)stream));
+    return 0;
+}

@@ -34,6 +34,23 @@ __global__ __launch_bounds__(256) void rope_norm_kernel(RopeNormParams p) {
 
 // Wan: one wave per token row; lane l owns rotary pair l of EVERY head (pairs l, l+64, l+128, ... of the row), so the row RMS is one
 // wave reduction and every load / store instruction of the wave covers 256 contiguous bytes.
+// sum over the 64 lanes on the VALU (DPP), result wave-uniform: quad swaps, half-row and row mirrors leave every lane its 16-lane row sum,
+// row_bcast15 / row_bcast31 carry the row sums up to lane 63.  (wave_sum's six ds_bpermute round trips per sum, twelve sums per row, made the
+// q / k kernel 3 x slower when it also measured the row norms.)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    auto dpp = [](float x, auto ctrl, auto rmask) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(rmask)::value, 0xf, false));
+    };
+    using std::integral_constant;
+    v += dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});      // quad_perm [1,0,3,2]
+    v += dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});      // quad_perm [2,3,0,1]
+    v += dpp(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});     // row_half_mirror
+    v += dpp(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});     // row_mirror
+    v += dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});     // row_bcast15 into rows 1, 3
+    v += dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});     // row_bcast31 into rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 template <int MAXH>
 __global__ __launch_bounds__(256) void norm_rope_full_kernel(NormRopeFullParams p) {
     const int lane = threadIdx.x & 63;
@@ -63,7 +80,7 @@ __global__ __launch_bounds__(256) void norm_rope_full_kernel(NormRopeFullParams 
             const unsigned u = pack_bf16(ra, rb);
             *(unsigned*)(p.out + (((long)b * p.H + h) * p.S_pad + s) * 128 + 2 * lane) = u;
             if (p.max2) {       // squared norm of the row AS STORED: the attention's data-dependent score bound (non-negative floats order like their bits)
-                const float n2 = wave_sum(bf_lo(u) * bf_lo(u) + bf_hi(u) * bf_hi(u));
+                const float n2 = wave_sum_dpp(bf_lo(u) * bf_lo(u) + bf_hi(u) * bf_hi(u));
                 // (the maximum only grows: a plain -- possibly stale, i.e. smaller -- read can only cause a redundant atomic, never skip a needed
                 // one; after the first rows of a (b, h) almost every row skips, so 40 000 rows do not queue on 24 addresses)
                 if (lane == 0 && __float_as_uint(n2) > p.max2[(long)b * p.H + h]) atomicMax(p.max2 + (long)b * p.H + h, __float_as_uint(n2));

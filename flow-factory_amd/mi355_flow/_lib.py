@@ -133,6 +133,7 @@ SIGNATURES = {
                                 C.POINTER(C.c_int32), _P, _P, _P, _I]),
     "mi355_op_attention128": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I]),
     "mi355_op_rope_norm": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F]),
+    "mi355_op_norm_rope_full": (_I, [_P, _P, _L, _I, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
     "mi355_wan_create": (_I, [C.POINTER(WanCfg), C.POINTER(_P)]),
     "mi355_wan_destroy": (_I, [_P]),
     "mi355_wan_bind_weight": (_I, [_P, C.c_char_p, _P, _I, _I, C.POINTER(_L), _P]),
