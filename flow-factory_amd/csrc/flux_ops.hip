@@ -59,6 +59,10 @@ __global__ __launch_bounds__(256) void norm_rope_full_kernel(NormRopeFullParams 
     const int b = m / p.rows_per_sample;
     const int s = m - b * p.rows_per_sample + p.s_off;
     const bf16_t* row = p.src + (long)m * p.src_ld + p.col + 2 * lane;
+    // the maxima measured so far, one head per lane, fetched with the row (a read inside the head loop would put one exposed L2 round trip
+    // per head on a wave that lives for a single row)
+    unsigned cur = 0xffffffffu;
+    if (p.max2 && lane < p.H) cur = p.max2[(long)b * p.H + lane];
     float x0[MAXH], x1[MAXH];
     float ss = 0.f;
 #pragma unroll
@@ -81,9 +85,9 @@ __global__ __launch_bounds__(256) void norm_rope_full_kernel(NormRopeFullParams 
             *(unsigned*)(p.out + (((long)b * p.H + h) * p.S_pad + s) * 128 + 2 * lane) = u;
             if (p.max2) {       // squared norm of the row AS STORED: the attention's data-dependent score bound (non-negative floats order like their bits)
                 const float n2 = wave_sum_dpp(bf_lo(u) * bf_lo(u) + bf_hi(u) * bf_hi(u));
-                // (the maximum only grows: a plain -- possibly stale, i.e. smaller -- read can only cause a redundant atomic, never skip a needed
-                // one; after the first rows of a (b, h) almost every row skips, so 40 000 rows do not queue on 24 addresses)
-                if (lane == 0 && __float_as_uint(n2) > p.max2[(long)b * p.H + h]) atomicMax(p.max2 + (long)b * p.H + h, __float_as_uint(n2));
+                // (the maximum only grows: a stale -- i.e. smaller -- `cur` can only cause a redundant atomic, never skip a needed one; after the
+                // first rows of a (b, h) almost every row skips, so 40 000 rows do not queue on 24 addresses)
+                if (lane == 0 && __float_as_uint(n2) > (unsigned)__builtin_amdgcn_readlane((int)cur, h)) atomicMax(p.max2 + (long)b * p.H + h, __float_as_uint(n2));
             }
         }
 }
