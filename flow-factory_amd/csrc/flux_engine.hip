@@ -781,6 +781,14 @@ extern "C" int mi355_op_norm_rope_full(void* stream, const void* src, int64_t sr
     r.src = (const bf16_t*)src; r.src_ld = src_ld; r.col = col; r.weight = weight; r.cs = (const float2*)cos_sin; r.out = (bf16_t*)out;
     r.M = M; r.H = H; r.rows_per_sample = rows_per_sample; r.s_off = 0; r.S_pad = S_pad; r.eps = eps; r.out_scale = out_scale;
     r.max2 = (unsigned*)max2;
-    HIPCHK(launch_norm_rope_full(r, (hipStream_t)stream));
+    float* part = nullptr;
+    if (max2) {
+        if (rows_per_sample <= 0 || M % rows_per_sample) return errorf("mi355_op_norm_rope_full: max2 needs whole samples");
+        HIPCHK(hipMalloc((void**)&part, (size_t)(M / rows_per_sample) * norm_rope_parts(rows_per_sample) * H * 4));
+        r.max2_part = part;
+    }
+    hipError_t e = launch_norm_rope_full(r, (hipStream_t)stream);
+    if (part) { if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream); (void)hipFree(part); }
+    if (e != hipSuccess) return errorf("mi355_op_norm_rope_full: %s", hipGetErrorString(e));
     return 0;
 }

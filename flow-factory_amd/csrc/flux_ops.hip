@@ -51,45 +51,77 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
-template <int MAXH>
+// MEASURE: also record the largest squared norm of the rows AS STORED per (batch, head) -- the self-attention's data-dependent score bound.
+// No atomics (tens of thousands of rows on B*H addresses queue: measured 3-10 x the kernel's time): a wave then walks RPW consecutive rows of
+// one sample with its running maxima in registers and writes ONE partial row [H]; max_finalize_kernel reduces the partial rows.
+constexpr int NR_RPW = 8;
+template <int MAXH, bool MEASURE>
 __global__ __launch_bounds__(256) void norm_rope_full_kernel(NormRopeFullParams p) {
     const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= p.M) return;
-    const int b = m / p.rows_per_sample;
-    const int s = m - b * p.rows_per_sample + p.s_off;
-    const bf16_t* row = p.src + (long)m * p.src_ld + p.col + 2 * lane;
-    // the maxima measured so far, one head per lane, fetched with the row (a read inside the head loop would put one exposed L2 round trip
-    // per head on a wave that lives for a single row)
-    unsigned cur = 0xffffffffu;
-    if (p.max2 && lane < p.H) cur = p.max2[(long)b * p.H + lane];
-    float x0[MAXH], x1[MAXH];
-    float ss = 0.f;
+    const int wave = threadIdx.x >> 6;
+    int m_first, n_rows, b0 = 0;
+    if constexpr (MEASURE) {        // grid (chunks of 4 * RPW rows, batch)
+        b0 = blockIdx.y;
+        const int s_first = (blockIdx.x * 4 + wave) * NR_RPW;
+        n_rows = min(NR_RPW, p.rows_per_sample - s_first);
+        m_first = b0 * p.rows_per_sample + s_first;
+    } else {
+        m_first = blockIdx.x * 4 + wave;
+        n_rows = m_first < p.M ? 1 : 0;
+    }
+    float mx[MEASURE ? MAXH : 1];
+    if constexpr (MEASURE) {
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h)
-        if (h < p.H) {
-            const unsigned u = *(const unsigned*)(row + h * 128);
-            x0[h] = bf_lo(u); x1[h] = bf_hi(u);
-            ss += x0[h] * x0[h] + x1[h] * x1[h];
-        }
-    const float rstd = rsqrtf(wave_sum(ss) / (float)(p.H * 128) + p.eps);
-    float c = 1.f, sn = 0.f;
-    if (p.cs) { const float2 cs = p.cs[(long)s * 64 + lane]; c = cs.x; sn = cs.y; }
+        for (int h = 0; h < MAXH; ++h) mx[h] = 0.f;
+    }
+    for (int r = 0; r < n_rows; ++r) {
+        const int m = m_first + r;
+        const int b = MEASURE ? b0 : m / p.rows_per_sample;
+        const int s = m - b * p.rows_per_sample + p.s_off;
+        const bf16_t* row = p.src + (long)m * p.src_ld + p.col + 2 * lane;
+        float x0[MAXH], x1[MAXH];
+        float ss = 0.f;
 #pragma unroll
-    for (int h = 0; h < MAXH; ++h)
-        if (h < p.H) {
-            const float2 w = *(const float2*)(p.weight + h * 128 + 2 * lane);
-            const float a = x0[h] * rstd * w.x, bb = x1[h] * rstd * w.y;
-            const float ra = (a * c - bb * sn) * p.out_scale, rb = (bb * c + a * sn) * p.out_scale;
-            const unsigned u = pack_bf16(ra, rb);
-            *(unsigned*)(p.out + (((long)b * p.H + h) * p.S_pad + s) * 128 + 2 * lane) = u;
-            if (p.max2) {       // squared norm of the row AS STORED: the attention's data-dependent score bound (non-negative floats order like their bits)
-                const float n2 = wave_sum_dpp(bf_lo(u) * bf_lo(u) + bf_hi(u) * bf_hi(u));
-                // (the maximum only grows: a stale -- i.e. smaller -- `cur` can only cause a redundant atomic, never skip a needed one; after the
-                // first rows of a (b, h) almost every row skips, so 40 000 rows do not queue on 24 addresses)
-                if (lane == 0 && __float_as_uint(n2) > (unsigned)__builtin_amdgcn_readlane((int)cur, h)) atomicMax(p.max2 + (long)b * p.H + h, __float_as_uint(n2));
+        for (int h = 0; h < MAXH; ++h)
+            if (h < p.H) {
+                const unsigned u = *(const unsigned*)(row + h * 128);
+                x0[h] = bf_lo(u); x1[h] = bf_hi(u);
+                ss += x0[h] * x0[h] + x1[h] * x1[h];
             }
-        }
+        const float rstd = rsqrtf(wave_sum(ss) / (float)(p.H * 128) + p.eps);
+        float c = 1.f, sn = 0.f;
+        if (p.cs) { const float2 cs = p.cs[(long)s * 64 + lane]; c = cs.x; sn = cs.y; }
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h)
+            if (h < p.H) {
+                const float2 w = *(const float2*)(p.weight + h * 128 + 2 * lane);
+                const float a = x0[h] * rstd * w.x, bb = x1[h] * rstd * w.y;
+                const float ra = (a * c - bb * sn) * p.out_scale, rb = (bb * c + a * sn) * p.out_scale;
+                const unsigned u = pack_bf16(ra, rb);
+                *(unsigned*)(p.out + (((long)b * p.H + h) * p.S_pad + s) * 128 + 2 * lane) = u;
+                if constexpr (MEASURE) mx[h] = fmaxf(mx[h], wave_sum_dpp(bf_lo(u) * bf_lo(u) + bf_hi(u) * bf_hi(u)));
+            }
+    }
+    if constexpr (MEASURE) {        // partial row of this wave: lane h holds head h
+        float v = 0.f;
+#pragma unroll
+        for (int h = 0; h < MAXH; ++h)
+            if (h < p.H) v = lane == h ? mx[h] : v;
+        if (lane < p.H) p.max2_part[(((long)b0 * gridDim.x + blockIdx.x) * 4 + wave) * p.H + lane] = v;
+    }
+}
+
+// max2[b][h] = float bits of the maximum over the `nparts` partial rows of sample b (one wave per (b, h))
+__global__ __launch_bounds__(256) void max_finalize_kernel(const float* part, int nparts, int H, int BH, unsigned* out) {
+    const int lane = threadIdx.x & 63;
+    const int bh = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (bh >= BH) return;
+    const int b = bh / H, h = bh - b * H;
+    float v = 0.f;
+    for (int i = lane; i < nparts; i += 64) v = fmaxf(v, part[((long)b * nparts + i) * H + h]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    if (lane == 0) out[bh] = __float_as_uint(v);
 }
 
 __global__ __launch_bounds__(256) void bcast_add_kernel(const bf16_t* a, const float* table, bf16_t* out, long out_ld, int rows, int W, int J) {
@@ -163,12 +195,24 @@ hipError_t launch_cfg_rescale(const bf16_t* neg, const bf16_t* pos, float g, bf1
     return hipGetLastError();
 }
 
+int norm_rope_parts(int rows_per_sample) { return (rows_per_sample + 4 * NR_RPW - 1) / (4 * NR_RPW) * 4; }   // partial rows per sample
 hipError_t launch_norm_rope_full(const NormRopeFullParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.H <= 0 || p.H > 48 || (p.src_ld & 1) || (p.col & 1)) return hipErrorInvalidValue;
+    if (p.max2) {
+        if (!p.max2_part || p.s_off != 0 || p.M % p.rows_per_sample) return hipErrorInvalidValue;
+        const int B = p.M / p.rows_per_sample;
+        const dim3 grid((unsigned)(norm_rope_parts(p.rows_per_sample) / 4), (unsigned)B);
+        if (p.H <= 12) hipLaunchKernelGGL((norm_rope_full_kernel<12, true>), grid, dim3(256), 0, stream, p);
+        else if (p.H <= 24) hipLaunchKernelGGL((norm_rope_full_kernel<24, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((norm_rope_full_kernel<48, true>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(max_finalize_kernel, dim3((unsigned)((B * p.H + 3) / 4)), dim3(256), 0, stream, p.max2_part, norm_rope_parts(p.rows_per_sample),
+                           p.H, B * p.H, p.max2);
+        return hipGetLastError();
+    }
     const dim3 grid((unsigned)((p.M + 3) / 4));
-    if (p.H <= 12) hipLaunchKernelGGL(norm_rope_full_kernel<12>, grid, dim3(256), 0, stream, p);
-    else if (p.H <= 24) hipLaunchKernelGGL(norm_rope_full_kernel<24>, grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(norm_rope_full_kernel<48>, grid, dim3(256), 0, stream, p);
+    if (p.H <= 12) hipLaunchKernelGGL((norm_rope_full_kernel<12, false>), grid, dim3(256), 0, stream, p);
+    else if (p.H <= 24) hipLaunchKernelGGL((norm_rope_full_kernel<24, false>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((norm_rope_full_kernel<48, false>), grid, dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -168,9 +168,11 @@ struct NormRopeFullParams {
     bf16_t* out;
     int M, H, rows_per_sample, s_off, S_pad;
     float eps, out_scale;
-    unsigned* max2;                           // optional [B*H]: atomic max of the squared norm of every stored (bf16-rounded) output row, as float bits
+    unsigned* max2;                           // optional [B*H]: largest squared norm of the stored (bf16-rounded) output rows per (batch, head), as float bits
+    float* max2_part;                         // scratch for it: [B][norm_rope_parts(rows_per_sample)][H] floats (s_off must be 0)
 };
 hipError_t launch_norm_rope_full(const NormRopeFullParams& p, hipStream_t stream);
+int norm_rope_parts(int rows_per_sample);
 // Qwen-Image: RMSNorm over whole rows (weight fp32 [D]) and the norm-rescaled true-CFG combine over C = 64 channel tokens (flux_ops.hip)
 hipError_t launch_rms_rows(const bf16_t* x, long ldx, const float* w, bf16_t* out, long ldo, int M, int D, float eps, hipStream_t stream);
 hipError_t launch_cfg_rescale(const bf16_t* neg, const bf16_t* pos, float g, bf16_t* out, long rows, int C, hipStream_t stream);

@@ -195,6 +195,7 @@ struct mi355_wan_plan {
     float *io_noise, *io_lp;
     bf16_t *io_pe, *io_ne;
     unsigned* max2;            // [2][Bp*H]: largest squared stored row norm of q / k per (batch, head) of the current self-attention (float bits)
+    float* max2_part;          // scratch of the kernel that measures them
     std::vector<float> host_t, host_sc;
     int mod_cols;
 };
@@ -234,7 +235,7 @@ extern "C" int mi355_wan_plan_create(mi355_wan* e, int batch, int n_cfg, int lat
     size_t o_ii = take(nl, 4), o_it = take((int64_t)(max_steps + 1) * nl, 4), o_in = take((int64_t)max_steps * nl, 4);
     size_t o_il = take((int64_t)max_steps * batch, 4);
     size_t o_ipe = take((int64_t)batch * n_text * e->cfg.text_dim, 2), o_ine = take((int64_t)batch * n_text * e->cfg.text_dim, 2);
-    size_t o_max2 = take((int64_t)2 * p->Bp * e->H, 4);
+    size_t o_max2 = take((int64_t)2 * p->Bp * e->H, 4), o_m2p = take((int64_t)p->Bp * norm_rope_parts(p->S) * e->H, 4);
     p->ws_bytes = off;
     if (hipMalloc((void**)&p->ws, off) != hipSuccess) {
         int r = errorf("mi355_wan_plan_create: hipMalloc of %zu bytes failed", off);
@@ -256,7 +257,7 @@ extern "C" int mi355_wan_plan_create(mi355_wan* e, int batch, int n_cfg, int lat
     p->cs = (float2*)(w + o_cs); p->t_dev = (float*)(w + o_t); p->scal = (float*)(w + o_sc);
     p->io_init = w + o_ii; p->io_traj = w + o_it; p->io_noise = (float*)(w + o_in); p->io_lp = (float*)(w + o_il);
     p->io_pe = (bf16_t*)(w + o_ipe); p->io_ne = (bf16_t*)(w + o_ine);
-    p->max2 = (unsigned*)(w + o_max2);
+    p->max2 = (unsigned*)(w + o_max2); p->max2_part = (float*)(w + o_m2p);
     // rotary table (WanRotaryPosEmbed): head_dim 128 -> t / h / w axes of 44 / 42 / 42 features, float64 angles, adjacent pairs
     {
         const int hw = 2 * (128 / 6), ax[3] = {128 - 2 * hw, hw, hw};
@@ -297,7 +298,7 @@ constexpr float kScale = 0.08838834764831845f * 1.4426950408889634f;   // log2(e
 
 // key 24: self-attention score bound from the data where the weights prove none (1 = default).  Wan's q / k RMSNorm runs ACROSS heads, so the
 // weight-side bound is 200 * max|w_q| * max|w_k| -- never <= 60 -- and every self-attention ran the running-max kernel.  The kernel that
-// stores q and k now also measures them (largest squared row norm per (batch, head), one atomic max per row and head); |q . k| <= |q| |k| then
+// stores q and k now also measures them (largest squared row norm per (batch, head): per-wave partial maxima + a tiny reduction); |q . k| <= |q| |k| then
 // bounds the scores of each (b, h) from what is actually there, and the static-softmax 4-wave kernel takes every (b, h) that passes.
 int g_wan_data_bound = 1;
 
@@ -341,7 +342,7 @@ int norm_rope(mi355_wan_plan* p, hipStream_t st, const bf16_t* src, long ld, int
     NormRopeFullParams r;
     memset(&r, 0, sizeof(r));
     r.src = src; r.src_ld = ld; r.col = col; r.weight = w; r.cs = rope ? p->cs : nullptr; r.out = out; r.M = M; r.H = p->e->H;
-    r.rows_per_sample = rps; r.s_off = 0; r.S_pad = S_pad; r.eps = p->e->cfg.eps; r.out_scale = scale; r.max2 = max2;
+    r.rows_per_sample = rps; r.s_off = 0; r.S_pad = S_pad; r.eps = p->e->cfg.eps; r.out_scale = scale; r.max2 = max2; r.max2_part = p->max2_part;
     HIPCHK(launch_norm_rope_full(r, st));
     return 0;
 }
@@ -423,7 +424,6 @@ int forward_core(mi355_wan_plan* p, hipStream_t st, const void* latents, int lat
         HIPCHK(launch_gemm(gq, st));
         // self-attention score bound from the data (the weights prove none: RMSNorm across heads): largest stored row norm per (b, h)
         const bool dyn_bound = g_wan_data_bound && !(e->bound_self[i] > 0.f && e->bound_self[i] <= 60.f);
-        if (dyn_bound) HIPCHK(hipMemsetAsync(p->max2, 0, (size_t)2 * p->Bp * e->H * 4, st));
         CHK(norm_rope(p, st, p->qkbuf, 2 * D, 0, b.nq, true, p->q, M, S, p->S_pad, kScale, dyn_bound ? p->max2 : nullptr));
         CHK(norm_rope(p, st, p->qkbuf, 2 * D, D, b.nk, true, p->k, M, S, p->S_pad, 1.0f, dyn_bound ? p->max2 + p->Bp * e->H : nullptr));
         CHK(vt_proj(p, st, b.w_v, b.b_v, p->xn, M, S, p->vT, p->S_pad));

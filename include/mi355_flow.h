@@ -254,8 +254,8 @@ int mi355_op_rope_norm(void* stream, const void* src, int64_t src_ld, int q_col,
                        int s_off, int S_pad, float eps, float q_scale);
 /* Wan's q / k producer (reference models/wan/wan2_t2v.py:426-543 -> diffusers WanAttnProcessor: RMSNorm ACROSS heads, 3-D RoPE) as an
  * operator: src [M][src_ld] bf16 (columns col .. col + H*128), weight fp32 [H*128], cos_sin fp32 [S][64][2] or NULL, out head-major
- * [B][H][S_pad][128] bf16.  max2 (optional, device uint32 [B*H], zeroed by the caller) receives the atomic maximum of the squared norm of
- * every stored row per (batch, head), as float bits: the data-dependent score bound of the self-attention (mi355_tune_set key 24). */
+ * [B][H][S_pad][128] bf16.  max2 (optional, device uint32 [B*H], overwritten; M must be whole samples) receives the maximum of the squared norm
+ * of every stored row per (batch, head), as float bits: the data-dependent score bound of the self-attention (mi355_tune_set key 24). */
 int mi355_op_norm_rope_full(void* stream, const void* src, int64_t src_ld, int col, const float* weight, const float* cos_sin,
                             void* out, int M, int H, int rows_per_sample, int S_pad, float eps, float out_scale, void* max2);
 
