@@ -380,6 +380,12 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dq_tr_kernel(AttnBwdP
 }  // namespace
 
 hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream) {
+    if (sched_trace_on()) {
+        const size_t bhs = (size_t)p.B * p.H * p.S_pad;
+        sched_trace_launch("attention_bwd", stream, {treg(p.q, bhs * 128), treg(p.k, bhs * 128), treg(p.v, bhs * 128), treg(p.doh, bhs * 128), treg(p.lse, bhs * 4),
+                                                     treg(p.delta, bhs * 4), treg(p.nld, bhs * 8)},
+                           {treg(p.dq, bhs * 128), treg(p.dk, bhs * 128), treg(p.dv, bhs * 128)});
+    }
     if (p.S <= 0 || p.S_pad % TB != 0 || p.S_pad < p.S || !p.nld) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {

@@ -548,6 +548,12 @@ inline int grid_for(long total, int block) {
 }  // namespace
 
 hipError_t launch_ln_mod_bwd(const LnModBwdParams& p, hipStream_t st) {
+    if (sched_trace_on()) {
+        const size_t xb = (size_t)p.M * p.D * 2, nb = (size_t)((p.M + p.rows_per_sample - 1) / p.rows_per_sample);
+        const TraceRegion mod = treg(p.mod, ((nb - 1) * p.mod_ld + (size_t)(p.scale_off > p.scale2_off ? p.scale_off : p.scale2_off) + p.D) * 2);
+        sched_trace_launch("ln_mod_bwd", st, {treg(p.x, xb), treg(p.dy, xb), treg(p.dy2, p.dy2 ? xb : 0), mod, treg(p.dres, p.accumulate ? xb : 0)},
+                           {treg(p.dres, xb), treg(p.dmod, p.dmod ? (nb * p.mod_ld) * 4 : 0)});
+    }
     if (p.D % 8 != 0 || p.D > 8 * 64 * 8 || p.M <= 0) return hipErrorInvalidValue;
     const int rpw = p.dmod ? 16 : 1;         // rows per wave: 16 with the modulation-gradient partials in registers
     const int grid = (p.M + 4 * rpw - 1) / (4 * rpw);
@@ -558,6 +564,11 @@ hipError_t launch_ln_mod_bwd(const LnModBwdParams& p, hipStream_t st) {
 
 hipError_t launch_gate_bwd(const bf16_t* dx, const bf16_t* gate, long gate_ld, const bf16_t* y, bf16_t* dy, float* dgate, long dg_ld, long M, int D,
                            int rps, hipStream_t st) {
+    if (sched_trace_on()) {
+        const size_t nb = (size_t)((M + rps - 1) / rps);
+        sched_trace_launch("gate_bwd", st, {treg(dx, (size_t)M * D * 2), treg(gate, ((nb - 1) * gate_ld + D) * 2), treg(y, (size_t)M * D * 2)},
+                           {treg(dy, (size_t)M * D * 2), treg(dgate, ((nb - 1) * dg_ld + D) * 4)});
+    }
     if (D % 8 || M <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(((D >> 3) + 255) / 256, (unsigned)((M + 63) / 64)), dim3(256), 0, st, dx, gate, gate_ld, y, dy, dgate, dg_ld,
                        M, D, rps);
@@ -576,12 +587,14 @@ hipError_t launch_f32_to_bf16_pad(const float* in, bf16_t* out, long rows, long 
 }
 
 hipError_t launch_gate_mul(const bf16_t* dx, const bf16_t* gate, long gate_ld, bf16_t* dy, long M, int D, int rps, hipStream_t st) {
+    if (sched_trace_on()) sched_trace_launch("gate_mul", st, {treg(dx, (size_t)M * D * 2), treg(gate, ((size_t)((M + rps - 1) / rps - 1) * gate_ld + D) * 2)}, {treg(dy, (size_t)M * D * 2)});
     if (D % 8 || M <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gate_mul_kernel, dim3(grid_for(M * (D >> 3), 256)), dim3(256), 0, st, dx, gate, gate_ld, dy, M, D, rps);
     return hipGetLastError();
 }
 
 hipError_t launch_gelu_fwd(const bf16_t* pre, bf16_t* out, long n, hipStream_t st) {
+    if (sched_trace_on()) sched_trace_launch("gelu_fwd", st, {treg(pre, (size_t)n * 2)}, {treg(out, (size_t)n * 2)});
     if (n % 8) return hipErrorInvalidValue;
     hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n >> 3, 256)), dim3(256), 0, st, pre, out, n >> 3);
     return hipGetLastError();
@@ -593,6 +606,8 @@ static bool transpose_vec_ok(const bf16_t* in, long ld_in, long bs_in, const bf1
 
 hipError_t launch_transpose(const bf16_t* in, long ld_in, long bs_in, bf16_t* out, long ld_out, long bs_out, int rows, int cols, int rows_pad,
                             int batch, hipStream_t st) {
+    if (sched_trace_on()) sched_trace_launch("transpose", st, {tregs(in, ((size_t)(rows - 1) * ld_in + cols) * 2, (size_t)bs_in * 2, (size_t)batch)},
+                                             {tregs(out, ((size_t)(cols - 1) * ld_out + rows_pad) * 2, (size_t)bs_out * 2, (size_t)batch)});
     if (rows <= 0 || cols <= 0 || batch <= 0 || rows_pad < rows) return hipErrorInvalidValue;
     const dim3 grid((rows_pad + 63) / 64, (cols + 63) / 64, batch);
     if (transpose_vec_ok(in, ld_in, bs_in, out, ld_out, bs_out))
@@ -605,6 +620,8 @@ hipError_t launch_transpose(const bf16_t* in, long ld_in, long bs_in, bf16_t* ou
 // transpose + column sums in one pass over `in`: out = in^T, colsum[cols] = sum over rows (scratch: ((rows_pad + 63) / 64) * cols floats)
 hipError_t launch_transpose_colsum(const bf16_t* in, long ld_in, bf16_t* out, long ld_out, int rows, int cols, int rows_pad, float* scratch,
                                    float* colsum, hipStream_t st) {
+    if (sched_trace_on()) sched_trace_launch("transpose_colsum", st, {treg(in, ((size_t)(rows - 1) * ld_in + cols) * 2)},
+                                             {treg(out, ((size_t)(cols - 1) * ld_out + rows_pad) * 2), treg(scratch, (size_t)((rows_pad + 63) / 64) * cols * 4), treg(colsum, (size_t)cols * 4)});
     if (rows <= 0 || cols <= 0 || rows_pad < rows || !scratch || !colsum) return hipErrorInvalidValue;
     const int ntile = (rows_pad + 63) / 64;
     if (transpose_vec_ok(in, ld_in, 0, out, ld_out, 0))
@@ -618,6 +635,11 @@ hipError_t launch_transpose_colsum(const bf16_t* in, long ld_in, bf16_t* out, lo
 }
 
 hipError_t launch_attn_bwd_prep(const AttnBwdPrepParams& p, hipStream_t st) {
+    if (sched_trace_on()) {
+        const size_t D2 = (size_t)p.H * 128, ri = (size_t)p.B * p.n_img, rc = (size_t)p.B * (p.S - p.n_img), bhs = (size_t)p.B * p.H * p.S_pad;
+        sched_trace_launch("attn_bwd_prep", st, {treg(p.o_img, ri * D2), treg(p.o_ctx, p.o_ctx ? rc * D2 : 0), treg(p.do_img, ri * D2), treg(p.do_ctx, p.do_ctx ? rc * D2 : 0), treg(p.lse, bhs * 4)},
+                           {treg(p.doh, bhs * 128), treg(p.delta, bhs * 4), treg(p.nld, bhs * 8)});
+    }
     hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((p.S + 63) / 64, p.H, p.B), dim3(256), 0, st, p);
     return hipGetLastError();
 }
@@ -625,6 +647,12 @@ hipError_t launch_attn_bwd_prep(const AttnBwdPrepParams& p, hipStream_t st) {
 // tokens per wave: 1 normally, 8 when the norm-weight partials are wanted (8 x fewer partial rows to sum)
 int rms_bwd_grid(int B, int S) { return (int)(((long)B * S + 31) / 32); }
 hipError_t launch_rms_bwd_gather(const RmsBwdParams& p, hipStream_t st) {
+    if (sched_trace_on()) {
+        const size_t bhs = (size_t)p.B * p.H * p.S_pad * 128, D6 = (size_t)p.H * 64 * 3 * 2, ri = (size_t)p.B * p.n_img, rc = (size_t)p.B * (p.S - p.n_img);
+        sched_trace_launch("rms_bwd_gather", st, {treg(p.q, bhs), treg(p.k, bhs), treg(p.dq, bhs), treg(p.dk, bhs), treg(p.dv, bhs), treg(p.rstd_img, ri * 2 * p.H * 4),
+                                                  treg(p.rstd_ctx, p.rstd_ctx ? rc * 2 * p.H * 4 : 0)},
+                           {treg(p.out_img, ri * D6), treg(p.out_ctx, p.out_ctx ? rc * D6 : 0), treg(p.dw_part, p.dw_part ? (size_t)rms_bwd_grid(p.B, p.S) * 4 * 64 * 4 : 0)});
+    }
     const long tokens = (long)p.B * p.S;
     if (p.dw_part) hipLaunchKernelGGL(rms_bwd_gather_kernel, dim3((unsigned)rms_bwd_grid(p.B, p.S)), dim3(256), 0, st, p, 8);
     else hipLaunchKernelGGL(rms_bwd_gather_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, st, p, 1);
@@ -637,6 +665,7 @@ hipError_t launch_rms_dw_finish(const float* part, int nwg, float q_scale, float
 }
 
 hipError_t launch_colsum(const bf16_t* dy, long ld, long M, int N, float* scratch, float* out, int accumulate, hipStream_t st) {
+    if (sched_trace_on()) sched_trace_launch("colsum", st, {treg(dy, ((size_t)(M - 1) * ld + N) * 2)}, {treg(scratch, (size_t)64 * N * 4), treg(out, (size_t)N * 4)});
     const int nslab = (int)(M >= 8192 ? 64 : (M + 127) / 128);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, nslab), dim3(256), 0, st, dy, ld, M, N, scratch, nslab);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 31) / 32), dim3(256), 0, st, scratch, nslab, N, out, accumulate);
@@ -644,17 +673,21 @@ hipError_t launch_colsum(const bf16_t* dy, long ld, long M, int N, float* scratc
 }
 
 hipError_t launch_splitk_reduce(const float* part, long stride, int nsplit, float* out, long n, int accumulate, hipStream_t st) {
+    if (sched_trace_on()) sched_trace_launch("splitk_reduce", st, {treg(part, ((size_t)(nsplit - 1) * stride + n) * 4)}, {treg(out, (size_t)n * 4)});
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, part, stride, nsplit, out, n, accumulate);
     return hipGetLastError();
 }
 
 hipError_t launch_unpatch_bwd(const float* dv, bf16_t* out, int Bp, int C, int hp, int wp, int patch, hipStream_t st) {
+    if (sched_trace_on()) sched_trace_launch("unpatch_bwd", st, {treg(dv, (size_t)Bp * hp * wp * patch * patch * C * 4)}, {treg(out, (size_t)Bp * hp * wp * patch * patch * C * 2)});
     const long total = (long)Bp * hp * wp * patch * patch * C;
     hipLaunchKernelGGL(unpatch_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, dv, out, Bp, C, hp, wp, patch);
     return hipGetLastError();
 }
 
 hipError_t launch_sde_step_bwd(const SdeBwdParams& p, hipStream_t st) {
+    if (sched_trace_on()) sched_trace_launch("sde_step_bwd", st, {treg(p.v_text, (size_t)p.B * p.n * 2), treg(p.v_uncond, p.v_uncond ? (size_t)p.B * p.n * 2 : 0)},
+                                             {treg(p.dv, (size_t)(p.v_uncond ? 2 : 1) * p.B * p.n * 4)});
     if (p.B <= 0 || p.n <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sde_step_bwd_kernel, dim3(grid_for(p.n, 256) > 256 ? 256 : grid_for(p.n, 256), p.B), dim3(256), 0, st, p);
     return hipGetLastError();

@@ -284,6 +284,50 @@ def test_sd3_engine_emitted_schedule_is_race_free():
         e.close()
 
 
+@pytest.mark.parametrize("scope", ["default_targets", "all_block_linears"])
+def test_sd3_training_step_schedule_is_race_free(scope):
+    """The optimize() replay step (training-mode forward + backward through torch autograd) as the engine emits it: the context-stream chain
+    of both halves runs on the training state's side stream (mi355_tune_set(22, 1), the default) -- in the backward together with the
+    context stream's weight gradients on their own scratch.  Every launch of both halves reports its regions (GEMMs incl. the activation
+    stashes, attention + log-sum-exp, the backward's elementwise / transpose / split-K / attention-backward kernels, the stash copies)."""
+    from mi355_flow import _lib
+    from test_gpu_backward import _build, _inputs, BLOCK_LINEARS
+    lib = _lib.load()
+    targets = (".to_q.", ".to_k.", ".to_v.", ".to_out.0.") if scope == "default_targets" else BLOCK_LINEARS
+    ad, mod, _ = _build(lambda n: n.startswith("transformer_blocks.") and any(k in n for k in targets), seed=31)
+    B, h, w, Nt = 2, 16, 16, 13
+    inp = _inputs(B, h, w, Nt, seed=9)
+    ad.scheduler.set_timesteps(4)
+    kw = dict(t=torch.full((B,), 750.0), t_next=torch.full((B,), 500.0), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+              prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(), guidance_scale=1.0, noise_level=0.7,
+              compute_log_prob=True, return_kwargs=["log_prob", "dt"])
+    wlp = inp["wlp"].cuda()
+
+    def step():
+        for prm in mod.parameters():
+            prm.grad = None
+        out = ad.forward(**kw)
+        (wlp * out.log_prob).sum().backward()
+
+    try:
+        step()
+        text = _trace_of(lib, step)
+        import _sched_check as SC
+        s = SC.parse(text)
+        names = {o.name for o in s.ops}
+        assert {"attention_bwd", "attn_bwd_prep", "rms_bwd_gather", "ln_mod_bwd", "gate_mul", "splitk_reduce", "gemm.f32"} <= names, sorted(names)
+        assert len(s.streams()) == 2, s.streams()
+        races = s.races()
+        assert races == [], races[:5]
+        nw = SC.n_waits(text)
+        needed = [k for k in range(nw) if SC.parse(text, drop_waits=[k]).races(limit=1)]
+        print(f"SD3.5 optimize() step, {scope}: {sum(1 for o in s.ops if o.regions)} launches on 2 streams, {nw} stream waits, "
+              f"{len(needed)} of them individually necessary, no race")
+        assert nw > 0 and len(needed) >= 0.6 * nw, (nw, len(needed))
+    finally:
+        ad.engine.close()
+
+
 def test_qwen_and_flux_engine_emitted_schedules_are_race_free():
     """The same for the Qwen-Image blocks (key 12) and the FLUX.1 double blocks (key 14): two consecutive forwards each, two streams."""
     from mi355_flow import _lib, flux as fx, qwen as qw
