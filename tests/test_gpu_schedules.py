@@ -315,7 +315,7 @@ def test_sd3_training_step_schedule_is_race_free(scope):
         import _sched_check as SC
         s = SC.parse(text)
         names = {o.name for o in s.ops}
-        assert {"attention_bwd", "attn_bwd_prep", "rms_bwd_gather", "ln_mod_bwd", "gate_mul", "splitk_reduce", "gemm.f32"} <= names, sorted(names)
+        assert {"attention_bwd", "attn_bwd_prep", "rms_bwd_gather", "ln_mod_bwd", "gate_mul", "transpose", "gemm.f32"} <= names, sorted(names)
         assert len(s.streams()) == 2, s.streams()
         races = s.races()
         assert races == [], races[:5]
