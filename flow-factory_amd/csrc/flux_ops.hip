@@ -51,14 +51,35 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Lane l of a wave owns 8 consecutive features of 4 heads per pass: pass `it` covers heads 4 it .. 4 it + 3, 16 lanes per head, one 16-byte
+// load / store per lane and pass (the first version moved 4 bytes per lane and load: 1.5 TB/s).  The rotary pairs (2 i, 2 i + 1) of a lane are
+// the same in every pass, so its 4 (cos, sin) pairs are fetched once per row.
 // MEASURE: also record the largest squared norm of the rows AS STORED per (batch, head) -- the self-attention's data-dependent score bound.
-// No atomics (tens of thousands of rows on B*H addresses queue: measured 3-10 x the kernel's time): a wave then walks RPW consecutive rows of
-// one sample with its running maxima in registers and writes ONE partial row [H]; max_finalize_kernel reduces the partial rows.
+// A head's 128 features sit in one 16-lane DPP row: 4 DPP steps leave every lane its head's sum.  No atomics (tens of thousands of rows on
+// B*H addresses queue: measured 3-10 x the kernel's time): a wave walks NR_RPW consecutive rows of one sample with its running maxima in
+// registers and writes ONE partial row [H]; max_finalize_kernel reduces the partial rows.
 constexpr int NR_RPW = 8;
+__device__ __forceinline__ void unpack8(const uint4 u, float (&v)[8]) {
+    v[0] = bf_lo(u.x); v[1] = bf_hi(u.x); v[2] = bf_lo(u.y); v[3] = bf_hi(u.y);
+    v[4] = bf_lo(u.z); v[5] = bf_hi(u.z); v[6] = bf_lo(u.w); v[7] = bf_hi(u.w);
+}
+__device__ __forceinline__ float row16_sum_dpp(float v) {      // sum over the 16 lanes of a DPP row, in every lane
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    using std::integral_constant;
+    v += dpp(v, integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+    v += dpp(v, integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+    v += dpp(v, integral_constant<int, 0x141>{});     // row_half_mirror
+    v += dpp(v, integral_constant<int, 0x140>{});     // row_mirror
+    return v;
+}
 template <int MAXH, bool MEASURE>
 __global__ __launch_bounds__(256) void norm_rope_full_kernel(NormRopeFullParams p) {
+    constexpr int NI = MAXH / 4;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    const int hl = lane >> 4, d0 = (lane & 15) * 8;          // head within the pass, first feature inside the head
     int m_first, n_rows, b0 = 0;
     if constexpr (MEASURE) {        // grid (chunks of 4 * RPW rows, batch)
         b0 = blockIdx.y;
@@ -69,45 +90,59 @@ __global__ __launch_bounds__(256) void norm_rope_full_kernel(NormRopeFullParams 
         m_first = blockIdx.x * 4 + wave;
         n_rows = m_first < p.M ? 1 : 0;
     }
-    float mx[MEASURE ? MAXH : 1];
+    float mx[MEASURE ? NI : 1];
     if constexpr (MEASURE) {
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h) mx[h] = 0.f;
+        for (int it = 0; it < NI; ++it) mx[it] = 0.f;
     }
     for (int r = 0; r < n_rows; ++r) {
         const int m = m_first + r;
         const int b = MEASURE ? b0 : m / p.rows_per_sample;
         const int s = m - b * p.rows_per_sample + p.s_off;
-        const bf16_t* row = p.src + (long)m * p.src_ld + p.col + 2 * lane;
-        float x0[MAXH], x1[MAXH];
+        const bf16_t* row = p.src + (long)m * p.src_ld + p.col + lane * 8;
+        float x[NI][8];
         float ss = 0.f;
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h)
-            if (h < p.H) {
-                const unsigned u = *(const unsigned*)(row + h * 128);
-                x0[h] = bf_lo(u); x1[h] = bf_hi(u);
-                ss += x0[h] * x0[h] + x1[h] * x1[h];
-            }
-        const float rstd = rsqrtf(wave_sum(ss) / (float)(p.H * 128) + p.eps);
-        float c = 1.f, sn = 0.f;
-        if (p.cs) { const float2 cs = p.cs[(long)s * 64 + lane]; c = cs.x; sn = cs.y; }
+        for (int it = 0; it < NI; ++it)
+            if (it * 4 + hl < p.H) {
+                unpack8(*(const uint4*)(row + it * 512), x[it]);
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h)
-            if (h < p.H) {
-                const float2 w = *(const float2*)(p.weight + h * 128 + 2 * lane);
-                const float a = x0[h] * rstd * w.x, bb = x1[h] * rstd * w.y;
-                const float ra = (a * c - bb * sn) * p.out_scale, rb = (bb * c + a * sn) * p.out_scale;
-                const unsigned u = pack_bf16(ra, rb);
-                *(unsigned*)(p.out + (((long)b * p.H + h) * p.S_pad + s) * 128 + 2 * lane) = u;
-                if constexpr (MEASURE) mx[h] = fmaxf(mx[h], wave_sum_dpp(bf_lo(u) * bf_lo(u) + bf_hi(u) * bf_hi(u)));
+                for (int e = 0; e < 8; ++e) ss += x[it][e] * x[it][e];
             }
+        const float rstd = rsqrtf(wave_sum_dpp(ss) / (float)(p.H * 128) + p.eps);
+        float cs[4][2] = {{1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}};
+        if (p.cs) {
+            const float4 c01 = *(const float4*)(p.cs + (long)s * 64 + (lane & 15) * 4), c23 = *(const float4*)(p.cs + (long)s * 64 + (lane & 15) * 4 + 2);
+            cs[0][0] = c01.x; cs[0][1] = c01.y; cs[1][0] = c01.z; cs[1][1] = c01.w;
+            cs[2][0] = c23.x; cs[2][1] = c23.y; cs[3][0] = c23.z; cs[3][1] = c23.w;
+        }
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int h = it * 4 + hl;
+            if (h < p.H) {
+                const float4 w0 = *(const float4*)(p.weight + h * 128 + d0), w1 = *(const float4*)(p.weight + h * 128 + d0 + 4);
+                const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                unsigned u[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = x[it][2 * j] * rstd * w[2 * j], bb = x[it][2 * j + 1] * rstd * w[2 * j + 1];
+                    u[j] = pack_bf16((a * cs[j][0] - bb * cs[j][1]) * p.out_scale, (bb * cs[j][0] + a * cs[j][1]) * p.out_scale);
+                }
+                *(uint4*)(p.out + (((long)b * p.H + h) * p.S_pad + s) * 128 + d0) = make_uint4(u[0], u[1], u[2], u[3]);
+                if constexpr (MEASURE) {
+                    float n2 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) n2 += bf_lo(u[j]) * bf_lo(u[j]) + bf_hi(u[j]) * bf_hi(u[j]);
+                    mx[it] = fmaxf(mx[it], row16_sum_dpp(n2));
+                }
+            }          // (h < p.H is uniform inside a 16-lane DPP row: hl = lane >> 4)
+        }
     }
-    if constexpr (MEASURE) {        // partial row of this wave: lane h holds head h
-        float v = 0.f;
+    if constexpr (MEASURE) {        // partial row of this wave: the first lane of every 16-lane row holds its head's maximum
+        float* dst = p.max2_part + (((long)b0 * gridDim.x + blockIdx.x) * 4 + wave) * p.H;
 #pragma unroll
-        for (int h = 0; h < MAXH; ++h)
-            if (h < p.H) v = lane == h ? mx[h] : v;
-        if (lane < p.H) p.max2_part[(((long)b0 * gridDim.x + blockIdx.x) * 4 + wave) * p.H + lane] = v;
+        for (int it = 0; it < NI; ++it)
+            if ((lane & 15) == 0 && it * 4 + hl < p.H) dst[it * 4 + hl] = mx[it];
     }
 }
 
@@ -197,7 +232,7 @@ hipError_t launch_cfg_rescale(const bf16_t* neg, const bf16_t* pos, float g, bf1
 
 int norm_rope_parts(int rows_per_sample) { return (rows_per_sample + 4 * NR_RPW - 1) / (4 * NR_RPW) * 4; }   // partial rows per sample
 hipError_t launch_norm_rope_full(const NormRopeFullParams& p, hipStream_t stream) {
-    if (p.M <= 0 || p.H <= 0 || p.H > 48 || (p.src_ld & 1) || (p.col & 1)) return hipErrorInvalidValue;
+    if (p.M <= 0 || p.H <= 0 || p.H > 48 || (p.src_ld & 7) || (p.col & 7) || ((size_t)p.src & 15) || ((size_t)p.out & 15)) return hipErrorInvalidValue;
     if (p.max2) {
         if (!p.max2_part || p.s_off != 0 || p.M % p.rows_per_sample) return hipErrorInvalidValue;
         const int B = p.M / p.rows_per_sample;
