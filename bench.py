@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--no-small-batch", action="store_true",
                     help="skip the (untimed w.r.t. `value`) small-batch legs: B = 2 at 1024^2 and the reference's 512^2 B = 2 CFG example shape")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the delivered-core-clock probe of one extra (untimed) rollout")
+    ap.add_argument("--no-train-step", action="store_true",
+                    help="skip the optimize()-replay leg (SURVEY.md 8(f) N1; scripts/train_bench.py in a subprocess, untimed w.r.t. `value`)")
     ap.add_argument("--no-graph", action="store_true", help="launch the rollout eagerly instead of replaying the hipGraph")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test without a GPU: gloo backend, the rollout replaced by a fixed sleep per micro-batch "
@@ -491,6 +493,23 @@ def main():
                              "note": "SD3 AutoencoderKL decoder, synthetic weights; outside the timed region"}
         assert bool(torch.isfinite(img.float()).all())
         dec.close()
+    if rank == 0 and world == 1 and not flux_mode and not args.no_train_step:
+        # the optimize() replay step with gradients (reference trainers/grpo.py:185-342) at B = 2, 1024^2, the reference's
+        # default target modules: forward with stash + native backward.  Its own process (its stash and scratch are ~10 GiB; nothing of
+        # this process's state is touched), reported beside the metric, never inside it; any failure is recorded, not raised.
+        try:
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train_bench.py"), "--batch", "2", "--size", "1024", "--train", "attn",
+                                "--iters", "3"], capture_output=True, text=True, timeout=300)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+            tb = json.loads(line)
+            out["optimize_step"] = {"ms_forward_backward": tb["ms_forward_backward"], "ms_forward_train": tb["ms_forward_train"],
+                                    "ms_forward_nograd": tb["ms_forward_nograd"], "achieved": tb["tflops_step"], "unit": "TFLOP/s",
+                                    "frac": tb["frac_of_2500"], "trainable_params": tb["trainable_params"], "ratio_is_one": tb["ratio_is_one"],
+                                    "note": "B = 2, 1024^2, attention projections trainable (the reference's default target modules); grad-mode "
+                                            "log-prob torch.equal the no-grad replay's; untimed w.r.t. `value`"}
+        except Exception as e:  # noqa: BLE001
+            out["optimize_step"] = {"error": repr(e)}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not flux_mode:
             out["cpu_baseline"] = cpu_baseline()
