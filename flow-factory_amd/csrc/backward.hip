@@ -295,6 +295,18 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* in, long l
 }
 
 // ------------------------------------------------------------------ attention backward: prologue
+// sum over the 8 lanes of a half DPP row (lanes 8 k .. 8 k + 7), in every lane: two quad swaps + the half-row mirror
+__device__ __forceinline__ float half8_sum_dpp(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    using std::integral_constant;
+    v += dpp(v, integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+    v += dpp(v, integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+    v += dpp(v, integral_constant<int, 0x141>{});     // row_half_mirror
+    return v;
+}
+
 // token-major o / do (image rows, then context rows, as the forward wrote o) -> per (b, h):
 //   doh [B][H][S_pad][64] = do rows, delta [B][H][S_pad] = sum_d do * o (fp32), nld = -lse | -delta per 64-query tile (the dK/dV pass
 //   moves a tile's 128 floats into LDS with one LDS-DMA instruction per wave and feeds them to its MFMA chains as C operands)
@@ -303,19 +315,25 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnBwdPrepParams p)
     const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
     const int D = p.H * 64, n_ctx = p.S - p.n_img;
     const long bh = (long)b * p.H + h;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // 4 waves x 16 tokens: lane = d
-    for (int r = w; r < 64; r += 4) {
-        const int s = s0 + r;
-        if (s >= p.S) continue;
+    // 8 lanes per token (16 bytes = 8 features each), 32 tokens per pass: whole 128-byte head rows per half DPP row
+    const int c = threadIdx.x & 7;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int s = s0 + pass * 32 + (threadIdx.x >> 3);
+        if (s >= p.S) continue;               // (uniform inside a half DPP row)
         const long row = (s < p.n_img) ? ((long)b * p.n_img + s) : ((long)b * n_ctx + (s - p.n_img));
         const bf16_t* dop = (s < p.n_img) ? p.do_img : p.do_ctx;
         const bf16_t* op = (s < p.n_img) ? p.o_img : p.o_ctx;
-        const float dov = dop ? bf2f(dop[row * D + h * 64 + lane]) : 0.f;      // do_ctx == nullptr: the context output is unused (last block)
-        const float ov = bf2f(op[row * D + h * 64 + lane]);
-        p.doh[(bh * p.S_pad + s) * 64 + lane] = f2bf(dov);
-        const float dl = wave_sum(dov * ov);
-        if (lane == 0) {
+        const uint4 du = dop ? *(const uint4*)(dop + row * D + h * 64 + c * 8) : make_uint4(0u, 0u, 0u, 0u);   // do_ctx == nullptr: unused (last block)
+        const uint4 ou = *(const uint4*)(op + row * D + h * 64 + c * 8);
+        *(uint4*)(p.doh + (bh * p.S_pad + s) * 64 + c * 8) = du;
+        float dv[8], ov[8];
+        unpack8(du, dv); unpack8(ou, ov);
+        float part = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += dv[e] * ov[e];
+        const float dl = half8_sum_dpp(part);
+        if (c == 0) {
             p.delta[bh * p.S_pad + s] = dl;
             float* nl = p.nld + (bh * p.S_pad + (s & ~63)) * 2 + (s & 63);
             nl[0] = -p.lse[bh * p.S_pad + s];
@@ -329,6 +347,52 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnBwdPrepParams p)
 // of the image stream (s < n_img) and the context stream.  forward: y = x * r * w  (x = projection + bias, r = 1/rms over the head's 64
 // features; for q, w already carries the folded softmax scale):  xhat = y / w,  g = dy * w,  dx = r * (g - xhat * mean(g * xhat)).
 // One wave per token, lane = feature d, loop over heads.
+// the same without the norm-weight partials (default gradient scope): one wave per token, 8 heads per pass, a head's 64 features = 8 lanes x
+// 16 bytes = one half DPP row (the general kernel below moves 2 bytes per lane and access and pays two 64-lane ds_bpermute reductions per
+// head: 73 us at B = 2, 1024^2).  Same arithmetic per element; the per-head sums are formed in another order.
+__global__ __launch_bounds__(256) void rms_bwd_gather_fast_kernel(RmsBwdParams p) {
+    const int lane = threadIdx.x & 63;
+    const long tok = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= (long)p.B * p.S) return;
+    const int hl = lane >> 3, d0 = (lane & 7) * 8;
+    const int D = p.H * 64, n_ctx = p.S - p.n_img;
+    const int b = (int)(tok / p.S), s = (int)(tok - (long)b * p.S);
+    const bool img = s < p.n_img;
+    const long row = img ? ((long)b * p.n_img + s) : ((long)b * n_ctx + (s - p.n_img));
+    bf16_t* out = (img ? p.out_img : p.out_ctx) + row * (3L * D);
+    const float* rstd = (img ? p.rstd_img : p.rstd_ctx) + row * (2L * p.H);
+    const float* nq = (img ? p.nw_q : p.nw_cq) + d0;
+    const float* nk = (img ? p.nw_k : p.nw_ck) + d0;
+    float wq[8], wk[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { wq[e] = nq[e] * p.q_scale; wk[e] = nk[e]; }
+    for (int h0 = 0; h0 < p.H; h0 += 8) {
+        const int h = h0 + hl;
+        if (h >= p.H) continue;               // (uniform inside a half DPP row)
+        const long src = (((long)b * p.H + h) * p.S_pad + s) * 64 + d0;
+        auto one = [&](const bf16_t* yv, const bf16_t* dyv, const float (&w)[8], float r, bf16_t* dst) {
+            float y[8], dy[8], xh[8], g[8];
+            unpack8(*(const uint4*)(yv + src), y);
+            unpack8(*(const uint4*)(dyv + src), dy);
+            float part = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xh[e] = fabsf(w[e]) > 1e-20f ? y[e] / w[e] : 0.f;
+                g[e] = dy[e] * w[e];
+                part += g[e] * xh[e];
+            }
+            const float mgx = half8_sum_dpp(part) * (1.0f / 64.0f);
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = r * (g[e] - xh[e] * mgx);
+            *(uint4*)dst = pack8(o);
+        };
+        one(p.q, p.dq, wq, rstd[h], out + h * 64 + d0);
+        one(p.k, p.dk, wk, rstd[p.H + h], out + D + h * 64 + d0);
+        *(uint4*)(out + 2 * D + h * 64 + d0) = *(const uint4*)(p.dv + src);
+    }
+}
+
 __global__ __launch_bounds__(256) void rms_bwd_gather_kernel(RmsBwdParams p, int tokens_per_wave) {
     __shared__ float red[4][4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -655,7 +719,7 @@ hipError_t launch_rms_bwd_gather(const RmsBwdParams& p, hipStream_t st) {
     }
     const long tokens = (long)p.B * p.S;
     if (p.dw_part) hipLaunchKernelGGL(rms_bwd_gather_kernel, dim3((unsigned)rms_bwd_grid(p.B, p.S)), dim3(256), 0, st, p, 8);
-    else hipLaunchKernelGGL(rms_bwd_gather_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, st, p, 1);
+    else hipLaunchKernelGGL(rms_bwd_gather_fast_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
