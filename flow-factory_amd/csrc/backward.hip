@@ -709,6 +709,8 @@ hipError_t launch_attn_bwd_prep(const AttnBwdPrepParams& p, hipStream_t st) {
 }
 
 // tokens per wave: 1 normally, 8 when the norm-weight partials are wanted (8 x fewer partial rows to sum)
+static int g_rms_bwd_fast = 1;
+void set_rms_bwd_fast(int v) { g_rms_bwd_fast = v != 0; }     // mi355_tune_set(25, .): 0 = the general gather kernel in the default scope too (cross-check)
 int rms_bwd_grid(int B, int S) { return (int)(((long)B * S + 31) / 32); }
 hipError_t launch_rms_bwd_gather(const RmsBwdParams& p, hipStream_t st) {
     if (sched_trace_on()) {
@@ -719,7 +721,8 @@ hipError_t launch_rms_bwd_gather(const RmsBwdParams& p, hipStream_t st) {
     }
     const long tokens = (long)p.B * p.S;
     if (p.dw_part) hipLaunchKernelGGL(rms_bwd_gather_kernel, dim3((unsigned)rms_bwd_grid(p.B, p.S)), dim3(256), 0, st, p, 8);
-    else hipLaunchKernelGGL(rms_bwd_gather_fast_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, st, p);
+    else if (g_rms_bwd_fast) hipLaunchKernelGGL(rms_bwd_gather_fast_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(rms_bwd_gather_kernel, dim3((unsigned)((tokens + 3) / 4)), dim3(256), 0, st, p, 1);
     return hipGetLastError();
 }
 

@@ -276,6 +276,7 @@ struct RmsBwdParams {
                                                            // (norm_q, norm_k, norm_added_q, norm_added_k), summed by launch_rms_dw_finish
 };
 // dw[which][64] = sum over workgroups of part[wg][which][64] (fixed order); outputs may be null; q gradients are w.r.t. the UNSCALED weight
+void set_rms_bwd_fast(int v);
 hipError_t launch_rms_dw_finish(const float* part, int nwg, float q_scale, float* dw_q, float* dw_k, float* dw_cq, float* dw_ck, hipStream_t stream);
 int rms_bwd_grid(int B, int S);
 hipError_t launch_rms_bwd_gather(const RmsBwdParams& p, hipStream_t stream);
