@@ -425,8 +425,8 @@ int mi355_profile_enable(int on);
  *  24     Wan self-attention: 1 (default) = the kernel that stores q and k also measures their largest row norm per (batch, head), and every
  *         (batch, head) whose |q| |k| bound stays <= 60 runs the static-softmax hand-scheduled kernel (the others keep the running max);
  *         0 = the weight-side bound only (never satisfied by Wan's across-head RMSNorm: running-max kernel everywhere).
- *  25     optimize() backward, RMSNorm-backward gather in the default gradient scope: 1 (default) = the 16-byte-access kernel, 0 = the general
- *         kernel (the one that also forms the norm-weight partials in the full scope); cross-check knob.
+ *  25     optimize() backward: 1 = the 16-byte-access forms of the attention-backward prep kernel and of the default-scope RMSNorm-backward
+ *         gather (step 94.2 -> 91.2 ms at B = 2, 1024^2), 0 (default) = the round-2 forms, until the full-width gradient comparison has run on them.
  * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);

@@ -41,10 +41,10 @@ def grads(all_params):
 from mi355_flow import _lib
 lib = _lib.load()
 rel = lambda a, b: {n: float((a[n] - b[n]).norm() / (b[n].norm() + 1e-30)) for n in a}
+lib.mi355_tune_set(25, 1)
 g_fast = grads(False)
 lib.mi355_tune_set(25, 0)
 g_gen = grads(False)
-lib.mi355_tune_set(25, 1)
 g_full = grads(True)
 for name, d in (("fast vs general kernel, both default scope", rel(g_fast, g_gen)), ("default scope (general kernel) vs full scope", rel(g_gen, g_full)),
                 ("default scope (fast kernel) vs full scope", rel(g_fast, g_full))):

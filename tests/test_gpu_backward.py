@@ -319,6 +319,42 @@ def test_side_stream_training_schedule_is_bit_identical_to_the_serial_one(gpu, t
     ad.engine.close()
 
 
+def test_wide_access_backward_helper_kernels_match_the_general_ones(gpu):
+    """mi355_tune_set(25, 1): the 16-byte-access forms of the attention-backward prep kernel (dO scatter + Delta) and of the default-scope
+    RMSNorm-backward gather.  Same arithmetic per element, per-head sums formed in another order: the last block's gradients (one gather
+    deep) agree to summation-order accuracy, everything else to what three blocks of bf16 backward amplify that to."""
+    from mi355_flow import _lib
+    lib = _lib.load()
+    targets = (".to_q.", ".to_k.", ".to_v.", ".to_out.0.")
+    ad, mod, _ = _build(lambda n: any(k in n for k in targets), seed=23)
+    B, h, w, Nt = 3, 12, 16, 21
+    inp = _inputs(B, h, w, Nt, seed=6)
+    ad.scheduler.set_timesteps(4)
+    kw = dict(t=torch.full((B,), 750.0), t_next=torch.full((B,), 500.0), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+              prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(), guidance_scale=1.0, noise_level=0.7,
+              compute_log_prob=True, return_kwargs=["log_prob", "dt"])
+
+    def grads():
+        for prm in mod.parameters():
+            prm.grad = None
+        out = ad.forward(**kw)
+        (inp["wlp"].cuda() * out.log_prob).sum().backward()
+        torch.cuda.synchronize()
+        return {n: prm.grad.clone() for n, prm in mod.named_parameters() if prm.requires_grad}
+
+    try:
+        _lib.check(lib.mi355_tune_set(25, 0), "tune_set")
+        g0 = grads()
+        _lib.check(lib.mi355_tune_set(25, 1), "tune_set")
+        g1 = grads()
+    finally:
+        _lib.check(lib.mi355_tune_set(25, 0), "tune_set")
+    for n in g0:
+        r = _rel(g1[n], g0[n])
+        assert r < (2e-3 if n.startswith("transformer_blocks.2.") else 5e-2), (n, r)
+    ad.engine.close()
+
+
 def test_lora_gradients_flow_through_the_merged_weight(gpu):
     ad, mod, cfg_o = _build(lambda n: False, seed=21)
     PF.wrap_lora(mod)
