@@ -120,8 +120,9 @@ def _inputs(B, h, w, Nt, seed=0):
                 ne=mk(B, Nt, 128).bfloat16(), npl=mk(B, 128).bfloat16(), wlp=mk(B), wnp=mk(B, 16, h, w))
 
 
-def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w):
-    """The same loss through the fp32 oracle network + the Flow-SDE step written in differentiable torch (CPU)."""
+def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=None):
+    """The same loss through the fp32 oracle network + the Flow-SDE step written in differentiable torch (CPU).  `quant=M.bf16_round` puts a
+    bf16 round-trip wherever a bf16 module materialises a tensor; autograd rounds the activation gradient at the same points."""
     from oracle import mmditx_ref as M
     sd = {n: p_.detach().cpu().float().requires_grad_(p_.requires_grad) for n, p_ in list(mod.named_parameters()) + list(mod.named_buffers())}
     x, x1 = inp["x"].float(), inp["x1"].float()
@@ -129,11 +130,11 @@ def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w):
     tt = torch.full((B,), float(torch.tensor(t).half()))            # the network sees t rounded to the latent dtype (sd3_5.py:394)
     if guidance > 1.0:
         v2 = M.mmdit_forward(sd, cfg_o, torch.cat([x, x]), torch.cat([tt, tt]), torch.cat([inp["ne"], inp["pe"]]).float(),
-                             torch.cat([inp["npl"], inp["pp"]]).float())
+                             torch.cat([inp["npl"], inp["pp"]]).float(), quant=quant)
         vu, vt = v2.chunk(2)
         v = vu + guidance * (vt - vu)
     else:
-        v = M.mmdit_forward(sd, cfg_o, x, tt, inp["pe"].float(), inp["pp"].float())
+        v = M.mmdit_forward(sd, cfg_o, x, tt, inp["pe"].float(), inp["pp"].float(), quant=quant)
     sigma, sigma_n = t / 1000.0, t_next / 1000.0
     dt = sigma_n - sigma
     std = math.sqrt(sigma / (1 - (sigma_max if sigma == 1.0 else sigma))) * eta
