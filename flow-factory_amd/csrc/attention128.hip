@@ -209,6 +209,8 @@ __global__ __launch_bounds__(NWAVE * 64, 2) void attn128_kernel(Attn128Params p)
     // ---- finalize: 1/l, stage O through LDS (row = query, 256 B; 16-byte chunks XOR-swizzled by q & 7) for full-row stores
     l_run += __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_run;
+    // training-mode forward: log2-sum-exp per query for the backward (a store only; the rollout passes lse == nullptr and runs this same binary)
+    if (p.lse && lg == 0 && q_row < p.S) p.lse[bh * p.S_pad + q_row] = m_run + __log2f(l_run);
     __syncthreads();
     char* ob = smem + wave * (QW * HD * 2);
 #pragma unroll
@@ -353,6 +355,10 @@ __global__ __launch_bounds__(256) void attn128_w4_kernel(Attn128Params p) {
         float l = l##C##0 + l##C##1;                                                                               \
         l += __shfl_xor(l, 32, 64);                                                                                \
         const float inv = 1.0f / l;                                                                                \
+        if (p.lse && lge == 0) {          /* training-mode forward: log2-sum-exp (static softmax: no running max) */ \
+            const int ql = qblk * QB + wave * 64 + C * 32 + lqe;                                                   \
+            if (ql < p.S) p.lse[bh * p.S_pad + ql] = __log2f(l);                                                   \
+        }                                                                                                          \
         char* ob = smem + (wave * 2 + C) * (32 * HD * 2);                                                          \
         f32x16 o;                                                                                                  \
         A128_STORE_DB(C, 0) A128_STORE_DB(C, 1) A128_STORE_DB(C, 2) A128_STORE_DB(C, 3)                            \

@@ -724,10 +724,11 @@ hipError_t launch_transpose_colsum(const bf16_t* in, long ld_in, bf16_t* out, lo
     return hipGetLastError();
 }
 
-// mi355_tune_set(25, .): 1 = the 16-byte-access forms of attn_bwd_prep and of the default-scope RMSNorm-backward gather (optimize() step
-// 94.2 -> 91.2 ms at B = 2, 1024^2; test_gpu_backward.py green, last-block gradients equal to 1e-5: profiles/r03ad_*).  0 (default) until
-// the full-width oracle comparison (tests/test_gpu_fullsize.py, 5.1e-2 at tolerance 6e-2) has run on them: they round in another order.
-static int g_rms_bwd_fast = 0;
+// mi355_tune_set(25, .): 1 (default since round 4) = the 16-byte-access forms of attn_bwd_prep and of the default-scope RMSNorm-backward gather
+// (optimize() step 94.2 -> 91.2 ms at B = 2, 1024^2).  They round in another order than the general kernels; verified at full width against the
+// oracle's autograd AND its bf16-emulating band (profiles/r04a_*: worst tensor 5.14e-2 vs fp32 with them, 5.25e-2 without; band 3.1-3.3e-2).
+// 0 = the general kernels (always used when norm-weight gradients are requested).
+static int g_rms_bwd_fast = 1;
 void set_rms_bwd_fast(int v) { g_rms_bwd_fast = v != 0; }
 hipError_t launch_attn_bwd_prep(const AttnBwdPrepParams& p, hipStream_t st) {
     if (sched_trace_on()) {

@@ -815,6 +815,29 @@ extern "C" int mi355_sde_step(void* stream, int batch, int64_t n, const void* v_
                     next_f32, mean_out, noise_pred_out, log_prob, std_dev_t, dt);
 }
 
+// adjoint of mi355_sde_step w.r.t. the network output(s): upstream gradients of (log_prob [B], noise_pred [B][n], next_latents_mean [B][n])
+// (any may be NULL) -> dv [n_cfg * B][n] fp32, order [uncond, text] (reference: autograd through FlowMatchEulerDiscreteSDEScheduler.step,
+// scheduler/flow_match_euler_discrete.py:305-426, and the CFG combine sd3_5.py:431-433).  v_text / v_uncond: the bf16 predictions the
+// forward step consumed.  One op for every model family (the FLUX.1 replay: mi355_flux_forward_train -> mi355_sde_step -> ... -> this ->
+// mi355_flux_backward).
+extern "C" int mi355_sde_step_bwd(void* stream, int batch, int64_t n, const void* v_text, const void* v_uncond, float guidance, const void* latents,
+                                  int lat_dtype, const void* next_in, int next_in_dtype, const float* sigma, const float* sigma_next, const float* eta,
+                                  int scalar_stride, float sigma_max, int dynamics, int compute_log_prob, const float* g_log_prob,
+                                  const float* g_noise_pred, const float* g_mean, float* dv) {
+    if (!v_text || !latents || !next_in || !sigma || !sigma_next || !eta || !dv) return fail("mi355_sde_step_bwd: null argument");
+    if (dynamics < 0 || dynamics > 3) return fail("mi355_sde_step_bwd: unknown dynamics %d", dynamics);
+    if (lat_dtype < 0 || lat_dtype > 2 || next_in_dtype < 0 || next_in_dtype > 2) return fail("mi355_sde_step_bwd: bad dtype");
+    SdeBwdParams s;
+    memset(&s, 0, sizeof(s));
+    s.v_text = (const bf16_t*)v_text; s.v_uncond = (const bf16_t*)v_uncond; s.guidance = guidance;
+    s.latents = latents; s.lat_dt = lat_dtype; s.next_in = next_in; s.next_in_dt = next_in_dtype;
+    s.sigma = sigma; s.sigma_next = sigma_next; s.eta = eta; s.scalar_stride = scalar_stride; s.sigma_max = sigma_max;
+    s.dynamics = dynamics; s.compute_log_prob = compute_log_prob; s.B = batch; s.n = n;
+    s.g_lp = g_log_prob; s.g_np = g_noise_pred; s.g_mean = g_mean; s.dv = dv;
+    HIPCHK(launch_sde_step_bwd(s, (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int mi355_denoise_step(mi355_plan* p, void* stream, const void* latents, int lat_dtype, const float* t,
                                   const void* enc_a, const void* pooled_a, const void* enc_b, const void* pooled_b,
                                   float guidance, const float* noise, const void* next_in, int next_in_dtype,

@@ -98,6 +98,12 @@ struct mi355_flux {
     void layout();
 };
 
+struct mi355_flux_plan;
+// training-mode state (flux_train.inc, included at the end of this file)
+static void flux_train_release(mi355_flux_plan* p);
+static void flux_train_release_engine(mi355_flux* e);
+static void flux_train_mark_dirty(mi355_flux* e);
+
 void mi355_flux::layout() {
     used16 = used32 = 0;
     slots.clear(); names.clear();
@@ -195,6 +201,7 @@ extern "C" int mi355_flux_create(const mi355_flux_cfg* cfg, mi355_flux** out) {
 
 extern "C" int mi355_flux_destroy(mi355_flux* e) {
     if (!e) return 0;
+    flux_train_release_engine(e);
     if (e->arena16) (void)hipFree(e->arena16);
     if (e->arena32) (void)hipFree(e->arena32);
     delete e;
@@ -218,6 +225,7 @@ extern "C" int mi355_flux_bind_weight(mi355_flux* e, const char* name, const voi
     HIPCHK(launch_convert(src, dtype, it->second.dst, it->second.dst_dt, n, (hipStream_t)stream));
     it->second.bound = true;
     if (strstr(name, ".norm_")) e->bounds_dirty = true;
+    flux_train_mark_dirty(e);          // the transposed copies the backward's dgrad GEMMs read are stale
     return 0;
 }
 extern "C" int mi355_flux_weights_ready(mi355_flux* e) {
@@ -340,6 +348,7 @@ extern "C" int mi355_flux_plan_create(mi355_flux* e, int batch, int latent_h, in
 
 extern "C" int mi355_flux_plan_destroy(mi355_flux_plan* p) {
     if (!p) return 0;
+    flux_train_release(p);
     if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     for (hipEvent_t ev : p->ev_join) (void)hipEventDestroy(ev);
@@ -792,3 +801,5 @@ extern "C" int mi355_op_norm_rope_full(void* stream, const void* src, int64_t sr
     if (e != hipSuccess) return errorf("mi355_op_norm_rope_full: %s", hipGetErrorString(e));
     return 0;
 }
+
+#include "flux_train.inc"

@@ -104,6 +104,10 @@ __global__ __launch_bounds__(256) void rope_norm_kernel(RopeNormParams p) {
         for (int e = 0; e < 8; ++e) { sq += q[e] * q[e]; sk += k[e] * k[e]; }
         const float rq = rsqrtf(row16_sum_dpp(sq) * (1.0f / 128.0f) + p.eps);
         const float rk = rsqrtf(row16_sum_dpp(sk) * (1.0f / 128.0f) + p.eps);
+        if (p.rstd_out && (lane & 15) == 0) {       // training-mode forward only (same binary as the rollout: a store, no arithmetic)
+            p.rstd_out[(long)m * 2 * p.H + h] = rq;
+            p.rstd_out[(long)m * 2 * p.H + p.H + h] = rk;
+        }
         unsigned uq[4], uk[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -322,6 +326,7 @@ hipError_t launch_rope_norm(const RopeNormParams& p, hipStream_t stream) {
         hipLaunchKernelGGL(rope_norm_kernel, dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, stream, p);
         return hipGetLastError();
     }
+    if (p.rstd_out) return hipErrorInvalidValue;      // the training-mode forward needs the 16-byte form (aligned operands)
     const long items = (long)p.M * p.H;
     hipLaunchKernelGGL(rope_norm_narrow_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, stream, p);
     return hipGetLastError();

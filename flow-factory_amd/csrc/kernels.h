@@ -130,6 +130,8 @@ struct Attn128Params {
     // kernel and the running-max kernel, and each workgroup runs or exits by its own (b, h)'s bound (`mode` below).
     const unsigned* qmax2; const unsigned* kmax2;
     int mode;           // set by launch_attention128: 0 = always run, 1 = run only where the measured bound <= 60, 2 = only where it is larger
+    float* lse;         // optional [B][H][S_pad] fp32: log2-sum-exp of the scaled scores per query (training-mode forward).  A RUNTIME branch in the
+                        // kernels' epilogues, not a second instantiation: rollout and training run the same binary, so their outputs agree bit for bit
 };
 hipError_t launch_attention128(const Attn128Params& p, hipStream_t stream);
 void set_attn128_variant(int v);   // 0 (default): 4-wave hand-scheduled kernel where it applies, else 8-wave workgroups; 1: 4-wave compiler-scheduled; 5: never hand-scheduled
@@ -155,6 +157,7 @@ struct RopeNormParams {
     bf16_t* q_out; bf16_t* k_out;
     int M, H, rows_per_sample, s_off, S_pad;
     float eps, q_scale;
+    float* rstd_out;                          // optional [M][2H] fp32: 1 / rms per (row, head) of q ([0, H)) and k ([H, 2H)) (training-mode forward; runtime branch)
 };
 hipError_t launch_rope_norm(const RopeNormParams& p, hipStream_t stream);
 
@@ -303,6 +306,33 @@ struct AttnBwdParams {
     int B, H, S, S_pad;
 };
 hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream);
+// head_dim 128 (attention128_bwd.hip): the same contract with [B][H][S_pad][128] operands
+hipError_t launch_attention128_bwd(const AttnBwdParams& p, hipStream_t stream);
+struct Attn128BwdPrepParams {
+    // o / dO token-major, split like Attn128Params' output: positions s < n_first of sample b at (b * n_first + s) * ld + h * 128, the others
+    // at (b * (S - n_first) + s - n_first) * ld + h * 128; do_first / do_rest may be null (that part of the output has no consumer: zeros)
+    const bf16_t* o_first; long ld_o_first; const bf16_t* o_rest; long ld_o_rest;
+    const bf16_t* do_first; long ld_do_first; const bf16_t* do_rest; long ld_do_rest;
+    int n_first;
+    const float* lse;                                                                     // [B][H][S_pad] from the forward
+    bf16_t* doh; float* delta; float* nld;                                                // [B][H][S_pad][128], [B][H][S_pad], [B][H][S_pad/64][2][64]
+    int B, H, S, S_pad;
+};
+hipError_t launch_attn128_bwd_prep(const Attn128BwdPrepParams& p, hipStream_t stream);
+// backward of rope_norm (per-head RMSNorm + RoPE of q, k) + gather of (dq~, dk, dv) [B][H][S_pad][128] to token-major rows
+// out[m][0 .. 3 H 128) = [dq_pre | dk_pre | dv] (row stride ld_out) of the M rows of one stream (row m = sample m / rows_per_sample,
+// joint position s_off + m % rows_per_sample)
+struct RopeRmsBwdParams {
+    const bf16_t* q; const bf16_t* k;                      // stored q~ (normalised, rotated, scaled), k
+    const bf16_t* dq; const bf16_t* dk; const bf16_t* dv;  // gradients in the same layout (dq w.r.t. the stored q~)
+    const float* rstd;                                     // [M][2H] from the forward (RopeNormParams::rstd_out)
+    const float* nw_q; const float* nw_k;                  // RMSNorm weights [128]
+    const float2* cs;                                      // [S_joint][64] (cos, sin)
+    float q_scale;
+    bf16_t* out; long ld_out;
+    int M, H, rows_per_sample, s_off, S_pad;
+};
+hipError_t launch_rope_rms_bwd128(const RopeRmsBwdParams& p, hipStream_t stream);
 
 // --------------------------------------------------------------------------- SDE step (K15)
 enum Dynamics : int { DYN_ODE = 0, DYN_FLOW_SDE = 1, DYN_DANCE_SDE = 2, DYN_CPS = 3 };

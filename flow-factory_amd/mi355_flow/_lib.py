@@ -89,6 +89,7 @@ SIGNATURES = {
     "mi355_transformer_forward": (_I, [_P, _P, _P, _I, _P, _I, _P, _P, _P, _P, _P]),
     "mi355_sde_step": (_I, [_P, _I, _L, _P, _P, _I, _F, _P, _I, _P, _P, _I, _P, _P, _P, _I, _F, _I, _I,
                             _P, _P, _P, _P, _P, _P, _P]),
+    "mi355_sde_step_bwd": (_I, [_P, _I, _L, _P, _P, _F, _P, _I, _P, _I, _P, _P, _P, _I, _F, _I, _I, _P, _P, _P, _P]),
     "mi355_denoise_step": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _P, _I, _P, _P, _P, _I, _F, _I, _I,
                                 _P, _P, _P, _P, _P, _P, _P]),
     "mi355_rollout": (_I, [_P, _P, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _I, _F, _P, _I, _I, _P,
@@ -131,6 +132,14 @@ SIGNATURES = {
     "mi355_flux_forward": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "mi355_flux_rollout": (_I, [_P, _P, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _I, _F, _P, _I, _I, _P, _P, _P,
                                 C.POINTER(C.c_int32), _P, _P, _P, _I]),
+    "mi355_flux_set_grad": (_I, [_P, C.c_char_p, _P]),
+    "mi355_flux_clear_grads": (_I, [_P]),
+    "mi355_flux_grad_supported": (_I, [_P, C.c_char_p]),
+    "mi355_flux_plan_training_bytes": (_L, [_P]),
+    "mi355_flux_forward_train": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P]),
+    "mi355_flux_backward": (_I, [_P, _P, _P]),
+    "mi355_op_attention128_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
+    "mi355_op_rope_norm_fwd_bwd": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F]),
     "mi355_op_attention128": (_I, [_P, _P, _P, _P, _P, _L, _I, _P, _L, _I, _I, _I, _I, _I]),
     "mi355_op_rope_norm": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _F]),
     "mi355_op_norm_rope_full": (_I, [_P, _P, _L, _I, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),

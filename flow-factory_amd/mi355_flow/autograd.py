@@ -73,6 +73,8 @@ def unsupported_reason(host) -> Optional[str]:
     if not pairs:
         return "the bound module has no trainable parameter"
     eng = host.engine
+    if not hasattr(eng, "grad_supported"):
+        return f"the {type(eng).__name__} has no native backward"
     for name, _ in pairs:
         if not eng.grad_supported(name):
             return f"parameter '{name}' is outside the native backward's scope"
@@ -149,6 +151,17 @@ def _ddp_of(module):
     return None
 
 
+def _arm_ddp(ddp) -> None:
+    """`DDP._pre_forward` as DDP.forward calls it.  With `device_ids` set -- what `accelerator.prepare` does on a GPU -- it moves its
+    inputs to the device and indexes the result, so it needs at least one input: an empty tensor on that device (found by the
+    world-size-1 RCCL test on the GPU; the gloo tests wrap without device_ids)."""
+    ids = getattr(ddp, "device_ids", None)
+    if ids:
+        ddp._pre_forward(torch.empty(0, device=torch.device(getattr(ddp, "device_type", "cuda"), ids[0])))
+    else:
+        ddp._pre_forward()
+
+
 # --------------------------------------------------------------------------------------------- the autograd node
 class _DenoiseReplayFn(torch.autograd.Function):
     """(log_prob [B], noise_pred [B,C,h,w], next_latents_mean [B,C,h,w]) = step(weights); d/d weights by the engine."""
@@ -197,8 +210,79 @@ def denoise_replay(host, plan, call: dict):
     plan.engine.set_train_scope(any(plan.engine.grad_supported(n) == 2 for n in names))
     ddp = _ddp_of(live.get_module())
     if ddp is not None:
-        ddp._pre_forward()                      # arms buffer sync / lazy init exactly like DDP.forward
+        _arm_ddp(ddp)                           # arms buffer sync / lazy init exactly like DDP.forward
     out = _DenoiseReplayFn.apply(host, plan, names, call, *weights)
     if ddp is not None:
         ddp._post_forward(out[0])               # reducer.prepare_for_backward: bucketed gradient all-reduce during our backward
+    return out
+
+
+
+# --------------------------------------------------------------------------------------------- FLUX.1 (mi355_flux_forward_train / _backward)
+class _FluxReplayFn(torch.autograd.Function):
+    """(log_prob [B], noise_pred [B,Ni,C], next_latents_mean [B,Ni,C]) = step(transformer(weights)); d/d weights by the FLUX engine.
+
+    forward  = `FluxPlan.forward_train` (the no-grad forward's kernel binaries on per-block buffers: the velocity is bit-identical) followed by
+               the SAME fused scheduler-step kernel the no-grad `forward()` runs -> the replay log-prob equals the rollout's bit for bit;
+    backward = `engine.sde_step_bwd` (adjoint of the step: d loss / d v) -> `FluxPlan.backward` (hand-written HIP: head_dim-128 flash-attention
+               backward, RoPE + RMSNorm backward, dgrad / wgrad GEMMs) -> fp32 weight gradients handed to autograd."""
+
+    @staticmethod
+    def forward(ctx, host, plan, names, call, *weights):
+        from .engine import sde_step
+        v = plan.forward_train(call["latents"], call["tm"], call["gm"], call["prompt_embeds"], call["pooled"])
+        o = sde_step(v, None, 1.0, call["latents"], call["sigma"], call["sigma_next"], call["eta"], call["sigma_max"], call["dynamics"],
+                     noise=None, next_latents=call["next_latents"], compute_log_prob=call["compute_log_prob"],
+                     want=("next_latents_mean", "noise_pred", "std_dev_t", "dt"))
+        ctx.set_materialize_grads(False)
+        ctx.host, ctx.plan, ctx.names, ctx.call, ctx.v = host, plan, names, call, v
+        ctx.serial = plan._train_serial
+        ctx.w_meta = [(w.shape, w.dtype) for w in weights]
+        lp = o.log_prob if o.log_prob is not None else torch.zeros((v.shape[0],), device=v.device)
+        ctx.mark_non_differentiable(o.std_dev_t, o.dt)
+        return lp, o.noise_pred, o.next_latents_mean, o.std_dev_t, o.dt
+
+    @staticmethod
+    def backward(ctx, g_lp, g_np, g_mean, _g_std, _g_dt):
+        from .engine import sde_step_bwd
+        host, plan, call = ctx.host, ctx.plan, ctx.call
+        sync = getattr(host, "_sync_weights", None)      # the weights may have been swapped after the forward (KL reference pass): re-bind
+        if sync is not None:
+            sync()
+        if g_lp is None and g_np is None and g_mean is None:
+            return (None,) * (4 + len(ctx.names))
+        if ctx.serial != plan._train_serial:
+            # another training forward ran on this plan since (a loss that sums several grad forwards before one backward): the stash
+            # holds ITS activations -- re-run this step's forward on the kept inputs (same kernels, same weights: bit-identical stash)
+            plan.recomputed_forwards = getattr(plan, "recomputed_forwards", 0) + 1
+            plan.forward_train(call["latents"], call["tm"], call["gm"], call["prompt_embeds"], call["pooled"])
+        if not call["compute_log_prob"]:
+            g_lp = None
+        dv = sde_step_bwd(ctx.v, None, 1.0, call["latents"], call["next_latents"], call["sigma"], call["sigma_next"], call["eta"],
+                          call["sigma_max"], call["dynamics"], call["compute_log_prob"], g_lp, g_np, g_mean)
+        eng = plan.engine
+        grads: Dict[str, torch.Tensor] = {}
+        eng.clear_grads()
+        for name, (shape, _) in zip(ctx.names, ctx.w_meta):
+            grads[name] = torch.zeros(shape, device=dv.device, dtype=torch.float32)
+            eng.set_grad(name, grads[name])
+        plan.backward(dv)
+        eng.clear_grads()
+        outs = tuple(grads[n].to(dt) for n, (_, dt) in zip(ctx.names, ctx.w_meta))
+        return (None, None, None, None) + outs
+
+
+def flux_replay(host, plan, call: dict):
+    """The differentiable FLUX.1 replay step; returns (log_prob, noise_pred, next_latents_mean, std_dev_t, dt) with autograd attached to
+    the trainable parameters behind `host._live_weights` (LoRA-merged weights, FSDP2 shards and DDP reducer arming as `denoise_replay`)."""
+    live: LiveWeights = host._live_weights
+    pairs = trainable_sources(live)
+    names = [n for n, _ in pairs]
+    weights = [_materialise_with_grad(s, live.lora_scale) for _, s in pairs]
+    ddp = _ddp_of(live.get_module())
+    if ddp is not None:
+        _arm_ddp(ddp)
+    out = _FluxReplayFn.apply(host, plan, names, call, *weights)
+    if ddp is not None:
+        ddp._post_forward(out[0])
     return out

@@ -444,6 +444,31 @@ def sde_step(v_text, v_uncond, guidance, latents, sigma, sigma_next, eta, sigma_
     return outs
 
 
+def sde_step_bwd(v_text, v_uncond, guidance, latents, next_latents, sigma, sigma_next, eta, sigma_max, dynamics: str, compute_log_prob: bool,
+                 g_log_prob=None, g_noise_pred=None, g_mean=None) -> torch.Tensor:
+    """Adjoint of `sde_step` w.r.t. the network prediction(s) (mi355_sde_step_bwd): upstream gradients of (log_prob [B], noise_pred,
+    next_latents_mean) -> d v, fp32, shape [n_cfg * B, ...] in the order [uncond, text].  `v_text` / `v_uncond`: the bf16 predictions the
+    forward step consumed; `next_latents`: the stored next state of the replay."""
+    lib = _lib.load()
+    B = latents.shape[0]
+    latents = latents.contiguous()
+    n = latents[0].numel()
+    if v_text.dtype != torch.bfloat16:
+        raise ValueError("mi355_flow: sde_step_bwd differentiates the engine's own bf16 prediction")
+    v_text = v_text.contiguous()
+    v_uncond = v_uncond.contiguous() if v_uncond is not None else None
+    nxt = next_latents.contiguous()
+    sig, sig_n, et, stride = _scalars(sigma, sigma_next, eta, B, latents.device)
+    f32 = lambda g: None if g is None else g.to(torch.float32).contiguous()
+    g_lp, g_np, g_mn = f32(g_log_prob), f32(g_noise_pred), f32(g_mean)
+    dv = torch.empty(((2 if v_uncond is not None else 1) * B,) + tuple(latents.shape[1:]), device=latents.device, dtype=torch.float32)
+    _lib.check(lib.mi355_sde_step_bwd(
+        _stream(), B, n, _ptr(v_text), _ptr(v_uncond), float(guidance), _ptr(latents), dtype_code(latents.dtype), _ptr(nxt), dtype_code(nxt.dtype),
+        _ptr(sig), _ptr(sig_n), _ptr(et), stride, float(sigma_max), DYNAMICS[dynamics], int(bool(compute_log_prob)), _ptr(g_lp), _ptr(g_np),
+        _ptr(g_mn), _ptr(dv)), "sde_step_bwd")
+    return dv
+
+
 # ---------------------------------------------------------------------- operator-level wrappers (tests / profiling)
 def op_linear(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, act: int = 0) -> torch.Tensor:
     lib = _lib.load()

@@ -27,6 +27,7 @@ Importing this module needs an importable `flow_factory`.
 from __future__ import annotations
 
 import functools
+import os
 import inspect
 import logging
 from contextlib import contextmanager
@@ -278,11 +279,19 @@ if _RefAdapter is not None:
                 images = self.vae_decoder.decode(lat, postprocess=False, out_dtype=torch.bfloat16, max_batch=self.vae_max_batch)
                 return self.pipeline.image_processor.postprocess(images, output_type=output_type)
 
-            @functools.wraps(FluxRolloutMixin.forward)
-            def forward(self, *args, **kwargs):
-                if torch.is_grad_enabled():          # optimize(): autograd on the reference path, values from the engine
-                    return self._replay_on_reference(_RefFlux.forward, FluxRolloutMixin.forward, args, kwargs)
-                return FluxRolloutMixin.forward(self, *args, **kwargs)
+            # `forward` is the mixin's own method: in grad mode -- optimize(), trainers/grpo.py:263 -- it runs the engine's differentiable
+            # forward + native backward (mi355_flow.autograd.flux_replay) whenever that backward covers the trainable set: the reference's
+            # default FLUX.1 target modules (flux1.py:76-84) and every other linear layer inside the blocks, full or LoRA.  Anything else
+            # trainable (`target_modules: all`: modulation linears, norm weights, embedders) arrives at this hook: autograd on the
+            # reference's torch path with the engine's values (a deliberate, documented deviation from "raise": INTEGRATION.md).
+            def _grad_fallback(self, why, kwargs):
+                if os.environ.get("MI355_STRICT_NATIVE") == "1":
+                    raise NotImplementedError(f"mi355_flow: FLUX.1 forward() with autograd is outside the native backward ({why}) and "
+                                              "MI355_STRICT_NATIVE=1 forbids the reference path")
+                if not getattr(self, "_warned_ref_grad", False):
+                    logger.warning("mi355_flow: grad-mode forward() differentiates through the reference path (%s); values stay the engine's", why)
+                    self._warned_ref_grad = True
+                return self._replay_on_reference(_RefFlux.forward, FluxRolloutMixin._forward_nograd, (), kwargs)
 
     try:
         from flow_factory.models.wan.wan2_t2v import Wan2_T2V_Adapter as _RefWan, WanT2VSample as _RefWanSample

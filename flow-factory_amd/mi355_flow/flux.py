@@ -101,6 +101,19 @@ class FluxEngine(WeightHolder):
             self._plans[key] = p
         return p
 
+    # ---------------------------------------------------------------- weight gradients (mi355_flow/autograd.py: flux_replay)
+    def grad_supported(self, name: str) -> int:
+        """1 = the native backward produces a gradient for this parameter (the linear layers inside the transformer blocks), 0 = it does not."""
+        return 1 if self.lib.mi355_flux_grad_supported(self._h, name.encode()) == 0 else 0
+
+    def set_grad(self, name: str, grad: torch.Tensor) -> None:
+        if grad.dtype != torch.float32 or not grad.is_contiguous():
+            raise ValueError("mi355_flow: gradient buffers are contiguous fp32 tensors")
+        _lib.check(self.lib.mi355_flux_set_grad(self._h, name.encode(), _ptr(grad)), f"flux_set_grad({name})")
+
+    def clear_grads(self) -> None:
+        _lib.check(self.lib.mi355_flux_clear_grads(self._h), "flux_clear_grads")
+
     def close(self) -> None:
         for p in self._plans.values():
             p.close()
@@ -153,6 +166,41 @@ class FluxPlan:
         _lib.check(self.lib.mi355_flux_forward(self._h, _stream(), _ptr(latents), dtype_code(latents.dtype), _ptr(tm), _ptr(gm), _ptr(pe),
                                                _ptr(pp), _ptr(out)), "flux_forward")
         return out
+
+    def _model_scalars(self, latents, t_model, guidance_model):
+        B, dev = self.batch, latents.device
+        tm = t_model.to(device=dev, dtype=torch.float32).reshape(-1)
+        tm = (tm.expand(B) if tm.numel() == 1 else tm).contiguous()
+        gm = None
+        if guidance_model is not None:
+            gm = guidance_model.to(device=dev, dtype=torch.float32).reshape(-1)
+            gm = (gm.expand(B) if gm.numel() == 1 else gm).contiguous()
+        return tm, gm
+
+    # ---------------------------------------------------------------- differentiable forward (optimize() replay)
+    def forward_train(self, latents: torch.Tensor, t_model: torch.Tensor, guidance_model: Optional[torch.Tensor],
+                      prompt_embeds: torch.Tensor, pooled: torch.Tensor) -> torch.Tensor:
+        """mi355_flux_forward_train: `transformer_forward` on per-block activation buffers -- the same kernel binaries, so the velocity is
+        bit-identical -- keeping what `backward` needs in the plan's training stash (ONE per plan; every call takes a serial number)."""
+        assert latents.shape == (self.batch, self.Ni, self.C), latents.shape
+        tm, gm = self._model_scalars(latents, t_model, guidance_model)
+        out = torch.empty((self.batch, self.Ni, self.C), device=latents.device, dtype=torch.bfloat16)
+        latents = latents.contiguous()
+        pe, pp = _bf16c(prompt_embeds), _bf16c(pooled)
+        _lib.check(self.lib.mi355_flux_forward_train(self._h, _stream(), _ptr(latents), dtype_code(latents.dtype), _ptr(tm), _ptr(gm), _ptr(pe),
+                                                     _ptr(pp), _ptr(out)), "flux_forward_train")
+        self._train_serial = getattr(self, "_train_serial", 0) + 1
+        return out
+
+    def backward(self, dv: torch.Tensor) -> None:
+        """mi355_flux_backward: d loss / d v [B, Ni, C] fp32 of the LAST `forward_train` -> the buffers registered with `FluxEngine.set_grad`."""
+        dv = dv.to(torch.float32).contiguous()
+        assert dv.shape == (self.batch, self.Ni, self.C), dv.shape
+        _lib.check(self.lib.mi355_flux_backward(self._h, _stream(), _ptr(dv)), "flux_backward")
+
+    @property
+    def training_bytes(self) -> int:
+        return int(self.lib.mi355_flux_plan_training_bytes(self._h))
 
     def rollout(self, timesteps: Sequence[float], sigmas: Sequence[float], noise_levels: Sequence[float], dynamics: str,
                 guidance_scale: float, init_latents: torch.Tensor, storage_dtype: torch.dtype, step_noise: Optional[torch.Tensor],
@@ -330,8 +378,12 @@ class FluxRolloutMixin:
             outs.append(o)
         return all_lat, log_probs, outs
 
-    # ------------------------------------------------------------------ single step / replay (flux1.py:294-346), no-grad
-    @torch.no_grad()
+    # ------------------------------------------------------------------ single step / replay (flux1.py:294-346)
+    def _grad_fallback(self, why: str, kwargs: Dict[str, Any]):
+        """Grad-mode forward() the native backward cannot serve.  Standalone: there is no other implementation -- raise (the Flow-Factory
+        plugin overrides this with the reference's autograd path)."""
+        raise NotImplementedError(f"mi355_flow: FLUX.1 forward() with autograd is not available natively: {why}")
+
     def forward(
         self,
         t: torch.Tensor,
@@ -349,6 +401,31 @@ class FluxRolloutMixin:
         height: Optional[int] = None,
         width: Optional[int] = None,
     ) -> SDESchedulerOutput:
+        kw = dict(t=t, latents=latents, prompt_embeds=prompt_embeds, pooled_prompt_embeds=pooled_prompt_embeds, img_ids=img_ids, t_next=t_next,
+                  next_latents=next_latents, guidance_scale=guidance_scale, noise_level=noise_level, joint_attention_kwargs=joint_attention_kwargs,
+                  compute_log_prob=compute_log_prob, return_kwargs=return_kwargs, height=height, width=width)
+        if torch.is_grad_enabled() and getattr(self, "_live_weights", None) is not None:
+            # optimize() (trainers/grpo.py:263): the replay of a stored transition WITH autograd on the engine's differentiable forward +
+            # native backward (mi355_flow.autograd.flux_replay) when its backward covers the trainable set; the matching-loss trainers'
+            # forward without a stored transition (noise_pred only) runs the same path with the log-prob switched off
+            from . import autograd as AG
+            self._before_engine_call()
+            why = AG.unsupported_reason(self)
+            sampled = next_latents is None and ("next_latents" in return_kwargs or (compute_log_prob and "log_prob" in return_kwargs))
+            if why is None and sampled:
+                why = "a sampled next state (or its log-prob) was requested with autograd"
+            if why is None:
+                return self._forward_impl(grad=True, **kw)
+            if not why.startswith("the bound module has no trainable"):
+                return self._grad_fallback(why, kw)
+        return self._forward_nograd(**kw)
+
+    def _forward_nograd(self, **kw) -> SDESchedulerOutput:
+        with torch.no_grad():
+            return self._forward_impl(grad=False, **kw)
+
+    def _forward_impl(self, t, latents, prompt_embeds, pooled_prompt_embeds, img_ids, t_next, next_latents, guidance_scale, noise_level,
+                      joint_attention_kwargs, compute_log_prob, return_kwargs, height, width, grad: bool) -> SDESchedulerOutput:
         self._before_engine_call()
         self._check_joint_attention_kwargs(joint_attention_kwargs)
         B, Ni, _ = latents.shape
@@ -368,7 +445,9 @@ class FluxRolloutMixin:
         tm = ((t.double() / 1000).float().to(latents.dtype) * 1000).float()   # exact quotient, as the fused rollout's host math
         g = torch.as_tensor(guidance_scale, device=dev, dtype=latents.dtype).reshape(-1)
         gm = (g * 1000).float()
-        v = plan.transformer_forward(latents, tm, gm if self.engine.cfg.guidance_embeds else None, prompt_embeds, pooled_prompt_embeds)
+        gm = gm if self.engine.cfg.guidance_embeds else None
+        if not grad:
+            v = plan.transformer_forward(latents, tm, gm, prompt_embeds, pooled_prompt_embeds)
         sched = self.scheduler
         if t_next is None:
             idx = [sched.index_for_timestep(x) for x in t]
@@ -383,10 +462,21 @@ class FluxRolloutMixin:
         noise = None
         if next_latents is None and dyn != "ODE":
             noise = randn_tensor(latents.shape, device=dev, dtype=torch.float32)
+        view = (-1, 1, 1)
+        if grad:
+            from . import autograd as AG
+            replay = next_latents is not None
+            clp = bool(compute_log_prob) and replay
+            call = dict(latents=latents, tm=tm, gm=gm, prompt_embeds=prompt_embeds, pooled=pooled_prompt_embeds, sigma=sigma, sigma_next=sigma_next,
+                        eta=noise_level, sigma_max=float(sched.sigmas[1]), dynamics=dyn, next_latents=next_latents if replay else latents,
+                        compute_log_prob=clp)
+            lp, npred, mean, std, dtt = AG.flux_replay(self, plan, call)
+            res = dict(noise_pred=npred, next_latents=next_latents.float() if replay else None, next_latents_mean=mean, std_dev_t=std.view(view),
+                       dt=dtt.view(view), log_prob=lp if clp else None)
+            return self._output_cls.from_dict({k: res[k] for k in return_kwargs if k in res})
         want = tuple(k for k in return_kwargs if k in ("next_latents", "next_latents_mean", "noise_pred", "std_dev_t", "dt"))
         o = sde_step(v, None, 1.0, latents, sigma, sigma_next, noise_level, float(sched.sigmas[1]), dyn, noise=noise,
                      next_latents=next_latents, compute_log_prob=compute_log_prob, want=want)
-        view = (-1, 1, 1)
         res = dict(
             noise_pred=o.noise_pred,
             next_latents=o.next_latents if next_latents is None else next_latents.float(),
@@ -404,7 +494,7 @@ class FluxRolloutMixin:
 class Flux1NativeAdapter(FluxRolloutMixin):
     """Standalone FLUX.1 adapter (no Flow-Factory import): engine + scheduler (+ optional native VAE decoder)."""
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], config: Optional[FluxConfig] = None,
+    def __init__(self, state_dict: Union[Dict[str, torch.Tensor], torch.nn.Module], config: Optional[FluxConfig] = None,
                  scheduler: Optional[FlowMatchEulerDiscreteSDEScheduler] = None, latent_storage_dtype: Optional[str] = "fp16",
                  transformer_dtype: torch.dtype = torch.bfloat16, device: Union[str, torch.device] = "cuda",
                  vae_state_dict: Optional[Dict[str, torch.Tensor]] = None, vae_config=None, vae_max_batch: int = 4):
@@ -417,7 +507,16 @@ class Flux1NativeAdapter(FluxRolloutMixin):
         self.scheduler = scheduler or FlowMatchEulerDiscreteSDEScheduler(shift=3.0, use_dynamic_shifting=True, sde_steps=[1, 2, 3],
                                                                          num_sde_steps=1)
         self.engine = FluxEngine(config or FluxConfig())
-        self.refresh_weights(state_dict)
+        self._live_weights = None
+        if isinstance(state_dict, torch.nn.Module):
+            # a torch module with HF parameter names (possibly DDP / peft wrapped): its CURRENT parameters are re-bound before every engine
+            # call, and grad-mode forward() differentiates w.r.t. its trainable parameters (mi355_flow/autograd.py: flux_replay)
+            from .binding import LiveWeights
+            module = state_dict
+            self._live_weights = LiveWeights(self.engine, lambda: module)
+            self._sync_weights()
+        else:
+            self.refresh_weights(state_dict)
         self.vae_decoder = None
         self.vae_max_batch = vae_max_batch
         if vae_state_dict is not None:
@@ -433,6 +532,17 @@ class Flux1NativeAdapter(FluxRolloutMixin):
     def refresh_weights(self, state_dict: Dict[str, torch.Tensor]) -> None:
         self.engine.bind_state_dict(state_dict)
         self.engine.ready()
+
+    def _sync_weights(self) -> int:
+        if self._live_weights is None:
+            return 0
+        n = self._live_weights.sync()
+        if n:
+            self.engine.ready()
+        return n
+
+    def _before_engine_call(self) -> None:
+        self._sync_weights()
 
     def rollout(self):
         self.scheduler.rollout()

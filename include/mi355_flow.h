@@ -106,6 +106,14 @@ int mi355_sde_step(void* stream, int batch, int64_t n, const void* v_text, const
                    int dynamics, int compute_log_prob, void* next_out, float* next_f32, float* mean_out,
                    float* noise_pred_out, float* log_prob, float* std_dev_t, float* dt);
 
+/* adjoint of mi355_sde_step w.r.t. the network prediction(s) (autograd through scheduler.step + the CFG combine): upstream gradients of
+ * (log_prob [batch], noise_pred [batch][n], next_latents_mean [batch][n]) fp32, any may be NULL -> dv [n_cfg*batch][n] fp32, order [uncond, text];
+ * v_text / v_uncond = the bf16 predictions the forward step consumed, next_in = the stored next state (replay) */
+int mi355_sde_step_bwd(void* stream, int batch, int64_t n, const void* v_text, const void* v_uncond, float guidance, const void* latents,
+                       int lat_dtype, const void* next_in, int next_in_dtype, const float* sigma, const float* sigma_next, const float* eta,
+                       int scalar_stride, float sigma_max, int dynamics, int compute_log_prob, const float* g_log_prob,
+                       const float* g_noise_pred, const float* g_mean, float* dv);
+
 /* ---- one denoise step = forward + CFG + step (SD3_5Adapter.forward); replay when next_in != NULL */
 int mi355_denoise_step(mi355_plan* p, void* stream, const void* latents, int lat_dtype, const float* t,
                        const void* enc_a, const void* pooled_a, const void* enc_b, const void* pooled_b,
@@ -246,6 +254,34 @@ int mi355_flux_rollout(mi355_flux_plan* plan, void* stream, int n_steps, const f
                        int init_dtype, int storage_dtype, const float* step_noise, const void* prompt_embeds, const void* pooled,
                        const int32_t* keep_slot_host, void* out_latents, float* out_log_probs, void* out_final,
                        int compute_log_prob);
+/* ---- FLUX.1 `optimize()` replay with gradients (SURVEY.md 8(f) N1 over N3) --------------------------------------------------
+ * Replaces the grad-mode `Flux1Adapter.forward(..., next_latents=x_{i+1})` + `accelerator.backward(loss)` of GRPOTrainer.optimize (reference
+ * src/flow_factory/trainers/grpo.py:263, :326-330 over models/flux/flux1.py:294-346):
+ *   mi355_flux_forward_train  = mi355_flux_forward on per-block activation buffers (same kernel binaries: v_out bit-identical), keeping what
+ *                               the backward needs in the plan's training stash (ONE per plan, overwritten by every call);
+ *   mi355_sde_step            = the scheduler step on v_out (unchanged: log-prob bit-identical to the rollout's, ratio == 1);
+ *   mi355_sde_step_bwd        = its adjoint: upstream gradients of (log_prob, noise_pred, next_latents_mean) -> d v (one op, every family);
+ *   mi355_flux_backward       = d v [B][Ni][C] fp32 -> fp32 weight gradients, OVERWRITING the buffers registered with mi355_flux_set_grad
+ *                               (same shape as the parameter; NULL un-registers).
+ * Gradient scope (mi355_flux_grad_supported == 0): weights and biases of every linear layer inside the transformer blocks --
+ * transformer_blocks.N.{attn.{to_q,to_k,to_v,to_out.0,add_q_proj,add_k_proj,add_v_proj,to_add_out},ff.net.{0.proj,2},ff_context.net.{0.proj,2}},
+ * single_transformer_blocks.N.{attn.{to_q,to_k,to_v},proj_mlp,proj_out}: a superset of the reference's FLUX.1 default target modules
+ * (models/flux/flux1.py:76-84).  Everything else (modulation linears, norm weights, embedders, conditioning MLPs, final proj_out): 1 = never. */
+int mi355_flux_set_grad(mi355_flux* e, const char* name, float* grad);
+int mi355_flux_clear_grads(mi355_flux* e);
+int mi355_flux_grad_supported(mi355_flux* e, const char* name);
+int64_t mi355_flux_plan_training_bytes(mi355_flux_plan* plan);
+int mi355_flux_forward_train(mi355_flux_plan* plan, void* stream, const void* latents, int lat_dtype, const float* t_model,
+                             const float* guidance_model, const void* prompt_embeds, const void* pooled, void* v_out);
+int mi355_flux_backward(mi355_flux_plan* plan, void* stream, const float* dv);
+/* unit-test helpers of the head_dim-128 backward kernels: attention forward (q pre-scaled by log2(e)/sqrt(128)) + flash backward, d_o / o
+ * token-major [B*S][H*128], dq / dk / dv head-major (synchronises); q | k producer (per-head RMSNorm + RoPE) forward with its 1/rms output
+ * and backward: dq / dk / dv head-major -> out [M][3*H*128] = [dq_pre | dk_pre | dv] */
+int mi355_op_attention128_fwd_bwd(void* stream, const void* q, const void* k, const void* vT, const void* d_o, void* o, void* dq, void* dk,
+                                  void* dv, int B, int H, int S, int S_pad);
+int mi355_op_rope_norm_fwd_bwd(void* stream, const void* src, int64_t src_ld, int q_col, int k_col, const float* nw_q, const float* nw_k,
+                               const float* cos_sin, void* q_out, void* k_out, float* rstd, const void* dq, const void* dk, const void* dv,
+                               void* out, int M, int H, int rows_per_sample, int s_off, int S_pad, float eps, float q_scale);
 /* head_dim-128 attention / RMSNorm+RoPE operators (unit tests) */
 int mi355_op_attention128(void* stream, const void* q, const void* k, const void* vT, void* o_first, int64_t ld_first,
                           int n_first, void* o_rest, int64_t ld_rest, int B, int H, int S, int S_pad, int q_prescaled);
@@ -425,8 +461,9 @@ int mi355_profile_enable(int on);
  *  24     Wan self-attention: 1 (default) = the kernel that stores q and k also measures their largest row norm per (batch, head), and every
  *         (batch, head) whose |q| |k| bound stays <= 60 runs the static-softmax hand-scheduled kernel (the others keep the running max);
  *         0 = the weight-side bound only (never satisfied by Wan's across-head RMSNorm: running-max kernel everywhere).
- *  25     optimize() backward: 1 = the 16-byte-access forms of the attention-backward prep kernel and of the default-scope RMSNorm-backward
- *         gather (step 94.2 -> 91.2 ms at B = 2, 1024^2), 0 (default) = the round-2 forms, until the full-width gradient comparison has run on them.
+ *  25     optimize() backward: 1 (default since round 4) = the 16-byte-access forms of the attention-backward prep kernel and of the
+ *         default-scope RMSNorm-backward gather (step 94.2 -> 91.2 ms at B = 2, 1024^2; verified at full width against the oracle's autograd
+ *         and its bf16 band, profiles/r04a_*), 0 = the general forms.
  * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);
