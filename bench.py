@@ -170,6 +170,8 @@ def main():
     ap.add_argument("--no-clock-probe", action="store_true", help="skip the delivered-core-clock probe of one extra (untimed) rollout")
     ap.add_argument("--no-train-step", action="store_true",
                     help="skip the optimize()-replay leg (SURVEY.md 8(f) N1; scripts/train_bench.py in a subprocess, untimed w.r.t. `value`)")
+    ap.add_argument("--no-families", action="store_true",
+                    help="skip the (untimed w.r.t. `value`) FLUX.1-dev / Wan2.1 / Qwen-Image rollout legs (BASELINE.json configs[2..4]; subprocesses)")
     ap.add_argument("--no-graph", action="store_true", help="launch the rollout eagerly instead of replaying the hipGraph")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test without a GPU: gloo backend, the rollout replaced by a fixed sleep per micro-batch "
@@ -343,17 +345,18 @@ def main():
         gemm_fl = (F - attn_fl) * B * fwd_per_timed        # fwd_per_timed already counts the n_cfg forwards
         # HBM bytes per launch come from a rocprofv3 --pmc pass (counters cannot be read from inside the process): the committed
         # summary names the commit it was collected at; `traffic` is null when there is none
-        traffic, traffic_src = None, None
+        traffic, traffic_src, mfma_busy = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_attention.json")
         if os.path.isfile(pmc):
             pj = json.load(open(pmc))
             traffic = pj.get("hbm_bytes_per_launch")
+            mfma_busy = pj.get("mfma_busy")
             traffic_src = f"profiles/pmc_attention.json@{pj.get('commit', 'round-' + str(pj.get('round')))} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
         ainfo = adapter.engine.attention_info()
         out["roofline"] = {
             "bound": "mfma", "kernel": "attn_kernel (joint S=4429 x24, dual S=4096 x13 per forward)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-            "traffic": traffic, "traffic_source": traffic_src, "flops_per_launch": a_flop, "ms_per_launch": round(a_ms, 4),
+            "traffic": traffic, "traffic_source": traffic_src, "mfma_busy": mfma_busy, "flops_per_launch": a_flop, "ms_per_launch": round(a_ms, 4),
             "static_softmax": ainfo["static"] == ainfo["total"] and os.environ.get("MI355_ATTN_STATIC") != "0",
             "static_softmax_launches": f"{ainfo['static']}/{ainfo['total']} (proven |score| bound {ainfo['max_bound']:.1f} <= 60 selects it per layer: "
                                        "weight-dependent -- see attention_dynamic for the kernel every checkpoint can run)",
@@ -391,8 +394,47 @@ def main():
                                                "forward_frac": round(dyn_fwd / PEAK_BF16_TFLOPS, 4), "forward_achieved": round(dyn_fwd, 1),
                                                "note": "running-max softmax on every layer (what a checkpoint whose norm weights prove no score "
                                                        "bound runs); one untimed eager rollout with event brackets"}
+        # the GEMM class (51 % of the kernel time) in the driver's own record: one more untimed eager rollout with EVERY class bracketed -- on a
+        # single stream, because beside a side stream the small text GEMMs' durations are concurrency stretch, not cost
+        if args.kernel_timing != "all":
+            try:
+                lib.mi355_tune_set(8, 0)
+                one_rollout()
+                lib.mi355_profile_enable(1)
+                one_rollout()
+                torch.cuda.synchronize()
+                _lib.check(lib.mi355_profile_collect(ms, cnt), "profile_collect")
+                lib.mi355_profile_enable(0)
+                g_fl = (F - attn_fl) * B * n_cfg * N
+                names5 = ["attention", "gemm", "ln_modulate", "sde_step", "misc"]
+                out["roofline"]["gemm"] = {"achieved": round(g_fl / (ms[1] * 1e-3) / 1e12, 1), "frac": round(g_fl / (ms[1] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                           "ms_per_rollout": round(ms[1], 2), "launches": int(cnt[1]),
+                                           "note": "all GEMM launches of one untimed single-stream eager rollout, event-bracketed; algorithmic FLOPs = forward minus attention"}
+                out["roofline"]["by_class_single_stream"] = {names5[i]: {"ms": round(ms[i], 3), "launches": int(cnt[i])} for i in range(5) if cnt[i] > 0}
+            except Exception as e:  # noqa: BLE001
+                out["roofline"]["gemm"] = {"error": repr(e)}
+            lib.mi355_tune_set(8, 2)
         lib.mi355_tune_set(2, 1)
         one_rollout(); one_rollout()                    # eager warm-up + capture
+        # package power and energy of the rollout (ROCm SMI, in-process): the round-3 finding that the rollout runs at the power cap had clock
+        # evidence only.  Two graph-replayed rollouts inside the sampling window; energy from the device's accumulator.
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "scripts"))
+            from power_meter import PowerMeter
+            one_rollout()
+            torch.cuda.synchronize()
+            with PowerMeter(device=local) as pm:
+                one_rollout(); one_rollout()
+                torch.cuda.synchronize()
+            ps = pm.summary()
+            if ps.get("energy_j"):
+                ps["joules_per_rollout"] = round(ps["energy_j"] / 2, 1)
+                ps["joules_per_denoise_step"] = round(ps["energy_j"] / 2 / (B * N), 2)
+                ps["algorithmic_tflop_per_joule"] = round(n_cfg * F * B * N * 2 / ps["energy_j"] / 1e12, 3)
+            ps["note"] = "socket power sampled every 20 ms (rsmi_dev_power_get) over two graph-replayed rollouts; energy = rsmi_dev_energy_count_get delta"
+            out["power"] = ps
+        except Exception as e:  # noqa: BLE001
+            out["power"] = {"error": repr(e)}
         if not args.no_clock_probe:
             # core clock DELIVERED under the package power cap while the rollout runs: one probe wave on a side stream samples
             # {s_memtime, s_memrealtime (100 MHz)} pairs beside one more (untimed) graph-replayed rollout
@@ -510,6 +552,27 @@ def main():
                                             "log-prob torch.equal the no-grad replay's; untimed w.r.t. `value`"}
         except Exception as e:  # noqa: BLE001
             out["optimize_step"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not flux_mode and not args.no_families:
+        # BASELINE.json configs[2..4] on the driver's box: the other engines' rollouts at their own geometries, 2 denoise
+        # steps each (the per-step cost does not depend on the step count), each in its own process (24 / 3 / 41 GB of weights), untimed w.r.t.
+        # `value`; a failure is recorded under its key, never raised.
+        import subprocess
+        fam = {}
+        for tag, cmd in (("flux1_dev_b8_1024", ["flux_bench.py", "--batch", "8", "--size", "1024", "--denoise-steps", "2", "--iters", "2"]),
+                         ("wan21_t2v_1p3b_b2_cfg_480x832x49", ["wan_bench.py", "--batch", "2", "--denoise-steps", "2", "--iters", "2"]),
+                         ("qwen_image_b2_cfg_1328", ["qwen_bench.py", "--batch", "2", "--size", "1328", "--denoise-steps", "2", "--iters", "2"])):
+            try:
+                t1 = time.perf_counter()
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", cmd[0])] + cmd[1:], capture_output=True, text=True, timeout=300)
+                fb = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                fam[tag] = {"denoise_steps_per_s": fb["denoise_steps_per_s"], "forward_tflops": fb["forward_tflops"], "forward_frac": fb["frac_of_2.5PF"],
+                            "batch": fb.get("batch"), "n_cfg": fb.get("n_cfg", 1), "denoise_steps": fb.get("denoise_steps"), "finite": fb.get("finite"),
+                            "leg_wall_s": round(time.perf_counter() - t1, 1)}
+            except Exception as e:  # noqa: BLE001
+                fam[tag] = {"error": repr(e)}
+        fam["note"] = ("real geometries (FLUX.1-dev 11.9 B, Wan2.1-T2V-1.3B, Qwen-Image 60 layers), synthetic weights / prompts, hipGraph / eager as each "
+                       "engine ships; denoise-steps/s = samples x steps / wall; forward_frac vs 2.5 PFLOP/s on algorithmic matmul FLOPs")
+        out["families"] = fam
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not flux_mode:
             out["cpu_baseline"] = cpu_baseline()

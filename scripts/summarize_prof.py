@@ -7,6 +7,9 @@ import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+# optional second argument: the sub-directory (below `out`) whose kernel-stats CSV is summarised.  Round 3's evidence script left the
+# single-stream run's directory beside the two-stream one and this script read "the first match": its two tables were the same table.
+stats_sub = sys.argv[2] if len(sys.argv) > 2 else None
 
 
 def short(name):
@@ -35,7 +38,11 @@ def short(name):
     return name[:60]
 
 
-stats = glob.glob(os.path.join(out, "**", "*kernel_stats*.csv"), recursive=True)
+stats = sorted(glob.glob(os.path.join(out, stats_sub, "**", "*kernel_stats*.csv") if stats_sub else os.path.join(out, "**", "*kernel_stats*.csv"),
+                        recursive=True))
+if stats_sub and len(stats) != 1:
+    print(f"expected exactly one kernel-stats CSV below {os.path.join(out, stats_sub)}, found {len(stats)}: {stats}")
+    stats = stats[:1]
 if stats:
     rows = list(csv.DictReader(open(stats[0])))
     print("== rocprofv3 --kernel-trace --stats (bench.py --steps 1 --warmup 1):", os.path.basename(stats[0]))
@@ -75,7 +82,17 @@ if "FETCH_SIZE" in a and "WRITE_SIZE" in a:
     except Exception:
         sha = ""
     sha = sha or os.environ.get("MI355_COMMIT", "unknown")
-    json.dump({"round": int(os.environ.get("MI355_ROUND", "3")), "commit": sha, "kernel": "mi355::attn_kernel (mean over the joint S=4429 and dual S=4096 launches of a forward, forward batch 8)",
+    # MFMA pipe utilisation of the kernel: SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 1024 SIMDs, GRBM_GUI_ACTIVE over its 8 XCDs
+    mfma_busy = None
+    if a.get("SQ_VALU_MFMA_BUSY_CYCLES") and a.get("GRBM_GUI_ACTIVE"):
+        mfma_busy = round(a["SQ_VALU_MFMA_BUSY_CYCLES"] / (a["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
+    by_kernel = {}
+    for k, v in summary.items():
+        if v.get("SQ_VALU_MFMA_BUSY_CYCLES") and v.get("GRBM_GUI_ACTIVE") and ("gemm" in k or "attn" in k):
+            by_kernel[k] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
+    json.dump({"round": int(os.environ.get("MI355_ROUND", "4")), "commit": sha, "mfma_busy": mfma_busy,
+               "mfma_busy_formula": "SQ_VALU_MFMA_BUSY_CYCLES (summed over 1024 SIMDs) / (GRBM_GUI_ACTIVE (summed over 8 XCDs) / 8 * 1024), per launch",
+               "mfma_busy_by_kernel": by_kernel, "kernel": "mi355::attn_kernel (mean over the joint S=4429 and dual S=4096 launches of a forward, forward batch 8)",
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py --steps 1 --warmup 0 --denoise-steps 2",
                "FETCH_SIZE_kb_per_launch": a["FETCH_SIZE"], "WRITE_SIZE_kb_per_launch": a["WRITE_SIZE"],
                "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> doubled; WRITE_SIZE as is",

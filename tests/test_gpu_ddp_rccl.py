@@ -111,8 +111,8 @@ def test_one_optimize_microstep_under_ddp_on_rccl(rccl_group):
     ra, kw_a = microstep(ad_a)
     rb, kw_b = microstep(ad_b)
     torch.cuda.synchronize()
-    assert len(fired) >= 2, fired                         # several buckets went through the communicator
-    assert sum(fired) == sum(p.numel() for p in params_a)
+    # (torch builds ONE bucket for the first reduction and re-buckets by `bucket_cap_mb` in gradient-ready order afterwards: part 4)
+    assert len(fired) >= 1 and sum(fired) == sum(p.numel() for p in params_a), fired
     n_nonzero = 0
     for pa, pb in zip(params_a, params_b):
         assert torch.isfinite(pa.grad).all()
@@ -128,6 +128,17 @@ def test_one_optimize_microstep_under_ddp_on_rccl(rccl_group):
         la = ad_a.forward(**kw_a).log_prob
         lb = ad_b.forward(**kw_b).log_prob
     assert torch.equal(la, lb)
+    # (4) the next synchronising micro-step runs on the REBUILT buckets (bucket_cap_mb = 0.05: many all-reduces, each launched on RCCL's
+    #     stream while the engine's backward is still producing the later gradients), on the updated weights; still bit-identical to the twin
+    n_before = len(fired)
+    ra, _ = microstep(ad_a)
+    rb, _ = microstep(ad_b)
+    torch.cuda.synchronize()
+    assert len(fired) - n_before >= 2, fired
+    assert sum(fired[n_before:]) == sum(p.numel() for p in params_a)
+    assert torch.equal(ra, rb) and float((ra - 1).abs().max()) > 0          # the policy moved: the ratio left 1, identically on both
+    for pa, pb in zip(params_a, params_b):
+        assert torch.equal(pa.grad, pb.grad)
     print(f"RCCL world-size-1 DDP optimize() micro-step: {len(fired)} buckets / {sum(fired)} gradient elements all-reduced on backend "
           f"{dist.get_backend()}; first ratio == 1; gradients bit-identical to the unwrapped twin; post-step log-prob {la.tolist()}")
     ad_a.engine.close()

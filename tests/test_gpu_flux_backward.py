@@ -230,6 +230,59 @@ def test_flux_replay_gradients_match_oracle_autograd_and_ratio_is_one(gpu, h, w,
     ad.engine.close()
 
 
+def test_flux_full_width_block_gradients_at_1024_token_count(gpu):
+    """BASELINE.json configs[2]'s own width and token count: FLUX.1-dev WIDTH (D = 3072, 24 heads x 128), one double-stream + one single-stream
+    block at 1024^2 (4096 image + 512 text = 4608 joint tokens), B = 1 -- the large-grid kernels (persistent GEMMs incl. the K = 7D = 21 504
+    fused dgrad and the K = 15 360 proj_out, the hand-scheduled attention with its log-sum-exp, 72 query / key tiles in the backward passes,
+    split-K weight gradients) -- the reference's default target modules, vs the oracle's autograd on the host cores and its bf16 band."""
+    from oracle import flux_ref as R
+    from mi355_flow import flux
+    from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
+    cfg_o = R.FluxConfig(num_layers=1, num_single_layers=1)
+    mod = PF.build_module_tree(R.state_dict_shapes(cfg_o), buffers=(), seed=11, std=0.02).cuda()
+    with torch.no_grad():
+        for prm in mod.parameters():
+            prm.copy_(prm.bfloat16().float())
+    for n, prm in mod.named_parameters():
+        prm.requires_grad_(any(k in n for k in DEFAULT_TARGETS))
+    sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=1, seed=42, dynamics_type="Flow-SDE", shift=3.0)
+    ad = flux.Flux1NativeAdapter(mod, flux.FluxConfig(num_layers=1, num_single_layers=1), sched, latent_storage_dtype="fp16")
+    ad.rollout()
+    try:
+        B, h, w, Nt = 1, 128, 128, 512
+        inp = _inputs(cfg_o, B, h, w, Nt, seed=17)
+        t, t_next, eta, smax, guidance = 900.0, 750.0, 0.7, 0.9, 3.5
+        ad.scheduler.set_timesteps(4)
+        ad.scheduler.sigmas = ad.scheduler.sigmas.clone()
+        ad.scheduler.sigmas[1] = smax
+        kw = dict(t=torch.full((B,), t), t_next=torch.full((B,), t_next), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+                  prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(), img_ids=inp["img_ids"].cuda(), guidance_scale=guidance,
+                  noise_level=eta, compute_log_prob=True, return_kwargs=["log_prob", "noise_pred", "dt"])
+        with torch.no_grad():
+            ref_out = ad.forward(**kw)
+        out = ad.forward(**kw)
+        assert torch.equal(out.noise_pred.detach(), ref_out.noise_pred) and torch.equal(out.log_prob.detach(), ref_out.log_prob)
+        kl_w = 3.0
+        ((inp["wlp"].cuda() * out.log_prob).sum() + kl_w * (inp["wnp"].cuda() * out.noise_pred).mean()).backward()
+        _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w)
+        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float())
+        worst, worst_name, worst_band, n = 0.0, None, 0.0, 0
+        for name, prm in mod.named_parameters():
+            if not prm.requires_grad:
+                continue
+            ref = g_ref[name]
+            r, band = _rel(prm.grad, ref), _rel(g_band[name], ref)
+            n, worst_band = n + 1, max(worst_band, band)
+            if r > worst:
+                worst, worst_name = r, name
+            assert r < 3.0 * band + 5e-3 and _cos(prm.grad, ref) > 0.995, (name, r, band)
+        print(f"FLUX.1 full-width 1 + 1 blocks at S = 4608: {n} parameter gradients vs fp32 oracle autograd, worst rel-L2 {worst:.3e} ({worst_name}); "
+              f"bf16-emulating oracle band, worst {worst_band:.3e}; stash + scratch {ad.engine.plan(B, h, w, Nt, 1).training_bytes / 2 ** 30:.2f} GiB")
+        assert n == 24 + 6
+    finally:
+        ad.engine.close()
+
+
 def test_flux_optimizer_step_moves_the_policy_and_the_next_backward_works(gpu):
     ad, mod, cfg_o = _build(lambda n: any(k in n for k in DEFAULT_TARGETS), seed=9)
     B, h, w, Nt = 2, 8, 8, 16
