@@ -763,7 +763,10 @@ hipError_t launch_rms_dw_finish(const float* part, int nwg, float q_scale, float
 }
 
 hipError_t launch_colsum(const bf16_t* dy, long ld, long M, int N, float* scratch, float* out, int accumulate, hipStream_t st) {
-    if (sched_trace_on()) sched_trace_launch("colsum", st, {treg(dy, ((size_t)(M - 1) * ld + N) * 2)}, {treg(scratch, (size_t)64 * N * 4), treg(out, (size_t)N * 4)});
+    if (M <= 0 || N <= 0 || !scratch || !out) return hipErrorInvalidValue;
+    if (sched_trace_on())       // accumulate: `out` is read as well (a read-after-write dependency the happens-before checker must see)
+        sched_trace_launch("colsum", st, {treg(dy, ((size_t)(M - 1) * ld + N) * 2), treg(out, accumulate ? (size_t)N * 4 : 0)},
+                           {treg(scratch, (size_t)64 * N * 4), treg(out, (size_t)N * 4)});
     const int nslab = (int)(M >= 8192 ? 64 : (M + 127) / 128);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, nslab), dim3(256), 0, st, dy, ld, M, N, scratch, nslab);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 31) / 32), dim3(256), 0, st, scratch, nslab, N, out, accumulate);
@@ -771,7 +774,9 @@ hipError_t launch_colsum(const bf16_t* dy, long ld, long M, int N, float* scratc
 }
 
 hipError_t launch_splitk_reduce(const float* part, long stride, int nsplit, float* out, long n, int accumulate, hipStream_t st) {
-    if (sched_trace_on()) sched_trace_launch("splitk_reduce", st, {treg(part, ((size_t)(nsplit - 1) * stride + n) * 4)}, {treg(out, (size_t)n * 4)});
+    if (nsplit <= 0 || n <= 0 || !part || !out) return hipErrorInvalidValue;
+    if (sched_trace_on())
+        sched_trace_launch("splitk_reduce", st, {treg(part, ((size_t)(nsplit - 1) * stride + n) * 4), treg(out, accumulate ? (size_t)n * 4 : 0)}, {treg(out, (size_t)n * 4)});
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, part, stride, nsplit, out, n, accumulate);
     return hipGetLastError();
 }

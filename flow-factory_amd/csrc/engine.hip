@@ -355,7 +355,7 @@ struct mi355_plan {
     hipStream_t cap_stream = nullptr;   // capture happens on a plan-owned stream: the caller's may be the legacy default stream (torch's
                                         // current stream unless the user switched), which cannot be captured; the graph is LAUNCHED on the caller's
     bool warmed = false;
-    int g_steps = -1, g_dyn = -1, g_storage = -1, g_init = -1, g_clp = -1, g_attn = -1, g_gemm = -1, g_bounds = -1, g_two = -1;
+    int g_steps = -1, g_dyn = -1, g_storage = -1, g_init = -1, g_clp = -1, g_attn = -1, g_gemm = -1, g_bounds = -1, g_two = -1, g_tune = -1;
     // text-stream chain of a forward on a second stream (forward_core): plan-owned, created on first use
     hipStream_t side = nullptr, side_v = nullptr;   // side_v: the image stream's V^T (and dual-attention q|k / V^T) projections
     std::vector<hipEvent_t> ev_vfork, ev_vjoin, ev_djoin;   // per block: xn ready (main -> side_v), V^T ready, dual q|k|V^T ready (side_v -> main)
@@ -934,7 +934,7 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
     if (g_use_graph && !g_prof.on && p->warmed) {
         const bool same = p->gexec && p->g_steps == n_steps && p->g_dyn == dynamics && p->g_storage == storage_dtype &&
                           p->g_init == init_dtype && p->g_clp == clp && p->g_guidance == guidance && p->g_sigma_max == sigma_max &&
-                          p->g_attn == get_attn_variant() && p->g_gemm == get_gemm_variant() &&
+                          p->g_attn == get_attn_variant() && p->g_gemm == get_gemm_variant() && p->g_tune == tune_epoch() &&
                           p->g_bounds == p->e->bounds_ver * 2 + (g_attn_static != 0) && p->g_two == (int)two_stream_wanted(p) * (1 + (int)late_fork_wanted(p) + 2 * (int)three_stream_wanted(p));
         if (!same) {
             if (two_stream_wanted(p)) CHK(two_stream_init(p));   // streams / events are created outside the capture
@@ -959,7 +959,7 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
             }
             if (p->gexec) {
                 p->g_steps = n_steps; p->g_dyn = dynamics; p->g_storage = storage_dtype; p->g_init = init_dtype; p->g_clp = clp;
-                p->g_guidance = guidance; p->g_sigma_max = sigma_max; p->g_attn = get_attn_variant(); p->g_gemm = get_gemm_variant();
+                p->g_guidance = guidance; p->g_sigma_max = sigma_max; p->g_attn = get_attn_variant(); p->g_gemm = get_gemm_variant(); p->g_tune = tune_epoch();
                 p->g_bounds = p->e->bounds_ver * 2 + (g_attn_static != 0);
                 p->g_two = (int)two_stream_wanted(p) * (1 + (int)late_fork_wanted(p) + 2 * (int)three_stream_wanted(p));
             } else {
@@ -999,7 +999,18 @@ extern "C" int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const flo
 
 // A/B knob for kernel variants (key 0: large-grid GEMM kernel, 0 = simple 2-stage, 1 = default (4-wave hand-scheduled loop up to K = key 19,
 // else ping-pong), 2 = 4-wave wherever it applies, 3 = ping-pong only)
+static int g_tune_epoch = 0;
+namespace mi355 { int tune_epoch() { return g_tune_epoch; } }
+
 extern "C" int mi355_tune_set(int key, int value) {
+    ++g_tune_epoch;
+    // keys of variants that were measured, dropped and deleted (18: hipGraph replay of the Wan loop; 11 stays; 20 / 23: never shipped):
+    // accepted as no-ops, so that an MI355_TUNE string from an older round does not make the library refuse to load
+    if (key == 18 || key == 20 || key == 23) {
+        static bool warned = false;
+        if (!warned) { fprintf(stderr, "mi355_flow: mi355_tune_set(%d, .) names a removed variant: ignored\n", key); warned = true; }
+        return 0;
+    }
     if (key == 0) { set_gemm_variant(value); return 0; }
     if (key == 1) { set_attn_variant(value); return 0; }
     if (key == 2) { g_use_graph = value; return 0; }

@@ -260,7 +260,7 @@ struct mi355_flux_plan {
     hipGraphExec_t gexec = nullptr;
     hipStream_t cap_stream = nullptr;
     bool warmed = false;
-    int g_steps = -1, g_dyn = -1, g_storage = -1, g_init = -1, g_clp = -1, g_noise = -1, g_bounds = -1, g_two = -1, g_gemm = -1, g_attn = -1;
+    int g_steps = -1, g_dyn = -1, g_storage = -1, g_init = -1, g_clp = -1, g_noise = -1, g_bounds = -1, g_two = -1, g_gemm = -1, g_attn = -1, g_tune = -1;
     float g_sigma_max = 0.f;
 };
 
@@ -702,7 +702,7 @@ extern "C" int mi355_flux_rollout(mi355_flux_plan* p, void* stream, int n_steps,
         const int two = (int)flux_two_stream_wanted(p);
         const bool same = p->gexec && p->g_steps == n_steps && p->g_dyn == dynamics && p->g_storage == storage_dtype && p->g_init == init_dtype &&
                           p->g_clp == clp && p->g_noise == (int)(step_noise != nullptr) && p->g_sigma_max == sigma_max &&
-                          p->g_bounds == p->e->bounds_ver && p->g_two == two && p->g_gemm == get_gemm_variant() && p->g_attn == get_attn128_variant();
+                          p->g_bounds == p->e->bounds_ver && p->g_two == two && p->g_gemm == get_gemm_variant() && p->g_attn == get_attn128_variant() && p->g_tune == tune_epoch();
         if (!same) {
             if (two) CHK(flux_two_stream_init(p));              // streams / events / buffers are created outside the capture
             if (p->gexec) { (void)hipGraphExecDestroy(p->gexec); p->gexec = nullptr; }
@@ -730,7 +730,7 @@ extern "C" int mi355_flux_rollout(mi355_flux_plan* p, void* stream, int n_steps,
             }
             p->g_steps = n_steps; p->g_dyn = dynamics; p->g_storage = storage_dtype; p->g_init = init_dtype; p->g_clp = clp;
             p->g_noise = (int)(step_noise != nullptr); p->g_sigma_max = sigma_max; p->g_bounds = p->e->bounds_ver; p->g_two = two;
-            p->g_gemm = get_gemm_variant(); p->g_attn = get_attn128_variant();
+            p->g_gemm = get_gemm_variant(); p->g_attn = get_attn128_variant(); p->g_tune = tune_epoch();
         }
         HIPCHK(hipGraphLaunch(p->gexec, st));
         launched = true;

@@ -264,17 +264,17 @@ __global__ __launch_bounds__(256) void cfg_rescale_kernel(const bf16_t* neg, con
 }  // namespace
 
 hipError_t launch_rms_rows(const bf16_t* x, long ldx, const float* w, bf16_t* out, long ldo, int M, int D, float eps, hipStream_t stream) {
+    if (M <= 0 || D <= 0 || (D & 1) || (ldx & 1) || (ldo & 1)) return hipErrorInvalidValue;      // (validation first: the trace's region arithmetic assumes M >= 1)
     if (sched_trace_on())
         sched_trace_launch("rms_rows", stream, {treg(x, ((size_t)(M - 1) * ldx + D) * 2), treg(w, (size_t)D * 4)}, {treg(out, ((size_t)(M - 1) * ldo + D) * 2)});
-    if (M <= 0 || D <= 0 || (D & 1) || (ldx & 1) || (ldo & 1)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(rms_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, x, ldx, w, out, ldo, M, D, eps);
     return hipGetLastError();
 }
 
 hipError_t launch_cfg_rescale(const bf16_t* neg, const bf16_t* pos, float g, bf16_t* out, long rows, int C, hipStream_t stream) {
+    if (rows <= 0 || C != 64) return hipErrorInvalidValue;
     if (sched_trace_on())
         sched_trace_launch("cfg_rescale", stream, {treg(neg, (size_t)rows * C * 2), treg(pos, (size_t)rows * C * 2)}, {treg(out, (size_t)rows * C * 2)});
-    if (rows <= 0 || C != 64) return hipErrorInvalidValue;
     hipLaunchKernelGGL(cfg_rescale_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, neg, pos, g, out, rows);
     return hipGetLastError();
 }
@@ -301,9 +301,9 @@ hipError_t launch_norm_rope_full(const NormRopeFullParams& p, hipStream_t stream
 }
 
 hipError_t launch_bcast_add(const bf16_t* a, const float* table, bf16_t* out, long out_ld, int rows, int W, int J, hipStream_t stream) {
+    if (rows <= 0 || W <= 0 || J <= 0 || (W & 1)) return hipErrorInvalidValue;
     if (sched_trace_on())
         sched_trace_launch("bcast_add", stream, {treg(a, (size_t)rows * W * 2), treg(table, (size_t)J * W * 4)}, {treg(out, ((size_t)(rows - 1) * out_ld + (size_t)J * W) * 2)});
-    if (W & 1) return hipErrorInvalidValue;
     const long n = (long)rows * J * (W / 2);
     hipLaunchKernelGGL(bcast_add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, table, out, out_ld, rows, W, J);
     return hipGetLastError();
@@ -315,13 +315,14 @@ hipError_t launch_affine_to_mod(const float* weight, const float* bias, bf16_t* 
 }
 
 hipError_t launch_rope_norm(const RopeNormParams& p, hipStream_t stream) {
+    if (p.M <= 0 || p.H <= 0 || p.rows_per_sample <= 0 || (p.src_ld & 1) || (p.q_col & 1) || (p.k_col & 1)) return hipErrorInvalidValue;
     if (sched_trace_on()) {
         const int hi = p.q_col > p.k_col ? p.q_col : p.k_col;
-        const size_t blocks = (size_t)(p.M / p.rows_per_sample) * p.H, len = (size_t)p.rows_per_sample * 256, stride = (size_t)p.S_pad * 256;
+        const size_t blocks = (size_t)((p.M + p.rows_per_sample - 1) / p.rows_per_sample) * p.H, len = (size_t)p.rows_per_sample * 256, stride = (size_t)p.S_pad * 256;
         sched_trace_launch("rope_norm", stream, {treg(p.src, ((size_t)(p.M - 1) * p.src_ld + hi + (size_t)p.H * 128) * 2), treg(p.nw_q, 512), treg(p.nw_k, 512)},
-                           {tregs(p.q_out + (size_t)p.s_off * 128, len, stride, blocks), tregs(p.k_out + (size_t)p.s_off * 128, len, stride, blocks)});
+                           {tregs(p.q_out + (size_t)p.s_off * 128, len, stride, blocks), tregs(p.k_out + (size_t)p.s_off * 128, len, stride, blocks),
+                            treg(p.rstd_out, p.rstd_out ? (size_t)p.M * 2 * p.H * 4 : 0)});
     }
-    if (p.M <= 0 || p.H <= 0 || (p.src_ld & 1) || (p.q_col & 1) || (p.k_col & 1)) return hipErrorInvalidValue;
     if (!((p.src_ld | p.q_col | p.k_col) & 7) && !(((size_t)p.src | (size_t)p.q_out | (size_t)p.k_out) & 15)) {
         hipLaunchKernelGGL(rope_norm_kernel, dim3((unsigned)((p.M + 3) / 4)), dim3(256), 0, stream, p);
         return hipGetLastError();

@@ -90,6 +90,9 @@ inline hipError_t copy_d2d(void* dst, const void* src, size_t bytes, hipStream_t
     return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
 }
 
+// bumped by every mi355_tune_set: part of the captured-graph key of every engine, so that an A/B through the knobs never replays a graph
+// captured under the previous kernel selection (engine.hip)
+int tune_epoch();
 hipError_t launch_gemm(const GemmParams& p, hipStream_t stream);
 void set_gemm_variant(int v);
 void set_w4_max_k(int k);      // largest K that the default dispatch gives to the 4-wave hand-scheduled kernel (mi355_tune_set(19, k))

@@ -213,8 +213,10 @@ def test_flux_two_stream_and_graph_replay_are_bit_identical():
 
 
 # ------------------------------------------------------------------------------------------------- engine-emitted launch lists, race check
-def _trace_of(lib, fn, reps=2):
-    """Run `fn` reps times with the library's schedule trace on (csrc/sched_trace.hip) and return the text."""
+def _trace_of(lib, fn, reps=2, tag=None):
+    """Run `fn` reps times with the library's schedule trace on (csrc/sched_trace.hip) and return the text.  With MI355_DUMP_TRACES=<dir> the
+    text is also written to <dir>/<tag>.txt: recorded launch lists are committed under tests/golden/sched_traces/ and re-checked WITHOUT a GPU
+    by tests/test_sched_recorded_traces.py."""
     import ctypes as C
     torch.cuda.synchronize()
     lib.mi355_sched_trace(1)
@@ -227,7 +229,13 @@ def _trace_of(lib, fn, reps=2):
         lib.mi355_sched_trace_read(buf, need)
     finally:
         lib.mi355_sched_trace(0)
-    return buf.value.decode()
+    text = buf.value.decode()
+    dump = os.environ.get("MI355_DUMP_TRACES")
+    if dump and tag:
+        os.makedirs(dump, exist_ok=True)
+        with open(os.path.join(dump, tag + ".txt"), "w") as f:
+            f.write(text)
+    return text
 
 
 def _assert_race_free(text, what, min_streams=2):
@@ -271,7 +279,7 @@ def test_sd3_engine_emitted_schedule_is_race_free():
         for name, keys in (("early fork", {8: 1, 10: 0, 11: 0}), ("late fork", {8: 1, 10: 1, 11: 0}), ("three streams", {8: 1, 10: 0, 11: 1})):
             for k, v in keys.items():
                 lib.mi355_tune_set(k, v)
-            text = _trace_of(lib, run)
+            text = _trace_of(lib, run, tag="sd3_forward_" + name.replace(" ", "_"))
             assert torch.equal(run(), ref), name
             _assert_race_free(text, f"SD3.5 forward, {name}", min_streams=3 if keys[11] else 2)
         lib.mi355_tune_set(8, 0)
@@ -311,7 +319,7 @@ def test_sd3_training_step_schedule_is_race_free(scope):
 
     try:
         step()
-        text = _trace_of(lib, step)
+        text = _trace_of(lib, step, tag="sd3_train_step_" + scope)
         import _sched_check as SC
         s = SC.parse(text)
         names = {o.name for o in s.ops}
@@ -354,7 +362,7 @@ def test_qwen_and_flux_engine_emitted_schedules_are_race_free():
         tm = qw.model_timestep(torch.tensor([875.0, 500.0]), torch.bfloat16)
         lib.mi355_tune_set(12, 1)
         plan = eng.plan(B, 2, h, w, Nt, 1)
-        text = _trace_of(lib, lambda: plan.transformer_forward(x, tm, emb, lens, guidance_scale=4.0, return_raw=True))
+        text = _trace_of(lib, lambda: plan.transformer_forward(x, tm, emb, lens, guidance_scale=4.0, return_raw=True), tag="qwen_forward_two_stream")
         _assert_race_free(text, "Qwen-Image forward, two streams")
         eng.close()
         # ---- FLUX.1 (double blocks on two streams, then the single blocks on the concatenated stream)
@@ -374,7 +382,7 @@ def test_qwen_and_flux_engine_emitted_schedules_are_race_free():
         gm = torch.full((B,), 3500.0) if fo.guidance_embeds else None
         lib.mi355_tune_set(14, 1)
         fplan = feng.plan(B, h, w, Nt, 1)
-        ftext = _trace_of(lib, lambda: fplan.transformer_forward(xl, tmf, gm, enc, pool))
+        ftext = _trace_of(lib, lambda: fplan.transformer_forward(xl, tmf, gm, enc, pool), tag="flux_forward_two_stream")
         _assert_race_free(ftext, "FLUX.1 forward, two streams")
         feng.close()
     finally:
