@@ -552,6 +552,22 @@ def main():
                                             "log-prob torch.equal the no-grad replay's; untimed w.r.t. `value`"}
         except Exception as e:  # noqa: BLE001
             out["optimize_step"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not flux_mode and not args.no_train_step:
+        # the same for FLUX.1 (round 4: native backward, SURVEY.md 8(f) N1 over N3): FLUX.1-dev geometry, B = 1, 1024^2 (4608 joint tokens),
+        # the reference's default FLUX.1 target modules (5.4 B trainable parameters); own process (~110 GB of HBM), recorded, never raised
+        try:
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "flux_train_bench.py"), "--batch", "1", "--size", "1024", "--iters", "2"],
+                               capture_output=True, text=True, timeout=300)
+            tb = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            out["optimize_step_flux1"] = {"ms_forward_backward": tb["ms_forward_backward"], "ms_forward_train": tb["ms_forward_train"],
+                                          "ms_forward_nograd": tb["ms_forward_nograd"], "achieved": tb["tflops_step"], "unit": "TFLOP/s",
+                                          "frac": tb["frac_of_2500"], "trainable_params": tb["trainable_params"], "ratio_is_one": tb["ratio_is_one"],
+                                          "stash_plus_scratch_GiB": tb["stash_plus_scratch_GiB"],
+                                          "note": "FLUX.1-dev geometry, B = 1, 1024^2, default target modules (flux1.py:76-84); grad-mode log-prob "
+                                                  "torch.equal the no-grad replay's; untimed w.r.t. `value`"}
+        except Exception as e:  # noqa: BLE001
+            out["optimize_step_flux1"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not flux_mode and not args.no_families:
         # BASELINE.json configs[2..4] on the driver's box: the other engines' rollouts at their own geometries, 2 denoise
         # steps each (the per-step cost does not depend on the step count), each in its own process (24 / 3 / 41 GB of weights), untimed w.r.t.

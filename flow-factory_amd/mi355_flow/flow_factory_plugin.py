@@ -94,6 +94,11 @@ class _LiveBinding:
     def _replay_on_reference(self, ref_forward, native_forward, args, kwargs):
         # the trainer filters its kwargs by THIS class's forward() signature (utils/base.py:38-63), which may carry parameters the
         # reference's forward does not know (FLUX: `height` / `width` to recover the latent grid without img_ids): drop those
+        if os.environ.get("MI355_STRICT_NATIVE") == "1":
+            # "unsupported configs must raise, never fall back".  The default keeps training possible for the trainable sets /
+            # model families without a native backward (a documented deviation: INTEGRATION.md, "Deliberate deviations"); this switch is the letter
+            raise NotImplementedError("mi355_flow: this grad-mode forward() is outside the native backward and MI355_STRICT_NATIVE=1 forbids the "
+                                      "reference autograd path")
         accepted = inspect.signature(ref_forward).parameters
         if not any(p.kind == inspect.Parameter.VAR_KEYWORD for p in accepted.values()):
             ref_kwargs = {k: v for k, v in kwargs.items() if k in accepted}

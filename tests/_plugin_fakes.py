@@ -728,6 +728,104 @@ class FluxStandinEngineModel(_StandinFamilyEngine):
     PLAN = FluxStandinPlanModel
 
 
+class FluxTrainPlanModel(FluxStandinPlanModel):
+    """+ the native training API of `mi355_flow.flux.FluxPlan` (mi355_flux_forward_train / mi355_flux_backward): the forward is the SAME
+    stand-in as the no-grad one (bit-identical velocity, like the real engine), plus a dependence on the bound weights so that an optimizer
+    step moves the policy; the backward writes d loss / d w = <dv, d v / d w> into the registered fp32 buffers."""
+
+    def _signal(self):
+        eng = self.engine
+        return sum(float(eng.bound[n].float().mean()) for n in eng.signal_names()) if eng.bound else 0.0
+
+    def transformer_forward(self, latents, t_model, guidance_model, prompt_embeds, pooled):
+        v = super().transformer_forward(latents, t_model, guidance_model, prompt_embeds, pooled)
+        return (v.float() + self._signal() * latents.float()).to(torch.bfloat16)
+
+    def rollout(self, timesteps, sigmas, noise_levels, dynamics, guidance_scale, init_latents, storage_dtype, step_noise, prompt_embeds, pooled,
+                keep_positions=None, compute_log_prob=True):
+        from oracle import flux_ref as FR
+        from oracle import standin
+        self.engine.calls.append(("rollout", dict(N=len(timesteps))))
+        if step_noise is None:
+            step_noise = torch.zeros((len(timesteps),) + tuple(init_latents.shape))
+        sig = self._signal()
+
+        def net(hidden_states=None, **kw):           # the same network as transformer_forward: stand-in + the weight-dependent term
+            return (standin.flux_transformer_call(hidden_states=hidden_states, **kw).float() + sig * hidden_states.float()).to(torch.bfloat16)
+        out = FR.rollout(None, None, prompt_embeds, pooled, guidance_scale, init_latents, step_noise, torch.tensor(timesteps, dtype=torch.float32),
+                         torch.tensor(sigmas, dtype=torch.float32), list(noise_levels),
+                         FR.prepare_img_ids(self.h // 2, self.w // 2).to(init_latents.dtype), storage_dtype, dynamics_type=dynamics,
+                         compute_log_prob=compute_log_prob, denoiser=net)
+        return _keep_rows(out, len(timesteps), keep_positions)
+
+    def forward_train(self, latents, t_model, guidance_model, prompt_embeds, pooled):
+        self.engine.calls.append(("forward_train", dict(t=float(t_model.reshape(-1)[0]))))
+        self._train_serial = getattr(self, "_train_serial", 0) + 1
+        self._stash = latents.float().clone()
+        self.engine.calls.pop()                      # (transformer_forward logs itself)
+        v = self.transformer_forward(latents, t_model, guidance_model, prompt_embeds, pooled)
+        self.engine.calls[-1] = ("forward_train", self.engine.calls[-1][1])
+        return v
+
+    def backward(self, dv):
+        eng = self.engine
+        eng.calls.append(("backward", dict(serial=self._train_serial)))
+        up = float((dv.float() * self._stash).sum())            # d v / d signal = latents; signal = sum of the means of the signal tensors
+        for name, buf in eng.grad_bufs.items():
+            buf += up / buf.numel()
+
+
+class FluxTrainEngineModel(_StandinFamilyEngine):
+    """FLUX.1 engine double WITH the native backward's host API (grad_supported / set_grad / clear_grads), scope = the block linears."""
+    PLAN = FluxTrainPlanModel
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.grad_bufs = {}
+
+    def signal_names(self):
+        return [n for n in self._names if n in self.bound and self.grad_supported(n)]
+
+    def grad_supported(self, name) -> int:
+        return 1 if (name in self._names and ".attn.to_" in name) else 0
+
+    def set_grad(self, name, t) -> None:
+        assert self.grad_supported(name) and t.dtype == torch.float32
+        self.grad_bufs[name] = t
+
+    def clear_grads(self) -> None:
+        self.grad_bufs = {}
+
+
+def oracle_sde_step_bwd(v_text, v_uncond, guidance, latents, next_latents, sigma, sigma_next, eta, sigma_max, dynamics: str, compute_log_prob,
+                        g_log_prob=None, g_noise_pred=None, g_mean=None):
+    """Signature of `mi355_flow.engine.sde_step_bwd` computed by torch autograd through the ORACLE step (`oracle.scheduler_ref.sde_step` is
+    plain differentiable torch): d loss / d v for the CPU-only plugin tests."""
+    from oracle import scheduler_ref as S
+    assert v_uncond is None
+    if torch.is_tensor(eta):
+        eta = float(eta.reshape(-1)[0])
+    with torch.enable_grad():                    # (called from inside an autograd Function's backward, where grad mode is off)
+        return _oracle_sde_step_bwd(S, v_text, latents, next_latents, sigma, sigma_next, eta, sigma_max, dynamics, compute_log_prob, g_log_prob,
+                                    g_noise_pred, g_mean)
+
+
+def _oracle_sde_step_bwd(S, v_text, latents, next_latents, sigma, sigma_next, eta, sigma_max, dynamics, compute_log_prob, g_log_prob, g_noise_pred,
+                         g_mean):
+    v = v_text.float().detach().requires_grad_(True)
+    out = S.sde_step(v, latents, torch.as_tensor(sigma, dtype=torch.float32), torch.as_tensor(sigma_next, dtype=torch.float32), float(eta),
+                     dynamics_type=dynamics, sigma_max=sigma_max, next_latents=next_latents, compute_log_prob=bool(compute_log_prob))
+    loss = v.sum() * 0.0
+    if g_log_prob is not None and out["log_prob"] is not None:
+        loss = loss + (g_log_prob.float() * out["log_prob"]).sum()
+    if g_noise_pred is not None:
+        loss = loss + (g_noise_pred.float() * out["noise_pred"]).sum()
+    if g_mean is not None:
+        loss = loss + (g_mean.float() * out["next_latents_mean"]).sum()
+    (dv,) = torch.autograd.grad(loss, v)
+    return dv
+
+
 class QwenStandinPlanModel(QwenStandinPlan):
     """Qwen-Image plan double at the MODEL level: `transformer_forward(latents, t_model, embeds, lens, guidance)` = the prediction the
     scheduler sees (norm-rescaled true CFG over the [negative | positive] halves when n_cfg == 2)."""
