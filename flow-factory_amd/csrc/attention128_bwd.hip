@@ -12,7 +12,10 @@
 //   attn128_bwd_dkv_kernel : one KEY per lane, loops over 64-query tiles (Q | dO | -L | -Delta per stage); dK^T, dV^T (8 accumulator
 //                            blocks = 128 registers) live in AGPRs for the whole loop;
 //   attn128_bwd_dq_kernel  : one QUERY per lane, loops over 64-key tiles (K | V per stage); dQ^T (4 blocks) in AGPRs.
-// One workgroup of 4 waves per CU (one wave per SIMD, the 512-register budget), 4-stage LDS-DMA rings with counted waits.
+// One workgroup of 4 waves per CU (one wave per SIMD, the 512-register budget), 4-stage LDS-DMA rings with counted waits.  With a single
+// wave per SIMD nothing hides a stall, so the loop is ordered by hand: the first products of BOTH 32-row halves are issued back to back
+// (their loop-invariant B fragments in AGPRs, the A fragments of k-step j + 1 read under k-step j's MFMAs), then each half's exp / pack
+// arithmetic runs while the matrix pipe works on the other half's products (round 4: 745 -> see profiles/r04d_* us per dK / dV launch).
 // Also here: the prep kernel (dO head-major, Delta, -L | -Delta per tile) for token-major o / dO with leading dimensions (the single-stream
 // blocks keep the attention output inside the [M][5D] concat buffer), and the backward of the q | k producer (per-head RMSNorm + RoPE,
 // flux_ops.hip rope_norm_kernel) gathered to token-major [dq_pre | dk_pre | dv] rows.
@@ -138,6 +141,20 @@ __device__ __forceinline__ void store_rows128(const f32x16 (&acc)[4], float scal
         : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [zf0] "v"(zf0), [zf1] "v"(zf1)                                                   \
         : "memory", TR_CLOBBER16)
 
+// First products of one k-step for BOTH 32-row halves: 4 MFMAs whose B operands (this lane's K / V -- or Q / dO -- fragments, loop-invariant)
+// live in AGPRs ("a"): as compiler builtins they sat in 64 VGPRs and, with both halves' S / dP accumulators live, pushed the allocator into
+// ~250 v_accvgpr moves per tile.  The compiler does not know these are MFMAs: the XDL-write -> VALU-read wait states of the LAST k-step are
+// inserted by hand (MFMA_DRAIN; 8-pass MFMA: 11 wait states, CDNA3 ISA 4.5) before the softmax arithmetic reads the accumulators.
+#define CHAIN4(S0, D0, S1, D1, FA0, FB0, FA1, FB1, BK, BV)                                                  \
+    asm volatile("s_nop 1\n\t"            /* (a VALU-written accumulator / fragment is read at once: no hazard bookkeeping by hipcc here) */ \
+                 "v_mfma_f32_32x32x16_bf16 %[s0], %[fa0], %[bk], %[s0]\n\t"                                  \
+                 "v_mfma_f32_32x32x16_bf16 %[d0], %[fb0], %[bv], %[d0]\n\t"                                  \
+                 "v_mfma_f32_32x32x16_bf16 %[s1], %[fa1], %[bk], %[s1]\n\t"                                  \
+                 "v_mfma_f32_32x32x16_bf16 %[d1], %[fb1], %[bv], %[d1]\n\t"                                  \
+                 : [s0] "+v"(S0), [d0] "+v"(D0), [s1] "+v"(S1), [d1] "+v"(D1)                                \
+                 : [fa0] "v"(FA0), [fb0] "v"(FB0), [fa1] "v"(FA1), [fb1] "v"(FB1), [bk] "a"(BK), [bv] "a"(BV))
+#define MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 3" ::: "memory")
+
 // ---- pass 1: dK, dV.  LDS stage: Q [2 subs][64 q][64 d] | dO [2 subs][64 q][64 d] | -L[64] | -Delta[64]; ring of 4 (130 KiB)
 constexpr int ST1 = 2 * TILE + 512;
 constexpr int NST1 = 4;
@@ -210,46 +227,63 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dkv_kernel(AttnBwd
         const char* sb = smem + (t & (NST1 - 1)) * ST1;
         const unsigned stg = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + (t & (NST1 - 1)) * ST1);
         const unsigned sLa = stg + 2 * TILE + 32 * lg;
+        const int q_lim = p.S - t * TB;
+        // Both 32-query halves' first products are issued back to back (4 independent accumulation chains, 32 MFMAs), THEN each half's
+        // softmax arithmetic + second products: with one wave per SIMD nothing else hides the VALU phase -- half 0's exp / pack work now runs
+        // while the matrix pipe still executes half 1's chains, half 1's while it executes half 0's second products.
+        f32x16 s[2], dp[2];
+        {   // -L / -Delta of the tile's queries as the chains' C operands (inline assembly: see attention_bwd.hip)
+            f32x4 a[4], b[4];
+            asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:64\n\tds_read_b128 %3, %8 offset:80\n\t"
+                         "ds_read_b128 %4, %8 offset:256\n\tds_read_b128 %5, %8 offset:272\n\tds_read_b128 %6, %8 offset:320\n\t"
+                         "ds_read_b128 %7, %8 offset:336\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]) : "v"(sLa) : "memory");
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            f32x16 s, dp;
-            {   // -L / -Delta of the half tile's queries as the chains' C operands (inline assembly: see attention_bwd.hip)
-                f32x4 a[4], b[4];
-                if (qb == 0) {
-                    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:64\n\tds_read_b128 %3, %8 offset:80\n\t"
-                                 "ds_read_b128 %4, %8 offset:256\n\tds_read_b128 %5, %8 offset:272\n\tds_read_b128 %6, %8 offset:320\n\t"
-                                 "ds_read_b128 %7, %8 offset:336\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]) : "v"(sLa) : "memory");
-                } else {
-                    asm volatile("ds_read_b128 %0, %8 offset:128\n\tds_read_b128 %1, %8 offset:144\n\tds_read_b128 %2, %8 offset:192\n\tds_read_b128 %3, %8 offset:208\n\t"
-                                 "ds_read_b128 %4, %8 offset:384\n\tds_read_b128 %5, %8 offset:400\n\tds_read_b128 %6, %8 offset:448\n\t"
-                                 "ds_read_b128 %7, %8 offset:464\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]) : "v"(sLa) : "memory");
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[0][4 * j + e] = a[j][e]; dp[0][4 * j + e] = b[j][e]; }
+            asm volatile("ds_read_b128 %0, %8 offset:128\n\tds_read_b128 %1, %8 offset:144\n\tds_read_b128 %2, %8 offset:192\n\tds_read_b128 %3, %8 offset:208\n\t"
+                         "ds_read_b128 %4, %8 offset:384\n\tds_read_b128 %5, %8 offset:400\n\tds_read_b128 %6, %8 offset:448\n\t"
+                         "ds_read_b128 %7, %8 offset:464\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]) : "v"(sLa) : "memory");
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { s[1][4 * j + e] = a[j][e]; dp[1][4 * j + e] = b[j][e]; }
+        }
+        {   // 8 k-steps x (2 halves x {S, dP}) = 32 MFMAs; the 4 A fragments of step j + 1 are read while step j's MFMAs run (hipcc puts a
+            // full lgkmcnt(0) between a read and the MFMA that consumes it when nothing else is in flight: one LDS latency per MFMA)
+            bf16x8 fq[2][2], fo[2][2];
+            auto rd = [&](int j, int buf) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const int off = (j >> 2) * SUB + offR[j & 3] + qb * 4096;
+                    fq[buf][qb] = *(const bf16x8*)(sb + off);
+                    fo[buf][qb] = *(const bf16x8*)(sb + TILE + off);
                 }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { s[4 * j + e] = a[j][e]; dp[4 * j + e] = b[j][e]; }
-            }
+            };
+            rd(0, 0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int off = (j >> 2) * SUB + offR[j & 3] + qb * 4096;
-                const bf16x8 qa = *(const bf16x8*)(sb + off);
-                const bf16x8 oa = *(const bf16x8*)(sb + TILE + off);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[j], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[j], dp, 0, 0, 0);
+                if (j + 1 < 8) rd(j + 1, (j + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                CHAIN4(s[0], dp[0], s[1], dp[1], fq[j & 1][0], fo[j & 1][0], fq[j & 1][1], fo[j & 1][1], kf[j], vf[j]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            MFMA_DRAIN();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
             unsigned pk[8], zk[8];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
-                if (t == nt - 1) {
-                    const int ql = 32 * qb + 16 * (r >> 3) + 8 * lg + (r & 7);
-                    if (t * TB + ql >= p.S) p0 = 0.f;
-                    if (t * TB + ql + 1 >= p.S) p1 = 0.f;
-                }
+                float p0 = __builtin_amdgcn_exp2f(s[qb][r]), p1 = __builtin_amdgcn_exp2f(s[qb][r + 1]);
+                const int ql = 32 * qb + 16 * (r >> 3) + 8 * lg + (r & 7);      // branch-free tail mask: q_lim = valid queries of this tile (64 except the last)
+                p0 = ql < q_lim ? p0 : 0.f;
+                p1 = ql + 1 < q_lim ? p1 : 0.f;
                 pk[r >> 1] = pack_bf16(p0, p1);
-                zk[r >> 1] = pack_bf16(p0 * dp[r], p1 * dp[r + 1]);
+                zk[r >> 1] = pack_bf16(p0 * dp[qb][r], p1 * dp[qb][r + 1]);
             }
             {
                 const bf16x8 pf0 = frag4(pk[0], pk[1], pk[2], pk[3]), pf1 = frag4(pk[4], pk[5], pk[6], pk[7]);
@@ -341,27 +375,40 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dq_kernel(AttnBwdP
         if (t + 3 < nt) stage(t + 3, (t + 3) % NST2);
         const char* sb = smem + (t % NST2) * ST2;
         const unsigned stg = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + (t % NST2) * ST2);
+        const int k_lim = p.S - t * TB;
+        f32x16 s[2], dp[2];          // both 32-key halves' chains first (see the dK / dV pass)
+        {   // fragments of k-step j + 1 are read while step j's MFMAs run (see the dK / dV pass)
+            bf16x8 fk[2][2], fv[2][2];
+            auto rd = [&](int j, int buf) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            f32x16 s, dp;
+                for (int kb = 0; kb < 2; ++kb) {
+                    const int off = (j >> 2) * SUB + offR[j & 3] + kb * 4096;
+                    fk[buf][kb] = *(const bf16x8*)(sb + off);
+                    fv[buf][kb] = *(const bf16x8*)(sb + TILE + off);
+                }
+            };
+            rd(0, 0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int off = (j >> 2) * SUB + offR[j & 3] + kb * 4096;
-                const bf16x8 ka = *(const bf16x8*)(sb + off);
-                const bf16x8 va = *(const bf16x8*)(sb + TILE + off);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[j], j == 0 ? nL : s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, of[j], j == 0 ? nD : dp, 0, 0, 0);
+                if (j + 1 < 8) rd(j + 1, (j + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j == 0) { s[0] = nL; s[1] = nL; dp[0] = nD; dp[1] = nD; }      // -L / -Delta of this lane's query: the chains' C operands
+                CHAIN4(s[0], dp[0], s[1], dp[1], fk[j & 1][0], fv[j & 1][0], fk[j & 1][1], fv[j & 1][1], qf[j], of[j]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+            MFMA_DRAIN();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
             unsigned zk[8];
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
-                if (t == nt - 1) {
-                    const int kl = t * TB + 32 * kb + 16 * (r >> 3) + 8 * lg + (r & 7);
-                    if (kl >= p.S) p0 = 0.f;
-                    if (kl + 1 >= p.S) p1 = 0.f;
-                }
-                zk[r >> 1] = pack_bf16(p0 * dp[r], p1 * dp[r + 1]);
+                float p0 = __builtin_amdgcn_exp2f(s[kb][r]), p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
+                const int kl = 32 * kb + 16 * (r >> 3) + 8 * lg + (r & 7);      // branch-free tail mask
+                p0 = kl < k_lim ? p0 : 0.f;
+                p1 = kl + 1 < k_lim ? p1 : 0.f;
+                zk[r >> 1] = pack_bf16(p0 * dp[kb][r], p1 * dp[kb][r + 1]);
             }
             {
                 const bf16x8 zf0 = frag4(zk[0], zk[1], zk[2], zk[3]), zf1 = frag4(zk[4], zk[5], zk[6], zk[7]);
