@@ -201,7 +201,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dkv_tr_kernel(AttnBwd
     for (int t = 0; t < nt; ++t) {
         wait_tiles_ahead(nt - 1 - t, 5);
         if (t + 3 < nt) stage(t + 3, (t + 3) & (NST1 - 1));      // its buffer held tile t - 1: every wave is past it (the barrier above)
-        const char* sb = smem + (t & (NST1 - 1)) * ST1T;
         // -L / -Delta reads as inline assembly: hipcc guards every C-level read of an LDS range that an in-flight LDS-DMA may alias with
         // `s_waitcnt vmcnt(0)` (it cannot tell the ring stages apart) -- which would drain the two tiles just put in flight
         const unsigned stg = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + (t & (NST1 - 1)) * ST1T);
@@ -352,7 +351,6 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dq_tr_kernel(AttnBwdP
     for (int t = 0; t < nt; ++t) {
         wait_tiles_ahead(nt - 1 - t, 4);
         if (t + 3 < nt) stage(t + 3, (t + 3) % NST2);
-        const char* sb = smem + (t % NST2) * ST2T;
         const unsigned stg = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + (t % NST2) * ST2T);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {

@@ -309,8 +309,8 @@ if _RefAdapter is not None:
         class Wan2T2VNativeAdapter(_LiveBinding, WanRolloutMixin, _RefWan):
             """`Wan2_T2V_Adapter` (reference models/wan/wan2_t2v.py) with the rollout on the MI355X engine: single-transformer Wan2.1, and
             two-expert Wan2.2 pipelines (`transformer` while t >= boundary_ratio * 1000, `transformer_2` below, each with its own
-            guidance scale: wan2_t2v.py:476-487) as two engines stepped per timestep.  Per-token timesteps (`expand_timesteps`, TI2V-5B)
-            are rejected.  The causal 3-D video VAE decode is native (csrc/wan_vae_engine.hip); evaluation-mode sampling (diffusers' UniPC multistep solver) stays on the
+            guidance scale: wan2_t2v.py:476-487) as two engines stepped per timestep.  Wan2.2-TI2V-5B in text-to-video use
+            (`expand_timesteps` with an all-ones mask = one timestep for every token) runs on the scalar-timestep forward.  The causal 3-D video VAE decode is native (csrc/wan_vae_engine.hip); evaluation-mode sampling (diffusers' UniPC multistep solver) stays on the
             reference path."""
 
             _sample_cls = _RefWanSample
@@ -318,8 +318,14 @@ if _RefAdapter is not None:
 
             def __init__(self, config, accelerator):
                 _RefWan.__init__(self, config, accelerator)
-                if getattr(self.pipeline.config, "expand_timesteps", False):
-                    raise ValueError("mi355_flow: per-token timesteps (expand_timesteps, Wan2.2-TI2V-5B) are not supported by the native engine")
+                # `expand_timesteps` (Wan2.2-TI2V-5B): the adapter hands the transformer one timestep PER TOKEN, `mask * t` with an all-ones mask in
+                # text-to-video use (wan2_t2v.py:498-504) -- every token carries the same t, and the model's per-token modulation then equals
+                # the scalar-timestep one (diffusers WanTransformer3DModel: `timestep.ndim == 2` only changes the broadcast shape; stated from
+                # its published design, the model body is not in tree).  The engine therefore runs its ordinary scalar-t forward; geometry
+                # (48 latent channels, 16 x 16 x 4 VAE compression) comes from the pipeline.  Image conditioning (a mask with zeros) is not on
+                # this adapter's path.
+                self.vae_scale_temporal = int(getattr(self.pipeline, "vae_scale_factor_temporal", 4))
+                self.vae_scale_spatial = int(getattr(self.pipeline, "vae_scale_factor_spatial", 8))
 
                 def wcfg(tc):
                     return WanConfig(in_channels=tc.in_channels, out_channels=tc.out_channels, num_layers=tc.num_layers,

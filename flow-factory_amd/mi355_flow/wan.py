@@ -4,7 +4,8 @@
 Kept from the reference: latents `(B, 16, T, h, w)` drawn in fp32 (`prepare_latents(dtype=float32)`), `timestep = t.expand(B)` with
 the scheduler's integer timesteps, classifier-free guidance as `u + g (c - u)` (here one forward over the batch [negative, positive]
 instead of two passes), `UniPCMultistepSDEScheduler.step` in rollout mode = the four SDE / ODE dynamics with sigma = t / 1000.
-Not covered (raise): `expand_timesteps` (Wan2.2-TI2V), `attention_kwargs`.  The causal 3-D video VAE decode is native too
+Not covered (raise): `attention_kwargs`; image-conditioned TI2V (per-token timesteps that DIFFER: the text-to-video use of Wan2.2-TI2V-5B, whose
+`expand_timesteps` mask is all ones, runs as the scalar-timestep forward).  The causal 3-D video VAE decode is native too
 (`mi355_flow.vae.WanVAEDecoder`, csrc/wan_vae_engine.hip): pass `vae_state_dict` to the standalone adapter (or a `video_decode` callable).
 """
 from __future__ import annotations
@@ -266,11 +267,14 @@ class WanRolloutMixin:
             guidance_scale_2 = None
         if guidance_scale_2 is not None and guidance_scale_2 != guidance_scale and self.engine_2 is None:
             raise ValueError("mi355_flow: guidance_scale_2 needs a two-expert (Wan2.2) adapter: no second transformer is bound")
-        if (num_frames - 1) % VAE_SCALE_TEMPORAL != 0:
-            num_frames = num_frames // VAE_SCALE_TEMPORAL * VAE_SCALE_TEMPORAL + 1
+        # (the pipeline's VAE compression: 4 x 8 x 8 for Wan2.1 / Wan2.2-A14B, 4 x 16 x 16 for the Wan2.2-TI2V-5B VAE; the plugin reads them
+        # from the pipeline, wan2_t2v.py:267-279)
+        vst, vss = int(getattr(self, "vae_scale_temporal", VAE_SCALE_TEMPORAL)), int(getattr(self, "vae_scale_spatial", VAE_SCALE_SPATIAL))
+        if (num_frames - 1) % vst != 0:
+            num_frames = num_frames // vst * vst + 1
         num_frames = max(num_frames, 1)
         ps = self.engine.cfg.patch_size
-        hm, wm = VAE_SCALE_SPATIAL * ps[1], VAE_SCALE_SPATIAL * ps[2]
+        hm, wm = vss * ps[1], vss * ps[2]
         height, width = height // hm * hm, width // wm * wm
         if prompt_embeds is None:
             enc = self.encode_prompt(prompt=prompt, negative_prompt=negative_prompt, guidance_scale=guidance_scale)
@@ -287,7 +291,7 @@ class WanRolloutMixin:
         self.scheduler.set_timesteps(N, device=device)
         timesteps = self.scheduler.timesteps
         Cl = self.engine.cfg.in_channels
-        T, h, w = (num_frames - 1) // VAE_SCALE_TEMPORAL + 1, height // VAE_SCALE_SPATIAL, width // VAE_SCALE_SPATIAL
+        T, h, w = (num_frames - 1) // vst + 1, height // vss, width // vss
         # RNG in the reference's order: prepare_latents in fp32, then one fp32 draw per step
         # (none of the step draws under ODE dynamics: the reference's ODE branch draws nothing)
         latents = randn_tensor((B, Cl, T, h, w), generator=generator, device=device, dtype=torch.float32)

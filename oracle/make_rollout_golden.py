@@ -322,6 +322,14 @@ WAN_CASES = {
     "wan22_two_expert_cps": ("CPS", 4.0, 3.0, 0.6, "bf16", 6, [0, 1, 2, 3, 4], 3, 0.8),
 }
 WAN_FRAMES, WAN_TD = 5, 96          # 5 frames -> 2 latent frames; text width
+# live-only cases (not in the committed fixture): Wan2.2-TI2V-5B in text-to-video use -- 48 latent channels, 4 x 16 x 16 VAE compression,
+# `expand_timesteps` (one timestep per token, all equal): tests/test_rollout_control_flow_pin.py compares the plugin with the reference adapter
+WAN_LIVE_CASES = {"wan22_ti2v_expand_timesteps": ("Flow-SDE", 5.0, None, None, "bf16", 5, [1, 2, 3], 2, 0.7)}
+WAN_GEOMETRY = {"wan22_ti2v_expand_timesteps": dict(z=48, spatial=16, expand=True)}
+
+
+def _wan_case(case):
+    return ({**WAN_CASES, **WAN_LIVE_CASES}[case] if isinstance(case, str) else case)
 
 
 def build_wan(case, adapter_base=None):
@@ -337,7 +345,8 @@ def build_wan(case, adapter_base=None):
     from flow_factory.models.wan.wan2_t2v import Wan2_T2V_Adapter
     from flow_factory.utils.trajectory_collector import compute_trajectory_indices
     from oracle import diffusers_stub as D
-    dyn, gs, gs2, ratio, storage, N, sde_steps, n_sde, eta = WAN_CASES[case] if isinstance(case, str) else case
+    dyn, gs, gs2, ratio, storage, N, sde_steps, n_sde, eta = _wan_case(case)
+    geo = WAN_GEOMETRY.get(case if isinstance(case, str) else "", dict(z=16, spatial=8, expand=False))
     cfg = Arguments.load_from_yaml(os.path.join(ref_package.REF_ROOT, "examples/grpo/full/wan21/t2v.yaml"))
     cfg.training_args.latent_storage_dtype = storage
     sa = cfg.scheduler_args
@@ -345,7 +354,7 @@ def build_wan(case, adapter_base=None):
 
     def transformer(expert):
         tr = F.build_module_tree({"blocks.0.attn1.to_q.weight": (8, 8), "blocks.0.attn1.to_q.bias": (8,)}, buffers=(), cls=F.FakeTransformer).bfloat16()
-        tr.config = types.SimpleNamespace(in_channels=16, out_channels=16, patch_size=(1, 2, 2), num_layers=1, num_attention_heads=1,
+        tr.config = types.SimpleNamespace(in_channels=geo["z"], out_channels=geo["z"], patch_size=(1, 2, 2), num_layers=1, num_attention_heads=1,
                                           attention_head_dim=128, ffn_dim=64, text_dim=WAN_TD, freq_dim=256, eps=1e-6)
         tr.forward = lambda hidden_states=None, timestep=None, encoder_hidden_states=None, attention_kwargs=None, return_dict=False: (
             standin.wan_denoiser(hidden_states, timestep, encoder_hidden_states, expert),)
@@ -355,16 +364,17 @@ def build_wan(case, adapter_base=None):
     def pipeline():
         vae = nn.Module()
         vae.add_module("decoder", nn.Linear(2, 2))
-        vae.config = types.SimpleNamespace(z_dim=16, base_dim=96, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_downsample=(False, True, True),
-                                           latents_mean=[0.0] * 16, latents_std=[1.0] * 16)
+        Z, SP = geo["z"], geo["spatial"]
+        vae.config = types.SimpleNamespace(z_dim=Z, base_dim=96, dim_mult=(1, 2, 4, 4), num_res_blocks=2, temperal_downsample=(False, True, True),
+                                           latents_mean=[0.0] * Z, latents_std=[1.0] * Z)
         vae.dtype = torch.float32
-        vae.decode = lambda lat, return_dict=False: (torch.zeros(lat.shape[0], 3, 1 + 4 * (lat.shape[2] - 1), lat.shape[3] * 8, lat.shape[4] * 8),)
+        vae.decode = lambda lat, return_dict=False: (torch.zeros(lat.shape[0], 3, 1 + 4 * (lat.shape[2] - 1), lat.shape[3] * SP, lat.shape[4] * SP),)
         pipe = types.SimpleNamespace()
         pipe.transformer, pipe.vae = transformer(0), vae
         pipe.transformer_2 = transformer(1) if ratio is not None else None
         pipe.text_encoder, pipe.tokenizer = nn.Linear(2, 2), object()
-        pipe.vae_scale_factor_temporal, pipe.vae_scale_factor_spatial = 4, 8
-        pipe.config = types.SimpleNamespace(boundary_ratio=ratio, expand_timesteps=False)
+        pipe.vae_scale_factor_temporal, pipe.vae_scale_factor_spatial = 4, SP
+        pipe.config = types.SimpleNamespace(boundary_ratio=ratio, expand_timesteps=geo["expand"])
         pipe.scheduler = D.UniPCMultistepScheduler(num_train_timesteps=1000, use_flow_sigmas=True, flow_shift=3.0)
         pipe.video_processor = types.SimpleNamespace(postprocess_video=lambda v, output_type="pt": v)
         pipe.maybe_free_model_hooks = lambda: None
@@ -374,7 +384,7 @@ def build_wan(case, adapter_base=None):
 
         def prepare_latents(batch_size, num_channels_latents, height, width, num_frames, dtype, device, generator, latents=None):
             # WanPipeline.prepare_latents: one randn of (B, 16, (F - 1) // 4 + 1, H / 8, W / 8) in the requested dtype (fp32 here)
-            shape = (batch_size, num_channels_latents, (int(num_frames) - 1) // 4 + 1, int(height) // 8, int(width) // 8)
+            shape = (batch_size, num_channels_latents, (int(num_frames) - 1) // 4 + 1, int(height) // SP, int(width) // SP)
             return D.randn_tensor(shape, generator=generator, device=device, dtype=dtype)
         pipe.prepare_latents = prepare_latents
         return pipe
@@ -392,11 +402,11 @@ def build_wan(case, adapter_base=None):
 def run_reference_wan(case, adapter_base=None, callbacks=True, explicit_generator=False, traj="train", clp=True, seed=None):
     ref_package.install()
     from flow_factory.utils.trajectory_collector import compute_trajectory_indices
-    dyn, gs, gs2, ratio, storage, N, sde_steps, n_sde, eta = WAN_CASES[case] if isinstance(case, str) else case
+    dyn, gs, gs2, ratio, storage, N, sde_steps, n_sde, eta = _wan_case(case)
     ad, N = build_wan(case, adapter_base)
     g = torch.Generator().manual_seed(41)
     pe, ne = torch.randn(B, NT, WAN_TD, generator=g).bfloat16(), torch.randn(B, NT, WAN_TD, generator=g).bfloat16()
-    seed = (4000 + sorted(WAN_CASES).index(case)) if seed is None else seed
+    seed = (4000 + sorted({**WAN_CASES, **WAN_LIVE_CASES}).index(case)) if seed is None else seed
     torch.manual_seed(seed)
     ad.scheduler.set_timesteps(N)                      # train_timesteps (the SDE-step selection) needs a schedule
     if traj == "train":

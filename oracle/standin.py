@@ -54,6 +54,9 @@ def wan_denoiser(hidden_states, timestep, encoder_hidden_states, expert: int = 0
     """The call of `Wan2_T2V_Adapter.forward` (reference models/wan/wan2_t2v.py:505-523): latents (B, 16, T, h, w) cast to the transformer's
     dtype, the scheduler's INTEGER timestep expanded to the batch, T5 embeddings.  `expert` distinguishes the two Wan2.2 transformers."""
     x = hidden_states.float()
+    if timestep.ndim == 2:        # `expand_timesteps` (Wan2.2-TI2V, wan2_t2v.py:502-504): one timestep per token -- all equal in text-to-video use
+        assert bool((timestep == timestep[:, :1]).all()), "per-token timesteps that differ are image conditioning: not on this path"
+        timestep = timestep[:, 0]
     t = timestep.float().reshape(-1, 1, 1, 1, 1) / 1000.0
     e = encoder_hidden_states.float().mean(dim=(1, 2)).reshape(-1, 1, 1, 1, 1)
     v = (0.7 * x + 0.3 * torch.roll(x, 1, dims=2)) * torch.cos(1.3 * t) + 0.8 * torch.sin(3.0 * x) * t + 4.0 * e

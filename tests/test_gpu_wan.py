@@ -53,6 +53,33 @@ def test_wan_forward_matches_oracle(wn, B, T, h, w, Nt, n_cfg):
     eng.close()
 
 
+def test_wan_forward_with_48_latent_channels_matches_oracle(wn):
+    """Wan2.2-TI2V-5B's latent geometry (48 channels: patch-embedding K = 192, proj_out N = 192) in text-to-video use, where the adapter's
+    per-token timesteps (`expand_timesteps`, reference models/wan/wan2_t2v.py:502-504) are all equal to t: the engine's scalar-timestep
+    forward (the plugin's choice, flow_factory_plugin.py) vs the oracle."""
+    import dataclasses
+    from oracle import wan_ref as R
+    cfg_o = dataclasses.replace(R.tiny_config(), in_channels=48, out_channels=48)
+    sd = {k: _bf(v) for k, v in R.make_synthetic_state_dict(cfg_o, 56).items()}
+    cfg = wn.WanConfig(in_channels=48, out_channels=48, num_layers=cfg_o.num_layers, num_attention_heads=cfg_o.num_attention_heads,
+                       ffn_dim=cfg_o.ffn_dim, text_dim=cfg_o.text_dim)
+    eng = wn.WanEngine(cfg)
+    eng.bind_state_dict({k: v.cuda() for k, v in sd.items()})
+    eng.ready()
+    B, T, h, w, Nt = 2, 3, 8, 10, 11
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, 48, T, h, w, generator=g).bfloat16()
+    pe = _bf(torch.randn(B, Nt, cfg_o.text_dim, generator=g))
+    ne = _bf(torch.randn(B, Nt, cfg_o.text_dim, generator=g))
+    t = torch.tensor([611.0])
+    got = eng.plan(B, 2, T, h, w, Nt, 1).transformer_forward(x.cuda(), t, ne.cuda(), pe.cuda()).float().cpu()
+    ref = torch.cat([R.wan_forward(sd, cfg_o, x.float(), t.expand(B), ne), R.wan_forward(sd, cfg_o, x.float(), t.expand(B), pe)])
+    assert got.shape == ref.shape == (2 * B, 48, T, h, w)
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert rel < 2e-2, rel
+    eng.close()
+
+
 @pytest.mark.parametrize("B,S,H", [(2, 100, 2), (1, 777, 12), (2, 130, 40)])
 def test_norm_rope_measures_the_largest_stored_row_norm_per_batch_and_head(wn, B, S, H):
     """`mi355_op_norm_rope_full` with `max2`: the atomic maximum, per (batch, head), of the squared norm of every row AS STORED (bf16) -- the

@@ -238,7 +238,7 @@ def test_plugin_host_path_reproduces_the_reference_adapter(name):
 
 
 @pytest.mark.parametrize("family,name", [("flux", "flux_flow_sde_fp16"), ("flux", "flux_dance_native"), ("qwen", "qwen_flow_sde_cfg_ragged"),
-                                         ("qwen", "qwen_cps_nocfg_fp16"), ("wan", "wan21_flow_sde_cfg_fp16")])
+                                         ("qwen", "qwen_cps_nocfg_fp16"), ("wan", "wan21_flow_sde_cfg_fp16"), ("wan", "wan22_ti2v_expand_timesteps")])
 @pytest.mark.parametrize("explicit_generator", [False, True], ids=["global-rng", "explicit-generator"])
 def test_family_plugin_host_paths_reproduce_the_reference_adapters(family, name, explicit_generator):
     """Same as above for `Flux1NativeAdapter`, `QwenImageNativeAdapter` and `Wan2T2VNativeAdapter` (single transformer): the reference
