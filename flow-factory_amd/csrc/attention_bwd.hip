@@ -107,20 +107,6 @@ __device__ __forceinline__ void stage_tile2(const bf16_t* src, long row_stride, 
 #define TR_RD(dst, a, off) "ds_read_b64_tr_b16 " dst ", " a " offset:" #off "\n\t"
 #define MFMA32(acc, afrag, b) "v_mfma_f32_32x32x16_bf16 " acc ", " afrag ", " b ", " acc "\n\t"
 
-// First products of one 32-row half tile (round 4): S += A . K^T and dP += A' . V^T, 4 k-steps each, as ONE inline-assembly block.  As
-// compiler builtins every MFMA sat behind its own ds_read_b128 + s_waitcnt lgkmcnt(0) (hipcc does not pipeline the fragment reads: one
-// exposed LDS latency per MFMA, 16 per tile).  Here the 8 fragments of the half are read in one batch into the registers the transposed reads
-// of the second products use later (v224-v255, free during this phase: no extra registers at 2 waves / SIMD), then 8 MFMAs issue back to
-// back.  a0..a3 = LDS byte addresses of the k-step fragments in the first operand tile, the second tile is 8192 bytes (TILE) on.
-// The compiler does not know these are MFMAs: the XDL-write -> VALU-read wait states before the exp / pack arithmetic are in the block.
-#define RD128(dst, a, off) "ds_read_b128 " dst ", " a " offset:" #off "\n\t"
-#define CHAIN_READS                                                                                                                    \
-    RD128("v[224:227]", "%[a0]", 0) RD128("v[228:231]", "%[a1]", 0) RD128("v[232:235]", "%[a2]", 0) RD128("v[236:239]", "%[a3]", 0)            \
-    RD128("v[240:243]", "%[a0]", 8192) RD128("v[244:247]", "%[a1]", 8192) RD128("v[248:251]", "%[a2]", 8192) RD128("v[252:255]", "%[a3]", 8192)
-#define CHAIN_CLOBBER "memory", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", \
-                      "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
-#define MFMA_ACC(acc, a, b, c) "v_mfma_f32_32x32x16_bf16 " acc ", " a ", " b ", " c "\n\t"
-
 __device__ __forceinline__ void wait_tiles_ahead(int ahead, int per_tile) {
     // `ahead` tiles were issued after the one about to be read, `per_tile` VM operations each (vmcnt retires in order)
     if (per_tile == 5) {
@@ -201,6 +187,7 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dkv_tr_kernel(AttnBwd
     for (int t = 0; t < nt; ++t) {
         wait_tiles_ahead(nt - 1 - t, 5);
         if (t + 3 < nt) stage(t + 3, (t + 3) & (NST1 - 1));      // its buffer held tile t - 1: every wave is past it (the barrier above)
+        const char* sb = smem + (t & (NST1 - 1)) * ST1T;
         // -L / -Delta reads as inline assembly: hipcc guards every C-level read of an LDS range that an in-flight LDS-DMA may alias with
         // `s_waitcnt vmcnt(0)` (it cannot tell the ring stages apart) -- which would drain the two tiles just put in flight
         const unsigned stg = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + (t & (NST1 - 1)) * ST1T);
@@ -226,29 +213,22 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dkv_tr_kernel(AttnBwd
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { s[4 * j + e] = a[j][e]; dp[4 * j + e] = b[j][e]; }
             }
-            {
-                const unsigned c0 = stg + qb * 4096 + offR[0], c1 = stg + qb * 4096 + offR[1], c2 = stg + qb * 4096 + offR[2], c3 = stg + qb * 4096 + offR[3];
-                asm volatile(CHAIN_READS
-                             "s_waitcnt lgkmcnt(4)\n\t"
-                             MFMA_ACC("%[s]", "v[224:227]", "%[k0]", "%[s]") MFMA_ACC("%[s]", "v[228:231]", "%[k1]", "%[s]")
-                             MFMA_ACC("%[s]", "v[232:235]", "%[k2]", "%[s]") MFMA_ACC("%[s]", "v[236:239]", "%[k3]", "%[s]")
-                             "s_waitcnt lgkmcnt(0)\n\t"
-                             MFMA_ACC("%[dp]", "v[240:243]", "%[v0]", "%[dp]") MFMA_ACC("%[dp]", "v[244:247]", "%[v1]", "%[dp]")
-                             MFMA_ACC("%[dp]", "v[248:251]", "%[v2]", "%[dp]") MFMA_ACC("%[dp]", "v[252:255]", "%[v3]", "%[dp]")
-                             "s_nop 15\n\ts_nop 3"
-                             : [s] "+v"(s), [dp] "+v"(dp)
-                             : [a0] "v"(c0), [a1] "v"(c1), [a2] "v"(c2), [a3] "v"(c3), [k0] "v"(kf[0]), [k1] "v"(kf[1]), [k2] "v"(kf[2]), [k3] "v"(kf[3]),
-                               [v0] "v"(vf[0]), [v1] "v"(vf[1]), [v2] "v"(vf[2]), [v3] "v"(vf[3])
-                             : CHAIN_CLOBBER);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 qa = *(const bf16x8*)(sb + offR[kk] + qb * 4096);
+                const bf16x8 oa = *(const bf16x8*)(sb + TILE + offR[kk] + qb * 4096);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[kk], dp, 0, 0, 0);
             }
             unsigned pk[8], zk[8];
-            const int q_lim = p.S - t * TB;          // valid queries of this tile: the tail mask without branches (64 except in the last tile)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
-                const int ql = 32 * qb + 16 * (r >> 3) + 8 * lg + (r & 7);
-                p0 = ql < q_lim ? p0 : 0.f;
-                p1 = ql + 1 < q_lim ? p1 : 0.f;
+                if (t == nt - 1) {
+                    const int ql = 32 * qb + 16 * (r >> 3) + 8 * lg + (r & 7);
+                    if (t * TB + ql >= p.S) p0 = 0.f;
+                    if (t * TB + ql + 1 >= p.S) p1 = 0.f;
+                }
                 pk[r >> 1] = pack_bf16(p0, p1);
                 zk[r >> 1] = pack_bf16(p0 * dp[r], p1 * dp[r + 1]);
             }
@@ -351,33 +331,27 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dq_tr_kernel(AttnBwdP
     for (int t = 0; t < nt; ++t) {
         wait_tiles_ahead(nt - 1 - t, 4);
         if (t + 3 < nt) stage(t + 3, (t + 3) % NST2);
+        const char* sb = smem + (t % NST2) * ST2T;
         const unsigned stg = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + (t % NST2) * ST2T);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 s, dp;
-            {
-                const unsigned c0 = stg + kb * 4096 + offR[0], c1 = stg + kb * 4096 + offR[1], c2 = stg + kb * 4096 + offR[2], c3 = stg + kb * 4096 + offR[3];
-                asm volatile(CHAIN_READS
-                             "s_waitcnt lgkmcnt(4)\n\t"
-                             MFMA_ACC("%[s]", "v[224:227]", "%[k0]", "%[cl]") MFMA_ACC("%[s]", "v[228:231]", "%[k1]", "%[s]")
-                             MFMA_ACC("%[s]", "v[232:235]", "%[k2]", "%[s]") MFMA_ACC("%[s]", "v[236:239]", "%[k3]", "%[s]")
-                             "s_waitcnt lgkmcnt(0)\n\t"
-                             MFMA_ACC("%[dp]", "v[240:243]", "%[v0]", "%[cd]") MFMA_ACC("%[dp]", "v[244:247]", "%[v1]", "%[dp]")
-                             MFMA_ACC("%[dp]", "v[248:251]", "%[v2]", "%[dp]") MFMA_ACC("%[dp]", "v[252:255]", "%[v3]", "%[dp]")
-                             "s_nop 15\n\ts_nop 3"
-                             : [s] "=&v"(s), [dp] "=&v"(dp)
-                             : [a0] "v"(c0), [a1] "v"(c1), [a2] "v"(c2), [a3] "v"(c3), [k0] "v"(qf[0]), [k1] "v"(qf[1]), [k2] "v"(qf[2]), [k3] "v"(qf[3]),
-                               [v0] "v"(of[0]), [v1] "v"(of[1]), [v2] "v"(of[2]), [v3] "v"(of[3]), [cl] "v"(nL), [cd] "v"(nD)
-                             : CHAIN_CLOBBER);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 ka = *(const bf16x8*)(sb + offR[kk] + kb * 4096);
+                const bf16x8 va = *(const bf16x8*)(sb + TILE + offR[kk] + kb * 4096);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[kk], kk == 0 ? nL : s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, of[kk], kk == 0 ? nD : dp, 0, 0, 0);
             }
             unsigned zk[8];
-            const int k_lim = p.S - t * TB;          // valid keys of this tile: the tail mask without branches
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
-                const int kl = 32 * kb + 16 * (r >> 3) + 8 * lg + (r & 7);
-                p0 = kl < k_lim ? p0 : 0.f;
-                p1 = kl + 1 < k_lim ? p1 : 0.f;
+                if (t == nt - 1) {
+                    const int kl = t * TB + 32 * kb + 16 * (r >> 3) + 8 * lg + (r & 7);
+                    if (kl >= p.S) p0 = 0.f;
+                    if (kl + 1 >= p.S) p1 = 0.f;
+                }
                 zk[r >> 1] = pack_bf16(p0 * dp[r], p1 * dp[r + 1]);
             }
             // dQ^T += K^T . dZ^T over this half tile's 32 keys: A fragments = transposed reads of the K tile, v[224:231] (hs = 0), v[232:239] (hs = 1)
