@@ -180,6 +180,10 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dkv_kernel(AttnBwd
     const float* NLg = p.nld + bh * p.S_pad * 2 + wave * 32 + (lane & 7) * 4;
     const int key = kblk * KB + wave * 32 + lk;
     const int key_ld = key < p.S ? key : p.S - 1;
+    // ragged text (Qwen-Image): keys >= kv_len[b] are masked in the forward; their P is zero here, so their dK / dV rows come out as zeros
+    int Skv = p.S;
+    if (p.kv_len) Skv = min(Skv, max(1, __builtin_amdgcn_readfirstlane(p.kv_len[bh / p.H])));
+    const bool key_ok = key < Skv;
     bf16x8 kf[8], vf[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -280,8 +284,8 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dkv_kernel(AttnBwd
             for (int r = 0; r < 16; r += 2) {
                 float p0 = __builtin_amdgcn_exp2f(s[qb][r]), p1 = __builtin_amdgcn_exp2f(s[qb][r + 1]);
                 const int ql = 32 * qb + 16 * (r >> 3) + 8 * lg + (r & 7);      // branch-free tail mask: q_lim = valid queries of this tile (64 except the last)
-                p0 = ql < q_lim ? p0 : 0.f;
-                p1 = ql + 1 < q_lim ? p1 : 0.f;
+                p0 = (ql < q_lim && key_ok) ? p0 : 0.f;
+                p1 = (ql + 1 < q_lim && key_ok) ? p1 : 0.f;
                 pk[r >> 1] = pack_bf16(p0, p1);
                 zk[r >> 1] = pack_bf16(p0 * dp[qb][r], p1 * dp[qb][r + 1]);
             }
@@ -366,7 +370,9 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dq_kernel(AttnBwdP
     f32x16 dq[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) dq[j] = (f32x16){0};
-    const int nt = (p.S + TB - 1) / TB;
+    int Skv = p.S;                   // ragged text: this sample's keys end at kv_len[b]
+    if (p.kv_len) Skv = min(Skv, max(1, __builtin_amdgcn_readfirstlane(p.kv_len[bh / p.H])));
+    const int nt = (Skv + TB - 1) / TB;
     stage(0, 0);
     if (nt > 1) stage(1, 1);
     if (nt > 2) stage(2, 2);
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dq_kernel(AttnBwdP
         if (t + 3 < nt) stage(t + 3, (t + 3) % NST2);
         const char* sb = smem + (t % NST2) * ST2;
         const unsigned stg = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + (t % NST2) * ST2);
-        const int k_lim = p.S - t * TB;
+        const int k_lim = Skv - t * TB;
         f32x16 s[2], dp[2];          // both 32-key halves' chains first (see the dK / dV pass)
         {   // fragments of k-step j + 1 are read while step j's MFMAs run (see the dK / dV pass)
             bf16x8 fk[2][2], fv[2][2];

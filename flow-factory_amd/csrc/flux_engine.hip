@@ -19,6 +19,7 @@
 
 #include "../../include/mi355_flow.h"
 #include "engine_common.h"
+#include "train_common.h"
 
 using namespace mi355;
 

@@ -261,6 +261,25 @@ __global__ __launch_bounds__(256) void cfg_rescale_kernel(const bf16_t* neg, con
     out[m * 64 + lane] = f2bf(comb * round_bf16(cn / nn));
 }
 
+
+// adjoint of cfg_rescale_kernel (the norms are differentiated through, as autograd does in the reference: qwen_image.py:579-587):
+//   s = ||pos|| / ||comb||;  dcomb = s * dout - (dout . comb) * s * comb / ||comb||^2;  dneg = (1 - g) * dcomb;
+//   dpos = g * dcomb + (dout . comb) * pos / (||pos|| * ||comb||).       dout fp32 [rows][64] -> dneg, dpos bf16.
+__global__ __launch_bounds__(256) void cfg_rescale_bwd_kernel(const bf16_t* neg, const bf16_t* pos, float g, const float* dout, bf16_t* dneg, bf16_t* dpos,
+                                                              long rows) {
+    const int lane = threadIdx.x & 63;
+    const long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= rows) return;
+    const float n = bf2f(neg[m * 64 + lane]), c = bf2f(pos[m * 64 + lane]), d = dout[m * 64 + lane];
+    const float comb = round_bf16(n + round_bf16(g * round_bf16(c - n)));
+    const float cn = sqrtf(wave_sum(c * c)), nn = sqrtf(wave_sum(comb * comb));
+    const float dot = wave_sum(d * comb);
+    const float s = cn / nn;
+    const float dcomb = s * d - dot * s * comb / (nn * nn);
+    dneg[m * 64 + lane] = f2bf((1.0f - g) * dcomb);
+    dpos[m * 64 + lane] = f2bf(g * dcomb + dot * c / (cn * nn));
+}
+
 }  // namespace
 
 hipError_t launch_rms_rows(const bf16_t* x, long ldx, const float* w, bf16_t* out, long ldo, int M, int D, float eps, hipStream_t stream) {
@@ -276,6 +295,16 @@ hipError_t launch_cfg_rescale(const bf16_t* neg, const bf16_t* pos, float g, bf1
     if (sched_trace_on())
         sched_trace_launch("cfg_rescale", stream, {treg(neg, (size_t)rows * C * 2), treg(pos, (size_t)rows * C * 2)}, {treg(out, (size_t)rows * C * 2)});
     hipLaunchKernelGGL(cfg_rescale_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, neg, pos, g, out, rows);
+    return hipGetLastError();
+}
+
+hipError_t launch_cfg_rescale_bwd(const bf16_t* neg, const bf16_t* pos, float g, const float* dout, bf16_t* dneg, bf16_t* dpos, long rows, int C,
+                                  hipStream_t stream) {
+    if (rows <= 0 || C != 64) return hipErrorInvalidValue;
+    if (sched_trace_on())
+        sched_trace_launch("cfg_rescale_bwd", stream, {treg(neg, (size_t)rows * C * 2), treg(pos, (size_t)rows * C * 2), treg(dout, (size_t)rows * C * 4)},
+                           {treg(dneg, (size_t)rows * C * 2), treg(dpos, (size_t)rows * C * 2)});
+    hipLaunchKernelGGL(cfg_rescale_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, neg, pos, g, dout, dneg, dpos, rows);
     return hipGetLastError();
 }
 

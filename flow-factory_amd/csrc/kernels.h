@@ -182,6 +182,8 @@ int norm_rope_parts(int rows_per_sample);
 // Qwen-Image: RMSNorm over whole rows (weight fp32 [D]) and the norm-rescaled true-CFG combine over C = 64 channel tokens (flux_ops.hip)
 hipError_t launch_rms_rows(const bf16_t* x, long ldx, const float* w, bf16_t* out, long ldo, int M, int D, float eps, hipStream_t stream);
 hipError_t launch_cfg_rescale(const bf16_t* neg, const bf16_t* pos, float g, bf16_t* out, long rows, int C, hipStream_t stream);
+hipError_t launch_cfg_rescale_bwd(const bf16_t* neg, const bf16_t* pos, float g, const float* dout, bf16_t* dneg, bf16_t* dpos, long rows, int C,
+                                  hipStream_t stream);
 // out[m][j*W + x] = bf16(a[m][x] + table[j][x])   (a bf16 [rows][W], table fp32 [J][W]): Wan modulation = scale_shift_table + time_proj
 hipError_t launch_bcast_add(const bf16_t* a, const float* table, bf16_t* out, long out_ld, int rows, int W, int J, hipStream_t stream);
 // LayerNorm affine (weight, bias fp32 [D]) -> the (shift, scale) row layout of ln_mod: out[0][d] = bias, out[1][d] = weight - 1
@@ -307,6 +309,8 @@ struct AttnBwdParams {
     const float* nld;                                                         // [B][H][S_pad / 64][2][64] = -lse | -delta per 64-query tile
     bf16_t* dq; bf16_t* dk; bf16_t* dv;
     int B, H, S, S_pad;
+    const int* kv_len;        // head_dim-128 kernels only: optional device [B], sample b attends to keys [0, kv_len[b]) (ragged text at the END of
+                              // the joint sequence, like Attn128Params::kv_len); dk / dv of the masked keys are written as zeros
 };
 hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream);
 // head_dim 128 (attention128_bwd.hip): the same contract with [B][H][S_pad][128] operands

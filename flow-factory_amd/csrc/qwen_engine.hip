@@ -22,6 +22,7 @@
 
 #include "../../include/mi355_flow.h"
 #include "engine_common.h"
+#include "train_common.h"
 
 using namespace mi355;
 
@@ -137,6 +138,12 @@ void mi355_qwen::layout() {
     w_proj = a16((int64_t)C * D); b_proj = a32(C); lin("proj_out", w_proj, b_proj, C, D);
 }
 
+// training-mode state (qwen_train.inc, included at the end of this file)
+struct mi355_qwen_plan;
+static void qwen_train_release(mi355_qwen_plan* p);
+static void qwen_train_release_engine(mi355_qwen* e);
+static void qwen_train_mark_dirty(mi355_qwen* e);
+
 extern "C" int mi355_qwen_create(const mi355_qwen_cfg* cfg, mi355_qwen** out) {
     if (!cfg || !out) return errorf("mi355_qwen_create: null argument");
     if (cfg->head_dim != 128) return errorf("mi355_qwen_create: head_dim must be 128 (got %d)", cfg->head_dim);
@@ -167,6 +174,7 @@ extern "C" int mi355_qwen_create(const mi355_qwen_cfg* cfg, mi355_qwen** out) {
 
 extern "C" int mi355_qwen_destroy(mi355_qwen* e) {
     if (!e) return 0;
+    qwen_train_release_engine(e);
     if (e->arena16) (void)hipFree(e->arena16);
     if (e->arena32) (void)hipFree(e->arena32);
     delete e;
@@ -189,6 +197,7 @@ extern "C" int mi355_qwen_bind_weight(mi355_qwen* e, const char* name, const voi
     if (dtype < 0 || dtype > 2) return errorf("mi355_qwen_bind_weight: bad dtype %d", dtype);
     HIPCHK(launch_convert(src, dtype, it->second.dst, it->second.dst_dt, n, (hipStream_t)stream));
     it->second.bound = true;
+    qwen_train_mark_dirty(e);          // the transposed copies the backward's dgrad GEMMs read are stale
     if (strstr(name, ".norm_")) e->bounds_dirty = true;
     return 0;
 }
@@ -327,6 +336,7 @@ extern "C" int mi355_qwen_plan_create(mi355_qwen* e, int batch, int n_cfg, int l
 
 extern "C" int mi355_qwen_plan_destroy(mi355_qwen_plan* p) {
     if (!p) return 0;
+    qwen_train_release(p);
     if (p->gexec) (void)hipGraphExecDestroy(p->gexec);
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     for (hipEvent_t ev : p->ev_join) (void)hipEventDestroy(ev);
@@ -729,3 +739,5 @@ extern "C" int mi355_op_rms_rows(void* stream, const void* x, const float* weigh
     HIPCHK(launch_rms_rows((const bf16_t*)x, dim, weight, (bf16_t*)out, dim, rows, dim, eps, (hipStream_t)stream));
     return 0;
 }
+
+#include "qwen_train.inc"

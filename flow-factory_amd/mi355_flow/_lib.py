@@ -167,6 +167,13 @@ SIGNATURES = {
     "mi355_qwen_forward": (_I, [_P, _P, _P, _I, _P, _P, C.POINTER(C.c_int32), _F, _P, _P]),
     "mi355_qwen_rollout": (_I, [_P, _P, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _I, _F, _P, _I, _I, _P, _P,
                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, _P, _P, _I]),
+    "mi355_qwen_set_grad": (_I, [_P, C.c_char_p, _P]),
+    "mi355_qwen_clear_grads": (_I, [_P]),
+    "mi355_qwen_grad_supported": (_I, [_P, C.c_char_p]),
+    "mi355_qwen_plan_training_bytes": (_L, [_P]),
+    "mi355_qwen_forward_train": (_I, [_P, _P, _P, _I, _P, _P, C.POINTER(C.c_int32), _F, _P, _P]),
+    "mi355_qwen_backward": (_I, [_P, _P, _P]),
+    "mi355_op_cfg_rescale_bwd": (_I, [_P, _P, _P, _F, _P, _P, _P, _L, _I]),
     "mi355_op_cfg_rescale": (_I, [_P, _P, _P, _F, _P, _L, _I]),
     "mi355_op_rms_rows": (_I, [_P, _P, _P, _P, _I, _I, _F]),
     "mi355_wvae_create": (_I, [C.POINTER(WvaeCfg), C.POINTER(_P)]),

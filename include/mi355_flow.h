@@ -362,6 +362,30 @@ int mi355_qwen_rollout(mi355_qwen_plan* plan, void* stream, int n_steps, const f
                        const float* noise_levels_host, int dynamics, float guidance_scale, const void* init_latents, int init_dtype,
                        int storage_dtype, const float* step_noise, const void* prompt_embeds, const int32_t* txt_lens_host,
                        const int32_t* keep_slot_host, void* out_latents, float* out_log_probs, void* out_final, int compute_log_prob);
+
+/* ---- Qwen-Image `optimize()` replay with gradients (SURVEY.md 8(f) N1 over N4) ----------------------------------------------
+ * Replaces the grad-mode `QwenImageAdapter.forward(...)` + `accelerator.backward(loss)` of the reference's trainers (src/flow_factory/
+ * trainers/grpo.py:263, :326-330; trainers/dgpo.py:352-364 -- BASELINE.json configs[4]) over models/qwen_image/qwen_image.py:476-600:
+ *   mi355_qwen_forward_train = mi355_qwen_forward (same arguments, same kernel binaries: v_out bit-identical) keeping the activations the
+ *                              backward needs in the plan's training stash (ONE per plan, overwritten by every call);
+ *   mi355_sde_step / mi355_sde_step_bwd = the scheduler step and its adjoint, as for every family;
+ *   mi355_qwen_backward      = d v_out [B][Ni][C] fp32 -> fp32 weight gradients, OVERWRITING the buffers registered with mi355_qwen_set_grad;
+ *                              with n_cfg == 2 the norm-rescaled true-CFG combine (qwen_image.py:579-587) is differentiated through, norms
+ *                              included, and both branches' forward batches are back-propagated together.
+ * Gradient scope (mi355_qwen_grad_supported == 0): weights and biases of every linear layer inside the transformer blocks --
+ * transformer_blocks.N.{attn.{to_q,to_k,to_v,to_out.0,add_q_proj,add_k_proj,add_v_proj,to_add_out},img_mlp.net.{0.proj,2},txt_mlp.net.{0.proj,2}}:
+ * a superset of the reference's Qwen-Image default target modules (models/qwen_image/qwen_image.py:81-89).  img_mod / txt_mod, norm weights,
+ * img_in / txt_in / txt_norm, the timestep MLP, norm_out and proj_out: 1 = never. */
+int mi355_qwen_set_grad(mi355_qwen* e, const char* name, float* grad);
+int mi355_qwen_clear_grads(mi355_qwen* e);
+int mi355_qwen_grad_supported(mi355_qwen* e, const char* name);
+int64_t mi355_qwen_plan_training_bytes(mi355_qwen_plan* plan);
+int mi355_qwen_forward_train(mi355_qwen_plan* plan, void* stream, const void* latents, int lat_dtype, const float* t_model,
+                             const void* prompt_embeds, const int32_t* txt_lens_host, float guidance_scale, void* v_out, void* v_raw);
+int mi355_qwen_backward(mi355_qwen_plan* plan, void* stream, const float* dv);
+/* unit-test helper: adjoint of mi355_op_cfg_rescale -- d_out fp32 [rows][64] -> d_neg, d_pos bf16 */
+int mi355_op_cfg_rescale_bwd(void* stream, const void* v_neg, const void* v_pos, float guidance_scale, const float* d_out, void* d_neg, void* d_pos,
+                             int64_t rows, int channels);
 /* operator-level (unit tests): comb = neg + g (pos - neg); out = comb * ||pos|| / ||comb|| per token of `channels` = 64 bf16 values */
 int mi355_op_cfg_rescale(void* stream, const void* v_neg, const void* v_pos, float guidance_scale, void* out, int64_t rows, int channels);
 /* RMSNorm over whole rows: x bf16 [rows][dim], weight fp32 [dim] -> out bf16 [rows][dim] */
