@@ -219,6 +219,11 @@ def denoise_replay(host, plan, call: dict):
 
 
 # --------------------------------------------------------------------------------------------- FLUX.1 (mi355_flux_forward_train / _backward)
+def _train_args(call: dict):
+    """Positional arguments of `plan.forward_train` for this step: `call["train_args"]` (Qwen-Image), else the FLUX.1 five."""
+    return call.get("train_args") or (call["latents"], call["tm"], call["gm"], call["prompt_embeds"], call["pooled"])
+
+
 class _FluxReplayFn(torch.autograd.Function):
     """(log_prob [B], noise_pred [B,Ni,C], next_latents_mean [B,Ni,C]) = step(transformer(weights)); d/d weights by the FLUX engine.
 
@@ -230,7 +235,7 @@ class _FluxReplayFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, host, plan, names, call, *weights):
         from .engine import sde_step
-        v = plan.forward_train(call["latents"], call["tm"], call["gm"], call["prompt_embeds"], call["pooled"])
+        v = plan.forward_train(*_train_args(call))
         o = sde_step(v, None, 1.0, call["latents"], call["sigma"], call["sigma_next"], call["eta"], call["sigma_max"], call["dynamics"],
                      noise=None, next_latents=call["next_latents"], compute_log_prob=call["compute_log_prob"],
                      want=("next_latents_mean", "noise_pred", "std_dev_t", "dt"))
@@ -255,7 +260,7 @@ class _FluxReplayFn(torch.autograd.Function):
             # another training forward ran on this plan since (a loss that sums several grad forwards before one backward): the stash
             # holds ITS activations -- re-run this step's forward on the kept inputs (same kernels, same weights: bit-identical stash)
             plan.recomputed_forwards = getattr(plan, "recomputed_forwards", 0) + 1
-            plan.forward_train(call["latents"], call["tm"], call["gm"], call["prompt_embeds"], call["pooled"])
+            plan.forward_train(*_train_args(call))
         if not call["compute_log_prob"]:
             g_lp = None
         dv = sde_step_bwd(ctx.v, None, 1.0, call["latents"], call["next_latents"], call["sigma"], call["sigma_next"], call["eta"],
@@ -286,3 +291,10 @@ def flux_replay(host, plan, call: dict):
     if ddp is not None:
         ddp._post_forward(out[0])
     return out
+
+
+def qwen_replay(host, plan, call: dict):
+    """The differentiable Qwen-Image replay step (mi355_qwen_forward_train / _backward: true-CFG combine included): the FLUX.1 node with
+    `call["train_args"] = (latents, t_model, embeds, lens, guidance_scale)`."""
+    assert "train_args" in call
+    return flux_replay(host, plan, call)

@@ -408,11 +408,19 @@ if _RefAdapter is not None:
                 images = decode_packed_latents(self.vae_decoder, latents, height, width, postprocess=False)
                 return self.pipeline.image_processor.postprocess(images, output_type=output_type)
 
-            @functools.wraps(QwenRolloutMixin.forward)
-            def forward(self, *args, **kwargs):
-                if torch.is_grad_enabled():          # optimize(): autograd on the reference path, values from the engine
-                    return self._replay_on_reference(_RefQwen.forward, QwenRolloutMixin.forward, args, kwargs)
-                return QwenRolloutMixin.forward(self, *args, **kwargs)
+            # `forward` is the mixin's own method: in grad mode -- optimize() of the GRPO / DGPO trainers -- it runs the engine's differentiable
+            # forward + native backward (mi355_flow.autograd.qwen_replay; true-CFG combine included) whenever that backward covers the
+            # trainable set: the reference's default Qwen-Image target modules (qwen_image.py:81-89) and every other linear layer inside
+            # the blocks, full or LoRA.  Anything else trainable arrives at this hook: autograd on the reference's torch path with the
+            # engine's values (a deliberate, documented deviation from "raise": INTEGRATION.md).
+            def _grad_fallback(self, why, kwargs):
+                if os.environ.get("MI355_STRICT_NATIVE") == "1":
+                    raise NotImplementedError(f"mi355_flow: Qwen-Image forward() with autograd is outside the native backward ({why}) and "
+                                              "MI355_STRICT_NATIVE=1 forbids the reference path")
+                if not getattr(self, "_warned_ref_grad", False):
+                    logger.warning("mi355_flow: grad-mode forward() differentiates through the reference path (%s); values stay the engine's", why)
+                    self._warned_ref_grad = True
+                return self._replay_on_reference(_RefQwen.forward, QwenRolloutMixin._forward_nograd, (), kwargs)
 
 else:
 

@@ -99,6 +99,19 @@ class QwenEngine(WeightHolder):
             self._plans[key] = p
         return p
 
+    # ---------------------------------------------------------------- weight gradients (mi355_flow/autograd.py: qwen_replay)
+    def grad_supported(self, name: str) -> int:
+        """1 = the native backward produces a gradient for this parameter (the linear layers inside the transformer blocks), 0 = it does not."""
+        return 1 if self.lib.mi355_qwen_grad_supported(self._h, name.encode()) == 0 else 0
+
+    def set_grad(self, name: str, grad: torch.Tensor) -> None:
+        if grad.dtype != torch.float32 or not grad.is_contiguous():
+            raise ValueError("mi355_flow: gradient buffers are contiguous fp32 tensors")
+        _lib.check(self.lib.mi355_qwen_set_grad(self._h, name.encode(), _ptr(grad)), f"qwen_set_grad({name})")
+
+    def clear_grads(self) -> None:
+        _lib.check(self.lib.mi355_qwen_clear_grads(self._h), "qwen_clear_grads")
+
     def close(self) -> None:
         for p in self._plans.values():
             p.close()
@@ -159,6 +172,34 @@ class QwenPlan:
         _lib.check(self.lib.mi355_qwen_forward(self._h, _stream(), _ptr(latents), dtype_code(latents.dtype), _ptr(tm), _ptr(pe), lens_c,
                                                float(guidance_scale), _ptr(out), _ptr(raw)), "qwen_forward")
         return (out, raw) if return_raw else out
+
+    # ---------------------------------------------------------------- differentiable forward (optimize() replay)
+    def forward_train(self, latents: torch.Tensor, t_model: torch.Tensor, embeds: torch.Tensor, lens: Optional[Sequence[int]] = None,
+                      guidance_scale: float = 1.0) -> torch.Tensor:
+        """mi355_qwen_forward_train: `transformer_forward` on per-block activation buffers -- the same kernel binaries, so the prediction is
+        bit-identical -- keeping what `backward` needs in the plan's training stash (ONE per plan; every call takes a serial number)."""
+        B = self.batch
+        assert latents.shape == (B, self.Ni, self.C), latents.shape
+        dev = latents.device
+        tm = t_model.to(device=dev, dtype=torch.float32).reshape(-1)
+        tm = (tm.expand(B) if tm.numel() == 1 else tm).contiguous()
+        out = torch.empty((B, self.Ni, self.C), device=dev, dtype=torch.bfloat16)
+        latents = latents.contiguous()
+        pe, lens_c = self._text(embeds, lens)
+        _lib.check(self.lib.mi355_qwen_forward_train(self._h, _stream(), _ptr(latents), dtype_code(latents.dtype), _ptr(tm), _ptr(pe), lens_c,
+                                                     float(guidance_scale), _ptr(out), None), "qwen_forward_train")
+        self._train_serial = getattr(self, "_train_serial", 0) + 1
+        return out
+
+    def backward(self, dv: torch.Tensor) -> None:
+        """mi355_qwen_backward: d loss / d v [B, Ni, C] fp32 of the LAST `forward_train` -> the buffers registered with `QwenEngine.set_grad`."""
+        dv = dv.to(torch.float32).contiguous()
+        assert dv.shape == (self.batch, self.Ni, self.C), dv.shape
+        _lib.check(self.lib.mi355_qwen_backward(self._h, _stream(), _ptr(dv)), "qwen_backward")
+
+    @property
+    def training_bytes(self) -> int:
+        return int(self.lib.mi355_qwen_plan_training_bytes(self._h))
 
     def rollout(self, timesteps: Sequence[float], sigmas: Sequence[float], noise_levels: Sequence[float], dynamics: str,
                 guidance_scale: float, init_latents: torch.Tensor, storage_dtype: torch.dtype, step_noise: Optional[torch.Tensor],
@@ -373,7 +414,6 @@ class QwenRolloutMixin:
         return all_lat, log_probs, outs
 
     # ------------------------------------------------------------------ single step / replay (qwen_image.py:476-600), no-grad
-    @torch.no_grad()
     def forward(
         self,
         t: torch.Tensor,
@@ -391,6 +431,37 @@ class QwenRolloutMixin:
         compute_log_prob: bool = True,
         return_kwargs: List[str] = ["noise_pred", "next_latents", "next_latents_mean", "std_dev_t", "dt", "log_prob"],
     ) -> SDESchedulerOutput:
+        kw = dict(t=t, latents=latents, prompt_embeds=prompt_embeds, prompt_embeds_mask=prompt_embeds_mask, img_shapes=img_shapes,
+                  negative_prompt_embeds=negative_prompt_embeds, negative_prompt_embeds_mask=negative_prompt_embeds_mask,
+                  guidance_scale=guidance_scale, t_next=t_next, next_latents=next_latents, noise_level=noise_level,
+                  attention_kwargs=attention_kwargs, compute_log_prob=compute_log_prob, return_kwargs=return_kwargs)
+        if torch.is_grad_enabled() and getattr(self, "_live_weights", None) is not None:
+            # optimize() (trainers/grpo.py:263; trainers/dgpo.py:352-364): the replay WITH autograd on the engine's differentiable forward +
+            # native backward (mi355_flow.autograd.qwen_replay) when its backward covers the trainable set
+            from . import autograd as AG
+            self._before_engine_call()
+            why = AG.unsupported_reason(self)
+            sampled = next_latents is None and ("next_latents" in return_kwargs or (compute_log_prob and "log_prob" in return_kwargs))
+            if why is None and sampled:
+                why = "a sampled next state (or its log-prob) was requested with autograd"
+            if why is None:
+                return self._forward_impl(grad=True, **kw)
+            if not why.startswith("the bound module has no trainable"):
+                return self._grad_fallback(why, kw)
+        return self._forward_nograd(**kw)
+
+    def _forward_nograd(self, **kw) -> SDESchedulerOutput:
+        with torch.no_grad():
+            return self._forward_impl(grad=False, **kw)
+
+    def _grad_fallback(self, why: str, kwargs: Dict[str, Any]):
+        """Grad-mode forward() the native backward cannot serve.  Standalone: there is no other implementation -- raise (the Flow-Factory
+        plugin overrides this with the reference's autograd path)."""
+        raise NotImplementedError(f"mi355_flow: Qwen-Image forward() with autograd is not available natively: {why}")
+
+    def _forward_impl(self, t, latents, prompt_embeds, prompt_embeds_mask, img_shapes, negative_prompt_embeds, negative_prompt_embeds_mask,
+                      guidance_scale, t_next, next_latents, noise_level, attention_kwargs, compute_log_prob, return_kwargs,
+                      grad: bool) -> SDESchedulerOutput:
         self._before_engine_call()
         self._check_attention_kwargs(attention_kwargs)
         B, Ni, _ = latents.shape
@@ -403,7 +474,9 @@ class QwenRolloutMixin:
                                                        guidance_scale, dev)
         plan = self.engine.plan(B, n_cfg, 2 * hp, 2 * wp, embeds.shape[1], 1)
         t = torch.as_tensor(t, device=dev, dtype=torch.float32).reshape(-1)
-        v = plan.transformer_forward(latents, model_timestep(t, latents.dtype), embeds, lens, guidance_scale)
+        tm = model_timestep(t, latents.dtype)
+        if not grad:
+            v = plan.transformer_forward(latents, tm, embeds, lens, guidance_scale)
         sched = self.scheduler
         if t_next is None:
             idx = [sched.index_for_timestep(x) for x in t]
@@ -418,10 +491,21 @@ class QwenRolloutMixin:
         noise = None
         if next_latents is None and dyn != "ODE":
             noise = randn_tensor(latents.shape, device=dev, dtype=torch.float32)
+        view = (-1, 1, 1)
+        if grad:
+            from . import autograd as AG
+            replay = next_latents is not None
+            clp = bool(compute_log_prob) and replay
+            call = dict(latents=latents, train_args=(latents, tm, embeds, lens, float(guidance_scale)), sigma=sigma, sigma_next=sigma_next,
+                        eta=noise_level, sigma_max=float(sched.sigmas[1]), dynamics=dyn, next_latents=next_latents if replay else latents,
+                        compute_log_prob=clp)
+            lp, npred, mean, std, dtt = AG.qwen_replay(self, plan, call)
+            res = dict(noise_pred=npred, next_latents=next_latents.float() if replay else None, next_latents_mean=mean, std_dev_t=std.view(view),
+                       dt=dtt.view(view), log_prob=lp if clp else None)
+            return self._output_cls.from_dict({k: res[k] for k in return_kwargs if k in res})
         want = tuple(k for k in return_kwargs if k in ("next_latents", "next_latents_mean", "noise_pred", "std_dev_t", "dt"))
         o = sde_step(v, None, 1.0, latents, sigma, sigma_next, noise_level, float(sched.sigmas[1]), dyn, noise=noise,
                      next_latents=next_latents, compute_log_prob=compute_log_prob, want=want)
-        view = (-1, 1, 1)
         res = dict(
             noise_pred=o.noise_pred,
             next_latents=o.next_latents if next_latents is None else next_latents.float(),
@@ -463,7 +547,7 @@ class QwenImageNativeAdapter(QwenRolloutMixin):
             from .binding import LiveWeights
             module = source
             self._live_weights = LiveWeights(self.engine, lambda: module)
-            self._live_weights.sync()
+            self._sync_weights()
         else:
             self.refresh_weights(source)
 
@@ -471,9 +555,16 @@ class QwenImageNativeAdapter(QwenRolloutMixin):
     def latent_storage_dtype(self) -> Optional[torch.dtype]:
         return _DTYPE_MAP.get(self._latent_storage) if self._latent_storage else None
 
+    def _sync_weights(self) -> int:
+        if self._live_weights is None:
+            return 0
+        n = self._live_weights.sync()
+        if n:
+            self.engine.ready()
+        return n
+
     def _before_engine_call(self) -> None:
-        if self._live_weights is not None:
-            self._live_weights.sync()
+        self._sync_weights()
 
     def refresh_weights(self, state_dict: Dict[str, torch.Tensor]) -> None:
         self.engine.bind_state_dict(state_dict)
@@ -527,3 +618,15 @@ def op_rms_rows(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6) -> tor
     out = torch.empty_like(a)
     _lib.check(lib.mi355_op_rms_rows(_stream(), _ptr(a), _ptr(w), _ptr(out), a.numel() // a.shape[-1], a.shape[-1], eps), "op_rms_rows")
     return out
+
+
+def op_cfg_rescale_bwd(v_neg: torch.Tensor, v_pos: torch.Tensor, guidance_scale: float, d_out: torch.Tensor):
+    """Adjoint of `op_cfg_rescale` (norms differentiated through): d_out fp32 (rows, 64) -> (d_neg, d_pos) bf16."""
+    lib = _lib.load()
+    a, b = _bf16c(v_neg), _bf16c(v_pos)
+    d = d_out.to(torch.float32).contiguous()
+    dn, dp = torch.empty_like(a), torch.empty_like(a)
+    rows = a.numel() // a.shape[-1]
+    _lib.check(lib.mi355_op_cfg_rescale_bwd(_stream(), _ptr(a), _ptr(b), float(guidance_scale), _ptr(d), _ptr(dn), _ptr(dp), rows, a.shape[-1]),
+               "op_cfg_rescale_bwd")
+    return dn, dp

@@ -7,33 +7,34 @@ import torch
 from mi355_flow import qwen
 
 
+def param_shape(cfg, name):
+    """Shape of the diffusers QwenImageTransformer2DModel parameter `name` at this config."""
+    D, J, C, T, hd = cfg.dim, cfg.joint_attention_dim, cfg.in_channels, cfg.time_proj_dim, cfg.attention_head_dim
+    base = name[:-5] if name.endswith(".bias") else name[:-7]
+    if "norm_q" in name or "norm_k" in name or "norm_added" in name:
+        return (hd,)
+    if name == "txt_norm.weight":
+        return (J,)
+    out_in = {"img_in": (D, C), "txt_in": (D, J), "time_text_embed.timestep_embedder.linear_1": (D, T),
+              "time_text_embed.timestep_embedder.linear_2": (D, D), "norm_out.linear": (2 * D, D), "proj_out": (C, D)}.get(base)
+    if out_in is None:
+        tail = base.split(".", 2)[2]
+        out_in = {"img_mod.1": (6 * D, D), "txt_mod.1": (6 * D, D), "img_mlp.net.0.proj": (4 * D, D), "img_mlp.net.2": (D, 4 * D),
+                  "txt_mlp.net.0.proj": (4 * D, D), "txt_mlp.net.2": (D, 4 * D)}.get(tail, (D, D))
+    return out_in if name.endswith(".weight") else (out_in[0],)
+
+
+def synthetic_tensor(cfg, name, device, g, std=0.02):
+    shape = param_shape(cfg, name)
+    t = torch.randn(shape, device=device, generator=g, dtype=torch.bfloat16) * std
+    return t + 1 if len(shape) == 1 and "norm" in name else t
+
+
 def synthetic_weights(engine, device, seed=7, std=0.02):
     """name -> bf16 tensor, drawn on the GPU tensor by tensor and bound immediately (never 2 x 41 GB alive)."""
     g = torch.Generator(device=device).manual_seed(seed)
-    lib = engine.lib
-    shapes = {}
-    D, J, C, T, hd = engine.cfg.dim, engine.cfg.joint_attention_dim, engine.cfg.in_channels, engine.cfg.time_proj_dim, engine.cfg.attention_head_dim
     for name in engine.param_names():
-        if name.endswith(".bias"):
-            base = name[:-5]
-        else:
-            base = name[:-7]
-        if "norm_q" in name or "norm_k" in name or "norm_added" in name:
-            shape = (hd,)
-        elif name == "txt_norm.weight":
-            shape = (J,)
-        else:
-            out_in = {"img_in": (D, C), "txt_in": (D, J), "time_text_embed.timestep_embedder.linear_1": (D, T),
-                      "time_text_embed.timestep_embedder.linear_2": (D, D), "norm_out.linear": (2 * D, D), "proj_out": (C, D)}.get(base)
-            if out_in is None:
-                tail = base.split(".", 2)[2]
-                out_in = {"img_mod.1": (6 * D, D), "txt_mod.1": (6 * D, D), "img_mlp.net.0.proj": (4 * D, D), "img_mlp.net.2": (D, 4 * D),
-                          "txt_mlp.net.0.proj": (4 * D, D), "txt_mlp.net.2": (D, 4 * D)}.get(tail, (D, D))
-            shape = out_in if name.endswith(".weight") else (out_in[0],)
-        t = torch.randn(shape, device=device, generator=g, dtype=torch.bfloat16) * std
-        if len(shape) == 1 and "norm" in name:
-            t = t + 1
-        engine.bind_tensor(name, t)
+        engine.bind_tensor(name, synthetic_tensor(engine.cfg, name, device, g, std))
         if len(engine._keepalive) >= 64:
             engine.finish_binding()
     engine.finish_binding()

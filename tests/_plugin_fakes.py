@@ -864,6 +864,56 @@ class QwenStandinEngineModel(_StandinFamilyEngine):
     PLAN = QwenStandinPlanModel
 
 
+class QwenTrainPlanModel(QwenStandinPlanModel):
+    """+ the native training API of `mi355_flow.qwen.QwenPlan` (mi355_qwen_forward_train / mi355_qwen_backward), single-branch (n_cfg == 1)
+    plans: the forward is the SAME stand-in as the no-grad one plus a dependence on the bound weights, so that an optimizer step moves the
+    policy; the backward writes d loss / d w = <dv, d v / d w> into the registered fp32 buffers (as `FluxTrainPlanModel`)."""
+
+    def _signal(self):
+        eng = self.engine
+        return sum(float(eng.bound[n].float().mean()) for n in eng.signal_names()) if eng.bound else 0.0
+
+    def transformer_forward(self, latents, t_model, embeds, lens=None, guidance_scale=1.0, return_raw=False):
+        assert self.n_cfg == 1
+        v = super().transformer_forward(latents, t_model, embeds, lens, guidance_scale)
+        return (v.float() + self._signal() * latents.float()).to(torch.bfloat16)
+
+    def rollout(self, timesteps, sigmas, noise_levels, dynamics, guidance_scale, init_latents, storage_dtype, step_noise, embeds, lens=None,
+                keep_positions=None, compute_log_prob=True):
+        from oracle import qwen_ref as Q
+        from oracle import standin
+        assert self.n_cfg == 1
+        self.engine.calls.append(("rollout", dict(N=len(timesteps), lens=list(lens), n_cfg=self.n_cfg)))
+        lens = [int(n) for n in lens]
+        sig = self._signal()
+
+        def net(hidden_states=None, **kw):           # the same network as transformer_forward: stand-in + the weight-dependent term
+            return (standin.qwen_transformer_call(hidden_states=hidden_states, **kw).float() + sig * hidden_states.float()).to(torch.bfloat16)
+        out = Q.rollout(None, None, embeds[:, :max(lens)], lens, None, None, guidance_scale, init_latents, step_noise,
+                        torch.tensor(timesteps, dtype=torch.float32), torch.tensor(sigmas, dtype=torch.float32), list(noise_levels), self.h // 2,
+                        self.w // 2, storage_dtype, dynamics_type=dynamics, compute_log_prob=compute_log_prob, denoiser=net)
+        return _keep_rows(out, len(timesteps), keep_positions)
+
+    def forward_train(self, latents, t_model, embeds, lens=None, guidance_scale=1.0):
+        self._train_serial = getattr(self, "_train_serial", 0) + 1
+        self._stash = latents.float().clone()
+        v = self.transformer_forward(latents, t_model, embeds, lens, guidance_scale)
+        self.engine.calls[-1] = ("forward_train", self.engine.calls[-1][1])
+        return v
+
+    def backward(self, dv):
+        eng = self.engine
+        eng.calls.append(("backward", dict(serial=self._train_serial)))
+        up = float((dv.float() * self._stash).sum())
+        for name, buf in eng.grad_bufs.items():
+            buf += up / buf.numel()
+
+
+class QwenTrainEngineModel(FluxTrainEngineModel):
+    """Qwen-Image engine double WITH the native backward's host API; scope = the attention projections (as the FLUX.1 double)."""
+    PLAN = QwenTrainPlanModel
+
+
 # --------------------------------------------------------------------------------------- a miniature `peft` for the reference's apply_lora()
 class MiniLoraConfig:
     def __init__(self, r=8, lora_alpha=16, init_lora_weights=True, target_modules=(), **unused):

@@ -1,0 +1,247 @@
+"""GPU parity of the Qwen-Image native backward (SURVEY.md 8(f) N1 over N4: mi355_qwen_forward_train / mi355_qwen_backward, the adjoint of the
+norm-rescaled true-CFG combine, ragged key lengths in the head_dim-128 flash-attention backward) against torch autograd through the CPU
+oracle (oracle/qwen_ref.py) -- fp32, and the bf16-emulating run that gives the tolerance band: rel-L2 < 3 x band + 5e-3, written below.
+Everything goes through the C ABI; the grad-mode `forward()` is the reference adapter's (models/qwen_image/qwen_image.py:476-600)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import _plugin_fakes as PF
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def _cos(a, b):
+    a, b = a.float().cpu().flatten(), b.float().cpu().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def qw():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mi355_flow import qwen
+    return qwen
+
+
+def _cfg_rescale_f32(neg, pos, g):
+    comb = neg + g * (pos - neg)
+    return comb * (torch.norm(pos, dim=-1, keepdim=True) / torch.norm(comb, dim=-1, keepdim=True))
+
+
+def test_cfg_rescale_backward_matches_autograd(qw):
+    g = torch.Generator().manual_seed(1)
+    neg = torch.randn(777, 64, generator=g).bfloat16()
+    pos = (neg.float() + 0.3 * torch.randn(777, 64, generator=g)).bfloat16()
+    d = torch.randn(777, 64, generator=g)
+    for gs in (1.5, 4.0):
+        n, c = neg.float().requires_grad_(True), pos.float().requires_grad_(True)
+        (_cfg_rescale_f32(n, c, gs) * d).sum().backward()
+        dn, dp = qw.op_cfg_rescale_bwd(neg.cuda(), pos.cuda(), gs, d.cuda())
+        # bf16 outputs of an fp32 computation on the bf16-rounded `comb`: 2^-8 relative per element + the rounding of comb
+        assert _rel(dn, n.grad) < 8e-3 and _rel(dp, c.grad) < 8e-3, (gs, _rel(dn, n.grad), _rel(dp, c.grad))
+
+
+# ------------------------------------------------------------------------------------------------- model-level gradients
+BLOCK_LINEARS = (".attn.to_q.", ".attn.to_k.", ".attn.to_v.", ".attn.to_out.0.", ".attn.add_q_proj.", ".attn.add_k_proj.", ".attn.add_v_proj.",
+                 ".attn.to_add_out.", ".img_mlp.net.0.proj.", ".img_mlp.net.2.", ".txt_mlp.net.0.proj.", ".txt_mlp.net.2.")
+# the reference's Qwen-Image default target modules (models/qwen_image/qwen_image.py:81-89; its "img_mlp.net.2.proj" names no module)
+DEFAULT_TARGETS = (".attn.to_q.", ".attn.to_k.", ".attn.to_v.", ".attn.to_out.0.", ".attn.add_q_proj.", ".attn.add_k_proj.", ".attn.add_v_proj.",
+                   ".attn.to_add_out.", ".img_mlp.net.0.proj.")
+
+
+def _build(qw, cfg_o, train_filter, seed=3, std=0.05):
+    from oracle import qwen_ref as R
+    from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
+    mod = PF.build_module_tree(R.state_dict_shapes(cfg_o), buffers=(), seed=seed, std=std).cuda()
+    with torch.no_grad():
+        for n, prm in mod.named_parameters():
+            if n.endswith("norm_q.weight") or n.endswith("norm_k.weight") or n.endswith("norm_added_q.weight") or n.endswith("norm_added_k.weight") \
+                    or n == "txt_norm.weight":
+                prm.copy_(1.0 + 0.1 * prm / std)
+            prm.copy_(prm.bfloat16().float())
+    for n, prm in mod.named_parameters():
+        prm.requires_grad_(train_filter(n))
+    cfg = qw.QwenConfig(num_layers=cfg_o.num_layers, num_attention_heads=cfg_o.num_attention_heads, joint_attention_dim=cfg_o.joint_attention_dim,
+                        scale_rope=cfg_o.scale_rope)
+    sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=1, seed=42, dynamics_type="Flow-SDE", shift=3.0)
+    ad = qw.QwenImageNativeAdapter(mod, cfg, sched, latent_storage_dtype="bf16")
+    ad.rollout()
+    return ad, mod
+
+
+def _inputs(cfg_o, B, h, w, Nt, n_cfg, ragged, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda *s: torch.randn(*s, generator=g)
+    Ni, J = (h // 2) * (w // 2), cfg_o.joint_attention_dim
+    pos_lens = [max(1, Nt - (3 * b + 2 if ragged else 0)) for b in range(B)]
+    neg_lens = [max(1, Nt - 4 - b) if ragged else Nt for b in range(B)]
+
+    def text(lens):
+        e = mk(B, Nt, J).bfloat16()
+        m = torch.zeros(B, Nt, dtype=torch.long)
+        for b, n in enumerate(lens):
+            e[b, n:] = 0
+            m[b, :n] = 1
+        return e, m
+    pe, pm = text(pos_lens)
+    ne, nm = text(neg_lens)
+    return dict(x=mk(B, Ni, 64).bfloat16(), x1=mk(B, Ni, 64).bfloat16(), pe=pe, pm=pm, ne=ne, nm=nm, pos_lens=pos_lens, neg_lens=neg_lens,
+                wlp=mk(B), wnp=mk(B, Ni, 64), hp=h // 2, wp=w // 2, n_cfg=n_cfg)
+
+
+def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=None):
+    """The same loss through the oracle network (+ the true-CFG combine) and the Flow-SDE step written in differentiable torch (CPU)."""
+    from oracle import qwen_ref as R
+    sd = {n: p_.detach().cpu().float().requires_grad_(p_.requires_grad) for n, p_ in mod.named_parameters()}
+    x, x1 = inp["x"].float(), inp["x1"].float()
+    B = x.shape[0]
+    tq = (torch.full((B,), float(t)).to(torch.bfloat16) / 1000).float()
+    pos = R.qwen_forward(sd, cfg_o, x, tq, inp["pe"].float(), inp["pos_lens"], inp["hp"], inp["wp"], quant=quant)
+    if inp["n_cfg"] == 2:
+        neg = R.qwen_forward(sd, cfg_o, x, tq, inp["ne"].float(), inp["neg_lens"], inp["hp"], inp["wp"], quant=quant)
+        v = R.cfg_rescale_bf16(neg, pos, guidance).float() if quant is not None else _cfg_rescale_f32(neg, pos, guidance)
+    else:
+        v = pos
+    sigma, sigma_n = t / 1000.0, t_next / 1000.0
+    dt = sigma_n - sigma
+    std = math.sqrt(sigma / (1 - (sigma_max if sigma == 1.0 else sigma))) * eta
+    mean = x * (1 + std ** 2 / (2 * sigma) * dt) + v * (1 + std ** 2 * (1 - sigma) / (2 * sigma)) * dt
+    sv = std * math.sqrt(-dt)
+    lp = (-((x1 - mean) ** 2) / (2 * sv ** 2) - math.log(sv) - math.log(math.sqrt(2 * math.pi))).mean(dim=(1, 2))
+    loss = (inp["wlp"] * lp).sum() + kl_w * (inp["wnp"] * v).mean()
+    loss.backward()
+    return lp.detach(), {n: s.grad for n, s in sd.items() if s.requires_grad}
+
+
+def _kw(inp, B, t, t_next, eta, guidance):
+    kw = dict(t=torch.full((B,), t), t_next=torch.full((B,), t_next), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+              prompt_embeds=inp["pe"].cuda(), prompt_embeds_mask=inp["pm"].cuda(), img_shapes=[[(1, inp["hp"], inp["wp"])]] * B,
+              guidance_scale=guidance, noise_level=eta, compute_log_prob=True, return_kwargs=["log_prob", "noise_pred", "dt"])
+    if inp["n_cfg"] == 2:
+        kw.update(negative_prompt_embeds=inp["ne"].cuda(), negative_prompt_embeds_mask=inp["nm"].cuda())
+    return kw
+
+
+def _compare(mod, g_ref, g_band, what, min_n):
+    worst, worst_name, worst_band, n, zeros = 0.0, None, 0.0, 0, 0
+    for name, prm in mod.named_parameters():
+        if not prm.requires_grad:
+            assert prm.grad is None, name
+            continue
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
+        ref = g_ref[name]
+        if ref is None or float(ref.norm()) < 1e-12:       # the last block's text out-projection / MLP feed nothing: exactly zero on both sides
+            assert float(prm.grad.float().norm()) == 0.0, name
+            zeros += 1
+            continue
+        r, band = _rel(prm.grad, ref), _rel(g_band[name], ref)
+        n, worst_band = n + 1, max(worst_band, band)
+        if r > worst:
+            worst, worst_name = r, name
+        assert r < 3.0 * band + 5e-3 and r < 8e-2 and _cos(prm.grad, ref) > 0.995, (name, r, band, _cos(prm.grad, ref))
+    print(f"{what}: {n} parameter gradients vs fp32 oracle autograd, worst rel-L2 {worst:.3e} ({worst_name}); bf16-emulating oracle band, worst "
+          f"{worst_band:.3e}; {zeros} exactly-zero gradients (last block's text tail)")
+    assert n >= min_n, n
+
+
+@pytest.mark.parametrize("h,w,Nt,B,n_cfg,ragged,scope", [(8, 8, 16, 2, 1, False, "blocks"), (8, 12, 19, 2, 2, True, "blocks"),
+                                                          (10, 6, 13, 1, 2, True, "default")])
+def test_qwen_replay_gradients_match_oracle_autograd_and_ratio_is_one(qw, h, w, Nt, B, n_cfg, ragged, scope):
+    from oracle import qwen_ref as R
+    cfg_o = R.tiny_config()
+    filt = (lambda n: any(k in n for k in BLOCK_LINEARS)) if scope == "blocks" else (lambda n: any(k in n for k in DEFAULT_TARGETS))
+    ad, mod = _build(qw, cfg_o, filt)
+    inp = _inputs(cfg_o, B, h, w, Nt, n_cfg, ragged, seed=5)
+    t, t_next, eta, smax, guidance = 900.0, 750.0, 0.7, 0.9, (4.0 if n_cfg == 2 else 1.0)
+    ad.scheduler.set_timesteps(4, mu=0.6)
+    ad.scheduler.sigmas = ad.scheduler.sigmas.clone()
+    ad.scheduler.sigmas[1] = smax
+    kw = _kw(inp, B, t, t_next, eta, guidance)
+    with torch.no_grad():
+        ref_out = ad.forward(**kw)                      # the no-grad replay (two-stream forward)
+    out = ad.forward(**kw)                              # grad mode: mi355_qwen_forward_train + the same scheduler-step kernel
+    assert out.log_prob.requires_grad and out.noise_pred.requires_grad
+    assert torch.equal(out.noise_pred.detach(), ref_out.noise_pred)      # the prediction: same kernel binaries on per-block buffers
+    assert torch.equal(out.log_prob.detach(), ref_out.log_prob)          # ratio == exp(0) == 1.0 EXACTLY in grad mode
+    kl_w = 3.0
+    ((inp["wlp"].cuda() * out.log_prob).sum() + kl_w * (inp["wnp"].cuda() * out.noise_pred).mean()).backward()
+    lp_ref, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w)
+    _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float())
+    np.testing.assert_allclose(out.log_prob.detach().cpu().numpy(), lp_ref.numpy(), rtol=2e-2)
+    _compare(mod, g_ref, g_band, f"Qwen-Image replay ({scope}, {h}x{w}, Nt {Nt}, B {B}, n_cfg {n_cfg}, ragged {ragged})", 36 if scope == "blocks" else 28)
+    ad.engine.close()
+
+
+def test_qwen_full_width_block_gradients_at_1024_token_count(qw):
+    """BASELINE.json configs[4]'s own width: Qwen-Image WIDTH (D = 3072, 24 heads x 128, text dim 3584), two blocks at 1024^2 (4096 image tokens)
+    with a ragged true-CFG text batch (forward batch 2: [negative | positive]) -- the large-grid kernels: persistent GEMMs, the hand-scheduled
+    attention with its log-sum-exp and masked keys, 66 query / key tiles in the backward passes, split-K weight gradients, the combine adjoint
+    -- the reference's default target modules, vs the oracle's autograd on the host cores and its bf16 band."""
+    from oracle import qwen_ref as R
+    cfg_o = R.QwenConfig(num_layers=2)
+    ad, mod = _build(qw, cfg_o, lambda n: any(k in n for k in DEFAULT_TARGETS), seed=11, std=0.02)
+    try:
+        B, h, w, Nt = 1, 128, 128, 96
+        inp = _inputs(cfg_o, B, h, w, Nt, 2, True, seed=17)
+        inp["pos_lens"], inp["neg_lens"] = [83], [7]
+        for key, lens in (("p", inp["pos_lens"]), ("n", inp["neg_lens"])):
+            inp[key + "e"][0, lens[0]:] = 0
+            inp[key + "m"][0] = 0
+            inp[key + "m"][0, :lens[0]] = 1
+        t, t_next, eta, smax, guidance = 900.0, 750.0, 0.7, 0.9, 4.0
+        ad.scheduler.set_timesteps(4, mu=0.6)
+        ad.scheduler.sigmas = ad.scheduler.sigmas.clone()
+        ad.scheduler.sigmas[1] = smax
+        kw = _kw(inp, B, t, t_next, eta, guidance)
+        with torch.no_grad():
+            ref_out = ad.forward(**kw)
+        out = ad.forward(**kw)
+        assert torch.equal(out.noise_pred.detach(), ref_out.noise_pred) and torch.equal(out.log_prob.detach(), ref_out.log_prob)
+        kl_w = 3.0
+        ((inp["wlp"].cuda() * out.log_prob).sum() + kl_w * (inp["wnp"].cuda() * out.noise_pred).mean()).backward()
+        _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w)
+        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float())
+        plan = next(iter(ad.engine._plans.values()))
+        _compare(mod, g_ref, g_band, f"Qwen-Image full-width 2 blocks at S = 4096 + 96, true CFG (stash + scratch {plan.training_bytes / 2 ** 30:.2f} GiB)", 30)
+    finally:
+        ad.engine.close()
+
+
+def test_qwen_optimizer_step_moves_the_policy_and_the_next_backward_works(qw):
+    from oracle import qwen_ref as R
+    cfg_o = R.tiny_config()
+    ad, mod = _build(qw, cfg_o, lambda n: any(k in n for k in DEFAULT_TARGETS), seed=9)
+    B, h, w, Nt = 2, 8, 8, 16
+    inp = _inputs(cfg_o, B, h, w, Nt, 2, True, seed=6)
+    ad.scheduler.set_timesteps(4, mu=0.6)
+    kw = _kw(inp, B, 900.0, 750.0, 0.7, 4.0)
+    kw.pop("next_latents")
+    torch.cuda.manual_seed(3)
+    with torch.no_grad():
+        o0 = ad.forward(**dict(kw, return_kwargs=["next_latents", "log_prob"]))          # a rollout step: samples x' and its log-prob
+    kw2 = dict(kw, next_latents=o0.next_latents.bfloat16(), return_kwargs=["log_prob", "dt"])
+    params = [p for p in mod.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=2e-3)
+    adv = torch.tensor([1.0, -1.0]).cuda()
+    ratios = []
+    for it in range(3):
+        out = ad.forward(**kw2)
+        ratio = torch.exp(out.log_prob - o0.log_prob)
+        ratios.append(ratio.detach().cpu())
+        loss = -(adv * ratio).mean()
+        opt.zero_grad()
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+        opt.step()
+    assert torch.equal(ratios[0], torch.ones(B))                      # before any update: the replay IS the rollout step
+    assert not torch.equal(ratios[1], torch.ones(B))                  # the update moved the policy, and the engine saw the new weights
+    assert float((adv.cpu() * (ratios[2] - 1)).sum()) > 0             # ... in the direction the advantages ask for
+    ad.engine.close()

@@ -1084,6 +1084,85 @@ def test_reference_grpo_trainer_on_the_flux_plugin_takes_the_native_backward(ref
         MF.sde_step, ME.sde_step, ME.sde_step_bwd = real
 
 
+def test_reference_grpo_trainer_on_the_qwen_plugin_takes_the_native_backward(ref):
+    """Round 4: Qwen-Image has a native backward (mi355_qwen_forward_train / mi355_qwen_backward).  With the reference's default Qwen-Image
+    target modules trainable (qwen_image.py:81-89: all inside the blocks) the plugin's grad-mode `forward()` runs `QwenPlan.forward_train` +
+    the engine's scheduler step + `QwenPlan.backward` (mi355_flow.autograd.qwen_replay) -- NEVER the torch transformer -- through the
+    reference's own, unmodified `GRPOTrainer.optimize()`: first ratio exactly 1, KL term exactly 0 before the update, the engine's gradient
+    reaches the torch parameters and the optimizer moves them.  A trainable parameter OUTSIDE the native scope raises under
+    MI355_STRICT_NATIVE=1 (and otherwise takes the documented deviation)."""
+    import mi355_flow.engine as ME
+    import mi355_flow.qwen as MQ
+    import mi355_flow.vae as MV
+    from flow_factory.trainers.grpo import GRPOTrainer
+    from oracle import make_rollout_golden as G
+    P = ref
+    M, K, Nt = 2, 2, 7
+    names = ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias", "img_in.weight"]
+
+    def make_adapter(cfg, acc):
+        tr = F.build_module_tree({n: ((8, 8) if n.endswith("weight") else (8,)) for n in names}, buffers=(), cls=F.FakeTransformer).bfloat16()
+        tcfg = MQ.QwenConfig(num_layers=1, num_attention_heads=1, joint_attention_dim=G.QJ)
+        saved = (P.QwenEngine, P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder)
+        P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = F.FakeVAEDecoder, types.SimpleNamespace(from_hf=lambda c: c), F.FakeVideoVAEDecoder
+        F.QwenTrainEngineModel.NAMES = names
+        P.QwenEngine = F.QwenTrainEngineModel
+        try:
+            class Plug(P.QwenImageNativeAdapter):
+                def load_pipeline(self):
+                    return _qwen_pipeline(tcfg, tr)
+            ad = Plug(cfg, acc)
+        finally:
+            P.QwenEngine, P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = saved
+        return ad, tr
+
+    def tweak(cfg):
+        _small(cfg.training_args, guidance_scale=1.0, kl_beta=0.05, kl_type="v-based", clip_range=(-1e-4, 1e-4), adv_clip_range=(-5.0, 5.0))
+        cfg.training_args.height = cfg.training_args.width = 64
+        cfg.training_args.resolution = (64, 64)
+    g = torch.Generator().manual_seed(3)
+    batches = [dict(prompt=[f"prompt {i}"] * K, prompt_ids=torch.full((K, 4), i), prompt_embeds=torch.randn(1, Nt, G.QJ, generator=g).bfloat16().repeat(K, 1, 1),
+                    prompt_embeds_mask=torch.ones(K, Nt, dtype=torch.long)) for i in range(M)]
+    real = (MQ.sde_step, ME.sde_step, ME.sde_step_bwd, MV.WanVAEDecoder)
+    MQ.sde_step = ME.sde_step = F.oracle_sde_step
+    ME.sde_step_bwd = F.oracle_sde_step_bwd
+    MV.WanVAEDecoder = F.FakeVideoVAEDecoder
+    try:
+        tr, ad, tr_mod, logged = _real_trainer(P, GRPOTrainer, "/root/reference/examples/grpo/full/qwen_image/default.yaml", tweak, batches, K, lr=5.0,
+                                               make_adapter=make_adapter)
+        trainable = ad.get_trainable_parameters()
+        assert len(trainable) == 2                                # to_q weight + bias: the default targets; img_in stays frozen
+        before = [p_.detach().clone() for p_ in trainable]
+        torch.manual_seed(99)
+        samples = tr.sample()
+        F.FakeTransformer.calls = 0
+        tr.compute_advantages(samples, {"r": torch.tensor([0.1, 0.9, 0.4, 0.2])}, store_to_samples=True)
+        torch.manual_seed(1234)
+        tr.optimize(samples)
+        kinds = [c[0] for c in ad.engine.calls]
+        assert "forward_train" in kinds and "backward" in kinds, kinds
+        assert F.FakeTransformer.calls == 0                       # the torch transformer was never called
+        first = logged[0][1]
+        assert first["train/ratio_min"] == 1.0 and first["train/ratio_max"] == 1.0, first
+        assert float(first["train/kl_div"]) == 0.0
+        assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable))             # the engine's gradient moved the parameters
+        assert all(torch.isfinite(torch.as_tensor(v)).all() for _, d in logged for v in d.values())
+        # ---- outside the native scope: a refusal in strict mode
+        tr_mod.get_submodule("img_in").weight.requires_grad_(True)
+        e = samples[0]
+        kw = dict(t=torch.tensor([900.0]), t_next=torch.tensor([750.0]), latents=e.all_latents[:1].clone(), next_latents=e.all_latents[1:2].clone(),
+                  prompt_embeds=batches[0]["prompt_embeds"][:1], prompt_embeds_mask=batches[0]["prompt_embeds_mask"][:1], img_shapes=[[(1, 4, 4)]],
+                  guidance_scale=1.0, noise_level=0.7, compute_log_prob=True, return_kwargs=["log_prob"])
+        os.environ["MI355_STRICT_NATIVE"] = "1"
+        try:
+            with torch.enable_grad(), pytest.raises(NotImplementedError, match="MI355_STRICT_NATIVE"):
+                ad.forward(**kw)
+        finally:
+            del os.environ["MI355_STRICT_NATIVE"]
+    finally:
+        MQ.sde_step, ME.sde_step, ME.sde_step_bwd, MV.WanVAEDecoder = real
+
+
 def _wan_pipeline(transformer):
     """Wan pseudo-pipeline (single transformer) for the trainer-level test: as oracle/make_rollout_golden.build_wan's."""
     import torch.nn as nn
