@@ -206,18 +206,20 @@ def test_qwen_module_source_is_live(qw):
               img_shapes=[[(1, hp, wp)]], guidance_scale=1.0, t_next=torch.tensor([400.0]), next_latents=x, noise_level=0.7,
               return_kwargs=["noise_pred", "log_prob"])
     ad.scheduler.set_timesteps(4, mu=0.6)
-    a = ad.forward(**kw).noise_pred
+    with torch.no_grad():                                  # (grad mode syncs once more while looking for trainable parameters)
+        a = ad.forward(**kw).noise_pred
     assert ad._live_weights.last_rebinds == 0              # second sync after the constructor's: nothing changed
     with torch.no_grad():
         for n, p in mod.named_parameters():
             if n.endswith("attn.to_q.weight"):
                 p.add_(0.05 * torch.randn(p.shape, generator=g).cuda())
-    b = ad.forward(**kw).noise_pred
+        b = ad.forward(**kw).noise_pred
     assert ad._live_weights.last_rebinds == cfg_o.num_layers and not torch.equal(a, b)
     fresh = qw.QwenImageNativeAdapter({k: v.detach().clone() for k, v in mod.state_dict().items()}, cfg, latent_storage_dtype="bf16")
     fresh.rollout()
     fresh.scheduler.set_timesteps(4, mu=0.6)
-    assert torch.equal(fresh.forward(**kw).noise_pred, b)
+    with torch.no_grad():
+        assert torch.equal(fresh.forward(**kw).noise_pred, b)
     fresh.engine.close()
     ad.engine.close()
 

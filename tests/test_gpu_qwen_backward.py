@@ -57,7 +57,7 @@ DEFAULT_TARGETS = (".attn.to_q.", ".attn.to_k.", ".attn.to_v.", ".attn.to_out.0.
                    ".attn.to_add_out.", ".img_mlp.net.0.proj.")
 
 
-def _build(qw, cfg_o, train_filter, seed=3, std=0.05):
+def _build(qw, cfg_o, train_filter, seed=3, std=0.05, norm_mean=1.0):
     from oracle import qwen_ref as R
     from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
     mod = PF.build_module_tree(R.state_dict_shapes(cfg_o), buffers=(), seed=seed, std=std).cuda()
@@ -65,7 +65,7 @@ def _build(qw, cfg_o, train_filter, seed=3, std=0.05):
         for n, prm in mod.named_parameters():
             if n.endswith("norm_q.weight") or n.endswith("norm_k.weight") or n.endswith("norm_added_q.weight") or n.endswith("norm_added_k.weight") \
                     or n == "txt_norm.weight":
-                prm.copy_(1.0 + 0.1 * prm / std)
+                prm.copy_(norm_mean * (1.0 + 0.1 * prm / std))
             prm.copy_(prm.bfloat16().float())
     for n, prm in mod.named_parameters():
         prm.requires_grad_(train_filter(n))
@@ -184,10 +184,14 @@ def test_qwen_full_width_block_gradients_at_1024_token_count(qw):
     """BASELINE.json configs[4]'s own width: Qwen-Image WIDTH (D = 3072, 24 heads x 128, text dim 3584), two blocks at 1024^2 (4096 image tokens)
     with a ragged true-CFG text batch (forward batch 2: [negative | positive]) -- the large-grid kernels: persistent GEMMs, the hand-scheduled
     attention with its log-sum-exp and masked keys, 66 query / key tiles in the backward passes, split-K weight gradients, the combine adjoint
-    -- the reference's default target modules, vs the oracle's autograd on the host cores and its bf16 band."""
+    -- the reference's default target modules, vs the oracle's autograd on the host cores and its bf16 band.
+    Conditioning: with random weights of this width and q / k norm weights around 1 the bf16-emulating oracle ITSELF sits 0.45 rel-L2 away from
+    the fp32 oracle on the first block's attention gradients (bf16 rounding amplified through two softmaxes of ~N(0, 1) logits; 6e-2 at norm
+    weights 0.5, 2.3e-2 at 0.3, 1.2e-2 at 0.02; independent of the token count) -- a band that wide tests nothing, so the norm weights here are
+    0.3 * (1 + 0.1 N(0, 1)).  Sharp attention is covered at the kernel level (tests/test_gpu_flux_backward.py, attention128 backward)."""
     from oracle import qwen_ref as R
     cfg_o = R.QwenConfig(num_layers=2)
-    ad, mod = _build(qw, cfg_o, lambda n: any(k in n for k in DEFAULT_TARGETS), seed=11, std=0.02)
+    ad, mod = _build(qw, cfg_o, lambda n: any(k in n for k in DEFAULT_TARGETS), seed=11, std=0.02, norm_mean=0.3)
     try:
         B, h, w, Nt = 1, 128, 128, 96
         inp = _inputs(cfg_o, B, h, w, Nt, 2, True, seed=17)
