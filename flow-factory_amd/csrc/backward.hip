@@ -3,6 +3,7 @@
 // Everything here is a row / tile streaming kernel: 16-byte accesses, one wave per row where a row reduction is
 // needed, fp32 arithmetic on bf16 activations / gradients.  The matrix work of the backward (dgrad / wgrad GEMMs,
 // the two flash-attention backward passes) lives in gemm.hip / attention_bwd.hip.
+#include <unordered_map>
 #include "kernels.h"
 
 namespace mi355 {
@@ -510,7 +511,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* dy, l
 // 32 columns x 8 slab lanes per workgroup: a lane sums every 8th partial (4 independent chains), the 8 lanes of a column combine in a
 // fixed order through LDS.  (One thread per column walking all partials was a chain of `nslab` dependent L2 round trips: 31 us for the
 // 128 row tiles of an 8192-row dY, 148 times per optimize() step.)
-__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* part, int nslab, int N, float* out, int accumulate) {
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* part, int nslab, int N, void* out_, int accumulate) {
     __shared__ float red[8][32];
     const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
     const int n = blockIdx.x * 32 + c;
@@ -531,16 +533,54 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* part, i
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k][c];
-        out[n] = accumulate ? out[n] + t : t;
+        if (OUT_BF16) {
+            bf16_t* out = (bf16_t*)out_;
+            out[n] = f2bf(accumulate ? bf2f(out[n]) + t : t);
+        } else {
+            float* out = (float*)out_;
+            out[n] = accumulate ? out[n] + t : t;
+        }
     }
 }
 
-// split-K second stage: out[i] (+)= sum_s part[s][i], fixed order
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, long stride, int nsplit, float* out, long n, int accumulate) {
+// split-K second stage: out[i] (+)= sum_s part[s][i], fixed order; 4 elements per thread and access (n % 4 == 0, 16-byte aligned parts) or
+// one.  OUT_BF16: the sum is rounded to bf16 on the way out (a gradient buffer registered with mi355_*_set_grad_typed(.., MI355_BF16): the
+// same value `fp32 buffer -> .to(bfloat16)` gives, without the fp32 round trip through HBM).
+template <bool OUT_BF16, bool VEC>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, long stride, int nsplit, void* out_, long n, int accumulate) {
+    if (VEC) {
+        const long n4 = n >> 2;
+        for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < nsplit; ++k) {
+                const float4 v = *(const float4*)(part + (long)k * stride + i * 4);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            if (OUT_BF16) {
+                bf16_t* out = (bf16_t*)out_ + i * 4;
+                if (accumulate) { s.x += bf2f(out[0]); s.y += bf2f(out[1]); s.z += bf2f(out[2]); s.w += bf2f(out[3]); }
+                uint2 o;
+                o.x = (unsigned)f2bf(s.x) | ((unsigned)f2bf(s.y) << 16);
+                o.y = (unsigned)f2bf(s.z) | ((unsigned)f2bf(s.w) << 16);
+                *(uint2*)out = o;
+            } else {
+                float4* out = (float4*)out_ + i;
+                if (accumulate) { const float4 v = *out; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+                *out = s;
+            }
+        }
+        return;
+    }
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float s = 0.f;
         for (int k = 0; k < nsplit; ++k) s += part[(long)k * stride + i];
-        out[i] = accumulate ? out[i] + s : s;
+        if (OUT_BF16) {
+            bf16_t* out = (bf16_t*)out_;
+            out[i] = f2bf(accumulate ? bf2f(out[i]) + s : s);
+        } else {
+            float* out = (float*)out_;
+            out[i] = accumulate ? out[i] + s : s;
+        }
     }
 }
 
@@ -637,6 +677,24 @@ inline int grid_for(long total, int block) {
 
 }  // namespace
 
+// ---- gradient-buffer dtype registry -------------------------------------------------------------------------------------------
+// The engines' training files keep `float*` gradient pointers (fp32 is the default contract of mi355_*_set_grad).  A buffer registered with
+// mi355_*_set_grad_typed(.., MI355_BF16) is marked here, and the kernels that FINISH a weight / bias gradient (split-K reduce, column-sum
+// finish) round their fp32 sum to bf16 on the way out: the value `fp32 buffer -> .to(bfloat16)` gives, without 10 bytes per parameter of HBM
+// round trip (fp32 write, fp32 read, bf16 write -> 2 bytes).  Host-side state, touched only by the thread that launches the backward.
+static std::unordered_map<const void*, int> g_grad_buf_dt;
+void grad_buf_mark(const void* p, int dt) {
+    if (!p) return;
+    if (dt == DT_F32) g_grad_buf_dt.erase(p);
+    else g_grad_buf_dt[p] = dt;
+}
+int grad_buf_dtype(const void* p) {
+    if (g_grad_buf_dt.empty()) return DT_F32;
+    auto it = g_grad_buf_dt.find(p);
+    return it == g_grad_buf_dt.end() ? DT_F32 : it->second;
+}
+int grad_buf_esize(const void* p) { return grad_buf_dtype(p) == DT_F32 ? 4 : 2; }
+
 hipError_t launch_ln_mod_bwd(const LnModBwdParams& p, hipStream_t st) {
     if (sched_trace_on()) {
         const size_t xb = (size_t)p.M * p.D * 2, nb = (size_t)((p.M + p.rows_per_sample - 1) / p.rows_per_sample);
@@ -711,7 +769,7 @@ hipError_t launch_transpose(const bf16_t* in, long ld_in, long bs_in, bf16_t* ou
 hipError_t launch_transpose_colsum(const bf16_t* in, long ld_in, bf16_t* out, long ld_out, int rows, int cols, int rows_pad, float* scratch,
                                    float* colsum, hipStream_t st) {
     if (sched_trace_on()) sched_trace_launch("transpose_colsum", st, {treg(in, ((size_t)(rows - 1) * ld_in + cols) * 2)},
-                                             {treg(out, ((size_t)(cols - 1) * ld_out + rows_pad) * 2), treg(scratch, (size_t)((rows_pad + 63) / 64) * cols * 4), treg(colsum, (size_t)cols * 4)});
+                                             {treg(out, ((size_t)(cols - 1) * ld_out + rows_pad) * 2), treg(scratch, (size_t)((rows_pad + 63) / 64) * cols * 4), treg(colsum, (size_t)cols * grad_buf_esize(colsum))});
     if (rows <= 0 || cols <= 0 || rows_pad < rows || !scratch || !colsum) return hipErrorInvalidValue;
     const int ntile = (rows_pad + 63) / 64;
     if (transpose_vec_ok(in, ld_in, 0, out, ld_out, 0))
@@ -720,7 +778,8 @@ hipError_t launch_transpose_colsum(const bf16_t* in, long ld_in, bf16_t* out, lo
     else
         hipLaunchKernelGGL(transpose_kernel<false>, dim3(ntile, (cols + 63) / 64, 1), dim3(256), 0, st, in, ld_in, 0L, out, ld_out, 0L, rows, cols,
                            rows_pad, scratch);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, scratch, ntile, cols, colsum, 0);
+    if (grad_buf_dtype(colsum) == DT_BF16) hipLaunchKernelGGL(colsum_finish_kernel<true>, dim3((cols + 31) / 32), dim3(256), 0, st, scratch, ntile, cols, (void*)colsum, 0);
+    else hipLaunchKernelGGL(colsum_finish_kernel<false>, dim3((cols + 31) / 32), dim3(256), 0, st, scratch, ntile, cols, (void*)colsum, 0);
     return hipGetLastError();
 }
 
@@ -765,19 +824,26 @@ hipError_t launch_rms_dw_finish(const float* part, int nwg, float q_scale, float
 hipError_t launch_colsum(const bf16_t* dy, long ld, long M, int N, float* scratch, float* out, int accumulate, hipStream_t st) {
     if (M <= 0 || N <= 0 || !scratch || !out) return hipErrorInvalidValue;
     if (sched_trace_on())       // accumulate: `out` is read as well (a read-after-write dependency the happens-before checker must see)
-        sched_trace_launch("colsum", st, {treg(dy, ((size_t)(M - 1) * ld + N) * 2), treg(out, accumulate ? (size_t)N * 4 : 0)},
-                           {treg(scratch, (size_t)64 * N * 4), treg(out, (size_t)N * 4)});
+        sched_trace_launch("colsum", st, {treg(dy, ((size_t)(M - 1) * ld + N) * 2), treg(out, accumulate ? (size_t)N * grad_buf_esize(out) : 0)},
+                           {treg(scratch, (size_t)64 * N * 4), treg(out, (size_t)N * grad_buf_esize(out))});
     const int nslab = (int)(M >= 8192 ? 64 : (M + 127) / 128);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, nslab), dim3(256), 0, st, dy, ld, M, N, scratch, nslab);
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((N + 31) / 32), dim3(256), 0, st, scratch, nslab, N, out, accumulate);
+    if (grad_buf_dtype(out) == DT_BF16) hipLaunchKernelGGL(colsum_finish_kernel<true>, dim3((N + 31) / 32), dim3(256), 0, st, scratch, nslab, N, (void*)out, accumulate);
+    else hipLaunchKernelGGL(colsum_finish_kernel<false>, dim3((N + 31) / 32), dim3(256), 0, st, scratch, nslab, N, (void*)out, accumulate);
     return hipGetLastError();
 }
 
 hipError_t launch_splitk_reduce(const float* part, long stride, int nsplit, float* out, long n, int accumulate, hipStream_t st) {
     if (nsplit <= 0 || n <= 0 || !part || !out) return hipErrorInvalidValue;
     if (sched_trace_on())
-        sched_trace_launch("splitk_reduce", st, {treg(part, ((size_t)(nsplit - 1) * stride + n) * 4), treg(out, accumulate ? (size_t)n * 4 : 0)}, {treg(out, (size_t)n * 4)});
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid_for(n, 256)), dim3(256), 0, st, part, stride, nsplit, out, n, accumulate);
+        sched_trace_launch("splitk_reduce", st, {treg(part, ((size_t)(nsplit - 1) * stride + n) * 4), treg(out, accumulate ? (size_t)n * grad_buf_esize(out) : 0)}, {treg(out, (size_t)n * grad_buf_esize(out))});
+    const bool b16 = grad_buf_dtype(out) == DT_BF16;
+    const bool vec = !(n & 3) && !(stride & 3) && !((size_t)part & 15) && !((size_t)out & 15);
+    const dim3 grid(grid_for(vec ? n / 4 : n, 256));
+    if (b16 && vec) hipLaunchKernelGGL((splitk_reduce_kernel<true, true>), grid, dim3(256), 0, st, part, stride, nsplit, (void*)out, n, accumulate);
+    else if (b16) hipLaunchKernelGGL((splitk_reduce_kernel<true, false>), grid, dim3(256), 0, st, part, stride, nsplit, (void*)out, n, accumulate);
+    else if (vec) hipLaunchKernelGGL((splitk_reduce_kernel<false, true>), grid, dim3(256), 0, st, part, stride, nsplit, (void*)out, n, accumulate);
+    else hipLaunchKernelGGL((splitk_reduce_kernel<false, false>), grid, dim3(256), 0, st, part, stride, nsplit, (void*)out, n, accumulate);
     return hipGetLastError();
 }
 

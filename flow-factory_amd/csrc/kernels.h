@@ -291,6 +291,11 @@ hipError_t launch_rms_bwd_gather(const RmsBwdParams& p, hipStream_t stream);
 // out[n] (+)= sum_m dy[m][n]; scratch >= 64 * N floats
 hipError_t launch_colsum(const bf16_t* dy, long ld, long M, int N, float* scratch, float* out, int accumulate, hipStream_t stream);
 hipError_t launch_splitk_reduce(const float* part, long stride, int nsplit, float* out, long n, int accumulate, hipStream_t stream);
+// gradient-buffer dtype registry (backward.hip): launch_splitk_reduce / launch_colsum / launch_transpose_colsum write bf16 into an output
+// pointer marked DT_BF16 (the pointer is still passed as float*); DT_F32 un-marks
+void grad_buf_mark(const void* p, int dt);
+int grad_buf_dtype(const void* p);
+int grad_buf_esize(const void* p);
 hipError_t launch_unpatch_bwd(const float* dv, bf16_t* out, int Bp, int C, int hp, int wp, int patch, hipStream_t stream);
 struct SdeBwdParams {
     const bf16_t* v_text; const bf16_t* v_uncond; float guidance;

@@ -51,11 +51,12 @@ static inline int t_wgrad(const TrainScratch& t, hipStream_t st, const bf16_t* d
     while (split > 1 && (size_t)split * N * K > t.part_floats) --split;
     GemmParams g = make_gemm(t.aT, M_pad, t.xT, M_pad, N, K, M_pad, EPI_F32, nullptr, nullptr, K);
     g.q_scale = 1.0f;
-    if (split <= 1) {
+    if (split <= 1 && grad_buf_dtype(gw) == DT_F32) {
         g.out_f32 = gw; g.k_split = 1;
         HIPCHK(launch_gemm(g, st));
         return 0;
     }
+    if ((size_t)N * K > t.part_floats) return errorf("wgrad: a %d x %d gradient does not fit the split-K scratch", N, K);   // (bf16 output, single split)
     g.out_f32 = t.part; g.k_split = split; g.split_stride = (long)N * K;
     HIPCHK(launch_gemm(g, st));
     HIPCHK(launch_splitk_reduce(t.part, (long)N * K, split, gw, (long)N * K, 0, st));

@@ -95,6 +95,7 @@ SIGNATURES = {
     "mi355_rollout": (_I, [_P, _P, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _I, _F, _P, _I, _I, _P,
                            _P, _P, _P, _P, C.POINTER(C.c_int32), _P, _P, _P, _I]),
     "mi355_engine_set_grad": (_I, [_P, C.c_char_p, _P]),
+    "mi355_engine_set_grad_typed": (_I, [_P, C.c_char_p, _P, _I]),
     "mi355_engine_clear_grads": (_I, [_P]),
     "mi355_engine_set_train_scope": (_I, [_P, _I]),
     "mi355_engine_grad_supported": (_I, [_P, C.c_char_p]),
@@ -133,6 +134,7 @@ SIGNATURES = {
     "mi355_flux_rollout": (_I, [_P, _P, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _I, _F, _P, _I, _I, _P, _P, _P,
                                 C.POINTER(C.c_int32), _P, _P, _P, _I]),
     "mi355_flux_set_grad": (_I, [_P, C.c_char_p, _P]),
+    "mi355_flux_set_grad_typed": (_I, [_P, C.c_char_p, _P, _I]),
     "mi355_flux_clear_grads": (_I, [_P]),
     "mi355_flux_grad_supported": (_I, [_P, C.c_char_p]),
     "mi355_flux_plan_training_bytes": (_L, [_P]),
@@ -168,6 +170,7 @@ SIGNATURES = {
     "mi355_qwen_rollout": (_I, [_P, _P, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _I, _F, _P, _I, _I, _P, _P,
                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32), _P, _P, _P, _I]),
     "mi355_qwen_set_grad": (_I, [_P, C.c_char_p, _P]),
+    "mi355_qwen_set_grad_typed": (_I, [_P, C.c_char_p, _P, _I]),
     "mi355_qwen_clear_grads": (_I, [_P]),
     "mi355_qwen_grad_supported": (_I, [_P, C.c_char_p]),
     "mi355_qwen_plan_training_bytes": (_L, [_P]),

@@ -162,6 +162,20 @@ def _arm_ddp(ddp) -> None:
         ddp._pre_forward()
 
 
+# --------------------------------------------------------------------------------------------- gradient buffers
+def _grad_buffers(eng, names, w_meta, device) -> Dict[str, torch.Tensor]:
+    """One buffer per trainable engine parameter, registered with the engine.  A bf16 parameter inside the default gradient scope (the blocks'
+    linear layers) gets a bf16 buffer the engine writes directly (its reduction kernels round the fp32 sums on the way out: the values of
+    `fp32 -> .to(bf16)` without the 4 + 4 + 2 bytes per parameter of HBM round trip); anything else an fp32 buffer, converted by the caller."""
+    bufs: Dict[str, torch.Tensor] = {}
+    eng.clear_grads()
+    for name, (shape, dt) in zip(names, w_meta):
+        direct = dt == torch.bfloat16 and eng.grad_supported(name) == 1
+        bufs[name] = torch.zeros(shape, device=device, dtype=torch.bfloat16 if direct else torch.float32)
+        eng.set_grad(name, bufs[name])
+    return bufs
+
+
 # --------------------------------------------------------------------------------------------- the autograd node
 class _DenoiseReplayFn(torch.autograd.Function):
     """(log_prob [B], noise_pred [B,C,h,w], next_latents_mean [B,C,h,w]) = step(weights); d/d weights by the engine."""
@@ -188,11 +202,7 @@ class _DenoiseReplayFn(torch.autograd.Function):
         if g_lp is None and g_np is None and g_mean is None:
             return (None,) * (4 + len(ctx.names))
         dev = next(g for g in (g_lp, g_np, g_mean) if g is not None).device
-        grads: Dict[str, torch.Tensor] = {}
-        eng.clear_grads()
-        for name, (shape, _) in zip(ctx.names, ctx.w_meta):
-            grads[name] = torch.zeros(shape, device=dev, dtype=torch.float32)
-            eng.set_grad(name, grads[name])
+        grads = _grad_buffers(eng, ctx.names, ctx.w_meta, dev)
         plan.denoise_step_backward(ctx.call, g_lp, g_np, g_mean)
         eng.clear_grads()
         outs = tuple(grads[n].to(dt) for n, (_, dt) in zip(ctx.names, ctx.w_meta))
@@ -266,11 +276,7 @@ class _FluxReplayFn(torch.autograd.Function):
         dv = sde_step_bwd(ctx.v, None, 1.0, call["latents"], call["next_latents"], call["sigma"], call["sigma_next"], call["eta"],
                           call["sigma_max"], call["dynamics"], call["compute_log_prob"], g_lp, g_np, g_mean)
         eng = plan.engine
-        grads: Dict[str, torch.Tensor] = {}
-        eng.clear_grads()
-        for name, (shape, _) in zip(ctx.names, ctx.w_meta):
-            grads[name] = torch.zeros(shape, device=dv.device, dtype=torch.float32)
-            eng.set_grad(name, grads[name])
+        grads = _grad_buffers(eng, ctx.names, ctx.w_meta, dv.device)
         plan.backward(dv)
         eng.clear_grads()
         outs = tuple(grads[n].to(dt) for n, (_, dt) in zip(ctx.names, ctx.w_meta))

@@ -105,9 +105,11 @@ class QwenEngine(WeightHolder):
         return 1 if self.lib.mi355_qwen_grad_supported(self._h, name.encode()) == 0 else 0
 
     def set_grad(self, name: str, grad: torch.Tensor) -> None:
-        if grad.dtype != torch.float32 or not grad.is_contiguous():
-            raise ValueError("mi355_flow: gradient buffers are contiguous fp32 tensors")
-        _lib.check(self.lib.mi355_qwen_set_grad(self._h, name.encode(), _ptr(grad)), f"qwen_set_grad({name})")
+        """Register the buffer the next backward writes d loss / d `name` into (same shape as the parameter): fp32, or bf16 for the weights /
+        biases of the linear layers inside the blocks (`grad_supported(name) == 1`) -- the engine then rounds its fp32 sums to bf16 itself."""
+        if grad.dtype not in (torch.float32, torch.bfloat16) or not grad.is_contiguous():
+            raise ValueError("mi355_flow: gradient buffers are contiguous fp32 (or bf16) tensors")
+        _lib.check(self.lib.mi355_qwen_set_grad_typed(self._h, name.encode(), _ptr(grad), dtype_code(grad.dtype)), f"qwen_set_grad({name})")
 
     def clear_grads(self) -> None:
         _lib.check(self.lib.mi355_qwen_clear_grads(self._h), "qwen_clear_grads")

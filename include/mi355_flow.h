@@ -146,6 +146,10 @@ int mi355_rollout(mi355_plan* p, void* stream, int n_steps, const float* timeste
  * the linear layers inside the transformer blocks (mi355_engine_grad_supported == 0); the data gradient covers the whole network.
  * The caller re-binds the CURRENT weights before the backward if they were swapped after the forward. */
 int mi355_engine_set_grad(mi355_engine* e, const char* name, float* grad);
+/* the same with the buffer's dtype (MI355_F32 / MI355_BF16).  bf16 is accepted for the weights and biases of the linear layers inside the
+ * transformer blocks (grad_supported == 0): the kernels that finish those gradients round their fp32 sums to bf16 on the way out -- the values
+ * an fp32 buffer converted to bf16 holds, without 8 bytes per parameter of HBM round trip -- what a bf16 parameter's `.grad` wants. */
+int mi355_engine_set_grad_typed(mi355_engine* e, const char* name, void* grad, int dtype);
 /* Gradient scope of the NEXT training-mode forward: 0 (default) = the blocks' linear layers; 1 = every parameter (`target_modules: all`):
  * AdaLN modulation linears, q/k RMSNorm weights, timestep / pooled-text MLPs, context_embedder, patch embedding, proj_out as well.  The
  * forward then stashes the un-gated projections too.  mi355_engine_grad_supported: 0 = default scope, 2 = full scope only, 1 = never. */
@@ -268,6 +272,7 @@ int mi355_flux_rollout(mi355_flux_plan* plan, void* stream, int n_steps, const f
  * single_transformer_blocks.N.{attn.{to_q,to_k,to_v},proj_mlp,proj_out}: a superset of the reference's FLUX.1 default target modules
  * (models/flux/flux1.py:76-84).  Everything else (modulation linears, norm weights, embedders, conditioning MLPs, final proj_out): 1 = never. */
 int mi355_flux_set_grad(mi355_flux* e, const char* name, float* grad);
+int mi355_flux_set_grad_typed(mi355_flux* e, const char* name, void* grad, int dtype);
 int mi355_flux_clear_grads(mi355_flux* e);
 int mi355_flux_grad_supported(mi355_flux* e, const char* name);
 int64_t mi355_flux_plan_training_bytes(mi355_flux_plan* plan);
@@ -377,6 +382,7 @@ int mi355_qwen_rollout(mi355_qwen_plan* plan, void* stream, int n_steps, const f
  * a superset of the reference's Qwen-Image default target modules (models/qwen_image/qwen_image.py:81-89).  img_mod / txt_mod, norm weights,
  * img_in / txt_in / txt_norm, the timestep MLP, norm_out and proj_out: 1 = never. */
 int mi355_qwen_set_grad(mi355_qwen* e, const char* name, float* grad);
+int mi355_qwen_set_grad_typed(mi355_qwen* e, const char* name, void* grad, int dtype);
 int mi355_qwen_clear_grads(mi355_qwen* e);
 int mi355_qwen_grad_supported(mi355_qwen* e, const char* name);
 int64_t mi355_qwen_plan_training_bytes(mi355_qwen_plan* plan);

@@ -426,7 +426,7 @@ class DiffFakeEngine(FakeEngine):
         self.scope_full = bool(full)
 
     def set_grad(self, name, t) -> None:
-        assert name in self._names and t.dtype == torch.float32
+        assert name in self._names and t.dtype in (torch.float32, torch.bfloat16)
         self.grad_bufs[name] = t
 
     def clear_grads(self) -> None:
@@ -790,7 +790,7 @@ class FluxTrainEngineModel(_StandinFamilyEngine):
         return 1 if (name in self._names and ".attn.to_" in name) else 0
 
     def set_grad(self, name, t) -> None:
-        assert self.grad_supported(name) and t.dtype == torch.float32
+        assert self.grad_supported(name) and t.dtype in (torch.float32, torch.bfloat16)
         self.grad_bufs[name] = t
 
     def clear_grads(self) -> None:
