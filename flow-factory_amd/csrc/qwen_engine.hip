@@ -38,6 +38,14 @@ struct QBlockW {
     float bound = 0.f;
 };
 
+// per-block activation stash of the training-mode forward (qwen_train.inc): what the backward of the block needs
+struct QTrainBlk {
+    bf16_t *x_in, *xn, *x_mid, *xn_mlp, *pre, *o_img;
+    bf16_t *c_in, *cn, *c_mid, *cn_mlp, *cpre, *o_ctx;
+    bf16_t *q, *k, *vT;
+    float *lse, *rstd_img, *rstd_ctx;
+};
+
 float q_host_round(float v, int dt) {
     if (dt == DT_F32) return v;
     if (dt == DT_BF16) {
@@ -415,7 +423,7 @@ int ln_mod(mi355_qwen_plan* p, hipStream_t st, const bf16_t* x, bf16_t* out, con
 
 // q|k projection (one GEMM) -> per-head RMSNorm + RoPE + scatter; V^T projection with the scatter fused (operands swapped)
 int qkv(mi355_qwen_plan* p, hipStream_t st, const bf16_t* xin, int M, int rps, int s_off, const bf16_t* w_qk, const float* b_qk,
-        const bf16_t* w_v, const float* b_v, const float* nq, const float* nk, bf16_t* qkb) {
+        const bf16_t* w_v, const float* b_v, const float* nq, const float* nk, bf16_t* qkb, const QTrainBlk* tb = nullptr, float* rstd = nullptr) {
     mi355_qwen* e = p->e;
     const int D = e->D;
     GemmParams g = make_gemm(xin, D, w_qk, D, M, 2 * D, D, EPI_BIAS, b_qk, qkb, 2 * D);
@@ -423,11 +431,12 @@ int qkv(mi355_qwen_plan* p, hipStream_t st, const bf16_t* xin, int M, int rps, i
     RopeNormParams r;
     memset(&r, 0, sizeof(r));
     r.src = qkb; r.src_ld = 2 * D; r.q_col = 0; r.k_col = D; r.nw_q = nq; r.nw_k = nk; r.cs = p->cs;
-    r.q_out = p->q; r.k_out = p->k; r.M = M; r.H = e->H; r.rows_per_sample = rps; r.s_off = s_off; r.S_pad = p->S_pad;
+    r.q_out = tb ? tb->q : p->q; r.k_out = tb ? tb->k : p->k; r.M = M; r.H = e->H; r.rows_per_sample = rps; r.s_off = s_off; r.S_pad = p->S_pad;
     r.eps = e->cfg.eps; r.q_scale = 0.08838834764831845f * 1.4426950408889634f;
+    r.rstd_out = rstd;                                 // (training mode: 1 / rms per (token, head) of q and k for the producer's backward)
     HIPCHK(launch_rope_norm(r, st));
     GemmParams gv = make_gemm(w_v, D, xin, D, D, M, D, EPI_VT, b_v, nullptr, 0);
-    gv.q = p->vT; gv.H = e->H; gv.S_pad = p->S_pad; gv.s_off = s_off; gv.rows_per_sample = rps; gv.hd_shift = 7;
+    gv.q = tb ? tb->vT : p->vT; gv.H = e->H; gv.S_pad = p->S_pad; gv.s_off = s_off; gv.rows_per_sample = rps; gv.hd_shift = 7;
     HIPCHK(launch_gemm(gv, st));
     return 0;
 }
@@ -479,10 +488,15 @@ int qwen_two_stream_init(mi355_qwen_plan* p) {
     return 0;
 }
 
-int forward_core(mi355_qwen_plan* p, hipStream_t st, const void* latents, int lat_dt, const bf16_t* mod) {
+// Training mode (`tb` = the plan's per-block stash, qwen_train.inc): the SAME launches with the activations the backward needs written to per-block
+// buffers instead of the plan's shared ones (+ the block inputs copied aside, the log-sum-exp / 1/rms side outputs switched on, the MLP
+// pre-activations stashed by the GEMM epilogue): the same kernel binaries on the same values -- the prediction is bit-identical.
+int forward_core(mi355_qwen_plan* p, hipStream_t st, const void* latents, int lat_dt, const bf16_t* mod, const QTrainBlk* tb = nullptr,
+                 bf16_t* x_final = nullptr) {
     mi355_qwen* e = p->e;
     const int D = e->D, F = e->F, C = e->cfg.in_channels;
     const int Ni = p->Ni, Nt = p->Nt;
+    const size_t xi_b = (size_t)p->Mi * D * 2, xc_b = (size_t)p->Mc * D * 2;
     const bool two = qwen_two_stream_wanted(p);
     hipStream_t ts = st;                               // carries the text chain
     bf16_t *qkb_c = p->qkbuf, *big_c = p->big;
@@ -500,41 +514,56 @@ int forward_core(mi355_qwen_plan* p, hipStream_t st, const void* latents, int la
     HIPCHK(launch_gemm(gx, st));
     if (p->ncfg == 2)
         HIPCHK(copy_d2d(p->x + (size_t)p->B * Ni * D, p->x, (size_t)p->B * Ni * D * 2, st));
-    HIPCHK(copy_d2d(p->c, p->c0, (size_t)p->Mc * D * 2, st));
+    HIPCHK(copy_d2d(p->c, p->c0, xc_b, st));
     if (two) {          // c, the conditioning (modulation table, prompt, key lengths) and the previous forward are complete on `st`
         HIPCHK(ev_record(p->ev_fork[e->L], st));
         HIPCHK(ev_wait(ts, p->ev_fork[e->L]));
     }
     for (int i = 0; i < e->L; ++i) {
         const QBlockW& b = e->blk[i];
+        const QTrainBlk* k = tb ? tb + i : nullptr;
         const int mi = b.mod_img, mc = b.mod_ctx;     // chunks: shift1, scale1, gate1, shift2, scale2, gate2
-        CHK(ln_mod(p, ts, p->c, p->cn, mod, p->Mc, Nt, mc, mc + D));
-        CHK(qkv(p, ts, p->cn, p->Mc, Nt, Ni, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck, qkb_c));
-        CHK(ln_mod(p, st, p->x, p->xn, mod, p->Mi, Ni, mi, mi + D));
-        CHK(qkv(p, st, p->xn, p->Mi, Ni, 0, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk, p->qkbuf));
+        bf16_t* cn = k ? k->cn : p->cn;
+        bf16_t* xn = k ? k->xn : p->xn;
+        if (k) {
+            HIPCHK(copy_d2d(k->c_in, p->c, xc_b, ts));
+            HIPCHK(copy_d2d(k->x_in, p->x, xi_b, st));
+        }
+        CHK(ln_mod(p, ts, p->c, cn, mod, p->Mc, Nt, mc, mc + D));
+        CHK(qkv(p, ts, cn, p->Mc, Nt, Ni, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck, qkb_c, k, k ? k->rstd_ctx : nullptr));
+        CHK(ln_mod(p, st, p->x, xn, mod, p->Mi, Ni, mi, mi + D));
+        CHK(qkv(p, st, xn, p->Mi, Ni, 0, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk, p->qkbuf, k, k ? k->rstd_img : nullptr));
         if (two) {      // join: the attention reads the text rows of q / k / vT
             HIPCHK(ev_record(p->ev_join[i], ts));
             HIPCHK(ev_wait(st, p->ev_join[i]));
         }
+        bf16_t* o_img = k ? k->o_img : p->o_img;
+        bf16_t* o_ctx = k ? k->o_ctx : p->o_ctx;
         Attn128Params a;
         memset(&a, 0, sizeof(a));
-        a.q = p->q; a.k = p->k; a.vT = p->vT; a.o_first = p->o_img; a.ld_first = D; a.n_first = Ni;
-        a.o_rest = p->o_ctx; a.ld_rest = D; a.B = p->FB; a.H = e->H; a.S = p->S; a.S_pad = p->S_pad; a.q_prescaled = 1;
-        a.score_bound = b.bound; a.kv_len = p->kvlen;
+        a.q = k ? k->q : p->q; a.k = k ? k->k : p->k; a.vT = k ? k->vT : p->vT; a.o_first = o_img; a.ld_first = D; a.n_first = Ni;
+        a.o_rest = o_ctx; a.ld_rest = D; a.B = p->FB; a.H = e->H; a.S = p->S; a.S_pad = p->S_pad; a.q_prescaled = 1;
+        a.score_bound = b.bound; a.kv_len = p->kvlen; a.lse = k ? k->lse : nullptr;
         HIPCHK(launch_attention128(a, st));
         if (two) {      // fork: o_ctx is written, and the text rows of q / k / vT are free for the next block's text projections
             HIPCHK(ev_record(p->ev_fork[i], st));
             HIPCHK(ev_wait(ts, p->ev_fork[i]));
         }
-        CHK(gate_res(p, st, p->o_img, D, D, b.w_o, b.b_o, p->x, p->Mi, Ni, mod, mi + 2 * D));
-        CHK(gate_res(p, ts, p->o_ctx, D, D, b.w_co, b.b_co, p->c, p->Mc, Nt, mod, mc + 2 * D));
-        CHK(ln_mod(p, st, p->x, p->xn, mod, p->Mi, Ni, mi + 3 * D, mi + 4 * D));
-        GemmParams f1 = make_gemm(p->xn, D, b.w_ff1, D, p->Mi, F, D, EPI_BIAS_GELU, b.b_ff1, p->big, F);
+        CHK(gate_res(p, st, o_img, D, D, b.w_o, b.b_o, p->x, p->Mi, Ni, mod, mi + 2 * D));
+        CHK(gate_res(p, ts, o_ctx, D, D, b.w_co, b.b_co, p->c, p->Mc, Nt, mod, mc + 2 * D));
+        bf16_t* xn2 = k ? k->xn_mlp : p->xn;
+        if (k) HIPCHK(copy_d2d(k->x_mid, p->x, xi_b, st));
+        CHK(ln_mod(p, st, p->x, xn2, mod, p->Mi, Ni, mi + 3 * D, mi + 4 * D));
+        GemmParams f1 = make_gemm(xn2, D, b.w_ff1, D, p->Mi, F, D, EPI_BIAS_GELU, b.b_ff1, p->big, F);
+        if (k) { f1.stash = k->pre; f1.ld_stash = F; }
         HIPCHK(launch_gemm(f1, st));
         CHK(gate_res(p, st, p->big, F, F, b.w_ff2, b.b_ff2, p->x, p->Mi, Ni, mod, mi + 5 * D));
         if (i + 1 < e->L) {       // the text stream of the last block feeds nothing
-            CHK(ln_mod(p, ts, p->c, p->cn, mod, p->Mc, Nt, mc + 3 * D, mc + 4 * D));
-            GemmParams c1 = make_gemm(p->cn, D, b.w_cff1, D, p->Mc, F, D, EPI_BIAS_GELU, b.b_cff1, big_c, F);
+            bf16_t* cn2 = k ? k->cn_mlp : p->cn;
+            if (k) HIPCHK(copy_d2d(k->c_mid, p->c, xc_b, ts));
+            CHK(ln_mod(p, ts, p->c, cn2, mod, p->Mc, Nt, mc + 3 * D, mc + 4 * D));
+            GemmParams c1 = make_gemm(cn2, D, b.w_cff1, D, p->Mc, F, D, EPI_BIAS_GELU, b.b_cff1, big_c, F);
+            if (k) { c1.stash = k->cpre; c1.ld_stash = F; }
             HIPCHK(launch_gemm(c1, ts));
             CHK(gate_res(p, ts, big_c, F, F, b.w_cff2, b.b_cff2, p->c, p->Mc, Nt, mod, mc + 5 * D));
         }
@@ -544,6 +573,7 @@ int forward_core(mi355_qwen_plan* p, hipStream_t st, const void* latents, int la
         HIPCHK(ev_record(p->ev_join[e->L], ts));
         HIPCHK(ev_wait(st, p->ev_join[e->L]));
     }
+    if (x_final) HIPCHK(copy_d2d(x_final, p->x, xi_b, st));
     // AdaLayerNormContinuous (scale first), proj_out
     CHK(ln_mod(p, st, p->x, p->xn, mod, p->Mi, Ni, e->mod_out + D, e->mod_out));
     GemmParams go = make_gemm(p->xn, D, e->w_proj, D, p->Mi, C, D, EPI_BIAS, e->b_proj, p->v2, C);

@@ -1243,6 +1243,76 @@ def test_reference_dgpo_trainer_on_the_qwen_image_plugin(ref):
     assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable)), logged
 
 
+def test_reference_dgpo_trainer_on_the_qwen_image_plugin_takes_the_native_backward(ref):
+    """BASELINE.json configs[4] with the round-4 native Qwen-Image backward: the reference's own `DGPOTrainer` on the Qwen-Image plugin whose
+    engine double carries the training API (`QwenPlan.forward_train` / `.backward`).  The DSM training forward -- WITHOUT a stored transition,
+    log-prob off (trainers/dgpo.py:352-364) -- runs `mi355_flow.autograd.qwen_replay`, never the torch transformer; the engine's gradient
+    reaches the default target modules and the optimizer moves them."""
+    import mi355_flow.engine as ME
+    import mi355_flow.qwen as MQ
+    import mi355_flow.vae as MV
+    from flow_factory.trainers.dgpo import DGPOTrainer
+    from oracle import make_rollout_golden as G
+    P = ref
+    M, K, Nt = 2, 2, 7
+    names = ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias", "img_in.weight"]
+
+    def make_adapter(cfg, acc):
+        tr = F.build_module_tree({n: ((8, 8) if n.endswith("weight") else (8,)) for n in names}, buffers=(), cls=F.FakeTransformer).bfloat16()
+        tcfg = MQ.QwenConfig(num_layers=1, num_attention_heads=1, joint_attention_dim=G.QJ)
+        saved = (P.QwenEngine, P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder)
+        P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = F.FakeVAEDecoder, types.SimpleNamespace(from_hf=lambda c: c), F.FakeVideoVAEDecoder
+        F.QwenTrainEngineModel.NAMES = names
+        P.QwenEngine = F.QwenTrainEngineModel
+        try:
+            class Plug(P.QwenImageNativeAdapter):
+                def load_pipeline(self):
+                    return _qwen_pipeline(tcfg, tr)
+            ad = Plug(cfg, acc)
+        finally:
+            P.QwenEngine, P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = saved
+        return ad, tr
+
+    g = torch.Generator().manual_seed(3)
+    batches = [dict(prompt=[f"prompt {i}"] * K, prompt_ids=torch.full((K, 4), i), prompt_embeds=torch.randn(1, Nt, G.QJ, generator=g).bfloat16().repeat(K, 1, 1),
+                    prompt_embeds_mask=torch.ones(K, Nt, dtype=torch.long)) for i in range(M)]
+
+    def tweak(cfg):
+        _small(cfg.training_args, guidance_scale=1.0)
+        cfg.training_args.height = cfg.training_args.width = 64
+        cfg.training_args.resolution = (64, 64)
+        cfg.model_args.finetune_type = "full"               # (peft is absent here; the default target modules, trained in full)
+        for k, v in (("num_train_timesteps", 2), ("off_policy", False)):
+            if hasattr(cfg.training_args, k):
+                setattr(cfg.training_args, k, v)
+    real = (MQ.sde_step, ME.sde_step, ME.sde_step_bwd, MV.WanVAEDecoder)
+    MQ.sde_step = ME.sde_step = F.oracle_sde_step
+    ME.sde_step_bwd = F.oracle_sde_step_bwd
+    MV.WanVAEDecoder = F.FakeVideoVAEDecoder
+    try:
+        tr, ad, tr_mod, logged = _real_trainer(P, DGPOTrainer, "/root/reference/examples/dgpo/lora/sd3_5/default.yaml", tweak, batches, K, lr=5.0,
+                                               make_adapter=make_adapter)
+        trainable = ad.get_trainable_parameters()
+        assert len(trainable) == 2
+        before = [p_.detach().clone() for p_ in trainable]
+        torch.manual_seed(99)
+        samples = tr.sample()
+        for s_, r in zip(samples, [0.1, 0.9, 0.4, 0.2]):
+            s_.extra_kwargs["reward"] = torch.tensor(r)
+        tr.compute_advantages(samples, {"r": torch.tensor([0.1, 0.9, 0.4, 0.2])}, store_to_samples=True)
+        n0 = len(ad.engine.calls)
+        F.FakeTransformer.calls = 0
+        torch.manual_seed(1234)
+        tr.optimize(samples)
+    finally:
+        MQ.sde_step, ME.sde_step, ME.sde_step_bwd, MV.WanVAEDecoder = real
+    kinds = [c[0] for c in ad.engine.calls[n0:]]
+    assert "forward_train" in kinds and "backward" in kinds and "transformer_forward" in kinds, kinds
+    assert F.FakeTransformer.calls == 0                       # the torch transformer was never called
+    assert logged and all(torch.isfinite(torch.as_tensor(v)).all() for _, d in logged for v in d.values() if torch.is_tensor(v) or isinstance(v, float))
+    assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable)), logged
+
+
 @pytest.mark.parametrize("family", ["sd3", "flux", "qwen"])
 def test_reference_evaluate_loop_runs_on_the_plugins(ref, family):
     """The reference's own `GRPOTrainer.evaluate()` (trainers/grpo.py:93-136): `adapter.eval()`, EMA parameters swapped in
