@@ -695,6 +695,12 @@ int grad_buf_dtype(const void* p) {
 }
 int grad_buf_esize(const void* p) { return grad_buf_dtype(p) == DT_F32 ? 4 : 2; }
 
+// mi355_tune_set(26, .): 1 (default) = the weight-gradient GEMMs of the head_dim-128 engines' backward (train_common.h) run on a side stream of
+// the plan's training state, 0 = on the backward's own stream.  Read when a plan's training state is created.
+static int g_wgrad_side = 1;
+void set_wgrad_side(int v) { g_wgrad_side = v != 0; }
+int get_wgrad_side() { return g_wgrad_side; }
+
 hipError_t launch_ln_mod_bwd(const LnModBwdParams& p, hipStream_t st) {
     if (sched_trace_on()) {
         const size_t xb = (size_t)p.M * p.D * 2, nb = (size_t)((p.M + p.rows_per_sample - 1) / p.rows_per_sample);

@@ -296,6 +296,8 @@ hipError_t launch_splitk_reduce(const float* part, long stride, int nsplit, floa
 void grad_buf_mark(const void* p, int dt);
 int grad_buf_dtype(const void* p);
 int grad_buf_esize(const void* p);
+void set_wgrad_side(int v);
+int get_wgrad_side();
 hipError_t launch_unpatch_bwd(const float* dv, bf16_t* out, int Bp, int C, int hp, int wp, int patch, hipStream_t stream);
 struct SdeBwdParams {
     const bf16_t* v_text; const bf16_t* v_uncond; float guidance;

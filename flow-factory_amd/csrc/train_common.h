@@ -6,15 +6,30 @@
 
 namespace mi355 {
 
+// One in-flight weight-gradient group: its operands in contraction-contiguous form (aT: the dY columns, [rows <= aT_rows][M_pad]; xT: the
+// layer input, [rows <= xT_rows][M_pad]) + the events that hand it to the side stream and back.
+struct WgradSlot {
+    bf16_t *aT = nullptr, *xT = nullptr;
+    hipEvent_t ready = nullptr, done = nullptr;
+    bool busy = false;
+};
+constexpr int WG_SLOTS = 3;
+
 // backward scratch of one plan (device pointers into the plan's training workspace).  Row counts: M = every token row of the forward batch,
 // Mc = its context rows; wide / widec hold [rows][3D + F] (the fused q|k|v|mlp gradient of a single-stream block, or [rows][3D] + [rows][F]).
 struct TrainScratch {
     bf16_t *g1, *g1c, *g2, *g2c, *g3, *g3c, *wide, *widec, *hid;
     bf16_t *doh, *v, *dq, *dk, *dvh;          // attention backward: dO head-major, V row-major, dq~ / dk / dv head-major
     float *delta, *nld;
-    bf16_t *aT, *xT;                          // wgrad operands, contraction-contiguous: [N_max][M_pad], [K_max][M_pad]
     float *part, *csum, *zero_bias;
     size_t part_floats;
+    // weight gradients: the operand transposes (+ the bias column sums) run on the backward's own stream, the split-K GEMMs and their
+    // reductions on `wside` when it exists (mi355_tune_set(26, .)): they are off the critical path -- nothing in the backward reads a weight
+    // gradient -- and their partial last rounds (144 output tiles x 2 splits on 256 CUs) fill with the dgrad chain's kernels and vice versa
+    WgradSlot slot[WG_SLOTS];
+    int n_slots = 1, next_slot = 0;
+    long aT_rows = 0, xT_rows = 0;
+    hipStream_t wside = nullptr;
 };
 
 struct AttnGeom {
@@ -32,16 +47,39 @@ static inline int t_dgrad(const TrainScratch& t, hipStream_t st, const bf16_t* A
     return 0;
 }
 
-// dW[N][K] (fp32, overwritten) = dY[:, col0 : col0 + N]^T . X;  db[N] = column sums.  x_ready: t.xT already holds X^T.
-// Operands are transposed to contraction-contiguous form (64 x 64 LDS tile transposes, rows zero-padded to M_pad), the GEMM is split-K over the
-// token dimension into partial buffers + a fixed-order reduction (deterministic); the bias gradient is taken by the dY transpose.
-static inline int t_wgrad(const TrainScratch& t, hipStream_t st, const bf16_t* dY, long ldY, int col0, int N, const bf16_t* X, long ldX, int K, int M,
-                          int M_pad, float* gw, float* gb, bool x_ready) {
-    if (gb && !gw) HIPCHK(launch_colsum(dY + col0, ldY, M, N, t.csum, gb, 0, st));
-    if (!gw) return 0;
-    if (!x_ready) HIPCHK(launch_transpose(X, ldX, 0, t.xT, M_pad, 0, M, K, M_pad, 1, st));
-    if (gb) HIPCHK(launch_transpose_colsum(dY + col0, ldY, t.aT, M_pad, M, N, M_pad, t.csum, gb, st));
-    else HIPCHK(launch_transpose(dY + col0, ldY, 0, t.aT, M_pad, 0, M, N, M_pad, 1, st));
+// ---- weight gradients -------------------------------------------------------------------------------------------------------------
+struct WgradSeg { int col0, N; float* gw; float* gb; };      // dW[N][K] = dY[:, col0 : col0 + N]^T . X (overwritten), db[N] = column sums
+struct WgradX { const bf16_t* p; long ld; int K; };          // X = [X0 | X1 ...] column blocks (a single block for every layer but FLUX.1's proj_out)
+
+static inline int t_wgrad_streams_init(TrainScratch& t, bool side) {
+    t.n_slots = 1;
+    if (!side) return 0;
+    HIPCHK(hipStreamCreateWithFlags(&t.wside, hipStreamNonBlocking));
+    for (int i = 0; i < WG_SLOTS; ++i) {
+        HIPCHK(hipEventCreateWithFlags(&t.slot[i].ready, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&t.slot[i].done, hipEventDisableTiming));
+    }
+    t.n_slots = WG_SLOTS;
+    return 0;
+}
+static inline void t_wgrad_streams_destroy(TrainScratch& t) {
+    for (int i = 0; i < WG_SLOTS; ++i) {
+        if (t.slot[i].ready) (void)hipEventDestroy(t.slot[i].ready);
+        if (t.slot[i].done) (void)hipEventDestroy(t.slot[i].done);
+    }
+    if (t.wside) (void)hipStreamDestroy(t.wside);
+    t.wside = nullptr;
+}
+// every gradient written so far is complete on `st` (end of the backward)
+static inline int t_wgrad_join(TrainScratch& t, hipStream_t st) {
+    for (int i = 0; i < t.n_slots; ++i)
+        if (t.slot[i].busy) { HIPCHK(ev_wait(st, t.slot[i].done)); t.slot[i].busy = false; }
+    return 0;
+}
+
+// One GEMM of a group on stream `ws`: dW = aT[N][M_pad] . xT[K][M_pad]^T, split-K over the token dimension into partial buffers + a fixed-order
+// reduction (deterministic; the reduction rounds to bf16 itself for a bf16 gradient buffer)
+static inline int t_wgrad_gemm(const TrainScratch& t, hipStream_t ws, const bf16_t* aT, const bf16_t* xT, int N, int K, int M_pad, float* gw) {
     const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
     int split = (int)((768 + tiles - 1) / tiles);
     const int nt = M_pad / 64;
@@ -49,18 +87,75 @@ static inline int t_wgrad(const TrainScratch& t, hipStream_t st, const bf16_t* d
     if (split > 16) split = 16;
     if (split < 1) split = 1;
     while (split > 1 && (size_t)split * N * K > t.part_floats) --split;
-    GemmParams g = make_gemm(t.aT, M_pad, t.xT, M_pad, N, K, M_pad, EPI_F32, nullptr, nullptr, K);
+    GemmParams g = make_gemm(aT, M_pad, xT, M_pad, N, K, M_pad, EPI_F32, nullptr, nullptr, K);
     g.q_scale = 1.0f;
     if (split <= 1 && grad_buf_dtype(gw) == DT_F32) {
         g.out_f32 = gw; g.k_split = 1;
-        HIPCHK(launch_gemm(g, st));
+        HIPCHK(launch_gemm(g, ws));
         return 0;
     }
     if ((size_t)N * K > t.part_floats) return errorf("wgrad: a %d x %d gradient does not fit the split-K scratch", N, K);   // (bf16 output, single split)
     g.out_f32 = t.part; g.k_split = split; g.split_stride = (long)N * K;
-    HIPCHK(launch_gemm(g, st));
-    HIPCHK(launch_splitk_reduce(t.part, (long)N * K, split, gw, (long)N * K, 0, st));
+    HIPCHK(launch_gemm(g, ws));
+    HIPCHK(launch_splitk_reduce(t.part, (long)N * K, split, gw, (long)N * K, 0, ws));
     return 0;
+}
+
+// The weight (and bias) gradients of the linear layers that share the input X: dY [M][..] holds their output gradients side by side.
+// On `st`: X^T once, the dY column blocks transposed (rows zero-padded to M_pad; the bias gradient = the column sums taken on the way).
+// On the side stream (or `st`): one split-K GEMM + reduction per layer.  A group larger than a slot's aT is cut (X^T is taken again).
+static inline int t_wgrad_group(TrainScratch& t, hipStream_t st, const bf16_t* dY, long ldY, const WgradSeg* seg, int nseg, const WgradX* xs, int nx,
+                                int M, int M_pad) {
+    int K = 0;
+    for (int i = 0; i < nx; ++i) K += xs[i].K;
+    if (K > t.xT_rows) return errorf("wgrad: K = %d exceeds the transposed-input scratch (%ld rows)", K, t.xT_rows);
+    int i = 0;
+    while (i < nseg) {
+        if (!seg[i].gw) {                              // bias only (or nothing): no GEMM
+            if (seg[i].gb) HIPCHK(launch_colsum(dY + seg[i].col0, ldY, M, seg[i].N, t.csum, seg[i].gb, 0, st));
+            ++i;
+            continue;
+        }
+        WgradSlot& s = t.slot[t.next_slot];
+        t.next_slot = (t.next_slot + 1) % t.n_slots;
+        if (s.busy) { HIPCHK(ev_wait(st, s.done)); s.busy = false; }       // the slot's previous GEMMs have read aT / xT
+        int r0 = 0;
+        for (int x = 0; x < nx; ++x) {
+            HIPCHK(launch_transpose(xs[x].p, xs[x].ld, 0, s.xT + (size_t)r0 * M_pad, M_pad, 0, M, xs[x].K, M_pad, 1, st));
+            r0 += xs[x].K;
+        }
+        const int first = i;
+        long rows = 0;
+        for (; i < nseg && seg[i].gw && rows + seg[i].N <= t.aT_rows; ++i) {
+            bf16_t* aT = s.aT + (size_t)rows * M_pad;
+            if (seg[i].gb) HIPCHK(launch_transpose_colsum(dY + seg[i].col0, ldY, aT, M_pad, M, seg[i].N, M_pad, t.csum, seg[i].gb, st));
+            else HIPCHK(launch_transpose(dY + seg[i].col0, ldY, 0, aT, M_pad, 0, M, seg[i].N, M_pad, 1, st));
+            rows += seg[i].N;
+        }
+        if (i == first) return errorf("wgrad: N = %d exceeds the transposed-gradient scratch (%ld rows)", seg[i].N, t.aT_rows);
+        hipStream_t ws = st;
+        if (t.wside) {
+            HIPCHK(ev_record(s.ready, st));
+            HIPCHK(ev_wait(t.wside, s.ready));
+            ws = t.wside;
+        }
+        rows = 0;
+        for (int j = first; j < i; ++j) {
+            CHK(t_wgrad_gemm(t, ws, s.aT + (size_t)rows * M_pad, s.xT, seg[j].N, K, M_pad, seg[j].gw));
+            rows += seg[j].N;
+        }
+        if (t.wside) { HIPCHK(ev_record(s.done, t.wside)); s.busy = true; }
+    }
+    return 0;
+}
+
+// single layer
+static inline int t_wgrad(TrainScratch& t, hipStream_t st, const bf16_t* dY, long ldY, int col0, int N, const bf16_t* X, long ldX, int K, int M,
+                          int M_pad, float* gw, float* gb) {
+    if (!gw && !gb) return 0;
+    const WgradSeg seg{col0, N, gw, gb};
+    const WgradX x{X, ldX, K};
+    return t_wgrad_group(t, st, dY, ldY, &seg, 1, &x, 1, M, M_pad);
 }
 
 // flash-attention backward of one head_dim-128 attention: o / dO token-major (row stride D), the first n_first positions of a sample in

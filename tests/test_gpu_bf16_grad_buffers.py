@@ -105,3 +105,48 @@ def test_bf16_buffers_are_refused_outside_the_block_linears(gpu):
     ad.engine.clear_grads()
     ad.engine.set_train_scope(False)
     ad.engine.close()
+
+
+@pytest.mark.parametrize("family", ["flux", "qwen"])
+def test_weight_gradients_on_the_side_stream_are_bit_identical_to_the_serial_schedule(gpu, family):
+    """mi355_tune_set(26, .): the split-K weight-gradient GEMMs + reductions on the training state's side stream (default) vs on the backward's own
+    stream -- the same kernels on the same operands, only the stream differs: every gradient bit for bit."""
+    from mi355_flow import _lib
+    lib = _lib.load()
+    grads = {}
+    try:
+        for side in (0, 1):
+            lib.mi355_tune_set(26, side)                  # read when the plan's training state is created: a fresh adapter per setting
+            if family == "flux":
+                import test_gpu_flux_backward as TF
+                ad, mod, cfg_o = TF._build(lambda n: any(k in n for k in TF.BLOCK_LINEARS))
+                B = 2
+                inp = TF._inputs(cfg_o, B, 8, 8, 16, seed=5)
+                ad.scheduler.set_timesteps(4)
+                kw = dict(t=torch.full((B,), 900.0), t_next=torch.full((B,), 750.0), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+                          prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(), img_ids=inp["img_ids"].cuda(), guidance_scale=3.5,
+                          noise_level=0.7, compute_log_prob=True, return_kwargs=["log_prob", "noise_pred", "dt"])
+            else:
+                import test_gpu_qwen_backward as TQ
+                from mi355_flow import qwen as qw
+                from oracle import qwen_ref as R
+                cfg_o = R.tiny_config()
+                ad, mod = TQ._build(qw, cfg_o, lambda n: any(k in n for k in TQ.BLOCK_LINEARS))
+                B = 2
+                inp = TQ._inputs(cfg_o, B, 8, 12, 19, 2, True, seed=5)
+                ad.scheduler.set_timesteps(4, mu=0.6)
+                kw = TQ._kw(inp, B, 900.0, 750.0, 0.7, 4.0)
+            for it in range(2):                           # the second step re-uses the operand slots
+                for p in mod.parameters():
+                    p.grad = None
+                out = ad.forward(**kw)
+                ((inp["wlp"].cuda() * out.log_prob).sum() + 3.0 * (inp["wnp"].cuda() * out.noise_pred).mean()).backward()
+            torch.cuda.synchronize()
+            grads[side] = {n: p.grad.clone() for n, p in mod.named_parameters() if p.requires_grad}
+            ad.engine.close()
+    finally:
+        lib.mi355_tune_set(26, 1)
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) >= 40
+    for n in grads[0]:
+        assert torch.equal(grads[0][n], grads[1][n]), n
+    print(f"{family}: {len(grads[0])} gradients, side-stream weight-gradient schedule == serial schedule bit for bit")

@@ -388,3 +388,61 @@ def test_qwen_and_flux_engine_emitted_schedules_are_race_free():
     finally:
         lib.mi355_tune_set(12, 2)
         lib.mi355_tune_set(14, 2)
+
+
+@pytest.mark.parametrize("family", ["qwen", "flux"])
+def test_head_dim_128_training_step_schedules_are_race_free(family):
+    """The optimize() replay step of the Qwen-Image / FLUX.1 engines as emitted: training-mode forward (the text chain of the double-stream blocks
+    on the plan's side stream, per-block stash buffers) + backward (dgrad chain, attention backward and the operand transposes on the caller's
+    stream; the weight-gradient split-K GEMMs and their reductions on the training state's side stream, three operand slots handed over and
+    back by events: mi355_tune_set(26, 1), the default).  Two steps back to back: the second forward overwrites the stash the first backward read."""
+    from mi355_flow import _lib
+    lib = _lib.load()
+    lib.mi355_tune_set(12, 1); lib.mi355_tune_set(14, 1); lib.mi355_tune_set(26, 1)
+    try:
+        if family == "qwen":
+            import test_gpu_qwen_backward as TQ
+            from mi355_flow import qwen as qw
+            from oracle import qwen_ref as R
+            cfg_o = R.tiny_config()
+            ad, mod = TQ._build(qw, cfg_o, lambda n: any(k in n for k in TQ.BLOCK_LINEARS), seed=31)
+            B = 2
+            inp = TQ._inputs(cfg_o, B, 8, 12, 19, 2, True, seed=9)
+            ad.scheduler.set_timesteps(4, mu=0.6)
+            kw = TQ._kw(inp, B, 750.0, 500.0, 0.7, 4.0)
+        else:
+            import test_gpu_flux_backward as TF
+            ad, mod, cfg_o = TF._build(lambda n: any(k in n for k in TF.BLOCK_LINEARS), seed=31)
+            B = 2
+            inp = TF._inputs(cfg_o, B, 8, 8, 13, seed=9)
+            ad.scheduler.set_timesteps(4)
+            kw = dict(t=torch.full((B,), 750.0), t_next=torch.full((B,), 500.0), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+                      prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(), img_ids=inp["img_ids"].cuda(), guidance_scale=3.5,
+                      noise_level=0.7, compute_log_prob=True, return_kwargs=["log_prob", "noise_pred", "dt"])
+        wlp, wnp = inp["wlp"].cuda(), inp["wnp"].cuda()
+
+        def step():
+            for prm in mod.parameters():
+                prm.grad = None
+            out = ad.forward(**kw)
+            ((wlp * out.log_prob).sum() + (wnp * out.noise_pred).mean()).backward()
+
+        try:
+            step()
+            text = _trace_of(lib, step, tag=f"{family}_train_step")
+            import _sched_check as SC
+            s = SC.parse(text)
+            names = {o.name for o in s.ops}
+            assert {"attention128_bwd", "attn128_bwd_prep", "rope_rms_bwd128", "ln_mod_bwd", "gate_mul", "transpose", "gemm.f32", "splitk_reduce"} <= names, sorted(names)
+            assert len(s.streams()) == 3, s.streams()          # caller's stream, text chain, weight gradients
+            races = s.races()
+            assert races == [], races[:5]
+            nw = SC.n_waits(text)
+            needed = [k for k in range(nw) if SC.parse(text, drop_waits=[k]).races(limit=1)]
+            print(f"{family} optimize() step: {sum(1 for o in s.ops if o.regions)} launches on 3 streams, {nw} stream waits, {len(needed)} of them "
+                  f"individually necessary, no race")
+            assert nw > 0 and len(needed) >= 0.5 * nw, (nw, len(needed))
+        finally:
+            ad.engine.close()
+    finally:
+        lib.mi355_tune_set(12, 2); lib.mi355_tune_set(14, 2)
