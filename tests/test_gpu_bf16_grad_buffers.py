@@ -107,7 +107,7 @@ def test_bf16_buffers_are_refused_outside_the_block_linears(gpu):
     ad.engine.close()
 
 
-@pytest.mark.parametrize("family", ["flux", "qwen"])
+@pytest.mark.parametrize("family", ["sd3", "flux", "qwen"])
 def test_weight_gradients_on_the_side_stream_are_bit_identical_to_the_serial_schedule(gpu, family):
     """mi355_tune_set(26, .): the split-K weight-gradient GEMMs + reductions on the training state's side stream (default) vs on the backward's own
     stream -- the same kernels on the same operands, only the stream differs: every gradient bit for bit."""
@@ -116,8 +116,18 @@ def test_weight_gradients_on_the_side_stream_are_bit_identical_to_the_serial_sch
     grads = {}
     try:
         for side in (0, 1):
-            lib.mi355_tune_set(26, side)                  # read when the plan's training state is created: a fresh adapter per setting
-            if family == "flux":
+            lib.mi355_tune_set(26, side)                  # (FLUX.1 / Qwen-Image read it when the plan's training state is created: a fresh adapter per setting)
+            if family == "sd3":
+                import test_gpu_backward as TB
+                ad, mod, _ = TB._build(lambda n: any(k in n for k in TB.BLOCK_LINEARS))
+                B = 2
+                inp = TB._inputs(B, 16, 16, 13, seed=5)
+                ad.scheduler.set_timesteps(4)
+                kw = dict(t=torch.full((B,), 900.0), t_next=torch.full((B,), 750.0), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+                          prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(), negative_prompt_embeds=inp["ne"].cuda(),
+                          negative_pooled_prompt_embeds=inp["npl"].cuda(), guidance_scale=4.5, noise_level=0.7, compute_log_prob=True,
+                          return_kwargs=["log_prob", "noise_pred", "dt"])
+            elif family == "flux":
                 import test_gpu_flux_backward as TF
                 ad, mod, cfg_o = TF._build(lambda n: any(k in n for k in TF.BLOCK_LINEARS))
                 B = 2
