@@ -695,11 +695,49 @@ int grad_buf_dtype(const void* p) {
 }
 int grad_buf_esize(const void* p) { return grad_buf_dtype(p) == DT_F32 ? 4 : 2; }
 
-// mi355_tune_set(26, .): 1 (default) = the weight-gradient GEMMs of the head_dim-128 engines' backward (train_common.h) run on a side stream of
-// the plan's training state, 0 = on the backward's own stream.  Read when a plan's training state is created.
+// mi355_tune_set(26, .): the weight-gradient GEMMs (+ their split-K reductions) of the backward on a side stream of the plan's training state.
+// 1 (default) = in the head_dim-128 engines (FLUX.1 / Qwen-Image, train_common.h; read when a plan's training state is created), 2 = in the SD3.5
+// engine as well, 0 = nowhere.  Measured on MI355X, same box, optimize() step of the reference's default target modules at B = 1, 1024^2
+// (profiles/r04i_*): FLUX.1 271.3 -> 249.1 ms, Qwen-Image (true CFG) 521.2 -> 468.7 ms -- their 3072 x 3072 gradients are 144 output tiles x 2
+// splits = 288 workgroups on 256 CUs, two half-empty rounds that the dgrad / attention-backward chain fills.  SD3.5-medium (1536 x 1536: 144
+// tiles of 128 x 128, two per CU) at B = 2, 1024^2 (profiles/r04j_*): attention projections trainable 91.6 -> 89.1 ms, every block linear
+// trainable 110.2 -> 112.6 ms -- no consistent gain, so it stays opt-in there.  Bit-identical either way (same kernels, operands, order).
 static int g_wgrad_side = 1;
-void set_wgrad_side(int v) { g_wgrad_side = v != 0; }
+void set_wgrad_side(int v) { g_wgrad_side = v < 0 ? 0 : v > 2 ? 2 : v; }
 int get_wgrad_side() { return g_wgrad_side; }
+
+// Split-K factor of a weight-gradient GEMM.  mi355_tune_set(27, .): 0 = the round-2 rule (about 768 tiles of 128 x 128 in flight), 1 (default)
+// = the smallest modelled time over s = 1 .. 16: launch_simple runs 256 x 256 tiles, one workgroup per CU, when N >= 256 and there are >= 128
+// of them, else 128 x 128 tiles, two per CU; a launch takes ceil(tiles * s / slots) rounds of M_pad / s contraction rows (20.75 ns per row and
+// 256 x 256 tile, 7.2 ns per 128 x 128 tile: measured, profiles/r04h_qwen_train_step_kernel_stats.txt) and its reduction streams s partial
+// copies at ~5 TB/s.  E.g. a 3072 x 3072 gradient over 8192 rows: 144 tiles, s = 2 -> 288 workgroups = 2 rounds of 85 us; s = 3 -> 2 rounds of 57.
+static int g_wgrad_split_model = 1;
+void set_wgrad_split_model(int v) { g_wgrad_split_model = v != 0; }
+int wgrad_split(int N, int K, int M_pad, size_t part_floats) {
+    const int nt = M_pad / 64;
+    int cap = nt / 2 < 16 ? nt / 2 : 16;
+    if (cap < 1) cap = 1;
+    while (cap > 1 && (size_t)cap * N * K > part_floats) --cap;
+    if (!g_wgrad_split_model) {
+        const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
+        int split = (int)((768 + tiles - 1) / tiles);
+        if (split > cap) split = cap;
+        return split < 1 ? 1 : split;
+    }
+    const long t256 = (long)((N + 255) / 256) * ((K + 255) / 256), t128 = (long)((N + 127) / 128) * ((K + 127) / 128);
+    const bool big = K >= 256 && t256 >= 128;
+    const double tiles = big ? (double)t256 : (double)t128, slots = big ? 256.0 : 512.0, ns_row = big ? 20.75 : 7.2;
+    int best = 1;
+    double best_t = 1e30;
+    for (int s = 1; s <= cap; ++s) {
+        const double rounds = (double)(long)((tiles * s + slots - 1) / slots);
+        const double gemm = rounds * ns_row * (double)M_pad / s;                                    // ns
+        const double red = s > 1 ? 3000.0 + (double)s * N * K * 4.0 / 5000.0 : 0.0;                // ns (5 TB/s = 5000 bytes / ns)
+        const double t = gemm + red;
+        if (t < best_t * 0.999) { best_t = t; best = s; }
+    }
+    return best;
+}
 
 hipError_t launch_ln_mod_bwd(const LnModBwdParams& p, hipStream_t st) {
     if (sched_trace_on()) {

@@ -80,13 +80,7 @@ static inline int t_wgrad_join(TrainScratch& t, hipStream_t st) {
 // One GEMM of a group on stream `ws`: dW = aT[N][M_pad] . xT[K][M_pad]^T, split-K over the token dimension into partial buffers + a fixed-order
 // reduction (deterministic; the reduction rounds to bf16 itself for a bf16 gradient buffer)
 static inline int t_wgrad_gemm(const TrainScratch& t, hipStream_t ws, const bf16_t* aT, const bf16_t* xT, int N, int K, int M_pad, float* gw) {
-    const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
-    int split = (int)((768 + tiles - 1) / tiles);
-    const int nt = M_pad / 64;
-    if (split > nt / 2) split = nt / 2;
-    if (split > 16) split = 16;
-    if (split < 1) split = 1;
-    while (split > 1 && (size_t)split * N * K > t.part_floats) --split;
+    const int split = wgrad_split(N, K, M_pad, t.part_floats);
     GemmParams g = make_gemm(aT, M_pad, xT, M_pad, N, K, M_pad, EPI_F32, nullptr, nullptr, K);
     g.q_scale = 1.0f;
     if (split <= 1 && grad_buf_dtype(gw) == DT_F32) {

@@ -116,7 +116,7 @@ def test_weight_gradients_on_the_side_stream_are_bit_identical_to_the_serial_sch
     grads = {}
     try:
         for side in (0, 1):
-            lib.mi355_tune_set(26, side)                  # (FLUX.1 / Qwen-Image read it when the plan's training state is created: a fresh adapter per setting)
+            lib.mi355_tune_set(26, side * (2 if family == "sd3" else 1))                  # (FLUX.1 / Qwen-Image read it when the plan's training state is created: a fresh adapter per setting)
             if family == "sd3":
                 import test_gpu_backward as TB
                 ad, mod, _ = TB._build(lambda n: any(k in n for k in TB.BLOCK_LINEARS))

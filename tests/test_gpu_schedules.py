@@ -296,7 +296,7 @@ def test_sd3_engine_emitted_schedule_is_race_free():
 def test_sd3_training_step_schedule_is_race_free(scope):
     """The optimize() replay step (training-mode forward + backward through torch autograd) as the engine emits it: the context-stream chain
     of both halves runs on the training state's side stream (mi355_tune_set(22, 1), the default); the backward's weight-gradient GEMMs and their
-    reductions on a third stream (mi355_tune_set(26, 1), the default), fed through three operand slots by the two chains.  Every launch of both halves reports its regions (GEMMs incl. the activation
+    reductions on a third stream (mi355_tune_set(26, 2): opt-in for this engine), fed through three operand slots by the two chains.  Every launch of both halves reports its regions (GEMMs incl. the activation
     stashes, attention + log-sum-exp, the backward's elementwise / transpose / split-K / attention-backward kernels, the stash copies)."""
     from mi355_flow import _lib
     from test_gpu_backward import _build, _inputs, BLOCK_LINEARS
@@ -317,6 +317,7 @@ def test_sd3_training_step_schedule_is_race_free(scope):
         out = ad.forward(**kw)
         (wlp * out.log_prob).sum().backward()
 
+    lib.mi355_tune_set(26, 2)                         # (opt-in for this engine)
     try:
         step()
         text = _trace_of(lib, step, tag="sd3_train_step_" + scope)
@@ -333,6 +334,7 @@ def test_sd3_training_step_schedule_is_race_free(scope):
               f"{len(needed)} of them individually necessary, no race")
         assert nw > 0 and len(needed) >= 0.6 * nw, (nw, len(needed))
     finally:
+        lib.mi355_tune_set(26, 1)
         ad.engine.close()
 
 
@@ -392,8 +394,8 @@ def test_qwen_and_flux_engine_emitted_schedules_are_race_free():
 
 @pytest.mark.parametrize("family", ["qwen", "flux"])
 def test_head_dim_128_training_step_schedules_are_race_free(family):
-    """The optimize() replay step of the Qwen-Image / FLUX.1 engines as emitted: training-mode forward (the text chain of the double-stream blocks
-    on the plan's side stream, per-block stash buffers) + backward (dgrad chain, attention backward and the operand transposes on the caller's
+    """The optimize() replay step of the Qwen-Image / FLUX.1 engines as emitted: training-mode forward (per-block stash buffers; Qwen-Image: the
+    text chain of the blocks on the plan's side stream, as in its no-grad forward) + backward (dgrad chain, attention backward and the operand transposes on the caller's
     stream; the weight-gradient split-K GEMMs and their reductions on the training state's side stream, three operand slots handed over and
     back by events: mi355_tune_set(26, 1), the default).  Two steps back to back: the second forward overwrites the stash the first backward read."""
     from mi355_flow import _lib
@@ -434,12 +436,13 @@ def test_head_dim_128_training_step_schedules_are_race_free(family):
             s = SC.parse(text)
             names = {o.name for o in s.ops}
             assert {"attention128_bwd", "attn128_bwd_prep", "rope_rms_bwd128", "ln_mod_bwd", "gate_mul", "transpose", "gemm.f32"} <= names, sorted(names)
-            assert len(s.streams()) == 3, s.streams()          # caller's stream, text chain, weight gradients
+            n_streams = 3 if family == "qwen" else 2           # caller's stream, [text chain of the forward: Qwen-Image,] weight gradients
+            assert len(s.streams()) == n_streams, s.streams()
             races = s.races()
             assert races == [], races[:5]
             nw = SC.n_waits(text)
             needed = [k for k in range(nw) if SC.parse(text, drop_waits=[k]).races(limit=1)]
-            print(f"{family} optimize() step: {sum(1 for o in s.ops if o.regions)} launches on 3 streams, {nw} stream waits, {len(needed)} of them "
+            print(f"{family} optimize() step: {sum(1 for o in s.ops if o.regions)} launches on {n_streams} streams, {nw} stream waits, {len(needed)} of them "
                   f"individually necessary, no race")
             assert nw > 0 and len(needed) >= 0.5 * nw, (nw, len(needed))
         finally:
