@@ -710,15 +710,18 @@ int get_wgrad_side() { return g_wgrad_side; }
 // = the smallest modelled time over s = 1 .. 16: launch_simple runs 256 x 256 tiles, one workgroup per CU, when N >= 256 and there are >= 128
 // of them, else 128 x 128 tiles, two per CU; a launch takes ceil(tiles * s / slots) rounds of M_pad / s contraction rows (20.75 ns per row and
 // 256 x 256 tile, 7.2 ns per 128 x 128 tile: measured, profiles/r04h_qwen_train_step_kernel_stats.txt) and its reduction streams s partial
-// copies at ~5 TB/s.  E.g. a 3072 x 3072 gradient over 8192 rows: 144 tiles, s = 2 -> 288 workgroups = 2 rounds of 85 us; s = 3 -> 2 rounds of 57.
+// copies at ~5 TB/s.  The model describes a GEMM that has the GPU to itself: `overlapped` launches (the side-stream schedule of key 26, whose
+// partial rounds are filled by the other stream) keep the round-2 rule.  A/B on MI355X (profiles/r04k_*, optimize() step, ms, rule -> model):
+// SD3.5 B = 2 1024^2 serial: attention projections 92.4 -> 91.7, every block linear 111.5 -> 108.3; overlapped FLUX.1 249.5 -> 252.6 and
+// Qwen-Image 471.2 -> 479.6 (more partial-sum traffic for rounds that were not idle): hence the exception.
 static int g_wgrad_split_model = 1;
 void set_wgrad_split_model(int v) { g_wgrad_split_model = v != 0; }
-int wgrad_split(int N, int K, int M_pad, size_t part_floats) {
+int wgrad_split(int N, int K, int M_pad, size_t part_floats, bool overlapped) {
     const int nt = M_pad / 64;
     int cap = nt / 2 < 16 ? nt / 2 : 16;
     if (cap < 1) cap = 1;
     while (cap > 1 && (size_t)cap * N * K > part_floats) --cap;
-    if (!g_wgrad_split_model) {
+    if (!g_wgrad_split_model || overlapped) {
         const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
         int split = (int)((768 + tiles - 1) / tiles);
         if (split > cap) split = cap;

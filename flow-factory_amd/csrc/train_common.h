@@ -80,7 +80,7 @@ static inline int t_wgrad_join(TrainScratch& t, hipStream_t st) {
 // One GEMM of a group on stream `ws`: dW = aT[N][M_pad] . xT[K][M_pad]^T, split-K over the token dimension into partial buffers + a fixed-order
 // reduction (deterministic; the reduction rounds to bf16 itself for a bf16 gradient buffer)
 static inline int t_wgrad_gemm(const TrainScratch& t, hipStream_t ws, const bf16_t* aT, const bf16_t* xT, int N, int K, int M_pad, float* gw) {
-    const int split = wgrad_split(N, K, M_pad, t.part_floats);
+    const int split = wgrad_split(N, K, M_pad, t.part_floats, ws == t.wside && t.wside != nullptr);
     GemmParams g = make_gemm(aT, M_pad, xT, M_pad, N, K, M_pad, EPI_F32, nullptr, nullptr, K);
     g.q_scale = 1.0f;
     if (split <= 1 && grad_buf_dtype(gw) == DT_F32) {
