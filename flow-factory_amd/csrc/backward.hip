@@ -706,6 +706,13 @@ static int g_wgrad_side = 1;
 void set_wgrad_side(int v) { g_wgrad_side = v < 0 ? 0 : v > 2 ? 2 : v; }
 int get_wgrad_side() { return g_wgrad_side; }
 
+// mi355_tune_set(28, .): 1 (default) = the text chain of the Qwen-Image backward (MLP backward, out-projection dgrad | join | joint attention
+// backward | fork | q|k|v producer backward, dgrad, norm backward, and its weight-gradient operand transposes) on the plan's side stream -- the
+// stream and events that carry the text chain of the forward (key 12, same size rule) -- beside the image chain; 0 = in line.
+static int g_train_text_side = 1;
+void set_train_text_side(int v) { g_train_text_side = v != 0; }
+int get_train_text_side() { return g_train_text_side; }
+
 // Split-K factor of a weight-gradient GEMM.  mi355_tune_set(27, .): 0 = the round-2 rule (about 768 tiles of 128 x 128 in flight), 1 (default)
 // = the smallest modelled time over s = 1 .. 16: launch_simple runs 256 x 256 tiles, one workgroup per CU, when N >= 256 and there are >= 128
 // of them, else 128 x 128 tiles, two per CU; a launch takes ceil(tiles * s / slots) rounds of M_pad / s contraction rows (20.75 ns per row and

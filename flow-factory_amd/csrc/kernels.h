@@ -299,6 +299,8 @@ int grad_buf_esize(const void* p);
 void set_wgrad_side(int v);
 int get_wgrad_side();
 // split-K factor of a weight-gradient GEMM dW[N][K] = aT[N][M_pad] . xT[K][M_pad]^T (EPI_F32 through launch_simple) -- backward.hip
+void set_train_text_side(int v);      // key 28
+int get_train_text_side();
 void set_wgrad_split_model(int v);
 int wgrad_split(int N, int K, int M_pad, size_t part_floats, bool overlapped);
 hipError_t launch_unpatch_bwd(const float* dv, bf16_t* out, int Bp, int C, int hp, int wp, int patch, hipStream_t stream);

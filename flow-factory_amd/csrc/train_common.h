@@ -23,6 +23,8 @@ struct TrainScratch {
     float *delta, *nld;
     float *part, *csum, *zero_bias;
     size_t part_floats;
+    bf16_t* hid_c = nullptr;                  // the text chain's own gelu(pre) / column-sum scratch when it runs on a second stream
+    float* csum_c = nullptr;
     // weight gradients: the operand transposes (+ the bias column sums) run on the backward's own stream, the split-K GEMMs and their
     // reductions on `wside` when it exists (mi355_tune_set(26, .)): they are off the critical path -- nothing in the backward reads a weight
     // gradient -- and their partial last rounds (144 output tiles x 2 splits on 256 CUs) fill with the dgrad chain's kernels and vice versa
@@ -99,14 +101,15 @@ static inline int t_wgrad_gemm(const TrainScratch& t, hipStream_t ws, const bf16
 // On `st`: X^T once, the dY column blocks transposed (rows zero-padded to M_pad; the bias gradient = the column sums taken on the way).
 // On the side stream (or `st`): one split-K GEMM + reduction per layer.  A group larger than a slot's aT is cut (X^T is taken again).
 static inline int t_wgrad_group(TrainScratch& t, hipStream_t st, const bf16_t* dY, long ldY, const WgradSeg* seg, int nseg, const WgradX* xs, int nx,
-                                int M, int M_pad) {
+                                int M, int M_pad, bool ctx_chain = false) {
+    float* csum = ctx_chain && t.csum_c ? t.csum_c : t.csum;          // (column-sum partials: one scratch per stream that takes them)
     int K = 0;
     for (int i = 0; i < nx; ++i) K += xs[i].K;
     if (K > t.xT_rows) return errorf("wgrad: K = %d exceeds the transposed-input scratch (%ld rows)", K, t.xT_rows);
     int i = 0;
     while (i < nseg) {
         if (!seg[i].gw) {                              // bias only (or nothing): no GEMM
-            if (seg[i].gb) HIPCHK(launch_colsum(dY + seg[i].col0, ldY, M, seg[i].N, t.csum, seg[i].gb, 0, st));
+            if (seg[i].gb) HIPCHK(launch_colsum(dY + seg[i].col0, ldY, M, seg[i].N, csum, seg[i].gb, 0, st));
             ++i;
             continue;
         }
@@ -122,7 +125,7 @@ static inline int t_wgrad_group(TrainScratch& t, hipStream_t st, const bf16_t* d
         long rows = 0;
         for (; i < nseg && seg[i].gw && rows + seg[i].N <= t.aT_rows; ++i) {
             bf16_t* aT = s.aT + (size_t)rows * M_pad;
-            if (seg[i].gb) HIPCHK(launch_transpose_colsum(dY + seg[i].col0, ldY, aT, M_pad, M, seg[i].N, M_pad, t.csum, seg[i].gb, st));
+            if (seg[i].gb) HIPCHK(launch_transpose_colsum(dY + seg[i].col0, ldY, aT, M_pad, M, seg[i].N, M_pad, csum, seg[i].gb, st));
             else HIPCHK(launch_transpose(dY + seg[i].col0, ldY, 0, aT, M_pad, 0, M, seg[i].N, M_pad, 1, st));
             rows += seg[i].N;
         }
@@ -145,11 +148,11 @@ static inline int t_wgrad_group(TrainScratch& t, hipStream_t st, const bf16_t* d
 
 // single layer
 static inline int t_wgrad(TrainScratch& t, hipStream_t st, const bf16_t* dY, long ldY, int col0, int N, const bf16_t* X, long ldX, int K, int M,
-                          int M_pad, float* gw, float* gb) {
+                          int M_pad, float* gw, float* gb, bool ctx_chain = false) {
     if (!gw && !gb) return 0;
     const WgradSeg seg{col0, N, gw, gb};
     const WgradX x{X, ldX, K};
-    return t_wgrad_group(t, st, dY, ldY, &seg, 1, &x, 1, M, M_pad);
+    return t_wgrad_group(t, st, dY, ldY, &seg, 1, &x, 1, M, M_pad, ctx_chain);
 }
 
 // flash-attention backward of one head_dim-128 attention: o / dO token-major (row stride D), the first n_first positions of a sample in

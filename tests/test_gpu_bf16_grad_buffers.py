@@ -107,16 +107,17 @@ def test_bf16_buffers_are_refused_outside_the_block_linears(gpu):
     ad.engine.close()
 
 
-@pytest.mark.parametrize("family", ["sd3", "flux", "qwen"])
-def test_weight_gradients_on_the_side_stream_are_bit_identical_to_the_serial_schedule(gpu, family):
-    """mi355_tune_set(26, .): the split-K weight-gradient GEMMs + reductions on the training state's side stream (default) vs on the backward's own
-    stream -- the same kernels on the same operands, only the stream differs: every gradient bit for bit."""
+@pytest.mark.parametrize("family,key", [("sd3", 26), ("flux", 26), ("qwen", 26), ("qwen", 28)])
+def test_weight_gradients_on_the_side_stream_are_bit_identical_to_the_serial_schedule(gpu, family, key):
+    """mi355_tune_set(26, .): the split-K weight-gradient GEMMs + reductions on the training state's side stream vs on the backward's own stream;
+    mi355_tune_set(28, .): the text chain of the Qwen-Image backward on the plan's side stream vs in line -- the same kernels on the same
+    operands, only the streams differ: every gradient bit for bit."""
     from mi355_flow import _lib
     lib = _lib.load()
     grads = {}
     try:
         for side in (0, 1):
-            lib.mi355_tune_set(26, side * (2 if family == "sd3" else 1))                  # (FLUX.1 / Qwen-Image read it when the plan's training state is created: a fresh adapter per setting)
+            lib.mi355_tune_set(key, side * (2 if family == "sd3" else 1))                  # (FLUX.1 / Qwen-Image read it when the plan's training state is created: a fresh adapter per setting)
             if family == "sd3":
                 import test_gpu_backward as TB
                 ad, mod, _ = TB._build(lambda n: any(k in n for k in TB.BLOCK_LINEARS))
@@ -155,8 +156,8 @@ def test_weight_gradients_on_the_side_stream_are_bit_identical_to_the_serial_sch
             grads[side] = {n: p.grad.clone() for n, p in mod.named_parameters() if p.requires_grad}
             ad.engine.close()
     finally:
-        lib.mi355_tune_set(26, 1)
+        lib.mi355_tune_set(key, 1)
     assert grads[0].keys() == grads[1].keys() and len(grads[0]) >= 40
     for n in grads[0]:
         assert torch.equal(grads[0][n], grads[1][n]), n
-    print(f"{family}: {len(grads[0])} gradients, side-stream weight-gradient schedule == serial schedule bit for bit")
+    print(f"{family}, key {key}: {len(grads[0])} gradients, side-stream schedule == serial schedule bit for bit")
