@@ -115,6 +115,7 @@ def test_weight_gradients_on_the_side_stream_are_bit_identical_to_the_serial_sch
     from mi355_flow import _lib
     lib = _lib.load()
     grads = {}
+    lib.mi355_tune_set(27, 0)          # one split-K rule for both legs (key 27's modelled factor applies to serial launches only: another summation order)
     try:
         for side in (0, 1):
             lib.mi355_tune_set(key, side * (2 if family == "sd3" else 1))                  # (FLUX.1 / Qwen-Image read it when the plan's training state is created: a fresh adapter per setting)
@@ -157,6 +158,7 @@ def test_weight_gradients_on_the_side_stream_are_bit_identical_to_the_serial_sch
             ad.engine.close()
     finally:
         lib.mi355_tune_set(key, 1)
+        lib.mi355_tune_set(27, 1)
     assert grads[0].keys() == grads[1].keys() and len(grads[0]) >= 40
     for n in grads[0]:
         assert torch.equal(grads[0][n], grads[1][n]), n
