@@ -568,6 +568,23 @@ def main():
                                                   "torch.equal the no-grad replay's; untimed w.r.t. `value`"}
         except Exception as e:  # noqa: BLE001
             out["optimize_step_flux1"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not flux_mode and not args.no_train_step:
+        # ... and for Qwen-Image (round 4: native backward, SURVEY.md 8(f) N1 over N4; BASELINE.json configs[4]'s family): 60 layers, B = 1, 1024^2,
+        # true CFG (forward batch [negative | positive]), the reference's default target modules (6.8 B trainable parameters); own process
+        # (~150 GB of HBM: 41 GB masters + 41 GB engine copy + transposed weights + 37 GB stash), recorded, never raised
+        try:
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "qwen_train_bench.py"), "--batch", "1", "--size", "1024", "--iters", "2"],
+                               capture_output=True, text=True, timeout=420)
+            tb = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            out["optimize_step_qwen_image"] = {"ms_forward_backward": tb["ms_forward_backward"], "ms_forward_train": tb["ms_forward_train"],
+                                               "ms_forward_nograd": tb["ms_forward_nograd"], "achieved": tb["tflops_step"], "unit": "TFLOP/s",
+                                               "frac": tb["frac_of_2500"], "trainable_params": tb["trainable_params"], "ratio_is_one": tb["ratio_is_one"],
+                                               "stash_plus_scratch_GiB": tb["stash_plus_scratch_GiB"], "n_cfg": tb["n_cfg"],
+                                               "note": "Qwen-Image geometry (60 layers), B = 1, 1024^2, true CFG, default target modules "
+                                                       "(qwen_image.py:81-89); grad-mode log-prob torch.equal the no-grad replay's; untimed w.r.t. `value`"}
+        except Exception as e:  # noqa: BLE001
+            out["optimize_step_qwen_image"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not flux_mode and not args.no_families:
         # BASELINE.json configs[2..4] on the driver's box: the other engines' rollouts at their own geometries, 2 denoise
         # steps each (the per-step cost does not depend on the step count), each in its own process (24 / 3 / 41 GB of weights), untimed w.r.t.
