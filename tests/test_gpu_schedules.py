@@ -394,8 +394,8 @@ def test_qwen_and_flux_engine_emitted_schedules_are_race_free():
 
 @pytest.mark.parametrize("family", ["qwen", "flux"])
 def test_head_dim_128_training_step_schedules_are_race_free(family):
-    """The optimize() replay step of the Qwen-Image / FLUX.1 engines as emitted: training-mode forward (per-block stash buffers; Qwen-Image: the
-    text chain of the blocks on the plan's side stream, as in its no-grad forward) + backward (dgrad chain, attention backward and the operand transposes on the caller's
+    """The optimize() replay step of the Qwen-Image / FLUX.1 engines as emitted: training-mode forward (per-block stash buffers; the text chain of
+    the double-stream blocks on the plan's side stream, as in the no-grad forward) + backward (dgrad chain, attention backward and the operand transposes on the caller's
     stream; the weight-gradient split-K GEMMs and their reductions on the training state's side stream, three operand slots handed over and
     back by events: mi355_tune_set(26, 1), the default).  Two steps back to back: the second forward overwrites the stash the first backward read."""
     from mi355_flow import _lib
@@ -436,7 +436,7 @@ def test_head_dim_128_training_step_schedules_are_race_free(family):
             s = SC.parse(text)
             names = {o.name for o in s.ops}
             assert {"attention128_bwd", "attn128_bwd_prep", "rope_rms_bwd128", "ln_mod_bwd", "gate_mul", "transpose", "gemm.f32"} <= names, sorted(names)
-            n_streams = 3 if family == "qwen" else 2           # caller's stream, [text chain of the forward: Qwen-Image,] weight gradients
+            n_streams = 3                                      # caller's stream, text chain (forward; Qwen-Image: backward too), weight gradients
             assert len(s.streams()) == n_streams, s.streams()
             races = s.races()
             assert races == [], races[:5]
