@@ -9,7 +9,7 @@ set -x
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r4final
 mkdir -p $OUT; rm -rf $OUT/prof_*
-PARTS=${PARTS:-"tests bench stats1 stats2 pmc"}
+PARTS=${PARTS:-"bench tests stats1 pmc stats2"}
 has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0 MI355_ROUND=4
 echo "commit ${MI355_COMMIT:-unknown}" > $OUT/commit.txt
