@@ -141,6 +141,100 @@ def test_ddp_reducer_is_armed_around_the_engine_autograd_node(tmp_path):
     assert all(int(np.load(tmp_path / f"ddp_{r}.npy")[0]) == 1 for r in range(2))
 
 
+def _qwen_replay_ddp_worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import types
+    import _plugin_fakes as F
+    import mi355_flow.engine as ME
+    from mi355_flow import autograd as AG
+    from mi355_flow.binding import LiveWeights
+    ME.sde_step, ME.sde_step_bwd = F.oracle_sde_step, F.oracle_sde_step_bwd          # the fused step kernels' CPU stand-ins (oracle arithmetic)
+    names = ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_q.bias", "transformer_blocks.0.attn.to_k.weight", "img_in.weight"]
+    mod = F.build_module_tree({n: ((8, 8) if n.endswith("weight") else (8,)) for n in names}, buffers=(), seed=3)      # same values on both ranks
+    mod.get_submodule("img_in").weight.requires_grad_(False)                      # frozen: outside the reducer and outside the native scope
+    ddp = torch.nn.parallel.DistributedDataParallel(mod)
+
+    class Eng:                                                                    # host API of QwenEngine that the replay node uses
+        def __init__(self):
+            self.bound, self.bufs = {}, {}
+
+        def param_names(self):
+            return list(names)
+
+        def bind_tensor(self, name, t):
+            self.bound[name] = t.detach().float().clone()
+
+        def finish_binding(self):
+            pass
+
+        def grad_supported(self, name):
+            return 1 if ".attn.to_" in name else 0
+
+        def set_grad(self, name, t):
+            assert self.grad_supported(name)
+            self.bufs[name] = t
+
+        def clear_grads(self):
+            self.bufs = {}
+
+    class Plan:                                                                   # QwenPlan.forward_train / backward
+        def __init__(self, eng):
+            self.engine, self._train_serial = eng, 0
+
+        def forward_train(self, latents, t_model, embeds, lens, guidance):
+            self._train_serial += 1
+            return (0.5 * latents.float()).to(torch.bfloat16)
+
+        def backward(self, dv):
+            assert torch.isfinite(dv).all() and float(dv.abs().sum()) > 0          # the scheduler-step adjoint produced d loss / d v
+            for buf in self.engine.bufs.values():
+                buf.fill_(float(rank + 1))                                        # this rank's micro-batch gradient
+
+    eng = Eng()
+    host = types.SimpleNamespace(engine=eng)
+    host._live_weights = LiveWeights(eng, lambda: ddp)
+    host._live_weights.sync()
+    assert AG.unsupported_reason(host) is None
+    g = torch.Generator().manual_seed(5 + rank)                                   # different data per rank
+    B = 2
+    x, x1 = torch.randn(B, 16, 64, generator=g).bfloat16(), torch.randn(B, 16, 64, generator=g).bfloat16()
+    call = dict(latents=x, train_args=(x, torch.full((B,), 900.0), None, None, 1.0), sigma=torch.full((B,), 0.9), sigma_next=torch.full((B,), 0.75),
+                eta=0.7, sigma_max=0.95, dynamics="Flow-SDE", next_latents=x1, compute_log_prob=True)
+    trainable = [p for p in mod.parameters() if p.requires_grad]
+    lp, npred, mean, std, dtt = AG.qwen_replay(host, Plan(eng), call)
+    assert lp.requires_grad and lp.shape == (B,)
+    lp.sum().backward()
+    ok = all(p.grad is not None and torch.allclose(p.grad, torch.full_like(p.grad, 1.5)) for p in trainable)      # mean of the ranks' 1 and 2
+    ok = ok and mod.get_submodule("img_in").weight.grad is None and eng.bufs == {}
+    for p in trainable:
+        p.grad = None
+    with ddp.no_sync():                                                           # accumulation window: no reduction
+        lp2 = AG.qwen_replay(host, Plan(eng), call)[0]
+        lp2.sum().backward()
+    ok = ok and all(torch.allclose(p.grad, torch.full_like(p.grad, float(rank + 1))) for p in trainable)
+    np.save(os.path.join(out_dir, f"qwen_ddp_{rank}.npy"), np.array([int(ok)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_qwen_replay_node_all_reduces_engine_gradients_under_ddp(tmp_path):
+    """Round 4: the FLUX.1 / Qwen-Image replay (`mi355_flow.autograd.flux_replay` / `qwen_replay`: training-mode forward -> scheduler step ->
+    step adjoint -> engine backward into registered buffers) under DistributedDataParallel on two ranks: the node arms the reducer itself,
+    the engine-written gradients are bucket-all-reduced (mean over ranks), a frozen parameter outside the native scope stays out of both,
+    and a `no_sync()` window accumulates locally.  Engine and plan are doubles of the host API; the scheduler step and its adjoint are the
+    oracle's (`_plugin_fakes.oracle_sde_step[_bwd]`)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    mp.spawn(_qwen_replay_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(int(np.load(tmp_path / f"qwen_ddp_{r}.npy")[0]) == 1 for r in range(2))
+
+
 def _fsdp2_worker(rank, world, port, out_dir):
     for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
         if p not in sys.path:
