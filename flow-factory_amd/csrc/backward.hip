@@ -706,7 +706,7 @@ static int g_wgrad_side = 1;
 void set_wgrad_side(int v) { g_wgrad_side = v < 0 ? 0 : v > 2 ? 2 : v; }
 int get_wgrad_side() { return g_wgrad_side; }
 
-// mi355_tune_set(28, .): 1 (default) = the text chain of the Qwen-Image backward (MLP backward, out-projection dgrad | join | joint attention
+// mi355_tune_set(28, .): 1 (default) = the text chain of the Qwen-Image backward and of the FLUX.1 double blocks' backward (MLP backward, out-projection dgrad | join | joint attention
 // backward | fork | q|k|v producer backward, dgrad, norm backward, and its weight-gradient operand transposes) on the plan's side stream -- the
 // stream and events that carry the text chain of the forward (key 12, same size rule) -- beside the image chain; 0 = in line.  Measured on
 // MI355X (profiles/r04l_*, 60 layers, true CFG, B = 1, optimize() step in line -> side): 512^2 164.4 -> 141.1 ms, 1024^2 470.2 -> 470.0 ms.
