@@ -709,7 +709,8 @@ int get_wgrad_side() { return g_wgrad_side; }
 // mi355_tune_set(28, .): 1 (default) = the text chain of the Qwen-Image backward and of the FLUX.1 double blocks' backward (MLP backward, out-projection dgrad | join | joint attention
 // backward | fork | q|k|v producer backward, dgrad, norm backward, and its weight-gradient operand transposes) on the plan's side stream -- the
 // stream and events that carry the text chain of the forward (key 12, same size rule) -- beside the image chain; 0 = in line.  Measured on
-// MI355X (profiles/r04l_*, 60 layers, true CFG, B = 1, optimize() step in line -> side): 512^2 164.4 -> 141.1 ms, 1024^2 470.2 -> 470.0 ms.
+// MI355X (profiles/r04l_*, Qwen-Image 60 layers, true CFG, B = 1, optimize() step in line -> side): 512^2 164.4 -> 141.1 ms, 1024^2 470.2 ->
+// 470.0 ms; FLUX.1-dev B = 1 (profiles/r04q_*): 512^2 120.2 -> 116.0 ms, 1024^2 256.5 -> 253.2 ms.
 // Bit-identical either way.
 static int g_train_text_side = 1;
 void set_train_text_side(int v) { g_train_text_side = v != 0; }
