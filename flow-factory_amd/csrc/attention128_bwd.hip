@@ -164,7 +164,9 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dkv_kernel(AttnBwd
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lk = lane & 31, lg = lane >> 5;
     constexpr int KB = 32 * NWAVES;
-    const int nkb = (p.S + KB - 1) / KB;
+    const int Sk = p.S_kv > 0 ? p.S_kv : p.S;                       // keys: the queries' own sequence, or another one (cross-attention)
+    const long Skp = p.S_kv > 0 ? p.S_kv_pad : p.S_pad;
+    const int nkb = (Sk + KB - 1) / KB;
     const int nwg = nkb * p.H * p.B;
     int wid = blockIdx.x;
     {   // XCD-aware work order: the key blocks of one (b, h) share an L2
@@ -179,16 +181,16 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dkv_kernel(AttnBwd
     // first 8 lanes of one 16-byte LDS-DMA instruction (every wave: 9 VM operations per tile)
     const float* NLg = p.nld + bh * p.S_pad * 2 + wave * 32 + (lane & 7) * 4;
     const int key = kblk * KB + wave * 32 + lk;
-    const int key_ld = key < p.S ? key : p.S - 1;
+    const int key_ld = key < Sk ? key : Sk - 1;
     // ragged text (Qwen-Image): keys >= kv_len[b] are masked in the forward; their P is zero here, so their dK / dV rows come out as zeros
-    int Skv = p.S;
+    int Skv = Sk;
     if (p.kv_len) Skv = min(Skv, max(1, __builtin_amdgcn_readfirstlane(p.kv_len[bh / p.H])));
     const bool key_ok = key < Skv;
     bf16x8 kf[8], vf[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        kf[j] = *(const bf16x8*)(p.k + (bh * p.S_pad + key_ld) * HD + j * 16 + lg * 8);
-        vf[j] = *(const bf16x8*)(p.v + (bh * p.S_pad + key_ld) * HD + j * 16 + lg * 8);
+        kf[j] = *(const bf16x8*)(p.k + (bh * Skp + key_ld) * HD + j * 16 + lg * 8);
+        vf[j] = *(const bf16x8*)(p.v + (bh * Skp + key_ld) * HD + j * 16 + lg * 8);
     }
     auto stage = [&](int t, int buf) {
         char* base = smem + buf * ST1;
@@ -303,8 +305,8 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dkv_kernel(AttnBwd
     __syncthreads();     // every wave is done with the ring: reuse it for the output transposes (8 KiB per wave)
     char* ob = smem + wave * 8192;
     const int row0 = kblk * KB + wave * 32;
-    store_rows128(dk, LN2, ob, p.dk + bh * p.S_pad * HD, row0, p.S, lane);
-    store_rows128(dv, 1.0f, ob, p.dv + bh * p.S_pad * HD, row0, p.S, lane);
+    store_rows128(dk, LN2, ob, p.dk + bh * Skp * HD, row0, Sk, lane);
+    store_rows128(dv, 1.0f, ob, p.dv + bh * Skp * HD, row0, Sk, lane);
 }
 
 // ---- pass 2: dQ.  LDS stage: K [2 subs][64 keys][64 d] | V [2 subs][64 keys][64 d]; ring of 4 (128 KiB)
@@ -325,8 +327,9 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dq_kernel(AttnBwdP
     }
     const int qblk = wid % nqb;
     const long bh = wid / nqb;
-    const bf16_t* Kg = p.k + bh * p.S_pad * HD;
-    const bf16_t* Vg = p.v + bh * p.S_pad * HD;
+    const long Skp = p.S_kv > 0 ? p.S_kv_pad : p.S_pad;               // (cross-attention: the keys are another sequence)
+    const bf16_t* Kg = p.k + bh * Skp * HD;
+    const bf16_t* Vg = p.v + bh * Skp * HD;
     const int q_row = qblk * QB + wave * 32 + lq;
     const int q_ld = q_row < p.S ? q_row : p.S - 1;
     bf16x8 qf[8], of[8];
@@ -370,7 +373,7 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dq_kernel(AttnBwdP
     f32x16 dq[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) dq[j] = (f32x16){0};
-    int Skv = p.S;                   // ragged text: this sample's keys end at kv_len[b]
+    int Skv = p.S_kv > 0 ? p.S_kv : p.S;      // ragged text: this sample's keys end at kv_len[b]
     if (p.kv_len) Skv = min(Skv, max(1, __builtin_amdgcn_readfirstlane(p.kv_len[bh / p.H])));
     const int nt = (Skv + TB - 1) / TB;
     stage(0, 0);
@@ -540,13 +543,15 @@ __global__ __launch_bounds__(256) void rope_rms_bwd128_kernel(RopeRmsBwdParams p
 }  // namespace
 
 hipError_t launch_attention128_bwd(const AttnBwdParams& p, hipStream_t stream) {
+    const int Sk = p.S_kv > 0 ? p.S_kv : p.S;
+    const long Skp = p.S_kv > 0 ? p.S_kv_pad : p.S_pad;
+    if (p.S <= 0 || p.S_pad % TB != 0 || p.S_pad < p.S || Skp % TB != 0 || Skp < Sk || !p.nld) return hipErrorInvalidValue;
     if (sched_trace_on()) {
-        const size_t bhs = (size_t)p.B * p.H * p.S_pad;
-        sched_trace_launch("attention128_bwd", stream, {treg(p.q, bhs * 256), treg(p.k, bhs * 256), treg(p.v, bhs * 256), treg(p.doh, bhs * 256),
+        const size_t bhs = (size_t)p.B * p.H * p.S_pad, bhk = (size_t)p.B * p.H * Skp;
+        sched_trace_launch("attention128_bwd", stream, {treg(p.q, bhs * 256), treg(p.k, bhk * 256), treg(p.v, bhk * 256), treg(p.doh, bhs * 256),
                                                         treg(p.lse, bhs * 4), treg(p.delta, bhs * 4), treg(p.nld, bhs * 8)},
-                           {treg(p.dq, bhs * 256), treg(p.dk, bhs * 256), treg(p.dv, bhs * 256)});
+                           {treg(p.dq, bhs * 256), treg(p.dk, bhk * 256), treg(p.dv, bhk * 256)});
     }
-    if (p.S <= 0 || p.S_pad % TB != 0 || p.S_pad < p.S || !p.nld) return hipErrorInvalidValue;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)attn128_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NST1 * ST1);
@@ -555,9 +560,9 @@ hipError_t launch_attention128_bwd(const AttnBwdParams& p, hipStream_t stream) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int nb = (p.S + 32 * NWAVES - 1) / (32 * NWAVES);
-    hipLaunchKernelGGL(attn128_bwd_dkv_kernel, dim3(nb * p.H * p.B), dim3(NWAVES * 64), NST1 * ST1, stream, p);
-    hipLaunchKernelGGL(attn128_bwd_dq_kernel, dim3(nb * p.H * p.B), dim3(NWAVES * 64), NST2 * ST2, stream, p);
+    const int nbq = (p.S + 32 * NWAVES - 1) / (32 * NWAVES), nbk = (Sk + 32 * NWAVES - 1) / (32 * NWAVES);
+    hipLaunchKernelGGL(attn128_bwd_dkv_kernel, dim3(nbk * p.H * p.B), dim3(NWAVES * 64), NST1 * ST1, stream, p);
+    hipLaunchKernelGGL(attn128_bwd_dq_kernel, dim3(nbq * p.H * p.B), dim3(NWAVES * 64), NST2 * ST2, stream, p);
     return hipGetLastError();
 }
 

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void norm_rope_full_kernel(NormRopeFullParams 
                 for (int e = 0; e < 8; ++e) ss += x[it][e] * x[it][e];
             }
         const float rstd = rsqrtf(wave_sum_dpp(ss) / (float)(p.H * 128) + p.eps);
+        if (p.rstd_out && lane == 0) p.rstd_out[m] = rstd;       // (training-mode forward; a runtime branch: same binary as the rollout's)
         float cs[4][2] = {{1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}};
         if (p.cs) {
             const float4 c01 = *(const float4*)(p.cs + (long)s * 64 + (lane & 15) * 4), c23 = *(const float4*)(p.cs + (long)s * 64 + (lane & 15) * 4 + 2);
@@ -192,6 +193,74 @@ __global__ __launch_bounds__(256) void norm_rope_full_kernel(NormRopeFullParams 
 #pragma unroll
         for (int it = 0; it < NI; ++it)
             if ((lane & 15) == 0 && it * 4 + hl < p.H) dst[it * 4 + hl] = mx[it];
+    }
+}
+
+// backward of norm_rope_full_kernel for one tensor (see NormRopeFullBwdParams): one wave per token, the forward's lane mapping (a head per
+// 16-lane DPP row, 8 features per lane, H / 4 passes), 16-byte accesses.  Forward per element pair (a, b) of a head, x = projection + bias:
+//   (a', b') = (a, b) * rstd * (w_a, w_b);  stored (a' c - b' s, b' c + a' s) * out_scale.
+template <int MAXH>
+__global__ __launch_bounds__(256) void norm_rope_full_bwd_kernel(NormRopeFullBwdParams p) {
+    constexpr int NI = MAXH / 4;
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= p.M) return;
+    const int hl = lane >> 4, d0 = (lane & 15) * 8;
+    const int b = m / p.rows_per_sample;
+    const int s = m - b * p.rows_per_sample + p.s_off;
+    bf16_t* orow = p.out + (long)m * p.out_ld + p.col + lane * 8;
+    if (!p.weight) {            // gather only (the V gradient)
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int h = it * 4 + hl;
+            if (h < p.H) *(uint4*)(orow + it * 512) = *(const uint4*)(p.dy + (((long)b * p.H + h) * p.S_pad + s) * 128 + d0);
+        }
+        return;
+    }
+    float cs[4][2] = {{1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}, {1.f, 0.f}};
+    if (p.cs) {
+        const float4 c01 = *(const float4*)(p.cs + (long)s * 64 + (lane & 15) * 4), c23 = *(const float4*)(p.cs + (long)s * 64 + (lane & 15) * 4 + 2);
+        cs[0][0] = c01.x; cs[0][1] = c01.y; cs[1][0] = c01.z; cs[1][1] = c01.w;
+        cs[2][0] = c23.x; cs[2][1] = c23.y; cs[3][0] = c23.z; cs[3][1] = c23.w;
+    }
+    const float inv_scale = 1.0f / p.out_scale;
+    float xh[NI][8], g[NI][8];
+    float dot = 0.f;
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int h = it * 4 + hl;
+        if (h < p.H) {
+            const long src = (((long)b * p.H + h) * p.S_pad + s) * 128 + d0;
+            float yv[8], dv[8];
+            unpack8(*(const uint4*)(p.y + src), yv);
+            unpack8(*(const uint4*)(p.dy + src), dv);
+            const float4 w0 = *(const float4*)(p.weight + h * 128 + d0), w1 = *(const float4*)(p.weight + h * 128 + d0 + 4);
+            const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float c = cs[j][0], sn = cs[j][1];
+                const float z0 = yv[2 * j] * inv_scale, z1 = yv[2 * j + 1] * inv_scale;          // un-scale, un-rotate: y = R^T z
+                const float y0 = z0 * c + z1 * sn, y1 = z1 * c - z0 * sn;
+                const float e0 = dv[2 * j] * p.out_scale, e1 = dv[2 * j + 1] * p.out_scale;      // d z = d y~ * out_scale; d y = R^T d z
+                const float dy0 = e0 * c + e1 * sn, dy1 = e1 * c - e0 * sn;
+                xh[it][2 * j] = y0 / w[2 * j]; xh[it][2 * j + 1] = y1 / w[2 * j + 1];
+                g[it][2 * j] = dy0 * w[2 * j]; g[it][2 * j + 1] = dy1 * w[2 * j + 1];
+                dot += g[it][2 * j] * xh[it][2 * j] + g[it][2 * j + 1] * xh[it][2 * j + 1];
+            }
+        }
+    }
+    const float mean = wave_sum_dpp(dot) / (float)(p.H * 128);
+    const float rstd = p.rstd[m];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const int h = it * 4 + hl;
+        if (h < p.H) {
+            unsigned u[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                u[j] = pack_bf16(rstd * (g[it][2 * j] - xh[it][2 * j] * mean), rstd * (g[it][2 * j + 1] - xh[it][2 * j + 1] * mean));
+            *(uint4*)(orow + it * 512) = make_uint4(u[0], u[1], u[2], u[3]);
+        }
     }
 }
 
@@ -326,6 +395,23 @@ hipError_t launch_norm_rope_full(const NormRopeFullParams& p, hipStream_t stream
     if (p.H <= 12) hipLaunchKernelGGL((norm_rope_full_kernel<12, false>), grid, dim3(256), 0, stream, p);
     else if (p.H <= 24) hipLaunchKernelGGL((norm_rope_full_kernel<24, false>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((norm_rope_full_kernel<48, false>), grid, dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_norm_rope_full_bwd(const NormRopeFullBwdParams& p, hipStream_t stream) {
+    if (p.M <= 0 || p.H <= 0 || p.H > 48 || p.rows_per_sample <= 0 || (p.out_ld & 7) || (p.col & 7) || ((size_t)p.y & 15) || ((size_t)p.dy & 15) ||
+        ((size_t)p.out & 15) || (p.weight && (!p.rstd || p.out_scale == 0.f)))
+        return hipErrorInvalidValue;
+    if (sched_trace_on()) {
+        const size_t blocks = (size_t)((p.M + p.rows_per_sample - 1) / p.rows_per_sample) * p.H, len = (size_t)p.rows_per_sample * 256, stride = (size_t)p.S_pad * 256;
+        sched_trace_launch("norm_rope_full_bwd", stream, {tregs(p.y + (size_t)p.s_off * 128, p.weight ? len : 0, stride, blocks), tregs(p.dy + (size_t)p.s_off * 128, len, stride, blocks),
+                                                          treg(p.rstd, p.weight ? (size_t)p.M * 4 : 0)},
+                           {tregs(p.out + p.col, (size_t)p.H * 256, (size_t)p.out_ld * 2, (size_t)p.M)});
+    }
+    const dim3 grid((unsigned)((p.M + 3) / 4));
+    if (p.H <= 12) hipLaunchKernelGGL((norm_rope_full_bwd_kernel<12>), grid, dim3(256), 0, stream, p);
+    else if (p.H <= 24) hipLaunchKernelGGL((norm_rope_full_bwd_kernel<24>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((norm_rope_full_bwd_kernel<48>), grid, dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

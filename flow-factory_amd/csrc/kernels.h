@@ -176,8 +176,22 @@ struct NormRopeFullParams {
     float eps, out_scale;
     unsigned* max2;                           // optional [B*H]: largest squared norm of the stored (bf16-rounded) output rows per (batch, head), as float bits
     float* max2_part;                         // scratch for it: [B][norm_rope_parts(rows_per_sample)][H] floats (s_off must be 0)
+    float* rstd_out = nullptr;                // optional [M]: 1 / rms of every row (training-mode forward: the backward needs it)
 };
 hipError_t launch_norm_rope_full(const NormRopeFullParams& p, hipStream_t stream);
+// backward of launch_norm_rope_full for ONE tensor (Wan q / k: RMSNorm over the whole row of H * 128 features, then RoPE, then out_scale):
+// from the STORED output y~ [B][H][S_pad][128] (= the forward's `out`), its gradient dy~ (same layout), the row's 1 / rms and the weight:
+//   z = y~ / out_scale;  y = R^T z;  xhat = y / w;  g = (R^T dy~ * out_scale) * w;  dx = rstd * (g - xhat * mean_row(g * xhat))
+// written token-major to out[m][col .. col + H * 128).  weight == nullptr: plain gather (dx = dy~: the V gradient).
+struct NormRopeFullBwdParams {
+    const bf16_t* y; const bf16_t* dy;         // stored output and its gradient, head-major
+    const float* weight; const float* rstd;    // [H*128], [M]
+    const float2* cs;                          // rotary table or nullptr
+    bf16_t* out; long out_ld; int col;
+    int M, H, rows_per_sample, s_off, S_pad;
+    float out_scale;
+};
+hipError_t launch_norm_rope_full_bwd(const NormRopeFullBwdParams& p, hipStream_t stream);
 int norm_rope_parts(int rows_per_sample);
 // Qwen-Image: RMSNorm over whole rows (weight fp32 [D]) and the norm-rescaled true-CFG combine over C = 64 channel tokens (flux_ops.hip)
 hipError_t launch_rms_rows(const bf16_t* x, long ldx, const float* w, bf16_t* out, long ldo, int M, int D, float eps, hipStream_t stream);
@@ -323,6 +337,7 @@ struct AttnBwdParams {
     int B, H, S, S_pad;
     const int* kv_len;        // head_dim-128 kernels only: optional device [B], sample b attends to keys [0, kv_len[b]) (ragged text at the END of
                               // the joint sequence, like Attn128Params::kv_len); dk / dv of the masked keys are written as zeros
+    int S_kv = 0, S_kv_pad = 0;   // head_dim-128 kernels only: cross-attention -- k, v, dk, dv are [B][H][S_kv_pad][128] over S_kv keys (0 = self)
 };
 hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream);
 // head_dim 128 (attention128_bwd.hip): the same contract with [B][H][S_pad][128] operands

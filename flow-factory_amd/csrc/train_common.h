@@ -38,6 +38,7 @@ struct AttnGeom {
     int B, H, D, S, S_pad;                    // forward batch, heads, H * 128, joint sequence length (padded to 64)
     const float2* cs;                         // rotary table [S][64]
     const int* kv_len;                        // optional device [B]: valid keys per sample (ragged text at the END of the joint sequence)
+    int S_kv = 0, S_kv_pad = 0;               // cross-attention: keys / values are another sequence ([B][H][S_kv_pad][128]); 0 = self
 };
 
 // out[M][N] (row stride ldo) = A[M][K] (row stride lda) . WT[N][K]^T  (WT = transposed weight: a dgrad), optional fused gelu'(pre)
@@ -167,9 +168,10 @@ static inline int t_attention128_backward(const TrainScratch& t, const AttnGeom&
     pp.do_first = do_first; pp.ld_do_first = a.D; pp.do_rest = do_rest; pp.ld_do_rest = a.D; pp.n_first = n_first;
     pp.lse = lse; pp.doh = t.doh; pp.delta = t.delta; pp.nld = t.nld; pp.B = a.B; pp.H = a.H; pp.S = a.S; pp.S_pad = a.S_pad;
     HIPCHK(launch_attn128_bwd_prep(pp, st));
-    const long hs = (long)a.S_pad * 128;
-    HIPCHK(launch_transpose(vT, a.S_pad, hs, t.v, 128, hs, 128, a.S_pad, 128, a.B * a.H, st));      // V^T [128][S_pad] -> V [S_pad][128] per (b, h)
-    AttnBwdParams ab{q, k, t.v, t.doh, lse, t.delta, t.nld, t.dq, t.dk, t.dvh, a.B, a.H, a.S, a.S_pad, a.kv_len};
+    const int Skp = a.S_kv > 0 ? a.S_kv_pad : a.S_pad;
+    const long hs = (long)Skp * 128;
+    HIPCHK(launch_transpose(vT, Skp, hs, t.v, 128, hs, 128, Skp, 128, a.B * a.H, st));      // V^T [128][S_pad] -> V [S_pad][128] per (b, h)
+    AttnBwdParams ab{q, k, t.v, t.doh, lse, t.delta, t.nld, t.dq, t.dk, t.dvh, a.B, a.H, a.S, a.S_pad, a.kv_len, a.S_kv, a.S_kv_pad};
     HIPCHK(launch_attention128_bwd(ab, st));
     return 0;
 }

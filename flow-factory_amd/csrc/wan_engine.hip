@@ -20,6 +20,7 @@
 
 #include "../../include/mi355_flow.h"
 #include "engine_common.h"
+#include "train_common.h"
 
 using namespace mi355;
 
@@ -27,6 +28,13 @@ using namespace mi355;
 namespace {
 
 struct WSlot { void* dst; int dst_dt; int64_t numel; bool bound; };
+
+// per-block activation stash of the training-mode forward (wan_train.inc): what the backward of the block needs
+struct WTrainBlk {
+    bf16_t *x_in, *xn1, *o1, *x_mid1, *xn2, *o2, *x_mid2, *xn3, *pre;     // [M][D] each; pre [M][F]
+    bf16_t *q, *k, *vT, *q2;                                              // [Bp][H][S_pad][128] (vT: [Bp][H][128][S_pad])
+    float *lse1, *lse2, *rstd_q, *rstd_k, *rstd_q2;                       // [Bp][H][S_pad] x 2, [M] x 3
+};
 
 struct WanBlockW {
     bf16_t *w_qk, *w_v, *w_o, *w_q2, *w_kv2, *w_o2, *w_ff1, *w_ff2;
@@ -117,6 +125,12 @@ void mi355_wan::layout() {
     w_proj = a16((int64_t)NO * D); b_proj = a32(NO); lin("proj_out", w_proj, b_proj, NO, D);
 }
 
+// training-mode state (wan_train.inc, included at the end of this file)
+struct mi355_wan_plan;
+static void wan_train_release(mi355_wan_plan* p);
+static void wan_train_release_engine(mi355_wan* e);
+static void wan_train_mark_dirty(mi355_wan* e);
+
 extern "C" int mi355_wan_create(const mi355_wan_cfg* cfg, mi355_wan** out) {
     if (!cfg || !out) return errorf("mi355_wan_create: null argument");
     if (cfg->head_dim != 128) return errorf("mi355_wan_create: head_dim must be 128 (got %d)", cfg->head_dim);
@@ -148,6 +162,7 @@ extern "C" int mi355_wan_create(const mi355_wan_cfg* cfg, mi355_wan** out) {
 
 extern "C" int mi355_wan_destroy(mi355_wan* e) {
     if (!e) return 0;
+    wan_train_release_engine(e);
     if (e->arena16) (void)hipFree(e->arena16);
     if (e->arena32) (void)hipFree(e->arena32);
     delete e;
@@ -171,6 +186,7 @@ extern "C" int mi355_wan_bind_weight(mi355_wan* e, const char* name, const void*
     HIPCHK(launch_convert(src, dtype, it->second.dst, it->second.dst_dt, n, (hipStream_t)stream));
     it->second.bound = true;
     e->derived_dirty = true;
+    wan_train_mark_dirty(e);           // the transposed copies the backward's dgrad GEMMs read are stale
     return 0;
 }
 extern "C" int mi355_wan_weights_ready(mi355_wan* e) {
@@ -285,6 +301,7 @@ extern "C" int mi355_wan_plan_create(mi355_wan* e, int batch, int n_cfg, int lat
 
 extern "C" int mi355_wan_plan_destroy(mi355_wan_plan* p) {
     if (!p) return 0;
+    wan_train_release(p);
     if (p->ws) (void)hipFree(p->ws);
     delete p;
     return 0;
@@ -338,11 +355,12 @@ int ln_mod(mi355_wan_plan* p, hipStream_t st, const bf16_t* x, bf16_t* out, cons
 }
 
 int norm_rope(mi355_wan_plan* p, hipStream_t st, const bf16_t* src, long ld, int col, const float* w, bool rope, bf16_t* out, int M, int rps,
-              int S_pad, float scale, unsigned* max2 = nullptr) {
+              int S_pad, float scale, unsigned* max2 = nullptr, float* rstd = nullptr) {
     NormRopeFullParams r;
     memset(&r, 0, sizeof(r));
     r.src = src; r.src_ld = ld; r.col = col; r.weight = w; r.cs = rope ? p->cs : nullptr; r.out = out; r.M = M; r.H = p->e->H;
     r.rows_per_sample = rps; r.s_off = 0; r.S_pad = S_pad; r.eps = p->e->cfg.eps; r.out_scale = scale; r.max2 = max2; r.max2_part = p->max2_part;
+    r.rstd_out = rstd;
     HIPCHK(launch_norm_rope_full(r, st));
     return 0;
 }
@@ -364,7 +382,7 @@ int gate_res(mi355_wan_plan* p, hipStream_t st, const bf16_t* A, int K, const bf
 }
 
 // step-invariant prompt work: text embedder, then every block's cross-attention K / V^T.  Prompt halves: [negative, positive] for CFG.
-int prepare_prompt(mi355_wan_plan* p, hipStream_t st, const void* enc_a, const void* enc_b) {
+int prepare_prompt(mi355_wan_plan* p, hipStream_t st, const void* enc_a, const void* enc_b, float* rstd_kx = nullptr) {
     mi355_wan* e = p->e;
     const int D = e->D, J = e->cfg.text_dim;
     const void* encs[2] = {enc_a, enc_b};
@@ -381,7 +399,8 @@ int prepare_prompt(mi355_wan_plan* p, hipStream_t st, const void* enc_a, const v
         const WanBlockW& b = e->blk[i];
         GemmParams gk = make_gemm(p->ctx, D, b.w_kv2, D, p->Mc, D, D, EPI_BIAS, b.b_kv2, p->kvbuf, D);     // to_k
         HIPCHK(launch_gemm(gk, st));
-        CHK(norm_rope(p, st, p->kvbuf, D, 0, b.nk2, false, p->kx + i * kx_el, p->Mc, p->Nt, p->Nt_pad, 1.0f));
+        CHK(norm_rope(p, st, p->kvbuf, D, 0, b.nk2, false, p->kx + i * kx_el, p->Mc, p->Nt, p->Nt_pad, 1.0f, nullptr,
+                      rstd_kx ? rstd_kx + (int64_t)i * p->Mc : nullptr));      // (training mode: 1 / rms of every text row for the k-norm backward)
         CHK(vt_proj(p, st, b.w_kv2 + (int64_t)D * D, b.b_kv2 + D, p->ctx, p->Mc, p->Nt, p->vTx + i * kx_el, p->Nt_pad));
     }
     return 0;
@@ -407,57 +426,81 @@ int prepare_conditioning(mi355_wan_plan* p, hipStream_t st, int nsteps) {
     return 0;
 }
 
-// one transformer forward over the forward batch Bp (latents replicated n_cfg times): v_out [Bp][16][T][h][w] bf16
-int forward_core(mi355_wan_plan* p, hipStream_t st, const void* latents, int lat_dt, const bf16_t* mod, bf16_t* v_out) {
+// one transformer forward over the forward batch Bp (latents replicated n_cfg times): v_out [Bp][16][T][h][w] bf16.
+// Training mode (`tb` = the plan's per-block stash, wan_train.inc): the SAME launches with the activations the backward needs written to
+// per-block buffers (+ the residual stream copied aside at the three sub-layer boundaries, the log-sum-exp / 1/rms side outputs switched on,
+// the FFN pre-activation stashed by the GEMM epilogue); `kx` / `vTx` = the cross-attention keys / values to read (the training state's copy).
+int forward_core(mi355_wan_plan* p, hipStream_t st, const void* latents, int lat_dt, const bf16_t* mod, bf16_t* v_out, const WTrainBlk* tb = nullptr,
+                 bf16_t* x_final = nullptr, const bf16_t* kx = nullptr, const bf16_t* vTx = nullptr) {
     mi355_wan* e = p->e;
     const int D = e->D, F = e->F, M = p->M, S = p->S;
     const int64_t kx_el = (int64_t)p->Bp * e->H * p->Nt_pad * 128;
+    const size_t x_b = (size_t)M * D * 2;
+    if (!kx) { kx = p->kx; vTx = p->vTx; }
     HIPCHK(launch_patchify(latents, lat_dt, p->patches, p->B, p->ncfg, e->cfg.in_channels, p->T * p->h, p->w, 2, st));
     GemmParams g0 = make_gemm(p->patches, e->KP, e->w_patch, e->KP, M, D, e->KP, EPI_BIAS, e->b_patch, p->x, D);
     HIPCHK(launch_gemm(g0, st));
     for (int i = 0; i < e->L; ++i) {
         const WanBlockW& b = e->blk[i];
+        const WTrainBlk* k = tb ? tb + i : nullptr;
         const int m0 = i * 6 * D;        // chunks: shift, scale, gate, c_shift, c_scale, c_gate
         // ---- self-attention
-        CHK(ln_mod(p, st, p->x, p->xn, mod, p->mod_cols, M, S, m0, m0 + D));
-        GemmParams gq = make_gemm(p->xn, D, b.w_qk, D, M, 2 * D, D, EPI_BIAS, b.b_qk, p->qkbuf, 2 * D);
+        bf16_t* xn1 = k ? k->xn1 : p->xn;
+        if (k) HIPCHK(copy_d2d(k->x_in, p->x, x_b, st));
+        CHK(ln_mod(p, st, p->x, xn1, mod, p->mod_cols, M, S, m0, m0 + D));
+        GemmParams gq = make_gemm(xn1, D, b.w_qk, D, M, 2 * D, D, EPI_BIAS, b.b_qk, p->qkbuf, 2 * D);
         HIPCHK(launch_gemm(gq, st));
         // self-attention score bound from the data (the weights prove none: RMSNorm across heads): largest stored row norm per (b, h)
         const bool dyn_bound = g_wan_data_bound && !(e->bound_self[i] > 0.f && e->bound_self[i] <= 60.f);
-        CHK(norm_rope(p, st, p->qkbuf, 2 * D, 0, b.nq, true, p->q, M, S, p->S_pad, kScale, dyn_bound ? p->max2 : nullptr));
-        CHK(norm_rope(p, st, p->qkbuf, 2 * D, D, b.nk, true, p->k, M, S, p->S_pad, 1.0f, dyn_bound ? p->max2 + p->Bp * e->H : nullptr));
-        CHK(vt_proj(p, st, b.w_v, b.b_v, p->xn, M, S, p->vT, p->S_pad));
+        bf16_t* q1 = k ? k->q : p->q;
+        bf16_t* k1 = k ? k->k : p->k;
+        bf16_t* v1 = k ? k->vT : p->vT;
+        CHK(norm_rope(p, st, p->qkbuf, 2 * D, 0, b.nq, true, q1, M, S, p->S_pad, kScale, dyn_bound ? p->max2 : nullptr, k ? k->rstd_q : nullptr));
+        CHK(norm_rope(p, st, p->qkbuf, 2 * D, D, b.nk, true, k1, M, S, p->S_pad, 1.0f, dyn_bound ? p->max2 + p->Bp * e->H : nullptr,
+                      k ? k->rstd_k : nullptr));
+        CHK(vt_proj(p, st, b.w_v, b.b_v, xn1, M, S, v1, p->S_pad));
+        bf16_t* o1 = k ? k->o1 : p->o;
         {
             Attn128Params a;
             memset(&a, 0, sizeof(a));
-            a.q = p->q; a.k = p->k; a.vT = p->vT; a.o_first = p->o; a.ld_first = D; a.n_first = S; a.o_rest = p->o; a.ld_rest = D;
+            a.q = q1; a.k = k1; a.vT = v1; a.o_first = o1; a.ld_first = D; a.n_first = S; a.o_rest = o1; a.ld_rest = D;
             a.B = p->Bp; a.H = e->H; a.S = S; a.S_pad = p->S_pad; a.q_prescaled = 1; a.score_bound = e->bound_self[i];
             if (dyn_bound) { a.qmax2 = p->max2; a.kmax2 = p->max2 + p->Bp * e->H; }
+            a.lse = k ? k->lse1 : nullptr;
             HIPCHK(launch_attention128(a, st));
         }
-        CHK(gate_res(p, st, p->o, D, b.w_o, b.b_o, p->x, M, S, mod, m0 + 2 * D));
+        CHK(gate_res(p, st, o1, D, b.w_o, b.b_o, p->x, M, S, mod, m0 + 2 * D));
         // ---- cross-attention to the cached text keys / values
-        CHK(ln_mod(p, st, p->x, p->xn, b.ln2_mod, 0, M, S, 0, D));
-        GemmParams gq2 = make_gemm(p->xn, D, b.w_q2, D, M, D, D, EPI_BIAS, b.b_q2, p->qkbuf, D);
+        bf16_t* xn2 = k ? k->xn2 : p->xn;
+        if (k) HIPCHK(copy_d2d(k->x_mid1, p->x, x_b, st));
+        CHK(ln_mod(p, st, p->x, xn2, b.ln2_mod, 0, M, S, 0, D));
+        GemmParams gq2 = make_gemm(xn2, D, b.w_q2, D, M, D, D, EPI_BIAS, b.b_q2, p->qkbuf, D);
         HIPCHK(launch_gemm(gq2, st));
-        CHK(norm_rope(p, st, p->qkbuf, D, 0, b.nq2, false, p->q, M, S, p->S_pad, kScale));
+        bf16_t* q2 = k ? k->q2 : p->q;
+        CHK(norm_rope(p, st, p->qkbuf, D, 0, b.nq2, false, q2, M, S, p->S_pad, kScale, nullptr, k ? k->rstd_q2 : nullptr));
+        bf16_t* o2 = k ? k->o2 : p->o;
         {
             Attn128Params a;
             memset(&a, 0, sizeof(a));
-            a.q = p->q; a.k = p->kx + i * kx_el; a.vT = p->vTx + i * kx_el; a.o_first = p->o; a.ld_first = D; a.n_first = S;
-            a.o_rest = p->o; a.ld_rest = D; a.B = p->Bp; a.H = e->H; a.S = S; a.S_pad = p->S_pad; a.q_prescaled = 1;
+            a.q = q2; a.k = kx + i * kx_el; a.vT = vTx + i * kx_el; a.o_first = o2; a.ld_first = D; a.n_first = S;
+            a.o_rest = o2; a.ld_rest = D; a.B = p->Bp; a.H = e->H; a.S = S; a.S_pad = p->S_pad; a.q_prescaled = 1;
             a.S_kv = p->Nt; a.S_kv_pad = p->Nt_pad; a.score_bound = e->bound_cross[i];
+            a.lse = k ? k->lse2 : nullptr;
             HIPCHK(launch_attention128(a, st));
         }
-        GemmParams go2 = make_gemm(p->o, D, b.w_o2, D, M, D, D, EPI_POSADD, b.b_o2, p->x, D);
+        GemmParams go2 = make_gemm(o2, D, b.w_o2, D, M, D, D, EPI_POSADD, b.b_o2, p->x, D);
         go2.aux = p->x; go2.ld_aux = D; go2.rows_per_sample = M;
         HIPCHK(launch_gemm(go2, st));
         // ---- feed-forward
-        CHK(ln_mod(p, st, p->x, p->xn, mod, p->mod_cols, M, S, m0 + 3 * D, m0 + 4 * D));
-        GemmParams f1 = make_gemm(p->xn, D, b.w_ff1, D, M, F, D, EPI_BIAS_GELU, b.b_ff1, p->hid, F);
+        bf16_t* xn3 = k ? k->xn3 : p->xn;
+        if (k) HIPCHK(copy_d2d(k->x_mid2, p->x, x_b, st));
+        CHK(ln_mod(p, st, p->x, xn3, mod, p->mod_cols, M, S, m0 + 3 * D, m0 + 4 * D));
+        GemmParams f1 = make_gemm(xn3, D, b.w_ff1, D, M, F, D, EPI_BIAS_GELU, b.b_ff1, p->hid, F);
+        if (k) { f1.stash = k->pre; f1.ld_stash = F; }
         HIPCHK(launch_gemm(f1, st));
         CHK(gate_res(p, st, p->hid, F, b.w_ff2, b.b_ff2, p->x, M, S, mod, m0 + 5 * D));
     }
+    if (x_final) HIPCHK(copy_d2d(x_final, p->x, x_b, st));
     const int mo = e->L * 6 * D;         // output modulation: shift, scale
     CHK(ln_mod(p, st, p->x, p->xn, mod, p->mod_cols, M, S, mo, mo + D));
     GemmParams g = make_gemm(p->xn, D, e->w_proj, D, M, e->NO, D, EPI_UNPATCH, e->b_proj, v_out, 0);
@@ -569,3 +612,5 @@ extern "C" int mi355_wan_rollout(mi355_wan_plan* p, void* stream, int n_steps, c
         HIPCHK(hipMemcpyAsync(out_final, p->io_traj + (size_t)n_steps * lat_bytes, lat_bytes, hipMemcpyDeviceToDevice, st));
     return 0;
 }
+
+#include "wan_train.inc"

@@ -157,6 +157,14 @@ SIGNATURES = {
     "mi355_wan_forward": (_I, [_P, _P, _P, _I, _P, _P, _P, _P]),
     "mi355_wan_rollout": (_I, [_P, _P, _I, C.POINTER(_F), C.POINTER(_F), C.POINTER(_F), _I, _F, _P, _I, _I, _P, _P, _P,
                                C.POINTER(C.c_int32), _P, _P, _P, _I]),
+    "mi355_wan_set_grad": (_I, [_P, C.c_char_p, _P]),
+    "mi355_wan_set_grad_typed": (_I, [_P, C.c_char_p, _P, _I]),
+    "mi355_wan_clear_grads": (_I, [_P]),
+    "mi355_wan_grad_supported": (_I, [_P, C.c_char_p]),
+    "mi355_wan_plan_training_bytes": (_L, [_P]),
+    "mi355_wan_forward_train": (_I, [_P, _P, _P, _I, _P, _P, _P, _P]),
+    "mi355_wan_backward": (_I, [_P, _P, _P]),
+    "mi355_op_norm_rope_full_fwd_bwd": (_I, [_P, _P, _L, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F]),
     "mi355_qwen_create": (_I, [C.POINTER(QwenCfg), C.POINTER(_P)]),
     "mi355_qwen_destroy": (_I, [_P]),
     "mi355_qwen_bind_weight": (_I, [_P, C.c_char_p, _P, _I, _I, C.POINTER(_L), _P]),

@@ -332,6 +332,25 @@ int mi355_wan_rollout(mi355_wan_plan* plan, void* stream, int n_steps, const flo
                       int storage_dtype, const float* step_noise, const void* prompt_embeds, const void* neg_embeds,
                       const int32_t* keep_slot_host, void* out_latents, float* out_log_probs, void* out_final, int compute_log_prob);
 
+/* ---- Wan2.1 / Wan2.2 T2V `optimize()` replay with gradients (SURVEY.md 8(f) N1 over N4) ----------------------------------------
+ * Replaces the grad-mode `Wan2_T2V_Adapter.forward(...)` + `accelerator.backward(loss)` (trainers/grpo.py:263, :326-330 over
+ * models/wan/wan2_t2v.py:426-543).  Same contract as mi355_flux_forward_train / _backward: the training-mode forward is mi355_wan_forward's own
+ * launch sequence on per-block buffers (prediction bit-identical), the backward writes the gradients of blocks.N.{attn1.{to_q,to_k,to_v,
+ * to_out.0},attn2.{to_q,to_k,to_v,to_out.0},ffn.net.{0.proj,2}} (the reference's Wan default target modules, wan2_t2v.py:74-85) into the
+ * buffers registered with mi355_wan_set_grad[_typed]; dv = d loss / d v_out for BOTH CFG halves [uncond | text], as mi355_sde_step_bwd
+ * produces it.  STATUS at the end of round 4: compiled, not yet run on a GPU (the host side keeps it behind MI355_WAN_NATIVE_BACKWARD=1). */
+int mi355_wan_set_grad(mi355_wan* e, const char* name, float* grad);
+int mi355_wan_set_grad_typed(mi355_wan* e, const char* name, void* grad, int dtype);
+int mi355_wan_clear_grads(mi355_wan* e);
+int mi355_wan_grad_supported(mi355_wan* e, const char* name);
+int64_t mi355_wan_plan_training_bytes(mi355_wan_plan* plan);
+int mi355_wan_forward_train(mi355_wan_plan* plan, void* stream, const void* latents, int lat_dtype, const float* t, const void* enc_a,
+                            const void* enc_b, void* v_out);
+int mi355_wan_backward(mi355_wan_plan* plan, void* stream, const float* dv);
+/* unit-test helper: full-row RMSNorm [+ RoPE] producer (Wan q / k) forward with its 1 / rms output, then its backward */
+int mi355_op_norm_rope_full_fwd_bwd(void* stream, const void* src, int64_t src_ld, int col, const float* weight, const float* cos_sin, void* y,
+                                    float* rstd, const void* dy, void* dx, int M, int H, int rows_per_sample, int S_pad, float eps, float out_scale);
+
 /* ---- Qwen-Image -----------------------------------------------
  * Replaces, inside QwenImageAdapter.inference / .forward (reference models/qwen_image/qwen_image.py:372-423, :476-600), the two
  * `self.transformer(...)` calls (cond / uncond), the norm-rescaled true-CFG combine (:579-587) and `self.scheduler.step(...)`.
