@@ -234,6 +234,16 @@ def _train_args(call: dict):
     return call.get("train_args") or (call["latents"], call["tm"], call["gm"], call["prompt_embeds"], call["pooled"])
 
 
+def _cfg_halves(v: torch.Tensor, call: dict):
+    """(v_text, v_uncond, guidance) of the fused scheduler step: the network output itself, or -- Wan with classifier-free guidance, whose
+    two branches are one forward batch [negative | positive] -- its halves and the guidance scale (`call["cfg_guidance"]`)."""
+    g = call.get("cfg_guidance")
+    if g is None:
+        return v, None, 1.0
+    B = v.shape[0] // 2
+    return v[B:], v[:B], float(g)
+
+
 class _FluxReplayFn(torch.autograd.Function):
     """(log_prob [B], noise_pred [B,Ni,C], next_latents_mean [B,Ni,C]) = step(transformer(weights)); d/d weights by the FLUX engine.
 
@@ -246,14 +256,15 @@ class _FluxReplayFn(torch.autograd.Function):
     def forward(ctx, host, plan, names, call, *weights):
         from .engine import sde_step
         v = plan.forward_train(*_train_args(call))
-        o = sde_step(v, None, 1.0, call["latents"], call["sigma"], call["sigma_next"], call["eta"], call["sigma_max"], call["dynamics"],
+        vt, vu, g = _cfg_halves(v, call)
+        o = sde_step(vt, vu, g, call["latents"], call["sigma"], call["sigma_next"], call["eta"], call["sigma_max"], call["dynamics"],
                      noise=None, next_latents=call["next_latents"], compute_log_prob=call["compute_log_prob"],
                      want=("next_latents_mean", "noise_pred", "std_dev_t", "dt"))
         ctx.set_materialize_grads(False)
         ctx.host, ctx.plan, ctx.names, ctx.call, ctx.v = host, plan, names, call, v
         ctx.serial = plan._train_serial
         ctx.w_meta = [(w.shape, w.dtype) for w in weights]
-        lp = o.log_prob if o.log_prob is not None else torch.zeros((v.shape[0],), device=v.device)
+        lp = o.log_prob if o.log_prob is not None else torch.zeros((vt.shape[0],), device=v.device)
         ctx.mark_non_differentiable(o.std_dev_t, o.dt)
         return lp, o.noise_pred, o.next_latents_mean, o.std_dev_t, o.dt
 
@@ -273,8 +284,9 @@ class _FluxReplayFn(torch.autograd.Function):
             plan.forward_train(*_train_args(call))
         if not call["compute_log_prob"]:
             g_lp = None
-        dv = sde_step_bwd(ctx.v, None, 1.0, call["latents"], call["next_latents"], call["sigma"], call["sigma_next"], call["eta"],
-                          call["sigma_max"], call["dynamics"], call["compute_log_prob"], g_lp, g_np, g_mean)
+        vt, vu, g = _cfg_halves(ctx.v, call)
+        dv = sde_step_bwd(vt, vu, g, call["latents"], call["next_latents"], call["sigma"], call["sigma_next"], call["eta"],
+                          call["sigma_max"], call["dynamics"], call["compute_log_prob"], g_lp, g_np, g_mean)      # [uncond | text] with CFG
         eng = plan.engine
         grads = _grad_buffers(eng, ctx.names, ctx.w_meta, dv.device)
         plan.backward(dv)
@@ -303,4 +315,12 @@ def qwen_replay(host, plan, call: dict):
     """The differentiable Qwen-Image replay step (mi355_qwen_forward_train / _backward: true-CFG combine included): the FLUX.1 node with
     `call["train_args"] = (latents, t_model, embeds, lens, guidance_scale)`."""
     assert "train_args" in call
+    return flux_replay(host, plan, call)
+
+
+
+def wan_replay(host, plan, call: dict):
+    """The differentiable Wan replay step (mi355_wan_forward_train / _backward; CFG = `u + g (c - u)` inside the fused scheduler step, whose
+    adjoint returns d v for both halves): the FLUX.1 node with `call["train_args"] = (latents, t, enc_a, enc_b)` and `call["cfg_guidance"]`."""
+    assert "train_args" in call and "cfg_guidance" in call
     return flux_replay(host, plan, call)

@@ -364,9 +364,20 @@ if _RefAdapter is not None:
             def forward(self, *args, **kwargs):
                 if bool(getattr(self.scheduler, "is_eval", False)):
                     return _RefWan.forward(self, *args, **kwargs)
-                if torch.is_grad_enabled():          # optimize(): autograd on the reference path, values from the engine
-                    return self._replay_on_reference(_RefWan.forward, WanRolloutMixin.forward, args, kwargs)
+                if torch.is_grad_enabled() and not (WanEngine.native_backward_enabled and getattr(self, "engine_2", None) is None):
+                    # optimize(): autograd on the reference path, values from the engine (the native Wan backward is opt-in until its GPU
+                    # tests have run: MI355_WAN_NATIVE_BACKWARD=1; with it the mixin's forward dispatches and `_grad_fallback` is this route)
+                    return self._replay_on_reference(_RefWan.forward, WanRolloutMixin.forward, args, kwargs)     # (called under no_grad)
                 return WanRolloutMixin.forward(self, *args, **kwargs)
+
+            def _grad_fallback(self, why, kwargs):
+                if os.environ.get("MI355_STRICT_NATIVE") == "1":
+                    raise NotImplementedError(f"mi355_flow: Wan forward() with autograd is outside the native backward ({why}) and "
+                                              "MI355_STRICT_NATIVE=1 forbids the reference path")
+                if not getattr(self, "_warned_ref_grad", False):
+                    logger.warning("mi355_flow: grad-mode forward() differentiates through the reference path (%s); values stay the engine's", why)
+                    self._warned_ref_grad = True
+                return self._replay_on_reference(_RefWan.forward, WanRolloutMixin._forward_nograd, (), kwargs)
 
     try:
         from flow_factory.models.qwen_image.qwen_image import QwenImageAdapter as _RefQwen, QwenImageSample as _RefQwenSample

@@ -11,6 +11,7 @@ Not covered (raise): `attention_kwargs`; image-conditioned TI2V (per-token times
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Any, Callable, Dict, List, Optional, Sequence, Tuple, Union
 
@@ -97,6 +98,24 @@ class WanEngine(WeightHolder):
             self._plans[key] = p
         return p
 
+    # ---------------------------------------------------------------- weight gradients (mi355_flow/autograd.py: wan_replay)
+    #: the native backward was written at the end of round 4 and has not run on a GPU yet: opt-in until its GPU tests have
+    native_backward_enabled = os.environ.get("MI355_WAN_NATIVE_BACKWARD") == "1"
+
+    def grad_supported(self, name: str) -> int:
+        """1 = the native backward produces a gradient for this parameter (the linear layers inside the transformer blocks), 0 = it does not."""
+        if not type(self).native_backward_enabled:
+            return 0
+        return 1 if self.lib.mi355_wan_grad_supported(self._h, name.encode()) == 0 else 0
+
+    def set_grad(self, name: str, grad: torch.Tensor) -> None:
+        if grad.dtype not in (torch.float32, torch.bfloat16) or not grad.is_contiguous():
+            raise ValueError("mi355_flow: gradient buffers are contiguous fp32 (or bf16) tensors")
+        _lib.check(self.lib.mi355_wan_set_grad_typed(self._h, name.encode(), _ptr(grad), dtype_code(grad.dtype)), f"wan_set_grad({name})")
+
+    def clear_grads(self) -> None:
+        _lib.check(self.lib.mi355_wan_clear_grads(self._h), "wan_clear_grads")
+
     def close(self) -> None:
         for p in self._plans.values():
             p.close()
@@ -145,6 +164,36 @@ class WanPlan:
         _lib.check(self.lib.mi355_wan_forward(self._h, _stream(), _ptr(latents), dtype_code(latents.dtype), _ptr(t), _ptr(ea), _ptr(eb),
                                               _ptr(out)), "wan_forward")
         return out
+
+    # ---------------------------------------------------------------- differentiable forward (optimize() replay)
+    def forward_train(self, latents: torch.Tensor, t: torch.Tensor, enc_a: torch.Tensor, enc_b: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """mi355_wan_forward_train: `transformer_forward` on per-block activation buffers -- the same kernel binaries, so the prediction is
+        bit-identical -- keeping what `backward` needs in the plan's training stash (ONE per plan; every call takes a serial number)."""
+        B, Bp = self.batch, self.batch * self.n_cfg
+        assert tuple(latents.shape) == (B, self.C, self.T, self.h, self.w), latents.shape
+        dev = latents.device
+        t = t.to(device=dev, dtype=torch.float32).reshape(-1)
+        t = (t.expand(Bp) if t.numel() == 1 else (t.repeat(self.n_cfg) if t.numel() == B and self.n_cfg == 2 else t)).contiguous()
+        assert t.numel() == Bp
+        out = torch.empty((Bp, self.engine.cfg.out_channels, self.T, self.h, self.w), device=dev, dtype=torch.bfloat16)
+        latents = latents.contiguous()
+        ea = _bf16c(enc_a)
+        eb = _bf16c(enc_b) if enc_b is not None else None
+        _lib.check(self.lib.mi355_wan_forward_train(self._h, _stream(), _ptr(latents), dtype_code(latents.dtype), _ptr(t), _ptr(ea), _ptr(eb),
+                                                    _ptr(out)), "wan_forward_train")
+        self._train_serial = getattr(self, "_train_serial", 0) + 1
+        return out
+
+    def backward(self, dv: torch.Tensor) -> None:
+        """mi355_wan_backward: d loss / d v [n_cfg * B, C, T, h, w] fp32 ([uncond | text], as `engine.sde_step_bwd` returns it) of the LAST
+        `forward_train` -> the buffers registered with `WanEngine.set_grad`."""
+        dv = dv.to(torch.float32).contiguous()
+        assert tuple(dv.shape) == (self.batch * self.n_cfg, self.engine.cfg.out_channels, self.T, self.h, self.w), dv.shape
+        _lib.check(self.lib.mi355_wan_backward(self._h, _stream(), _ptr(dv)), "wan_backward")
+
+    @property
+    def training_bytes(self) -> int:
+        return int(self.lib.mi355_wan_plan_training_bytes(self._h))
 
     def rollout(self, timesteps: Sequence[float], sigmas: Sequence[float], noise_levels: Sequence[float], dynamics: str, guidance: float,
                 init_latents: torch.Tensor, storage_dtype: torch.dtype, step_noise: Optional[torch.Tensor], prompt_embeds: torch.Tensor,
@@ -375,7 +424,6 @@ class WanRolloutMixin:
         return all_lat, log_probs, outs
 
     # ------------------------------------------------------------------ single step / replay (wan2_t2v.py:426-543), no-grad
-    @torch.no_grad()
     def forward(
         self,
         t: torch.Tensor,
@@ -392,6 +440,36 @@ class WanRolloutMixin:
         return_kwargs: List[str] = ["noise_pred", "next_latents", "next_latents_mean", "std_dev_t", "dt", "log_prob"],
         boundary_timestep: Optional[float] = None,
     ) -> SDESchedulerOutput:
+        kw = dict(t=t, latents=latents, prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds, guidance_scale=guidance_scale,
+                  guidance_scale_2=guidance_scale_2, t_next=t_next, next_latents=next_latents, noise_level=noise_level,
+                  attention_kwargs=attention_kwargs, compute_log_prob=compute_log_prob, return_kwargs=return_kwargs, boundary_timestep=boundary_timestep)
+        if torch.is_grad_enabled() and getattr(self, "_live_weights", None) is not None and WanEngine.native_backward_enabled \
+                and getattr(self, "engine_2", None) is None:
+            # optimize() (trainers/grpo.py:263): the replay WITH autograd on the engine's differentiable forward + native backward
+            # (mi355_flow.autograd.wan_replay) when its backward covers the trainable set (single-expert pipelines; opt-in: see WanEngine)
+            from . import autograd as AG
+            self._before_engine_call()
+            why = AG.unsupported_reason(self)
+            sampled = next_latents is None and ("next_latents" in return_kwargs or (compute_log_prob and "log_prob" in return_kwargs))
+            if why is None and sampled:
+                why = "a sampled next state (or its log-prob) was requested with autograd"
+            if why is None:
+                return self._forward_impl(grad=True, **kw)
+            if not why.startswith("the bound module has no trainable"):
+                return self._grad_fallback(why, kw)
+        return self._forward_nograd(**kw)
+
+    def _forward_nograd(self, **kw) -> SDESchedulerOutput:
+        with torch.no_grad():
+            return self._forward_impl(grad=False, **kw)
+
+    def _grad_fallback(self, why: str, kwargs: Dict[str, Any]):
+        """Grad-mode forward() the native backward cannot serve.  Standalone: there is no other implementation -- raise (the Flow-Factory
+        plugin overrides this with the reference's autograd path)."""
+        raise NotImplementedError(f"mi355_flow: Wan forward() with autograd is not available natively: {why}")
+
+    def _forward_impl(self, t, latents, prompt_embeds, negative_prompt_embeds, guidance_scale, guidance_scale_2, t_next, next_latents, noise_level,
+                      attention_kwargs, compute_log_prob, return_kwargs, boundary_timestep, grad: bool) -> SDESchedulerOutput:
         self._before_engine_call()
         if attention_kwargs:
             raise NotImplementedError("mi355_flow: attention_kwargs are not supported by the native engine")
@@ -409,8 +487,10 @@ class WanRolloutMixin:
         eng, guidance_scale = self._expert(float(t0), guidance_scale, guidance_scale_2, boundary_timestep)
         do_cfg = negative_prompt_embeds is not None and guidance_scale > 1.0
         plan = eng.plan(B, 2 if do_cfg else 1, T, h, w, prompt_embeds.shape[1], 1)
-        v = plan.transformer_forward(latents, t0.reshape(1), negative_prompt_embeds if do_cfg else prompt_embeds, prompt_embeds if do_cfg else None)
-        vu, vt = (v[:B], v[B:]) if do_cfg else (None, v)
+        enc_a, enc_b = (negative_prompt_embeds, prompt_embeds) if do_cfg else (prompt_embeds, None)
+        if not grad:
+            v = plan.transformer_forward(latents, t0.reshape(1), enc_a, enc_b)
+            vu, vt = (v[:B], v[B:]) if do_cfg else (None, v)
         dyn = sched.dynamics_type
         sigma, sigma_next = (t0.double() / 1000).float(), (t_next.double() / 1000).float()
         if sched.is_eval or dyn == "ODE":
@@ -420,10 +500,21 @@ class WanRolloutMixin:
         noise = None
         if next_latents is None and dyn != "ODE":
             noise = randn_tensor(latents.shape, device=dev, dtype=torch.float32)
+        view = (-1, 1, 1, 1, 1)
+        if grad:
+            from . import autograd as AG
+            replay = next_latents is not None
+            clp = bool(compute_log_prob) and replay
+            call = dict(latents=latents, train_args=(latents, t0.reshape(1), enc_a, enc_b), cfg_guidance=float(guidance_scale) if do_cfg else None,
+                        sigma=sigma, sigma_next=sigma_next, eta=noise_level, sigma_max=float(sched.sigmas[1]), dynamics=dyn,
+                        next_latents=next_latents if replay else latents, compute_log_prob=clp)
+            lp, npred, mean, std, dtt = AG.wan_replay(self, plan, call)
+            res = dict(noise_pred=npred, next_latents=next_latents.float() if replay else None, next_latents_mean=mean, std_dev_t=std.view(view),
+                       dt=dtt.view(view), log_prob=lp if clp else None)
+            return self._output_cls.from_dict({k: res[k] for k in return_kwargs if k in res})
         want = tuple(k for k in return_kwargs if k in ("next_latents", "next_latents_mean", "noise_pred", "std_dev_t", "dt"))
         o = sde_step(vt, vu, guidance_scale, latents, sigma, sigma_next, noise_level, float(sched.sigmas[1]), dyn, noise=noise,
                      next_latents=next_latents, compute_log_prob=compute_log_prob, want=want)
-        view = (-1, 1, 1, 1, 1)
         res = dict(
             noise_pred=o.noise_pred,
             next_latents=o.next_latents if next_latents is None else next_latents.float(),
@@ -451,7 +542,16 @@ class Wan2T2VNativeAdapter(WanRolloutMixin):
         self._latent_storage = latent_storage_dtype
         self.scheduler = scheduler or UniPCMultistepSDEScheduler(flow_shift=3.0, sde_steps=[1, 2, 3], num_sde_steps=1)
         self.engine = WanEngine(config or WanConfig())
-        self.refresh_weights(state_dict)
+        self._live_weights = None
+        if isinstance(state_dict, torch.nn.Module):
+            # a torch module with HF parameter names (possibly DDP / peft wrapped): its CURRENT parameters are re-bound before every engine
+            # call, and grad-mode forward() differentiates w.r.t. its trainable parameters (mi355_flow/autograd.py: wan_replay; opt-in)
+            from .binding import LiveWeights
+            module = state_dict
+            self._live_weights = LiveWeights(self.engine, lambda: module)
+            self._sync_weights()
+        else:
+            self.refresh_weights(state_dict)
         if state_dict_2 is not None:            # Wan2.2: low-noise expert (`transformer_2`), same architecture
             if boundary_ratio is None:
                 raise ValueError("mi355_flow: a two-expert Wan2.2 adapter needs `boundary_ratio` (pipeline.config.boundary_ratio)")
@@ -475,6 +575,17 @@ class Wan2T2VNativeAdapter(WanRolloutMixin):
     def refresh_weights(self, state_dict: Dict[str, torch.Tensor]) -> None:
         self.engine.bind_state_dict(state_dict)
         self.engine.ready()
+
+    def _sync_weights(self) -> int:
+        if self._live_weights is None:
+            return 0
+        n = self._live_weights.sync()
+        if n:
+            self.engine.ready()
+        return n
+
+    def _before_engine_call(self) -> None:
+        self._sync_weights()
 
     def rollout(self):
         self.scheduler.rollout()

@@ -800,19 +800,21 @@ class FluxTrainEngineModel(_StandinFamilyEngine):
 def oracle_sde_step_bwd(v_text, v_uncond, guidance, latents, next_latents, sigma, sigma_next, eta, sigma_max, dynamics: str, compute_log_prob,
                         g_log_prob=None, g_noise_pred=None, g_mean=None):
     """Signature of `mi355_flow.engine.sde_step_bwd` computed by torch autograd through the ORACLE step (`oracle.scheduler_ref.sde_step` is
-    plain differentiable torch): d loss / d v for the CPU-only plugin tests."""
+    plain differentiable torch): d loss / d v for the CPU-only plugin tests -- [uncond | text] when a CFG pair is given (the combine
+    `u + g (c - u)` differentiated in fp32)."""
     from oracle import scheduler_ref as S
-    assert v_uncond is None
     if torch.is_tensor(eta):
         eta = float(eta.reshape(-1)[0])
     with torch.enable_grad():                    # (called from inside an autograd Function's backward, where grad mode is off)
-        return _oracle_sde_step_bwd(S, v_text, latents, next_latents, sigma, sigma_next, eta, sigma_max, dynamics, compute_log_prob, g_log_prob,
-                                    g_noise_pred, g_mean)
+        return _oracle_sde_step_bwd(S, v_text, v_uncond, float(guidance), latents, next_latents, sigma, sigma_next, eta, sigma_max, dynamics,
+                                    compute_log_prob, g_log_prob, g_noise_pred, g_mean)
 
 
-def _oracle_sde_step_bwd(S, v_text, latents, next_latents, sigma, sigma_next, eta, sigma_max, dynamics, compute_log_prob, g_log_prob, g_noise_pred,
-                         g_mean):
-    v = v_text.float().detach().requires_grad_(True)
+def _oracle_sde_step_bwd(S, v_text, v_uncond, guidance, latents, next_latents, sigma, sigma_next, eta, sigma_max, dynamics, compute_log_prob, g_log_prob,
+                         g_noise_pred, g_mean):
+    vt = v_text.float().detach().requires_grad_(True)
+    vu = v_uncond.float().detach().requires_grad_(True) if v_uncond is not None else None
+    v = vt if vu is None else vu + guidance * (vt - vu)
     out = S.sde_step(v, latents, torch.as_tensor(sigma, dtype=torch.float32), torch.as_tensor(sigma_next, dtype=torch.float32), float(eta),
                      dynamics_type=dynamics, sigma_max=sigma_max, next_latents=next_latents, compute_log_prob=bool(compute_log_prob))
     loss = v.sum() * 0.0
@@ -822,8 +824,67 @@ def _oracle_sde_step_bwd(S, v_text, latents, next_latents, sigma, sigma_next, et
         loss = loss + (g_noise_pred.float() * out["noise_pred"]).sum()
     if g_mean is not None:
         loss = loss + (g_mean.float() * out["next_latents_mean"]).sum()
-    (dv,) = torch.autograd.grad(loss, v)
-    return dv
+    if vu is None:
+        (dv,) = torch.autograd.grad(loss, vt)
+        return dv
+    du, dt_ = torch.autograd.grad(loss, (vu, vt))
+    return torch.cat([du, dt_])
+
+
+class WanTrainPlanModel(WanStandinPlanStepwise):
+    """+ the native training API of `mi355_flow.wan.WanPlan` (mi355_wan_forward_train / mi355_wan_backward): the forward is the SAME stand-in as
+    the no-grad one plus a dependence on the bound weights; the backward writes d loss / d w = <dv, d v / d w> into the registered buffers
+    (as `FluxTrainPlanModel`).  v = [negative | positive] halves when n_cfg == 2; dv likewise."""
+
+    def _signal(self):
+        eng = self.engine
+        return sum(float(eng.bound[n].float().mean()) for n in eng.signal_names()) if eng.bound else 0.0
+
+    def transformer_forward(self, latents, t, enc_a, enc_b=None):
+        v = super().transformer_forward(latents, t, enc_a, enc_b)
+        rep = 1 if enc_b is None else 2
+        return (v.float() + self._signal() * latents.to(torch.bfloat16).float().repeat(rep, 1, 1, 1, 1)).to(torch.bfloat16)   # (the network sees bf16 latents)
+
+    def rollout(self, timesteps, sigmas, noise_levels, dynamics, guidance, init_latents, storage_dtype, step_noise, prompt_embeds,
+                neg_embeds=None, keep_positions=None, compute_log_prob=True):
+        from oracle import standin
+        from oracle import wan_ref as W
+        self.engine.calls.append(("rollout", dict(N=len(timesteps), n_cfg=self.n_cfg)))
+        if step_noise is None:
+            step_noise = torch.zeros((len(timesteps),) + tuple(init_latents.shape))
+        sig = self._signal()
+
+        def net(x, t, enc):                          # the same network as transformer_forward: stand-in + the weight-dependent term
+            return (standin.wan_denoiser(x, t, enc, 0).float() + sig * x.float()).to(torch.bfloat16)
+        out = W.rollout(None, None, prompt_embeds, neg_embeds, guidance, init_latents, step_noise, torch.tensor(timesteps).long(),
+                        torch.tensor(sigmas, dtype=torch.float32), list(noise_levels), storage_dtype, dynamics_type=dynamics,
+                        compute_log_prob=compute_log_prob, denoiser=net)
+        return _keep_rows(out, len(timesteps), keep_positions)
+
+    def forward_train(self, latents, t, enc_a, enc_b=None):
+        self._train_serial = getattr(self, "_train_serial", 0) + 1
+        rep = 1 if enc_b is None else 2
+        self._stash = latents.to(torch.bfloat16).float().repeat(rep, 1, 1, 1, 1).clone()
+        v = self.transformer_forward(latents, t, enc_a, enc_b)
+        self.engine.calls[-1] = ("forward_train", self.engine.calls[-1][1])
+        return v
+
+    def backward(self, dv):
+        eng = self.engine
+        eng.calls.append(("backward", dict(serial=self._train_serial)))
+        assert dv.shape == self._stash.shape, (dv.shape, self._stash.shape)
+        up = float((dv.float() * self._stash).sum())
+        for name, buf in eng.grad_bufs.items():
+            buf += up / buf.numel()
+
+
+class WanTrainEngineModel(FluxTrainEngineModel):
+    """Wan engine double WITH the native backward's host API; scope = the attention projections (as the FLUX.1 double)."""
+    PLAN = WanTrainPlanModel
+    expert = 0
+
+    def grad_supported(self, name) -> int:
+        return 1 if (name in self._names and (".attn1.to_" in name or ".attn2.to_" in name)) else 0
 
 
 class QwenStandinPlanModel(QwenStandinPlan):

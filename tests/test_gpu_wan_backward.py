@@ -1,0 +1,243 @@
+"""GPU parity of the Wan native backward (SURVEY.md 8(f) N1 over N4: mi355_wan_forward_train / mi355_wan_backward -- head_dim-128 attention backward
+with a separate key length (cross-attention), full-row RMSNorm + 3-D RoPE backward, the un-gated cross-attention residual, CFG as one forward
+batch) against torch autograd through the CPU oracle (oracle/wan_ref.py): fp32, and the bf16-emulating run that gives the tolerance band
+(`rel-L2 < 3 x band + 5e-3`).  GATED: this code was written at the end of round 4 and had not run on a GPU when it was committed -- the tests
+(and the product path they exercise) need MI355_WAN_NATIVE_BACKWARD=1; round 5's first GPU call runs them (scripts/gpu_r5_call1.sh)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import _plugin_fakes as PF
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("MI355_WAN_NATIVE_BACKWARD") != "1",
+                                                  reason="opt-in until its first GPU run: MI355_WAN_NATIVE_BACKWARD=1")]
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def _cos(a, b):
+    a, b = a.float().cpu().flatten(), b.float().cpu().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def wn():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mi355_flow import wan
+    assert wan.WanEngine.native_backward_enabled
+    return wan
+
+
+@pytest.mark.parametrize("rope", [True, False])
+def test_norm_rope_full_backward_matches_autograd(wn, rope):
+    """The q / k producer of the Wan attention (RMSNorm over the WHOLE row of H x 128 features, weight, [3-D RoPE on adjacent pairs], scale) and
+    its backward from the STORED output + 1 / rms: vs torch autograd of the same arithmetic in fp32."""
+    import ctypes as C
+    from mi355_flow import _lib
+    from mi355_flow.engine import _ptr, _stream
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    B, S, H = 2, 70, 3
+    S_pad, D, M = 128, H * 128, B * S
+    src = (torch.randn(M, D, generator=g) * 1.5).bfloat16()
+    w = 1.0 + 0.1 * torch.randn(D, generator=g)
+    ang = torch.rand(S, 64, generator=g) * 6.28
+    cs = torch.stack([ang.cos(), ang.sin()], dim=-1).contiguous()          # [S][64][2]
+    dy = torch.randn(B, H, S_pad, 128, generator=g).bfloat16()
+    scale, eps = 0.1275, 1e-6
+    y = torch.zeros(B, H, S_pad, 128, dtype=torch.bfloat16, device="cuda")
+    rstd = torch.zeros(M, dtype=torch.float32, device="cuda")
+    dx = torch.zeros(M, D, dtype=torch.bfloat16, device="cuda")
+    src_d, w_d, cs_d, dy_d = src.cuda(), w.cuda(), cs.cuda(), dy.cuda()
+    _lib.check(lib.mi355_op_norm_rope_full_fwd_bwd(_stream(), _ptr(src_d), D, 0, _ptr(w_d), _ptr(cs_d) if rope else None, _ptr(y), _ptr(rstd), _ptr(dy_d),
+                                                   _ptr(dx), M, H, S, S_pad, eps, scale), "op_norm_rope_full_fwd_bwd")
+    torch.cuda.synchronize()
+    x = src.float().requires_grad_(True)
+    r = torch.rsqrt((x * x).mean(dim=-1, keepdim=True) + eps)
+    yn = (x * r * w).view(B, S, H, 64, 2)
+    if rope:
+        c, s_ = cs[:, :, 0].view(1, S, 1, 64), cs[:, :, 1].view(1, S, 1, 64)
+        yn = torch.stack([yn[..., 0] * c - yn[..., 1] * s_, yn[..., 1] * c + yn[..., 0] * s_], dim=-1)
+    yo = (yn.reshape(B, S, H, 128) * scale).permute(0, 2, 1, 3)              # [B][H][S][128]
+    assert _rel(y[:, :, :S].cpu(), yo.detach()) < 5e-3
+    assert _rel(rstd.cpu(), r.detach().reshape(-1)) < 1e-5
+    (yo * dy[:, :, :S].float()).sum().backward()
+    r_dx = _rel(dx.cpu(), x.grad)
+    print(f"norm_rope_full backward (rope {rope}): dx rel-L2 {r_dx:.3e}")
+    assert r_dx < 1.5e-2 and _cos(dx.cpu(), x.grad) > 0.9995           # from the bf16-STORED output (2^-9 per element) and bf16 dx
+
+
+# ------------------------------------------------------------------------------------------------- model-level gradients
+# the reference's Wan default target modules (models/wan/wan2_t2v.py:74-85) = the native backward's scope
+DEFAULT_TARGETS = (".attn1.to_q.", ".attn1.to_k.", ".attn1.to_v.", ".attn1.to_out.0.", ".attn2.to_q.", ".attn2.to_k.", ".attn2.to_v.",
+                   ".attn2.to_out.0.", ".ffn.net.0.proj.", ".ffn.net.2.")
+
+
+def _build(wn, cfg_o, train_filter, seed=3, std=0.05, norm_mean=1.0):
+    from oracle import wan_ref as R
+    mod = PF.build_module_tree(R.state_dict_shapes(cfg_o), buffers=(), seed=seed, std=std).cuda()
+    with torch.no_grad():
+        for n, prm in mod.named_parameters():
+            if ".norm_q." in n or ".norm_k." in n:
+                prm.copy_(norm_mean * (1.0 + 0.1 * prm / std))
+            elif n.endswith("norm2.weight"):
+                prm.copy_(1.0 + 0.1 * prm / std)
+            prm.copy_(prm.bfloat16().float())
+    for n, prm in mod.named_parameters():
+        prm.requires_grad_(train_filter(n))
+    cfg = wn.WanConfig(num_layers=cfg_o.num_layers, num_attention_heads=cfg_o.num_attention_heads, ffn_dim=cfg_o.ffn_dim, text_dim=cfg_o.text_dim)
+    sched = wn.UniPCMultistepSDEScheduler(flow_shift=3.0, noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=1, seed=42, dynamics_type="Flow-SDE")
+    ad = wn.Wan2T2VNativeAdapter(mod, cfg, sched, latent_storage_dtype="fp16")
+    ad.rollout()
+    return ad, mod
+
+
+def _inputs(cfg_o, B, T, h, w, Nt, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    mk = lambda *s: torch.randn(*s, generator=g)
+    return dict(x=mk(B, 16, T, h, w).half(), x1=mk(B, 16, T, h, w).half(), pe=mk(B, Nt, cfg_o.text_dim).bfloat16(), ne=mk(B, Nt, cfg_o.text_dim).bfloat16(),
+                wlp=mk(B), wnp=mk(B, 16, T, h, w))
+
+
+def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=None):
+    """The same loss through the oracle network (both CFG branches, `u + g (c - u)` in bf16 like the fused step) and the Flow-SDE step (CPU)."""
+    from oracle import wan_ref as R
+    sd = {n: p_.detach().cpu().float().requires_grad_(p_.requires_grad) for n, p_ in mod.named_parameters()}
+    x, x1 = inp["x"].float(), inp["x1"].float()
+    B = x.shape[0]
+    tt = torch.full((B,), float(t))
+    pos = R.wan_forward(sd, cfg_o, x, tt, inp["pe"].float(), quant=quant)
+    if guidance > 1.0:
+        neg = R.wan_forward(sd, cfg_o, x, tt, inp["ne"].float(), quant=quant)
+        v = neg + guidance * (pos - neg)
+    else:
+        v = pos
+    sigma, sigma_n = t / 1000.0, t_next / 1000.0
+    dt = sigma_n - sigma
+    std = math.sqrt(sigma / (1 - (sigma_max if sigma == 1.0 else sigma))) * eta
+    mean = x * (1 + std ** 2 / (2 * sigma) * dt) + v * (1 + std ** 2 * (1 - sigma) / (2 * sigma)) * dt
+    sv = std * math.sqrt(-dt)
+    lp = (-((x1 - mean) ** 2) / (2 * sv ** 2) - math.log(sv) - math.log(math.sqrt(2 * math.pi))).mean(dim=(1, 2, 3, 4))
+    loss = (inp["wlp"] * lp).sum() + kl_w * (inp["wnp"] * v).mean()
+    loss.backward()
+    return lp.detach(), {n: s.grad for n, s in sd.items() if s.requires_grad}
+
+
+def _kw(inp, B, t, t_next, eta, guidance):
+    kw = dict(t=torch.full((B,), t), t_next=torch.full((B,), t_next), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(), prompt_embeds=inp["pe"].cuda(),
+              guidance_scale=guidance, noise_level=eta, compute_log_prob=True, return_kwargs=["log_prob", "noise_pred", "dt"])
+    if guidance > 1.0:
+        kw["negative_prompt_embeds"] = inp["ne"].cuda()
+    return kw
+
+
+def _compare(mod, g_ref, g_band, what, min_n):
+    worst, worst_name, worst_band, n = 0.0, None, 0.0, 0
+    for name, prm in mod.named_parameters():
+        if not prm.requires_grad:
+            assert prm.grad is None, name
+            continue
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
+        ref = g_ref[name]
+        r, band = _rel(prm.grad, ref), _rel(g_band[name], ref)
+        n, worst_band = n + 1, max(worst_band, band)
+        if r > worst:
+            worst, worst_name = r, name
+        assert r < 3.0 * band + 5e-3 and _cos(prm.grad, ref) > 0.99, (name, r, band, _cos(prm.grad, ref))       # (CFG 5 amplifies: bands up to 0.1)
+    print(f"{what}: {n} parameter gradients vs fp32 oracle autograd, worst rel-L2 {worst:.3e} ({worst_name}); bf16-emulating oracle band, worst {worst_band:.3e}")
+    assert n >= min_n, n
+
+
+@pytest.mark.parametrize("B,T,h,w,Nt,guidance", [(2, 3, 8, 12, 9, 1.0), (1, 2, 6, 10, 64, 5.0), (2, 1, 16, 16, 17, 5.0)])
+def test_wan_replay_gradients_match_oracle_autograd_and_ratio_is_one(wn, B, T, h, w, Nt, guidance):
+    from oracle import wan_ref as R
+    cfg_o = R.tiny_config()
+    ad, mod = _build(wn, cfg_o, lambda n: any(k in n for k in DEFAULT_TARGETS))
+    inp = _inputs(cfg_o, B, T, h, w, Nt, seed=5)
+    t, t_next, eta, smax = 900.0, 750.0, 0.7, 0.9
+    ad.scheduler.set_timesteps(4)
+    ad.scheduler.sigmas = ad.scheduler.sigmas.clone()
+    ad.scheduler.sigmas[1] = smax
+    kw = _kw(inp, B, t, t_next, eta, guidance)
+    with torch.no_grad():
+        ref_out = ad.forward(**kw)                      # the no-grad replay
+    out = ad.forward(**kw)                              # grad mode: mi355_wan_forward_train + the same scheduler-step kernel
+    assert out.log_prob.requires_grad and out.noise_pred.requires_grad
+    assert torch.equal(out.noise_pred.detach(), ref_out.noise_pred)      # the prediction: same kernel binaries on per-block buffers
+    assert torch.equal(out.log_prob.detach(), ref_out.log_prob)          # ratio == exp(0) == 1.0 EXACTLY in grad mode
+    kl_w = 3.0
+    ((inp["wlp"].cuda() * out.log_prob).sum() + kl_w * (inp["wnp"].cuda() * out.noise_pred).mean()).backward()
+    lp_ref, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w)
+    _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float())
+    np.testing.assert_allclose(out.log_prob.detach().cpu().numpy(), lp_ref.numpy(), rtol=2e-2)
+    _compare(mod, g_ref, g_band, f"Wan replay (B {B}, {T}x{h}x{w}, Nt {Nt}, guidance {guidance})", 36)
+    ad.engine.close()
+
+
+def test_wan_full_width_block_gradients(wn):
+    """Wan2.1-T2V-1.3B WIDTH (D = 1536, 12 heads x 128, ffn 8960, text dim 4096), two blocks, 4 608 video tokens (4 x 48 x 96 latents) with CFG:
+    the large-grid kernels -- persistent GEMMs, the hand-scheduled self-attention with its log-sum-exp, the cross-attention backward over 512
+    text keys, split-K weight gradients on the side stream -- vs the oracle's autograd on the host cores and its bf16 band.  (Norm weights around
+    0.3: see tests/test_gpu_qwen_backward.py on the conditioning of random full-width models.)"""
+    from oracle import wan_ref as R
+    cfg_o = R.WanConfig(num_layers=2)
+    ad, mod = _build(wn, cfg_o, lambda n: any(k in n for k in DEFAULT_TARGETS), seed=11, std=0.02, norm_mean=0.3)
+    try:
+        B, T, h, w, Nt = 1, 4, 48, 96, 512
+        inp = _inputs(cfg_o, B, T, h, w, Nt, seed=17)
+        t, t_next, eta, smax, guidance = 900.0, 750.0, 0.7, 0.9, 5.0
+        ad.scheduler.set_timesteps(4)
+        ad.scheduler.sigmas = ad.scheduler.sigmas.clone()
+        ad.scheduler.sigmas[1] = smax
+        kw = _kw(inp, B, t, t_next, eta, guidance)
+        with torch.no_grad():
+            ref_out = ad.forward(**kw)
+        out = ad.forward(**kw)
+        assert torch.equal(out.noise_pred.detach(), ref_out.noise_pred) and torch.equal(out.log_prob.detach(), ref_out.log_prob)
+        kl_w = 3.0
+        ((inp["wlp"].cuda() * out.log_prob).sum() + kl_w * (inp["wnp"].cuda() * out.noise_pred).mean()).backward()
+        _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w)
+        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float())
+        plan = next(iter(ad.engine._plans.values()))
+        _compare(mod, g_ref, g_band, f"Wan full-width 2 blocks, S = 4608, CFG (stash + scratch {plan.training_bytes / 2 ** 30:.2f} GiB)", 40)
+    finally:
+        ad.engine.close()
+
+
+def test_wan_optimizer_step_moves_the_policy_and_the_next_backward_works(wn):
+    from oracle import wan_ref as R
+    cfg_o = R.tiny_config()
+    ad, mod = _build(wn, cfg_o, lambda n: any(k in n for k in DEFAULT_TARGETS), seed=9)
+    B, T, h, w, Nt = 2, 2, 8, 8, 16
+    inp = _inputs(cfg_o, B, T, h, w, Nt, seed=6)
+    ad.scheduler.set_timesteps(4)
+    kw = _kw(inp, B, 900.0, 750.0, 0.7, 5.0)
+    kw.pop("next_latents")
+    torch.cuda.manual_seed(3)
+    with torch.no_grad():
+        o0 = ad.forward(**dict(kw, return_kwargs=["next_latents", "log_prob"]))
+    kw2 = dict(kw, next_latents=o0.next_latents.half(), return_kwargs=["log_prob", "dt"])
+    params = [p for p in mod.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=2e-3)
+    adv = torch.tensor([1.0, -1.0]).cuda()
+    ratios = []
+    for it in range(3):
+        out = ad.forward(**kw2)
+        ratio = torch.exp(out.log_prob - o0.log_prob)
+        ratios.append(ratio.detach().cpu())
+        loss = -(adv * ratio).mean()
+        opt.zero_grad()
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+        opt.step()
+    assert torch.equal(ratios[0], torch.ones(B))
+    assert not torch.equal(ratios[1], torch.ones(B))
+    assert float((adv.cpu() * (ratios[2] - 1)).sum()) > 0
+    ad.engine.close()

@@ -1243,6 +1243,95 @@ def test_reference_dgpo_trainer_on_the_qwen_image_plugin(ref):
     assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable)), logged
 
 
+def test_reference_grpo_trainer_on_the_wan_plugin_takes_the_native_backward_when_opted_in(ref):
+    """The Wan native backward (mi355_wan_forward_train / mi355_wan_backward; written at the end of round 4, opt-in until its GPU tests have run:
+    MI355_WAN_NATIVE_BACKWARD=1 = `WanEngine.native_backward_enabled`).  With the flag on and the reference's default Wan target modules
+    trainable (wan2_t2v.py:74-85) the plugin's grad-mode `forward()` runs `WanPlan.forward_train` + the engine's scheduler step +
+    `WanPlan.backward` (mi355_flow.autograd.wan_replay) through the reference's own, unmodified `GRPOTrainer.optimize()`: the torch transformer
+    is never called, first ratio exactly 1, KL term exactly 0, the engine's gradient moves the parameters.  With the flag off (the default) the
+    same epoch takes the engine-valued replay (`test_reference_grpo_trainer_on_the_family_plugins_replays_engine_valued[wan]`)."""
+    import mi355_flow.engine as ME
+    import mi355_flow.vae as MV
+    import mi355_flow.wan as MW
+    from flow_factory.trainers.grpo import GRPOTrainer
+    from oracle import make_rollout_golden as G
+    P = ref
+    M, K, Nt = 2, 2, 7
+    names = ["blocks.0.attn1.to_q.weight", "blocks.0.attn1.to_q.bias", "blocks.0.attn2.to_k.weight", "patch_embedding.weight"]
+
+    def make_adapter(cfg, acc):
+        tr = F.build_module_tree({n: ((8, 8) if n.endswith("weight") else (8,)) for n in names}, buffers=(), cls=F.FakeTransformer).bfloat16()
+        tr.config = types.SimpleNamespace(in_channels=16, out_channels=16, patch_size=(1, 2, 2), num_layers=1, num_attention_heads=1,
+                                          attention_head_dim=128, ffn_dim=64, text_dim=G.WAN_TD, freq_dim=256, eps=1e-6)
+        saved = (P.WanEngine, P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder)
+        P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = F.FakeVAEDecoder, types.SimpleNamespace(from_hf=lambda c: c), F.FakeVideoVAEDecoder
+        F.WanTrainEngineModel.NAMES = names
+        P.WanEngine = F.WanTrainEngineModel
+        try:
+            class Plug(P.Wan2T2VNativeAdapter):
+                def load_pipeline(self):
+                    return _wan_pipeline(tr)
+            ad = Plug(cfg, acc)
+        finally:
+            P.WanEngine, P.VAEDecoder, P.VAEConfig, MV.WanVAEDecoder = saved
+        return ad, tr
+
+    def tweak(cfg):
+        _small(cfg.training_args, guidance_scale=1.0, kl_beta=0.05, kl_type="v-based", clip_range=(-1e-4, 1e-4), adv_clip_range=(-5.0, 5.0))
+        cfg.training_args.height = cfg.training_args.width = 64
+        cfg.training_args.resolution = (64, 64)
+        cfg.training_args.extra_kwargs = {**getattr(cfg.training_args, "extra_kwargs", {}), "num_frames": 5}
+    g = torch.Generator().manual_seed(3)
+    batches = [dict(prompt=[f"prompt {i}"] * K, prompt_ids=torch.full((K, 4), i), prompt_embeds=torch.randn(1, Nt, G.WAN_TD, generator=g).bfloat16().repeat(K, 1, 1))
+               for i in range(M)]
+    real = (MW.sde_step, ME.sde_step, ME.sde_step_bwd, MV.WanVAEDecoder, MW.WanEngine.native_backward_enabled)
+    MW.sde_step = ME.sde_step = F.oracle_sde_step
+    ME.sde_step_bwd = F.oracle_sde_step_bwd
+    MV.WanVAEDecoder = F.FakeVideoVAEDecoder
+    MW.WanEngine.native_backward_enabled = True
+    try:
+        tr, ad, tr_mod, logged = _real_trainer(P, GRPOTrainer, "/root/reference/examples/grpo/full/wan21/t2v.yaml", tweak, batches, K, lr=5.0,
+                                               make_adapter=make_adapter)
+        trainable = ad.get_trainable_parameters()
+        assert len(trainable) == 3                                # attn1.to_q weight + bias, attn2.to_k weight; the patch embedding stays frozen
+        before = [p_.detach().clone() for p_ in trainable]
+        torch.manual_seed(99)
+        samples = tr.sample()
+        F.FakeTransformer.calls = 0
+        tr.compute_advantages(samples, {"r": torch.tensor([0.1, 0.9, 0.4, 0.2])}, store_to_samples=True)
+        torch.manual_seed(1234)
+        tr.optimize(samples)
+        kinds = [c[0] for c in ad.engine.calls]
+        assert "forward_train" in kinds and "backward" in kinds, kinds
+        assert F.FakeTransformer.calls == 0                       # the torch transformer was never called
+        first = logged[0][1]
+        assert first["train/ratio_min"] == 1.0 and first["train/ratio_max"] == 1.0, first
+        assert float(first["train/kl_div"]) == 0.0
+        assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable))
+        assert all(torch.isfinite(torch.as_tensor(v)).all() for _, d in logged for v in d.values())
+    finally:
+        MW.sde_step, ME.sde_step, ME.sde_step_bwd, MV.WanVAEDecoder, MW.WanEngine.native_backward_enabled = real
+
+
+def test_cfg_pair_adjoint_of_the_oracle_step_splits_the_gradient_like_the_combine():
+    """`_plugin_fakes.oracle_sde_step_bwd` with a CFG pair (the Wan replay's step adjoint on the CPU): d v = [uncond | text] with
+    d uncond = (1 - g) d v_combined, d text = g d v_combined."""
+    g = torch.Generator().manual_seed(0)
+    B = 2
+    x, x1 = torch.randn(B, 4, 2, 4, 4, generator=g), torch.randn(B, 4, 2, 4, 4, generator=g)
+    vt, vu = torch.randn(B, 4, 2, 4, 4, generator=g).bfloat16(), torch.randn(B, 4, 2, 4, 4, generator=g).bfloat16()
+    glp = torch.randn(B, generator=g)
+    kw = dict(latents=x, next_latents=x1, sigma=torch.full((B,), 0.9), sigma_next=torch.full((B,), 0.75), eta=0.7, sigma_max=0.95, dynamics="Flow-SDE",
+              compute_log_prob=True, g_log_prob=glp)
+    guidance = 4.0
+    dv = F.oracle_sde_step_bwd(vt, vu, guidance, **kw)
+    assert dv.shape == (2 * B, 4, 2, 4, 4)
+    comb = (vu.float() + guidance * (vt.float() - vu.float())).to(torch.bfloat16)
+    dc = F.oracle_sde_step_bwd(comb, None, 1.0, **kw)
+    # (the pair path differentiates the fp32 combine, the single path the bf16-rounded one: the step is linear in v up to the rounding of comb)
+    assert torch.allclose(dv[B:], guidance * dc, rtol=2e-2, atol=1e-4) and torch.allclose(dv[:B], (1 - guidance) * dc, rtol=2e-2, atol=1e-4)
+
+
 def test_reference_dgpo_trainer_on_the_qwen_image_plugin_takes_the_native_backward(ref):
     """BASELINE.json configs[4] with the round-4 native Qwen-Image backward: the reference's own `DGPOTrainer` on the Qwen-Image plugin whose
     engine double carries the training API (`QwenPlan.forward_train` / `.backward`).  The DSM training forward -- WITHOUT a stored transition,
