@@ -99,8 +99,9 @@ class WanEngine(WeightHolder):
         return p
 
     # ---------------------------------------------------------------- weight gradients (mi355_flow/autograd.py: wan_replay)
-    #: the native backward was written at the end of round 4 and has not run on a GPU yet: opt-in until its GPU tests have
-    native_backward_enabled = os.environ.get("MI355_WAN_NATIVE_BACKWARD") == "1"
+    #: the native backward (end of round 4; its seven GPU tests are green on MI355X: profiles/r04u_*, r04v_*).  MI355_WAN_NATIVE_BACKWARD=0 keeps
+    #: grad-mode forward() on the engine-valued replay (value = engine, gradient = the reference's torch path)
+    native_backward_enabled = os.environ.get("MI355_WAN_NATIVE_BACKWARD", "1") != "0"
 
     def grad_supported(self, name: str) -> int:
         """1 = the native backward produces a gradient for this parameter (the linear layers inside the transformer blocks), 0 = it does not."""
@@ -446,7 +447,7 @@ class WanRolloutMixin:
         if torch.is_grad_enabled() and getattr(self, "_live_weights", None) is not None and WanEngine.native_backward_enabled \
                 and getattr(self, "engine_2", None) is None:
             # optimize() (trainers/grpo.py:263): the replay WITH autograd on the engine's differentiable forward + native backward
-            # (mi355_flow.autograd.wan_replay) when its backward covers the trainable set (single-expert pipelines; opt-in: see WanEngine)
+            # (mi355_flow.autograd.wan_replay) when its backward covers the trainable set (single-expert pipelines; MI355_WAN_NATIVE_BACKWARD=0 opts out)
             from . import autograd as AG
             self._before_engine_call()
             why = AG.unsupported_reason(self)
@@ -545,7 +546,7 @@ class Wan2T2VNativeAdapter(WanRolloutMixin):
         self._live_weights = None
         if isinstance(state_dict, torch.nn.Module):
             # a torch module with HF parameter names (possibly DDP / peft wrapped): its CURRENT parameters are re-bound before every engine
-            # call, and grad-mode forward() differentiates w.r.t. its trainable parameters (mi355_flow/autograd.py: wan_replay; opt-in)
+            # call, and grad-mode forward() differentiates w.r.t. its trainable parameters (mi355_flow/autograd.py: wan_replay)
             from .binding import LiveWeights
             module = state_dict
             self._live_weights = LiveWeights(self.engine, lambda: module)

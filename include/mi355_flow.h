@@ -338,7 +338,7 @@ int mi355_wan_rollout(mi355_wan_plan* plan, void* stream, int n_steps, const flo
  * launch sequence on per-block buffers (prediction bit-identical), the backward writes the gradients of blocks.N.{attn1.{to_q,to_k,to_v,
  * to_out.0},attn2.{to_q,to_k,to_v,to_out.0},ffn.net.{0.proj,2}} (the reference's Wan default target modules, wan2_t2v.py:74-85) into the
  * buffers registered with mi355_wan_set_grad[_typed]; dv = d loss / d v_out for BOTH CFG halves [uncond | text], as mi355_sde_step_bwd
- * produces it.  STATUS at the end of round 4: compiled, not yet run on a GPU (the host side keeps it behind MI355_WAN_NATIVE_BACKWARD=1). */
+ * produces it.  Validated by tests/test_gpu_wan_backward.py (profiles/r04u_*, r04v_*); MI355_WAN_NATIVE_BACKWARD=0 keeps the host side off it. */
 int mi355_wan_set_grad(mi355_wan* e, const char* name, float* grad);
 int mi355_wan_set_grad_typed(mi355_wan* e, const char* name, void* grad, int dtype);
 int mi355_wan_clear_grads(mi355_wan* e);

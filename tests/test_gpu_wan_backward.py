@@ -1,8 +1,8 @@
 """GPU parity of the Wan native backward (SURVEY.md 8(f) N1 over N4: mi355_wan_forward_train / mi355_wan_backward -- head_dim-128 attention backward
 with a separate key length (cross-attention), full-row RMSNorm + 3-D RoPE backward, the un-gated cross-attention residual, CFG as one forward
 batch) against torch autograd through the CPU oracle (oracle/wan_ref.py): fp32, and the bf16-emulating run that gives the tolerance band
-(`rel-L2 < 3 x band + 5e-3`).  GATED: this code was written at the end of round 4 and had not run on a GPU when it was committed -- the tests
-(and the product path they exercise) need MI355_WAN_NATIVE_BACKWARD=1; round 5's first GPU call runs them (scripts/gpu_r5_call1.sh)."""
+(`rel-L2 < 3 x band + 5e-3`).  Written at the end of round 4; first GPU contact: 2 of 3 gradient cases green, the third a scratch overflow for a
+clip shorter than its prompt (profiles/r04s_*, r04t_*); all seven green after the fix (profiles/r04u_*, r04v_*)."""
 import math
 import os
 
@@ -12,8 +12,7 @@ import torch
 
 import _plugin_fakes as PF
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("MI355_WAN_NATIVE_BACKWARD") != "1",
-                                                  reason="opt-in until its first GPU run: MI355_WAN_NATIVE_BACKWARD=1")]
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("MI355_WAN_NATIVE_BACKWARD") == "0", reason="MI355_WAN_NATIVE_BACKWARD=0 opts out")]
 
 
 def _rel(a, b):

@@ -1243,13 +1243,13 @@ def test_reference_dgpo_trainer_on_the_qwen_image_plugin(ref):
     assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable)), logged
 
 
-def test_reference_grpo_trainer_on_the_wan_plugin_takes_the_native_backward_when_opted_in(ref):
-    """The Wan native backward (mi355_wan_forward_train / mi355_wan_backward; written at the end of round 4, opt-in until its GPU tests have run:
-    MI355_WAN_NATIVE_BACKWARD=1 = `WanEngine.native_backward_enabled`).  With the flag on and the reference's default Wan target modules
+def test_reference_grpo_trainer_on_the_wan_plugin_takes_the_native_backward(ref):
+    """The Wan native backward (mi355_wan_forward_train / mi355_wan_backward; end of round 4; `WanEngine.native_backward_enabled`,
+    MI355_WAN_NATIVE_BACKWARD=0 opts out).  With the reference's default Wan target modules
     trainable (wan2_t2v.py:74-85) the plugin's grad-mode `forward()` runs `WanPlan.forward_train` + the engine's scheduler step +
     `WanPlan.backward` (mi355_flow.autograd.wan_replay) through the reference's own, unmodified `GRPOTrainer.optimize()`: the torch transformer
-    is never called, first ratio exactly 1, KL term exactly 0, the engine's gradient moves the parameters.  With the flag off (the default) the
-    same epoch takes the engine-valued replay (`test_reference_grpo_trainer_on_the_family_plugins_replays_engine_valued[wan]`)."""
+    is never called, first ratio exactly 1, KL term exactly 0, the engine's gradient moves the parameters.  On an engine without the training API
+    (or with the flag off) the same epoch takes the engine-valued replay (`test_reference_grpo_trainer_on_the_family_plugins_replays_engine_valued[wan]`)."""
     import mi355_flow.engine as ME
     import mi355_flow.vae as MV
     import mi355_flow.wan as MW
