@@ -449,3 +449,48 @@ def test_head_dim_128_training_step_schedules_are_race_free(family):
             ad.engine.close()
     finally:
         lib.mi355_tune_set(12, 2); lib.mi355_tune_set(14, 2)
+
+
+def test_wan_training_step_schedule_is_race_free():
+    """The Wan optimize() replay step as emitted (training-mode forward on the caller's stream, backward with the weight-gradient GEMMs on the
+    training state's side stream): every launch reports its regions; no unordered conflicting pair.  (Written after round 4's GPU budget was
+    spent: first run = round 5's first GPU call.)"""
+    import os
+    if os.environ.get("MI355_WAN_NATIVE_BACKWARD") == "0":
+        pytest.skip("MI355_WAN_NATIVE_BACKWARD=0 opts out")
+    from mi355_flow import _lib, wan as wn
+    import test_gpu_wan_backward as TW
+    from oracle import wan_ref as R
+    lib = _lib.load()
+    lib.mi355_tune_set(26, 1)
+    cfg_o = R.tiny_config()
+    ad, mod = TW._build(wn, cfg_o, lambda n: any(k in n for k in TW.DEFAULT_TARGETS), seed=31)
+    B = 2
+    inp = TW._inputs(cfg_o, B, 2, 8, 12, 17, seed=9)
+    ad.scheduler.set_timesteps(4)
+    kw = TW._kw(inp, B, 750.0, 500.0, 0.7, 5.0)
+    wlp, wnp = inp["wlp"].cuda(), inp["wnp"].cuda()
+
+    def step():
+        for prm in mod.parameters():
+            prm.grad = None
+        out = ad.forward(**kw)
+        ((wlp * out.log_prob).sum() + (wnp * out.noise_pred).mean()).backward()
+
+    try:
+        step()
+        text = _trace_of(lib, step, tag="wan_train_step")
+        import _sched_check as SC
+        s = SC.parse(text)
+        names = {o.name for o in s.ops}
+        assert {"attention128_bwd", "attn128_bwd_prep", "norm_rope_full_bwd", "ln_mod_bwd", "gate_mul", "transpose", "gemm.f32"} <= names, sorted(names)
+        assert len(s.streams()) == 2, s.streams()
+        races = s.races()
+        assert races == [], races[:5]
+        nw = SC.n_waits(text)
+        needed = [k for k in range(nw) if SC.parse(text, drop_waits=[k]).races(limit=1)]
+        print(f"wan optimize() step: {sum(1 for o in s.ops if o.regions)} launches on 2 streams, {nw} stream waits, {len(needed)} of them individually "
+              f"necessary, no race")
+        assert nw > 0 and len(needed) >= 0.5 * nw, (nw, len(needed))
+    finally:
+        ad.engine.close()
