@@ -458,6 +458,8 @@ def test_wan_training_step_schedule_is_race_free():
     import os
     if os.environ.get("MI355_WAN_NATIVE_BACKWARD") == "0":
         pytest.skip("MI355_WAN_NATIVE_BACKWARD=0 opts out")
+    if os.environ.get("MI355_RUN_UNVERIFIED") != "1":
+        pytest.skip("written after round 4's GPU budget was spent; never run: MI355_RUN_UNVERIFIED=1 (scripts/gpu_r5_call1.sh)")
     from mi355_flow import _lib, wan as wn
     import test_gpu_wan_backward as TW
     from oracle import wan_ref as R
