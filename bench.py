@@ -587,6 +587,23 @@ def main():
                                                        "(qwen_image.py:81-89); grad-mode log-prob torch.equal the no-grad replay's; untimed w.r.t. `value`"}
         except Exception as e:  # noqa: BLE001
             out["optimize_step_qwen_image"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and not flux_mode and not args.no_train_step:
+        # ... and for Wan2.1-T2V-1.3B (native backward written at the very end of round 4: its seven GPU tests are green, its full-depth step had
+        # not been timed when the round's GPU budget ran out -- this leg is that measurement): 480 x 832 x 17 frames, B = 1, CFG, default target
+        # modules; own process, recorded, never raised
+        try:
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "wan_train_bench.py"), "--batch", "1", "--frames", "17", "--iters", "2"],
+                               capture_output=True, text=True, timeout=300)
+            tb = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            out["optimize_step_wan21"] = {"ms_forward_backward": tb["ms_forward_backward"], "ms_forward_train": tb["ms_forward_train"],
+                                          "ms_forward_nograd": tb["ms_forward_nograd"], "achieved": tb["tflops_step"], "unit": "TFLOP/s",
+                                          "frac": tb["frac_of_2500"], "trainable_params": tb["trainable_params"], "ratio_is_one": tb["ratio_is_one"],
+                                          "stash_plus_scratch_GiB": tb["stash_plus_scratch_GiB"], "tokens": tb["tokens"], "n_cfg": tb["n_cfg"],
+                                          "note": "Wan2.1-T2V-1.3B geometry (30 layers), B = 1, 480 x 832 x 17 frames, CFG, default target modules "
+                                                  "(wan2_t2v.py:74-85); untimed w.r.t. `value`"}
+        except Exception as e:  # noqa: BLE001
+            out["optimize_step_wan21"] = {"error": repr(e), "stderr_tail": (r.stderr[-400:] if "r" in dir() and hasattr(r, "stderr") else "")}
     if rank == 0 and world == 1 and not flux_mode and not args.no_families:
         # BASELINE.json configs[2..4] on the driver's box: the other engines' rollouts at their own geometries, 2 denoise
         # steps each (the per-step cost does not depend on the step count), each in its own process (24 / 3 / 41 GB of weights), untimed w.r.t.

@@ -89,7 +89,7 @@ t_ng, t_f, t_fb = timed(nograd, args.iters), timed(fwd, args.iters), timed(fwd_b
 lp_a, lp_b = nograd().log_prob, ad.forward(**kw).log_prob.detach()
 D, F, L, Bp = cfg.dim, cfg.ffn_dim, cfg.num_layers, B * n_cfg
 S = T * (h // 2) * (w // 2)
-lin = L * S * (8 * D * D + 2 * D * F)                       # per token and block: attn1 q k v o + attn2 q o (6 D^2; text k / v are per text token) + FFN
+lin = L * S * (6 * D * D + 2 * D * F)                       # per token and block: attn1 q k v o + attn2 q o (6 D^2; text k / v are per text token) + FFN
 lin += L * Nt * 2 * D * D
 attn = L * (2 * S * S * D + 2 * S * Nt * D)
 fwd_fl = 2.0 * (lin + attn) * Bp
