@@ -364,9 +364,9 @@ if _RefAdapter is not None:
             def forward(self, *args, **kwargs):
                 if bool(getattr(self.scheduler, "is_eval", False)):
                     return _RefWan.forward(self, *args, **kwargs)
-                if torch.is_grad_enabled() and not (WanEngine.native_backward_enabled and getattr(self, "engine_2", None) is None):
-                    # optimize() of a two-expert (Wan2.2) pipeline, or MI355_WAN_NATIVE_BACKWARD=0: autograd on the reference path, values from the
-                    # engine.  Otherwise the mixin's forward dispatches to the native backward and `_grad_fallback` is this route.
+                if torch.is_grad_enabled() and not WanEngine.native_backward_enabled:
+                    # MI355_WAN_NATIVE_BACKWARD=0: autograd on the reference path, values from the engine.  Otherwise the mixin's forward
+                    # dispatches to the native backward (of the expert the timestep selects) and `_grad_fallback` is this route.
                     return self._replay_on_reference(_RefWan.forward, WanRolloutMixin.forward, args, kwargs)     # (called under no_grad)
                 return WanRolloutMixin.forward(self, *args, **kwargs)
 

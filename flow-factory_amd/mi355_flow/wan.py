@@ -444,18 +444,20 @@ class WanRolloutMixin:
         kw = dict(t=t, latents=latents, prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds, guidance_scale=guidance_scale,
                   guidance_scale_2=guidance_scale_2, t_next=t_next, next_latents=next_latents, noise_level=noise_level,
                   attention_kwargs=attention_kwargs, compute_log_prob=compute_log_prob, return_kwargs=return_kwargs, boundary_timestep=boundary_timestep)
-        if torch.is_grad_enabled() and getattr(self, "_live_weights", None) is not None and WanEngine.native_backward_enabled \
-                and getattr(self, "engine_2", None) is None:
+        if torch.is_grad_enabled() and getattr(self, "_live_weights", None) is not None and WanEngine.native_backward_enabled:
             # optimize() (trainers/grpo.py:263): the replay WITH autograd on the engine's differentiable forward + native backward
-            # (mi355_flow.autograd.wan_replay) when its backward covers the trainable set (single-expert pipelines; MI355_WAN_NATIVE_BACKWARD=0 opts out)
+            # (mi355_flow.autograd.wan_replay) when its backward covers the trainable set of the transformer THIS step runs on (Wan2.2: the
+            # expert the timestep selects, wan2_t2v.py:476-487).  MI355_WAN_NATIVE_BACKWARD=0 opts out.
             from . import autograd as AG
             self._before_engine_call()
-            why = AG.unsupported_reason(self)
+            t0 = float(torch.as_tensor(t, dtype=torch.float32).reshape(-1)[0])
+            host = self._replay_host(self._expert(t0, guidance_scale, guidance_scale_2, boundary_timestep)[0])
+            why = AG.unsupported_reason(host)
             sampled = next_latents is None and ("next_latents" in return_kwargs or (compute_log_prob and "log_prob" in return_kwargs))
             if why is None and sampled:
                 why = "a sampled next state (or its log-prob) was requested with autograd"
             if why is None:
-                return self._forward_impl(grad=True, **kw)
+                return self._forward_impl(grad=True, host=host, **kw)
             if not why.startswith("the bound module has no trainable"):
                 return self._grad_fallback(why, kw)
         return self._forward_nograd(**kw)
@@ -469,8 +471,17 @@ class WanRolloutMixin:
         plugin overrides this with the reference's autograd path)."""
         raise NotImplementedError(f"mi355_flow: Wan forward() with autograd is not available natively: {why}")
 
+    def _replay_host(self, eng):
+        """What `mi355_flow.autograd` differentiates against for a step on `eng`: this adapter (single transformer / the high-noise expert), or
+        the low-noise expert's (engine, live module binding) pair of a two-expert Wan2.2 pipeline."""
+        if eng is self.engine or self.engine_2 is None:
+            return self
+        import types
+        return types.SimpleNamespace(engine=self.engine_2, _live_weights=getattr(self, "_live_weights_2", None),
+                                     _sync_weights=getattr(self, "_sync_weights", None))
+
     def _forward_impl(self, t, latents, prompt_embeds, negative_prompt_embeds, guidance_scale, guidance_scale_2, t_next, next_latents, noise_level,
-                      attention_kwargs, compute_log_prob, return_kwargs, boundary_timestep, grad: bool) -> SDESchedulerOutput:
+                      attention_kwargs, compute_log_prob, return_kwargs, boundary_timestep, grad: bool, host=None) -> SDESchedulerOutput:
         self._before_engine_call()
         if attention_kwargs:
             raise NotImplementedError("mi355_flow: attention_kwargs are not supported by the native engine")
@@ -509,7 +520,7 @@ class WanRolloutMixin:
             call = dict(latents=latents, train_args=(latents, t0.reshape(1), enc_a, enc_b), cfg_guidance=float(guidance_scale) if do_cfg else None,
                         sigma=sigma, sigma_next=sigma_next, eta=noise_level, sigma_max=float(sched.sigmas[1]), dynamics=dyn,
                         next_latents=next_latents if replay else latents, compute_log_prob=clp)
-            lp, npred, mean, std, dtt = AG.wan_replay(self, plan, call)
+            lp, npred, mean, std, dtt = AG.wan_replay(host if host is not None else self, plan, call)
             res = dict(noise_pred=npred, next_latents=next_latents.float() if replay else None, next_latents_mean=mean, std_dev_t=std.view(view),
                        dt=dtt.view(view), log_prob=lp if clp else None)
             return self._output_cls.from_dict({k: res[k] for k in return_kwargs if k in res})

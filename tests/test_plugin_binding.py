@@ -1313,6 +1313,73 @@ def test_reference_grpo_trainer_on_the_wan_plugin_takes_the_native_backward(ref)
         MW.sde_step, ME.sde_step, ME.sde_step_bwd, MV.WanVAEDecoder, MW.WanEngine.native_backward_enabled = real
 
 
+def test_wan22_two_expert_grad_forward_differentiates_the_expert_the_timestep_selects():
+    """Wan2.2 (two transformers, `boundary_ratio`): a grad-mode `forward()` runs on the expert the timestep selects (wan2_t2v.py:476-487) and the
+    native replay differentiates THAT transformer's live module: above the boundary the high-noise expert's `forward_train` / `backward` and
+    gradients into `transformer`, below it the low-noise expert's and gradients into `transformer_2`, with its own guidance scale.  Mixin-level
+    test on the training doubles (no Flow-Factory classes involved)."""
+    import mi355_flow.engine as ME
+    import mi355_flow.wan as MW
+    from mi355_flow.binding import LiveWeights
+    from mi355_flow.scheduler import SDESchedulerOutput
+    from oracle import make_rollout_golden as G
+    names = ["blocks.0.attn1.to_q.weight", "blocks.0.attn2.to_v.bias"]
+    mods, engs = [], []
+    for k in range(2):
+        mods.append(F.build_module_tree({n: ((8, 8) if n.endswith("weight") else (8,)) for n in names}, buffers=(), seed=3 + k).bfloat16())
+        F.WanTrainEngineModel.NAMES = names
+        e = F.WanTrainEngineModel(types.SimpleNamespace())
+        e.expert = k
+        engs.append(e)
+
+    class Host(MW.WanRolloutMixin):
+        _output_cls = SDESchedulerOutput
+
+        def __init__(self):
+            self.engine, self.engine_2, self.boundary_ratio = engs[0], engs[1], 0.5
+            self.scheduler = MW.UniPCMultistepSDEScheduler(flow_shift=3.0, noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=1, seed=42)
+            self.scheduler.set_timesteps(4)
+            self._live_weights = LiveWeights(engs[0], lambda: mods[0])
+            self._live_weights_2 = LiveWeights(engs[1], lambda: mods[1])
+
+        def _sync_weights(self):
+            return self._live_weights.sync() + self._live_weights_2.sync()
+
+        def _before_engine_call(self):
+            self._sync_weights()
+
+    real = (MW.sde_step, ME.sde_step, ME.sde_step_bwd, MW.WanEngine.native_backward_enabled)
+    MW.sde_step = ME.sde_step = F.oracle_sde_step
+    ME.sde_step_bwd = F.oracle_sde_step_bwd
+    MW.WanEngine.native_backward_enabled = True
+    try:
+        h = Host()
+        g = torch.Generator().manual_seed(1)
+        B = 2
+        x, x1 = torch.randn(B, 16, 2, 4, 4, generator=g).half(), torch.randn(B, 16, 2, 4, 4, generator=g).half()
+        pe, ne = torch.randn(B, 5, G.WAN_TD, generator=g).bfloat16(), torch.randn(B, 5, G.WAN_TD, generator=g).bfloat16()
+        for t, t_next, which in ((900.0, 750.0, 0), (300.0, 150.0, 1)):
+            for m in mods:
+                for p_ in m.parameters():
+                    p_.grad = None
+            for e in engs:
+                e.calls.clear()
+            out = h.forward(t=torch.full((B,), t), t_next=torch.full((B,), t_next), latents=x, next_latents=x1, prompt_embeds=pe, negative_prompt_embeds=ne,
+                            guidance_scale=5.0, guidance_scale_2=3.0, noise_level=0.7, compute_log_prob=True, return_kwargs=["log_prob", "noise_pred"])
+            assert out.log_prob.requires_grad
+            out.log_prob.sum().backward()
+            kinds = [[c[0] for c in e.calls] for e in engs]
+            assert "forward_train" in kinds[which] and "backward" in kinds[which] and kinds[1 - which] == [], kinds
+            assert all(p_.grad is not None and float(p_.grad.float().abs().sum()) > 0 for p_ in mods[which].parameters())
+            assert all(p_.grad is None for p_ in mods[1 - which].parameters())
+            with torch.no_grad():                      # the no-grad replay of the same call: same expert, same values
+                ref = h.forward(t=torch.full((B,), t), t_next=torch.full((B,), t_next), latents=x, next_latents=x1, prompt_embeds=pe, negative_prompt_embeds=ne,
+                                guidance_scale=5.0, guidance_scale_2=3.0, noise_level=0.7, compute_log_prob=True, return_kwargs=["log_prob", "noise_pred"])
+            assert torch.equal(out.log_prob.detach(), ref.log_prob) and torch.equal(out.noise_pred.detach(), ref.noise_pred)
+    finally:
+        MW.sde_step, ME.sde_step, ME.sde_step_bwd, MW.WanEngine.native_backward_enabled = real
+
+
 def test_cfg_pair_adjoint_of_the_oracle_step_splits_the_gradient_like_the_combine():
     """`_plugin_fakes.oracle_sde_step_bwd` with a CFG pair (the Wan replay's step adjoint on the CPU): d v = [uncond | text] with
     d uncond = (1 - g) d v_combined, d text = g d v_combined."""
