@@ -379,7 +379,15 @@ hipError_t launch_cfg_rescale_bwd(const bf16_t* neg, const bf16_t* pos, float g,
 
 int norm_rope_parts(int rows_per_sample) { return (rows_per_sample + 4 * NR_RPW - 1) / (4 * NR_RPW) * 4; }   // partial rows per sample
 hipError_t launch_norm_rope_full(const NormRopeFullParams& p, hipStream_t stream) {
-    if (p.M <= 0 || p.H <= 0 || p.H > 48 || (p.src_ld & 7) || (p.col & 7) || ((size_t)p.src & 15) || ((size_t)p.out & 15)) return hipErrorInvalidValue;
+    if (p.M <= 0 || p.H <= 0 || p.H > 48 || p.rows_per_sample <= 0 || (p.src_ld & 7) || (p.col & 7) || ((size_t)p.src & 15) || ((size_t)p.out & 15))
+        return hipErrorInvalidValue;
+    if (sched_trace_on()) {       // (regions: the source rows, the weight; the head-major output rows of every (sample, head), 1 / rms, the measured maxima)
+        const size_t blocks = (size_t)((p.M + p.rows_per_sample - 1) / p.rows_per_sample) * p.H, len = (size_t)p.rows_per_sample * 256, stride = (size_t)p.S_pad * 256;
+        const size_t nb = (size_t)((p.M + p.rows_per_sample - 1) / p.rows_per_sample);
+        sched_trace_launch("norm_rope_full", stream, {treg(p.src + p.col, ((size_t)(p.M - 1) * p.src_ld + (size_t)p.H * 128) * 2), treg(p.weight, (size_t)p.H * 512)},
+                           {tregs(p.out + (size_t)p.s_off * 128, len, stride, blocks), treg(p.rstd_out, p.rstd_out ? (size_t)p.M * 4 : 0),
+                            treg(p.max2, p.max2 ? nb * p.H * 4 : 0), treg(p.max2_part, p.max2 ? nb * (size_t)norm_rope_parts(p.rows_per_sample) * p.H * 4 : 0)});
+    }
     if (p.max2) {
         if (!p.max2_part || p.s_off != 0 || p.M % p.rows_per_sample) return hipErrorInvalidValue;
         const int B = p.M / p.rows_per_sample;
