@@ -20,6 +20,11 @@ layers inside the transformer blocks (attention projections of both streams, att
 linears, q/k norm weights, timestep / pooled-text MLPs, embedders, proj_out) `denoise_replay` switches the engine to its full
 scope for that step (`mi355_engine_set_train_scope`).  `unsupported_reason` reports what cannot be differentiated natively (a
 module that is not bound, trainable tensors the engine does not know) and the caller falls back.
+
+Round 4: the same contract for the other families -- `flux_replay` (FLUX.1), `qwen_replay` (Qwen-Image; the true-CFG combine is inside the
+engine's forward / backward) and `wan_replay` (Wan; CFG lives in the fused scheduler step, whose adjoint returns d v for both halves of the
+forward batch) share ONE autograd node, `_FluxReplayFn`: training-mode transformer forward -> `engine.sde_step` -> `engine.sde_step_bwd` ->
+the plan's `backward`.  Gradient buffers are bf16 where the parameter is (`_grad_buffers`: the engines' reduction kernels round on the way out).
 """
 from __future__ import annotations
 
