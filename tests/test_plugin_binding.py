@@ -1380,6 +1380,68 @@ def test_wan22_two_expert_grad_forward_differentiates_the_expert_the_timestep_se
         MW.sde_step, ME.sde_step, ME.sde_step_bwd, MW.WanEngine.native_backward_enabled = real
 
 
+def test_two_grad_forwards_on_one_flux_plan_before_a_single_backward_recompute_the_stash():
+    """A loss that sums SEVERAL grad-mode `forward()` calls before ONE `backward()` (DPO's chosen / rejected pair, CRD's two timesteps) runs them
+    on the same plan, whose training stash holds only the LAST forward's activations: the autograd node of an earlier call notices the newer
+    serial number and re-runs its own forward on the kept inputs before its backward (`_FluxReplayFn.backward`; the SD3.5 node's GPU test is
+    `test_two_grad_forwards_on_one_plan_before_a_single_backward`).  Here on the FLUX.1 node with the training double: the summed loss's
+    gradients equal the sum of the two calls' separate gradients, and exactly one forward was recomputed."""
+    import mi355_flow.engine as ME
+    import mi355_flow.flux as MF
+    from mi355_flow.binding import LiveWeights
+    from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler, SDESchedulerOutput
+    names = ["transformer_blocks.0.attn.to_q.weight", "transformer_blocks.0.attn.to_k.weight"]
+    mod = F.build_module_tree({n: (8, 8) for n in names}, buffers=(), seed=3).bfloat16()
+    F.FluxTrainEngineModel.NAMES = names
+    eng = F.FluxTrainEngineModel(types.SimpleNamespace(guidance_embeds=True))
+
+    class Host(MF.FluxRolloutMixin):
+        _output_cls = SDESchedulerOutput
+
+        def __init__(self):
+            self.engine = eng
+            self.scheduler = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=1, seed=42, shift=3.0)
+            self.scheduler.set_timesteps(4)
+            self._live_weights = LiveWeights(eng, lambda: mod)
+
+        def _sync_weights(self):
+            return self._live_weights.sync()
+
+        def _before_engine_call(self):
+            self._sync_weights()
+
+    real = (MF.sde_step, ME.sde_step, ME.sde_step_bwd)
+    MF.sde_step = ME.sde_step = F.oracle_sde_step
+    ME.sde_step_bwd = F.oracle_sde_step_bwd
+    try:
+        h = Host()
+        g = torch.Generator().manual_seed(1)
+        B = 2
+        mk = lambda *s_: torch.randn(*s_, generator=g)
+        common = dict(prompt_embeds=mk(B, 5, 128).bfloat16(), pooled_prompt_embeds=mk(B, 128).bfloat16(), height=64, width=64, guidance_scale=3.5,
+                      noise_level=0.7, compute_log_prob=True, return_kwargs=["log_prob"])
+        calls = [dict(common, t=torch.full((B,), 900.0), t_next=torch.full((B,), 750.0), latents=mk(B, 16, 64).half(), next_latents=mk(B, 16, 64).half()),
+                 dict(common, t=torch.full((B,), 750.0), t_next=torch.full((B,), 500.0), latents=mk(B, 16, 64).half(), next_latents=mk(B, 16, 64).half())]
+        w = [mk(B), mk(B)]
+        params = list(mod.parameters())
+
+        def grads_of(loss):
+            for p_ in params:
+                p_.grad = None
+            loss.backward()
+            return [p_.grad.float().clone() for p_ in params]
+
+        separate = [grads_of((w[i] * h.forward(**calls[i]).log_prob).sum()) for i in range(2)]
+        plan = next(iter(eng._plans.values()))
+        n0 = getattr(plan, "recomputed_forwards", 0)
+        both = grads_of((w[0] * h.forward(**calls[0]).log_prob).sum() + (w[1] * h.forward(**calls[1]).log_prob).sum())
+        assert getattr(plan, "recomputed_forwards", 0) == n0 + 1
+        for a, b, c in zip(both, separate[0], separate[1]):
+            assert torch.allclose(a, b + c, rtol=2e-2, atol=1e-6), (a.flatten()[:3], (b + c).flatten()[:3])        # (bf16 gradient buffers)
+    finally:
+        MF.sde_step, ME.sde_step, ME.sde_step_bwd = real
+
+
 def test_cfg_pair_adjoint_of_the_oracle_step_splits_the_gradient_like_the_combine():
     """`_plugin_fakes.oracle_sde_step_bwd` with a CFG pair (the Wan replay's step adjoint on the CPU): d v = [uncond | text] with
     d uncond = (1 - g) d v_combined, d text = g d v_combined."""
