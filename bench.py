@@ -594,7 +594,7 @@ def main():
         try:
             import subprocess
             r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "wan_train_bench.py"), "--batch", "1", "--frames", "17", "--iters", "2"],
-                               capture_output=True, text=True, timeout=180)
+                               capture_output=True, text=True, timeout=90)        # (never timed before: bounded tightly)
             tb = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
             out["optimize_step_wan21"] = {"ms_forward_backward": tb["ms_forward_backward"], "ms_forward_train": tb["ms_forward_train"],
                                           "ms_forward_nograd": tb["ms_forward_nograd"], "achieved": tb["tflops_step"], "unit": "TFLOP/s",
