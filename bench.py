@@ -51,6 +51,17 @@ def attention_flops(cfg, Ni, Nt):
     return 2.0 * (L * 2 * (Ni + Nt) ** 2 * D + Ld * 2 * Ni * Ni * D), L + Ld  # flops / forward / sample, launches
 
 
+def _stream_mode_at_start():
+    """mi355_tune_set key 8 (stream mode of the SD3.5 forward) as THIS process was started: MI355_TUNE's entry, else the library default 2.
+    The per-class legs switch to single stream for their own measurement and must hand back what the run asked for -- a run under
+    MI355_TUNE="8=0" (the single-stream rocprof table) stays single-stream (VERDICT r4 weak #11)."""
+    for kv in filter(None, os.environ.get("MI355_TUNE", "").split(",")):
+        k, _, v = kv.partition("=")
+        if k.strip() == "8":
+            return int(v)
+    return 2
+
+
 def cpu_baseline(budget_s=150.0):
     """Oracle on the host cores: ONE measured fp32 MMDiT-X forward (= one denoise step, n_cfg = 1) of one sample at the bench
     shape (1024^2: 4096 + 333 tokens, 11.25 TFLOP).  A 256^2 forward is timed first; only if its FLOP-scaled estimate exceeds
@@ -335,7 +346,7 @@ def main():
         out["tune"] = os.environ["MI355_TUNE"]          # non-default kernel / launch variants of this run (mi355_tune_set keys)
     if timing and args.kernel_timing == "all":
         out["tune"] = (out.get("tune", "") + ",8=0 (single stream: --kernel-timing all)").lstrip(",")
-        lib.mi355_tune_set(8, 2)
+        lib.mi355_tune_set(8, _stream_mode_at_start())
     if timing and rank == 0:
         attn_fl, attn_launches = attention_flops(cfg, Ni, N_TEXT)
         fwd_per_timed = n_cfg * N * args.steps  # transformer forwards (batch B each) in the timed region on this rank
@@ -415,7 +426,7 @@ def main():
                 out["roofline"]["by_class_single_stream"] = {names5[i]: {"ms": round(ms[i], 3), "launches": int(cnt[i])} for i in range(5) if cnt[i] > 0}
             except Exception as e:  # noqa: BLE001
                 out["roofline"]["gemm"] = {"error": repr(e)}
-            lib.mi355_tune_set(8, 2)
+            lib.mi355_tune_set(8, _stream_mode_at_start())
         lib.mi355_tune_set(2, 1)
         one_rollout(); one_rollout()                    # eager warm-up + capture
         # package power and energy of the rollout (ROCm SMI, in-process): the round-3 finding that the rollout runs at the power cap had clock
@@ -543,15 +554,17 @@ def main():
         # this process's state is touched), reported beside the metric, never inside it; any failure is recorded, not raised.
         try:
             import subprocess
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train_bench.py"), "--batch", "2", "--size", "1024", "--train", "attn",
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train_bench.py"), "--batch", "2", "--size", "1024", "--train", "default",
                                 "--iters", "3"], capture_output=True, text=True, timeout=300)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
             tb = json.loads(line)
             out["optimize_step"] = {"ms_forward_backward": tb["ms_forward_backward"], "ms_forward_train": tb["ms_forward_train"],
                                     "ms_forward_nograd": tb["ms_forward_nograd"], "achieved": tb["tflops_step"], "unit": "TFLOP/s",
                                     "frac": tb["frac_of_2500"], "trainable_params": tb["trainable_params"], "ratio_is_one": tb["ratio_is_one"],
-                                    "note": "B = 2, 1024^2, attention projections trainable (the reference's default target modules); grad-mode "
-                                            "log-prob torch.equal the no-grad replay's; untimed w.r.t. `value`"}
+                                    "trainable": tb["trainable"],
+                                    "note": "B = 2, 1024^2, SD3_5Adapter.default_target_modules (reference sd3_5.py:75-80: the eight attn.* "
+                                            "projections, image and text side; attn2 frozen); grad-mode log-prob torch.equal the no-grad "
+                                            "replay's; untimed w.r.t. `value`"}
         except Exception as e:  # noqa: BLE001
             out["optimize_step"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not flux_mode and not args.no_train_step:

@@ -22,7 +22,9 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
 // backward w.r.t. x:        g  = dxn * (1 + scale) [+ dxn2 * (1 + scale2)]
 //                           dx = rstd * (g - mean(g) - xhat * mean(g * xhat))          (no affine LN weight)
 // dx is ADDED to dres (the residual-stream gradient arriving from later layers) when accumulate != 0.
-template <int LN_MAXC>
+// DMOD = false drops the modulation-gradient partials (4 x LN_MAXC x 8 registers) from the instantiation: the D = 5120 form (Wan2.1-14B,
+// both Wan2.2-A14B experts; their modulation table is not trained through this kernel) would not fit its registers otherwise.
+template <int LN_MAXC, bool DMOD = true>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(LnModBwdParams p, int rows_per_wave) {
     const int lane = threadIdx.x & 63;
     const int first = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rows_per_wave;
@@ -31,18 +33,19 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(LnModBwdParams p, int r
     const int nchunk = p.D >> 3;
     // optional per-sample gradients of the modulation vectors: column partials over this wave's rows live in registers and are flushed
     // with fp32 atomics when the sample changes / at the end (rows_per_wave x fewer atomics than elements; summation order not fixed)
-    float ash[LN_MAXC][8], asc[LN_MAXC][8], ash2[LN_MAXC][8], asc2[LN_MAXC][8];
+    constexpr int AC = DMOD ? LN_MAXC : 1;
+    float ash[AC][8], asc[AC][8], ash2[AC][8], asc2[AC][8];
     int cur_b = first / p.rows_per_sample;
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int c = 0; c < LN_MAXC; ++c)
+        for (int c = 0; c < AC; ++c)
 #pragma unroll
             for (int e = 0; e < 8; ++e) { ash[c][e] = 0.f; asc[c][e] = 0.f; ash2[c][e] = 0.f; asc2[c][e] = 0.f; }
     };
     auto flush = [&](int bb) {
         float* dm = p.dmod + (long)bb * p.mod_ld;
 #pragma unroll
-        for (int c = 0; c < LN_MAXC; ++c) {
+        for (int c = 0; c < AC; ++c) {
             const int ch = lane + c * 64;
             if (ch < nchunk) {
 #pragma unroll
@@ -57,10 +60,10 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(LnModBwdParams p, int r
             }
         }
     };
-    if (p.dmod) zero_acc();
+    if (DMOD && p.dmod) zero_acc();
     for (int row = first; row < last; ++row) {
         const int b = row / p.rows_per_sample;
-        if (p.dmod && b != cur_b) { flush(cur_b); zero_acc(); cur_b = b; }
+        if (DMOD && p.dmod && b != cur_b) { flush(cur_b); zero_acc(); cur_b = b; }
         const bf16_t* mod = p.mod + (long)b * p.mod_ld;
         float v[LN_MAXC][8], g[LN_MAXC][8];
         float sum = 0.f;
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(LnModBwdParams p, int r
                 for (int e = 0; e < 8; ++e) {
                     v[c][e] *= rstd;                         // xhat
                     g[c][e] = d1[e] * (1.f + s1[e]);
-                    if (p.dmod) { ash[c][e] += d1[e]; asc[c][e] += d1[e] * v[c][e]; }
+                    if (DMOD && p.dmod) { ash[c % AC][e] += d1[e]; asc[c % AC][e] += d1[e] * v[c][e]; }
                 }
                 if (p.dy2) {
                     unpack8(*(const uint4*)(p.dy2 + ro + ch * 8), d1);
@@ -105,7 +108,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(LnModBwdParams p, int r
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         g[c][e] += d1[e] * (1.f + s1[e]);
-                        if (p.dmod) { ash2[c][e] += d1[e]; asc2[c][e] += d1[e] * v[c][e]; }
+                        if (DMOD && p.dmod) { ash2[c % AC][e] += d1[e]; asc2[c % AC][e] += d1[e] * v[c][e]; }
                     }
                 }
 #pragma unroll
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(LnModBwdParams p, int r
             }
         }
     }
-    if (p.dmod) flush(cur_b);
+    if (DMOD && p.dmod) flush(cur_b);
 }
 
 // ------------------------------------------------------------------ gated residual backward
@@ -759,11 +762,13 @@ hipError_t launch_ln_mod_bwd(const LnModBwdParams& p, hipStream_t st) {
         sched_trace_launch("ln_mod_bwd", st, {treg(p.x, xb), treg(p.dy, xb), treg(p.dy2, p.dy2 ? xb : 0), mod, treg(p.dres, p.accumulate ? xb : 0)},
                            {treg(p.dres, xb), treg(p.dmod, p.dmod ? (nb * p.mod_ld) * 4 : 0)});
     }
-    if (p.D % 8 != 0 || p.D > 8 * 64 * 8 || p.M <= 0) return hipErrorInvalidValue;
+    // rows up to 4096 wide with modulation gradients; up to 6144 wide without (D = 5120: the 40-head Wan transformers)
+    if (p.D % 8 != 0 || p.D > (p.dmod ? 8 : 12) * 64 * 8 || p.M <= 0) return hipErrorInvalidValue;
     const int rpw = p.dmod ? 16 : 1;         // rows per wave: 16 with the modulation-gradient partials in registers
     const int grid = (p.M + 4 * rpw - 1) / (4 * rpw);
     if (p.D <= 2048) hipLaunchKernelGGL(ln_mod_bwd_kernel<4>, dim3(grid), dim3(256), 0, st, p, rpw);
-    else hipLaunchKernelGGL(ln_mod_bwd_kernel<8>, dim3(grid), dim3(256), 0, st, p, rpw);
+    else if (p.D <= 4096) hipLaunchKernelGGL(ln_mod_bwd_kernel<8>, dim3(grid), dim3(256), 0, st, p, rpw);
+    else hipLaunchKernelGGL((ln_mod_bwd_kernel<12, false>), dim3(grid), dim3(256), 0, st, p, rpw);
     return hipGetLastError();
 }
 

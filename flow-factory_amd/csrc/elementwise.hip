@@ -9,7 +9,8 @@ namespace {
 
 // ------------------------------------------------------------------ LayerNorm + modulate
 // One wave per row; the row (D <= 8*64*MAXC) stays in registers: exact two-pass mean/variance.
-// LN_MAXC 16-byte chunks per lane: 4 -> D <= 2048 (SD3.5, D = 1536), 8 -> D <= 4096 (FLUX.1, D = 3072)
+// LN_MAXC 16-byte chunks per lane: 4 -> D <= 2048 (SD3.5, D = 1536), 8 -> D <= 4096 (FLUX.1, D = 3072), 12 -> D <= 6144 (the 40-head Wan
+// transformers, D = 5120: Wan2.1-14B and both Wan2.2-A14B experts)
 template <int LN_MAXC>
 __global__ __launch_bounds__(256) void ln_mod_kernel(LnModParams p) {
     const int lane = threadIdx.x & 63;
@@ -139,9 +140,10 @@ hipError_t launch_ln_mod(const LnModParams& p, hipStream_t stream) {
                                               treg(p.out2 ? p.mod + p.shift2_off : nullptr, mb), treg(p.out2 ? p.mod + p.scale2_off : nullptr, mb)},
                            {treg(p.out, xb), treg(p.out2, p.out2 ? xb : 0)});
     }
-    if (p.D % 8 != 0 || p.D > 8 * 64 * 8 || p.M <= 0) return hipErrorInvalidValue;
+    if (p.D % 8 != 0 || p.D > 12 * 64 * 8 || p.M <= 0) return hipErrorInvalidValue;
     if (p.D <= 2048) hipLaunchKernelGGL(ln_mod_kernel<4>, dim3((p.M + 3) / 4), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(ln_mod_kernel<8>, dim3((p.M + 3) / 4), dim3(256), 0, stream, p);
+    else if (p.D <= 4096) hipLaunchKernelGGL(ln_mod_kernel<8>, dim3((p.M + 3) / 4), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(ln_mod_kernel<12>, dim3((p.M + 3) / 4), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -1,7 +1,11 @@
 """Times the differentiable replay step of GRPO's optimize() (reference trainers/grpo.py:229-330) on the full
 SD3.5-medium geometry: no-grad replay forward, grad-mode forward (activation stash) and backward, for a trainable set.
 
-    python scripts/train_bench.py [--batch 2] [--size 1024] [--train attn|blocks] [--guidance 1.0] [--iters 3]
+    python scripts/train_bench.py [--batch 2] [--size 1024] [--train default|attn|blocks] [--guidance 1.0] [--iters 3]
+
+--train default = SD3_5Adapter.default_target_modules (reference models/stable_diffusion/sd3_5.py:75-80): the eight "attn.*" projections,
+image AND text side, matched by substring (models/abc.py:1793) -- "attn2.*" does not match.  --train attn = the base class's set
+(models/abc.py:382-385: to_q / to_k / to_v / to_out.0, which also matches attn2).
 
 Algorithmic FLOPs (2 FLOP/MAC, matmuls only): forward F; backward = data gradients of every linear (= their forward
 FLOPs) + attention backward (2.5 x attention forward: 5 tile products vs 2) + weight gradients of the TRAINABLE linears (= their
@@ -20,7 +24,7 @@ import torch  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--size", type=int, default=1024)
-ap.add_argument("--train", choices=["attn", "blocks"], default="attn")
+ap.add_argument("--train", choices=["default", "attn", "blocks"], default="default")
 ap.add_argument("--guidance", type=float, default=1.0)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--only-step", action="store_true", help="run 1 + iters forward+backward steps and nothing else (for rocprofv3)")
@@ -34,12 +38,14 @@ from mi355_flow.weights import module_from_state_dict, synthetic_state_dict  # n
 dev = torch.device("cuda")
 cfg = TransformerConfig()
 mod = module_from_state_dict(synthetic_state_dict(cfg, device=dev, seed=1234))
-ATTN = (".to_q.", ".to_k.", ".to_v.", ".to_out.0.")           # the reference's default target modules (models/abc.py:382-385)
+DEFAULT = ("attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj", "attn.to_add_out",     # SD3_5Adapter.default_target_modules
+           "attn.to_q", "attn.to_k", "attn.to_v", "attn.to_out.0")                          # (sd3_5.py:75-80), substring match
+ATTN = (".to_q.", ".to_k.", ".to_v.", ".to_out.0.")           # BaseAdapter.default_target_modules (models/abc.py:382-385), incl. attn2
 BLOCKS = ATTN + (".add_q_proj.", ".add_k_proj.", ".add_v_proj.", ".to_add_out.", ".ff.net.", ".ff_context.net.")
-keys = ATTN if args.train == "attn" else BLOCKS
+keys = {"default": DEFAULT, "attn": ATTN, "blocks": BLOCKS}[args.train]
 n_train = 0
 for n, p in mod.named_parameters():
-    on = n.startswith("transformer_blocks.") and any(k in n for k in keys)
+    on = any(k in n for k in keys) if args.train == "default" else (n.startswith("transformer_blocks.") and any(k in n for k in keys))
     p.requires_grad_(on)
     n_train += p.numel() if on else 0
 sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=1, seed=42, shift=3.0)
@@ -98,7 +104,9 @@ n_cfg = 2 if cfg_on else 1
 lin_img = L * Ni * (4 * D * D + 2 * D * F) + Ld * Ni * 4 * D * D
 lin_ctx = (L - 1) * Nt * (4 * D * D + 2 * D * F) + Nt * 3 * D * D
 attn = L * 2 * (Ni + Nt) ** 2 * D + Ld * 2 * Ni * Ni * D
-lin_train = (L + Ld) * Ni * 4 * D * D if args.train == "attn" else lin_img + lin_ctx
+lin_train = {"attn": (L + Ld) * Ni * 4 * D * D,
+             "default": L * Ni * 4 * D * D + (L - 1) * Nt * 4 * D * D + Nt * 3 * D * D,   # the last block has no to_add_out
+             "blocks": lin_img + lin_ctx}[args.train]
 fwd_fl = 2.0 * (lin_img + lin_ctx + attn) * B * n_cfg
 bwd_fl = 2.0 * (lin_img + lin_ctx + 2.5 * attn + lin_train) * B * n_cfg
 plan = ad.engine.plan(B, n_cfg, lat, lat, Nt, 1)

@@ -347,10 +347,16 @@ def test_config_a_advantages_from_engine_images_match_the_oracle_pipeline(full):
                     assert agg_e[s][a] > agg_e[s][b], (gidx, a, b)
 
 
+DEFAULT_SD35_TARGETS = ("attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj", "attn.to_add_out",        # reference sd3_5.py:75-80
+                        "attn.to_q", "attn.to_k", "attn.to_v", "attn.to_out.0")
+
+
 def test_config_a_replay_gradients_vs_oracle_autograd(full):
     """SURVEY.md 8(f) N1 at the real geometry: the differentiable replay step on full SD3.5-medium (256^2, B = 1) -- grad-mode log-prob
-    bit-identical to the no-grad replay (ratio == 1), weight gradients of the attention projections of blocks 0 / 12 / 23 (the
-    reference's default target modules, models/abc.py:382-385) vs torch autograd through the fp32 oracle on the host cores."""
+    bit-identical to the no-grad replay (ratio == 1), weight gradients of blocks 0 / 12 / 23 vs torch autograd through the fp32 oracle on
+    the host cores.  The trainable set is SD3_5Adapter.default_target_modules (reference sd3_5.py:75-80: the eight "attn.*" projections,
+    image AND text side, substring match of models/abc.py:1793) plus the attn2 projections of the dual blocks (the base class's set,
+    models/abc.py:382-385, which the bench leg of rounds 2-4 trained)."""
     from mi355_flow.adapter import SD3_5NativeAdapter
     from mi355_flow.engine import TransformerConfig
     from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
@@ -361,7 +367,8 @@ def test_config_a_replay_gradients_vs_oracle_autograd(full):
     mod = module_from_state_dict({k: v.clone().cuda() for k, v in sd.items()})          # fp32 master copy of the bf16-rounded values
     picks = ("transformer_blocks.0.", "transformer_blocks.12.", "transformer_blocks.23.")
     for n, p in mod.named_parameters():
-        p.requires_grad_(n.startswith(picks) and any(k in n for k in (".to_q.", ".to_k.", ".to_v.", ".to_out.0.")))
+        p.requires_grad_(n.startswith(picks) and any(k in n for k in DEFAULT_SD35_TARGETS + (".attn2.to_q.", ".attn2.to_k.", ".attn2.to_v.",
+                                                                                             ".attn2.to_out.0.")))
     sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=1, seed=42, shift=3.0)
     ad = SD3_5NativeAdapter(mod, TransformerConfig(), sched, latent_storage_dtype="fp16")
     ad.rollout()
@@ -392,19 +399,30 @@ def test_config_a_replay_gradients_vs_oracle_autograd(full):
         # computes (up to accumulation order) -- against its own fp32 self, per tensor.  The tolerance is DERIVED from it (3x the band + 5e-3),
         # like the forward's; the bare 6e-2 of rounds 2-3 stays only as an outer fence.
         _, g_band = _oracle_loss(mod, cfg, inp, 1.0, t, t_next, eta, smax, 0.0, quant=M.bf16_round)
-        worst, worst_band, worst_q, n, worst_name = 0.0, 0.0, 0.0, 0, None
+        # Tensors whose EXACT gradient is zero or numerically nothing (the text-side query projection of the context-pre-only last block,
+        # whose output is discarded; biases the fp32 oracle itself only sees as rounding residue) carry no value to compare: a relative
+        # error there is noise over noise.  They are checked for being small in absolute terms and kept out of "worst" (VERDICT r4 weak #4).
+        rms = {name: float(g_ref[name].float().pow(2).mean().sqrt()) for name, prm in mod.named_parameters() if prm.requires_grad}
+        typical = sorted(rms.values())[len(rms) // 2]
+        worst, worst_band, worst_q, n, worst_name, n_null = 0.0, 0.0, 0.0, 0, None, 0
         for name, prm in mod.named_parameters():
             if not prm.requires_grad:
+                continue
+            n += 1
+            if rms[name] < 1e-4 * typical:
+                n_null += 1
+                assert float(prm.grad.float().pow(2).mean().sqrt()) < 1e-2 * typical, (name, "the oracle's gradient is (numerically) zero")
                 continue
             r, band, rq = _rel(prm.grad, g_ref[name]), _rel(g_band[name], g_ref[name]), _rel(prm.grad, g_band[name])
             if r > worst:
                 worst, worst_name = r, name
-            worst_band, worst_q, n = max(worst_band, band), max(worst_q, rq), n + 1
+            worst_band, worst_q = max(worst_band, band), max(worst_q, rq)
             assert r < 3.0 * band + 5e-3, (name, r, band)
             assert r < 6e-2 and _cos(prm.grad, g_ref[name]) > 0.99, (name, r)
-        print(f"full SD3.5-medium replay gradients: {n} tensors, worst rel-L2 vs fp32 oracle autograd {worst:.3e} ({worst_name}); "
+        print(f"full SD3.5-medium replay gradients: {n} tensors ({n_null} with a null exact gradient, checked absolutely), worst rel-L2 vs "
+              f"fp32 oracle autograd {worst:.3e} ({worst_name}); "
               f"bf16-emulating oracle autograd vs fp32 (band), worst {worst_band:.3e}; engine vs bf16-emulating, worst {worst_q:.3e}; "
               f"MI355_TUNE={__import__('os').environ.get('MI355_TUNE', '')!r}")
-        assert n == 8 * 3 + 8 * 2
+        assert n == 16 + 16 + 14 + 8 * 2 and n_null >= 2            # blocks 0 / 12: 8 names x (w, b); block 23: no to_add_out; attn2 x 2
     finally:
         ad.engine.close()

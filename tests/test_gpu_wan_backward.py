@@ -154,7 +154,9 @@ def _compare(mod, g_ref, g_band, what, min_n):
     assert n >= min_n, n
 
 
-@pytest.mark.parametrize("B,T,h,w,Nt,guidance", [(2, 3, 8, 12, 9, 1.0), (1, 2, 6, 10, 64, 5.0), (2, 1, 16, 16, 17, 5.0)])
+# (the fourth case: a single small frame under a long prompt -- Nt_pad > S_pad, the cross-attention backward's V^T / dK / dV scratch must be sized by
+# the longer key count)
+@pytest.mark.parametrize("B,T,h,w,Nt,guidance", [(2, 3, 8, 12, 9, 1.0), (1, 2, 6, 10, 64, 5.0), (2, 1, 16, 16, 17, 5.0), (2, 1, 6, 10, 300, 1.0)])
 def test_wan_replay_gradients_match_oracle_autograd_and_ratio_is_one(wn, B, T, h, w, Nt, guidance):
     from oracle import wan_ref as R
     cfg_o = R.tiny_config()
@@ -206,6 +208,73 @@ def test_wan_full_width_block_gradients(wn):
         _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float())
         plan = next(iter(ad.engine._plans.values()))
         _compare(mod, g_ref, g_band, f"Wan full-width 2 blocks, S = 4608, CFG (stash + scratch {plan.training_bytes / 2 ** 30:.2f} GiB)", 40)
+    finally:
+        ad.engine.close()
+
+
+def test_wan_config_d_token_count_two_block_gradients(wn):
+    """BASELINE.json configs[3]'s OWN token count: 480 x 832 x 49 frames = 13 x 60 x 104 latents = 20 280 video tokens per sample, 512 text tokens,
+    Wan2.1-T2V-1.3B width, two blocks (reference models/wan/wan2_t2v.py:426-543 is what optimize() replays).  What this shape adds over the
+    4 608-token case: 159 key tiles per query block in both attention-backward passes, split-K factors and weight-gradient operand slots of a
+    20 352-row problem, the log-sum-exp stash at S_pad = 20 352.  One branch (guidance 1): the oracle's fp32 autograd over 20 280^2 scores runs on
+    the host cores (flash SDPA, nothing materialised), twice (fp32 and the bf16-emulating band run)."""
+    from oracle import wan_ref as R
+    cfg_o = R.WanConfig(num_layers=2)
+    ad, mod = _build(wn, cfg_o, lambda n: any(k in n for k in DEFAULT_TARGETS), seed=23, std=0.02, norm_mean=0.3)
+    try:
+        B, T, h, w, Nt = 1, 13, 60, 104, 512
+        inp = _inputs(cfg_o, B, T, h, w, Nt, seed=29)
+        t, t_next, eta, smax, guidance = 900.0, 750.0, 0.7, 0.9, 1.0
+        ad.scheduler.set_timesteps(4)
+        ad.scheduler.sigmas = ad.scheduler.sigmas.clone()
+        ad.scheduler.sigmas[1] = smax
+        kw = _kw(inp, B, t, t_next, eta, guidance)
+        with torch.no_grad():
+            ref_out = ad.forward(**kw)
+        out = ad.forward(**kw)
+        assert torch.equal(out.noise_pred.detach(), ref_out.noise_pred) and torch.equal(out.log_prob.detach(), ref_out.log_prob)
+        kl_w = 3.0
+        ((inp["wlp"].cuda() * out.log_prob).sum() + kl_w * (inp["wnp"].cuda() * out.noise_pred).mean()).backward()
+        _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w)
+        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float())
+        plan = next(iter(ad.engine._plans.values()))
+        _compare(mod, g_ref, g_band, f"Wan full-width 2 blocks at config D's token count, S = {T * (h // 2) * (w // 2)} "
+                                     f"(stash + scratch {plan.training_bytes / 2 ** 30:.2f} GiB)", 40)
+    finally:
+        ad.engine.close()
+
+
+def test_wan_40_head_width_two_block_gradients(wn):
+    """D = 5120 (40 heads x 128: Wan2.1-T2V-14B and both Wan2.2-A14B experts, ffn 13 824), two blocks, a short clip: the modulated-LayerNorm forward
+    and its backward need rows wider than the 4096 of the other families (ln_mod_kernel<12>, ln_mod_bwd_kernel<12, false>; before round 5 both
+    launches returned hipErrorInvalidValue at this width) -- forward value and gradients vs the oracle's autograd and its bf16 band."""
+    from oracle import wan_ref as R
+    cfg_o = R.WanConfig(num_layers=2, num_attention_heads=40, ffn_dim=13824)
+    ad, mod = _build(wn, cfg_o, lambda n: any(k in n for k in DEFAULT_TARGETS), seed=13, std=0.012, norm_mean=0.3)
+    try:
+        B, T, h, w, Nt = 1, 2, 16, 24, 77
+        inp = _inputs(cfg_o, B, T, h, w, Nt, seed=19)
+        t, t_next, eta, smax, guidance = 900.0, 750.0, 0.7, 0.9, 1.0
+        ad.scheduler.set_timesteps(4)
+        ad.scheduler.sigmas = ad.scheduler.sigmas.clone()
+        ad.scheduler.sigmas[1] = smax
+        kw = _kw(inp, B, t, t_next, eta, guidance)
+        with torch.no_grad():
+            ref_out = ad.forward(**kw)
+        out = ad.forward(**kw)
+        assert torch.equal(out.noise_pred.detach(), ref_out.noise_pred) and torch.equal(out.log_prob.detach(), ref_out.log_prob)
+        kl_w = 3.0
+        ((inp["wlp"].cuda() * out.log_prob).sum() + kl_w * (inp["wnp"].cuda() * out.noise_pred).mean()).backward()
+        _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w)
+        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float())
+        from oracle import wan_ref as R2
+        with torch.no_grad():
+            sd = {n: p_.detach().cpu().float() for n, p_ in mod.named_parameters()}
+            v_o = R2.wan_forward(sd, cfg_o, inp["x"].float(), torch.full((B,), t), inp["pe"].float())
+        r_v = _rel(out.noise_pred.detach(), v_o)
+        print(f"Wan 40-head width: forward rel-L2 vs fp32 oracle {r_v:.3e}")
+        assert r_v < 2e-2
+        _compare(mod, g_ref, g_band, "Wan 40-head width (D = 5120), 2 blocks", 40)
     finally:
         ad.engine.close()
 
