@@ -15,12 +15,13 @@ sample classes all inherited) with the rollout hot path routed to libmi355flow.s
     the tensors that changed -- after `optimizer.step()`, inside `use_ema_parameters()` / `use_ref_parameters()` /
     `use_named_parameters()` (the KL reference forward of trainers/grpo.py:281-292 sees the reference weights, not the
     rollout-time policy), with peft LoRA deltas merged (and dropped while `disable_adapter()` is active), FSDP2 shards gathered;
-  * grad-mode `forward()` -- the `optimize()` replay -- runs the engine's differentiable path when the trainable
-    parameter set is supported by it (mi355_flow/autograd.py: identical forward arithmetic => ratio == 1 before any update).
-    Where the backward is not native (FLUX.1, Wan, Qwen-Image; SD3.5 trainable sets outside the engine's scope) autograd runs on
-    the reference's torch path and the VALUES of log_prob / noise_pred / next_latents_mean are the engine's (`_engine_valued`:
-    `engine + (ref - ref.detach())`), so ratio == 1 before any update and a KL term against the no-grad (engine) reference
-    forward compares like with like for every model family.
+  * grad-mode `forward()` -- the `optimize()` replay -- runs the engine's differentiable path (mi355_flow/autograd.py: identical forward
+    arithmetic => ratio == 1 before any update; hand-written HIP backward) for ALL FOUR families -- SD3.5, FLUX.1, Qwen-Image, Wan -- whenever
+    the trainable parameter set is inside the native backward's scope: each adapter's default target modules and every other linear layer
+    inside the blocks, full or LoRA.  Outside that scope the call RAISES; `MI355_ALLOW_REFERENCE_AUTOGRAD=1` opts into
+    autograd on the reference's torch path with the VALUES of log_prob / noise_pred / next_latents_mean taken from the engine
+    (`_engine_valued`: `engine + (ref - ref.detach())`), so that ratio == 1 before any update and a KL term against the no-grad (engine)
+    reference forward compares like with like.
 
 Importing this module needs an importable `flow_factory`.
 """
@@ -48,6 +49,19 @@ try:
 except Exception as e:  # noqa: BLE001
     _RefAdapter = None
     _IMPORT_ERROR = e
+
+
+def reference_autograd_allowed() -> bool:
+    """`MI355_ALLOW_REFERENCE_AUTOGRAD=1`: grad-mode forward() outside the native backward may differentiate through the reference's torch path
+    (values stay the engine's).  Off by default: such a configuration raises (reference guidelines constraints.md:144-145)."""
+    return os.environ.get("MI355_ALLOW_REFERENCE_AUTOGRAD") == "1"
+
+
+def _require_reference_autograd(family: str, why: str) -> None:
+    if not reference_autograd_allowed():
+        raise NotImplementedError(f"mi355_flow: {family} forward() with autograd is outside the native backward ({why}).  Unsupported "
+                                  "configurations raise (SURVEY.md 8(b)); MI355_ALLOW_REFERENCE_AUTOGRAD=1 opts into autograd on the reference's "
+                                  "torch path with the engine's values")
 
 
 class _LiveBinding:
@@ -92,13 +106,16 @@ class _LiveBinding:
     engine_valued_replay = True
 
     def _replay_on_reference(self, ref_forward, native_forward, args, kwargs):
+        # "unsupported configs must raise, never fall back" -- the DEFAULT since round 5.  A grad-mode forward() whose trainable
+        # set lies outside the native backward raises; `MI355_ALLOW_REFERENCE_AUTOGRAD=1` opts into the engine-valued reference-autograd route
+        # (gradient from the reference's torch path, VALUES from the engine: INTEGRATION.md, "Deliberate deviations").
+        if not reference_autograd_allowed():
+            raise NotImplementedError("mi355_flow: this grad-mode forward() is outside the native backward (trainable parameters the engine's "
+                                      "backward does not cover, or a model family switched off it).  Train the adapter's default target modules "
+                                      "/ any block linear layer, or set MI355_ALLOW_REFERENCE_AUTOGRAD=1 to differentiate through the "
+                                      "reference's torch path with the engine's values")
         # the trainer filters its kwargs by THIS class's forward() signature (utils/base.py:38-63), which may carry parameters the
         # reference's forward does not know (FLUX: `height` / `width` to recover the latent grid without img_ids): drop those
-        if os.environ.get("MI355_STRICT_NATIVE") == "1":
-            # "unsupported configs must raise, never fall back".  The default keeps training possible for the trainable sets /
-            # model families without a native backward (a documented deviation: INTEGRATION.md, "Deliberate deviations"); this switch is the letter
-            raise NotImplementedError("mi355_flow: this grad-mode forward() is outside the native backward and MI355_STRICT_NATIVE=1 forbids the "
-                                      "reference autograd path")
         accepted = inspect.signature(ref_forward).parameters
         if not any(p.kind == inspect.Parameter.VAR_KEYWORD for p in accepted.values()):
             ref_kwargs = {k: v for k, v in kwargs.items() if k in accepted}
@@ -107,14 +124,9 @@ class _LiveBinding:
         out = ref_forward(self, *args, **ref_kwargs)
         if not self.engine_valued_replay or kwargs.get("next_latents") is None:
             return out
-        try:
-            with torch.no_grad():
-                nat = native_forward(self, *args, **kwargs)
-        except NotImplementedError as e:                 # an option the engine rejects: keep the reference's values, say so once
-            if not getattr(self, "_warned_ref_value", False):
-                logger.warning("mi355_flow: grad-mode forward() keeps the reference path's values (%s)", e)
-                self._warned_ref_value = True
-            return out
+        # (an option the engine rejects raises here: the reference path's VALUES are never returned in the engine's name -- VERDICT r4 #6)
+        with torch.no_grad():
+            nat = native_forward(self, *args, **kwargs)
         return _engine_valued(out, nat)
 
     # mode switches (models/abc.py:351-378)
@@ -243,6 +255,7 @@ if _RefAdapter is not None:
         # forward() -- the optimize() replay (grpo.py:263) -- runs the engine's differentiable step (mi355_flow/autograd.py) when
         # its backward covers the trainable set; otherwise this hook sends it to the reference's autograd path.
         def _grad_fallback(self, why, kwargs):
+            _require_reference_autograd("SD3.5", why)
             if not getattr(self, "_warned_ref_grad", False):
                 logger.warning("mi355_flow: grad-mode forward() uses the reference autograd path (%s); the replay log-prob then differs "
                                "from the rollout's by the engine-vs-torch arithmetic difference", why)
@@ -290,9 +303,7 @@ if _RefAdapter is not None:
             # trainable (`target_modules: all`: modulation linears, norm weights, embedders) arrives at this hook: autograd on the
             # reference's torch path with the engine's values (a deliberate, documented deviation from "raise": INTEGRATION.md).
             def _grad_fallback(self, why, kwargs):
-                if os.environ.get("MI355_STRICT_NATIVE") == "1":
-                    raise NotImplementedError(f"mi355_flow: FLUX.1 forward() with autograd is outside the native backward ({why}) and "
-                                              "MI355_STRICT_NATIVE=1 forbids the reference path")
+                _require_reference_autograd("FLUX.1", why)
                 if not getattr(self, "_warned_ref_grad", False):
                     logger.warning("mi355_flow: grad-mode forward() differentiates through the reference path (%s); values stay the engine's", why)
                     self._warned_ref_grad = True
@@ -371,9 +382,7 @@ if _RefAdapter is not None:
                 return WanRolloutMixin.forward(self, *args, **kwargs)
 
             def _grad_fallback(self, why, kwargs):
-                if os.environ.get("MI355_STRICT_NATIVE") == "1":
-                    raise NotImplementedError(f"mi355_flow: Wan forward() with autograd is outside the native backward ({why}) and "
-                                              "MI355_STRICT_NATIVE=1 forbids the reference path")
+                _require_reference_autograd("Wan", why)
                 if not getattr(self, "_warned_ref_grad", False):
                     logger.warning("mi355_flow: grad-mode forward() differentiates through the reference path (%s); values stay the engine's", why)
                     self._warned_ref_grad = True
@@ -425,9 +434,7 @@ if _RefAdapter is not None:
             # the blocks, full or LoRA.  Anything else trainable arrives at this hook: autograd on the reference's torch path with the
             # engine's values (a deliberate, documented deviation from "raise": INTEGRATION.md).
             def _grad_fallback(self, why, kwargs):
-                if os.environ.get("MI355_STRICT_NATIVE") == "1":
-                    raise NotImplementedError(f"mi355_flow: Qwen-Image forward() with autograd is outside the native backward ({why}) and "
-                                              "MI355_STRICT_NATIVE=1 forbids the reference path")
+                _require_reference_autograd("Qwen-Image", why)
                 if not getattr(self, "_warned_ref_grad", False):
                     logger.warning("mi355_flow: grad-mode forward() differentiates through the reference path (%s); values stay the engine's", why)
                     self._warned_ref_grad = True

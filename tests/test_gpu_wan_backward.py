@@ -267,13 +267,13 @@ def test_wan_40_head_width_two_block_gradients(wn):
         ((inp["wlp"].cuda() * out.log_prob).sum() + kl_w * (inp["wnp"].cuda() * out.noise_pred).mean()).backward()
         _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w)
         _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float())
-        from oracle import wan_ref as R2
-        with torch.no_grad():
+        with torch.no_grad():                   # the forward value against the oracle, inside the oracle's own bf16 band (derived, like the gradients')
             sd = {n: p_.detach().cpu().float() for n, p_ in mod.named_parameters()}
-            v_o = R2.wan_forward(sd, cfg_o, inp["x"].float(), torch.full((B,), t), inp["pe"].float())
-        r_v = _rel(out.noise_pred.detach(), v_o)
-        print(f"Wan 40-head width: forward rel-L2 vs fp32 oracle {r_v:.3e}")
-        assert r_v < 2e-2
+            v_o = R.wan_forward(sd, cfg_o, inp["x"].float(), torch.full((B,), t), inp["pe"].float())
+            v_b = R.wan_forward(sd, cfg_o, inp["x"].float(), torch.full((B,), t), inp["pe"].float(), quant=lambda z: z.to(torch.bfloat16).float())
+        r_v, band_v = _rel(out.noise_pred.detach(), v_o), _rel(v_b, v_o)
+        print(f"Wan 40-head width: forward rel-L2 vs fp32 oracle {r_v:.3e} (bf16-emulating oracle band {band_v:.3e})")
+        assert r_v < 3.0 * band_v + 5e-3, (r_v, band_v)
         _compare(mod, g_ref, g_band, "Wan 40-head width (D = 5120), 2 blocks", 40)
     finally:
         ad.engine.close()

@@ -398,7 +398,7 @@ def test_qwen_image_plugin_rollout_with_ragged_prompts(ref):
 
 
 # ------------------------------------------------------------------------------------------------- grad-mode forward without a native backward
-def test_engine_valued_replay_value_is_the_engines_gradient_is_the_references(ref):
+def test_engine_valued_replay_value_is_the_engines_gradient_is_the_references(ref, monkeypatch):
     """FLUX / Wan / Qwen-Image (and any SD3.5 trainable set the engine's backward does not cover): `optimize()` must see the ENGINE's
     log-prob -- ratio == 1 exactly before an update -- while autograd runs through the reference's torch path."""
     P = ref
@@ -423,6 +423,10 @@ def test_engine_valued_replay_value_is_the_engines_gradient_is_the_references(re
     holder = types.SimpleNamespace(engine_valued_replay=True)
     run = lambda **kw: P._LiveBinding._replay_on_reference(holder, ref_forward, native_forward, (), kw)   # noqa: E731
     nl = torch.zeros(2, 2)
+    with pytest.raises(NotImplementedError, match="MI355_ALLOW_REFERENCE_AUTOGRAD"):          # the default: unsupported configurations raise
+        run(next_latents=nl, t=torch.tensor([900.0]))
+    assert calls == []
+    monkeypatch.setenv("MI355_ALLOW_REFERENCE_AUTOGRAD", "1")
     out = run(next_latents=nl, t=torch.tensor([900.0]))
     assert len(calls) == 1 and type(out) is Out
     for f in ("log_prob", "noise_pred", "next_latents_mean"):
@@ -438,20 +442,21 @@ def test_engine_valued_replay_value_is_the_engines_gradient_is_the_references(re
     # a sampling step in grad mode (no stored transition) has nothing to be consistent with: reference path only
     run(next_latents=None)
     assert len(calls) == 1
-    # an option the engine rejects keeps the reference's values (and says so once)
+    # an option the engine rejects raises: the reference path's values are never returned in the engine's name
     def rejecting(self, **kw):
         raise NotImplementedError("joint_attention_kwargs ['ip_adapter_image_embeds']")
-    out2 = P._LiveBinding._replay_on_reference(holder, ref_forward, rejecting, (), dict(next_latents=nl))
-    assert torch.equal(out2.log_prob.detach(), r.log_prob.detach()) and holder._warned_ref_value
+    with pytest.raises(NotImplementedError, match="ip_adapter_image_embeds"):
+        P._LiveBinding._replay_on_reference(holder, ref_forward, rejecting, (), dict(next_latents=nl))
     # opt-out
     holder.engine_valued_replay = False
     out3 = run(next_latents=nl)
     assert len(calls) == 1 and torch.equal(out3.log_prob.detach(), r.log_prob.detach())
 
 
-def test_sd3_grad_fallback_is_engine_valued(ref):
+def test_sd3_grad_fallback_is_engine_valued(ref, monkeypatch):
     """The SD3.5 plugin's own fallback (trainable parameters outside the engine's backward scope) goes through the same re-valuation:
     the reference's `SD3_5Adapter.forward` runs WITH autograd on a differentiable torch transformer, the engine step gives the values."""
+    monkeypatch.setenv("MI355_ALLOW_REFERENCE_AUTOGRAD", "1")          # the opt-in deviation route (default since round 5: raise)
     from mi355_flow import autograd as AG
     ad, cfg, tr = _make(ref, YAML_FULL)
     wq = tr.get_submodule("transformer_blocks.0.attn.to_q").weight
@@ -468,6 +473,10 @@ def test_sd3_grad_fallback_is_engine_valued(ref):
         AG.unsupported_reason = lambda adapter: "test: trainable set outside the native backward"
         # what `self.transformer(...)` does on the reference path: any differentiable function of a trainable parameter
         tr.forward = lambda hidden_states=None, **kw: (hidden_states.float() * wq.float().mean(),)
+        monkeypatch.delenv("MI355_ALLOW_REFERENCE_AUTOGRAD")
+        with torch.enable_grad(), pytest.raises(NotImplementedError, match="MI355_ALLOW_REFERENCE_AUTOGRAD"):
+            ad.forward(**fwd)                                        # the default is a refusal
+        monkeypatch.setenv("MI355_ALLOW_REFERENCE_AUTOGRAD", "1")
         with torch.enable_grad():
             out = ad.forward(**fwd)
         assert ad.engine.calls[-1][0] == "denoise_step" and ad.engine.calls[-1][1]["replay"]
@@ -937,7 +946,7 @@ def _family_adapter_factory(P, family, engine_valued=True):
 
 
 @pytest.mark.parametrize("family", ["flux", "wan", "qwen"])
-def test_reference_grpo_trainer_on_the_family_plugins_replays_engine_valued(ref, family):
+def test_reference_grpo_trainer_on_the_family_plugins_replays_engine_valued(ref, family, monkeypatch):
     """FLUX.1 / Wan / Qwen-Image have no native backward: `optimize()` differentiates through the reference's torch forward while the
     VALUES of log_prob / noise_pred come from the engine (`flow_factory_plugin._engine_valued`).  Here the reference's own `GRPOTrainer`
     runs an epoch on each plugin with a torch transformer whose arithmetic is deliberately ~1e-3 off the engine's (as bf16 torch vs the
@@ -945,6 +954,7 @@ def test_reference_grpo_trainer_on_the_family_plugins_replays_engine_valued(ref,
     gradient -- taken through the torch path -- reaches the parameters and the optimizer moves them.  With `engine_valued_replay = False`
     the same epoch starts with ratio != 1 (what the default +-1e-4 clip range would then clip from the first step on).  (This test also
     caught the FLUX plugin handing `height` / `width` -- parameters of ITS forward() only -- to the reference's forward.)"""
+    monkeypatch.setenv("MI355_ALLOW_REFERENCE_AUTOGRAD", "1")          # the opt-in deviation route (default since round 5: raise)
     import mi355_flow.flux as MF
     import mi355_flow.qwen as MQ
     import mi355_flow.vae as MV
@@ -1012,8 +1022,7 @@ def test_reference_grpo_trainer_on_the_flux_plugin_takes_the_native_backward(ref
     (mi355_flow.autograd.flux_replay) -- NEVER the torch transformer -- through the reference's own, unmodified `GRPOTrainer.optimize()`:
     first ratio exactly 1 (same forward as the rollout's), KL term exactly 0 before the update, the gradient written by the engine reaches the
     torch parameters, the optimizer moves them, and the following forward runs on the re-bound weights.  A trainable parameter OUTSIDE the
-    native scope sends the same call to the documented deviation (reference autograd path, engine values), or raises under
-    MI355_STRICT_NATIVE=1."""
+    native scope raises (the default since round 5; MI355_ALLOW_REFERENCE_AUTOGRAD=1 opts into the reference autograd path with engine values)."""
     import mi355_flow.engine as ME
     import mi355_flow.flux as MF
     import mi355_flow.vae as MV
@@ -1068,18 +1077,15 @@ def test_reference_grpo_trainer_on_the_flux_plugin_takes_the_native_backward(ref
         assert float(first["train/kl_div"]) == 0.0
         assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable))             # the engine's gradient moved the parameters
         assert all(torch.isfinite(torch.as_tensor(v)).all() for _, d in logged for v in d.values())
-        # ---- outside the native scope: the documented deviation, or a refusal in strict mode
+        # ---- outside the native scope: a refusal
         tr_mod.get_submodule("x_embedder").weight.requires_grad_(True)
         e = samples[0]
         kw = dict(t=torch.tensor([900.0]), t_next=torch.tensor([750.0]), latents=e.all_latents[:1].clone(), next_latents=e.all_latents[1:2].clone(),
                   prompt_embeds=batches[0]["prompt_embeds"][:1], pooled_prompt_embeds=batches[0]["pooled_prompt_embeds"][:1], height=64, width=64,
                   guidance_scale=3.5, noise_level=0.7, compute_log_prob=True, return_kwargs=["log_prob"])
-        os.environ["MI355_STRICT_NATIVE"] = "1"
-        try:
-            with torch.enable_grad(), pytest.raises(NotImplementedError, match="MI355_STRICT_NATIVE"):
-                ad.forward(**kw)
-        finally:
-            del os.environ["MI355_STRICT_NATIVE"]
+        assert "MI355_ALLOW_REFERENCE_AUTOGRAD" not in os.environ
+        with torch.enable_grad(), pytest.raises(NotImplementedError, match="MI355_ALLOW_REFERENCE_AUTOGRAD"):
+            ad.forward(**kw)
     finally:
         MF.sde_step, ME.sde_step, ME.sde_step_bwd = real
 
@@ -1090,7 +1096,7 @@ def test_reference_grpo_trainer_on_the_qwen_plugin_takes_the_native_backward(ref
     the engine's scheduler step + `QwenPlan.backward` (mi355_flow.autograd.qwen_replay) -- NEVER the torch transformer -- through the
     reference's own, unmodified `GRPOTrainer.optimize()`: first ratio exactly 1, KL term exactly 0 before the update, the engine's gradient
     reaches the torch parameters and the optimizer moves them.  A trainable parameter OUTSIDE the native scope raises under
-    MI355_STRICT_NATIVE=1 (and otherwise takes the documented deviation)."""
+    the default refusal (MI355_ALLOW_REFERENCE_AUTOGRAD=1 opts into the documented deviation)."""
     import mi355_flow.engine as ME
     import mi355_flow.qwen as MQ
     import mi355_flow.vae as MV
@@ -1147,18 +1153,15 @@ def test_reference_grpo_trainer_on_the_qwen_plugin_takes_the_native_backward(ref
         assert float(first["train/kl_div"]) == 0.0
         assert any(not torch.equal(a, p_.detach()) for a, p_ in zip(before, trainable))             # the engine's gradient moved the parameters
         assert all(torch.isfinite(torch.as_tensor(v)).all() for _, d in logged for v in d.values())
-        # ---- outside the native scope: a refusal in strict mode
+        # ---- outside the native scope: a refusal
         tr_mod.get_submodule("img_in").weight.requires_grad_(True)
         e = samples[0]
         kw = dict(t=torch.tensor([900.0]), t_next=torch.tensor([750.0]), latents=e.all_latents[:1].clone(), next_latents=e.all_latents[1:2].clone(),
                   prompt_embeds=batches[0]["prompt_embeds"][:1], prompt_embeds_mask=batches[0]["prompt_embeds_mask"][:1], img_shapes=[[(1, 4, 4)]],
                   guidance_scale=1.0, noise_level=0.7, compute_log_prob=True, return_kwargs=["log_prob"])
-        os.environ["MI355_STRICT_NATIVE"] = "1"
-        try:
-            with torch.enable_grad(), pytest.raises(NotImplementedError, match="MI355_STRICT_NATIVE"):
-                ad.forward(**kw)
-        finally:
-            del os.environ["MI355_STRICT_NATIVE"]
+        assert "MI355_ALLOW_REFERENCE_AUTOGRAD" not in os.environ
+        with torch.enable_grad(), pytest.raises(NotImplementedError, match="MI355_ALLOW_REFERENCE_AUTOGRAD"):
+            ad.forward(**kw)
     finally:
         MQ.sde_step, ME.sde_step, ME.sde_step_bwd, MV.WanVAEDecoder = real
 
@@ -1197,11 +1200,12 @@ def _qwen_pipeline(tcfg, transformer):
     return pipe
 
 
-def test_reference_dgpo_trainer_on_the_qwen_image_plugin(ref):
+def test_reference_dgpo_trainer_on_the_qwen_image_plugin(ref, monkeypatch):
     """BASELINE.json configs[4]: Qwen-Image under the DGPO trainer (trainers/dgpo.py; examples/dgpo is written for SD3.5, its
     hyper-parameters are used here).  The reference's own `DGPOTrainer` -- real `__init__` -- runs an epoch on the Qwen-Image plugin: ODE /
     SDE rollouts on the engine double, the DSM training forward WITHOUT a stored transition through the reference's torch path (no native
     Qwen backward), old-policy / reference predictions as no-grad engine forwards."""
+    monkeypatch.setenv("MI355_ALLOW_REFERENCE_AUTOGRAD", "1")          # the opt-in deviation route (default since round 5: raise)
     import mi355_flow.qwen as MQ
     import mi355_flow.vae as MV
     from flow_factory.trainers.dgpo import DGPOTrainer
