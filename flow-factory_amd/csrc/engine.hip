@@ -557,12 +557,19 @@ static int prepare_conditioning(mi355_plan* p, hipStream_t st, int nsteps, int t
     return 0;
 }
 
+// key 29: MEASUREMENT ONLY (scripts/ablate_forward.py) -- a bit mask of launches the forward SKIPS, to put a measured ceiling on what fusing them
+// away could buy before building the fusion: 1 = the whole text-stream chain (what a grouped image + text launch would absorb), 2 = every
+// LayerNorm-modulate launch (what a GEMM-prologue fusion would absorb), 4 = the V^T projections (what a fused q|k|v weight would absorb).
+// The results are WRONG by construction; nothing but the ablation script sets it.
+static int g_ablate = 0;
+
 static int ln_mod(mi355_plan* p, hipStream_t st, const bf16_t* x, bf16_t* out, bf16_t* out2, const bf16_t* mod, int M,
                   int rps, int shift_off, int scale_off, int shift2_off, int scale2_off) {
     LnModParams l;
     l.x = x; l.out = out; l.out2 = out2; l.mod = mod; l.mod_ld = p->e->mod_cols;
     l.shift_off = shift_off; l.scale_off = scale_off; l.shift2_off = shift2_off; l.scale2_off = scale2_off;
     l.M = M; l.D = p->e->D; l.rows_per_sample = rps; l.eps = p->e->cfg.eps;
+    if (g_ablate & 2) return 0;
     HIPCHK(lnmod_p(l, st));
     return 0;
 }
@@ -583,7 +590,7 @@ static int qkv_proj(mi355_plan* p, hipStream_t st, const bf16_t* xin, int M, int
     if (!v_only) HIPCHK(gemm_p(g, st));
     GemmParams gv = gp(w_v, D, xin, D, D, M, D, EPI_VT, b_v, nullptr, 0);
     gv.q = vT; gv.H = e->cfg.num_heads; gv.S_pad = S_pad; gv.s_off = s_off; gv.rows_per_sample = rps;
-    if (!qk_only) HIPCHK(gemm_p(gv, st_v));
+    if (!qk_only && !(g_ablate & 4)) HIPCHK(gemm_p(gv, st_v));
     return 0;
 }
 
@@ -686,7 +693,9 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
         const int mi = b.mod_img, mc = b.mod_ctx;
         // AdaLN-Zero chunk order: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp[, shift2, scale2, gate2]
         CHK(ln_mod(p, st, p->x, p->xn, b.dual ? p->xn2 : nullptr, mod, Mi, Ni, mi + 0 * D, mi + 1 * D, mi + 6 * D, mi + 7 * D));
-        if (b.last)  // AdaLayerNormContinuous: scale first, then shift
+        const bool text = !(g_ablate & 1);
+        if (!text) {}
+        else if (b.last)  // AdaLayerNormContinuous: scale first, then shift
             CHK(ln_mod(p, ts, p->c, p->cn, nullptr, mod, Mc, Nt, mc + 1 * D, mc + 0 * D, 0, 0));
         else
             CHK(ln_mod(p, ts, p->c, p->cn, nullptr, mod, Mc, Nt, mc + 0 * D, mc + 1 * D, 0, 0));
@@ -696,7 +705,7 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
             HIPCHK(ev_wait(vs, p->ev_vfork[i]));
         }
         CHK(qkv_proj(p, st, p->xn, Mi, Ni, b.w_qk, b.b_qk, b.w_v, b.b_v, b.nq, b.nk, p->q, p->k, p->vT, p->S_pad, 0, vs));
-        CHK(qkv_proj(p, ts, p->cn, Mc, Nt, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck, p->q, p->k, p->vT, p->S_pad, Ni));
+        if (text) CHK(qkv_proj(p, ts, p->cn, Mc, Nt, b.w_cqk, b.b_cqk, b.w_cv, b.b_cv, b.ncq, b.nck, p->q, p->k, p->vT, p->S_pad, Ni));
         if (three) {
             HIPCHK(ev_record(p->ev_vjoin[i], vs));
             HIPCHK(ev_wait(st, p->ev_vjoin[i]));
@@ -728,7 +737,7 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
         const bool late = b.dual && late_fork_wanted(p);
         if (fork_here && !late) CHK(fork());
         CHK(gate_res(p, st, p->o_img, D, b.w_o, b.b_o, p->x, Mi, Ni, mod, mi + 2 * D));
-        if (!two && !b.last) CHK(gate_res(p, st, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
+        if (!two && !b.last && text) CHK(gate_res(p, st, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
         if (b.dual) {
             if (three) HIPCHK(ev_wait(st, p->ev_djoin[i]));
             else CHK(qkv_proj(p, st, p->xn2, Mi, Ni, b.w_qk2, b.b_qk2, b.w_v2, b.b_v2, b.nq2, b.nk2, p->q2, p->k2, p->vT2, Ni_pad, 0));
@@ -739,7 +748,7 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
             if (fork_here && late) CHK(fork());
             CHK(gate_res(p, st, p->o_img, D, b.w_o2, b.b_o2, p->x, Mi, Ni, mod, mi + 8 * D));
         }
-        if (two && !b.last) CHK(gate_res(p, ts, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
+        if (two && !b.last && text) CHK(gate_res(p, ts, p->o_ctx, D, b.w_co, b.b_co, p->c, Mc, Nt, mod, mc + 2 * D));
         // MLP (image stream)
         CHK(ln_mod(p, st, p->x, p->xn, nullptr, mod, Mi, Ni, mi + 3 * D, mi + 4 * D, 0, 0));
         {
@@ -747,7 +756,7 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
             HIPCHK(gemm_p(g, st));
         }
         CHK(gate_res(p, st, p->hid, F, b.w_ff2, b.b_ff2, p->x, Mi, Ni, mod, mi + 5 * D));
-        if (!b.last) {
+        if (!b.last && text) {
             CHK(ln_mod(p, ts, p->c, p->cn, nullptr, mod, Mc, Nt, mc + 3 * D, mc + 4 * D, 0, 0));
             GemmParams g = gp(p->cn, D, b.w_cff1, D, Mc, F, D, EPI_BIAS_GELU, b.b_cff1, p->chid, F);
             HIPCHK(gemm_p(g, ts));
@@ -1035,6 +1044,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 26) { set_wgrad_side(value); return 0; }        // weight-gradient GEMMs on a side stream: 1 = FLUX.1 / Qwen-Image backward (default), 2 = SD3.5 too, 0 = off
     if (key == 27) { set_wgrad_split_model(value); return 0; } // split-K factor of the weight-gradient GEMMs: 1 = modelled-time minimum (default), 0 = the round-2 rule
     if (key == 28) { set_train_text_side(value); return 0; }   // Qwen-Image backward: the text chain on the plan's side stream (1 = default)
+    if (key == 29) { g_ablate = value; return 0; }             // MEASUREMENT ONLY: launches the SD3.5 forward skips (wrong results; scripts/ablate_forward.py)
     if (key == 22) { g_train_two_stream = value; return 0; }   // optimize() replay: the context-stream chain of the training forward / backward on a side stream (1 = default)
     if (key == 21) { set_attn128_op_bound(value); return 0; }  // mi355_op_attention128: the |score| bound the caller asserts (0 = none)          // default GEMM dispatch: largest K for the 4-wave hand-scheduled kernel
     return fail("mi355_tune_set: unknown key %d", key);

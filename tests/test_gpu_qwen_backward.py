@@ -180,6 +180,46 @@ def test_qwen_replay_gradients_match_oracle_autograd_and_ratio_is_one(qw, h, w, 
     ad.engine.close()
 
 
+def test_qwen_one_block_gradient_values_and_real_transition_log_prob(qw):
+    """VALUE, not direction: ONE block, no CFG, 2 048 image tokens over the batch, every non-null gradient tensor within
+    an ABSOLUTE 2e-2 rel-L2 of the fp32 oracle's autograd (no band in the tolerance), and the replay log-prob of a REAL stored transition (x'
+    from the engine's own rollout step) at the north star's rtol 1e-3."""
+    from oracle import qwen_ref as R
+    from test_gpu_wan_backward import _compare_value
+    cfg_o = R.tiny_config(num_layers=1)
+    ad, mod = _build(qw, cfg_o, lambda n: any(k in n for k in BLOCK_LINEARS), seed=41)
+    try:
+        h, w, Nt, B = 64, 64, 24, 2
+        inp = _inputs(cfg_o, B, h, w, Nt, 1, False, seed=43)
+        t, t_next, eta, smax, guidance = 900.0, 750.0, 0.7, 0.9, 1.0
+        ad.scheduler.set_timesteps(4, mu=0.6)
+        ad.scheduler.sigmas = ad.scheduler.sigmas.clone()
+        ad.scheduler.sigmas[1] = smax
+        kw = _kw(inp, B, t, t_next, eta, guidance)
+        kw.pop("next_latents")
+        torch.cuda.manual_seed(5)
+        with torch.no_grad():
+            o0 = ad.forward(**dict(kw, return_kwargs=["next_latents", "log_prob"]))
+        inp["x1"] = o0.next_latents.bfloat16().cpu()
+        kw = _kw(inp, B, t, t_next, eta, guidance)
+        out = ad.forward(**kw)
+        assert torch.equal(out.log_prob.detach(), o0.log_prob)
+        inp["wlp"] = torch.ones(B)
+        out.log_prob.sum().backward()
+        lp_ref, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, 0.0)
+        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, 0.0, quant=lambda z: z.to(torch.bfloat16).float())
+        np.testing.assert_allclose(out.log_prob.detach().cpu().numpy(), lp_ref.numpy(), rtol=1e-3)
+        print(f"Qwen-Image one block, real transition: log-prob engine {out.log_prob.tolist()} vs oracle {lp_ref.tolist()}")
+        g_ref = {k: v for k, v in g_ref.items() if v is not None}
+        for n_, p_ in mod.named_parameters():
+            if p_.requires_grad and n_ not in g_ref:           # the last (= only) block's text tail feeds nothing: no gradient on either side
+                assert p_.grad is None or float(p_.grad.float().norm()) == 0.0, n_
+                p_.requires_grad_(False)
+        _compare_value(mod, g_ref, g_band, "Qwen-Image one block (2 048 image tokens, no CFG, real transition)")
+    finally:
+        ad.engine.close()
+
+
 def test_qwen_full_width_block_gradients_at_1024_token_count(qw):
     """BASELINE.json configs[4]'s own width: Qwen-Image WIDTH (D = 3072, 24 heads x 128, text dim 3584), two blocks at 1024^2 (4096 image tokens)
     with a ragged true-CFG text batch (forward batch 2: [negative | positive]) -- the large-grid kernels: persistent GEMMs, the hand-scheduled

