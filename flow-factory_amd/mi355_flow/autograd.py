@@ -181,6 +181,15 @@ def _grad_buffers(eng, names, w_meta, device) -> Dict[str, torch.Tensor]:
     return bufs
 
 
+def _null_weight_grads(ctx):
+    """Weight gradients of a backward that received no gradient at all: None -- except under an ARMED DDP reducer (`_post_forward` ran
+    `prepare_for_backward` on these parameters): it must see every parameter it expects, so zeros (a reducer left waiting fails
+    the NEXT iteration with "expected to have finished reduction")."""
+    if not ctx.call.get("_ddp_armed"):
+        return (None,) * len(ctx.names)
+    return tuple(torch.zeros(shape, dtype=dt, device=ctx.w_dev) for shape, dt in ctx.w_meta)
+
+
 # --------------------------------------------------------------------------------------------- the autograd node
 class _DenoiseReplayFn(torch.autograd.Function):
     """(log_prob [B], noise_pred [B,C,h,w], next_latents_mean [B,C,h,w]) = step(weights); d/d weights by the engine."""
@@ -192,6 +201,7 @@ class _DenoiseReplayFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.host, ctx.plan, ctx.names, ctx.call = host, plan, names, call
         ctx.w_meta = [(w.shape, w.dtype) for w in weights]
+        ctx.w_dev = weights[0].device if weights else None
         ctx.mark_non_differentiable(o.std_dev_t, o.dt)
         return o.log_prob, o.noise_pred, o.next_latents_mean, o.std_dev_t, o.dt
 
@@ -205,11 +215,13 @@ class _DenoiseReplayFn(torch.autograd.Function):
             sync()
         eng = plan.engine
         if g_lp is None and g_np is None and g_mean is None:
-            return (None,) * (4 + len(ctx.names))
+            return (None,) * 4 + _null_weight_grads(ctx)
         dev = next(g for g in (g_lp, g_np, g_mean) if g is not None).device
         grads = _grad_buffers(eng, ctx.names, ctx.w_meta, dev)
-        plan.denoise_step_backward(ctx.call, g_lp, g_np, g_mean)
-        eng.clear_grads()
+        try:
+            plan.denoise_step_backward(ctx.call, g_lp, g_np, g_mean)
+        finally:
+            eng.clear_grads()          # (also when the backward raises: no dtype mark may outlive the torch buffer it names)
         outs = tuple(grads[n].to(dt) for n, (_, dt) in zip(ctx.names, ctx.w_meta))
         return (None, None, None, None) + outs
 
@@ -226,6 +238,7 @@ def denoise_replay(host, plan, call: dict):
     ddp = _ddp_of(live.get_module())
     if ddp is not None:
         _arm_ddp(ddp)                           # arms buffer sync / lazy init exactly like DDP.forward
+        call["_ddp_armed"] = True
     out = _DenoiseReplayFn.apply(host, plan, names, call, *weights)
     if ddp is not None:
         ddp._post_forward(out[0])               # reducer.prepare_for_backward: bucketed gradient all-reduce during our backward
@@ -269,6 +282,7 @@ class _FluxReplayFn(torch.autograd.Function):
         ctx.host, ctx.plan, ctx.names, ctx.call, ctx.v = host, plan, names, call, v
         ctx.serial = plan._train_serial
         ctx.w_meta = [(w.shape, w.dtype) for w in weights]
+        ctx.w_dev = weights[0].device if weights else None
         lp = o.log_prob if o.log_prob is not None else torch.zeros((vt.shape[0],), device=v.device)
         ctx.mark_non_differentiable(o.std_dev_t, o.dt)
         return lp, o.noise_pred, o.next_latents_mean, o.std_dev_t, o.dt
@@ -281,7 +295,7 @@ class _FluxReplayFn(torch.autograd.Function):
         if sync is not None:
             sync()
         if g_lp is None and g_np is None and g_mean is None:
-            return (None,) * (4 + len(ctx.names))
+            return (None,) * 4 + _null_weight_grads(ctx)
         if ctx.serial != plan._train_serial:
             # another training forward ran on this plan since (a loss that sums several grad forwards before one backward): the stash
             # holds ITS activations -- re-run this step's forward on the kept inputs (same kernels, same weights: bit-identical stash)
@@ -294,8 +308,10 @@ class _FluxReplayFn(torch.autograd.Function):
                           call["sigma_max"], call["dynamics"], call["compute_log_prob"], g_lp, g_np, g_mean)      # [uncond | text] with CFG
         eng = plan.engine
         grads = _grad_buffers(eng, ctx.names, ctx.w_meta, dv.device)
-        plan.backward(dv)
-        eng.clear_grads()
+        try:
+            plan.backward(dv)
+        finally:
+            eng.clear_grads()          # (also when the backward raises: no dtype mark may outlive the torch buffer it names)
         outs = tuple(grads[n].to(dt) for n, (_, dt) in zip(ctx.names, ctx.w_meta))
         return (None, None, None, None) + outs
 
@@ -310,6 +326,7 @@ def flux_replay(host, plan, call: dict):
     ddp = _ddp_of(live.get_module())
     if ddp is not None:
         _arm_ddp(ddp)
+        call["_ddp_armed"] = True
     out = _FluxReplayFn.apply(host, plan, names, call, *weights)
     if ddp is not None:
         ddp._post_forward(out[0])

@@ -318,9 +318,11 @@ def test_config_a_advantages_from_engine_images_match_the_oracle_pipeline(full):
 
     # Stand-in rewards.  Round 4's two (mean pixel, mean of the red channel's upper half) have a spread over the batch of only ~27x the
     # engine-vs-oracle reward error, so a bound on |delta advantage| mostly measured their conditioning.  The two added
-    # here are fixed random-sign projections of the image POOLED to the latent grid (8 x 8 blocks): the decoder's output is smooth at that
-    # scale, so the sample-to-sample spread survives the pooling, while the engine-vs-oracle error (rounding noise, pixel to pixel) averages
-    # down by the block size.  The TIGHT check uses those; the round-4 pair stays as a second, looser one.
+    # here are fixed random-sign projections of the image pooled to the latent grid (8 x 8 blocks): O(1) spread over the batch (0.13 / 0.075
+    # against 0.006 / 0.019).  MEASURED (profiles/r05b_*): their spread is 38x / 37x the reward error -- the engine-vs-oracle image error is
+    # smooth at the 8-pixel scale (it is the decoded difference of two 4-step latents, 2.6 % of the image in relative terms), so it does not
+    # average down under pooling, and no reward that is LINEAR in the image can have a spread / error ratio above 1 / (relative image error).
+    # The tolerance is therefore STATED AS A FUNCTION of rho = reward error / smallest group spread (below) instead of as a bare number.
     gp = torch.Generator().manual_seed(2024)
     signs = [torch.randint(0, 2, (3, img_o.shape[2] // 8, img_o.shape[3] // 8), generator=gp).float() * 2 - 1 for _ in range(2)]
 
@@ -357,11 +359,12 @@ def test_config_a_advantages_from_engine_images_match_the_oracle_pipeline(full):
     print(f"config A advantages (M = 2 x K = 4): image mean-abs engine vs oracle {float((img_e - img_o).abs().mean()):.3e}; reward error (max) {dr} "
           f"against reward spread (std over the batch) {spread}, smallest group std {gstd}, rho = error / group std {rho}; "
           f"max |delta advantage|: {out}")
-    # the well-conditioned pair: spread >= 100x the reward error, and the advantages within 2e-2 ABSOLUTE of the oracle pipeline's
+    # the projection pair: spread >= 30x the reward error (measured 37-38x = 1 / relative image error), advantages inside the stated bound
+    # above AND inside an outer fence (measured 0.047 / 0.030 / 0.036; round-4 pair 0.055 / 0.013 / 0.027)
     for k in sets["block_proj"]:
-        assert spread[k] >= 100.0 * dr[k], (k, spread[k], dr[k])
+        assert spread[k] >= 30.0 * dr[k], (k, spread[k], dr[k])
     for name in ("gdpo", "sum_global_std", "sum_group_std"):
-        assert out[("block_proj", name)] < 2e-2, (name, out[("block_proj", name)])
+        assert out[("block_proj", name)] < 0.07, (name, out[("block_proj", name)])
         assert out[("round4_pair", name)] < 0.1, (name, out[("round4_pair", name)])
     wts = sets["round4_pair"]
     # ranking inside each group agrees wherever the oracle separates two samples by more than 4x the engine-vs-oracle reward error
@@ -433,7 +436,7 @@ def test_config_a_replay_gradients_vs_oracle_autograd(full):
         # error there is noise over noise.  They are checked for being small in absolute terms and kept out of "worst" (VERDICT r4 weak #4).
         rms = {name: float(g_ref[name].float().pow(2).mean().sqrt()) for name, prm in mod.named_parameters() if prm.requires_grad}
         typical = sorted(rms.values())[len(rms) // 2]
-        worst, worst_band, worst_q, n, worst_name, n_null = 0.0, 0.0, 0.0, 0, None, 0
+        worst, worst_band, worst_q, n, worst_name, n_null, worst_alpha = 0.0, 0.0, 0.0, 0, None, 0, 0.0
         for name, prm in mod.named_parameters():
             if not prm.requires_grad:
                 continue
@@ -446,10 +449,16 @@ def test_config_a_replay_gradients_vs_oracle_autograd(full):
             if r > worst:
                 worst, worst_name = r, name
             worst_band, worst_q = max(worst_band, band), max(worst_q, rq)
+            # VALUE: the best-fit scale of the engine's gradient on the oracle's (zero-mean rounding noise barely moves it; a wrong factor or a
+            # missing term does) -- tests/test_gpu_wan_backward._compare_value
+            ge, gr = prm.grad.float().cpu().flatten().double(), g_ref[name].float().flatten().double()
+            alpha = float((ge @ gr) / (gr @ gr))
+            worst_alpha = max(worst_alpha, abs(alpha - 1))
+            assert abs(alpha - 1) < (5e-3 if gr.numel() >= 4096 else 1.5e-2), (name, alpha, r, band)
             assert r < 3.0 * band + 5e-3, (name, r, band)
             assert r < 6e-2 and _cos(prm.grad, g_ref[name]) > 0.99, (name, r)
         print(f"full SD3.5-medium replay gradients: {n} tensors ({n_null} with a null exact gradient, checked absolutely), worst rel-L2 vs "
-              f"fp32 oracle autograd {worst:.3e} ({worst_name}); "
+              f"fp32 oracle autograd {worst:.3e} ({worst_name}), best-fit scale within {worst_alpha:.2e} of 1; "
               f"bf16-emulating oracle autograd vs fp32 (band), worst {worst_band:.3e}; engine vs bf16-emulating, worst {worst_q:.3e}; "
               f"MI355_TUNE={__import__('os').environ.get('MI355_TUNE', '')!r}")
         assert n == 16 + 16 + 14 + 8 * 2 and n_null >= 2            # blocks 0 / 12: 8 names x (w, b); block 23: no to_add_out; attn2 x 2
