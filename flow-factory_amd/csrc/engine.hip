@@ -829,6 +829,23 @@ extern "C" int mi355_sde_step(void* stream, int batch, int64_t n, const void* v_
 // scheduler/flow_match_euler_discrete.py:305-426, and the CFG combine sd3_5.py:431-433).  v_text / v_uncond: the bf16 predictions the
 // forward step consumed.  One op for every model family (the FLUX.1 replay: mi355_flux_forward_train -> mi355_sde_step -> ... -> this ->
 // mi355_flux_backward).
+// UniPC multistep update of the evaluation-mode Wan sampler (kernels: sde_step.hip; coefficients: mi355_flow/unipc.py)
+extern "C" int mi355_unipc_convert(void* stream, const void* v_text, const void* v_uncond, int v_dtype, float guidance, const void* sample,
+                                   int sample_dtype, float sigma, float* x0_out, int64_t n) {
+    if (!v_text || !sample || !x0_out) return fail("mi355_unipc_convert: null argument");
+    if (n <= 0 || (n & 3)) return fail("mi355_unipc_convert: n must be a positive multiple of 4 (got %lld)", (long long)n);
+    HIPCHK(launch_unipc_convert(v_text, v_uncond, v_dtype, guidance, sample, sample_dtype, sigma, x0_out, (long)n, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int mi355_op_lincomb(void* stream, int n_terms, const void* const* tensors, const int* dtypes, const float* coefs, void* out, int out_dtype,
+                                int64_t n) {
+    if (!tensors || !dtypes || !coefs || !out) return fail("mi355_op_lincomb: null argument");
+    if (n_terms < 1 || n_terms > 5) return fail("mi355_op_lincomb: 1..5 terms (got %d)", n_terms);
+    if (n <= 0 || (n & 3)) return fail("mi355_op_lincomb: n must be a positive multiple of 4 (got %lld)", (long long)n);
+    HIPCHK(launch_lincomb(n_terms, tensors, dtypes, coefs, out, out_dtype, (long)n, (hipStream_t)stream));
+    return 0;
+}
+
 extern "C" int mi355_sde_step_bwd(void* stream, int batch, int64_t n, const void* v_text, const void* v_uncond, float guidance, const void* latents,
                                   int lat_dtype, const void* next_in, int next_in_dtype, const float* sigma, const float* sigma_next, const float* eta,
                                   int scalar_stride, float sigma_max, int dynamics, int compute_log_prob, const float* g_log_prob,

@@ -391,5 +391,9 @@ struct SdeStepParams {
     float* log_prob; float* std_dev_t; float* dt_out;   // [B] (optional)
 };
 hipError_t launch_sde_step(const SdeStepParams& p, hipStream_t stream);
+// UniPC multistep update (sde_step.hip): out = sum_i round_i(c_i * t_i), at most 5 terms, n % 4 == 0; x0 = sample - round(sigma * CFG-combine(v))
+hipError_t launch_lincomb(int n_terms, const void* const* t, const int* dt, const float* c, void* out, int out_dt, long n, hipStream_t stream);
+hipError_t launch_unipc_convert(const void* v_text, const void* v_uncond, int v_dt, float guidance, const void* sample, int sample_dt, float sigma,
+                                float* x0, long n, hipStream_t stream);
 
 }  // namespace mi355

@@ -15,6 +15,7 @@
 // thread and iteration (8/16-byte accesses); the log-prob mean is reduced DETERMINISTICALLY: every workgroup writes its
 // partial sum, the last one to arrive (agent-scope ticket) adds the NCHUNK partials in index order, so the replay of a
 // rollout step reproduces the rollout log-prob bit for bit (ratio == 1 invariant).
+#include <string.h>
 #include "kernels.h"
 
 namespace mi355 {
@@ -194,6 +195,56 @@ __global__ __launch_bounds__(NT) void sde_step_kernel(SdeStepParams p, float* pa
 
 }  // namespace
 
+namespace {
+// ---------------------------------------------------------------------------------------------------------------------------
+// UniPC multistep predictor-corrector (evaluation-mode sampling of the Wan adapters: reference scheduler/unipc_multistep.py:282-285 hands the
+// step to diffusers' UniPCMultistepScheduler.step -- convert_model_output, multistep_uni_c_bh_update, multistep_uni_p_bh_update; the
+// solver body is NOT in the reference tree, restated from its published algorithm: oracle/unipc_ref.py, parity unpinned).
+// With flow sigmas and x0-prediction every update of the solver is a LINEAR combination of at most five tensors whose coefficients depend on
+// the sigma schedule alone (mi355_flow/unipc.py computes them on the host): the stored sample, up to two stored x0-predictions, the new one.
+//   unipc_convert:  x0 = sample - round_v(sigma * v),  v = CFG-combine(uncond, text) op by op in the network's dtype   (convert_model_output)
+//   lincomb:        out = sum_i round_i(c_i * t_i)      round_i = to t_i's dtype (torch: a 0-dim fp32 scalar times a half tensor stays half)
+// HBM-bound streaming kernels, 4 elements per thread, fp32 arithmetic in term order (no contraction: this file's compile flag).
+struct LinCombParams { const void* t[5]; int dt[5]; float c[5]; int n_terms; void* out; int out_dt; long n4; };
+
+__global__ __launch_bounds__(NT) void lincomb_kernel(LinCombParams p) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < p.n4; i += (long)gridDim.x * NT) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            if (k < p.n_terms) {
+                float v[4];
+                load4(p.t[k], i * 4, p.dt[k], v);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float term = round_to_dtype(p.c[k] * v[e], p.dt[k]);
+                    acc[e] = k == 0 ? term : acc[e] + term;
+                }
+            }
+        }
+        store4(p.out, i * 4, p.out_dt, acc);
+    }
+}
+
+struct UniPcConvertParams { const void* v_text; const void* v_uncond; int v_dt; float guidance; const void* sample; int sample_dt; float sigma; float* x0; long n4; };
+
+__global__ __launch_bounds__(NT) void unipc_convert_kernel(UniPcConvertParams p) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < p.n4; i += (long)gridDim.x * NT) {
+        float vt[4], vu[4], x[4], o[4];
+        load4(p.v_text, i * 4, p.v_dt, vt);
+        if (p.v_uncond) load4(p.v_uncond, i * 4, p.v_dt, vu);
+        load4(p.sample, i * 4, p.sample_dt, x);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float v = p.v_uncond ? cfg_combine(vu[e], vt[e], p.guidance, p.v_dt) : vt[e];
+            o[e] = x[e] - round_to_dtype(p.sigma * v, p.v_dt);
+        }
+        *(float4*)(p.x0 + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+}  // namespace
+
 static float* g_scratch = nullptr;      // SCRATCH_SLOTS x (MAX_B*NCHUNK partials + MAX_B tickets)
 static unsigned g_scratch_next = 0;
 
@@ -219,6 +270,36 @@ hipError_t launch_sde_step(const SdeStepParams& p, hipStream_t stream) {
     // A captured graph keeps the slot it was captured with: the tickets are self-resetting.
     float* slot = g_scratch + (size_t)(g_scratch_next++ % SCRATCH_SLOTS) * slot_words;
     hipLaunchKernelGGL(sde_step_kernel, dim3(NCHUNK, p.B), dim3(NT), 0, stream, p, slot, (unsigned*)(slot + (size_t)MAX_B * NCHUNK));
+    return hipGetLastError();
+}
+
+hipError_t launch_lincomb(int n_terms, const void* const* t, const int* dt, const float* c, void* out, int out_dt, long n, hipStream_t stream) {
+    if (n_terms < 1 || n_terms > 5 || n <= 0 || (n & 3) || !out || out_dt < 0 || out_dt > 2) return hipErrorInvalidValue;
+    LinCombParams p;
+    memset(&p, 0, sizeof(p));
+    for (int k = 0; k < n_terms; ++k) {
+        if (!t[k] || dt[k] < 0 || dt[k] > 2) return hipErrorInvalidValue;
+        p.t[k] = t[k]; p.dt[k] = dt[k]; p.c[k] = c[k];
+    }
+    p.n_terms = n_terms; p.out = out; p.out_dt = out_dt; p.n4 = n >> 2;
+    if (sched_trace_on()) {
+        auto rg = [&](int k) { return treg(p.t[k], k < n_terms ? (size_t)n * (p.dt[k] == DT_F32 ? 4 : 2) : 0); };
+        sched_trace_launch("lincomb", stream, {rg(0), rg(1), rg(2), rg(3), rg(4)}, {treg(out, (size_t)n * (out_dt == DT_F32 ? 4 : 2))});
+    }
+    const long g = (p.n4 + NT - 1) / NT;
+    hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(NT), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_unipc_convert(const void* v_text, const void* v_uncond, int v_dt, float guidance, const void* sample, int sample_dt, float sigma,
+                                float* x0, long n, hipStream_t stream) {
+    if (!v_text || !sample || !x0 || n <= 0 || (n & 3) || v_dt < 0 || v_dt > 2 || sample_dt < 0 || sample_dt > 2) return hipErrorInvalidValue;
+    UniPcConvertParams p{v_text, v_uncond, v_dt, guidance, sample, sample_dt, sigma, x0, n >> 2};
+    if (sched_trace_on())
+        sched_trace_launch("unipc_convert", stream, {treg(v_text, (size_t)n * (v_dt == DT_F32 ? 4 : 2)), treg(v_uncond, v_uncond ? (size_t)n * (v_dt == DT_F32 ? 4 : 2) : 0),
+                                                     treg(sample, (size_t)n * (sample_dt == DT_F32 ? 4 : 2))}, {treg(x0, (size_t)n * 4)});
+    const long g = (p.n4 + NT - 1) / NT;
+    hipLaunchKernelGGL(unipc_convert_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(NT), 0, stream, p);
     return hipGetLastError();
 }
 

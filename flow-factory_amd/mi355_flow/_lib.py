@@ -104,6 +104,8 @@ SIGNATURES = {
     "mi355_denoise_step_backward": (_I, [_P, _P, _P, _I, _F, _P, _I, _P, _P, _P, _I, _F, _I, _I, _P, _P, _P]),
     "mi355_op_attention_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
     "mi355_op_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I]),
+    "mi355_unipc_convert": (_I, [_P, _P, _P, _I, _F, _P, _I, _F, _P, _L]),
+    "mi355_op_lincomb": (_I, [_P, _I, C.POINTER(_P), C.POINTER(_I), C.POINTER(_F), _P, _I, _L]),
     "mi355_sched_trace": (_I, [_I]),
     "mi355_sched_trace_read": (C.c_longlong, [C.c_char_p, C.c_longlong]),
     "mi355_op_linear_trace": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -185,7 +185,7 @@ def _null_weight_grads(ctx):
     """Weight gradients of a backward that received no gradient at all: None -- except under an ARMED DDP reducer (`_post_forward` ran
     `prepare_for_backward` on these parameters): it must see every parameter it expects, so zeros (a reducer left waiting fails
     the NEXT iteration with "expected to have finished reduction")."""
-    if not ctx.call.get("_ddp_armed"):
+    if not ctx.ddp_armed:
         return (None,) * len(ctx.names)
     return tuple(torch.zeros(shape, dtype=dt, device=ctx.w_dev) for shape, dt in ctx.w_meta)
 
@@ -202,6 +202,7 @@ class _DenoiseReplayFn(torch.autograd.Function):
         ctx.host, ctx.plan, ctx.names, ctx.call = host, plan, names, call
         ctx.w_meta = [(w.shape, w.dtype) for w in weights]
         ctx.w_dev = weights[0].device if weights else None
+        ctx.ddp_armed = _ddp_of(host._live_weights.get_module()) is not None if getattr(host, "_live_weights", None) is not None else False
         ctx.mark_non_differentiable(o.std_dev_t, o.dt)
         return o.log_prob, o.noise_pred, o.next_latents_mean, o.std_dev_t, o.dt
 
@@ -238,7 +239,6 @@ def denoise_replay(host, plan, call: dict):
     ddp = _ddp_of(live.get_module())
     if ddp is not None:
         _arm_ddp(ddp)                           # arms buffer sync / lazy init exactly like DDP.forward
-        call["_ddp_armed"] = True
     out = _DenoiseReplayFn.apply(host, plan, names, call, *weights)
     if ddp is not None:
         ddp._post_forward(out[0])               # reducer.prepare_for_backward: bucketed gradient all-reduce during our backward
@@ -283,6 +283,7 @@ class _FluxReplayFn(torch.autograd.Function):
         ctx.serial = plan._train_serial
         ctx.w_meta = [(w.shape, w.dtype) for w in weights]
         ctx.w_dev = weights[0].device if weights else None
+        ctx.ddp_armed = _ddp_of(host._live_weights.get_module()) is not None if getattr(host, "_live_weights", None) is not None else False
         lp = o.log_prob if o.log_prob is not None else torch.zeros((vt.shape[0],), device=v.device)
         ctx.mark_non_differentiable(o.std_dev_t, o.dt)
         return lp, o.noise_pred, o.next_latents_mean, o.std_dev_t, o.dt
@@ -326,7 +327,6 @@ def flux_replay(host, plan, call: dict):
     ddp = _ddp_of(live.get_module())
     if ddp is not None:
         _arm_ddp(ddp)
-        call["_ddp_armed"] = True
     out = _FluxReplayFn.apply(host, plan, names, call, *weights)
     if ddp is not None:
         ddp._post_forward(out[0])

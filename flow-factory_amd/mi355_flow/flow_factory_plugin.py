@@ -321,8 +321,10 @@ if _RefAdapter is not None:
             """`Wan2_T2V_Adapter` (reference models/wan/wan2_t2v.py) with the rollout on the MI355X engine: single-transformer Wan2.1, and
             two-expert Wan2.2 pipelines (`transformer` while t >= boundary_ratio * 1000, `transformer_2` below, each with its own
             guidance scale: wan2_t2v.py:476-487) as two engines stepped per timestep.  Wan2.2-TI2V-5B in text-to-video use
-            (`expand_timesteps` with an all-ones mask = one timestep for every token) runs on the scalar-timestep forward.  The causal 3-D video VAE decode is native (csrc/wan_vae_engine.hip); evaluation-mode sampling (diffusers' UniPC multistep solver) stays on the
-            reference path."""
+            (`expand_timesteps` with an all-ones mask = one timestep for every token) runs on the scalar-timestep forward.  The causal 3-D video VAE
+            decode is native (csrc/wan_vae_engine.hip).  Evaluation-mode sampling (diffusers' UniPC multistep predictor-corrector,
+            scheduler/unipc_multistep.py:282-285) is native since round 5 (`WanRolloutMixin._rollout_eval`, mi355_flow/unipc.py; the solver body is
+            third-party code restated from its published algorithm: parity unpinned); `MI355_WAN_EVAL_REFERENCE=1` keeps the reference's own loop."""
 
             _sample_cls = _RefWanSample
             _output_cls = _RefOutput
@@ -356,7 +358,7 @@ if _RefAdapter is not None:
                 else:
                     self._init_live(WanEngine(wcfg(self.pipeline.transformer.config)))
 
-            def _eval_inference(self, **kwargs):
+            def _eval_inference(self, **kwargs):          # MI355_WAN_EVAL_REFERENCE=1 only: the reference's own evaluation loop
                 return _RefWan.inference(self, **kwargs)
 
             @torch.no_grad()

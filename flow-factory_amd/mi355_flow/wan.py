@@ -233,10 +233,11 @@ class WanRolloutMixin:
     single-transformer Wan2.1 configuration.  Host classes provide `engine` (WanEngine), `scheduler`, `device`, `transformer_dtype`,
     `latent_storage_dtype`, `encode_prompt`, `decode_latents(latents, output_type)`.
 
-    Evaluation mode: the reference's `UniPCMultistepSDEScheduler.step` delegates to diffusers' UniPC multistep predictor-corrector
-    when `is_eval` (scheduler/unipc_multistep.py:282-285), which the engine does not implement -- `inference()` in eval mode is
-    routed to `_eval_inference` (the Flow-Factory plugin sends it to the reference path; standalone it raises) instead of silently
-    sampling with a first-order Euler step."""
+    Evaluation mode: the reference's `UniPCMultistepSDEScheduler.step` delegates to diffusers' UniPC multistep predictor-corrector when
+    `is_eval` (scheduler/unipc_multistep.py:282-285).  Since round 5 `inference()` samples it natively (`_rollout_eval`: per-step engine
+    forwards + the solver as two streaming HIP kernels, mi355_flow/unipc.py; the solver body is third-party code restated from its published
+    algorithm -- oracle/unipc_ref.py, parity unpinned).  `MI355_WAN_EVAL_REFERENCE=1` routes evaluation to `_eval_inference` instead (the
+    Flow-Factory plugin: the reference's own loop; standalone it raises) -- never a silent first-order Euler step."""
 
     _sample_cls = WanT2VSample
     _output_cls = SDESchedulerOutput
@@ -300,7 +301,8 @@ class WanRolloutMixin:
         trajectory_indices: TrajectoryIndicesType = "all",
     ) -> List[WanT2VSample]:
         device = self.device
-        if bool(getattr(self.scheduler, "is_eval", False)):
+        eval_mode = bool(getattr(self.scheduler, "is_eval", False))
+        if eval_mode and os.environ.get("MI355_WAN_EVAL_REFERENCE") == "1":
             return self._eval_inference(
                 prompt=prompt, negative_prompt=negative_prompt, height=height, width=width, num_frames=num_frames,
                 num_inference_steps=num_inference_steps, guidance_scale=guidance_scale, guidance_scale_2=guidance_scale_2,
@@ -346,7 +348,7 @@ class WanRolloutMixin:
         # (none of the step draws under ODE dynamics: the reference's ODE branch draws nothing)
         latents = randn_tensor((B, Cl, T, h, w), generator=generator, device=device, dtype=torch.float32)
         step_noise = None
-        if self.scheduler.dynamics_type != "ODE":
+        if self.scheduler.dynamics_type != "ODE" and not eval_mode:      # (the evaluation-mode solver is deterministic: the reference draws nothing)
             step_noise = torch.empty((N, B, Cl, T, h, w), device=device, dtype=torch.float32)
             for i in range(N):
                 step_noise[i] = randn_tensor((B, Cl, T, h, w), generator=None, device=device, dtype=torch.float32)
@@ -361,7 +363,16 @@ class WanRolloutMixin:
         kept = _resolve(trajectory_indices, N + 1)
         keep_positions = list(range(N + 1)) if kept is None else sorted(kept)
         step_outputs = None
-        if not stepwise:
+        if eval_mode:
+            if compute_log_prob or any(k != "noise_level" for k in extra_call_back_kwargs):
+                raise NotImplementedError("mi355_flow: evaluation-mode Wan sampling returns latents only (the reference's UniPC step yields neither "
+                                          "a log-prob nor per-step callback tensors: unipc_multistep.py:282-285)")
+            lat_kept = self._rollout_eval(plan, ts_host, sig_host, guidance_scale, latents, storage, prompt_embeds,
+                                          negative_prompt_embeds if do_cfg else None, plan_2=plan_2, guidance_2=g2)
+            log_probs = torch.full((N, B), float("nan"), device=device)
+            final = lat_kept[N]
+            pos_to_slot = {p: p for p in range(N + 1)}
+        elif not stepwise:
             lat_kept, log_probs, final = plan.rollout(ts_host, sig_host, eta_host, self.scheduler.dynamics_type, guidance_scale, latents,
                                                       storage, step_noise, prompt_embeds, negative_prompt_embeds if do_cfg else None,
                                                       keep_positions=keep_positions, compute_log_prob=compute_log_prob)
@@ -392,6 +403,38 @@ class WanRolloutMixin:
             )
             for b in range(B)
         ]
+
+    def _rollout_eval(self, plan, ts, sig, guidance, latents, storage, pe, ne, plan_2=None, guidance_2=None):
+        """Evaluation-mode sampling (reference: the loop of wan2_t2v.py:346-375 with `scheduler.step` in its `is_eval` branch,
+        unipc_multistep.py:282-285 = diffusers' UniPC multistep predictor-corrector): one engine forward per step (per expert and guidance by
+        the boundary rule, like the rollout), then the solver step on the GPU -- `mi355_unipc_convert` + `mi355_op_lincomb` with host-side
+        coefficients (mi355_flow/unipc.py).  Deterministic: no noise is drawn."""
+        from .unipc import UniPCSampler
+        cfg = self.scheduler.config
+        get = (lambda k, d: cfg.get(k, d)) if hasattr(cfg, "get") else (lambda k, d: getattr(cfg, k, d))
+        if get("prediction_type", "flow_prediction") != "flow_prediction" or not get("predict_x0", True):
+            raise NotImplementedError("mi355_flow: the native UniPC sampler implements flow prediction with predict_x0 (the Wan pipelines' setting)")
+        if get("thresholding", False) or get("solver_p", None) is not None:
+            raise NotImplementedError("mi355_flow: UniPC thresholding / a custom predictor solver are not implemented")
+        solver = UniPCSampler(sig, solver_order=int(get("solver_order", 2)), solver_type=str(get("solver_type", "bh2")),
+                              lower_order_final=bool(get("lower_order_final", True)), disable_corrector=tuple(get("disable_corrector", ()) or ()))
+        N, B = len(ts), latents.shape[0]
+        cur = self.cast_latents(latents, storage)
+        all_lat = [cur]
+        f32 = lambda v: torch.tensor(float(v), dtype=torch.float32)          # noqa: E731
+        bt = self._boundary_timestep()
+        for i in range(N):
+            low = plan_2 is not None and bt is not None and ts[i] < bt
+            pl, gd = (plan_2, guidance_2) if low else (plan, guidance)
+            cfg_i = ne is not None and gd > 1.0
+            if not cfg_i and pl.n_cfg == 2:
+                pl = pl.engine.plan(B, 1, pl.T, pl.h, pl.w, pl.n_text, 1)
+            v = pl.transformer_forward(cur, f32(ts[i]).reshape(1), ne if cfg_i else pe, pe if cfg_i else None)
+            vu, vt = (v[:B], v[B:]) if cfg_i else (None, v)
+            nxt = solver.step(i, vt.reshape(cur.shape), vu.reshape(cur.shape) if vu is not None else None, gd, cur)
+            cur = self.cast_latents(nxt, storage)
+            all_lat.append(cur)
+        return all_lat
 
     def _rollout_stepwise(self, plan, ts, sig, eta, guidance, latents, storage, step_noise, pe, ne, compute_log_prob, extra_keys, plan_2=None,
                           guidance_2=None):

@@ -166,6 +166,20 @@ int mi355_denoise_step_backward(mi355_plan* p, void* stream, const void* latents
                                 int next_in_dtype, const float* sigma, const float* sigma_next, const float* eta, int scalar_stride,
                                 float sigma_max, int dynamics, int compute_log_prob, const float* g_log_prob, const float* g_noise_pred,
                                 const float* g_mean);
+/* ---- UniPC multistep predictor-corrector: evaluation-mode sampling of the Wan adapters ------------------------------------------------
+ * Replaces: `UniPCMultistepSDEScheduler.step` in evaluation mode (reference src/flow_factory/scheduler/unipc_multistep.py:282-285), which
+ * hands the step to diffusers' `UniPCMultistepScheduler.step` (convert_model_output -> multistep_uni_c_bh_update -> multistep_uni_p_bh_update;
+ * solver body not in the reference tree: restated in oracle/unipc_ref.py, parity unpinned).  With flow sigmas and x0-prediction every update
+ * is a linear combination of stored tensors with schedule-only coefficients (computed on the host, mi355_flow/unipc.py).
+ *   mi355_unipc_convert: x0_out[n] (fp32) = sample - round_v(sigma * v), v = v_text, or `v_uncond + g * (v_text - v_uncond)` evaluated op by op
+ *                        in `v_dtype` (as torch does on the network's bf16 output; the product with the 0-dim sigma stays in that dtype too)
+ *   mi355_op_lincomb:    out[n] (`out_dtype`) = sum_{i < n_terms} round_i(coefs[i] * tensors[i]),  round_i = to dtypes[i] (a 0-dim fp32 scalar
+ *                        times a half-precision tensor stays half precision in torch), fp32 accumulation in term order; n_terms <= 5
+ * n must be a multiple of 4; all pointers device memory. */
+int mi355_unipc_convert(void* stream, const void* v_text, const void* v_uncond, int v_dtype, float guidance, const void* sample, int sample_dtype,
+                        float sigma, float* x0_out, int64_t n);
+int mi355_op_lincomb(void* stream, int n_terms, const void* const* tensors, const int* dtypes, const float* coefs, void* out, int out_dtype,
+                     int64_t n);
 /* unit-test helper: attention forward (q pre-scaled by log2(e)/8) + flash backward; d_o / o token-major [B*S][H*64]; synchronises */
 int mi355_op_attention_fwd_bwd(void* stream, const void* q, const void* k, const void* vT, const void* d_o, void* o, void* dq, void* dk,
                                void* dv, int B, int H, int S, int S_pad);

@@ -181,17 +181,23 @@ class FlowMatchEulerDiscreteScheduler:
 
 class UniPCMultistepScheduler:
     """Restatement of diffusers' UniPCMultistepScheduler for the part the GRPO rollout uses: schedule construction with
-    `use_flow_sigmas=True` (the Wan pipelines) and `index_for_timestep`.  The multistep predictor-corrector `step()` itself (only reached by
-    the reference in evaluation mode, scheduler/unipc_multistep.py:282-285) is NOT restated: it raises."""
+    `use_flow_sigmas=True` (the Wan pipelines) and `index_for_timestep`.  The multistep predictor-corrector `step()` (only reached by the
+    reference in evaluation mode, scheduler/unipc_multistep.py:282-285) delegates to oracle/unipc_ref.py -- the published algorithm restated
+    tensor by tensor, PARITY UNPINNED (see that file's header): with it the reference's own adapter loop runs in evaluation mode on the CPU,
+    which pins the plugin's CONTROL FLOW (RNG order, cast_latents, expert / guidance per step) against it, not the solver body."""
 
     order = 1
 
     def __init__(self, num_train_timesteps: int = 1000, solver_order: int = 2, prediction_type: str = "flow_prediction",
-                 use_flow_sigmas: bool = True, flow_shift: float = 3.0, final_sigmas_type: str = "zero", **unused):
+                 use_flow_sigmas: bool = True, flow_shift: float = 3.0, final_sigmas_type: str = "zero", solver_type: str = "bh2",
+                 predict_x0: bool = True, lower_order_final: bool = True, disable_corrector=(), thresholding: bool = False, **unused):
         if not use_flow_sigmas:
             raise NotImplementedError("diffusers_stub.UniPCMultistepScheduler: only the use_flow_sigmas schedule is restated")
         self.config = _FrozenConfig(num_train_timesteps=num_train_timesteps, solver_order=solver_order, prediction_type=prediction_type,
-                                    use_flow_sigmas=use_flow_sigmas, flow_shift=flow_shift, final_sigmas_type=final_sigmas_type)
+                                    use_flow_sigmas=use_flow_sigmas, flow_shift=flow_shift, final_sigmas_type=final_sigmas_type,
+                                    solver_type=solver_type, predict_x0=predict_x0, lower_order_final=lower_order_final,
+                                    disable_corrector=list(disable_corrector), thresholding=thresholding, solver_p=None)
+        self._solver = None
         self.timesteps = torch.from_numpy(np.linspace(0, num_train_timesteps - 1, num_train_timesteps, dtype=np.float32)[::-1].copy())
         self.sigmas = torch.zeros(num_train_timesteps + 1)
         self.num_inference_steps = None
@@ -210,6 +216,7 @@ class UniPCMultistepScheduler:
         self.num_inference_steps = len(timesteps)
         self._step_index = None
         self._begin_index = None
+        self._solver = None                   # (set_timesteps resets model_outputs / lower_order_nums / last_sample)
 
     def index_for_timestep(self, timestep, schedule_timesteps=None):
         if schedule_timesteps is None:
@@ -219,8 +226,14 @@ class UniPCMultistepScheduler:
             return len(self.timesteps) - 1
         return indices[1 if len(indices) > 1 else 0].item()
 
-    def step(self, *a, **k):
-        raise NotImplementedError("diffusers_stub.UniPCMultistepScheduler.step: the multistep solver is not restated (evaluation mode only)")
+    def step(self, model_output, timestep, sample, return_dict: bool = True):
+        from .unipc_ref import UniPCRef
+        if self._solver is None:
+            c = self.config
+            self._solver = UniPCRef(self.sigmas.tolist(), solver_order=c.solver_order, solver_type=c.solver_type,
+                                    lower_order_final=c.lower_order_final, disable_corrector=c.disable_corrector)
+        prev = self._solver.step(model_output, sample)
+        return (prev,)
 
 
 def retrieve_timesteps(scheduler, num_inference_steps=None, device=None, timesteps=None, sigmas=None, **kwargs):

@@ -399,7 +399,7 @@ def build_wan(case, adapter_base=None):
     return ad, N
 
 
-def run_reference_wan(case, adapter_base=None, callbacks=True, explicit_generator=False, traj="train", clp=True, seed=None):
+def run_reference_wan(case, adapter_base=None, callbacks=True, explicit_generator=False, traj="train", clp=True, seed=None, evaluation=False):
     ref_package.install()
     from flow_factory.utils.trajectory_collector import compute_trajectory_indices
     dyn, gs, gs2, ratio, storage, N, sde_steps, n_sde, eta = _wan_case(case)
@@ -412,6 +412,8 @@ def run_reference_wan(case, adapter_base=None, callbacks=True, explicit_generato
     ad.scheduler.set_timesteps(N)                      # train_timesteps (the SDE-step selection) needs a schedule
     if traj == "train":
         traj = compute_trajectory_indices(train_timestep_indices=ad.scheduler.train_timesteps, num_inference_steps=N)
+    if evaluation:                                     # models/abc.py:351-378: eval() puts the scheduler into its `is_eval` branch
+        ad.eval()
     samples = ad.inference(prompt=["p0", "p1"], generator=torch.Generator().manual_seed(77) if explicit_generator else None, negative_prompt=["", ""], height=H, width=W, num_frames=WAN_FRAMES, num_inference_steps=N,
                            guidance_scale=gs, guidance_scale_2=gs2, prompt_ids=torch.zeros(B, 4, dtype=torch.long), prompt_embeds=pe,
                            negative_prompt_ids=torch.zeros(B, 4, dtype=torch.long), negative_prompt_embeds=ne, compute_log_prob=clp,

@@ -288,3 +288,33 @@ def rollout_two_expert(sd_hi, sd_lo, cfg: WanConfig, boundary_timestep, prompt_e
         lps.append(out["log_prob"] if clp else torch.full((B,), float("nan")))
         means.append(out["next_latents_mean"])
     return dict(all_latents=torch.stack(all_lat, 0), log_probs=torch.stack(lps, 0), next_latents_means=torch.stack(means, 0))
+
+
+def rollout_eval(sd, cfg: WanConfig, prompt_embeds, negative_prompt_embeds, guidance_scale, init_latents, timesteps, sigmas,
+                 storage_dtype=torch.float16, solver_order: int = 2, solver_type: str = "bh2", sd_low=None, boundary_timestep=None,
+                 guidance_scale_2=None):
+    """EVALUATION-mode sampling: the adapter loop of reference wan2_t2v.py:346-375 with `scheduler.step` in its `is_eval` branch
+    (scheduler/unipc_multistep.py:282-285 -> diffusers' UniPCMultistepScheduler.step, restated in oracle/unipc_ref.py: PARITY UNPINNED).
+    No noise is drawn; the network sees the latents in bf16 and the integer timestep; the cond / uncond passes are combined in bf16; the
+    solver receives the bf16 prediction and the latents in their storage dtype.  `sd_low` / `boundary_timestep` / `guidance_scale_2`: the
+    Wan2.2 two-expert rule (wan2_t2v.py:476-487)."""
+    from . import scheduler_ref as S
+    from .rollout_ref import cfg_combine_bf16
+    from .unipc_ref import UniPCRef
+    N = len(timesteps)
+    solver = UniPCRef([float(s) for s in sigmas], solver_order=solver_order, solver_type=solver_type)
+    lat = S.cast_latents(init_latents, storage_dtype)
+    all_lat = [lat]
+    B = lat.shape[0]
+    for i in range(N):
+        t = timesteps[i].float()
+        low = sd_low is not None and boundary_timestep is not None and float(t) < boundary_timestep
+        sd_i, g = (sd_low, guidance_scale_2 if guidance_scale_2 is not None else guidance_scale) if low else (sd, guidance_scale)
+        x_in = lat.to(torch.bfloat16).float()
+        net = lambda emb: wan_forward(sd_i, cfg, x_in, t.expand(B), emb.float()).to(torch.bfloat16)          # noqa: E731
+        v = net(prompt_embeds)
+        if negative_prompt_embeds is not None and g > 1.0:
+            v = cfg_combine_bf16(net(negative_prompt_embeds), v, g)
+        lat = S.cast_latents(solver.step(v, lat), storage_dtype)
+        all_lat.append(lat)
+    return dict(all_latents=torch.stack(all_lat, 0))

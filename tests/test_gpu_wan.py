@@ -199,6 +199,81 @@ def test_wan_rollout_matches_oracle_and_replays(wn, guidance):
     ad.engine.close()
 
 
+@pytest.mark.parametrize("guidance,storage,N", [(5.0, "fp16", 6), (1.0, "bf16", 4), (4.0, None, 2)])
+def test_wan_evaluation_mode_sampling_matches_oracle(wn, guidance, storage, N):
+    """Evaluation-mode `inference()` (round 5: native -- per-step engine forwards + the UniPC multistep predictor-corrector as
+    mi355_unipc_convert / mi355_op_lincomb with host-side coefficients, mi355_flow/unipc.py; reference wan2_t2v.py:346-375 over
+    scheduler/unipc_multistep.py:282-285) against the oracle's evaluation loop (oracle/wan_ref.rollout_eval over oracle/unipc_ref.py, the
+    published solver tensor by tensor; parity with diffusers itself unpinned).  Deterministic: two runs from one seed agree bit for bit and
+    draw nothing but the initial latents."""
+    from oracle import wan_ref as R
+    cfg_o = R.tiny_config()
+    sd, cfg = _setup(wn, cfg_o, seed=21)
+    sched = wn.UniPCMultistepSDEScheduler(flow_shift=3.0, noise_level=0.7, sde_steps=[0, 1, 2], num_sde_steps=2, seed=42, dynamics_type="Flow-SDE")
+    ad = wn.Wan2T2VNativeAdapter({k: v.cuda() for k, v in sd.items()}, cfg, sched, latent_storage_dtype=storage)
+    ad.eval()
+    assert ad.scheduler.is_eval
+    B, Nt, H, W, frames = 2, 12, 64, 96, 9           # latent grid (T, h, w) = (3, 8, 12)
+    g = torch.Generator().manual_seed(4)
+    pe = torch.randn(B, Nt, cfg_o.text_dim, generator=g).bfloat16()
+    ne = torch.randn(B, Nt, cfg_o.text_dim, generator=g).bfloat16()
+    cfg_on = guidance > 1.0
+    kw = dict(prompt=["a", "b"], height=H, width=W, num_frames=frames, num_inference_steps=N, guidance_scale=guidance, prompt_embeds=pe.cuda(),
+              negative_prompt_embeds=ne.cuda() if cfg_on else None, compute_log_prob=False, trajectory_indices="all")
+    torch.cuda.manual_seed(31)
+    samples = ad.inference(**kw)
+    after = torch.randn(4, device="cuda")
+    torch.cuda.manual_seed(31)
+    T, h, w = 3, 8, 12
+    init = torch.randn((B, 16, T, h, w), device="cuda", dtype=torch.float32)
+    assert torch.equal(after, torch.randn(4, device="cuda"))               # inference() drew the initial latents and nothing else
+    torch.cuda.manual_seed(31)
+    again = ad.inference(**kw)
+    ts, sig = R.unipc_flow_schedule(N, 3.0)
+    assert torch.equal(samples[0].timesteps.cpu(), ts)
+    sdt = {"fp16": torch.float16, "bf16": torch.bfloat16, None: torch.float32}[storage]
+    ref = R.rollout_eval(sd, cfg_o, pe, ne if cfg_on else None, guidance, init.cpu(), ts, sig, sdt)
+    assert samples[0].all_latents.shape == (N + 1, 16, T, h, w) and samples[0].all_latents.dtype == sdt and samples[0].log_probs is None
+    worst = 0.0
+    for b in range(B):
+        got = samples[b].all_latents.float().cpu()
+        assert torch.equal(samples[b].all_latents, again[b].all_latents)
+        assert torch.equal(got[0], ref["all_latents"][0, b].float())
+        for pos in range(1, N + 1):
+            r = ref["all_latents"][pos, b].float()
+            worst = max(worst, ((got[pos] - r).norm() / r.norm()).item())
+    print(f"Wan evaluation-mode sampling (guidance {guidance}, storage {storage}, {N} steps): worst latent rel-L2 vs the oracle loop {worst:.3e}")
+    assert worst < 2e-2
+    with pytest.raises(NotImplementedError, match="latents only"):
+        ad.inference(**dict(kw, compute_log_prob=True))
+    ad.engine.close()
+
+
+def test_unipc_kernels_match_their_torch_statements(wn):
+    """mi355_unipc_convert / mi355_op_lincomb against the torch statements of what they compute (the ones the CPU control-flow test runs)."""
+    from mi355_flow import unipc as U
+    from oracle import rollout_ref as RR
+    g = torch.Generator().manual_seed(9)
+    n = (3, 16, 2, 6, 10)
+    vt, vu = torch.randn(n, generator=g).bfloat16(), torch.randn(n, generator=g).bfloat16()
+    for sdt in (torch.float16, torch.bfloat16, torch.float32):
+        x = (2 * torch.randn(n, generator=g)).to(sdt)
+        for cfg_on in (False, True):
+            got = U.unipc_convert(vt.cuda(), vu.cuda() if cfg_on else None, 4.5, x.cuda(), 0.8125).cpu()
+            v = RR.cfg_combine_bf16(vu, vt, 4.5) if cfg_on else vt
+            want = x.float() - (torch.tensor(0.8125) * v.float()).to(torch.bfloat16).float()
+            assert got.dtype == torch.float32 and torch.equal(got, want), (sdt, cfg_on)
+        ms = [torch.randn(n, generator=g) for _ in range(3)]
+        for k in range(1, 5):
+            ts_, cs = [x] + ms[:k - 1], [0.91, -0.37, 0.52, -0.11][:k]
+            got = U.lincomb([t.cuda() for t in ts_], cs, sdt).cpu()
+            acc = None
+            for t, c in zip(ts_, cs):
+                term = (torch.tensor(c, dtype=torch.float32) * t.float()).to(t.dtype).float()
+                acc = term if acc is None else acc + term
+            assert got.dtype == sdt and torch.equal(got, acc.to(sdt)), (sdt, k)
+
+
 def test_wan_errors(wn):
     with pytest.raises(RuntimeError, match="head_dim must be 128"):
         wn.WanEngine(wn.WanConfig(attention_head_dim=64))

@@ -879,3 +879,81 @@ def test_differential_sweep_flux_qwen_forward_plugin_vs_reference_adapter(family
         assert a is not None, (ctx, k, "missing")
         assert a.dtype == b.dtype and a.shape == b.shape, (ctx, k, a.dtype, b.dtype, tuple(a.shape), tuple(b.shape))
         assert torch.equal(torch.nan_to_num(a.float()), torch.nan_to_num(b.float())), (ctx, k, float((a.float() - b.float()).abs().max()))
+
+
+@pytest.mark.parametrize("case", [("Flow-SDE", 5.0, None, None, "fp16", 6, [1, 2, 3], 2, 0.7),          # Wan2.1, CFG, fp16 storage
+                                  ("Flow-SDE", 1.0, None, None, "bf16", 3, [0, 1], 1, 0.7),              # no CFG, 3 steps (warm-up + final-order-1 only)
+                                  ("CPS", 4.0, 3.0, 0.6, "bf16", 7, [0, 1, 2, 3], 2, 0.8),                # Wan2.2 two experts, a guidance scale each
+                                  ("ODE", 4.0, 1.0, 0.5, None, 5, [0, 1], 1, 0.7)],                       # second expert without CFG, fp32 storage
+                         ids=["wan21_cfg_fp16", "nocfg_3_steps", "wan22_two_expert", "wan22_low_expert_nocfg_fp32"])
+def test_wan_plugin_evaluation_mode_sampler_follows_the_reference_adapter_loop(case):
+    """Evaluation-mode sampling (round 5: native; reference wan2_t2v.py:346-375 with `scheduler.step` in its `is_eval` branch,
+    unipc_multistep.py:282-285 = diffusers' UniPC multistep predictor-corrector).  The reference's own `Wan2_T2V_Adapter.inference`, in eval
+    mode, on the diffusers stub whose solver step is oracle/unipc_ref.py (the published algorithm tensor by tensor) against the plugin's
+    `_rollout_eval`: per-step engine forwards on the stand-in network double + the solver as host-side linear coefficients
+    (mi355_flow/unipc.py; its two HIP kernels replaced here by torch statements of what they compute).  Pins the control flow -- one latent
+    draw and no step noise, the expert / guidance / CFG decision per step, cast_latents after every step, corrector from the second step on,
+    warm-up and final order -- with the solver body itself unpinned on both sides (diffusers is not in this image)."""
+    import sys
+    from oracle import ref_package
+    if not ref_package.available():
+        pytest.skip("needs /root/reference (build container only)")
+    ref_package.install()
+    sys.path.insert(0, os.path.dirname(__file__))
+    import _plugin_fakes as F
+    import mi355_flow.flow_factory_plugin as P
+    import mi355_flow.unipc as MU
+    import mi355_flow.vae as MV
+    import mi355_flow.wan as MW
+    from oracle import make_rollout_golden as G
+    from oracle import rollout_ref as R
+    if P._RefAdapter is None:
+        import importlib
+        P = importlib.reload(P)
+    kw = dict(callbacks=False, traj="all", clp=False, seed=4242, evaluation=True)
+    want = G.run_reference_wan(case, **kw)
+
+    def convert(v_text, v_uncond, guidance, sample, sigma):          # mi355_unipc_convert
+        v = v_text if v_uncond is None else R.cfg_combine_bf16(v_uncond, v_text, float(guidance))
+        return sample.float() - (torch.tensor(float(sigma), dtype=torch.float32) * v.float()).to(v.dtype).float()
+
+    def lincomb(tensors, coefs, out_dtype):                          # mi355_op_lincomb
+        acc = None
+        for t, c in zip(tensors, coefs):
+            term = (torch.tensor(float(c), dtype=torch.float32) * t.float()).to(t.dtype).float()
+            acc = term if acc is None else acc + term
+        return acc.to(out_dtype)
+
+    saved = (P.WanEngine, MV.WanVAEDecoder, MW.sde_step, MU.unipc_convert, MU.lincomb)
+    F.WanStandinEngineStepwise.NAMES = ["blocks.0.attn1.to_q.weight", "blocks.0.attn1.to_q.bias"]
+    F.WanStandinEngineStepwise._count = 0
+    P.WanEngine, MV.WanVAEDecoder, MW.sde_step, MU.unipc_convert, MU.lincomb = F.WanStandinEngineStepwise, F.FakeVideoVAEDecoder, F.oracle_sde_step, convert, lincomb
+    calls = []
+    try:
+        orig = F.WanStandinPlanStepwise.transformer_forward
+
+        def spy(self, latents, t, enc_a, enc_b=None):
+            calls.append((self.engine_expert, 1 if enc_b is None else 2))
+            return orig(self, latents, t, enc_a, enc_b)
+        F.WanStandinPlanStepwise.transformer_forward = spy
+        got = G.run_reference_wan(case, adapter_base=P.Wan2T2VNativeAdapter, **kw)
+    finally:
+        F.WanStandinPlanStepwise.transformer_forward = orig
+        P.WanEngine, MV.WanVAEDecoder, MW.sde_step, MU.unipc_convert, MU.lincomb = saved
+    N = case[5]
+    assert len(calls) == N                                            # one engine forward per step (both CFG branches in one batch), nothing else
+    assert sorted(got) == sorted(want), (sorted(got), sorted(want))
+    for k in ("timesteps", "sigmas", "latent_index_map", "latents_dtype"):
+        assert torch.equal(got[k].float(), want[k].float()), k
+    a, b = got["all_latents"], want["all_latents"]
+    assert a.shape == b.shape and a.shape[1] == N + 1
+    assert torch.equal(a[:, 0], b[:, 0])                              # the initial latents: same draw, same cast
+    # Close, not equal: the two statements of the solver round different intermediate sums, and the stand-in network quantises its input and
+    # output to bf16 -- a last-bit difference in a latent flips a bf16 rounding and comes back as a bf16 ulp of the prediction (measured: up to
+    # 4e-3 of the latent range after four steps).  A control-flow error (wrong expert or guidance, a missing corrector, an extra noise draw)
+    # moves the latents by O(0.1 ... 1) of their range.  (bf16 storage: every stored latent is itself rounded to 2^-8.)
+    tol = 5e-2 if case[4] == "bf16" else 2e-2
+    for i in range(1, N + 1):
+        d = float((a[:, i] - b[:, i]).abs().max())
+        assert d <= tol * max(1.0, float(b[:, i].abs().max())), (i, d)
+    assert "log_probs" not in got and "log_probs" not in want
