@@ -129,11 +129,11 @@ DEFAULT_TARGETS = ("attn.to_k.", "attn.to_q.", "attn.to_v.", "attn.to_out.0.", "
                    "attn.to_add_out.", "ff.net.0.proj.", "ff.net.2.", "ff_context.net.0.proj.", "ff_context.net.2.")
 
 
-def _build(train_filter, seed=3, std=0.05, guidance_embeds=True):
+def _build(train_filter, seed=3, std=0.05, guidance_embeds=True, cfg_o=None):
     from oracle import flux_ref as R
     from mi355_flow import flux
     from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
-    cfg_o = R.tiny_config()
+    cfg_o = cfg_o or R.tiny_config()
     cfg_o.guidance_embeds = guidance_embeds
     mod = PF.build_module_tree(R.state_dict_shapes(cfg_o), buffers=(), seed=seed, std=std).cuda()
     with torch.no_grad():
@@ -228,6 +228,44 @@ def test_flux_replay_gradients_match_oracle_autograd_and_ratio_is_one(gpu, h, w,
           f"bf16-emulating oracle band, worst {worst_band:.3e}")
     assert n >= (56 if scope == "blocks" else 40), n
     ad.engine.close()
+
+
+def test_flux_one_double_one_single_block_gradient_values_and_real_transition_log_prob(gpu):
+    """VALUE, not direction (`test_gpu_wan_backward._compare_value`): one double + one single block, 2 048 image tokens over
+    the batch, every non-null gradient tensor's best-fit scale on the fp32 oracle's autograd within 5e-3 of 1 and its noise within 1.5 x the
+    bf16-emulating oracle's own; the replay log-prob of a REAL stored transition (x' from the engine's own rollout step) at rtol 1e-3."""
+    from oracle import flux_ref as R
+    from test_gpu_wan_backward import _compare_value
+    ad, mod, cfg_o = _build(lambda n: any(k in n for k in BLOCK_LINEARS), seed=41, cfg_o=R.tiny_config(num_layers=1, num_single_layers=1))
+    try:
+        h, w, Nt, B = 64, 64, 24, 2
+        inp = _inputs(cfg_o, B, h, w, Nt, seed=43)
+        t, t_next, eta, smax, guidance = 900.0, 750.0, 0.7, 0.9, 3.5
+        ad.scheduler.set_timesteps(4)
+        ad.scheduler.sigmas = ad.scheduler.sigmas.clone()
+        ad.scheduler.sigmas[1] = smax
+        kw = dict(t=torch.full((B,), t), t_next=torch.full((B,), t_next), latents=inp["x"].cuda(), prompt_embeds=inp["pe"].cuda(),
+                  pooled_prompt_embeds=inp["pp"].cuda(), img_ids=inp["img_ids"].cuda(), guidance_scale=guidance, noise_level=eta, compute_log_prob=True)
+        torch.cuda.manual_seed(5)
+        with torch.no_grad():
+            o0 = ad.forward(**kw, return_kwargs=["next_latents", "log_prob"])           # the rollout step: draws the noise, stores x'
+        inp["x1"] = o0.next_latents.half().cpu()
+        out = ad.forward(**kw, next_latents=inp["x1"].cuda(), return_kwargs=["log_prob", "dt"])
+        assert torch.equal(out.log_prob.detach(), o0.log_prob)
+        inp["wlp"] = torch.ones(B)
+        out.log_prob.sum().backward()
+        lp_ref, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, 0.0)
+        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, 0.0, quant=lambda z: z.to(torch.bfloat16).float())
+        np.testing.assert_allclose(out.log_prob.detach().cpu().numpy(), lp_ref.numpy(), rtol=1e-3)
+        print(f"FLUX.1 one double + one single block, real transition: log-prob engine {out.log_prob.tolist()} vs oracle {lp_ref.tolist()}")
+        g_ref = {k: v for k, v in g_ref.items() if v is not None}
+        for n_, p_ in mod.named_parameters():
+            if p_.requires_grad and n_ not in g_ref:
+                assert p_.grad is None or float(p_.grad.float().norm()) == 0.0, n_
+                p_.requires_grad_(False)
+        _compare_value(mod, g_ref, g_band, "FLUX.1 one double + one single block (2 048 image tokens, real transition)")
+    finally:
+        ad.engine.close()
 
 
 def test_flux_full_width_block_gradients_at_1024_token_count(gpu):

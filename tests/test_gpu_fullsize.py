@@ -436,7 +436,7 @@ def test_config_a_replay_gradients_vs_oracle_autograd(full):
         # error there is noise over noise.  They are checked for being small in absolute terms and kept out of "worst" (VERDICT r4 weak #4).
         rms = {name: float(g_ref[name].float().pow(2).mean().sqrt()) for name, prm in mod.named_parameters() if prm.requires_grad}
         typical = sorted(rms.values())[len(rms) // 2]
-        worst, worst_band, worst_q, n, worst_name, n_null, worst_alpha = 0.0, 0.0, 0.0, 0, None, 0, 0.0
+        worst, worst_band, worst_q, n, worst_name, n_null, worst_alpha, worst_alpha_name = 0.0, 0.0, 0.0, 0, None, 0, 0.0, None
         for name, prm in mod.named_parameters():
             if not prm.requires_grad:
                 continue
@@ -453,12 +453,13 @@ def test_config_a_replay_gradients_vs_oracle_autograd(full):
             # missing term does) -- tests/test_gpu_wan_backward._compare_value
             ge, gr = prm.grad.float().cpu().flatten().double(), g_ref[name].float().flatten().double()
             alpha = float((ge @ gr) / (gr @ gr))
-            worst_alpha = max(worst_alpha, abs(alpha - 1))
+            if abs(alpha - 1) > worst_alpha:
+                worst_alpha, worst_alpha_name = abs(alpha - 1), name
             assert abs(alpha - 1) < (5e-3 if gr.numel() >= 4096 else 1.5e-2), (name, alpha, r, band)
             assert r < 3.0 * band + 5e-3, (name, r, band)
             assert r < 6e-2 and _cos(prm.grad, g_ref[name]) > 0.99, (name, r)
         print(f"full SD3.5-medium replay gradients: {n} tensors ({n_null} with a null exact gradient, checked absolutely), worst rel-L2 vs "
-              f"fp32 oracle autograd {worst:.3e} ({worst_name}), best-fit scale within {worst_alpha:.2e} of 1; "
+              f"fp32 oracle autograd {worst:.3e} ({worst_name}), best-fit scale within {worst_alpha:.2e} of 1 ({worst_alpha_name}); "
               f"bf16-emulating oracle autograd vs fp32 (band), worst {worst_band:.3e}; engine vs bf16-emulating, worst {worst_q:.3e}; "
               f"MI355_TUNE={__import__('os').environ.get('MI355_TUNE', '')!r}")
         assert n == 16 + 16 + 14 + 8 * 2 and n_null >= 2            # blocks 0 / 12: 8 names x (w, b); block 23: no to_add_out; attn2 x 2

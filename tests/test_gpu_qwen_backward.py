@@ -182,7 +182,7 @@ def test_qwen_replay_gradients_match_oracle_autograd_and_ratio_is_one(qw, h, w, 
 
 def test_qwen_one_block_gradient_values_and_real_transition_log_prob(qw):
     """VALUE, not direction (`test_gpu_wan_backward._compare_value`): ONE block, no CFG, 2 048 image tokens over the batch,
-    every non-null gradient tensor's best-fit scale on the fp32 oracle's autograd within 5e-3 of 1 and its noise within 1.5 x the bf16-emulating
+    every non-null gradient tensor's best-fit scale on the fp32 oracle's autograd within 5e-3 of 1 and its noise within 2 x the bf16-emulating
     oracle's own, and the replay log-prob of a REAL stored transition (x' from the engine's own rollout step) at the north star's rtol 1e-3."""
     from oracle import qwen_ref as R
     from test_gpu_wan_backward import _compare_value
