@@ -601,19 +601,19 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["optimize_step_qwen_image"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not flux_mode and not args.no_train_step:
-        # ... and for Wan2.1-T2V-1.3B (native backward written at the very end of round 4: its seven GPU tests are green, its full-depth step had
-        # not been timed when the round's GPU budget ran out -- this leg is that measurement): 480 x 832 x 17 frames, B = 1, CFG, default target
-        # modules; own process, recorded, never raised
+        # ... and for Wan2.1-T2V-1.3B at BASELINE.json configs[3]'s OWN shape: 480 x 832 x 49 frames (20 280 video tokens), B = 1, CFG, all 30 blocks,
+        # the reference's default Wan target modules (first timed in round 5's first GPU call: 1092.8 ms, profiles/r05a_wan_train_b1_480p49.json);
+        # own process (~83 GiB of HBM), recorded, never raised
         try:
             import subprocess
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "wan_train_bench.py"), "--batch", "1", "--frames", "17", "--iters", "2"],
-                               capture_output=True, text=True, timeout=90)        # (never timed before: bounded tightly)
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "wan_train_bench.py"), "--batch", "1", "--frames", "49", "--iters", "2"],
+                               capture_output=True, text=True, timeout=150)
             tb = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
             out["optimize_step_wan21"] = {"ms_forward_backward": tb["ms_forward_backward"], "ms_forward_train": tb["ms_forward_train"],
                                           "ms_forward_nograd": tb["ms_forward_nograd"], "achieved": tb["tflops_step"], "unit": "TFLOP/s",
                                           "frac": tb["frac_of_2500"], "trainable_params": tb["trainable_params"], "ratio_is_one": tb["ratio_is_one"],
                                           "stash_plus_scratch_GiB": tb["stash_plus_scratch_GiB"], "tokens": tb["tokens"], "n_cfg": tb["n_cfg"],
-                                          "note": "Wan2.1-T2V-1.3B geometry (30 layers), B = 1, 480 x 832 x 17 frames, CFG, default target modules "
+                                          "note": "Wan2.1-T2V-1.3B geometry (30 layers), B = 1, 480 x 832 x 49 frames (config D's own shape), CFG, default target modules "
                                                   "(wan2_t2v.py:74-85); untimed w.r.t. `value`"}
         except Exception as e:  # noqa: BLE001
             out["optimize_step_wan21"] = {"error": repr(e), "stderr_tail": (r.stderr[-400:] if "r" in dir() and hasattr(r, "stderr") else "")}
