@@ -527,6 +527,11 @@ int mi355_profile_enable(int on);
  *  25     optimize() backward: 1 (default since round 4) = the 16-byte-access forms of the attention-backward prep kernel and of the
  *         default-scope RMSNorm-backward gather (step 94.2 -> 91.2 ms at B = 2, 1024^2; verified at full width against the oracle's autograd
  *         and its bf16 band, profiles/r04a_*), 0 = the general forms.
+ *  26-28  optimize() backward: weight-gradient GEMMs on a side stream (26), modelled split-K factor (27), text chain of the Qwen-Image / FLUX.1
+ *         double-block backward on the plan's side stream (28): csrc/backward.hip.
+ *  29     MEASUREMENT ONLY (scripts/gpu_r5_call2.sh): bit mask of launches the SD3.5 forward SKIPS -- 1 the text-stream chain, 2 every
+ *         LayerNorm-modulate, 4 the V^T projections -- to put a measured ceiling on what fusing them away could buy.  Results
+ *         are WRONG by construction; 0 (default) = nothing skipped.
  * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);
