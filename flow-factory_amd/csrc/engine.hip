@@ -282,7 +282,7 @@ extern "C" int mi355_engine_create(const mi355_model_cfg* cfg, mi355_engine** ou
     hipError_t e1 = hipMalloc((void**)&e->arena16, e->cap16);
     hipError_t e2 = hipMalloc((void**)&e->arena32, e->cap32);
     if (e1 != hipSuccess || e2 != hipSuccess) {
-        int r = fail("mi355_engine_create: hipMalloc of %zu + %zu bytes failed", e->cap16, e->cap32);
+        int r = fail("mi355_engine_create: hipMalloc of %zu + %zu bytes failed (%s)", e->cap16, e->cap32, hipGetErrorString(e1 != hipSuccess ? e1 : e2));
         if (e->arena16) (void)hipFree(e->arena16);
         if (e->arena32) (void)hipFree(e->arena32);
         delete e;

@@ -222,6 +222,11 @@ def load() -> C.CDLL:
             f"mi355_flow: {LIB_PATH} is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C flow-factory_amd/csrc`).  There is no CPU / PyTorch fallback for the rollout hot path."
         )
+    # One HIP runtime per process, and always the same one: torch bundles its own libamdhip64 / libhsa-runtime64, libmi355flow.so links the
+    # system ROCm's.  Whichever loads first serves both (same sonames), so load torch FIRST -- every caller that reaches a compute call has
+    # imported it anyway (tensors are how memory gets here), and a process that loaded this library before torch (`__graft_entry__.py smoke`
+    # after `build()`) failed its first hipMalloc on a round-5 box (profiles/r05e_smoke_order.txt).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
