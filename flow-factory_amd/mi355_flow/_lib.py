@@ -224,8 +224,9 @@ def load() -> C.CDLL:
         )
     # One HIP runtime per process, and always the same one: torch bundles its own libamdhip64 / libhsa-runtime64, libmi355flow.so links the
     # system ROCm's.  Whichever loads first serves both (same sonames), so load torch FIRST -- every caller that reaches a compute call has
-    # imported it anyway (tensors are how memory gets here), and a process that loaded this library before torch (`__graft_entry__.py smoke`
-    # after `build()`) failed its first hipMalloc on a round-5 box (profiles/r05e_smoke_order.txt).
+    # imported it anyway (tensors are how memory gets here).  (Round 5: one `__graft_entry__.py smoke` process -- build() then smoke(), the
+    # library loaded before torch -- failed its first hipMalloc right behind a bench run; it did not reproduce with either order one call
+    # later, profiles/r05f_smoke_order.txt.  The import keeps the order fixed regardless; engine_create now reports the HIP error string.)
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
