@@ -27,7 +27,6 @@ constexpr bool is_qk_epi(int e) { return e == EPI_QK_NORM || e == EPI_QK_NORM_RS
 constexpr int BK = 64;
 int g_raster_gm = 6;          // tile rows per raster band (0 = plain row-major order); mi355_tune_set(7, v)
 int g_pp_min_tiles = 128;     // smallest 256x256-tile grid for gemm_pp_kernel
-int g_mid_tiles = 0;          // mi355_tune_set(30, v): 1 = the six-wave 128 x 192 / 192 x 128 tiles for one-round mid-size grids (launch_epi)
 
 // linear tile id -> (tm, tn).  Bands of `gm` tile rows are walked column by column, so the ~32 consecutive ids that the workgroups of one
 // XCD hold at any time form a near-square block: gm A-panels + ~32/gm W-panels stream through that XCD's L2 per round instead of ~1 + 32
@@ -59,13 +58,10 @@ struct Cfg {
     static constexpr int A_BYTES = BM * BK * 2;
     static constexpr int W_BYTES = BN * BK * 2;
     static constexpr int STAGE = A_BYTES + W_BYTES;
-    static constexpr int GA = (BM / 8 + NW - 1) / NW;  // 8-row glds groups per wave (A)
-    static constexpr int GW = (BN / 8 + NW - 1) / NW;
-    // the six-wave mid-size tiles (128 x 192: 16 A groups over 6 waves; 192 x 128: 16 W groups): the last group index of some waves lies
-    // beyond the operand -- skipped by a wave-uniform guard in the staging loop
-    static constexpr bool RAG_A = (BM / 8) % NW != 0, RAG_W = (BN / 8) % NW != 0;
+    static constexpr int GA = BM / 8 / NW;  // 8-row glds groups per wave (A)
+    static constexpr int GW = BN / 8 / NW;
     static_assert(TN == 64, "wave N extent must equal head_dim (q/k RMSNorm epilogue)");
-    static_assert(BM % 8 == 0 && BN % 8 == 0, "glds groups are 8 rows");
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "glds group split");
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -413,8 +409,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
     int cy[C::GA], cx[C::GA], ct[C::GA];                  // CONV: output pixel (and frame) of the row; srcA = frame base + chunk
 #pragma unroll
     for (int i = 0; i < C::GA; ++i) {
-        int row = (wave + i * C::NW) * 8 + srow;         // row inside the A tile
-        if constexpr (C::RAG_A) row = row < BM ? row : BM - 1;     // (a group beyond the tile: never staged, any valid address)
+        const int row = (wave + i * C::NW) * 8 + srow;   // row inside the A tile
         const int c = spc ^ ((row >> 1) & 7);             // logical chunk stored at physical chunk spc
         int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;  // clamp: rows beyond M are never stored
         if constexpr (CONV) {
@@ -437,8 +432,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
     if constexpr (CONV) zsrc = p.zero_page + spc * 8;
 #pragma unroll
     for (int i = 0; i < C::GW; ++i) {
-        int row = (wave + i * C::NW) * 8 + srow;
-        if constexpr (C::RAG_W) row = row < BN ? row : BN - 1;
+        const int row = (wave + i * C::NW) * 8 + srow;
         const int c = spc ^ ((row >> 1) & 7);
         int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
         srcW[i] = p.W + (long)gn * p.ldw + c * 8;
@@ -466,12 +460,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < C::GA; ++i)
-                if (!C::RAG_A || (wave + i * C::NW) * 8 < BM) glds16(srcA[i] + ko, base + (wave + i * C::NW) * 1024);
+            for (int i = 0; i < C::GA; ++i) glds16(srcA[i] + ko, base + (wave + i * C::NW) * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < C::GW; ++i)
-            if (!C::RAG_W || (wave + i * C::NW) * 8 < BN) glds16(srcW[i] + ko, base + C::A_BYTES + (wave + i * C::NW) * 1024);
+        for (int i = 0; i < C::GW; ++i) glds16(srcW[i] + ko, base + C::A_BYTES + (wave + i * C::NW) * 1024);
     };
 
     // ---- fragment read addresses (bytes inside a stage)
@@ -995,9 +987,7 @@ template <int BM, int BN, int WM, int WN, int EPI, bool CONV = false>
 hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
     using C = Cfg<BM, BN, WM, WN>;
     auto kern = gemm_kernel<BM, BN, WM, WN, EPI, CONV>;
-    // (the six-wave mid-size tiles are dispatched for grids of at most one tile per CU: ask for more than half of the 160 KiB of LDS so
-    // that two of them never share a CU while another CU has none)
-    constexpr int smem = (C::NW == 6) ? 2 * C::STAGE + 4096 : 2 * C::STAGE;
+    constexpr int smem = 2 * C::STAGE;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -1064,21 +1054,6 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
         }
         if (big >= 200 && !fits32) return launch_cfg<256, 256, 2, 4, EPI>(p, stream);    // > 4 GiB operand (FLUX modulation table)
     }
-    // Mid-size tiles (round 5; mi355_tune_set key 30).  The 128 x 128 grid of an N = 1536 GEMM over 4096 rows -- the image stream of the
-    // reference's 512^2 examples at forward batch 4 -- is 384 tiles on 512 slots: half the CUs run two co-resident tiles, half run one, and
-    // the launch lasts as long as the pairs (measured 558 TFLOP/s on the gated-residual class, which is 36 % of that rollout's kernel time:
-    // profiles/r05_final_prof_summary_512_b2_cfg_single_stream.txt).  128 x 192 (activations x weights; 192 x 128 for the V^T GEMM, whose
-    // operands are swapped) cuts the same problem into 256 tiles, ONE per CU, six waves of 64 x 64 each: same MFMAs in the same k order, same
-    // epilogue -- bit-identical results.  Taken only when the 128 x 128 grid needs co-resident pairs and the mid-size grid fits one round.
-    if constexpr (EPI == EPI_GATE_RES || EPI == EPI_VT) {
-        if (g_mid_tiles && t128 > 256) {
-            if constexpr (EPI == EPI_VT) {
-                if (p.M % 192 == 0 && (long)(p.M / 192) * ((p.N + 127) / 128) <= 256) return launch_cfg<192, 128, 3, 2, EPI>(p, stream);
-            } else {
-                if (p.N % 192 == 0 && (long)((p.M + 127) / 128) * (p.N / 192) <= 256) return launch_cfg<128, 192, 2, 3, EPI>(p, stream);
-            }
-        }
-    }
     return launch_cfg<128, 128, 2, 2, EPI>(p, stream);
 }
 
@@ -1105,7 +1080,6 @@ void set_conv_cfg(int v) { g_conv_cfg = v; }
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 void set_w4_max_k(int v) { g_w4_max_k = v; }
 void set_pp_min_tiles(int v) { g_pp_min_tiles = v; }
-void set_mid_tiles(int v) { g_mid_tiles = v; }
 int get_gemm_variant() { return g_gemm_variant; }
 
 void set_raster_gm(int v) { g_raster_gm = v; }
