@@ -699,14 +699,15 @@ int grad_buf_dtype(const void* p) {
 int grad_buf_esize(const void* p) { return grad_buf_dtype(p) == DT_F32 ? 4 : 2; }
 
 // mi355_tune_set(26, .): the weight-gradient GEMMs (+ their split-K reductions) of the backward on a side stream of the plan's training state.
-// 1 (default) = in the head_dim-128 engines (FLUX.1 / Qwen-Image, train_common.h; read when a plan's training state is created), 2 = in the SD3.5
-// engine as well, 0 = nowhere.  Measured on MI355X, same box, optimize() step of the reference's default target modules at B = 1, 1024^2
+// 1 (default) = in the head_dim-128 engines (FLUX.1 / Qwen-Image / Wan, train_common.h; read when a plan's training state is created), 0 = nowhere
+// (a third value, the SD3.5 engine as well, was an opt-in through round 4 and is gone: see the end of this comment).  Measured on MI355X, same box, optimize() step of the reference's default target modules at B = 1, 1024^2
 // (profiles/r04i_*): FLUX.1 271.3 -> 249.1 ms, Qwen-Image (true CFG) 521.2 -> 468.7 ms -- their 3072 x 3072 gradients are 144 output tiles x 2
 // splits = 288 workgroups on 256 CUs, two half-empty rounds that the dgrad / attention-backward chain fills.  SD3.5-medium (1536 x 1536: 144
 // tiles of 128 x 128, two per CU) at B = 2, 1024^2 (profiles/r04j_*): attention projections trainable 91.6 -> 89.1 ms, every block linear
-// trainable 110.2 -> 112.6 ms -- no consistent gain, so it stays opt-in there.  Bit-identical either way (same kernels, operands, order).
+// trainable 110.2 -> 112.6 ms -- no consistent gain; re-measured in round 5 on the reference's default target set (86.5 / 86.7 vs 87.2 / 86.2 ms; 512^2:
+// 31.4 vs 32.5 ms, profiles/r05h_*) and removed from that engine.  Bit-identical either way (same kernels, operands, order).
 static int g_wgrad_side = 1;
-void set_wgrad_side(int v) { g_wgrad_side = v < 0 ? 0 : v > 2 ? 2 : v; }
+void set_wgrad_side(int v) { g_wgrad_side = v != 0 ? 1 : 0; }      // (value 2 -- the SD3.5 engine too -- measured neutral twice and was removed in round 5)
 int get_wgrad_side() { return g_wgrad_side; }
 
 // mi355_tune_set(28, .): 1 (default) = the text chain of the Qwen-Image backward and of the FLUX.1 double blocks' backward (MLP backward, out-projection dgrad | join | joint attention

@@ -1058,7 +1058,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 19) { set_w4_max_k(value); return 0; }
     if (key == 24) { set_wan_data_bound(value); return 0; }    // Wan self-attention: static / running-max softmax per (batch, head) by the measured q / k norms (1 = default)
     if (key == 25) { set_rms_bwd_fast(value); return 0; }      // optimize() backward: 1 = 16-byte forms of attn_bwd_prep and of the default-scope RMSNorm-backward gather (0 = default)
-    if (key == 26) { set_wgrad_side(value); return 0; }        // weight-gradient GEMMs on a side stream: 1 = FLUX.1 / Qwen-Image backward (default), 2 = SD3.5 too, 0 = off
+    if (key == 26) { set_wgrad_side(value); return 0; }        // weight-gradient GEMMs of the FLUX.1 / Qwen-Image / Wan backward on a side stream: 1 = on (default), 0 = off
     if (key == 27) { set_wgrad_split_model(value); return 0; } // split-K factor of the weight-gradient GEMMs: 1 = modelled-time minimum (default), 0 = the round-2 rule
     if (key == 28) { set_train_text_side(value); return 0; }   // Qwen-Image backward: the text chain on the plan's side stream (1 = default)
     if (key == 29) { g_ablate = value; return 0; }             // MEASUREMENT ONLY: launches the SD3.5 forward skips (wrong results; scripts/ablate_forward.py)

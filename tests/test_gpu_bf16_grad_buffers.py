@@ -107,7 +107,7 @@ def test_bf16_buffers_are_refused_outside_the_block_linears(gpu):
     ad.engine.close()
 
 
-@pytest.mark.parametrize("family,key", [("sd3", 26), ("flux", 26), ("qwen", 26), ("qwen", 28), ("flux", 28)])
+@pytest.mark.parametrize("family,key", [("flux", 26), ("qwen", 26), ("qwen", 28), ("flux", 28)])
 def test_weight_gradients_on_the_side_stream_are_bit_identical_to_the_serial_schedule(gpu, family, key):
     """mi355_tune_set(26, .): the split-K weight-gradient GEMMs + reductions on the training state's side stream vs on the backward's own stream;
     mi355_tune_set(28, .): the text chain of the Qwen-Image backward on the plan's side stream vs in line -- the same kernels on the same
@@ -118,7 +118,7 @@ def test_weight_gradients_on_the_side_stream_are_bit_identical_to_the_serial_sch
     lib.mi355_tune_set(27, 0)          # one split-K rule for both legs (key 27's modelled factor applies to serial launches only: another summation order)
     try:
         for side in (0, 1):
-            lib.mi355_tune_set(key, side * (2 if family == "sd3" else 1))                  # (FLUX.1 / Qwen-Image read it when the plan's training state is created: a fresh adapter per setting)
+            lib.mi355_tune_set(key, side)                  # (FLUX.1 / Qwen-Image read it when the plan's training state is created: a fresh adapter per setting)
             if family == "sd3":
                 import test_gpu_backward as TB
                 ad, mod, _ = TB._build(lambda n: any(k in n for k in TB.BLOCK_LINEARS))
