@@ -27,6 +27,7 @@ constexpr bool is_qk_epi(int e) { return e == EPI_QK_NORM || e == EPI_QK_NORM_RS
 constexpr int BK = 64;
 int g_raster_gm = 6;          // tile rows per raster band (0 = plain row-major order); mi355_tune_set(7, v)
 int g_pp_min_tiles = 128;     // smallest 256x256-tile grid for gemm_pp_kernel
+int g_w4_min_tiles = 512;     // smallest 256x256-tile grid the DEFAULT dispatch (key 0 = 1) gives to the 4-wave kernel; mi355_tune_set(31, v)
 
 // linear tile id -> (tm, tn).  Bands of `gm` tile rows are walked column by column, so the ~32 consecutive ids that the workgroups of one
 // XCD hold at any time form a near-square block: gm A-panels + ~32/gm W-panels stream through that XCD's L2 per round instead of ~1 + 32
@@ -1022,7 +1023,10 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
         // default dispatch, from IN-MODEL per-kernel durations (profiles/r03g_*: the rollout runs at the package power cap, where the 4-wave
         // kernel's +5 ... +10 % of the back-to-back microbenchmark shrink to -2.8 % time on the wide MLP projection, +-0 on q|k, and turn into
         // +2 ... +4 % on the N = 1536 gated-residual and V^T shapes, whose read-modify-write / scatter epilogues its single wave per SIMD exposes)
-        const bool w4_default = p.K <= g_w4_max_k && p.N >= 3072 && EPI != EPI_VT && EPI != EPI_GATE_RES;
+        // ... and only for grids of at least g_w4_min_tiles tiles (round 5, profiles/r05j_knob_sweep.txt): on the 192 / 384-tile grids of the
+        // reference's 512^2 examples (forward batch 4: q|k, MLP projection) its single wave per SIMD has no second round to hide a tile's
+        // epilogue behind -- the ping-pong kernel runs that rollout 2.5 % faster (154.5 vs 150.7 denoise-steps/s), +-0.3 % at 8192 rows
+        const bool w4_default = p.K <= g_w4_max_k && p.N >= 3072 && EPI != EPI_VT && EPI != EPI_GATE_RES && big >= g_w4_min_tiles;
         if ((g_gemm_variant == 2 || (g_gemm_variant == 1 && w4_default)) && big >= g_pp_min_tiles && w4_ok<EPI>(p) && cost_pp <= cost_128) {
             if constexpr (EPI == EPI_BIAS) {      // ablation builds of the hand-scheduled loop (scripts/gemm_ab.py): 33 no loads, 34 no fragment reads, 35 MFMA only
                 switch (p.dbg_skip_prefetch) {
@@ -1080,6 +1084,7 @@ void set_conv_cfg(int v) { g_conv_cfg = v; }
 void set_gemm_variant(int v) { g_gemm_variant = v; }
 void set_w4_max_k(int v) { g_w4_max_k = v; }
 void set_pp_min_tiles(int v) { g_pp_min_tiles = v; }
+void set_w4_min_tiles(int v) { g_w4_min_tiles = v; }
 int get_gemm_variant() { return g_gemm_variant; }
 
 void set_raster_gm(int v) { g_raster_gm = v; }

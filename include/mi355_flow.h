@@ -529,6 +529,8 @@ int mi355_profile_enable(int on);
  *         and its bf16 band, profiles/r04a_*), 0 = the general forms.
  *  26-28  optimize() backward: weight-gradient GEMMs on a side stream (26), modelled split-K factor (27), text chain of the Qwen-Image / FLUX.1
  *         double-block backward on the plan's side stream (28): csrc/backward.hip.
+ *  31     smallest 256x256-tile grid that key 0 = 1 gives to the 4-wave GEMM kernel (default 512: below it the ping-pong kernel, +2.5 % on the
+ *         reference's 512^2 example rollouts, profiles/r05j_*).  Results are bit-identical for every value.
  *  29     MEASUREMENT ONLY (scripts/gpu_r5_call2.sh): bit mask of launches the SD3.5 forward SKIPS -- 1 the text-stream chain, 2 every
  *         LayerNorm-modulate, 4 the V^T projections -- to put a measured ceiling on what fusing them away could buy.  Results
  *         are WRONG by construction; 0 (default) = nothing skipped.
