@@ -334,7 +334,8 @@ if _RefAdapter is not None:
                 # `expand_timesteps` (Wan2.2-TI2V-5B): the adapter hands the transformer one timestep PER TOKEN, `mask * t` with an all-ones mask in
                 # text-to-video use (wan2_t2v.py:498-504) -- every token carries the same t, and the model's per-token modulation then equals
                 # the scalar-timestep one (diffusers WanTransformer3DModel: `timestep.ndim == 2` only changes the broadcast shape; stated from
-                # its published design, the model body is not in tree).  The engine therefore runs its ordinary scalar-t forward; geometry
+                # its published design, the model body is not in tree -- oracle/wan_ref.wan_forward restates the per-token path and
+                # tests/test_host_mirrors.py::test_wan_oracle_per_token_timesteps_* shows uniform == scalar, masked != scalar).  The engine therefore runs its ordinary scalar-t forward; geometry
                 # (48 latent channels, 16 x 16 x 4 VAE compression) comes from the pipeline.  Image conditioning (a mask with zeros) is not on
                 # this adapter's path.
                 self.vae_scale_temporal = int(getattr(self.pipeline, "vae_scale_factor_temporal", 4))

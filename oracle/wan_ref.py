@@ -156,8 +156,14 @@ def _heads(x, H):
 
 def wan_forward(sd: Dict[str, torch.Tensor], cfg: WanConfig, latents: torch.Tensor, timestep: torch.Tensor, enc: torch.Tensor,
                 quant: Optional[Callable] = None) -> torch.Tensor:
-    """latents (B, 16, T, h, w); timestep (B,) in [0, 1000]; enc (B, Nt, text_dim) -> velocity (B, 16, T, h, w)."""
+    """latents (B, 16, T, h, w); timestep (B,) in [0, 1000]; enc (B, Nt, text_dim) -> velocity (B, 16, T, h, w).
+    `timestep` of shape (B, S) = ONE TIMESTEP PER TOKEN (`expand_timesteps`, Wan2.2-TI2V-5B: the adapter passes `mask[0][0][:, ::2, ::2] * t`
+    flattened, reference wan2_t2v.py:498-504): the time embedding and its six modulation vectors are then computed per token and applied per
+    token (published WanTransformer3DModel: `timestep.ndim == 2` -> temb (B, S, D), timestep_proj (B, S, 6, D); model body not in the reference
+    tree -- restated, unpinned).  With an all-ones mask every token carries the same t and the result equals the scalar-timestep forward,
+    which is what the engine runs for TI2V in text-to-video use (tests/test_host_mirrors.py::test_wan_oracle_per_token_timesteps_*)."""
     q = quant or _id
+    per_token = timestep.ndim == 2
     D, H, eps = cfg.dim, cfg.num_attention_heads, cfg.eps
     lin = lambda n, x: F.linear(q(x), q(sd[n + ".weight"]), sd[n + ".bias"])
     ln = lambda x: F.layer_norm(x, (D,), eps=eps)
@@ -165,8 +171,13 @@ def wan_forward(sd: Dict[str, torch.Tensor], cfg: WanConfig, latents: torch.Tens
     cos, sin = rope_cos_sin(T, h // 2, w // 2, cfg.attention_head_dim)
     x = q(F.linear(q(patchify(latents.float())), q(sd["patch_embedding.weight"].reshape(D, -1)), sd["patch_embedding.bias"]))
     temb = q(lin("condition_embedder.time_embedder.linear_2",
-                 F.silu(q(lin("condition_embedder.time_embedder.linear_1", q(timestep_embedding(timestep.float(), cfg.freq_dim)))))))
-    tproj = q(lin("condition_embedder.time_proj", q(F.silu(temb)))).view(B, 6, D)
+                 F.silu(q(lin("condition_embedder.time_embedder.linear_1", q(timestep_embedding(timestep.float().flatten(), cfg.freq_dim)))))))
+    tproj = q(lin("condition_embedder.time_proj", q(F.silu(temb))))
+    if per_token:                                       # (B * S, .) -> one set of modulation vectors per token
+        temb, tproj = temb.view(B, -1, D), tproj.view(B, -1, 6, D)
+    else:
+        tproj = tproj.view(B, 6, D)
+    bc = (lambda v: v) if per_token else (lambda v: v[:, None])       # a (B, S, D) vector applies as is, a (B, D) one broadcasts over the tokens
     ctx = q(lin("condition_embedder.text_embedder.linear_2",
                 q(F.gelu(lin("condition_embedder.text_embedder.linear_1", enc.float()), approximate="tanh"))))
 
@@ -176,22 +187,22 @@ def wan_forward(sd: Dict[str, torch.Tensor], cfg: WanConfig, latents: torch.Tens
 
     for i in range(cfg.num_layers):
         b = f"blocks.{i}"
-        m = (sd[f"{b}.scale_shift_table"] + tproj.float()).unbind(1)      # shift, scale, gate, c_shift, c_scale, c_gate  (B, D)
-        xn = q(ln(x) * (1 + m[1][:, None]) + m[0][:, None])
+        m = (sd[f"{b}.scale_shift_table"] + tproj.float()).unbind(-2)     # shift, scale, gate, c_shift, c_scale, c_gate  (B, D) / (B, S, D)
+        xn = q(ln(x) * (1 + bc(m[1])) + bc(m[0]))
         qq = apply_rope(_heads(_rms(q(lin(f"{b}.attn1.to_q", xn)), sd[f"{b}.attn1.norm_q.weight"], eps), H), cos, sin)
         kk = apply_rope(_heads(_rms(q(lin(f"{b}.attn1.to_k", xn)), sd[f"{b}.attn1.norm_k.weight"], eps), H), cos, sin)
         vv = _heads(lin(f"{b}.attn1.to_v", xn), H)
-        x = q(x + q(lin(f"{b}.attn1.to_out.0", attention(qq, kk, vv))) * m[2][:, None])
+        x = q(x + q(lin(f"{b}.attn1.to_out.0", attention(qq, kk, vv))) * bc(m[2]))
         xn = q(F.layer_norm(x, (D,), sd[f"{b}.norm2.weight"], sd[f"{b}.norm2.bias"], eps))
         qq = _heads(_rms(q(lin(f"{b}.attn2.to_q", xn)), sd[f"{b}.attn2.norm_q.weight"], eps), H)
         kk = _heads(_rms(q(lin(f"{b}.attn2.to_k", ctx)), sd[f"{b}.attn2.norm_k.weight"], eps), H)
         vv = _heads(lin(f"{b}.attn2.to_v", ctx), H)
         x = q(x + q(lin(f"{b}.attn2.to_out.0", attention(qq, kk, vv))))
-        xn = q(ln(x) * (1 + m[4][:, None]) + m[3][:, None])
+        xn = q(ln(x) * (1 + bc(m[4])) + bc(m[3]))
         ff = q(lin(f"{b}.ffn.net.2", q(F.gelu(lin(f"{b}.ffn.net.0.proj", xn), approximate="tanh"))))
-        x = q(x + ff * m[5][:, None])
-    mo = (sd["scale_shift_table"] + temb.float()[:, None]).unbind(1)      # shift, scale
-    xo = q(ln(x) * (1 + mo[1][:, None]) + mo[0][:, None])
+        x = q(x + ff * bc(m[5]))
+    mo = (sd["scale_shift_table"] + temb.float().unsqueeze(-2)).unbind(-2)      # shift, scale
+    xo = q(ln(x) * (1 + bc(mo[1])) + bc(mo[0]))
     out = q(lin("proj_out", xo))
     return unpatchify(out, T, h, w, cfg.out_channels)
 
