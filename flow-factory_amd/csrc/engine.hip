@@ -1061,7 +1061,6 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 26) { set_wgrad_side(value); return 0; }        // weight-gradient GEMMs of the FLUX.1 / Qwen-Image / Wan backward on a side stream: 1 = on (default), 0 = off
     if (key == 27) { set_wgrad_split_model(value); return 0; } // split-K factor of the weight-gradient GEMMs: 1 = modelled-time minimum (default), 0 = the round-2 rule
     if (key == 28) { set_train_text_side(value); return 0; }   // Qwen-Image backward: the text chain on the plan's side stream (1 = default)
-    if (key == 32) { set_pp_long_k(value); return 0; }         // experiment: long-K gated-residual GEMMs on the ping-pong kernel from 96 tiles up
     if (key == 31) { set_w4_min_tiles(value); return 0; }      // default GEMM dispatch: smallest 256 x 256-tile grid for the 4-wave hand-scheduled kernel (default 512)
     if (key == 29) { g_ablate = value; return 0; }             // MEASUREMENT ONLY: launches the SD3.5 forward skips (wrong results; scripts/ablate_forward.py)
     if (key == 22) { g_train_two_stream = value; return 0; }   // optimize() replay: the context-stream chain of the training forward / backward on a side stream (1 = default)

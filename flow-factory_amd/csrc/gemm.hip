@@ -27,7 +27,6 @@ constexpr bool is_qk_epi(int e) { return e == EPI_QK_NORM || e == EPI_QK_NORM_RS
 constexpr int BK = 64;
 int g_raster_gm = 6;          // tile rows per raster band (0 = plain row-major order); mi355_tune_set(7, v)
 int g_pp_min_tiles = 128;     // smallest 256x256-tile grid for gemm_pp_kernel
-int g_pp_long_k = 0;          // EXPERIMENT (mi355_tune_set(32, K0)): gated-residual GEMMs with K >= K0 take the ping-pong kernel from 96 tiles up
 int g_w4_min_tiles = 512;     // smallest 256x256-tile grid the DEFAULT dispatch (key 0 = 1) gives to the 4-wave kernel; mi355_tune_set(31, v)
 
 // linear tile id -> (tm, tn).  Bands of `gm` tile rows are walked column by column, so the ~32 consecutive ids that the workgroups of one
@@ -1041,8 +1040,7 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
             }
             return launch_w4<EPI>(p, stream);
         }
-        const bool long_k_pp = EPI == EPI_GATE_RES && g_pp_long_k > 0 && p.K >= g_pp_long_k && big >= 96 && fits32;
-        if ((big >= g_pp_min_tiles && fits32 && cost_pp <= cost_128) || long_k_pp) {
+        if (big >= g_pp_min_tiles && fits32 && cost_pp <= cost_128) {
             if constexpr (EPI == EPI_BIAS) {      // ablation builds (scripts/gemm_ablate.py)
                 switch (p.dbg_skip_prefetch) {
                     case 0: break;
@@ -1087,7 +1085,6 @@ void set_gemm_variant(int v) { g_gemm_variant = v; }
 void set_w4_max_k(int v) { g_w4_max_k = v; }
 void set_pp_min_tiles(int v) { g_pp_min_tiles = v; }
 void set_w4_min_tiles(int v) { g_w4_min_tiles = v; }
-void set_pp_long_k(int v) { g_pp_long_k = v; }
 int get_gemm_variant() { return g_gemm_variant; }
 
 void set_raster_gm(int v) { g_raster_gm = v; }
