@@ -120,14 +120,22 @@ def _inputs(B, h, w, Nt, seed=0):
                 ne=mk(B, Nt, 128).bfloat16(), npl=mk(B, 128).bfloat16(), wlp=mk(B), wnp=mk(B, 16, h, w))
 
 
-def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=None):
-    """The same loss through the fp32 oracle network + the Flow-SDE step written in differentiable torch (CPU).  `quant=M.bf16_round` puts a
-    bf16 round-trip wherever a bf16 module materialises a tensor; autograd rounds the activation gradient at the same points."""
+def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=None, device="cpu"):
+    """The same loss through the fp32 oracle network + the Flow-SDE step written in differentiable torch (host cores; `device="cuda"`: the
+    same plain-PyTorch fp32 oracle on GPU tensors with the MATH attention backend, tests/_gpu_oracle.py -- what makes the full-width model
+    affordable).  `quant=M.bf16_round` puts a bf16 round-trip wherever a bf16 module materialises a tensor; autograd rounds the activation
+    gradient at the same points."""
+    if device != "cpu":
+        from _gpu_oracle import cuda, on_gpu
+        with on_gpu(grad=True):
+            lp, gr = _oracle_loss(mod, cfg_o, cuda(dict(inp)), guidance, t, t_next, eta, sigma_max, kl_w, quant=quant, device="cpu")
+        return lp.cpu(), gr
     from oracle import mmditx_ref as M
-    sd = {n: p_.detach().cpu().float().requires_grad_(p_.requires_grad) for n, p_ in list(mod.named_parameters()) + list(mod.named_buffers())}
+    dev = inp["x"].device
+    sd = {n: p_.detach().to(dev).float().requires_grad_(p_.requires_grad) for n, p_ in list(mod.named_parameters()) + list(mod.named_buffers())}
     x, x1 = inp["x"].float(), inp["x1"].float()
     B = x.shape[0]
-    tt = torch.full((B,), float(torch.tensor(t).half()))            # the network sees t rounded to the latent dtype (sd3_5.py:394)
+    tt = torch.full((B,), float(torch.tensor(t, device="cpu").half()), device=dev)            # the network sees t rounded to the latent dtype (sd3_5.py:394)
     if guidance > 1.0:
         v2 = M.mmdit_forward(sd, cfg_o, torch.cat([x, x]), torch.cat([tt, tt]), torch.cat([inp["ne"], inp["pe"]]).float(),
                              torch.cat([inp["npl"], inp["pp"]]).float(), quant=quant)
@@ -143,7 +151,7 @@ def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, qua
     if sv > 0:
         lp = (-((x1 - mean) ** 2) / (2 * sv ** 2) - math.log(sv) - math.log(math.sqrt(2 * math.pi))).mean(dim=(1, 2, 3))
     else:                                          # eta = 0 (the matching-loss trainers): no log-prob term
-        lp = torch.zeros(B)
+        lp = torch.zeros(B, device=dev)
     loss = (inp["wlp"] * lp).sum() + kl_w * (inp["wnp"] * v).mean()
     loss.backward()
     return lp.detach(), {n: s.grad for n, s in sd.items() if s.requires_grad}

@@ -1,14 +1,20 @@
 """GPU parity at the REAL configurations of BASELINE.json (full SD3.5-medium: 24 blocks, 13 dual, D = 1536) against the
-fp32 CPU oracle on identical bf16-rounded weights, prompts and noise:
+fp32 oracle on identical bf16-rounded weights, prompts and noise:
 
   * config A end to end: 256x256, 4 Euler/SDE steps, B = 1 -- per-step latents, rollout log-prob (rtol 1e-3, north star);
   * replay log-prob ENGINE vs ORACLE on the engine's stored (x_i, x_{i+1}) (SURVEY.md 8(a) item iii, 8(d) tolerance 1e-3):
     the number that sizes the train/inference-consistency hazard when optimize() replays on a different implementation;
-  * config B shape: one full-model forward at 1024x1024 (S = 4096 + 333 = 4429 joint tokens), B = 1.
+  * config B -- BASELINE.json configs[1], the configuration the headline metric is quoted on -- END TO END AT ITS OWN LENGTH: 1024x1024
+    (S = 4096 + 333 = 4429 joint tokens), **N = 28 steps**, B = 1: every step's latents, the SDE step's log-prob, the oracle replay.
 
 Reference control flow: src/flow_factory/models/stable_diffusion/sd3_5.py:258-304 (loop), :352-448 (forward).
 The oracle model body is an unpinned restatement of diffusers' SD3Transformer2DModel (oracle/mmditx_ref.py header).
-CPU cost: ~0.9 TFLOP per 256^2 forward (seconds), 11.25 TFLOP for the 1024^2 forward (~1 min on the box's host cores).
+
+Round 6: the oracle runs ON THE GPU in fp32 (tests/_gpu_oracle.py: plain PyTorch on cuda tensors, MATH attention backend; gfx950 has no
+TF32, so this is an exact-fp32 checker).  One 1024^2 oracle forward costs a fraction of a second instead of ~25 s on the host cores, which
+is what makes the 28-step comparison (56 oracle forwards: fp32 + bf16-emulating) affordable inside the suite.  Tolerances: latents and
+forwards within `1.5 x band + 1e-3` of the fp32 oracle, band = the bf16-emulating oracle's own distance from fp32 (measured: the engine
+sits at 1.0 x band); the fraction of elements within one storage-dtype ulp is reported per step (SURVEY.md 8(d)'s second criterion).
 """
 import os
 
@@ -16,7 +22,11 @@ import numpy as np
 import pytest
 import torch
 
+from _gpu_oracle import cuda, on_gpu, ulp_fraction
+
 pytestmark = pytest.mark.gpu
+
+BAND_FACTOR, BAND_FLOOR = 1.5, 1e-3          # latents / forwards: engine-vs-fp32 <= 1.5 x (bf16-emulating oracle vs fp32) + 1e-3
 
 N_TEXT = 333
 
@@ -39,11 +49,8 @@ def full():
     e = engine.Engine(cfg_e)
     e.bind_state_dict(sd_gpu)
     e.ready()
-    sd = {k: v.float().cpu() for k, v in sd_gpu.items()}
-    del sd_gpu
-    torch.cuda.empty_cache()
-    torch.set_num_threads(max(torch.get_num_threads(), 1))
-    yield e, sd, M.SD35_MEDIUM
+    # the ORACLE's weights: the same bf16-rounded values, resident on the GPU (mmditx_ref takes `.float()` of a weight where it uses it)
+    yield e, sd_gpu, M.SD35_MEDIUM
     e.close()
 
 
@@ -53,79 +60,79 @@ def test_config_a_rollout_and_replay_vs_oracle(full):
     e, sd, cfg = full
     B, h, w, N = 1, 32, 32, 4
     g = torch.Generator().manual_seed(4321)
-    pe = torch.randn(B, N_TEXT, 4096, generator=g).bfloat16()
-    pp = torch.randn(B, 2048, generator=g).bfloat16()
-    init, noise = R.draw_rollout_noise(B, 16, h, w, N, torch.bfloat16, torch.Generator().manual_seed(42))
-    ts, sig = S.make_schedule(N, shift=3.0)
+    pe = torch.randn(B, N_TEXT, 4096, generator=g).bfloat16().cuda()
+    pp = torch.randn(B, 2048, generator=g).bfloat16().cuda()
+    init, noise = cuda(R.draw_rollout_noise(B, 16, h, w, N, torch.bfloat16, torch.Generator().manual_seed(42)))
+    ts, sig = cuda(S.make_schedule(N, shift=3.0))
     sde = S.current_sde_steps([1, 2, 3], 1, 42, N)
     nl = S.noise_levels(N, sde, 0.7).tolist()
-    ref = R.rollout(sd, cfg, pe, pp, None, None, 1.0, init, noise, ts, sig, nl, torch.float16)
+    with on_gpu():
+        ref = R.rollout(sd, cfg, pe, pp, None, None, 1.0, init, noise, ts, sig, nl, torch.float16)
+        # how much of the distance is bf16 itself: the same oracle with bf16 round-trips where the reference's bf16 network rounds
+        # (what a diffusers bf16 run computes, up to accumulation order) against its own fp32 self -- the engine must sit in that band
+        refq = R.rollout(sd, cfg, pe, pp, None, None, 1.0, init, noise, ts, sig, nl, torch.float16, quant=M.bf16_round)
     plan = e.plan(B, 1, h, w, N_TEXT, N)
-    lat, lp, fin = plan.rollout(ts.tolist(), sig.tolist(), nl, "Flow-SDE", 1.0, init.cuda(), torch.float16, noise.cuda(),
-                                pe.cuda(), pp.cuda())
+    lat, lp, fin = plan.rollout(ts.tolist(), sig.tolist(), nl, "Flow-SDE", 1.0, init, torch.float16, noise, pe, pp)
     torch.cuda.synchronize()
-    assert torch.equal(lat[0].cpu(), S.cast_latents(init, torch.float16))
+    assert torch.equal(lat[0], S.cast_latents(init, torch.float16))
     worst = 0.0
     for i in range(1, N + 1):
-        r = _rel(lat[i], ref["all_latents"][i])
+        r, band, rq = _rel(lat[i], ref["all_latents"][i]), _rel(refq["all_latents"][i], ref["all_latents"][i]), _rel(lat[i], refq["all_latents"][i])
         worst = max(worst, r)
-        assert r < 2e-2, (i, r)
+        print(f"config A step {i}: latents engine vs fp32 oracle {r:.3e}; band {band:.3e}; engine vs bf16-emulating {rq:.3e}; "
+              f"within 1 fp16 ulp of the fp32 oracle {ulp_fraction(lat[i], ref['all_latents'][i], torch.float16):.4f} "
+              f"(bf16-emulating oracle: {ulp_fraction(refq['all_latents'][i], ref['all_latents'][i], torch.float16):.4f})")
+        assert r < BAND_FACTOR * band + BAND_FLOOR, (i, r, band)
     steps = [i for i in range(N) if nl[i] > 0]
     assert len(steps) == 1
     i = steps[0]
-    np.testing.assert_allclose(lp[i].cpu().numpy(), ref["log_probs"][i].numpy(), rtol=1e-3)   # rollout log-prob, north star
-    # how much of that distance is bf16 itself: the same oracle with bf16 round-trips where the reference's bf16 network rounds
-    # (what a diffusers bf16 run computes, up to accumulation order) against its own fp32 self -- the engine should sit in that band
-    refq = R.rollout(sd, cfg, pe, pp, None, None, 1.0, init, noise, ts, sig, nl, torch.float16, quant=M.bf16_round)
-    band = max(_rel(refq["all_latents"][j], ref["all_latents"][j]) for j in range(1, N + 1))
-    worst_q = max(_rel(lat[j], refq["all_latents"][j]) for j in range(1, N + 1))
-    print(f"config A: bf16-emulating oracle vs fp32 oracle, worst per-step latent rel-L2 {band:.3e}; engine vs bf16-emulating oracle {worst_q:.3e}; "
-          f"engine vs fp32 oracle {worst:.3e}")
-    assert worst < 3.0 * band + 2e-3, (worst, band)          # the engine is no further from fp32 than a bf16 network is (x3 slack)
+    np.testing.assert_allclose(lp[i].cpu().numpy(), ref["log_probs"][i].cpu().numpy(), rtol=1e-3)   # rollout log-prob, north star
 
     # ---- replay (what optimize() computes, trainers/grpo.py:229-263) on the ENGINE's stored transition, evaluated by the ORACLE
-    x_i, x_n = lat[i].cpu(), lat[i + 1].cpu()
-    t = ts[i]
-    t_next = ts[i + 1] if i + 1 < N else torch.tensor(0.0)
-    o = R.forward_step(sd, cfg, t, t_next, x_i, pe, pp, None, None, 1.0, noise_level=nl[i], sigma_max=float(sig[1]),
-                       next_latents=x_n.float())
-    lp_engine = lp[i].cpu()
-    ratio = torch.exp(o["log_prob"] - lp_engine)
+    t_next = ts[i + 1] if i + 1 < N else torch.tensor(0.0).cuda()
+    with on_gpu():
+        o = R.forward_step(sd, cfg, ts[i], t_next, lat[i], pe, pp, None, None, 1.0, noise_level=nl[i], sigma_max=float(sig[1]),
+                           next_latents=lat[i + 1].float())
+    ratio = torch.exp(o["log_prob"] - lp[i])
     print(f"config A: worst per-step latent rel-L2 {worst:.3e}; replay log-prob oracle {o['log_prob'].tolist()} vs engine rollout "
-          f"{lp_engine.tolist()}; |ratio-1| = {float((ratio - 1).abs().max()):.3e}")
-    np.testing.assert_allclose(o["log_prob"].numpy(), lp_engine.numpy(), rtol=1e-3)
+          f"{lp[i].tolist()}; |ratio-1| = {float((ratio - 1).abs().max()):.3e}")
+    np.testing.assert_allclose(o["log_prob"].cpu().numpy(), lp[i].cpu().numpy(), rtol=1e-3)
     assert float((ratio - 1).abs().max()) < 1e-3      # abs(ratio - 1) <= 1e-3 engine-vs-oracle
     # ... and the engine's own replay of the same transition is bit-identical (ratio == 1.0 exactly)
-    o2 = plan.denoise_step(lat[i], ts[i].reshape(1).expand(B), pe.cuda(), pp.cuda(), None, None, 1.0,
-                           (ts[i].double() / 1000).float().reshape(1).expand(B), (t_next.double() / 1000).float().reshape(1).expand(B),
+    tc, tn = ts[i].cpu(), t_next.cpu()
+    o2 = plan.denoise_step(lat[i], tc.reshape(1).expand(B), pe, pp, None, None, 1.0,
+                           (tc.double() / 1000).float().reshape(1).expand(B), (tn.double() / 1000).float().reshape(1).expand(B),
                            torch.full((B,), nl[i]), float(sig[1]), "Flow-SDE", next_latents=lat[i + 1])
     assert torch.equal(o2.log_prob, lp[i])
 
 
-def test_config_b_forward_1024_vs_oracle(full):
-    """BASELINE.json configs[1] shape: 1024^2 (latent 128x128 -> 4096 image tokens + 333 text tokens), B = 1."""
+def test_config_b_forward_1024_sits_in_the_bf16_band(full):
+    """BASELINE.json configs[1] shape: 1024^2 (latent 128x128 -> 4096 image tokens + 333 text tokens), B = 1, one forward.  How far from
+    the fp32 oracle may a bf16 network be at S = 4429?  The oracle with bf16 round-trips wherever the reference's bf16 module materialises a
+    tensor (`quant=M.bf16_round`) against its own fp32 self is the band; the engine must sit within 1.5 x that band (+1e-3) of the fp32
+    oracle -- i.e. its 1.4e-2 at this shape is bf16 rounding through 24 blocks, not an implementation error."""
     from oracle import mmditx_ref as M
     e, sd, cfg = full
     g = torch.Generator().manual_seed(99)
     B, h, w = 1, 128, 128
-    x = torch.randn(B, 16, h, w, generator=g).half()
-    enc = torch.randn(B, N_TEXT, 4096, generator=g).bfloat16()
-    pooled = torch.randn(B, 2048, generator=g).bfloat16()
-    t = torch.tensor([750.0])
+    x = torch.randn(B, 16, h, w, generator=g).half().cuda()
+    enc = torch.randn(B, N_TEXT, 4096, generator=g).bfloat16().cuda()
+    pooled = torch.randn(B, 2048, generator=g).bfloat16().cuda()
+    t = torch.tensor([750.0]).cuda()
     plan = e.plan(B, 1, h, w, N_TEXT, 1)
-    y = plan.transformer_forward(x.cuda(), t.cuda(), enc.cuda(), pooled.cuda())
+    y = plan.transformer_forward(x, t, enc, pooled)
     torch.cuda.synchronize()
-    with torch.no_grad():
+    with on_gpu():
         ref = M.mmdit_forward(sd, cfg, x.float(), t, enc.float(), pooled.float())
-    r = _rel(y, ref)
-    print(f"config B forward (S = 4429) rel-L2 vs fp32 oracle: {r:.3e}")
+        refq = M.mmdit_forward(sd, cfg, x.float(), t, enc.float(), pooled.float(), quant=M.bf16_round)
+    band, r, rq = _rel(refq, ref), _rel(y, ref), _rel(y, refq)
+    print(f"config B forward (S = 4429): bf16-emulating oracle vs fp32 oracle {band:.3e}; engine vs fp32 {r:.3e}; engine vs bf16-emulating {rq:.3e}")
     assert torch.isfinite(y.float()).all()
-    assert r < 3e-2, r
+    assert r < BAND_FACTOR * band + BAND_FLOOR, (r, band)
     # the same sample inside a batch of 2 (different tile positions / workgroup mapping) gives the same result
     plan2 = e.plan(2, 1, h, w, N_TEXT, 1)
-    y2 = plan2.transformer_forward(torch.cat([x, x]).cuda(), t.repeat(2).cuda(), torch.cat([enc, enc]).cuda(),
-                                   torch.cat([pooled, pooled]).cuda())
-    assert _rel(y2[0:1], ref) < 3e-2 and _rel(y2[1:2], ref) < 3e-2
+    y2 = plan2.transformer_forward(torch.cat([x, x]), t.repeat(2), torch.cat([enc, enc]), torch.cat([pooled, pooled]))
+    assert torch.equal(y2[0:1], y) and torch.equal(y2[1:2], y)
 
 
 def test_forward_is_bitwise_independent_of_the_batch_a_sample_sits_in(full):
@@ -162,90 +169,63 @@ def test_forward_is_bitwise_independent_of_the_batch_at_the_bench_shape(full):
         assert torch.equal(y8[b:b + 1], y1), b
 
 
-def test_config_b_forward_sits_in_the_bf16_band(full):
-    """How far from the fp32 oracle may a bf16 network be at S = 4429?  The oracle with bf16 round-trips wherever the reference's bf16 module
-    materialises a tensor (`quant=M.bf16_round`: what a diffusers bf16 run computes up to accumulation order) against its own fp32 self is
-    the band; the engine must sit within 3x that band (+2e-3) of the fp32 oracle -- i.e. its 1.4e-2 at this shape is bf16 rounding through 24
-    blocks, not an implementation error (the distance to the bf16-emulating oracle is printed for the record)."""
-    from oracle import mmditx_ref as M
-    e, sd, cfg = full
-    g = torch.Generator().manual_seed(99)                                   # the inputs of test_config_b_forward_1024_vs_oracle
-    B, h, w = 1, 128, 128
-    x = torch.randn(B, 16, h, w, generator=g).half()
-    enc = torch.randn(B, N_TEXT, 4096, generator=g).bfloat16()
-    pooled = torch.randn(B, 2048, generator=g).bfloat16()
-    t = torch.tensor([750.0])
-    y = e.plan(B, 1, h, w, N_TEXT, 1).transformer_forward(x.cuda(), t.cuda(), enc.cuda(), pooled.cuda())
-    with torch.no_grad():
-        ref = M.mmdit_forward(sd, cfg, x.float(), t, enc.float(), pooled.float())
-        refq = M.mmdit_forward(sd, cfg, x.float(), t, enc.float(), pooled.float(), quant=M.bf16_round)
-    band, r, rq = _rel(refq, ref), _rel(y, ref), _rel(y, refq)
-    print(f"config B forward (S = 4429): bf16-emulating oracle vs fp32 oracle {band:.3e}; engine vs fp32 {r:.3e}; engine vs bf16-emulating {rq:.3e}")
-    assert r < 3.0 * band + 2e-3, (r, band)
-
-
 @pytest.fixture(scope="module")
 def config_b(full):
-    """BASELINE.json configs[1]'s geometry END TO END (the north star's own sentence: per-step log-probs at 1024^2): B = 1, N = 4 Flow-SDE
-    steps (eta 0.7, one SDE step of [1, 2, 3], scheduler seed 42, fp16 storage).  The ORACLE side -- the fp32 rollout, the bf16-emulating rollout
-    (the band), the negative branch of the CFG pair: 10 oracle forwards at S = 4429, ~25 s each on the box's host cores -- is deterministic given
-    the seeded inputs and is loaded from tests/golden/config_b_oracle.npz (oracle/make_config_b_golden.py: generated on a GPU box because the
-    synthetic weights are GPU-drawn; the spatial subsample [:, :, ::4, ::4] of every compared tensor).  MI355_CONFIG_B_LIVE=1 recomputes it here,
-    in full.  What depends on the ENGINE's output (the oracle replay of the engine's stored transition) is always computed live."""
-    from oracle import make_config_b_golden as GB
+    """BASELINE.json configs[1] END TO END AT ITS OWN LENGTH (the north star's own sentence: per-step log-probs at 1024^2, 28 steps): B = 1,
+    N = 28 Flow-SDE steps (eta 0.7, one SDE step of [1, 2, 3], scheduler seed 42, shift 3, fp16 storage).  The ORACLE side -- the fp32 rollout
+    and the bf16-emulating rollout (the band): 56 oracle forwards at S = 4429 -- runs live on the GPU in fp32 (tests/_gpu_oracle.py)."""
+    from oracle import config_b_inputs as GB, mmditx_ref as M, rollout_ref as R
     e, sd, cfg = full
-    c = GB.inputs()
-    if os.environ.get("MI355_CONFIG_B_LIVE") == "1":
-        o = GB.compute(sd, cfg, c)
-        c.update(o, stride=1, live=True)
-    else:
-        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "config_b_oracle.npz"))
-        assert int(z["n_text"]) == N_TEXT
-        wsum = float(sum(float(v.double().sum()) for v in sd.values()))          # the fixture belongs to THESE weights (GPU generator, seed 1234)
-        assert abs(wsum - float(z["weights_checksum"])) <= 1e-6 * max(1.0, abs(wsum)), (wsum, float(z["weights_checksum"]))
-        c.update({k: torch.from_numpy(z[k].astype(np.float32)) for k in ("lat", "latq", "lp", "vt", "vtq", "vu", "vuq")}, stride=int(z["stride"]), live=False)
+    c = cuda(GB.inputs(N=28))
+    with on_gpu():
+        ref = R.rollout(sd, cfg, c["pe"], c["pp"], None, None, 1.0, c["init"], c["noise"], c["ts"], c["sig"], c["nl"], torch.float16)
+        refq = R.rollout(sd, cfg, c["pe"], c["pp"], None, None, 1.0, c["init"], c["noise"], c["ts"], c["sig"], c["nl"], torch.float16, quant=M.bf16_round)
+    c.update(lat=ref["all_latents"], latq=refq["all_latents"], lp=ref["log_probs"], vt=ref["noise_preds"][0], vtq=refq["noise_preds"][0])
     return c
 
 
-def _sub(x, c):
-    return x[..., ::c["stride"], ::c["stride"]]
-
-
-def test_config_b_rollout_1024_latents_logprob_and_oracle_replay(full, config_b):
-    """sd3_5.py:258-304 + trainers/grpo.py:229-263 at 1024^2 (S = 4429): (i) every step's latents inside the bf16 band of the oracle,
-    (ii) the rollout log-prob to rtol 1e-3 (north star), (iii) the ENGINE's stored transition (x_i, x_{i+1}) replayed by the fp32 ORACLE:
-    |ratio - 1| <= 1e-3, (iv) the engine's own replay of it bit-identical (ratio == 1 exactly)."""
+def test_config_b_rollout_1024_28_steps_latents_logprob_and_oracle_replay(full, config_b):
+    """sd3_5.py:258-304 + trainers/grpo.py:229-263 at BASELINE.json configs[1]'s own geometry AND length (1024^2, S = 4429, N = 28: with
+    sde_steps [1, 2, 3] one early SDE step feeds 24+ ODE steps -- the drift of a 28-step trajectory is what this observes): (i) EVERY step's
+    latents inside the bf16 band of the fp32 oracle, (ii) the rollout log-prob to rtol 1e-3 (north star), (iii) the ENGINE's stored
+    transition (x_i, x_{i+1}) replayed by the fp32 ORACLE: |ratio - 1| <= 1e-3, (iv) the engine's own replay of it
+    bit-identical (ratio == 1 exactly), (v) the second (hipGraph-replayed) rollout bit-identical to the first."""
     from oracle import rollout_ref as R, scheduler_ref as S
     e, sd, cfg = full
     c = config_b
     B, h, w, N, ts, sig, nl, pe, pp = c["B"], c["h"], c["w"], c["N"], c["ts"], c["sig"], c["nl"], c["pe"], c["pp"]
+    assert N == 28
     plan = e.plan(B, 1, h, w, N_TEXT, N)
-    lat, lp, fin = plan.rollout(ts.tolist(), sig.tolist(), nl, "Flow-SDE", 1.0, c["init"].cuda(), torch.float16, c["noise"].cuda(),
-                                pe.cuda(), pp.cuda())
+    lat, lp, fin = (x.clone() for x in plan.rollout(ts.tolist(), sig.tolist(), nl, "Flow-SDE", 1.0, c["init"], torch.float16, c["noise"], pe, pp))
+    lat2, lp2, fin2 = plan.rollout(ts.tolist(), sig.tolist(), nl, "Flow-SDE", 1.0, c["init"], torch.float16, c["noise"], pe, pp)     # graph replay
     torch.cuda.synchronize()
-    assert torch.equal(lat[0].cpu(), S.cast_latents(c["init"], torch.float16))
-    per_step = [(_rel(_sub(lat[i], c), c["lat"][i]), _rel(c["latq"][i], c["lat"][i]), _rel(_sub(lat[i], c), c["latq"][i])) for i in range(1, N + 1)]
-    for i, (r, band, rq) in enumerate(per_step, 1):
-        print(f"config B rollout step {i}: latents engine vs fp32 oracle {r:.3e}; bf16-emulating oracle vs fp32 (band) {band:.3e}; "
-              f"engine vs bf16-emulating {rq:.3e}")
-        assert r < 3.0 * band + 2e-3, (i, r, band)
+    assert torch.equal(lat, lat2) and torch.equal(lp.nan_to_num(7.0), lp2.nan_to_num(7.0)) and torch.equal(fin, fin2)
+    assert torch.equal(lat[0], S.cast_latents(c["init"], torch.float16))
+    worst_ratio = 0.0
+    for i in range(1, N + 1):
+        r, band, rq = _rel(lat[i], c["lat"][i]), _rel(c["latq"][i], c["lat"][i]), _rel(lat[i], c["latq"][i])
+        worst_ratio = max(worst_ratio, r / band)
+        print(f"config B (N = 28) step {i:2d} eta {nl[i - 1]:.2f}: latents engine vs fp32 oracle {r:.3e}; bf16-emulating oracle vs fp32 (band) "
+              f"{band:.3e}; engine vs bf16-emulating {rq:.3e}; within 1 fp16 ulp of fp32 oracle: engine "
+              f"{ulp_fraction(lat[i], c['lat'][i], torch.float16):.4f}, bf16-emulating oracle {ulp_fraction(c['latq'][i], c['lat'][i], torch.float16):.4f}")
+        assert r < BAND_FACTOR * band + BAND_FLOOR, (i, r, band)
+    print(f"config B (N = 28): worst engine / band ratio over the 28 steps {worst_ratio:.3f}")
     steps = [i for i in range(N) if nl[i] > 0]
     assert len(steps) == 1
     i = steps[0]
-    np.testing.assert_allclose(lp[i].cpu().numpy(), c["lp"][i].numpy(), rtol=1e-3)        # rollout log-prob, north star
-    x_i, x_n = lat[i].cpu(), lat[i + 1].cpu()
-    t_next = ts[i + 1] if i + 1 < N else torch.tensor(0.0)
-    with torch.no_grad():
-        o = R.forward_step(sd, cfg, ts[i], t_next, x_i, pe, pp, None, None, 1.0, noise_level=nl[i], sigma_max=float(sig[1]),
-                           next_latents=x_n.float())
-    lp_engine = lp[i].cpu()
-    ratio = torch.exp(o["log_prob"] - lp_engine)
-    print(f"config B rollout: log-prob engine {lp_engine.tolist()} vs oracle rollout {c['lp'][i].tolist()}; ORACLE replay of the "
+    np.testing.assert_allclose(lp[i].cpu().numpy(), c["lp"][i].cpu().numpy(), rtol=1e-3)        # rollout log-prob, north star
+    t_next = ts[i + 1] if i + 1 < N else torch.tensor(0.0).cuda()
+    with on_gpu():
+        o = R.forward_step(sd, cfg, ts[i], t_next, lat[i], pe, pp, None, None, 1.0, noise_level=nl[i], sigma_max=float(sig[1]),
+                           next_latents=lat[i + 1].float())
+    ratio = torch.exp(o["log_prob"] - lp[i])
+    print(f"config B (N = 28) SDE step {i}: log-prob engine {lp[i].tolist()} vs oracle rollout {c['lp'][i].tolist()}; ORACLE replay of the "
           f"engine's stored transition {o['log_prob'].tolist()}: |ratio - 1| = {float((ratio - 1).abs().max()):.3e}")
-    np.testing.assert_allclose(o["log_prob"].numpy(), lp_engine.numpy(), rtol=1e-3)
+    np.testing.assert_allclose(o["log_prob"].cpu().numpy(), lp[i].cpu().numpy(), rtol=1e-3)
     assert float((ratio - 1).abs().max()) < 1e-3
-    o2 = plan.denoise_step(lat[i], ts[i].reshape(1).expand(B), pe.cuda(), pp.cuda(), None, None, 1.0,
-                           (ts[i].double() / 1000).float().reshape(1).expand(B), (t_next.double() / 1000).float().reshape(1).expand(B),
+    tc, tn = ts[i].cpu(), t_next.cpu()
+    o2 = plan.denoise_step(lat[i], tc.reshape(1).expand(B), pe, pp, None, None, 1.0,
+                           (tc.double() / 1000).float().reshape(1).expand(B), (tn.double() / 1000).float().reshape(1).expand(B),
                            torch.full((B,), nl[i]), float(sig[1]), "Flow-SDE", next_latents=lat[i + 1])
     assert torch.equal(o2.log_prob, lp[i])
 
@@ -254,32 +234,38 @@ def test_config_b_cfg_forward_pair_1024_sits_in_its_own_band(full, config_b):
     """The reference's shipped SD3.5 example runs CFG 4.5 (examples/grpo/full/sd3_5/default.yaml:51): `u + g (c - u)` in bf16 (sd3_5.py:431-433)
     amplifies the difference of two nearly equal predictions.  One [negative, positive] forward pair at 1024^2, guidance 4.5, on the first
     rollout state: the combined prediction against the fp32 oracle, with the band the bf16-emulating oracle sets for THIS quantity (the
-    positive branch of both oracles is step 0 of the rollouts above; the negative branch's two oracle forwards come with the same fixture)."""
+    positive branch of both oracles is step 0 of the rollouts above; the negative branch's two oracle forwards are computed here)."""
     from oracle import mmditx_ref as M, rollout_ref as R, scheduler_ref as S
     e, sd, cfg = full
     c = config_b
     B, h, w, ts, sig, pe, pp, ne, npl = c["B"], c["h"], c["w"], c["ts"], c["sig"], c["pe"], c["pp"], c["ne"], c["npl"]
     g = 4.5
     x0 = S.cast_latents(c["init"], torch.float16)
-    vu, vuq, vt, vtq = c["vu"], c["vuq"], c["vt"], c["vtq"]          # negative branch; positive branch = step 0 of the rollouts (same x0, t0)
-    ref = R.cfg_combine_bf16(vu, vt, g).float()
-    refq = R.cfg_combine_bf16(vuq, vtq, g).float()
+    with on_gpu():
+        t_in = ts[0].reshape(1).to(torch.float16).float()
+        vu = M.mmdit_forward(sd, cfg, x0.float(), t_in, ne.float(), npl.float())
+        vuq = M.mmdit_forward(sd, cfg, x0.float(), t_in, ne.float(), npl.float(), quant=M.bf16_round)
+        vt, vtq = c["vt"], c["vtq"]          # positive branch = step 0 of the rollouts (same x0, t0)
+        ref = R.cfg_combine_bf16(vu, vt, g).float()
+        refq = R.cfg_combine_bf16(vuq, vtq, g).float()
     plan = e.plan(B, 2, h, w, N_TEXT, 1)
-    o = plan.denoise_step(x0.cuda(), ts[0].reshape(1), ne.cuda(), npl.cuda(), pe.cuda(), pp.cuda(), g,
-                          (ts[0].double() / 1000).float().reshape(1), (ts[1].double() / 1000).float().reshape(1), torch.zeros(B),
-                          float(sig[1]), "Flow-SDE", noise=c["noise"][0].cuda(), compute_log_prob=False, want=("noise_pred", "next_latents"))
+    tc0, tc1 = ts[0].cpu(), ts[1].cpu()
+    o = plan.denoise_step(x0, tc0.reshape(1), ne, npl, pe, pp, g,
+                          (tc0.double() / 1000).float().reshape(1), (tc1.double() / 1000).float().reshape(1), torch.zeros(B),
+                          float(sig[1]), "Flow-SDE", noise=c["noise"][0], compute_log_prob=False, want=("noise_pred", "next_latents"))
     torch.cuda.synchronize()
-    npred = _sub(o.noise_pred, c)
+    npred = o.noise_pred
     r, band, rq = _rel(npred, ref), _rel(refq, ref), _rel(npred, refq)
-    r1, band1 = _rel(npred, vt), _rel(vtq, vt)
+    band1 = _rel(vtq, vt)
     print(f"config B CFG 4.5 pair (S = 4429): combined prediction engine vs fp32 oracle {r:.3e}; bf16-emulating oracle vs fp32 (band) {band:.3e}; "
           f"engine vs bf16-emulating {rq:.3e}  [single-branch band for scale: {band1:.3e}; amplification {band / band1:.2f}x]")
     assert torch.isfinite(o.noise_pred.float()).all()
-    assert r < 3.0 * band + 2e-3, (r, band)
+    assert r < BAND_FACTOR * band + BAND_FLOOR, (r, band)
     # and the step it feeds: x' = x + v dt (eta = 0) in fp16 storage, vs the oracle's step on ITS combined prediction
-    so = S.sde_step(ref.to(torch.bfloat16), _sub(x0, c), ts[0].float() / 1000, ts[1].float() / 1000, 0.0, dynamics_type="Flow-SDE", sigma_max=float(sig[1]),
-                    variance_noise=_sub(c["noise"][0], c), compute_log_prob=False)          # (elementwise: the subsample steps like the whole)
-    rs = _rel(_sub(o.next_latents, c), S.cast_latents(so["next_latents"], torch.float16))
+    with on_gpu():
+        so = S.sde_step(ref.to(torch.bfloat16), x0, ts[0].float() / 1000, ts[1].float() / 1000, 0.0, dynamics_type="Flow-SDE", sigma_max=float(sig[1]),
+                        variance_noise=c["noise"][0], compute_log_prob=False)
+    rs = _rel(o.next_latents, S.cast_latents(so["next_latents"], torch.float16))
     print(f"config B CFG 4.5 step: next latents engine vs oracle {rs:.3e}")
     assert rs < 1e-2, rs            # |dt| = 0.1 of the prediction's relative error, on top of the fp16 storage rounding
 
@@ -299,14 +285,14 @@ def test_config_a_advantages_from_engine_images_match_the_oracle_pipeline(full):
     B = Mg * K
     g = torch.Generator().manual_seed(911)
     pe_u, pp_u = torch.randn(Mg, N_TEXT, 4096, generator=g).bfloat16(), torch.randn(Mg, 2048, generator=g).bfloat16()
-    pe, pp = pe_u.repeat_interleave(K, 0), pp_u.repeat_interleave(K, 0)
-    init, noise = R.draw_rollout_noise(B, 16, h, w, N, torch.bfloat16, torch.Generator().manual_seed(44))
-    ts, sig = S.make_schedule(N, shift=3.0)
+    pe, pp = pe_u.repeat_interleave(K, 0).cuda(), pp_u.repeat_interleave(K, 0).cuda()
+    init, noise = cuda(R.draw_rollout_noise(B, 16, h, w, N, torch.bfloat16, torch.Generator().manual_seed(44)))
+    ts, sig = cuda(S.make_schedule(N, shift=3.0))
     nl = S.noise_levels(N, S.current_sde_steps([1, 2, 3], 1, 42, N), 0.7).tolist()
-    with torch.no_grad():
+    with on_gpu():
         ref = R.rollout(sd, cfg, pe, pp, None, None, 1.0, init, noise, ts, sig, nl, torch.float16)
     plan = e.plan(B, 1, h, w, N_TEXT, N)
-    lat, lp, fin = plan.rollout(ts.tolist(), sig.tolist(), nl, "Flow-SDE", 1.0, init.cuda(), torch.float16, noise.cuda(), pe.cuda(), pp.cuda())
+    lat, lp, fin = plan.rollout(ts.tolist(), sig.tolist(), nl, "Flow-SDE", 1.0, init, torch.float16, noise, pe, pp)
     vsd = V.make_synthetic_state_dict(V.SD3_VAE, 4242)
     dec = vae.VAEDecoder(vae.VAEConfig())
     dec.bind_state_dict({k: v.cuda() for k, v in vsd.items()})
@@ -314,7 +300,9 @@ def test_config_a_advantages_from_engine_images_match_the_oracle_pipeline(full):
     img_e = dec.decode(fin, postprocess=True, out_dtype=torch.bfloat16, max_batch=4).float().cpu()
     dec.close()
     with torch.no_grad():
-        img_o = V.vae_decode(vsd, V.SD3_VAE, ref["all_latents"][-1].float(), postprocess=True)          # fp32 oracle decode of the ORACLE's latents
+        # fp32 oracle decode of the ORACLE's latents -- on the host cores (eight 256^2 images: seconds; the GPU's fp32 convolutions would go
+        # through MIOpen's algorithm search)
+        img_o = V.vae_decode(vsd, V.SD3_VAE, ref["all_latents"][-1].float().cpu(), postprocess=True)
 
     # Stand-in rewards.  Round 4's two (mean pixel, mean of the red channel's upper half) have a spread over the batch of only ~27x the
     # engine-vs-oracle reward error, so a bound on |delta advantage| mostly measured their conditioning.  The two added
@@ -385,8 +373,7 @@ DEFAULT_SD35_TARGETS = ("attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj",
 
 def test_config_a_replay_gradients_vs_oracle_autograd(full):
     """SURVEY.md 8(f) N1 at the real geometry: the differentiable replay step on full SD3.5-medium (256^2, B = 1) -- grad-mode log-prob
-    bit-identical to the no-grad replay (ratio == 1), weight gradients of blocks 0 / 12 / 23 vs torch autograd through the fp32 oracle on
-    the host cores.  The trainable set is SD3_5Adapter.default_target_modules (reference sd3_5.py:75-80: the eight "attn.*" projections,
+    bit-identical to the no-grad replay (ratio == 1), weight gradients of blocks 0 / 12 / 23 vs torch autograd through the fp32 oracle (on the GPU, fp32).  The trainable set is SD3_5Adapter.default_target_modules (reference sd3_5.py:75-80: the eight "attn.*" projections,
     image AND text side, substring match of models/abc.py:1793) plus the attn2 projections of the dual blocks (the base class's set,
     models/abc.py:382-385, which the bench leg of rounds 2-4 trained)."""
     from mi355_flow.adapter import SD3_5NativeAdapter
@@ -396,7 +383,7 @@ def test_config_a_replay_gradients_vs_oracle_autograd(full):
     from oracle import mmditx_ref as M
     from test_gpu_backward import _cos, _inputs, _oracle_loss
     e, sd, cfg = full
-    mod = module_from_state_dict({k: v.clone().cuda() for k, v in sd.items()})          # fp32 master copy of the bf16-rounded values
+    mod = module_from_state_dict({k: v.float() for k, v in sd.items()})          # fp32 master copy of the bf16-rounded values
     picks = ("transformer_blocks.0.", "transformer_blocks.12.", "transformer_blocks.23.")
     for n, p in mod.named_parameters():
         p.requires_grad_(n.startswith(picks) and any(k in n for k in DEFAULT_SD35_TARGETS + (".attn2.to_q.", ".attn2.to_k.", ".attn2.to_v.",
@@ -424,13 +411,13 @@ def test_config_a_replay_gradients_vs_oracle_autograd(full):
         out = ad.forward(**kw)
         assert torch.equal(out.log_prob.detach(), ref.log_prob) and torch.equal(ref.log_prob, o0.log_prob)      # rollout == replay == grad replay
         out.log_prob.sum().backward()
-        lp_ref, g_ref = _oracle_loss(mod, cfg, inp, 1.0, t, t_next, eta, smax, 0.0)
+        lp_ref, g_ref = _oracle_loss(mod, cfg, inp, 1.0, t, t_next, eta, smax, 0.0, device="cuda")
         np.testing.assert_allclose(out.log_prob.detach().cpu().numpy(), lp_ref.numpy(), rtol=1e-3)
         # the band for GRADIENTS: the same oracle with bf16 round-trips where a bf16 module materialises a tensor -- autograd through
         # `x.to(bf16).float()` rounds the activation GRADIENT at the same points on the way back, which is what a bf16 autocast training run
         # computes (up to accumulation order) -- against its own fp32 self, per tensor.  The tolerance is DERIVED from it (3x the band + 5e-3),
         # like the forward's; the bare 6e-2 of rounds 2-3 stays only as an outer fence.
-        _, g_band = _oracle_loss(mod, cfg, inp, 1.0, t, t_next, eta, smax, 0.0, quant=M.bf16_round)
+        _, g_band = _oracle_loss(mod, cfg, inp, 1.0, t, t_next, eta, smax, 0.0, quant=M.bf16_round, device="cuda")
         # Tensors whose EXACT gradient is zero or numerically nothing (the text-side query projection of the context-pre-only last block,
         # whose output is discarded; biases the fp32 oracle itself only sees as rounding residue) carry no value to compare: a relative
         # error there is noise over noise.  They are checked for being small in absolute terms and kept out of "worst" (VERDICT r4 weak #4).
@@ -451,7 +438,7 @@ def test_config_a_replay_gradients_vs_oracle_autograd(full):
             worst_band, worst_q = max(worst_band, band), max(worst_q, rq)
             # VALUE: the best-fit scale of the engine's gradient on the oracle's (zero-mean rounding noise barely moves it; a wrong factor or a
             # missing term does) -- tests/test_gpu_wan_backward._compare_value
-            ge, gr = prm.grad.float().cpu().flatten().double(), g_ref[name].float().flatten().double()
+            ge, gr = prm.grad.float().cpu().flatten().double(), g_ref[name].float().cpu().flatten().double()
             alpha = float((ge @ gr) / (gr @ gr))
             if abs(alpha - 1) > worst_alpha:
                 worst_alpha, worst_alpha_name = abs(alpha - 1), name
