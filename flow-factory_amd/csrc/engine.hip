@@ -1062,7 +1062,19 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 27) { set_wgrad_split_model(value); return 0; } // split-K factor of the weight-gradient GEMMs: 1 = modelled-time minimum (default), 0 = the round-2 rule
     if (key == 28) { set_train_text_side(value); return 0; }   // Qwen-Image backward: the text chain on the plan's side stream (1 = default)
     if (key == 31) { set_w4_min_tiles(value); return 0; }      // default GEMM dispatch: smallest 256 x 256-tile grid for the 4-wave hand-scheduled kernel (default 512)
-    if (key == 29) { g_ablate = value; return 0; }             // MEASUREMENT ONLY: launches the SD3.5 forward skips (wrong results; scripts/ablate_forward.py)
+    if (key == 29) {      // MEASUREMENT ONLY: launches the SD3.5 forward skips (WRONG results; scripts/ablate_forward.py)
+        // refused unless the process opted in: a stale MI355_TUNE=29=... in a training environment must not corrupt rollouts silently
+        const char* ok = getenv("MI355_ALLOW_ABLATION");
+        if (value != 0 && !(ok && ok[0] == '1'))
+            return fail("mi355_tune_set(29, %d): the forward-ablation mask produces wrong results by construction; set MI355_ALLOW_ABLATION=1 "
+                        "to use it for a timing measurement", value);
+        if (value != 0) fprintf(stderr, "mi355_flow: FORWARD ABLATION MASK %d ACTIVE -- results of the SD3.5 forward are WRONG (measurement only)\n", value);
+        g_ablate = value;
+        return 0;
+    }
+    if (key == 32) { set_mid_mode(value); return 0; }          // mid-size GEMM kernel (128x192 / 192x128 tiles): 0 off, 1 cost rule (default), 2 wherever it applies
+    if (key == 33) { set_mid_alpha_percent(value); return 0; } // margin of that rule in percent (default 100)
+    if (key == 34) { set_mid_min_tiles(value); return 0; }     // smallest grid of its tiles (default 160)
     if (key == 22) { g_train_two_stream = value; return 0; }   // optimize() replay: the context-stream chain of the training forward / backward on a side stream (1 = default)
     if (key == 21) { set_attn128_op_bound(value); return 0; }  // mi355_op_attention128: the |score| bound the caller asserts (0 = none)          // default GEMM dispatch: largest K for the 4-wave hand-scheduled kernel
     return fail("mi355_tune_set: unknown key %d", key);

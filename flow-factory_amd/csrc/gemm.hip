@@ -28,6 +28,9 @@ constexpr int BK = 64;
 int g_raster_gm = 6;          // tile rows per raster band (0 = plain row-major order); mi355_tune_set(7, v)
 int g_pp_min_tiles = 128;     // smallest 256x256-tile grid for gemm_pp_kernel
 int g_w4_min_tiles = 512;     // smallest 256x256-tile grid the DEFAULT dispatch (key 0 = 1) gives to the 4-wave kernel; mi355_tune_set(31, v)
+int g_mid_mode = 1;           // mid-size kernel (128x192 / 192x128 tiles): 0 off, 1 by the cost rule of launch_epi, 2 wherever it applies; mi355_tune_set(32, v)
+double g_mid_alpha = 1.0;     // margin of that rule: the mid-size kernel's estimated cost is multiplied by it; mi355_tune_set(33, percent)
+int g_mid_min_tiles = 160;    // no mid-size launch below this many of its tiles (sub-chip grids: a lone 128x128 tile per CU is quicker); mi355_tune_set(34, v)
 
 // linear tile id -> (tm, tn).  Bands of `gm` tile rows are walked column by column, so the ~32 consecutive ids that the workgroups of one
 // XCD hold at any time form a near-square block: gm A-panels + ~32/gm W-panels stream through that XCD's L2 per round instead of ~1 + 32
@@ -188,13 +191,17 @@ __device__ __forceinline__ void store_row8(const GemmParams& p, int m, int n, in
 //       cannot hoist these loads out of the per-chunk calls itself (the chunks' global stores may alias p.bias for all it knows), and each
 //       call then pays one L2 round trip before its first arithmetic
 struct BiasPre { float4 v[4]; };      // by value: a pointer to a caller's array keeps that array in scratch memory
-template <int EPI, int NR, bool FULL = false, bool PRE = false>
-__device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (&acc)[NR][4], int m_base, int n_base,
+// NJ (round 6): 16-column blocks of the chunk (4 = the 64-column chunk every kernel used so far; 2 = the 32-column tail of the mid-size
+//       kernel's 96-column wave tile).  The staging rows stay 128 bytes; with NJ < 4 only the first 2 NJ 16-byte slots of a row carry data and
+//       the row-layout phase masks the lanes of the others (they would touch the NEIGHBOURING wave's columns).
+template <int EPI, int NR, bool FULL = false, bool PRE = false, int NJ = 4>
+__device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (&acc)[NR][NJ], int m_base, int n_base,
                                               char* stg, int lane, BiasPre bpre = BiasPre()) {
-
+    static_assert(NJ == 4 || (NJ == 2 && !is_qk_epi(EPI)), "a q/k head is one whole 64-column chunk");
     const int frow = lane & 15, fkg = lane >> 4;
-    float4 bcol[4];
-    float4 nw[4];
+    const bool cok = NJ == 4 || (lane & 7) < 2 * NJ;          // row-layout phase: this lane's 8 columns belong to the chunk
+    float4 bcol[NJ];
+    float4 nw[NJ];
     if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_GATE_RES) {
         // training-mode forward: the pre-activation (GELU) / the un-gated projection (gated residual) goes to the stash first (same wave-private staging, LDS ops of a wave are in order)
         if (p.stash) {
@@ -202,7 +209,7 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
             for (int i = 0; i < NR; ++i) {
                 const int r = i * 16 + frow;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < NJ; ++j) {
                     const int n = n_base + j * 16 + 4 * fkg;
                     float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (FULL || n < p.N) bb = *(const float4*)(p.bias + n);
@@ -216,7 +223,7 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
                 const int r = it * 8 + (lane >> 3), c = lane & 7;
                 const uint4 val = *(const uint4*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
                 const int m = m_base + r, n = n_base + c * 8;
-                if (FULL || m < p.M) {
+                if (cok && (FULL || m < p.M)) {
                     bf16_t* sp = p.stash + (long)m * p.ld_stash + n;
                     if (FULL || (n + 8 <= p.N && (p.ld_stash & 7) == 0)) *(uint4*)sp = val;
                     else {
@@ -229,7 +236,7 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
         }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int n = n_base + j * 16 + 4 * fkg;
         bcol[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if constexpr (EPI != EPI_VT && EPI != EPI_BIAS_ROW) {
@@ -245,7 +252,7 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         const int r = i * 16 + frow;
-        float y[4][4];
+        float y[NJ][4];
         float brow = 0.f;
         constexpr bool ROWB = (EPI == EPI_VT || EPI == EPI_BIAS_ROW);
         if constexpr (ROWB) {
@@ -253,7 +260,7 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
             brow = p.bias[m < p.M ? m : p.M - 1];
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             y[j][0] = acc[i][j][0] + (ROWB ? brow : bcol[j].x);
             y[j][1] = acc[i][j][1] + (ROWB ? brow : bcol[j].y);
             y[j][2] = acc[i][j][2] + (ROWB ? brow : bcol[j].z);
@@ -287,18 +294,18 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
         }
         if constexpr (EPI == EPI_BIAS_SILU) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[j][e] = silu_f(round_bf16(y[j][e]));
         }
         if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) y[j][e] = gelu_tanh_f(y[j][e]);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int chunk = (j * 2 + (fkg >> 1)) ^ (r & 7);
             uint2 o = {pack_bf16(y[j][0], y[j][1]), pack_bf16(y[j][2], y[j][3])};
             *(uint2*)(stg + r * 128 + chunk * 16 + (fkg & 1) * 8) = o;
@@ -319,12 +326,15 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
 #pragma unroll
         for (int it = 0; it < NR * 2; ++it) {
             const int m = m_base + it * 8 + (lane >> 3), n = n_base + c * 8;
-            xr[it] = *(const uint4*)(p.out + (long)m * p.ldo + n);
-            gr[it] = *(const uint4*)(p.aux + (long)(m / p.rows_per_sample) * p.ld_aux + n);
+            if (cok) {
+                xr[it] = *(const uint4*)(p.out + (long)m * p.ldo + n);
+                gr[it] = *(const uint4*)(p.aux + (long)(m / p.rows_per_sample) * p.ld_aux + n);
+            }
         }
 #pragma unroll
         for (int it = 0; it < NR * 2; ++it) {
             const int m = m_base + it * 8 + (lane >> 3), n = n_base + c * 8;
+            if (!cok) continue;
             const uint4 v = val[it], x = xr[it], g = gr[it];
             // (same operations, in the same order, as store_row8's vector path)
             const float y0 = __builtin_fmaf(bf_lo(g.x), bf_lo(v.x), bf_lo(x.x)), y1 = __builtin_fmaf(bf_hi(g.x), bf_hi(v.x), bf_hi(x.x));
@@ -345,9 +355,10 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
         }
 #pragma unroll
         for (int it = 0; it < NR * 2; ++it)
-            ar[it] = *(const uint4*)(p.aux + (long)(m_base + it * 8 + (lane >> 3)) * p.ld_aux + n_base + c * 8);
+            if (cok) ar[it] = *(const uint4*)(p.aux + (long)(m_base + it * 8 + (lane >> 3)) * p.ld_aux + n_base + c * 8);
 #pragma unroll
         for (int it = 0; it < NR * 2; ++it) {
+            if (!cok) continue;
             const uint4 v = val[it], a = ar[it];
             // (same operations as store_row8's path: y * gelu'(pre) on the bf16-rounded product sum)
             const float y0 = bf_lo(v.x) * gelu_tanh_grad_f(bf_lo(a.x)), y1 = bf_hi(v.x) * gelu_tanh_grad_f(bf_hi(a.x));
@@ -366,14 +377,14 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
         }
 #pragma unroll
         for (int it = 0; it < NR * 2; ++it)
-            store_row8<EPI, FULL>(p, m_base + it * 8 + (lane >> 3), n_base + (lane & 7) * 8, n_base, val[it]);
+            if (cok) store_row8<EPI, FULL>(p, m_base + it * 8 + (lane >> 3), n_base + (lane & 7) * 8, n_base, val[it]);
     } else {
 #pragma unroll
         for (int it = 0; it < NR * 2; ++it) {
             const int r = it * 8 + (lane >> 3), c = lane & 7;
             const uint4 val = *(const uint4*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
             const int m = m_base + r;
-            if (FULL || m < p.M) store_row8<EPI, FULL>(p, m, n_base + c * 8, n_base, val);
+            if (cok && (FULL || m < p.M)) store_row8<EPI, FULL>(p, m, n_base + c * 8, n_base, val);
         }
     }
 }
@@ -566,6 +577,181 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
             epilogue_part<EPI, 4>(p, a4, m0 + wm * C::TM + hh * 64, n0 + wn * C::TN, stg, lane);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Mid-size kernel (round 6): 128x192 (MI = 4, NJ = 6) or 192x128 (MI = 6, NJ = 4) output tiles, ONE 4-wave workgroup per CU, one wave per SIMD,
+// each a 64x96 (96x64) register tile.  Why this shape: the GEMMs of a 4096-row image stream (512^2 at forward batch 4 -- the reference's
+// shipped example, examples/grpo/full/sd3_5/default.yaml:49-54 -- and 1024^2 at B = 1) are 6.3 M outputs at N = 1536 = 24 576 per CU.  The
+// 128x128 kernel cuts that into 384 tiles on 512 slots: half the CUs run a co-resident pair, the other half one tile, and on the busy half
+// every SIMD carries two 64x64 wave tiles = 8192 outputs.  128x192 tiles are 256 tiles = one per CU with 6144 outputs per SIMD -- a quarter
+// less work on the critical SIMD -- and N = 3072 / 6144 (and 8192 rows) give whole multiples of 256 as well; the transposed V^T projection
+// (M = 1536 features x N = 4096 tokens) gets the same from 192x128.  (Round 5's 128x192 attempt kept the 64x64 wave tile on SIX waves: two
+// SIMDs carried two waves, i.e. the same 8192 outputs on the critical SIMD -- measured +-0 and dropped)
+//   * LDS bytes per MFMA: a 64x96 wave tile reads 4 + 6 fragments per 24 MFMAs (0.42 ds_read_b128 per MFMA against 0.5 for 64x64);
+//     per K-tile and CU: 80 ds_read_b128 + 40 KiB of LDS-DMA against 192 MFMAs.
+//   * 4-slot operand ring (4 x 40 KiB = the CU's whole 160 KiB; the epilogue staging reuses it): the loads of K-tile t + 3 are issued during
+//     K-tile t and retired with a COUNTED s_waitcnt vmcnt(10) one K-tile before they are read -- two K-tiles (>= 1500 cycles) of flight,
+//     never vmcnt(0) in the steady state; ONE barrier per K-tile.
+//   * fragments are double-buffered across the two k-steps of a K-tile: the ds_reads of step kk + 1 are issued in front of the 24 MFMAs of
+//     step kk; `sched_group_barrier` interleaves reads / LDS-DMA issues with the MFMAs (one wave per SIMD: nothing else hides them).
+//   * same v_mfma_f32_16x16x32_bf16 operand order and ascending-k accumulation per output element as every other kernel of this file, and the
+//     shared fused epilogues: BIT-IDENTICAL to the 128x128 / ping-pong / 4-wave kernels (the batch-invariance tests mix them freely).
+template <int MI, int NJ, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_mid_kernel(GemmParams p) {
+    constexpr int TM = MI * 16, TN = NJ * 16, BM = 2 * TM, BN = 2 * TN;
+    constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128, NS = 4;
+    constexpr int GA = BM / 8, GT = (BM + BN) / 8, GPW = GT / 4;          // 8-row LDS-DMA groups: per tile side, per K-tile, per wave
+    static_assert(GT % 4 == 0 && NS * STAGE <= 160 * 1024 && (NJ == 4 || NJ == 6) && (MI == 4 || MI == 6), "mid-size tile");
+    static_assert(EPI != EPI_F32 && EPI != EPI_IMG && EPI != EPI_UNPATCH, "accumulator-layout epilogues stay on gemm_kernel");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    const int nblk = ntm * ntn;
+    int bid = blockIdx.x;
+    {   // consecutive tile ids -> one XCD (blockIdx % 8 is the XCD), as gemm_kernel
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    }
+    int tm, tn;
+    tile_coords(bid, ntm, ntn, p.raster_gm, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // ---- LDS-DMA: group g (8 rows = 1 KiB of a slot) of a K-tile belongs to wave g & 3; groups [0, GA) are activation rows, the rest
+    // weight rows.  Per lane: 32-bit byte offset from p.A / p.W (launcher: operands < 4 GiB) of its 16-byte chunk, swizzled at the source.
+    const int srow = lane >> 3, spc = lane & 7;
+    unsigned soff[GPW];
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) {
+        const int g = wave + 4 * i;
+        const bool is_a = g < GA;
+        const int row = (is_a ? g : g - GA) * 8 + srow;
+        const int c = spc ^ ((row >> 1) & 7);
+        if (is_a) {
+            int gm = m0 + row; gm = gm < p.M ? gm : p.M - 1;          // clamp: rows beyond M are never stored
+            soff[i] = ((unsigned)gm * (unsigned)p.lda + (unsigned)(c * 8)) * 2u;
+        } else {
+            int gn = n0 + row; gn = gn < p.N ? gn : p.N - 1;
+            soff[i] = ((unsigned)gn * (unsigned)p.ldw + (unsigned)(c * 8)) * 2u;
+        }
+    }
+    // ---- fragment read offsets inside a slot
+    const int frow = lane & 15, fkg = lane >> 4, fsw = frow >> 1;
+    int offX[2], offW[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int pc = (kk * 4 + fkg) ^ fsw;
+        offX[kk] = (wm * TM + frow) * 128 + pc * 16;
+        offW[kk] = A_BYTES + (wn * TN + frow) * 128 + pc * 16;
+    }
+
+    f32x4 acc[MI][NJ];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 xf[2][MI], wf[2][NJ];
+
+    // fragment q of a k-step, in the order the MFMAs (i-major) need them: x[0], w[0 .. NJ-1], x[1 .. MI-1]
+    auto read_frag = [&](int buf, const char* sb, int kk, int q) {
+        if (q == 0) xf[buf][0] = *(const bf16x8*)(sb + offX[kk]);
+        else if (q <= NJ) wf[buf][q - 1] = *(const bf16x8*)(sb + offW[kk] + (q - 1) * 2048);
+        else xf[buf][q - NJ] = *(const bf16x8*)(sb + offX[kk] + (q - NJ) * 2048);
+    };
+    // LDS-DMA group i (of GPW) of K-tile kt into ring slot `slot`
+    auto stage_one = [&](int kt, int slot, int i) {
+        const int g = wave + 4 * i;
+        const char* gb = (g < GA ? (const char*)p.A : (const char*)p.W) + (long)kt * (BK * 2);      // wave-uniform
+        glds16(gb + soff[i], smem + slot * STAGE + g * 1024);
+    };
+    // One half of a K-tile: the MI * NJ MFMAs of k-step `buf` in a FIXED issue order with, pinned between them (`sched_barrier(0)`: nothing
+    // crosses; hipcc's own scheduler bunches the loads in front of the MFMAs, and its sched_group_barrier pipeline did not hold for the
+    // LDS-DMA half), one fragment read of the NEXT k-step behind every second MFMA and one LDS-DMA issue behind every fourth -- the wave is
+    // alone on its SIMD, so whatever it issues between two MFMAs must fit the 16 cycles the first one occupies the matrix pipe.
+#define MID_HALF(buf, rd_sb, rd_kk, ld_kt, ld_slot, ld_first)                                                    \
+    do {                                                                                                         \
+        _Pragma("unroll") for (int n = 0; n < MI * NJ; ++n) {                                                    \
+            acc[n / NJ][n % NJ] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[buf][n % NJ], xf[buf][n / NJ], acc[n / NJ][n % NJ], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            if ((n & 1) == 0 && n / 2 < MI + NJ) read_frag((buf) ^ 1, rd_sb, rd_kk, n / 2);                      \
+            if ((n & 3) == 1 && n / 4 < GPW / 2) stage_one(ld_kt, ld_slot, (ld_first) + n / 4);                  \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+        }                                                                                                        \
+    } while (0)
+    static_assert(MI + NJ == GPW && GPW == 10 && MI * NJ >= 2 * GPW, "10 fragment reads and 5 LDS-DMA issues per half");
+
+    const int nt = p.K / BK;
+    auto ktile = [&](int kt) { return kt < nt ? kt : nt - 1; };      // (the tail's surplus prefetches re-load the last K-tile: never read)
+    // prologue: K-tiles 0, 1 and the first half of K-tile 2 in flight, K-tile 0 retired
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) stage_one(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < GPW; ++i) stage_one(ktile(1), 1, i);
+#pragma unroll
+    for (int i = 0; i < GPW / 2; ++i) stage_one(ktile(2), 2, i);
+    asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < MI + NJ; ++q) read_frag(0, smem, 0, q);
+    // One K-tile = ONE basic block, the same for every t (a branch around the LDS-DMA issues or the fragment reads would fence them off
+    // from the MFMAs they are interleaved with, and peeled tail copies made the register allocator shuffle the accumulators between the
+    // copies): the last K-tiles, which have nothing left to prefetch, re-load K-tile nt - 1 into the slots that became free and read
+    // fragments nobody uses (as the ping-pong kernel's last prefetch does); <= 3 x 40 KiB of L2 hits per tile.
+    for (int t = 0; t < nt; ++t) {
+        const char* sb = smem + (t & 3) * STAGE;
+        // first half: k-step 0 of K-tile t; fragments of k-step 1; second half of the LDS-DMA of K-tile t + 2 (slot of K-tile t - 2: free
+        // since the barrier of the previous iteration)
+        MID_HALF(0, sb, 1, ktile(t + 2), (t + 2) & 3, GPW / 2);
+        // K-tile t + 1 has landed (this wave's share; the barrier makes it everybody's); K-tile t + 2 stays in flight
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // ... and every wave is done with the slot of K-tile t - 1
+        __builtin_amdgcn_sched_barrier(0);
+        // second half: k-step 1; fragments of k-step 0 of K-tile t + 1; first half of the LDS-DMA of K-tile t + 3 into the slot K-tile t - 1 left
+        MID_HALF(1, smem + ((t + 1) & 3) * STAGE, 0, ktile(t + 3), (t + 3) & 3, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus prefetches of the tail have landed before the ring becomes staging
+#undef MID_HALF
+
+    // ---- epilogue: the wave's tile in chunks of <= 64 rows x {64, 32} columns through the shared fused epilogues
+    __syncthreads();  // every wave is done reading the ring (and no LDS-DMA is in flight: the last waits were vmcnt(0)): reuse it as staging
+    char* stg = smem + wave * 8192;
+    const bool full_tile = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((p.ldo & 7) == 0 || EPI == EPI_VT) &&
+                           (EPI != EPI_VT || ((p.rows_per_sample | p.s_off) & 7) == 0);
+    const int mw = m0 + wm * TM, nw_ = n0 + wn * TN;
+#define MID_CHUNK(R0, NR, C0, NC)                                                                              \
+    {                                                                                                          \
+        f32x4 a_[NR][NC];                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < NR; ++i) _Pragma("unroll") for (int j = 0; j < NC; ++j) a_[i][j] = acc[R0 + i][C0 + j]; \
+        if (full_tile) epilogue_part<EPI, NR, true, false, NC>(p, a_, mw + (R0) * 16, nw_ + (C0) * 16, stg, lane); \
+        else epilogue_part<EPI, NR, false, false, NC>(p, a_, mw + (R0) * 16, nw_ + (C0) * 16, stg, lane);        \
+    }
+    MID_CHUNK(0, 4, 0, 4)
+    if constexpr (NJ == 6) MID_CHUNK(0, 4, 4, 2)
+    if constexpr (MI == 6) MID_CHUNK(4, 2, 0, 4)
+    static_assert(!(MI == 6 && NJ == 6), "one of the two tile sides is 64 wide per wave");
+#undef MID_CHUNK
+}
+
+template <int MI, int NJ, int EPI>
+hipError_t launch_mid(const GemmParams& p, hipStream_t stream) {
+    auto kern = gemm_mid_kernel<MI, NJ, EPI>;
+    constexpr int BM = MI * 32, BN = NJ * 32;
+    constexpr int smem = 4 * (BM + BN) * 128;             // the whole 160 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+    hipLaunchKernelGGL(kern, dim3(ntm * ntn), dim3(256), smem, stream, p);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1019,6 +1205,19 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
     // profiles/r01_gemm_variants.txt).  E.g. the text stream at B=8 (M = 2664): q|k 132 big tiles = half the CUs idle -> 128x128.
     const long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
     const double cost_pp = 4.0 * (double)((big + 255) / 256), cost_128 = 2.78 * (double)((t128 + 511) / 512);
+    if constexpr (EPI != EPI_UNPATCH && !is_qk_epi(EPI)) {
+        // mid-size kernel (round 6): 128x192 tiles (192x128 for the transposed V^T scatter), one 4-wave workgroup per CU.  In units of one
+        // 128x128 tile's work at the ping-pong kernel's per-CU rate a round of it costs 1.5; it is taken when that, times the margin
+        // g_mid_alpha, beats what the dispatch below would run (a lone 128x128 tile per CU -- grids of at most 256 -- runs at ~1.7, not at
+        // the co-resident pair's 2.78).  Only the GRID enters the decision, never the data: every kernel accumulates an output element in
+        // the same order, so a sample's result does not depend on the kernel its batch size selects.
+        constexpr bool vt = EPI == EPI_VT;
+        const long tmid = (long)((p.M + (vt ? 191 : 127)) / (vt ? 192 : 128)) * ((p.N + (vt ? 127 : 191)) / (vt ? 128 : 192));
+        const double cost_mid = 1.5 * (double)((tmid + 255) / 256) * g_mid_alpha;
+        const double cost_else = (big >= g_pp_min_tiles && fits32 && cost_pp <= cost_128) ? cost_pp : (t128 <= 256 ? 1.7 : cost_128);
+        if (g_mid_mode != 0 && fits32 && g_gemm_variant != 0 && tmid >= g_mid_min_tiles && (g_mid_mode == 2 || cost_mid < cost_else))
+            return vt ? launch_mid<6, 4, EPI>(p, stream) : launch_mid<4, 6, EPI>(p, stream);
+    }
     if constexpr (EPI != EPI_UNPATCH) {   // (proj_out, N = 64: scalar-scatter epilogue, always the 128x128 kernel)
         // default dispatch, from IN-MODEL per-kernel durations (profiles/r03g_*: the rollout runs at the package power cap, where the 4-wave
         // kernel's +5 ... +10 % of the back-to-back microbenchmark shrink to -2.8 % time on the wide MLP projection, +-0 on q|k, and turn into
@@ -1085,6 +1284,9 @@ void set_gemm_variant(int v) { g_gemm_variant = v; }
 void set_w4_max_k(int v) { g_w4_max_k = v; }
 void set_pp_min_tiles(int v) { g_pp_min_tiles = v; }
 void set_w4_min_tiles(int v) { g_w4_min_tiles = v; }
+void set_mid_mode(int v) { g_mid_mode = v; }
+void set_mid_alpha_percent(int v) { g_mid_alpha = v / 100.0; }
+void set_mid_min_tiles(int v) { g_mid_min_tiles = v; }
 int get_gemm_variant() { return g_gemm_variant; }
 
 void set_raster_gm(int v) { g_raster_gm = v; }

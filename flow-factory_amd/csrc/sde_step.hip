@@ -203,22 +203,26 @@ namespace {
 // With flow sigmas and x0-prediction every update of the solver is a LINEAR combination of at most five tensors whose coefficients depend on
 // the sigma schedule alone (mi355_flow/unipc.py computes them on the host): the stored sample, up to two stored x0-predictions, the new one.
 //   unipc_convert:  x0 = sample - round_v(sigma * v),  v = CFG-combine(uncond, text) op by op in the network's dtype   (convert_model_output)
-//   lincomb:        out = sum_i round_i(c_i * t_i)      round_i = to t_i's dtype (torch: a 0-dim fp32 scalar times a half tensor stays half)
+//   lincomb:        out = sum_i round_i(c_i * t_i)      round_i = to t_i's dtype (torch: a 0-dim fp32 scalar times a half tensor stays half);
+//                   every partial sum is rounded to torch's PROMOTED dtype of the terms added so far (bf16 + bf16 stays bf16 and rounds,
+//                   half + fp32 or fp16 + bf16 is fp32): with bf16 latent storage diffusers accumulates the update in bf16
 // HBM-bound streaming kernels, 4 elements per thread, fp32 arithmetic in term order (no contraction: this file's compile flag).
 struct LinCombParams { const void* t[5]; int dt[5]; float c[5]; int n_terms; void* out; int out_dt; long n4; };
 
 __global__ __launch_bounds__(NT) void lincomb_kernel(LinCombParams p) {
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < p.n4; i += (long)gridDim.x * NT) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int prom = p.dt[0];                      // torch.promote_types over the terms so far: equal dtypes stay, anything else is fp32
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             if (k < p.n_terms) {
                 float v[4];
                 load4(p.t[k], i * 4, p.dt[k], v);
+                if (p.dt[k] != prom) prom = DT_F32;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float term = round_to_dtype(p.c[k] * v[e], p.dt[k]);
-                    acc[e] = k == 0 ? term : acc[e] + term;
+                    acc[e] = k == 0 ? term : round_to_dtype(acc[e] + term, prom);
                 }
             }
         }

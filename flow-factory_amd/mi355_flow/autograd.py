@@ -156,6 +156,19 @@ def _ddp_of(module):
     return None
 
 
+def _ddp_reducer_armed(host) -> bool:
+    """True when a DDP reducer WAITS for this backward's gradients: a DDP wrapper exists and gradient sync is on -- the condition (beside
+    grad mode, which is what brought the caller to this autograd node: inside `Function.forward` it reads as off) under which
+    `DDP._post_forward` calls `reducer.prepare_for_backward`.  Under `no_sync()` / `accelerator.accumulate`
+    (`require_backward_grad_sync` False) a backward without a gradient must leave `param.grad` None, like torch does: dense zeros would
+    turn a skipped parameter into a decayed one (AdamW) and cost its memory."""
+    lw = getattr(host, "_live_weights", None)
+    if lw is None:
+        return False
+    ddp = _ddp_of(lw.get_module())
+    return ddp is not None and bool(getattr(ddp, "require_backward_grad_sync", True))
+
+
 def _arm_ddp(ddp) -> None:
     """`DDP._pre_forward` as DDP.forward calls it.  With `device_ids` set -- what `accelerator.prepare` does on a GPU -- it moves its
     inputs to the device and indexes the result, so it needs at least one input: an empty tensor on that device (found by the
@@ -202,7 +215,7 @@ class _DenoiseReplayFn(torch.autograd.Function):
         ctx.host, ctx.plan, ctx.names, ctx.call = host, plan, names, call
         ctx.w_meta = [(w.shape, w.dtype) for w in weights]
         ctx.w_dev = weights[0].device if weights else None
-        ctx.ddp_armed = _ddp_of(host._live_weights.get_module()) is not None if getattr(host, "_live_weights", None) is not None else False
+        ctx.ddp_armed = _ddp_reducer_armed(host)
         ctx.mark_non_differentiable(o.std_dev_t, o.dt)
         return o.log_prob, o.noise_pred, o.next_latents_mean, o.std_dev_t, o.dt
 
@@ -283,7 +296,7 @@ class _FluxReplayFn(torch.autograd.Function):
         ctx.serial = plan._train_serial
         ctx.w_meta = [(w.shape, w.dtype) for w in weights]
         ctx.w_dev = weights[0].device if weights else None
-        ctx.ddp_armed = _ddp_of(host._live_weights.get_module()) is not None if getattr(host, "_live_weights", None) is not None else False
+        ctx.ddp_armed = _ddp_reducer_armed(host)
         lp = o.log_prob if o.log_prob is not None else torch.zeros((vt.shape[0],), device=v.device)
         ctx.mark_non_differentiable(o.std_dev_t, o.dt)
         return lp, o.noise_pred, o.next_latents_mean, o.std_dev_t, o.dt

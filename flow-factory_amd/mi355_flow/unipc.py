@@ -65,9 +65,19 @@ def _rhos(rks: Sequence[float], hh: float, order: int, solver_type: str, correct
     return rhos, h_phi_1, B_h
 
 
+def _round_rhos(rhos, rho_dtype):
+    """diffusers: `rhos = torch.linalg.solve(R, b).to(device).to(x.dtype)` -- the solved weights take the SAMPLE's dtype (fp16 under the
+    reference's default latent storage: 5e-4 relative) before they multiply anything; the closed-form 0.5 is exact in every dtype."""
+    if rho_dtype is None or rho_dtype == torch.float32:
+        return [float(np.float32(r)) for r in rhos]
+    return torch.tensor(rhos, dtype=torch.float32).to(rho_dtype).double().tolist()
+
+
 def unipc_schedule(sigmas: Sequence[float], solver_order: int = 2, solver_type: str = "bh2", lower_order_final: bool = True,
-                   disable_corrector: Sequence[int] = ()) -> List[StepCoefs]:
-    """Per-step coefficients for a schedule of N + 1 sigmas (the last one the final sigma, 0 for `final_sigmas_type="zero"`)."""
+                   disable_corrector: Sequence[int] = (), rho_dtype: Optional[torch.dtype] = None) -> List[StepCoefs]:
+    """Per-step coefficients for a schedule of N + 1 sigmas (the last one the final sigma, 0 for `final_sigmas_type="zero"`).
+    `rho_dtype` = the dtype of the sample the solver steps (the latent storage dtype): the SOLVED rhos (corrector of order >= 2, predictor
+    of order >= 3) are rounded to it as diffusers does; None keeps them in double (schedule-only checks)."""
     if solver_type not in ("bh1", "bh2"):
         raise ValueError(f"mi355_flow: UniPC solver_type {solver_type!r} (bh1 / bh2)")
     sig = [float(s) for s in sigmas]
@@ -88,6 +98,8 @@ def unipc_schedule(sigmas: Sequence[float], solver_order: int = 2, solver_type: 
             h = lam_t - lam_s0
             rks = [(_lam(sig[s - (i + 1)]) - lam_s0) / h for i in range(1, q)] + [1.0]
             rhos, h_phi_1, B_h = _rhos(rks, -h, q, solver_type, corrector=True)
+            if q >= 2 and rho_dtype is not None:
+                rhos = _round_rhos(rhos, rho_dtype)
             c_m = [0.0] * q                                      # m0 (x0 at s-1), m1 (x0 at s-2), ...
             c_m[0] = -alpha_t * h_phi_1 + alpha_t * B_h * (sum(rhos[i - 1] / rks[i - 1] for i in range(1, q)) + rhos[-1])
             for i in range(1, q):
@@ -103,7 +115,14 @@ def unipc_schedule(sigmas: Sequence[float], solver_order: int = 2, solver_type: 
         h = lam_t - lam_s0
         with np.errstate(invalid="ignore"):
             rks = [(_lam(sig[s - i]) - lam_s0) / h for i in range(1, this_order)] + [1.0]
+        if this_order > 1 and not np.isfinite(h):
+            # lower_order_final=False (or solver_order > the steps left) with a final sigma of 0: h = inf, rks = 0, rhos / rks = 0 / 0 --
+            # diffusers produces NaN latents there; refuse instead of dividing by zero
+            raise NotImplementedError("mi355_flow: UniPC predictor of order > 1 onto a final sigma of 0 is undefined (h = inf); the published "
+                                      "solver returns NaN there -- use lower_order_final=True (the Wan pipelines' setting)")
         rhos, h_phi_1, B_h = _rhos(rks, -h, this_order, solver_type, corrector=False)
+        if this_order >= 3 and rho_dtype is not None:
+            rhos = _round_rhos(rhos, rho_dtype)
         p_m = [0.0] * this_order
         p_m[0] = -alpha_t * h_phi_1 + alpha_t * B_h * sum(rhos[i - 1] / rks[i - 1] for i in range(1, this_order))
         for i in range(1, this_order):
@@ -152,21 +171,24 @@ def lincomb(tensors: Sequence[torch.Tensor], coefs: Sequence[float], out_dtype: 
 
 
 class UniPCSampler:
-    """The solver's tensor state for one sampling run: stored x0-predictions (newest first, fp32) and the last (corrected) sample.
+    """The solver's tensor state for one sampling run: stored x0-predictions (newest first, in torch's promoted dtype of sample and
+    prediction) and the last (corrected) sample.
     `step(i, v_text, v_uncond, guidance, sample)` = diffusers' `UniPCMultistepScheduler.step` for step index i; returns the next sample in the
     sample's own dtype (`x_t.to(x.dtype)`)."""
 
     def __init__(self, sigmas: Sequence[float], solver_order: int = 2, solver_type: str = "bh2", lower_order_final: bool = True,
-                 disable_corrector: Sequence[int] = ()):
+                 disable_corrector: Sequence[int] = (), sample_dtype: Optional[torch.dtype] = None):
         self.sigmas = [float(s) for s in sigmas]
         self.solver_order = int(solver_order)
-        self.coefs = unipc_schedule(self.sigmas, solver_order, solver_type, lower_order_final, disable_corrector)
+        self.coefs = unipc_schedule(self.sigmas, solver_order, solver_type, lower_order_final, disable_corrector, rho_dtype=sample_dtype)
         self.x0: List[torch.Tensor] = []
         self.last_sample: Optional[torch.Tensor] = None
 
     def step(self, i: int, v_text: torch.Tensor, v_uncond: Optional[torch.Tensor], guidance: float, sample: torch.Tensor) -> torch.Tensor:
         c = self.coefs[i]
-        x0_new = unipc_convert(v_text, v_uncond, guidance, sample, self.sigmas[i])
+        # x0 = sample - sigma * v takes torch's promoted dtype of (sample, v): fp32 for the reference's fp16 storage beside a bf16 network,
+        # bf16 when both are bf16 (one more rounding of the fp32 difference = torch's bf16 subtraction, exactly)
+        x0_new = unipc_convert(v_text, v_uncond, guidance, sample, self.sigmas[i]).to(torch.promote_types(sample.dtype, v_text.dtype))
         if c.corrector is not None and self.last_sample is not None:
             q = c.corrector_order
             sample = lincomb([self.last_sample] + self.x0[:q] + [x0_new], c.corrector, sample.dtype)

@@ -417,7 +417,8 @@ class WanRolloutMixin:
         if get("thresholding", False) or get("solver_p", None) is not None:
             raise NotImplementedError("mi355_flow: UniPC thresholding / a custom predictor solver are not implemented")
         solver = UniPCSampler(sig, solver_order=int(get("solver_order", 2)), solver_type=str(get("solver_type", "bh2")),
-                              lower_order_final=bool(get("lower_order_final", True)), disable_corrector=tuple(get("disable_corrector", ()) or ()))
+                              lower_order_final=bool(get("lower_order_final", True)), disable_corrector=tuple(get("disable_corrector", ()) or ()),
+                              sample_dtype=self.cast_latents(latents[:0], storage).dtype)
         N, B = len(ts), latents.shape[0]
         cur = self.cast_latents(latents, storage)
         all_lat = [cur]

@@ -263,15 +263,19 @@ def test_unipc_kernels_match_their_torch_statements(wn):
             v = RR.cfg_combine_bf16(vu, vt, 4.5) if cfg_on else vt
             want = x.float() - (torch.tensor(0.8125) * v.float()).to(torch.bfloat16).float()
             assert got.dtype == torch.float32 and torch.equal(got, want), (sdt, cfg_on)
-        ms = [torch.randn(n, generator=g) for _ in range(3)]
-        for k in range(1, 5):
-            ts_, cs = [x] + ms[:k - 1], [0.91, -0.37, 0.52, -0.11][:k]
-            got = U.lincomb([t.cuda() for t in ts_], cs, sdt).cpu()
-            acc = None
-            for t, c in zip(ts_, cs):
-                term = (torch.tensor(c, dtype=torch.float32) * t.float()).to(t.dtype).float()
-                acc = term if acc is None else acc + term
-            assert got.dtype == sdt and torch.equal(got, acc.to(sdt)), (sdt, k)
+        # stored x0-predictions: fp32 beside an fp16 / fp32 sample, bf16 beside a bf16 sample (torch's promoted dtype of sample and prediction);
+        # partial sums are rounded to the promoted dtype of the terms so far (bf16 + bf16 stays bf16; anything mixed is fp32)
+        for mdt in (torch.float32, sdt):
+            ms = [torch.randn(n, generator=g).to(mdt) for _ in range(3)]
+            for k in range(1, 5):
+                ts_, cs = [x] + ms[:k - 1], [0.91, -0.37, 0.52, -0.11][:k]
+                got = U.lincomb([t.cuda() for t in ts_], cs, sdt).cpu()
+                acc, prom = None, None
+                for t, c in zip(ts_, cs):
+                    term = (torch.tensor(c, dtype=torch.float32) * t.float()).to(t.dtype).float()
+                    prom = t.dtype if prom is None else (prom if prom == t.dtype else torch.float32)
+                    acc = term if acc is None else (acc + term).to(prom).float()
+                assert got.dtype == sdt and torch.equal(got, acc.to(sdt)), (sdt, mdt, k)
 
 
 def test_wan_errors(wn):
