@@ -119,6 +119,52 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def ddp_optimize_leg(ddp, microstep, params, world, rank, device, iters=3, backend="nccl (RCCL)"):
+    """The policy-update collective of the north star, measured (world > 1 only): one `optimize()` micro-step -- grad-mode replay forward +
+    backward -- under `DistributedDataParallel` (reference: the trainable component is DDP-wrapped by `accelerator.prepare`,
+    trainers/loader.py:33, and the loss goes through `accelerator.backward`, trainers/grpo.py:326-330), timed twice per rank:
+    synchronising (the reducer all-reduces every bucket on the process group while the backward still produces the later gradients) and
+    inside `no_sync()` (the same backward, no collective).  Their difference is the all-reduce time the backward does NOT hide.  MAX over
+    ranks for both; the bytes are what one micro-step hands to the collective.  Every rank runs this; rank 0 gets the dict."""
+    import contextlib
+
+    def timed(ctx):
+        with ctx():
+            microstep()                                   # warm-up (first synchronising step also builds the buckets)
+        if device is not None:
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            with ctx():
+                microstep()
+        if device is not None:
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        for q in params:
+            q.grad = None
+        return dt
+    t_sync = timed(contextlib.nullcontext)
+    t_sync = timed(contextlib.nullcontext)                # (second pass: on the rebuilt, gradient-ready-ordered buckets)
+    t_nosync = timed(ddp.no_sync)
+    both = torch.tensor([t_sync, t_nosync], dtype=torch.float64, device=device if device is not None else "cpu")
+    allb = [torch.zeros_like(both) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allb, both)
+    else:
+        allb = [both]
+    per_rank = [[float(v) for v in b.tolist()] for b in allb]
+    n_bytes = sum(q.numel() * q.element_size() for q in params)
+    ms_sync, ms_nosync = max(r[0] for r in per_rank) * 1e3, max(r[1] for r in per_rank) * 1e3
+    return {"ms_per_microstep_allreduce": round(ms_sync, 3), "ms_per_microstep_no_sync": round(ms_nosync, 3),
+            "ms_exposed_allreduce": round(ms_sync - ms_nosync, 3), "bytes_reduced_per_microstep": int(n_bytes),
+            "trainable_tensors": len(params), "world_size": world, "backend": backend,
+            "per_rank_ms": [[round(v * 1e3, 3) for v in r] for r in per_rank],
+            "note": "one optimize() micro-step (grad-mode replay forward + native backward) under DistributedDataParallel; MAX over ranks; "
+                    "exposed = synchronising - no_sync() on the same backward; untimed w.r.t. `value`"}
+
+
 def dry_run(args, world, rank):
     """Launcher / aggregation self-test WITHOUT a GPU (tests/test_dist_gloo.py): same rendezvous, barriers, MAX-over-ranks timing,
     per-rank gather and JSON assembly as the real path, on the gloo backend with the rollout replaced by a sleep.  Not a measurement."""
@@ -146,8 +192,22 @@ def dry_run(args, world, rank):
         dist.all_gather(allt, tt)
         per_rank = [float(x.item()) for x in allt]
         elapsed = max(per_rank)
+    ddp_leg = None
+    if world > 1 and not args.no_ddp_step:
+        # the assembly of the `optimize_step_ddp` leg (wrapper, sync / no_sync timing, MAX over ranks, byte count) on gloo with a stand-in
+        # module -- what the real path runs around the engine's autograd node
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.Tanh(), torch.nn.Linear(128, 64))
+        wrapped = DDP(net)
+        xin = torch.randn(8, 64)
+
+        def microstep():
+            wrapped(xin).square().mean().backward()
+        ddp_leg = ddp_optimize_leg(wrapped, microstep, list(net.parameters()), world, rank, None, iters=2, backend="gloo")
     if rank == 0:
         print(json.dumps({
+            **({"optimize_step_ddp": ddp_leg} if ddp_leg is not None else {}),
             "metric": "denoise-steps/sec (whole node), SD3.5-medium 1024^2 GRPO rollout", "value": round(B * N * args.steps * world / elapsed, 3),
             "unit": "denoise-steps/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -185,6 +245,12 @@ def main():
                     help="skip the optimize()-replay leg (SURVEY.md 8(f) N1; scripts/train_bench.py in a subprocess, untimed w.r.t. `value`)")
     ap.add_argument("--no-families", action="store_true",
                     help="skip the (untimed w.r.t. `value`) FLUX.1-dev / Wan2.1 / Qwen-Image rollout legs (BASELINE.json configs[2..4]; subprocesses)")
+    ap.add_argument("--no-ddp-step", action="store_true",
+                    help="(--gpus > 1) skip the `optimize_step_ddp` leg: one optimize() micro-step under DistributedDataParallel on the RCCL group, "
+                         "synchronising vs no_sync() (the exposed gradient all-reduce time of the policy update)")
+    ap.add_argument("--ddp-step-world1", action="store_true",
+                    help="(--gpus 1) run the `optimize_step_ddp` leg on a world-size-1 RCCL group: communicator, reducer buckets and all-reduce "
+                         "kernels without a second peer -- a self-test of the leg on a 1-GPU box, not a scaling number")
     ap.add_argument("--no-graph", action="store_true", help="launch the rollout eagerly instead of replaying the hipGraph")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test without a GPU: gloo backend, the rollout replaced by a fixed sleep per micro-batch "
@@ -207,6 +273,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL over xGMI; the rollout itself needs no collective
+    elif args.ddp_step_world1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     from mi355_flow import _lib
     from mi355_flow.adapter import SD3_5NativeAdapter
@@ -638,11 +708,47 @@ def main():
         fam["note"] = ("real geometries (FLUX.1-dev 11.9 B, Wan2.1-T2V-1.3B, Qwen-Image 60 layers), synthetic weights / prompts, hipGraph / eager as each "
                        "engine ships; denoise-steps/s = samples x steps / wall; forward_frac vs 2.5 PFLOP/s on algorithmic matmul FLOPs")
         out["families"] = fam
+    if (world > 1 or args.ddp_step_world1) and not flux_mode and not args.no_ddp_step:
+        # north star: "gradient all-reduce on RCCL over xGMI for the policy update" -- every rank takes part; a failure on any rank is
+        # recorded (and keeps the headline line), never raised
+        leg = None
+        try:
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            from mi355_flow.weights import module_from_state_dict
+            del samples
+            torch.cuda.empty_cache()
+            mod = module_from_state_dict(synthetic_state_dict(cfg, device=dev, seed=1234))
+            targets = ("attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj", "attn.to_add_out",      # SD3_5Adapter.default_target_modules
+                       "attn.to_q", "attn.to_k", "attn.to_v", "attn.to_out.0")                           # (reference sd3_5.py:75-80)
+            for n_, q_ in mod.named_parameters():
+                q_.requires_grad_(any(k_ in n_ for k_ in targets))
+            wrapped = DDP(mod, device_ids=[local], broadcast_buffers=False)          # default 25 MiB buckets, like accelerate's
+            sched2 = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=1, seed=42, shift=3.0)
+            ad2 = SD3_5NativeAdapter(wrapped, cfg, sched2, latent_storage_dtype="fp16", device=dev)      # bound to the WRAPPED module, like the plugin
+            ad2.rollout()
+            sched2.set_timesteps(28)
+            b2, lat2 = 2, 1024 // 8
+            mk = lambda *sh: torch.randn(*sh, device=dev, generator=g)      # noqa: E731
+            kw2 = dict(t=sched2.timesteps[2].expand(b2), t_next=sched2.timesteps[3].expand(b2), latents=mk(b2, 16, lat2, lat2).half(),
+                       next_latents=mk(b2, 16, lat2, lat2).half(), prompt_embeds=mk(b2, N_TEXT, 4096).bfloat16(),
+                       pooled_prompt_embeds=mk(b2, 2048).bfloat16(), guidance_scale=1.0, noise_level=0.7, compute_log_prob=True,
+                       return_kwargs=["log_prob", "dt"])
+            ad2.train()
+
+            def microstep():
+                ad2.forward(**kw2).log_prob.sum().backward()
+            leg = ddp_optimize_leg(wrapped, microstep, [q_ for q_ in mod.parameters() if q_.requires_grad], world, rank, dev)
+            leg["shape"] = "SD3.5-medium, B = 2 per rank, 1024^2, the reference's default target modules"
+            ad2.engine.close()
+        except Exception as e:  # noqa: BLE001
+            leg = {"error": repr(e)}
+        if rank == 0:
+            out["optimize_step_ddp"] = leg
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and not flux_mode:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or (args.ddp_step_world1 and dist.is_initialized()):
         dist.barrier()
         dist.destroy_process_group()
 

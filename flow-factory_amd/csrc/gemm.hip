@@ -16,6 +16,7 @@
 //   * workgroup -> tile mapping is XCD-aware (8 XCDs, private L2 each): consecutive tiles of one
 //     activation row-panel stay on one XCD.
 #include "kernels.h"
+#include <type_traits>
 
 namespace mi355 {
 
@@ -30,6 +31,7 @@ int g_pp_min_tiles = 128;     // smallest 256x256-tile grid for gemm_pp_kernel
 int g_w4_min_tiles = 512;     // smallest 256x256-tile grid the DEFAULT dispatch (key 0 = 1) gives to the 4-wave kernel; mi355_tune_set(31, v)
 int g_mid_mode = 1;           // mid-size kernel (128x192 / 192x128 tiles): 0 off, 1 by the cost rule of launch_epi, 2 wherever it applies; mi355_tune_set(32, v)
 double g_mid_alpha = 1.0;     // margin of that rule: the mid-size kernel's estimated cost is multiplied by it; mi355_tune_set(33, percent)
+int g_mid_stagger = 1;        // mid-size kernel: per-wave staggered LDS-DMA issue slots (0 = all four waves issue behind the same MFMAs); mi355_tune_set(35, v)
 int g_mid_min_tiles = 160;    // no mid-size launch below this many of its tiles (sub-chip grids: a lone 128x128 tile per CU is quicker); mi355_tune_set(34, v)
 
 // linear tile id -> (tm, tn).  Bands of `gm` tile rows are walked column by column, so the ~32 consecutive ids that the workgroups of one
@@ -663,23 +665,29 @@ __global__ __launch_bounds__(256, 2) void gemm_mid_kernel(GemmParams p) {
         else if (q <= NJ) wf[buf][q - 1] = *(const bf16x8*)(sb + offW[kk] + (q - 1) * 2048);
         else xf[buf][q - NJ] = *(const bf16x8*)(sb + offX[kk] + (q - NJ) * 2048);
     };
-    // LDS-DMA group i (of GPW) of K-tile kt into ring slot `slot`
+    // LDS-DMA group i (of GPW) of K-tile kt into ring slot `slot`: SGPR base + 32-bit VGPR offset (hipcc's builtin forms a 64-bit address
+    // per lane with v_lshl_add_u64 in front of every load: twice the address bytes on the way to the texture-address unit)
+    const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem);
     auto stage_one = [&](int kt, int slot, int i) {
         const int g = wave + 4 * i;
         const char* gb = (g < GA ? (const char*)p.A : (const char*)p.W) + (long)kt * (BK * 2);      // wave-uniform
-        glds16(gb + soff[i], smem + slot * STAGE + g * 1024);
+        const unsigned dst = lds0 + slot * STAGE + g * 1024;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(dst), "v"(soff[i]), "s"(gb) : "memory");
     };
     // One half of a K-tile: the MI * NJ MFMAs of k-step `buf` in a FIXED issue order with, pinned between them (`sched_barrier(0)`: nothing
     // crosses; hipcc's own scheduler bunches the loads in front of the MFMAs, and its sched_group_barrier pipeline did not hold for the
     // LDS-DMA half), one fragment read of the NEXT k-step behind every second MFMA and one LDS-DMA issue behind every fourth -- the wave is
     // alone on its SIMD, so whatever it issues between two MFMAs must fit the 16 cycles the first one occupies the matrix pipe.
+    // PH (0 .. 3, = the wave's index): the four waves of the workgroup run in lockstep between barriers; with the SAME slots their LDS-DMA
+    // issues would reach the CU's one texture-address unit in the same cycle and each wave would sit out the other three's 1 KiB requests.
+    // Wave w issues behind MFMA 4 q + w instead: four copies of the loop, one per wave (the interleave has to be static).
 #define MID_HALF(buf, rd_sb, rd_kk, ld_kt, ld_slot, ld_first)                                                    \
     do {                                                                                                         \
         _Pragma("unroll") for (int n = 0; n < MI * NJ; ++n) {                                                    \
             acc[n / NJ][n % NJ] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[buf][n % NJ], xf[buf][n / NJ], acc[n / NJ][n % NJ], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
             if ((n & 1) == 0 && n / 2 < MI + NJ) read_frag((buf) ^ 1, rd_sb, rd_kk, n / 2);                      \
-            if ((n & 3) == 1 && n / 4 < GPW / 2) stage_one(ld_kt, ld_slot, (ld_first) + n / 4);                  \
+            if ((n & 3) == PH && n / 4 < GPW / 2) stage_one(ld_kt, ld_slot, (ld_first) + n / 4);                 \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
         }                                                                                                        \
     } while (0)
@@ -703,18 +711,26 @@ __global__ __launch_bounds__(256, 2) void gemm_mid_kernel(GemmParams p) {
     // from the MFMAs they are interleaved with, and peeled tail copies made the register allocator shuffle the accumulators between the
     // copies): the last K-tiles, which have nothing left to prefetch, re-load K-tile nt - 1 into the slots that became free and read
     // fragments nobody uses (as the ping-pong kernel's last prefetch does); <= 3 x 40 KiB of L2 hits per tile.
-    for (int t = 0; t < nt; ++t) {
-        const char* sb = smem + (t & 3) * STAGE;
-        // first half: k-step 0 of K-tile t; fragments of k-step 1; second half of the LDS-DMA of K-tile t + 2 (slot of K-tile t - 2: free
-        // since the barrier of the previous iteration)
-        MID_HALF(0, sb, 1, ktile(t + 2), (t + 2) & 3, GPW / 2);
-        // K-tile t + 1 has landed (this wave's share; the barrier makes it everybody's); K-tile t + 2 stays in flight
-        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // ... and every wave is done with the slot of K-tile t - 1
-        __builtin_amdgcn_sched_barrier(0);
-        // second half: k-step 1; fragments of k-step 0 of K-tile t + 1; first half of the LDS-DMA of K-tile t + 3 into the slot K-tile t - 1 left
-        MID_HALF(1, smem + ((t + 1) & 3) * STAGE, 0, ktile(t + 3), (t + 3) & 3, 0);
-    }
+    auto k_loop = [&](auto ph) {
+        constexpr int PH = decltype(ph)::value;
+        for (int t = 0; t < nt; ++t) {
+            const char* sb = smem + (t & 3) * STAGE;
+            // first half: k-step 0 of K-tile t; fragments of k-step 1; second half of the LDS-DMA of K-tile t + 2 (slot of K-tile t - 2:
+            // free since the barrier of the previous iteration)
+            MID_HALF(0, sb, 1, ktile(t + 2), (t + 2) & 3, GPW / 2);
+            // K-tile t + 1 has landed (this wave's share; the barrier makes it everybody's); K-tile t + 2 stays in flight
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // ... and every wave is done with the slot of K-tile t - 1
+            __builtin_amdgcn_sched_barrier(0);
+            // second half: k-step 1; fragments of k-step 0 of K-tile t + 1; first half of the LDS-DMA of K-tile t + 3 into the slot K-tile t - 1 left
+            MID_HALF(1, smem + ((t + 1) & 3) * STAGE, 0, ktile(t + 3), (t + 3) & 3, 0);
+        }
+    };
+    if (p.mid_stagger == 0) k_loop(std::integral_constant<int, 1>{});
+    else if (wave == 0) k_loop(std::integral_constant<int, 0>{});
+    else if (wave == 1) k_loop(std::integral_constant<int, 1>{});
+    else if (wave == 2) k_loop(std::integral_constant<int, 2>{});
+    else k_loop(std::integral_constant<int, 3>{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus prefetches of the tail have landed before the ring becomes staging
 #undef MID_HALF
 
@@ -1287,6 +1303,7 @@ void set_w4_min_tiles(int v) { g_w4_min_tiles = v; }
 void set_mid_mode(int v) { g_mid_mode = v; }
 void set_mid_alpha_percent(int v) { g_mid_alpha = v / 100.0; }
 void set_mid_min_tiles(int v) { g_mid_min_tiles = v; }
+void set_mid_stagger(int v) { g_mid_stagger = v; }
 int get_gemm_variant() { return g_gemm_variant; }
 
 void set_raster_gm(int v) { g_raster_gm = v; }
@@ -1340,6 +1357,7 @@ static void trace_gemm(const GemmParams& p, hipStream_t stream) {
 hipError_t launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.raster_gm = g_raster_gm;
+    p.mid_stagger = g_mid_stagger;
     if (sched_trace_on()) trace_gemm(p, stream);
     if (p.K % BK != 0 || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;
     if (p.conv_cin > 0) {

@@ -70,6 +70,7 @@ struct GemmParams {
     // [s*nt/k_split, (s+1)*nt/k_split) into out_f32 + s * split_stride (deterministic second-stage reduction by the caller)
     int k_split; long split_stride;
     int raster_gm;            // tile rows per raster band (set by launch_gemm from the global knob)
+    int mid_stagger;          // mid-size kernel: 1 = per-wave staggered LDS-DMA issue slots (set by launch_gemm from the global knob, key 35)
     // optional s_memtime trace (debug): per workgroup, per tile 4 stamps {tile start, main loop start, main loop end, epilogue end}
     long long* trace;
     int dbg_skip_prefetch;    // debug ablation: the K-loop prefetches are not issued (results are garbage)
@@ -102,6 +103,7 @@ void set_w4_min_tiles(int v);
 void set_mid_mode(int v);
 void set_mid_alpha_percent(int v);
 void set_mid_min_tiles(int v);
+void set_mid_stagger(int v);
 void set_raster_gm(int v);      // GEMM tile raster: tile rows per band (0 = row-major)
 void set_conv_cfg(int v);       // VAE conv tile shape A/B knob (0 auto)
 void set_attn_variant(int v);  // 0 = plain online softmax, 1 = deferred-rescale (default)

@@ -28,6 +28,9 @@ bad = 0
 shapes = [(4096, 1536, 1536), (4096, 1536, 6144), (4096, 6144, 1536), (4096, 3072, 1536), (8192, 1536, 1536), (8192, 1536, 6144), (8192, 6144, 1536),
           (16384, 1536, 1536), (16384, 1536, 6144), (32768, 1536, 1536), (32768, 1536, 6144), (2664, 1536, 1536), (1332, 1536, 6144), (2048, 1536, 1536),
           (4096 + 77, 1536 + 8, 1536), (333, 1536, 1536), (130, 200, 64), (4096, 1536, 64), (4096, 1536, 128), (4096, 1536, 192)]
+if os.environ.get("MID_AB_SHORT") == "1":
+    shapes = [(4096, 1536, 1536), (4096, 1536, 6144), (4096, 6144, 1536), (8192, 1536, 1536), (8192, 1536, 6144), (2664, 1536, 1536), (1332, 1536, 6144),
+              (4096 + 77, 1536 + 8, 1536)]
 for (M, N, K) in shapes:
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
@@ -65,7 +68,7 @@ cfg = engine.TransformerConfig()
 e = engine.Engine(cfg)
 e.bind_state_dict(synthetic_state_dict(cfg, device="cuda", seed=1234, dtype=torch.bfloat16))
 e.ready()
-for (B, hw) in ((4, 64), (1, 128), (2, 128), (8, 64)):
+for (B, hw) in (((4, 64), (1, 128)) if os.environ.get("MID_AB_SHORT") == "1" else ((4, 64), (1, 128), (2, 128), (8, 64))):
     g = torch.Generator(device="cuda").manual_seed(B * hw)
     xl = torch.randn(B, 16, hw, hw, device="cuda", generator=g).half()
     pe = torch.randn(B, 333, 4096, device="cuda", generator=g).bfloat16()

@@ -82,6 +82,34 @@ def test_bench_self_launches_n_ranks_and_aggregates():
     wall = j["ms_per_step"] * 1e-3 * 2
     assert wall >= 0.05 * 2 * 2 * 0.99                    # the slow rank (2 x 0.1 s) bounds the job: MAX over ranks
     assert abs(j["value"] - 4 * 10 * 2 * 2 / wall) < 0.02 * j["value"]      # whole-job aggregate over both ranks
+    # the policy-update leg: one optimize() micro-step under DistributedDataParallel, synchronising vs no_sync(), MAX over
+    # ranks, bytes handed to the collective -- assembled here on gloo around a stand-in module; the real path wraps the SD3.5 module bound to
+    # the engine (bench.py: `optimize_step_ddp`, world > 1 only)
+    leg = j["optimize_step_ddp"]
+    assert leg["world_size"] == 2 and leg["backend"] == "gloo" and len(leg["per_rank_ms"]) == 2 and all(len(r) == 2 for r in leg["per_rank_ms"])
+    assert leg["bytes_reduced_per_microstep"] == 4 * (64 * 128 + 128 + 128 * 64 + 64) and leg["trainable_tensors"] == 4
+    assert leg["ms_per_microstep_allreduce"] > 0 and leg["ms_per_microstep_no_sync"] > 0
+    assert abs(leg["ms_exposed_allreduce"] - (leg["ms_per_microstep_allreduce"] - leg["ms_per_microstep_no_sync"])) < 2e-3
+    assert leg["ms_per_microstep_allreduce"] == max(r[0] for r in leg["per_rank_ms"])
+
+
+def test_bench_single_rank_line_has_no_ddp_leg():
+    """N = 1: no process group, no collective -- the leg must not appear (and `--no-ddp-step` removes it at N > 1)."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--dry-run"], capture_output=True, text=True,
+                       timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "optimize_step_ddp" not in json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run", "--no-ddp-step"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "optimize_step_ddp" not in json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
 
 
 def _ddp_worker(rank, world, port, out_dir):
