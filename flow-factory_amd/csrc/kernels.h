@@ -104,6 +104,8 @@ void set_mid_mode(int v);
 void set_mid_alpha_percent(int v);
 void set_mid_min_tiles(int v);
 void set_mid_stagger(int v);
+void set_mid_mask(int v);
+void set_mid_max_tiles(int v);
 void set_raster_gm(int v);      // GEMM tile raster: tile rows per band (0 = row-major)
 void set_conv_cfg(int v);       // VAE conv tile shape A/B knob (0 auto)
 void set_attn_variant(int v);  // 0 = plain online softmax, 1 = deferred-rescale (default)

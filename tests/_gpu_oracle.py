@@ -62,3 +62,39 @@ def ulp_fraction(got: torch.Tensor, ref: torch.Tensor, dtype: torch.dtype, n_ulp
     e = torch.floor(torch.log2(r.abs().clamp_min(tiny)))
     ulp = torch.exp2(e - mant)
     return float(((g - r).abs() <= n_ulp * ulp).float().mean())
+
+
+def oracle_loss_on(device, fn, mod, cfg_o, inp, *a, **kw):
+    """Run a test module's `_oracle_loss_impl(mod, cfg_o, inp, ...)` (autograd through the fp32 oracle) on the host cores (`device="cpu"`) or on
+    the GPU in fp32 (`"cuda"`: the inputs are moved, factories default to the GPU, MATH attention; the implementation builds its weight leaves
+    on `inp["x"].device`).  Returns (log_prob on the host, {name: gradient})."""
+    if device == "cpu":
+        return fn(mod, cfg_o, inp, *a, **kw)
+    with on_gpu(grad=True):
+        lp, gr = fn(mod, cfg_o, cuda(dict(inp)), *a, **kw)
+    return lp.cpu(), gr
+
+
+def bf16_round(x):
+    return x.to(torch.bfloat16).float()
+
+
+def ref_on_gpu(fn, *args, **kw):
+    """`fn(*args, **kw)` with every tensor / dict of tensors among the arguments moved to the GPU, under `on_gpu()`; the result stays there."""
+    with on_gpu():
+        return fn(*[cuda(a) for a in args], **{k: cuda(v) for k, v in kw.items()})
+
+
+def check_in_band(name, got, oracle_fn, *args, factor=1.5, floor=1e-3, **kw):
+    """The parity statement every full-width forward test makes since round 6: the engine's output `got` is no further
+    from the fp32 oracle than `factor` x the BAND + `floor`, the band being the same oracle with a bf16 round-trip wherever the reference's bf16
+    module materialises a tensor (`quant=bf16_round`) against its own fp32 self -- both oracle runs on the GPU in fp32.  Measured everywhere so
+    far: engine = 1.0 x band.  Returns (ref, refq, rel-L2 to fp32, band)."""
+    ref = ref_on_gpu(oracle_fn, *args, **kw)
+    refq = ref_on_gpu(oracle_fn, *args, quant=bf16_round, **kw)
+    band, r = rel(refq, ref), rel(got, ref)
+    print(f"{name}: engine vs fp32 oracle {r:.3e}; bf16-emulating oracle vs fp32 (band) {band:.3e} ({r / max(band, 1e-30):.2f} x band); "
+          f"engine vs bf16-emulating {rel(got, refq):.3e}")
+    assert torch.isfinite(got.float()).all(), name
+    assert r < factor * band + floor, (name, r, band)
+    return ref, refq, r, band

@@ -175,10 +175,10 @@ def test_flux_full_width_blocks_large_grid_dispatch(fx):
     tm = torch.tensor([875.0, 600.0, 310.5, 48.0])
     gm = torch.full((B,), 3500.0)
     plan = eng.plan(B, h, w, Nt, 1)
-    got = plan.transformer_forward(x.cuda(), tm, gm, enc.cuda(), pool.cuda()).float().cpu()
-    ref = R.flux_forward(sd, cfg_o, x.float(), tm, gm, pool, enc, R.prepare_img_ids(h // 2, w // 2), premultiplied=True)
-    rel = ((got - ref).norm() / ref.norm()).item()
-    assert rel < 2e-2, rel
+    got = plan.transformer_forward(x.cuda(), tm, gm, enc.cuda(), pool.cuda())
+    from _gpu_oracle import check_in_band
+    check_in_band("FLUX full width 1 + 2 blocks, B = 4, 512^2 (large-grid dispatch)", got, R.flux_forward, sd, cfg_o, x.float(), tm, gm, pool, enc,
+                  R.prepare_img_ids(h // 2, w // 2), premultiplied=True)
     eng.close()
 
 
@@ -221,10 +221,8 @@ def test_flux_full_width_blocks_at_1024_token_count(fx):
     enc = _bf(torch.randn(B, Nt, 4096, generator=g))
     pool = _bf(torch.randn(B, 768, generator=g))
     tm, gm = torch.tensor([640.0]), torch.full((B,), 3500.0)
-    got = eng.plan(B, h, w, Nt, 1).transformer_forward(x.cuda(), tm, gm, enc.cuda(), pool.cuda()).float().cpu()
-    with torch.no_grad():
-        ref = R.flux_forward(sd, cfg_o, x.float(), tm, gm, pool, enc, R.prepare_img_ids(h // 2, w // 2), premultiplied=True)
-    rel = ((got - ref).norm() / ref.norm()).item()
-    print(f"FLUX full-width 1+1 blocks, S = 4608: rel-L2 {rel:.3e}")
-    assert rel < 2e-2, rel
+    got = eng.plan(B, h, w, Nt, 1).transformer_forward(x.cuda(), tm, gm, enc.cuda(), pool.cuda())
+    from _gpu_oracle import check_in_band
+    check_in_band("FLUX full-width 1+1 blocks, S = 4608", got, R.flux_forward, sd, cfg_o, x.float(), tm, gm, pool, enc,
+                  R.prepare_img_ids(h // 2, w // 2), premultiplied=True)
     eng.close()

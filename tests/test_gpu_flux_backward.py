@@ -160,10 +160,16 @@ def _inputs(cfg_o, B, h, w, Nt, seed=0):
                 img_ids=R.prepare_img_ids(h // 2, w // 2))
 
 
-def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=None):
+def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=None, device="cpu"):
+    """`device="cuda"`: the same plain-PyTorch fp32 oracle autograd on GPU tensors (tests/_gpu_oracle.py) -- the full-width cases."""
+    from _gpu_oracle import oracle_loss_on
+    return oracle_loss_on(device, _oracle_loss_impl, mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=quant)
+
+
+def _oracle_loss_impl(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=None):
     """The same loss through the fp32 oracle network + the Flow-SDE step written in differentiable torch (CPU)."""
     from oracle import flux_ref as R
-    sd = {n: p_.detach().cpu().float().requires_grad_(p_.requires_grad) for n, p_ in mod.named_parameters()}
+    sd = {n: p_.detach().to(inp["x"].device).float().requires_grad_(p_.requires_grad) for n, p_ in mod.named_parameters()}
     x, x1 = inp["x"].float(), inp["x1"].float()
     B = x.shape[0]
     tm = R.model_scalar(torch.tensor(t) / 1000, torch.float16).reshape(-1).expand(B)
@@ -272,7 +278,7 @@ def test_flux_full_width_block_gradients_at_1024_token_count(gpu):
     """BASELINE.json configs[2]'s own width and token count: FLUX.1-dev WIDTH (D = 3072, 24 heads x 128), one double-stream + one single-stream
     block at 1024^2 (4096 image + 512 text = 4608 joint tokens), B = 1 -- the large-grid kernels (persistent GEMMs incl. the K = 7D = 21 504
     fused dgrad and the K = 15 360 proj_out, the hand-scheduled attention with its log-sum-exp, 72 query / key tiles in the backward passes,
-    split-K weight gradients) -- the reference's default target modules, vs the oracle's autograd on the host cores and its bf16 band."""
+    split-K weight gradients) -- the reference's default target modules, vs the oracle's autograd (fp32, on the GPU: tests/_gpu_oracle.py) and its bf16 band."""
     from oracle import flux_ref as R
     from mi355_flow import flux
     from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
@@ -302,8 +308,8 @@ def test_flux_full_width_block_gradients_at_1024_token_count(gpu):
         assert torch.equal(out.noise_pred.detach(), ref_out.noise_pred) and torch.equal(out.log_prob.detach(), ref_out.log_prob)
         kl_w = 3.0
         ((inp["wlp"].cuda() * out.log_prob).sum() + kl_w * (inp["wnp"].cuda() * out.noise_pred).mean()).backward()
-        _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w)
-        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float())
+        _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, device="cuda")
+        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float(), device="cuda")
         worst, worst_name, worst_band, n = 0.0, None, 0.0, 0
         for name, prm in mod.named_parameters():
             if not prm.requires_grad:

@@ -180,7 +180,7 @@ def test_rollout_tiny_vs_oracle(tiny, storage, guidance):
 
 def test_full_size_model_256(eng_full=None):
     """SD3.5-medium shapes (24 blocks, 13 dual, D=1536), config A of BASELINE.json (256x256, B=1) vs the fp32
-    oracle on the host cores."""
+    oracle (on the GPU, fp32), inside 1.5 x its bf16 band."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from oracle import mmditx_ref as M
@@ -195,10 +195,8 @@ def test_full_size_model_256(eng_full=None):
         plan = e.plan(B, 1, h, w, Nt, 4)
         y = plan.transformer_forward(x.cuda(), t.cuda(), enc.cuda(), pooled.cuda())
         torch.cuda.synchronize()
-        ref = M.mmdit_forward(sd, M.SD35_MEDIUM, x.float(), t, enc.float(), pooled.float())
-        r = _rel(y, ref)
-        assert torch.isfinite(y.float()).all()
-        assert r < 3e-2, r
+        from _gpu_oracle import check_in_band
+        check_in_band("SD3.5-medium full depth, 256^2 (config A forward)", y, M.mmdit_forward, sd, M.SD35_MEDIUM, x.float(), t, enc.float(), pooled.float())
     finally:
         e.close()
 
@@ -220,9 +218,8 @@ def test_sd35_large_width_blocks():
         pooled = torch.randn(B, 2048, generator=g).bfloat16()
         t = torch.tensor([650.0, 120.0])
         y = e.plan(B, 1, h, w, Nt, 1).transformer_forward(x.cuda(), t.cuda(), enc.cuda(), pooled.cuda())
-        ref = M.mmdit_forward(sd, cfg, x.float(), t, enc.float(), pooled.float())
-        assert torch.isfinite(y.float()).all()
-        assert _rel(y, ref) < 2e-2
+        from _gpu_oracle import check_in_band
+        check_in_band("SD3.5-large width, 2 blocks, 512^2", y, M.mmdit_forward, sd, cfg, x.float(), t, enc.float(), pooled.float())
     finally:
         e.close()
 

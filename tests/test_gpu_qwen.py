@@ -240,13 +240,12 @@ def test_qwen_full_width_blocks_at_1024(qw):
     v, raw = eng.plan(B, 2, h, w, Nt, 1).transformer_forward(x.bfloat16().cuda(), qw.model_timestep(t, torch.bfloat16), torch.cat([ne, pe]).cuda(),
                                                               neg_lens + pos_lens, guidance_scale=4.0, return_raw=True)
     tq = (t.to(torch.bfloat16) / 1000).float()
-    with torch.no_grad():
-        rp = R.qwen_forward(sd, cfg_o, x, tq, pe, pos_lens, 64, 64)
-        rn = R.qwen_forward(sd, cfg_o, x, tq, ne, neg_lens, 64, 64)
-    r1, r2 = _rel(raw[1:], rp), _rel(raw[:1], rn)
-    r3 = _rel(v, R.cfg_rescale_bf16(rn, rp, 4.0))
-    print(f"Qwen-Image full-width 2 blocks, S = 4096 + 96: rel-L2 cond {r1:.3e} uncond {r2:.3e} cfg {r3:.3e}")
-    assert r1 < 2e-2 and r2 < 2e-2 and r3 < 4e-2
+    from _gpu_oracle import check_in_band
+    rp, rpq, _, _ = check_in_band("Qwen-Image full-width 2 blocks, S = 4096 + 96, conditional", raw[1:], R.qwen_forward, sd, cfg_o, x, tq, pe, pos_lens, 64, 64)
+    rn, rnq, _, _ = check_in_band("Qwen-Image full-width 2 blocks, unconditional (7-token prompt)", raw[:1], R.qwen_forward, sd, cfg_o, x, tq, ne, neg_lens, 64, 64)
+    band3, r3 = _rel(R.cfg_rescale_bf16(rnq, rpq, 4.0), R.cfg_rescale_bf16(rn, rp, 4.0)), _rel(v, R.cfg_rescale_bf16(rn, rp, 4.0))
+    print(f"Qwen-Image full-width 2 blocks: norm-rescaled true CFG 4.0 {r3:.3e} (band {band3:.3e})")
+    assert r3 < 1.5 * band3 + 1e-3, (r3, band3)
     eng.close()
 
 
@@ -269,16 +268,17 @@ def test_qwen_full_width_blocks_at_config_e_1328(qw):
                                                               neg_lens + pos_lens, guidance_scale=4.0, return_raw=True)
     assert torch.isfinite(v.float()).all()
     tq = (t.to(torch.bfloat16) / 1000).float()
-    with torch.no_grad():
-        rp = R.qwen_forward(sd, cfg_o, x, tq, pe, pos_lens, h // 2, w // 2)
-        rn = R.qwen_forward(sd, cfg_o, x, tq, ne, neg_lens, h // 2, w // 2)
-    r1, r2 = _rel(raw[1:], rp), _rel(raw[:1], rn)
-    r3 = _rel(v, R.cfg_rescale_bf16(rn, rp, 4.0))
+    from _gpu_oracle import check_in_band
+    rp, rpq, _, band = check_in_band("Qwen-Image full-width 2 blocks, 1328^2 (S = 6889 + 96), conditional", raw[1:], R.qwen_forward, sd, cfg_o, x, tq, pe,
+                                     pos_lens, h // 2, w // 2)
+    rn, rnq, _, _ = check_in_band("Qwen-Image full-width 2 blocks, 1328^2, unconditional (5-token prompt)", raw[:1], R.qwen_forward, sd, cfg_o, x, tq, ne,
+                                  neg_lens, h // 2, w // 2)
+    band3, r3 = _rel(R.cfg_rescale_bf16(rnq, rpq, 4.0), R.cfg_rescale_bf16(rn, rp, 4.0)), _rel(v, R.cfg_rescale_bf16(rn, rp, 4.0))
     rows = raw[1].float().cpu().reshape(h // 2, w // 2, 64)
-    rrows = rp[0].reshape(h // 2, w // 2, 64)
+    rrows = rp[0].float().cpu().reshape(h // 2, w // 2, 64)
     worst_row = max(float((rows[i] - rrows[i]).norm() / rrows[i].norm()) for i in range(h // 2))
-    print(f"Qwen-Image full-width 2 blocks, 1328^2 (S = 6889 + 96): rel-L2 cond {r1:.3e} uncond {r2:.3e} cfg {r3:.3e}, worst image row {worst_row:.3e}")
-    assert r1 < 2e-2 and r2 < 2e-2 and r3 < 4e-2 and worst_row < 3e-2
+    print(f"Qwen-Image full-width 2 blocks, 1328^2: true CFG {r3:.3e} (band {band3:.3e}), worst image row {worst_row:.3e}")
+    assert r3 < 1.5 * band3 + 1e-3 and worst_row < 2.0 * (1.5 * band + 1e-3), (r3, band3, worst_row, band)
     eng.close()
 
 

@@ -97,10 +97,16 @@ def _inputs(cfg_o, B, h, w, Nt, n_cfg, ragged, seed=0):
                 wlp=mk(B), wnp=mk(B, Ni, 64), hp=h // 2, wp=w // 2, n_cfg=n_cfg)
 
 
-def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=None):
+def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=None, device="cpu"):
+    """`device="cuda"`: the same plain-PyTorch fp32 oracle autograd on GPU tensors (tests/_gpu_oracle.py) -- the full-width cases."""
+    from _gpu_oracle import oracle_loss_on
+    return oracle_loss_on(device, _oracle_loss_impl, mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=quant)
+
+
+def _oracle_loss_impl(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=None):
     """The same loss through the oracle network (+ the true-CFG combine) and the Flow-SDE step written in differentiable torch (CPU)."""
     from oracle import qwen_ref as R
-    sd = {n: p_.detach().cpu().float().requires_grad_(p_.requires_grad) for n, p_ in mod.named_parameters()}
+    sd = {n: p_.detach().to(inp["x"].device).float().requires_grad_(p_.requires_grad) for n, p_ in mod.named_parameters()}
     x, x1 = inp["x"].float(), inp["x1"].float()
     B = x.shape[0]
     tq = (torch.full((B,), float(t)).to(torch.bfloat16) / 1000).float()
@@ -224,7 +230,7 @@ def test_qwen_full_width_block_gradients_at_1024_token_count(qw):
     """BASELINE.json configs[4]'s own width: Qwen-Image WIDTH (D = 3072, 24 heads x 128, text dim 3584), two blocks at 1024^2 (4096 image tokens)
     with a ragged true-CFG text batch (forward batch 2: [negative | positive]) -- the large-grid kernels: persistent GEMMs, the hand-scheduled
     attention with its log-sum-exp and masked keys, 66 query / key tiles in the backward passes, split-K weight gradients, the combine adjoint
-    -- the reference's default target modules, vs the oracle's autograd on the host cores and its bf16 band.
+    -- the reference's default target modules, vs the oracle's autograd (fp32, on the GPU: tests/_gpu_oracle.py) and its bf16 band.
     Conditioning: with random weights of this width and q / k norm weights around 1 the bf16-emulating oracle ITSELF sits 0.45 rel-L2 away from
     the fp32 oracle on the first block's attention gradients (bf16 rounding amplified through two softmaxes of ~N(0, 1) logits; 6e-2 at norm
     weights 0.5, 2.3e-2 at 0.3, 1.2e-2 at 0.02; independent of the token count) -- a band that wide tests nothing, so the norm weights here are
@@ -251,8 +257,8 @@ def test_qwen_full_width_block_gradients_at_1024_token_count(qw):
         assert torch.equal(out.noise_pred.detach(), ref_out.noise_pred) and torch.equal(out.log_prob.detach(), ref_out.log_prob)
         kl_w = 3.0
         ((inp["wlp"].cuda() * out.log_prob).sum() + kl_w * (inp["wnp"].cuda() * out.noise_pred).mean()).backward()
-        _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w)
-        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float())
+        _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, device="cuda")
+        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float(), device="cuda")
         plan = next(iter(ad.engine._plans.values()))
         _compare(mod, g_ref, g_band, f"Qwen-Image full-width 2 blocks at S = 4096 + 96, true CFG (stash + scratch {plan.training_bytes / 2 ** 30:.2f} GiB)", 30)
     finally:

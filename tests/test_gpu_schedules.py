@@ -41,9 +41,8 @@ def test_forward_at_sd3_5_large_width_vs_oracle():
             y = plan.transformer_forward(x.cuda(), t.cuda(), enc.cuda(), pooled.cuda())
             torch.cuda.synchronize()
             t_net = t.half().float()
-            ref = M.mmdit_forward(sd, cfg, x.float(), t_net, enc.float(), pooled.float())
-            assert torch.isfinite(y.float()).all()
-            assert _rel(y, ref) < 2e-2, _rel(y, ref)
+            from _gpu_oracle import check_in_band
+            check_in_band("SD3.5-large width forward", y, M.mmdit_forward, sd, cfg, x.float(), t_net, enc.float(), pooled.float())
     finally:
         e.close()
 
@@ -55,7 +54,8 @@ def test_bench_small_batch_legs_report_numbers():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--no-vae", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--no-vae", "--no-cpu-baseline", "--no-families",
+                        "--no-train-step", "--no-clock-probe", "--no-selfcheck"],      # (the other legs have their own scripts; this test is about one leg)
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])

@@ -328,12 +328,10 @@ def test_wan_full_width_blocks_at_4608_tokens(wn):
     pe = _bf(torch.randn(B, Nt, cfg_o.text_dim, generator=g))
     ne = _bf(torch.randn(B, Nt, cfg_o.text_dim, generator=g))
     t = torch.tensor([601.0])
-    got = eng.plan(B, 2, T, h, w, Nt, 1).transformer_forward(x.cuda(), t, ne.cuda(), pe.cuda()).float().cpu()
-    with torch.no_grad():
-        ref = torch.cat([R.wan_forward(sd, cfg_o, x.float(), t.expand(B), ne), R.wan_forward(sd, cfg_o, x.float(), t.expand(B), pe)])
-    rel = ((got - ref).norm() / ref.norm()).item()
-    print(f"Wan full-width 2 blocks, S = 4608: rel-L2 {rel:.3e}")
-    assert rel < 2e-2, rel
+    got = eng.plan(B, 2, T, h, w, Nt, 1).transformer_forward(x.cuda(), t, ne.cuda(), pe.cuda())
+    from _gpu_oracle import check_in_band
+    pair = lambda sd_, x_, t_, ne_, pe_, quant=None: torch.cat([R.wan_forward(sd_, cfg_o, x_, t_, ne_, quant=quant), R.wan_forward(sd_, cfg_o, x_, t_, pe_, quant=quant)])  # noqa: E731
+    check_in_band("Wan full-width 2 blocks, S = 4608, CFG pair", got, pair, sd, x.float(), t.expand(B), ne, pe)
     eng.close()
 
 
@@ -353,15 +351,14 @@ def test_wan_full_width_blocks_at_config_d_20280_tokens(wn):
     pe = _bf(torch.randn(B, Nt, cfg_o.text_dim, generator=g))
     ne = _bf(torch.randn(B, Nt, cfg_o.text_dim, generator=g))
     t = torch.tensor([601.0])
-    got = eng.plan(B, 2, T, h, w, Nt, 1).transformer_forward(x.cuda(), t, ne.cuda(), pe.cuda()).float().cpu()
-    assert torch.isfinite(got).all()
-    with torch.no_grad():
-        ref = torch.cat([R.wan_forward(sd, cfg_o, x.float(), t.expand(B), ne), R.wan_forward(sd, cfg_o, x.float(), t.expand(B), pe)])
-    rel = ((got - ref).norm() / ref.norm()).item()
+    got = eng.plan(B, 2, T, h, w, Nt, 1).transformer_forward(x.cuda(), t, ne.cuda(), pe.cuda())
+    from _gpu_oracle import check_in_band, rel as rel_
+    pair = lambda sd_, x_, t_, ne_, pe_, quant=None: torch.cat([R.wan_forward(sd_, cfg_o, x_, t_, ne_, quant=quant), R.wan_forward(sd_, cfg_o, x_, t_, pe_, quant=quant)])  # noqa: E731
+    ref, _, r, band = check_in_band("Wan full-width 2 blocks, S = 20280 (config D), CFG pair", got, pair, sd, x.float(), t.expand(B), ne, pe)
     # per-frame: an indexing slip that only hits the far end of the 20 280-token axis must not hide in the global norm
-    per_frame = [((got[:, :, f] - ref[:, :, f]).norm() / ref[:, :, f].norm()).item() for f in range(T)]
-    print(f"Wan full-width 2 blocks, S = 20280 (config D): rel-L2 {rel:.3e}, worst frame {max(per_frame):.3e}")
-    assert rel < 2e-2 and max(per_frame) < 3e-2, (rel, per_frame)
+    per_frame = [rel_(got[:, :, f], ref[:, :, f]) for f in range(T)]
+    print(f"  worst frame {max(per_frame):.3e}")
+    assert max(per_frame) < 1.5 * (1.5 * band + 1e-3), per_frame
     eng.close()
 
 

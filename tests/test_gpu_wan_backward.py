@@ -105,10 +105,16 @@ def _inputs(cfg_o, B, T, h, w, Nt, seed=0):
                 wlp=mk(B), wnp=mk(B, 16, T, h, w))
 
 
-def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=None):
+def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=None, device="cpu"):
+    """`device="cuda"`: the same plain-PyTorch fp32 oracle autograd on GPU tensors (tests/_gpu_oracle.py) -- the full-width cases."""
+    from _gpu_oracle import oracle_loss_on
+    return oracle_loss_on(device, _oracle_loss_impl, mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=quant)
+
+
+def _oracle_loss_impl(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=None):
     """The same loss through the oracle network (both CFG branches, `u + g (c - u)` in bf16 like the fused step) and the Flow-SDE step (CPU)."""
     from oracle import wan_ref as R
-    sd = {n: p_.detach().cpu().float().requires_grad_(p_.requires_grad) for n, p_ in mod.named_parameters()}
+    sd = {n: p_.detach().to(inp["x"].device).float().requires_grad_(p_.requires_grad) for n, p_ in mod.named_parameters()}
     x, x1 = inp["x"].float(), inp["x1"].float()
     B = x.shape[0]
     tt = torch.full((B,), float(t))
@@ -255,7 +261,7 @@ def test_wan_one_block_gradient_values_and_real_transition_log_prob(wn):
 def test_wan_full_width_block_gradients(wn):
     """Wan2.1-T2V-1.3B WIDTH (D = 1536, 12 heads x 128, ffn 8960, text dim 4096), two blocks, 4 608 video tokens (4 x 48 x 96 latents) with CFG:
     the large-grid kernels -- persistent GEMMs, the hand-scheduled self-attention with its log-sum-exp, the cross-attention backward over 512
-    text keys, split-K weight gradients on the side stream -- vs the oracle's autograd on the host cores and its bf16 band.  (Norm weights around
+    text keys, split-K weight gradients on the side stream -- vs the oracle's autograd (fp32, on the GPU: tests/_gpu_oracle.py) and its bf16 band.  (Norm weights around
     0.3: see tests/test_gpu_qwen_backward.py on the conditioning of random full-width models.)"""
     from oracle import wan_ref as R
     cfg_o = R.WanConfig(num_layers=2)
@@ -274,8 +280,8 @@ def test_wan_full_width_block_gradients(wn):
         assert torch.equal(out.noise_pred.detach(), ref_out.noise_pred) and torch.equal(out.log_prob.detach(), ref_out.log_prob)
         kl_w = 3.0
         ((inp["wlp"].cuda() * out.log_prob).sum() + kl_w * (inp["wnp"].cuda() * out.noise_pred).mean()).backward()
-        _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w)
-        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float())
+        _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, device="cuda")
+        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float(), device="cuda")
         plan = next(iter(ad.engine._plans.values()))
         _compare(mod, g_ref, g_band, f"Wan full-width 2 blocks, S = 4608, CFG (stash + scratch {plan.training_bytes / 2 ** 30:.2f} GiB)", 40)
     finally:
@@ -287,7 +293,7 @@ def test_wan_config_d_token_count_two_block_gradients(wn):
     Wan2.1-T2V-1.3B width, two blocks (reference models/wan/wan2_t2v.py:426-543 is what optimize() replays).  What this shape adds over the
     4 608-token case: 159 key tiles per query block in both attention-backward passes, split-K factors and weight-gradient operand slots of a
     20 352-row problem, the log-sum-exp stash at S_pad = 20 352.  One branch (guidance 1): the oracle's fp32 autograd over 20 280^2 scores runs on
-    the host cores (flash SDPA, nothing materialised), twice (fp32 and the bf16-emulating band run)."""
+    the GPU (MATH attention: ~20 GB of scores per layer, held for the backward), twice (fp32 and the bf16-emulating band run)."""
     from oracle import wan_ref as R
     cfg_o = R.WanConfig(num_layers=2)
     ad, mod = _build(wn, cfg_o, lambda n: any(k in n for k in DEFAULT_TARGETS), seed=23, std=0.02, norm_mean=0.3)
@@ -305,8 +311,8 @@ def test_wan_config_d_token_count_two_block_gradients(wn):
         assert torch.equal(out.noise_pred.detach(), ref_out.noise_pred) and torch.equal(out.log_prob.detach(), ref_out.log_prob)
         kl_w = 3.0
         ((inp["wlp"].cuda() * out.log_prob).sum() + kl_w * (inp["wnp"].cuda() * out.noise_pred).mean()).backward()
-        _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w)
-        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float())
+        _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, device="cuda")
+        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float(), device="cuda")
         plan = next(iter(ad.engine._plans.values()))
         _compare(mod, g_ref, g_band, f"Wan full-width 2 blocks at config D's token count, S = {T * (h // 2) * (w // 2)} "
                                      f"(stash + scratch {plan.training_bytes / 2 ** 30:.2f} GiB)", 40)
@@ -335,12 +341,13 @@ def test_wan_40_head_width_two_block_gradients(wn):
         assert torch.equal(out.noise_pred.detach(), ref_out.noise_pred) and torch.equal(out.log_prob.detach(), ref_out.log_prob)
         kl_w = 3.0
         ((inp["wlp"].cuda() * out.log_prob).sum() + kl_w * (inp["wnp"].cuda() * out.noise_pred).mean()).backward()
-        _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w)
-        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float())
-        with torch.no_grad():                   # the forward value against the oracle, inside the oracle's own bf16 band (derived, like the gradients')
-            sd = {n: p_.detach().cpu().float() for n, p_ in mod.named_parameters()}
-            v_o = R.wan_forward(sd, cfg_o, inp["x"].float(), torch.full((B,), t), inp["pe"].float())
-            v_b = R.wan_forward(sd, cfg_o, inp["x"].float(), torch.full((B,), t), inp["pe"].float(), quant=lambda z: z.to(torch.bfloat16).float())
+        _, g_ref = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, device="cuda")
+        _, g_band = _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, smax, kl_w, quant=lambda z: z.to(torch.bfloat16).float(), device="cuda")
+        from _gpu_oracle import on_gpu
+        with on_gpu():                          # the forward value against the oracle, inside the oracle's own bf16 band (derived, like the gradients')
+            sd = {n: p_.detach().float() for n, p_ in mod.named_parameters()}
+            v_o = R.wan_forward(sd, cfg_o, inp["x"].float().cuda(), torch.full((B,), t), inp["pe"].float().cuda())
+            v_b = R.wan_forward(sd, cfg_o, inp["x"].float().cuda(), torch.full((B,), t), inp["pe"].float().cuda(), quant=lambda z: z.to(torch.bfloat16).float())
         r_v, band_v = _rel(out.noise_pred.detach(), v_o), _rel(v_b, v_o)
         print(f"Wan 40-head width: forward rel-L2 vs fp32 oracle {r_v:.3e} (bf16-emulating oracle band {band_v:.3e})")
         assert r_v < 3.0 * band_v + 5e-3, (r_v, band_v)
