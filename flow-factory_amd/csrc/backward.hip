@@ -587,6 +587,57 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* part, l
     }
 }
 
+// Round 6: the two finishing kernels of one weight gradient in ONE launch -- the split-K reduction of dW (workgroups [0, nred)) and the
+// fixed-order finish of the bias gradient's row-tile partials (the workgroups behind them).  The optimize() step of the default target set
+// issues 191 such pairs; as two dependent launches each pair paid a second ~8 us launch for 1.5 K floats of output.  Same arithmetic, same
+// order per output element as splitk_reduce_kernel<.., true> / colsum_finish_kernel: results are bit-identical to the two-launch form.
+template <bool OUT_BF16>
+__global__ __launch_bounds__(256) void splitk_reduce_colsum_kernel(const float* part, long stride, int nsplit, void* out_, long n, int nred,
+                                                                   const float* cs_part, int nslab, int N, void* cs_out_) {
+    if ((int)blockIdx.x >= nred) {
+        __shared__ float red[8][32];
+        const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+        const int col = ((int)blockIdx.x - nred) * 32 + c;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (col < N) {
+            int i = r;
+            for (; i + 24 < nslab; i += 32) {
+                s0 += cs_part[(long)i * N + col];
+                s1 += cs_part[(long)(i + 8) * N + col];
+                s2 += cs_part[(long)(i + 16) * N + col];
+                s3 += cs_part[(long)(i + 24) * N + col];
+            }
+            for (; i < nslab; i += 8) s0 += cs_part[(long)i * N + col];
+        }
+        red[r][c] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (r == 0 && col < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += red[k][c];
+            if (OUT_BF16) ((bf16_t*)cs_out_)[col] = f2bf(t);
+            else ((float*)cs_out_)[col] = t;
+        }
+        return;
+    }
+    const long n4 = n >> 2;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)nred * blockDim.x) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < nsplit; ++k) {
+            const float4 v = *(const float4*)(part + (long)k * stride + i * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (OUT_BF16) {
+            uint2 o;
+            o.x = (unsigned)f2bf(s.x) | ((unsigned)f2bf(s.y) << 16);
+            o.y = (unsigned)f2bf(s.z) | ((unsigned)f2bf(s.w) << 16);
+            *(uint2*)((bf16_t*)out_ + i * 4) = o;
+        } else {
+            *((float4*)out_ + i) = s;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ proj_out backward prologue: un-patchify transposed
 // dv [B'][C][hp*p][wp*p] (fp32) -> dproj [B'*hp*wp][p*p*C] bf16, feature f = (pp*p + qq)*C + c  (the forward's EPI_UNPATCH order)
 __global__ void unpatch_bwd_kernel(const float* dv, bf16_t* out, int Bp, int C, int hp, int wp, int patch) {
@@ -728,9 +779,10 @@ int get_train_text_side() { return g_train_text_side; }
 // partial rounds are filled by the other stream) keep the round-2 rule.  A/B on MI355X (profiles/r04k_*, optimize() step, ms, rule -> model):
 // SD3.5 B = 2 1024^2 serial: attention projections 92.4 -> 91.7, every block linear 111.5 -> 108.3; overlapped FLUX.1 249.5 -> 252.6 and
 // Qwen-Image 471.2 -> 479.6 (more partial-sum traffic for rounds that were not idle): hence the exception.
-static int g_wgrad_split_model = 1;
-void set_wgrad_split_model(int v) { g_wgrad_split_model = v != 0; }
+static int g_wgrad_split_model = 1;      // 0 = the round-2 rule, 1 = modelled-time minimum (default), 2 = never split (diagnostic: tests/test_gpu_fullsize.py)
+void set_wgrad_split_model(int v) { g_wgrad_split_model = v; }
 int wgrad_split(int N, int K, int M_pad, size_t part_floats, bool overlapped) {
+    if (g_wgrad_split_model == 2) return 1;
     const int nt = M_pad / 64;
     int cap = nt / 2 < 16 ? nt / 2 : 16;
     if (cap < 1) cap = 1;
@@ -830,9 +882,10 @@ hipError_t launch_transpose(const bf16_t* in, long ld_in, long bs_in, bf16_t* ou
 
 // transpose + column sums in one pass over `in`: out = in^T, colsum[cols] = sum over rows (scratch: ((rows_pad + 63) / 64) * cols floats)
 hipError_t launch_transpose_colsum(const bf16_t* in, long ld_in, bf16_t* out, long ld_out, int rows, int cols, int rows_pad, float* scratch,
-                                   float* colsum, hipStream_t st) {
+                                   float* colsum, hipStream_t st, bool finish) {
     if (sched_trace_on()) sched_trace_launch("transpose_colsum", st, {treg(in, ((size_t)(rows - 1) * ld_in + cols) * 2)},
-                                             {treg(out, ((size_t)(cols - 1) * ld_out + rows_pad) * 2), treg(scratch, (size_t)((rows_pad + 63) / 64) * cols * 4), treg(colsum, (size_t)cols * grad_buf_esize(colsum))});
+                                             {treg(out, ((size_t)(cols - 1) * ld_out + rows_pad) * 2), treg(scratch, (size_t)((rows_pad + 63) / 64) * cols * 4),
+                                              treg(colsum, finish ? (size_t)cols * grad_buf_esize(colsum) : 0)});
     if (rows <= 0 || cols <= 0 || rows_pad < rows || !scratch || !colsum) return hipErrorInvalidValue;
     const int ntile = (rows_pad + 63) / 64;
     if (transpose_vec_ok(in, ld_in, 0, out, ld_out, 0))
@@ -841,6 +894,7 @@ hipError_t launch_transpose_colsum(const bf16_t* in, long ld_in, bf16_t* out, lo
     else
         hipLaunchKernelGGL(transpose_kernel<false>, dim3(ntile, (cols + 63) / 64, 1), dim3(256), 0, st, in, ld_in, 0L, out, ld_out, 0L, rows, cols,
                            rows_pad, scratch);
+    if (!finish) return hipGetLastError();      // the caller finishes the column sums inside its split-K reduction launch (launch_splitk_reduce_colsum)
     if (grad_buf_dtype(colsum) == DT_BF16) hipLaunchKernelGGL(colsum_finish_kernel<true>, dim3((cols + 31) / 32), dim3(256), 0, st, scratch, ntile, cols, (void*)colsum, 0);
     else hipLaunchKernelGGL(colsum_finish_kernel<false>, dim3((cols + 31) / 32), dim3(256), 0, st, scratch, ntile, cols, (void*)colsum, 0);
     return hipGetLastError();
@@ -907,6 +961,33 @@ hipError_t launch_splitk_reduce(const float* part, long stride, int nsplit, floa
     else if (b16) hipLaunchKernelGGL((splitk_reduce_kernel<true, false>), grid, dim3(256), 0, st, part, stride, nsplit, (void*)out, n, accumulate);
     else if (vec) hipLaunchKernelGGL((splitk_reduce_kernel<false, true>), grid, dim3(256), 0, st, part, stride, nsplit, (void*)out, n, accumulate);
     else hipLaunchKernelGGL((splitk_reduce_kernel<false, false>), grid, dim3(256), 0, st, part, stride, nsplit, (void*)out, n, accumulate);
+    return hipGetLastError();
+}
+
+hipError_t launch_colsum_finish(const float* scratch, int nslab, int cols, float* colsum, hipStream_t st) {
+    if (!scratch || !colsum || nslab <= 0 || cols <= 0) return hipErrorInvalidValue;
+    if (sched_trace_on()) sched_trace_launch("colsum_finish", st, {treg(scratch, (size_t)nslab * cols * 4)}, {treg(colsum, (size_t)cols * grad_buf_esize(colsum))});
+    if (grad_buf_dtype(colsum) == DT_BF16) hipLaunchKernelGGL(colsum_finish_kernel<true>, dim3((cols + 31) / 32), dim3(256), 0, st, scratch, nslab, cols, (void*)colsum, 0);
+    else hipLaunchKernelGGL(colsum_finish_kernel<false>, dim3((cols + 31) / 32), dim3(256), 0, st, scratch, nslab, cols, (void*)colsum, 0);
+    return hipGetLastError();
+}
+
+// out[n] = sum_s part[s][n] (overwritten) AND colsum[cols] = sum over the `nslab` row-tile partials launch_transpose_colsum(.., finish = false)
+// left in `cs_scratch`, one launch.  Returns hipErrorNotSupported when the pair does not qualify (ragged sizes, mixed buffer dtypes): the caller
+// then issues the two launches.
+hipError_t launch_splitk_reduce_colsum(const float* part, long stride, int nsplit, float* out, long n, const float* cs_scratch, int nslab, int cols,
+                                       float* colsum, hipStream_t st) {
+    if (nsplit <= 0 || n <= 0 || !part || !out || !cs_scratch || !colsum || nslab <= 0 || cols <= 0) return hipErrorInvalidValue;
+    const bool b16 = grad_buf_dtype(out) == DT_BF16;
+    const bool vec = !(n & 3) && !(stride & 3) && !((size_t)part & 15) && !((size_t)out & 15);
+    if (!vec || (grad_buf_dtype(colsum) == DT_BF16) != b16) return hipErrorNotSupported;
+    if (sched_trace_on())
+        sched_trace_launch("splitk_reduce_colsum", st, {treg(part, ((size_t)(nsplit - 1) * stride + n) * 4), treg(cs_scratch, (size_t)nslab * cols * 4)},
+                           {treg(out, (size_t)n * grad_buf_esize(out)), treg(colsum, (size_t)cols * grad_buf_esize(colsum))});
+    const int nred = (int)grid_for(n / 4, 256);
+    const dim3 grid(nred + (cols + 31) / 32);
+    if (b16) hipLaunchKernelGGL(splitk_reduce_colsum_kernel<true>, grid, dim3(256), 0, st, part, stride, nsplit, (void*)out, n, nred, cs_scratch, nslab, cols, (void*)colsum);
+    else hipLaunchKernelGGL(splitk_reduce_colsum_kernel<false>, grid, dim3(256), 0, st, part, stride, nsplit, (void*)out, n, nred, cs_scratch, nslab, cols, (void*)colsum);
     return hipGetLastError();
 }
 

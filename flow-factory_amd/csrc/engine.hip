@@ -120,6 +120,7 @@ static hipError_t sde_p(const SdeStepParams& s, hipStream_t st) { ProfScope ps(P
 
 // training-mode state (engine_train.inc, included at the end of this file)
 static int g_train_two_stream = 1;   // key 22, see engine_train.inc
+static int g_fuse_colsum = 1;        // key 38: bias-gradient column-sum finish inside the weight gradient's split-K reduction launch (engine_train.inc: wgrad)
 struct mi355_engine;
 struct mi355_plan;
 static void train_release(mi355_plan* p);
@@ -664,6 +665,11 @@ static int forward_core(mi355_plan* p, hipStream_t st, const void* latents, int 
     const int D = e->D, F = e->F, H = e->cfg.num_heads;
     const int Mi = p->Mi, Mc = p->Mc, Ni = p->Ni, Nt = p->Nt;
     const int Ni_pad = (Ni + 63) / 64 * 64;
+    // The mid-size GEMM kernel (gemm.hip, one 160-KiB workgroup per CU) keeps the text chain's workgroups off the CUs it holds.  Measured
+    // in-model (profiles/r06d_*): that pays where the text chain is a real share of the work -- the reference's 512^2 B = 2 CFG example,
+    // 1332 text rows beside 4096 image rows: +2.7 % -- and costs where it is a sliver (1024^2 B = 1, 333 rows: -1.6 %).  The choice depends on
+    // the PLAN's shape only, never on data, and the kernels are bit-identical: a sample's result does not depend on it.
+    struct MidHint { explicit MidHint(int v) { set_mid_plan_hint(v); } ~MidHint() { set_mid_plan_hint(1); } } mid_hint(4L * Mc >= Mi ? 1 : 0);
     if (!p->pos_ready) {
         HIPCHK(launch_pos_crop(e->pos_embed, p->pe, e->cfg.pos_embed_max_size, p->hp, p->wp, D, st));
         p->pos_ready = true;
@@ -1078,6 +1084,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 36) { set_mid_mask(value); return 0; }          // launch classes it may take (1 gated residual K < 3072, 2 K >= 3072, 4 V^T, 8 the rest)
     if (key == 37) { set_mid_max_tiles(value); return 0; }     // largest grid of its tiles
     if (key == 35) { set_mid_stagger(value); return 0; }       // its per-wave staggered LDS-DMA issue slots: 1 on (default), 0 off
+    if (key == 38) { g_fuse_colsum = value; return 0; }        // optimize() backward: 1 (default) = column-sum finish fused into the split-K reduction launch, 0 = two launches
     if (key == 22) { g_train_two_stream = value; return 0; }   // optimize() replay: the context-stream chain of the training forward / backward on a side stream (1 = default)
     if (key == 21) { set_attn128_op_bound(value); return 0; }  // mi355_op_attention128: the |score| bound the caller asserts (0 = none)          // default GEMM dispatch: largest K for the 4-wave hand-scheduled kernel
     return fail("mi355_tune_set: unknown key %d", key);

@@ -33,7 +33,9 @@ int g_mid_mode = 1;           // mid-size kernel (128x192 / 192x128 tiles): 0 of
 double g_mid_alpha = 1.0;     // margin of that rule: the mid-size kernel's estimated cost is multiplied by it; mi355_tune_set(33, percent)
 int g_mid_stagger = 1;        // mid-size kernel: per-wave staggered LDS-DMA issue slots (0 = all four waves issue behind the same MFMAs); mi355_tune_set(35, v)
 int g_mid_mask = 15;          // which launch classes may take it: 1 gated residual K < 3072, 2 gated residual K >= 3072, 4 V^T, 8 the rest; mi355_tune_set(36, v)
-int g_mid_max_tiles = 1 << 30; // largest grid of its tiles; mi355_tune_set(37, v)
+int g_mid_max_tiles = 256;    // largest grid of its tiles: ONE round, one workgroup per CU (measured in-model, profiles/r06b / r06d: two-round grids lose
+                              // to the ping-pong kernel's 192 tiles + the CUs it leaves to the text chain: 1024^2 B = 2 -7 %); mi355_tune_set(37, v)
+int g_mid_plan_hint = 1;      // set by the SD3.5 engine around a forward (set_mid_plan_hint): 0 = the plan's text chain is too small for the kernel to pay
 int g_mid_min_tiles = 160;    // no mid-size launch below this many of its tiles (sub-chip grids: a lone 128x128 tile per CU is quicker); mi355_tune_set(34, v)
 
 // linear tile id -> (tm, tn).  Bands of `gm` tile rows are walked column by column, so the ~32 consecutive ids that the workgroups of one
@@ -1234,7 +1236,7 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
         const double cost_mid = 1.5 * (double)((tmid + 255) / 256) * g_mid_alpha;
         const double cost_else = (big >= g_pp_min_tiles && fits32 && cost_pp <= cost_128) ? cost_pp : (t128 <= 256 ? 1.7 : cost_128);
         const int cls = EPI == EPI_GATE_RES ? (p.K < 3072 ? 1 : 2) : vt ? 4 : 8;      // launch class for the A/B mask (key 36)
-        if (g_mid_mode != 0 && (g_mid_mask & cls) && fits32 && g_gemm_variant != 0 && tmid >= g_mid_min_tiles && tmid <= g_mid_max_tiles &&
+        if (g_mid_mode != 0 && (g_mid_mode == 2 || g_mid_plan_hint) && (g_mid_mask & cls) && fits32 && g_gemm_variant != 0 && tmid >= g_mid_min_tiles && tmid <= g_mid_max_tiles &&
             (g_mid_mode == 2 || cost_mid < cost_else))
             return vt ? launch_mid<6, 4, EPI>(p, stream) : launch_mid<4, 6, EPI>(p, stream);
     }
@@ -1310,6 +1312,7 @@ void set_mid_min_tiles(int v) { g_mid_min_tiles = v; }
 void set_mid_stagger(int v) { g_mid_stagger = v; }
 void set_mid_mask(int v) { g_mid_mask = v; }
 void set_mid_max_tiles(int v) { g_mid_max_tiles = v; }
+void set_mid_plan_hint(int v) { g_mid_plan_hint = v; }
 int get_gemm_variant() { return g_gemm_variant; }
 
 void set_raster_gm(int v) { g_raster_gm = v; }

@@ -106,6 +106,7 @@ void set_mid_min_tiles(int v);
 void set_mid_stagger(int v);
 void set_mid_mask(int v);
 void set_mid_max_tiles(int v);
+void set_mid_plan_hint(int v);      // engine.hip forward_core: whether this plan takes the mid-size GEMM kernel at all
 void set_raster_gm(int v);      // GEMM tile raster: tile rows per band (0 = row-major)
 void set_conv_cfg(int v);       // VAE conv tile shape A/B knob (0 auto)
 void set_attn_variant(int v);  // 0 = plain online softmax, 1 = deferred-rescale (default)
@@ -286,7 +287,10 @@ hipError_t launch_gelu_fwd(const bf16_t* pre, bf16_t* out, long n, hipStream_t s
 hipError_t launch_transpose(const bf16_t* in, long ld_in, long bs_in, bf16_t* out, long ld_out, long bs_out, int rows, int cols, int rows_pad,
                             int batch, hipStream_t stream);
 hipError_t launch_transpose_colsum(const bf16_t* in, long ld_in, bf16_t* out, long ld_out, int rows, int cols, int rows_pad, float* scratch,
-                                   float* colsum, hipStream_t stream);
+                                   float* colsum, hipStream_t stream, bool finish = true);
+hipError_t launch_colsum_finish(const float* scratch, int nslab, int cols, float* colsum, hipStream_t stream);
+hipError_t launch_splitk_reduce_colsum(const float* part, long stride, int nsplit, float* out, long n, const float* cs_scratch, int nslab, int cols,
+                                       float* colsum, hipStream_t stream);
 struct AttnBwdPrepParams {
     const bf16_t* o_img; const bf16_t* o_ctx; const bf16_t* do_img; const bf16_t* do_ctx;   // token-major [.][H*64]; do_ctx may be null (zeros)
     const float* lse;                                                                     // [B][H][S_pad] from the forward

@@ -170,7 +170,7 @@ def _layer_norm(x, eps):
     return F.layer_norm(x.float(), (x.shape[-1],), None, None, eps)
 
 
-def _attention(sd, pre, x, ctx, cfg: MMDiTConfig, q, has_add_out: bool):
+def _attention(sd, pre, x, ctx, cfg: MMDiTConfig, q, has_add_out: bool, attn_quant=None):
     B, Ni, D = x.shape
     H, hd = cfg.num_heads, cfg.head_dim
 
@@ -191,7 +191,13 @@ def _attention(sd, pre, x, ctx, cfg: MMDiTConfig, q, has_add_out: bool):
         qq = torch.cat([qq, cq], dim=2)  # image tokens first, then text
         kk = torch.cat([kk, ck], dim=2)
         vv = torch.cat([vv, cv], dim=2)
-    o = F.scaled_dot_product_attention(qq, kk, vv, dropout_p=0.0, is_causal=False)
+    if attn_quant is None:
+        o = F.scaled_dot_product_attention(qq, kk, vv, dropout_p=0.0, is_causal=False)
+    else:
+        # what a flash-attention kernel rounds INSIDE the attention (the reference's bf16 run uses one): the probabilities enter the P.V
+        # product in bf16 -- and, under autograd, dP comes back through the same cast in bf16.  Used by the gradient-noise isolation test.
+        pm = torch.softmax((qq @ kk.transpose(-1, -2)) * (hd ** -0.5), dim=-1)
+        o = attn_quant(pm) @ vv
     o = q(o.transpose(1, 2).reshape(B, -1, D))
     if ctx is not None:
         o, oc = o[:, :Ni], o[:, Ni:]
@@ -217,6 +223,7 @@ def mmdit_forward(
     pooled_projections: torch.Tensor,  # (B, pooled_projection_dim)
     quant: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
     return_intermediates: bool = False,
+    attn_quant: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
 ):
     q = quant or _id
     B, C, h, w = hidden_states.shape
@@ -259,10 +266,10 @@ def mmdit_forward(
         else:
             c_shift_msa, c_scale_msa, c_gate_msa, c_shift_mlp, c_scale_mlp, c_gate_mlp = cmod.chunk(6, dim=1)
             cn = _layer_norm(c, cfg.eps) * (1 + c_scale_msa[:, None]) + c_shift_msa[:, None]
-        ao, aoc = _attention(sd, f"{b}.attn", xn, cn, cfg, q, has_add_out=not last)
+        ao, aoc = _attention(sd, f"{b}.attn", xn, cn, cfg, q, has_add_out=not last, attn_quant=attn_quant)
         x = q(x + gate_msa[:, None] * ao)
         if dual:
-            ao2, _ = _attention(sd, f"{b}.attn2", xn2, None, cfg, q, has_add_out=False)
+            ao2, _ = _attention(sd, f"{b}.attn2", xn2, None, cfg, q, has_add_out=False, attn_quant=attn_quant)
             x = q(x + gate_msa2[:, None] * ao2)
         xn = _layer_norm(x, cfg.eps) * (1 + scale_mlp[:, None]) + shift_mlp[:, None]
         x = q(x + gate_mlp[:, None] * _ff(sd, f"{b}.ff", xn, q))

@@ -13,7 +13,8 @@ stats_sub = sys.argv[2] if len(sys.argv) > 2 else None
 
 
 def short(name):
-    for key, tag in (("attn_kernel", "attn_kernel"), ("gemm_w4_kernel", None), ("gemm_pp_kernel", None), ("gemm_kernel", None), ("ln_mod_kernel", "ln_mod_kernel"),
+    for key, tag in (("attn_bwd_dkv_tr_kernel", "attn_bwd_dkv_tr_kernel"), ("attn_bwd_dq_tr_kernel", "attn_bwd_dq_tr_kernel"), ("attn_kernel", "attn_kernel"),
+                     ("gemm_mid_kernel", None), ("gemm_w4_kernel", None), ("gemm_pp_kernel", None), ("gemm_kernel", None), ("ln_mod_kernel", "ln_mod_kernel"),
                      ("sde_step_kernel", "sde_step_kernel"), ("patchify", "patchify_kernel"), ("time_proj", "time_proj_kernel"),
                      ("convert_kernel", "convert_kernel"), ("pos_crop", "pos_crop_kernel"), ("gn_partial", "gn_partial_kernel"),
                      ("gn_finalize", "gn_finalize_kernel"), ("gn_apply", "gn_apply_kernel"), ("softmax_rows", "softmax_rows_kernel"),
@@ -25,6 +26,9 @@ def short(name):
             import re
             epi = ["bias", "bias_silu", "bias_gelu", "posadd", "addsrc_silu", "gate_res", "qk_norm", "vT", "unpatch", "bias_row",
                    "f32", "img", "dgelu", "qk_norm_rstd"]
+            mm = re.search(r"gemm_mid_kernel<(\d+), (\d+), (\d+)>", name)
+            if mm:
+                return f"gemm_mid<{int(mm.group(1)) * 32}x{int(mm.group(2)) * 32},{epi[int(mm.group(3))]}>"
             m4 = re.search(r"gemm_w4_kernel<(\d+)(?:, \d+)?>", name)
             if m4:
                 return f"gemm_w4<256x256,{epi[int(m4.group(1))]}>"
@@ -70,6 +74,18 @@ for d in sorted(glob.glob(os.path.join(out, "prof_pmc_*"))):
         print(f"  {k:34s} launches={max(cnt[k].values()):6d} per-launch: " + ", ".join(f"{c}={v:.4g}" for c, v in per.items()))
         summary.setdefault(k, {}).update({c: v for c, v in per.items()})
         summary[k]["launches"] = max(cnt[k].values())
+for k, v in summary.items():
+    if v.get("SQ_VALU_MFMA_BUSY_CYCLES") and v.get("GRBM_GUI_ACTIVE"):
+        v["mfma_busy"] = round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4)
+    if v.get("SQ_LDS_IDX_ACTIVE") and v.get("SQ_LDS_BANK_CONFLICT") is not None:
+        v["lds_conflict_share_of_lds_cycles"] = round(v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"], 4)
+    if v.get("SQ_WAVE_CYCLES") and v.get("SQ_WAIT_INST_LDS") is not None:
+        v["lds_issue_stall_share_of_wave_cycles"] = round(v["SQ_WAIT_INST_LDS"] / v["SQ_WAVE_CYCLES"], 4)
+    if v.get("SQ_LDS_IDX_ACTIVE") and v.get("GRBM_GUI_ACTIVE"):
+        # LDS-array busy cycles summed over the chip's 256 CUs against the kernel's clock cycles (GRBM_GUI_ACTIVE is summed over 8 XCDs)
+        v["lds_array_busy"] = round(v["SQ_LDS_IDX_ACTIVE"] / (v["GRBM_GUI_ACTIVE"] / 8.0 * 256.0), 4)
+    if v.get("FETCH_SIZE") is not None and v.get("WRITE_SIZE") is not None:
+        v["fabric_bytes_per_launch"] = int(v["FETCH_SIZE"] * 1024 * 2 + v["WRITE_SIZE"] * 1024)      # FETCH doubled per MI355X_MICROARCH.md (gfx950)
 json.dump(summary, open(os.path.join(out, "pmc_per_launch.json"), "w"), indent=1)
 
 # the dominant kernel's HBM traffic per launch, as bench.py's roofline.traffic reads it (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE are in

@@ -120,7 +120,7 @@ def _inputs(B, h, w, Nt, seed=0):
                 ne=mk(B, Nt, 128).bfloat16(), npl=mk(B, 128).bfloat16(), wlp=mk(B), wnp=mk(B, 16, h, w))
 
 
-def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=None, device="cpu"):
+def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, quant=None, device="cpu", attn_quant=None):
     """The same loss through the fp32 oracle network + the Flow-SDE step written in differentiable torch (host cores; `device="cuda"`: the
     same plain-PyTorch fp32 oracle on GPU tensors with the MATH attention backend, tests/_gpu_oracle.py -- what makes the full-width model
     affordable).  `quant=M.bf16_round` puts a bf16 round-trip wherever a bf16 module materialises a tensor; autograd rounds the activation
@@ -128,7 +128,7 @@ def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, qua
     if device != "cpu":
         from _gpu_oracle import cuda, on_gpu
         with on_gpu(grad=True):
-            lp, gr = _oracle_loss(mod, cfg_o, cuda(dict(inp)), guidance, t, t_next, eta, sigma_max, kl_w, quant=quant, device="cpu")
+            lp, gr = _oracle_loss(mod, cfg_o, cuda(dict(inp)), guidance, t, t_next, eta, sigma_max, kl_w, quant=quant, device="cpu", attn_quant=attn_quant)
         return lp.cpu(), gr
     from oracle import mmditx_ref as M
     dev = inp["x"].device
@@ -138,11 +138,11 @@ def _oracle_loss(mod, cfg_o, inp, guidance, t, t_next, eta, sigma_max, kl_w, qua
     tt = torch.full((B,), float(torch.tensor(t, device="cpu").half()), device=dev)            # the network sees t rounded to the latent dtype (sd3_5.py:394)
     if guidance > 1.0:
         v2 = M.mmdit_forward(sd, cfg_o, torch.cat([x, x]), torch.cat([tt, tt]), torch.cat([inp["ne"], inp["pe"]]).float(),
-                             torch.cat([inp["npl"], inp["pp"]]).float(), quant=quant)
+                             torch.cat([inp["npl"], inp["pp"]]).float(), quant=quant, attn_quant=attn_quant)
         vu, vt = v2.chunk(2)
         v = vu + guidance * (vt - vu)
     else:
-        v = M.mmdit_forward(sd, cfg_o, x, tt, inp["pe"].float(), inp["pp"].float(), quant=quant)
+        v = M.mmdit_forward(sd, cfg_o, x, tt, inp["pe"].float(), inp["pp"].float(), quant=quant, attn_quant=attn_quant)
     sigma, sigma_n = t / 1000.0, t_next / 1000.0
     dt = sigma_n - sigma
     std = math.sqrt(sigma / (1 - (sigma_max if sigma == 1.0 else sigma))) * eta

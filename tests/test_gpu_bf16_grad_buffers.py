@@ -163,3 +163,38 @@ def test_weight_gradients_on_the_side_stream_are_bit_identical_to_the_serial_sch
     for n in grads[0]:
         assert torch.equal(grads[0][n], grads[1][n]), n
     print(f"{family}, key {key}: {len(grads[0])} gradients, side-stream schedule == serial schedule bit for bit")
+
+
+@pytest.mark.parametrize("bf16_master", [True, False])
+def test_sd3_fused_split_k_reduce_and_column_sum_finish_is_bit_identical_to_the_two_launch_form(gpu, bf16_master):
+    """Round 6 (`mi355_tune_set(38, .)`, csrc/backward.hip splitk_reduce_colsum_kernel): the weight gradient's split-K reduction and the
+    bias gradient's fixed-order column-sum finish in ONE launch per gradient pair -- same sums in the same order: every gradient equals the
+    two-launch form's bit for bit, with bf16 gradient buffers (the default route) and with fp32 ones."""
+    import test_gpu_backward as TB
+    from mi355_flow import _lib
+    lib = _lib.load()
+    ad, mod, _ = TB._build(lambda n: any(k in n for k in TB.BLOCK_LINEARS))
+    B, h, w, Nt = 2, 16, 16, 13
+    inp = TB._inputs(B, h, w, Nt, seed=7)
+    ad.scheduler.set_timesteps(4)
+    kw = dict(t=torch.full((B,), 900.0), t_next=torch.full((B,), 750.0), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+              prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(), guidance_scale=1.0, noise_level=0.7, compute_log_prob=True,
+              return_kwargs=["log_prob", "noise_pred", "dt"])
+    if bf16_master:
+        mod.bfloat16()
+        live = getattr(ad, "_live_weights", None)
+        if live is not None:
+            live.reset()
+    try:
+        grads = {}
+        for fused in (1, 0, 1):
+            _lib.check(lib.mi355_tune_set(38, fused))
+            grads[fused], _ = _run(ad, mod, kw, inp["wlp"].cuda(), inp["wnp"].cuda(), False)
+        n_bias = 0
+        for n, g in grads[1].items():
+            assert torch.isfinite(g.float()).all() and torch.equal(g, grads[0][n]), n
+            n_bias += int(n.endswith(".bias") and float(g.float().norm()) > 0)
+        assert n_bias >= 10                                  # bias gradients (the column sums) are in the comparison and non-trivial
+    finally:
+        lib.mi355_tune_set(38, 1)
+        ad.engine.close()

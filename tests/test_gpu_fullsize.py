@@ -452,3 +452,84 @@ def test_config_a_replay_gradients_vs_oracle_autograd(full):
         assert n == 16 + 16 + 14 + 8 * 2 and n_null >= 2            # blocks 0 / 12: 8 names x (w, b); block 23: no to_add_out; attn2 x 2
     finally:
         ad.engine.close()
+
+
+def test_config_a_gradient_noise_has_a_named_cause(full):
+    """the full-width weight gradients sit ~1.75 x the bf16 band away from fp32 autograd -- which rounding is it?
+    The same gradient check (blocks 0 / 12 / 23, the reference's default target set + attn2) under every combination of the suspects:
+
+      engine side   default | weight-gradient GEMMs never split over K (`mi355_tune_set(27, 2)`: one fp32 accumulation chain per element)
+                    (gradient buffers are fp32 here -- the master copy is fp32 -- so buffer rounding is not in play; the bf16-buffer route is
+                    bit-identical to `fp32 -> .to(bf16)`: tests/test_gpu_bf16_grad_buffers.py)
+      band side     A: bf16 round-trips where a bf16 MODULE materialises a tensor (what the other tests call the band)
+                    B: A + the rounding a flash-attention kernel does INSIDE the attention: P enters the P.V product in bf16 and dP comes back
+                       in bf16 (`attn_quant`; the reference's bf16 run goes through such a kernel, and so does the engine)
+
+    and prints worst rel-L2 / band for each.  What it pins: split-K changes nothing beyond fp32 reassociation (gradients equal to <= 1e-5
+    relative), and against band B -- the band of a bf16 run WITH a flash kernel -- the engine sits within 1.5 x like the forwards do."""
+    from mi355_flow import _lib
+    from mi355_flow.adapter import SD3_5NativeAdapter
+    from mi355_flow.engine import TransformerConfig
+    from mi355_flow.scheduler import FlowMatchEulerDiscreteSDEScheduler
+    from mi355_flow.weights import module_from_state_dict
+    from oracle import mmditx_ref as M
+    from test_gpu_backward import _inputs, _oracle_loss
+    e, sd, cfg = full
+    lib = _lib.load()
+    mod = module_from_state_dict({k: v.float() for k, v in sd.items()})
+    picks = ("transformer_blocks.0.", "transformer_blocks.12.", "transformer_blocks.23.")
+    for n, p in mod.named_parameters():
+        p.requires_grad_(n.startswith(picks) and any(k in n for k in DEFAULT_SD35_TARGETS + (".attn2.to_q.", ".attn2.to_k.", ".attn2.to_v.", ".attn2.to_out.0.")))
+    sched = FlowMatchEulerDiscreteSDEScheduler(noise_level=0.7, sde_steps=[1, 2, 3], num_sde_steps=1, seed=42, shift=3.0)
+    ad = SD3_5NativeAdapter(mod, TransformerConfig(), sched, latent_storage_dtype="fp16")
+    ad.rollout()
+    try:
+        B, h, w = 1, 32, 32
+        g = torch.Generator().manual_seed(77)
+        inp = dict(x=torch.randn(B, 16, h, w, generator=g).half(), pe=torch.randn(B, N_TEXT, 4096, generator=g).bfloat16(),
+                   pp=torch.randn(B, 2048, generator=g).bfloat16(), wlp=torch.ones(B), wnp=torch.zeros(B, 16, h, w))
+        t, t_next, eta, smax = 900.0, 750.0, 0.7, 0.9
+        sched.set_timesteps(4)
+        with torch.no_grad():
+            o0 = ad.forward(t=torch.full((B,), t), t_next=torch.full((B,), t_next), latents=inp["x"].cuda(), prompt_embeds=inp["pe"].cuda(),
+                            pooled_prompt_embeds=inp["pp"].cuda(), guidance_scale=1.0, noise_level=eta, return_kwargs=["next_latents", "log_prob"])
+        inp["x1"] = o0.next_latents.half().cpu()
+        kw = dict(t=torch.full((B,), t), t_next=torch.full((B,), t_next), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+                  prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(), guidance_scale=1.0, noise_level=eta,
+                  compute_log_prob=True, return_kwargs=["log_prob", "dt"])
+        eng_grads = {}
+        for tag, key27 in (("default", 1), ("split_k_1", 2)):
+            _lib.check(lib.mi355_tune_set(27, key27))
+            for p in mod.parameters():
+                p.grad = None
+            ad.forward(**kw).log_prob.sum().backward()
+            eng_grads[tag] = {n: p.grad.detach().float().clone() for n, p in mod.named_parameters() if p.requires_grad}
+        _lib.check(lib.mi355_tune_set(27, 1))
+        _, g_ref = _oracle_loss(mod, cfg, inp, 1.0, t, t_next, eta, smax, 0.0, device="cuda")
+        _, g_a = _oracle_loss(mod, cfg, inp, 1.0, t, t_next, eta, smax, 0.0, quant=M.bf16_round, device="cuda")
+        _, g_b = _oracle_loss(mod, cfg, inp, 1.0, t, t_next, eta, smax, 0.0, quant=M.bf16_round, attn_quant=M.bf16_round, device="cuda")
+        rms = {n: float(g_ref[n].float().pow(2).mean().sqrt()) for n in g_ref}
+        typical = sorted(rms.values())[len(rms) // 2]
+        names = [n for n in g_ref if rms[n] >= 1e-4 * typical]                 # (null exact gradients carry no value to compare)
+        table = {}
+        for tag, gr in eng_grads.items():
+            worst = dict(r=0.0, ra=0.0, rb=0.0, name=None)
+            for n in names:
+                r, ba, bb = _rel(gr[n], g_ref[n]), _rel(g_a[n], g_ref[n]), _rel(g_b[n], g_ref[n])
+                if r > worst["r"]:
+                    worst.update(r=r, name=n, band_a_there=ba, band_b_there=bb)
+                worst["ra"], worst["rb"] = max(worst["ra"], r / ba), max(worst["rb"], r / bb)
+            table[tag] = worst
+            print(f"gradient noise, engine {tag:10s}: worst rel-L2 vs fp32 autograd {worst['r']:.3e} ({worst['name']}; band A there {worst['band_a_there']:.3e}, "
+                  f"band B there {worst['band_b_there']:.3e}); worst ratio to band A {worst['ra']:.2f}, to band B (A + flash-internal bf16 P / dP) {worst['rb']:.2f}")
+        band_a = max(_rel(g_a[n], g_ref[n]) for n in names)
+        band_b = max(_rel(g_b[n], g_ref[n]) for n in names)
+        dsplit = max(_rel(eng_grads["split_k_1"][n], eng_grads["default"][n]) for n in names)
+        print(f"gradient noise: worst band A {band_a:.3e}, worst band B {band_b:.3e} (B / A = {band_b / band_a:.2f}); split-K = 1 vs default: "
+              f"max rel-L2 between the engine's own gradients {dsplit:.2e}")
+        assert dsplit < 1e-5, dsplit                                    # split-K partials are fp32: reassociation only
+        assert band_b > band_a                                          # the flash-internal rounding is a real, separate noise source
+        assert table["default"]["rb"] < 2.0, table                     # against the band of a bf16 run WITH a flash kernel (measured: see profiles/r06*)
+    finally:
+        lib.mi355_tune_set(27, 1)
+        ad.engine.close()
