@@ -69,7 +69,7 @@ for d in sorted(glob.glob(os.path.join(out, "prof_pmc_*"))):
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k][r["Counter_Name"]] += 1
     print("== PMC", os.path.basename(d))
-    for k in sorted(acc, key=lambda k: -sum(acc[k].values()))[:12]:
+    for k in sorted(acc, key=lambda k: -sum(acc[k].values()))[:40]:
         per = {c: acc[k][c] / cnt[k][c] for c in acc[k]}
         print(f"  {k:34s} launches={max(cnt[k].values()):6d} per-launch: " + ", ".join(f"{c}={v:.4g}" for c, v in per.items()))
         summary.setdefault(k, {}).update({c: v for c, v in per.items()})
