@@ -243,14 +243,18 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* in, long l
                     if (gc + e < cols) u[e >> 1] |= (unsigned)ib[(long)gr * ld_in + gc + e] << ((e & 1) * 16);
                 v = make_uint4(u[0], u[1], u[2], u[3]);
             }
-            *(uint4*)&tile[r][ch * 8] = v;
+            // Round 6: the 8-column chunk index is XORed with the row's group (r >> 3).  The transposed read below has the 8 lanes of an output
+            // line walk rows 8 apart -- 8 x 144 bytes = 288 dwords = 0 mod 32 banks: an 8-way conflict on every 2-byte read
+            // (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.78, LDS issue stalls 22 % of the kernel's wave cycles: profiles/r06f_pmc_*);
+            // with the swizzle those lanes sit 4 dwords apart.  Pure layout: same values to the same places.
+            *(uint4*)&tile[r][(ch ^ (r >> 3)) * 8] = v;
         }
         __syncthreads();
         if (colpart) {      // 4 threads per column, 16 rows each
             const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
             float cs = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cs += bf2f(tile[q * 16 + r][c]);
+            for (int r = 0; r < 16; ++r) cs += bf2f(tile[q * 16 + r][(c & 7) | ((((c >> 3) ^ ((q * 16 + r) >> 3)) & 7) << 3)]);
             csum[q][c] = cs;
         }
         // out row = input column c, 8 consecutive input rows per 16-byte store
@@ -260,8 +264,9 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* in, long l
             const int c = c0 + 32 * pass, gc = tc + c, gr = tr + rc * 8;
             if (gc < cols && gr < rows_pad) {
                 unsigned u[4];
+                const int cs_ = (c & 7) | ((((c >> 3) ^ rc) & 7) << 3);          // rows rc * 8 .. rc * 8 + 7 all have row group rc
 #pragma unroll
-                for (int e = 0; e < 4; ++e) u[e] = (unsigned)tile[rc * 8 + 2 * e][c] | ((unsigned)tile[rc * 8 + 2 * e + 1][c] << 16);
+                for (int e = 0; e < 4; ++e) u[e] = (unsigned)tile[rc * 8 + 2 * e][cs_] | ((unsigned)tile[rc * 8 + 2 * e + 1][cs_] << 16);
                 if (gr + 8 <= rows_pad) *(uint4*)(ob + (long)gc * ld_out + gr) = make_uint4(u[0], u[1], u[2], u[3]);
                 else {
 #pragma unroll

@@ -443,7 +443,13 @@ def test_config_a_replay_gradients_vs_oracle_autograd(full):
             if abs(alpha - 1) > worst_alpha:
                 worst_alpha, worst_alpha_name = abs(alpha - 1), name
             assert abs(alpha - 1) < (5e-3 if gr.numel() >= 4096 else 1.5e-2), (name, alpha, r, band)
-            assert r < 3.0 * band + 5e-3, (name, r, band)
+            # Round 6 (test_config_a_gradient_noise_has_a_named_cause, profiles/r06f_*): by tensor class the engine sits at 1.04 x (weights) and
+            # 1.11 x (biases) the band; the ONE class above that is the key-projection biases (worst 1.74 x: attn2.to_k.bias of block 12, a
+            # gradient 0.12 x the typical rms).  Softmax is invariant to a common shift of a query's scores, so a key bias acts only through the
+            # key RMSNorm: its gradient is the small remainder of column sums that nearly cancel, and the rounding noise of the summands is
+            # divided by that remainder.  Hence 1.5 x band for everything else (was 3 x), 3 x band for the key biases.
+            key_bias = name.endswith("to_k.bias") or name.endswith("add_k_proj.bias")
+            assert r < (3.0 if key_bias else 1.5) * band + 5e-3, (name, r, band)
             assert r < 6e-2 and _cos(prm.grad, g_ref[name]) > 0.99, (name, r)
         print(f"full SD3.5-medium replay gradients: {n} tensors ({n_null} with a null exact gradient, checked absolutely), worst rel-L2 vs "
               f"fp32 oracle autograd {worst:.3e} ({worst_name}), best-fit scale within {worst_alpha:.2e} of 1 ({worst_alpha_name}); "
