@@ -943,13 +943,14 @@ hipError_t launch_rms_dw_finish(const float* part, int nwg, float q_scale, float
     return hipGetLastError();
 }
 
-hipError_t launch_colsum(const bf16_t* dy, long ld, long M, int N, float* scratch, float* out, int accumulate, hipStream_t st) {
+hipError_t launch_colsum(const bf16_t* dy, long ld, long M, int N, float* scratch, float* out, int accumulate, hipStream_t st, int* deferred_nslab) {
     if (M <= 0 || N <= 0 || !scratch || !out) return hipErrorInvalidValue;
     if (sched_trace_on())       // accumulate: `out` is read as well (a read-after-write dependency the happens-before checker must see)
-        sched_trace_launch("colsum", st, {treg(dy, ((size_t)(M - 1) * ld + N) * 2), treg(out, accumulate ? (size_t)N * grad_buf_esize(out) : 0)},
-                           {treg(scratch, (size_t)64 * N * 4), treg(out, (size_t)N * grad_buf_esize(out))});
+        sched_trace_launch("colsum", st, {treg(dy, ((size_t)(M - 1) * ld + N) * 2), treg(out, accumulate && !deferred_nslab ? (size_t)N * grad_buf_esize(out) : 0)},
+                           {treg(scratch, (size_t)64 * N * 4), treg(out, deferred_nslab ? 0 : (size_t)N * grad_buf_esize(out))});
     const int nslab = (int)(M >= 8192 ? 64 : (M + 127) / 128);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((N + 255) / 256, nslab), dim3(256), 0, st, dy, ld, M, N, scratch, nslab);
+    if (deferred_nslab) { *deferred_nslab = nslab; return hipGetLastError(); }
     if (grad_buf_dtype(out) == DT_BF16) hipLaunchKernelGGL(colsum_finish_kernel<true>, dim3((N + 31) / 32), dim3(256), 0, st, scratch, nslab, N, (void*)out, accumulate);
     else hipLaunchKernelGGL(colsum_finish_kernel<false>, dim3((N + 31) / 32), dim3(256), 0, st, scratch, nslab, N, (void*)out, accumulate);
     return hipGetLastError();

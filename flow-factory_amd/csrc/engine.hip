@@ -120,6 +120,7 @@ static hipError_t sde_p(const SdeStepParams& s, hipStream_t st) { ProfScope ps(P
 
 // training-mode state (engine_train.inc, included at the end of this file)
 static int g_train_two_stream = 1;   // key 22, see engine_train.inc
+static int g_wgrad_tn = 1;           // key 39: weight gradients of whole-tile shapes on the row-major-operand kernel (gemm_tn.hip): no dY^T / X^T copies
 static int g_fuse_colsum = 1;        // key 38: bias-gradient column-sum finish inside the weight gradient's split-K reduction launch (engine_train.inc: wgrad)
 struct mi355_engine;
 struct mi355_plan;
@@ -1084,6 +1085,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 36) { set_mid_mask(value); return 0; }          // launch classes it may take (1 gated residual K < 3072, 2 K >= 3072, 4 V^T, 8 the rest)
     if (key == 37) { set_mid_max_tiles(value); return 0; }     // largest grid of its tiles
     if (key == 35) { set_mid_stagger(value); return 0; }       // its per-wave staggered LDS-DMA issue slots: 1 on (default), 0 off
+    if (key == 39) { g_wgrad_tn = value; return 0; }           // optimize() backward: 1 (default) = weight-gradient GEMMs read dY / X row-major through transposed LDS reads, 0 = transposed copies
     if (key == 38) { g_fuse_colsum = value; return 0; }        // optimize() backward: 1 (default) = column-sum finish fused into the split-K reduction launch, 0 = two launches
     if (key == 22) { g_train_two_stream = value; return 0; }   // optimize() replay: the context-stream chain of the training forward / backward on a side stream (1 = default)
     if (key == 21) { set_attn128_op_bound(value); return 0; }  // mi355_op_attention128: the |score| bound the caller asserts (0 = none)          // default GEMM dispatch: largest K for the 4-wave hand-scheduled kernel
@@ -1110,6 +1112,29 @@ extern "C" int mi355_op_linear_gate_res(void* stream, const void* A, const void*
     GemmParams g = gp((const bf16_t*)A, K, (const bf16_t*)W, K, M, N, K, EPI_GATE_RES, bias, (bf16_t*)x, N);
     g.aux = (const bf16_t*)gate; g.ld_aux = N; g.rows_per_sample = rows_per_sample;
     HIPCHK(launch_gemm(g, (hipStream_t)stream));
+    return 0;
+}
+
+// weight-gradient product as an operator (unit tests / A/B scripts): variant 1 = gemm_tn.hip on the row-major operands, variant 0 = the
+// transposed-copy path (launch_transpose x 2 + the K-contiguous EPI_F32 GEMM).  Output: k_split fp32 partial slabs [N][K].
+extern "C" int mi355_op_wgrad(void* stream, const void* dY, int64_t ld_dy, const void* X, int64_t ld_x, float* out, int M, int N, int K, int k_split,
+                              int variant, void* scratch) {
+    if (!dY || !X || !out || M <= 0 || N <= 0 || K <= 0 || k_split < 1) return fail("mi355_op_wgrad: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (variant == 1) {
+        GemmTnParams tp{(const bf16_t*)dY, (long)ld_dy, (const bf16_t*)X, (long)ld_x, M, N, K, out, (long)K, k_split, (long)N * K};
+        if (!gemm_tn_ok(tp)) return fail("mi355_op_wgrad: the row-major-operand kernel needs M %% 64 == 0, N %% 128 == 0, K %% 128 == 0, 16-byte aligned rows");
+        HIPCHK(launch_gemm_tn(tp, st));
+        return 0;
+    }
+    if (!scratch) return fail("mi355_op_wgrad: variant 0 needs (N + K) * M bf16 of scratch");
+    bf16_t* aT = (bf16_t*)scratch;
+    bf16_t* xT = aT + (size_t)N * M;
+    HIPCHK(launch_transpose((const bf16_t*)dY, (long)ld_dy, 0, aT, M, 0, M, N, M, 1, st));
+    HIPCHK(launch_transpose((const bf16_t*)X, (long)ld_x, 0, xT, M, 0, M, K, M, 1, st));
+    GemmParams g = gp(aT, M, xT, M, N, K, M, EPI_F32, nullptr, nullptr, K);
+    g.q_scale = 1.0f; g.out_f32 = out; g.k_split = k_split; g.split_stride = (long)N * K;
+    HIPCHK(launch_gemm(g, st));
     return 0;
 }
 

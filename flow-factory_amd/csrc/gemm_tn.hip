@@ -1,0 +1,193 @@
+// mi355_flow -- weight-gradient GEMM on ROW-MAJOR operands (round 6):
+//
+//   dW[n][k] = sum_m dY[m][n] * X[m][k]        dY: [M][lda] (n contiguous), X: [M][ldb] (k contiguous), bf16;  dW fp32 [N][ldo]
+//
+// The reduction index m is the ROW index of both operands.  Rounds 2-5 fed this product to the K-contiguous kernel of gemm.hip through two
+// HBM-bound transposes per weight (dY^T, X^T: `transpose_kernel`, 392 launches = 4.6 ms of the 87 ms SD3.5 optimize() step, 3.8 %;
+// profiles/r05_final_sd3_train_step_default_set_kernel_stats.txt).  Here the row-major [64 m][128 cols] tiles are staged as they lie in HBM
+// and the MFMA fragments -- 8 consecutive m for one column -- are read out of them with `ds_read_b64_tr_b16` (per 16-lane group: a
+// [4 rows][16 columns] block, lane i receives column i; two reads per fragment), the idiom of attention_bwd.hip.  Same
+// v_mfma_f32_16x16x32_bf16, same operand order (X fragment first), same ascending-m accumulation and the same split boundaries as the
+// transposed-copy path: the fp32 partial sums are BIT-IDENTICAL to it (tests/test_gpu_backward.py).
+//
+//   * tile 128 (n) x 128 (k) x 64 (m), 4 waves 2 x 2, wave tile 64 x 64 (acc[4][4] f32x4), 2 LDS stages of 32 KiB, two workgroups per CU;
+//   * LDS rows are 256 B; the 32-byte chunk index of a row is XORed with s(row) = (row & 3) | ((row >> 3) & 1) << 2, applied on the
+//     SOURCE address of the LDS-DMA and on the read address: the 8 rows a 32-lane half of a transposed read touches (4 rows of two k-groups
+//     8 rows apart) land in 8 distinct 32-byte bank groups;
+//   * the transposed reads and their MFMAs are one inline-assembly block per k-step with the fragments in FIXED registers (a fragment is two
+//     64-bit reads into the halves of one 4-register operand; and hipcc guards every LDS read it recognises with `s_waitcnt vmcnt(0)` while an
+//     LDS-DMA is in flight, which would drain the prefetch of the next m-tile);
+//   * split over m (k_split) into fp32 partial buffers like gemm_kernel<.., EPI_F32>; the caller reduces in fixed order (backward.hip).
+// Requirements (launcher): M % 64 == 0, N % 128 == 0, K % 128 == 0, lda / ldb multiples of 8, operands below 4 GiB.
+#include "kernels.h"
+
+namespace mi355 {
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int TM = 64;                       // m rows per tile
+constexpr int OP_BYTES = TM * 256;           // one operand tile: 64 rows x 128 columns bf16
+constexpr int STAGE = 2 * OP_BYTES;          // 32 KiB
+
+__device__ __forceinline__ int swz_row(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+#define TN_RD(dst, a, off) "ds_read_b64_tr_b16 " dst ", " a " offset:" #off "\n\t"
+#define TN_MFMA(c, w, x) "v_mfma_f32_16x16x32_bf16 " c ", " w ", " x ", " c "\n\t"
+// one k-step (32 m): 16 transposed reads into v[224:255] (x fragments i = 0..3 at v[224 + 4 i ..], w fragments j = 0..3 at v[240 + 4 j ..]),
+// then the 16 MFMAs of the 64 x 64 wave tile.  KOFF = byte offset of the k-step inside the operand tile (32 rows x 256 B).
+#define TN_STEP(KOFF, KOFF4)                                                                                                     \
+    asm volatile(                                                                                                                \
+        TN_RD("v[224:225]", "%[xa0]", KOFF) TN_RD("v[226:227]", "%[xa0]", KOFF4)                                                  \
+        TN_RD("v[240:241]", "%[wa0]", KOFF) TN_RD("v[242:243]", "%[wa0]", KOFF4)                                                  \
+        TN_RD("v[244:245]", "%[wa1]", KOFF) TN_RD("v[246:247]", "%[wa1]", KOFF4)                                                  \
+        TN_RD("v[248:249]", "%[wa2]", KOFF) TN_RD("v[250:251]", "%[wa2]", KOFF4)                                                  \
+        TN_RD("v[252:253]", "%[wa3]", KOFF) TN_RD("v[254:255]", "%[wa3]", KOFF4)                                                  \
+        TN_RD("v[228:229]", "%[xa1]", KOFF) TN_RD("v[230:231]", "%[xa1]", KOFF4)                                                  \
+        TN_RD("v[232:233]", "%[xa2]", KOFF) TN_RD("v[234:235]", "%[xa2]", KOFF4)                                                  \
+        TN_RD("v[236:237]", "%[xa3]", KOFF) TN_RD("v[238:239]", "%[xa3]", KOFF4)                                                  \
+        "s_waitcnt lgkmcnt(6)\n\t"                                                                                               \
+        TN_MFMA("%[c00]", "v[240:243]", "v[224:227]") TN_MFMA("%[c01]", "v[244:247]", "v[224:227]")                               \
+        TN_MFMA("%[c02]", "v[248:251]", "v[224:227]") TN_MFMA("%[c03]", "v[252:255]", "v[224:227]")                               \
+        "s_waitcnt lgkmcnt(4)\n\t"                                                                                               \
+        TN_MFMA("%[c10]", "v[240:243]", "v[228:231]") TN_MFMA("%[c11]", "v[244:247]", "v[228:231]")                               \
+        TN_MFMA("%[c12]", "v[248:251]", "v[228:231]") TN_MFMA("%[c13]", "v[252:255]", "v[228:231]")                               \
+        "s_waitcnt lgkmcnt(2)\n\t"                                                                                               \
+        TN_MFMA("%[c20]", "v[240:243]", "v[232:235]") TN_MFMA("%[c21]", "v[244:247]", "v[232:235]")                               \
+        TN_MFMA("%[c22]", "v[248:251]", "v[232:235]") TN_MFMA("%[c23]", "v[252:255]", "v[232:235]")                               \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                               \
+        TN_MFMA("%[c30]", "v[240:243]", "v[236:239]") TN_MFMA("%[c31]", "v[244:247]", "v[236:239]")                               \
+        TN_MFMA("%[c32]", "v[248:251]", "v[236:239]") TN_MFMA("%[c33]", "v[252:255]", "v[236:239]")                               \
+        : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c02] "+v"(acc[0][2]), [c03] "+v"(acc[0][3]), [c10] "+v"(acc[1][0]),       \
+          [c11] "+v"(acc[1][1]), [c12] "+v"(acc[1][2]), [c13] "+v"(acc[1][3]), [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]),       \
+          [c22] "+v"(acc[2][2]), [c23] "+v"(acc[2][3]), [c30] "+v"(acc[3][0]), [c31] "+v"(acc[3][1]), [c32] "+v"(acc[3][2]),       \
+          [c33] "+v"(acc[3][3])                                                                                                    \
+        : [xa0] "v"(xa[0]), [xa1] "v"(xa[1]), [xa2] "v"(xa[2]), [xa3] "v"(xa[3]), [wa0] "v"(wa[0]), [wa1] "v"(wa[1]), [wa2] "v"(wa[2]), \
+          [wa3] "v"(wa[3])                                                                                                         \
+        : "memory", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237",  \
+          "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252",  \
+          "v253", "v254", "v255")
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;          // wave tile: output rows (n of dY) 64 wm .., output columns (k of X) 64 wn ..
+
+    // ---- tile mapping (XCD-aware, as gemm_kernel): blocks of one split first
+    const int ntn = p.N / 128, ntk = p.K / 128;
+    const int nsplit = p.k_split > 1 ? p.k_split : 1;
+    const int nblk = ntn * ntk * nsplit;
+    int bid = blockIdx.x;
+    {
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    }
+    const int split = bid / (ntn * ntk);
+    bid -= split * (ntn * ntk);
+    const int tn = bid / ntk, tk = bid - tn * ntk;
+    const int n0 = tn * 128, k0 = tk * 128;
+
+    // ---- LDS-DMA: one instruction = 4 rows x 256 B; group g (16 per operand tile) belongs to wave g & 3.  Lane -> (row l >> 4 of the
+    // group, physical 16-byte chunk l & 15); the physical 32-byte chunk pc holds the logical chunk pc ^ s(row).
+    unsigned soffA[4], soffB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = wave + 4 * i;
+        const int row = g * 4 + (lane >> 4);
+        const int c32 = ((lane & 15) >> 1) ^ swz_row(row);
+        const int col = c32 * 16 + (lane & 1) * 8;
+        soffA[i] = ((unsigned)row * (unsigned)p.lda + (unsigned)(n0 + col)) * 2u;
+        soffB[i] = ((unsigned)row * (unsigned)p.ldb + (unsigned)(k0 + col)) * 2u;
+    }
+    auto stage = [&](int mt, int buf) {
+        char* base = smem + buf * STAGE;
+        const char* ga = (const char*)p.A + (long)mt * TM * p.lda * 2;      // wave-uniform
+        const char* gb = (const char*)p.B + (long)mt * TM * p.ldb * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = wave + 4 * i;
+            __builtin_amdgcn_global_load_lds((gptr_t)(ga + soffA[i]), (lptr_t)(base + g * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(gb + soffB[i]), (lptr_t)(base + OP_BYTES + g * 1024), 16, 0, 0);
+        }
+    };
+
+    // ---- transposed-read addresses: lane (r = l & 15, kg = l >> 4) of 16-column block b supplies the 8-byte piece
+    // (row kg * 8 [+ 4 for the second read] + (r >> 2), columns 16 b + 4 (r & 3) ..) and receives column r of the 4-row block.
+    const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem);
+    const int r = lane & 15, kg = lane >> 4;
+    const int rrow = kg * 8 + (r >> 2);
+    const int sw = swz_row(rrow);                    // (unchanged by the + 4 of the second read and the + 32 of the second k-step)
+    unsigned xa_s[2][4], wa_s[2][4];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            xa_s[st][b] = lds0 + st * STAGE + rrow * 256 + (((wm * 4 + b) ^ sw) << 5) + (r & 3) * 8;
+            wa_s[st][b] = lds0 + st * STAGE + OP_BYTES + rrow * 256 + (((wn * 4 + b) ^ sw) << 5) + (r & 3) * 8;
+        }
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt_all = p.M / TM;
+    const int mt0 = (int)((long)nt_all * split / nsplit);
+    const int nt = (int)((long)nt_all * (split + 1) / nsplit) - mt0;
+    if (nt > 0) stage(mt0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();          // tile t landed for every wave; everyone is done reading the other buffer
+        if (t + 1 < nt) stage(mt0 + t + 1, (t + 1) & 1);
+        unsigned xa[4], wa[4];
+        if (t & 1) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { xa[b] = xa_s[1][b]; wa[b] = wa_s[1][b]; }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { xa[b] = xa_s[0][b]; wa[b] = wa_s[0][b]; }
+        }
+        TN_STEP(0, 1024);           // m rows  0 .. 31 of the tile (second read of a fragment: + 4 rows = 1024 B)
+        TN_STEP(8192, 9216);        // m rows 32 .. 63
+    }
+
+    // ---- epilogue: fp32 partial sums straight from the accumulator layout: acc[i][j][e] = C[n0 + 64 wm + 16 i + r][k0 + 64 wn + 16 j + 4 kg + e]
+    float* ob = p.out + (long)split * p.split_stride;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wm * 64 + i * 16 + r, k = k0 + wn * 64 + j * 16 + 4 * kg;
+            *(float4*)(ob + (long)n * p.ldo + k) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+}
+
+}  // namespace
+
+bool gemm_tn_ok(const GemmTnParams& p) {
+    return p.M > 0 && p.M % TM == 0 && p.N % 128 == 0 && p.K % 128 == 0 && (p.lda & 7) == 0 && (p.ldb & 7) == 0 && (p.ldo & 3) == 0 &&
+           ((size_t)p.M * (size_t)p.lda) * 2 < (1ull << 32) && ((size_t)p.M * (size_t)p.ldb) * 2 < (1ull << 32) &&
+           (((size_t)p.A | (size_t)p.B | (size_t)p.out) & 15) == 0;
+}
+
+hipError_t launch_gemm_tn(const GemmTnParams& p, hipStream_t stream) {
+    if (!gemm_tn_ok(p) || !p.A || !p.B || !p.out) return hipErrorInvalidValue;
+    if (sched_trace_on())
+        sched_trace_launch("gemm_tn", stream, {treg(p.A, ((size_t)(p.M - 1) * p.lda + p.N) * 2), treg(p.B, ((size_t)(p.M - 1) * p.ldb + p.K) * 2)},
+                           {treg(p.out, (((size_t)(p.N - 1) * p.ldo + p.K) + (size_t)(p.k_split > 1 ? p.k_split - 1 : 0) * p.split_stride) * 4)});
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int nsplit = p.k_split > 1 ? p.k_split : 1;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((p.N / 128) * (p.K / 128) * nsplit), dim3(256), 2 * STAGE, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace mi355

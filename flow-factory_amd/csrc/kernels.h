@@ -76,6 +76,17 @@ struct GemmParams {
     int dbg_skip_prefetch;    // debug ablation: the K-loop prefetches are not issued (results are garbage)
 };
 
+// weight-gradient GEMM on row-major operands (gemm_tn.hip): out[n][k] (fp32, + split * split_stride) = sum_m A[m][n] * B[m][k]
+struct GemmTnParams {
+    const bf16_t* A; long lda;        // dY [M][lda], the N columns of interest starting at A
+    const bf16_t* B; long ldb;        // X  [M][ldb], K columns
+    int M, N, K;
+    float* out; long ldo;             // fp32 [N][ldo]
+    int k_split; long split_stride;   // split over m, like GemmParams
+};
+bool gemm_tn_ok(const GemmTnParams& p);
+hipError_t launch_gemm_tn(const GemmTnParams& p, hipStream_t stream);
+
 // ---- launch-schedule trace (sched_trace.hip; off unless mi355_sched_trace(1)): every launch_* / event call reports (stream, regions)
 struct TraceRegion { const void* p; size_t len; size_t stride; size_t count; };     // `count` blocks of `len` bytes, `stride` apart
 inline TraceRegion treg(const void* p, size_t len) { return TraceRegion{p, len, 0, 1}; }
@@ -315,7 +326,8 @@ hipError_t launch_rms_dw_finish(const float* part, int nwg, float q_scale, float
 int rms_bwd_grid(int B, int S);
 hipError_t launch_rms_bwd_gather(const RmsBwdParams& p, hipStream_t stream);
 // out[n] (+)= sum_m dy[m][n]; scratch >= 64 * N floats
-hipError_t launch_colsum(const bf16_t* dy, long ld, long M, int N, float* scratch, float* out, int accumulate, hipStream_t stream);
+hipError_t launch_colsum(const bf16_t* dy, long ld, long M, int N, float* scratch, float* out, int accumulate, hipStream_t stream,
+                         int* deferred_nslab = nullptr);      // non-null: only the slab partials; *deferred_nslab slabs are left for the caller's finish
 hipError_t launch_splitk_reduce(const float* part, long stride, int nsplit, float* out, long n, int accumulate, hipStream_t stream);
 // gradient-buffer dtype registry (backward.hip): launch_splitk_reduce / launch_colsum / launch_transpose_colsum write bf16 into an output
 // pointer marked DT_BF16 (the pointer is still passed as float*); DT_F32 un-marks

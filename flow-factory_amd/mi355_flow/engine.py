@@ -495,6 +495,21 @@ def op_linear_gate_res(x: torch.Tensor, a: torch.Tensor, w: torch.Tensor, bias: 
     return x
 
 
+def op_wgrad(dy: torch.Tensor, x: torch.Tensor, k_split: int = 1, variant: int = 1) -> torch.Tensor:
+    """Weight-gradient partial sums [k_split, N, K] (fp32) of dW = dy^T @ x over `k_split` slices of the M rows; dy [M, N] and x [M, K] bf16
+    row-major (rows may be strided views: the row stride is passed).  variant 1 = the row-major-operand kernel (csrc/gemm_tn.hip), 0 = the
+    transposed-copy path; both return the same bits."""
+    lib = _lib.load()
+    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(1) == 1 and x.stride(1) == 1 and dy.shape[0] == x.shape[0]
+    M, N = dy.shape
+    K = x.shape[1]
+    out = torch.empty((k_split, N, K), device=dy.device, dtype=torch.float32)
+    scratch = torch.empty(((N + K) * M,), device=dy.device, dtype=torch.bfloat16) if variant == 0 else None
+    _lib.check(lib.mi355_op_wgrad(_stream(), _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(out), M, N, K, k_split, variant,
+                                  _ptr(scratch) if scratch is not None else None), "op_wgrad")
+    return out
+
+
 def op_attention(q: torch.Tensor, k: torch.Tensor, vT: torch.Tensor, S: int, n_img: int):
     """q,k: [B,H,S_pad,64] bf16; vT: [B,H,64,S_pad] bf16 -> (o_img [B*n_img, H*64], o_ctx [B*(S-n_img), H*64])."""
     lib = _lib.load()

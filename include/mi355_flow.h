@@ -193,6 +193,13 @@ int mi355_op_linear(void* stream, const void* A, const void* W, const float* bia
  * JointTransformerBlock.forward, reached from models/stable_diffusion/sd3_5.py:421-428) as an operator */
 int mi355_op_linear_gate_res(void* stream, const void* A, const void* W, const float* bias, const void* gate, void* x, int M, int N, int K,
                              int rows_per_sample);
+/* Weight-gradient product on ROW-MAJOR operands (round 6, csrc/gemm_tn.hip): out[s][n][k] (fp32, [k_split][N][K]) = sum over the s-th slice of
+ * the M rows of dY[m][n] * X[m][k]; dY [M][ld_dy] and X [M][ld_x] bf16 as the backward leaves them in HBM -- no transposed copies (reference: the
+ * weight gradients `accelerator.backward(loss)` produces for the trainable linear layers, trainers/grpo.py:326-330).  M % 64, N % 128, K % 128
+ * must be 0.  variant 0 = the transposed-copy path of rounds 2-5 (two transposes + the K-contiguous GEMM; scratch: (N + K) * M bf16) for A/B
+ * tests: both variants give the same bits. */
+int mi355_op_wgrad(void* stream, const void* dY, int64_t ld_dy, const void* X, int64_t ld_x, float* out, int M, int N, int K, int k_split,
+                   int variant, void* scratch);
 /* debug: mi355_op_linear (act 0) that also records s_memtime stamps per workgroup / tile / wave-group:
  * trace[((wg*16 + tile_iter)*2 + group)*4 + {0: tile start, 1: main loop start, 2: main loop end, 3: stores drained}] */
 int mi355_op_linear_trace(void* stream, const void* A, const void* W, const float* bias, void* out, int M, int N, int K,

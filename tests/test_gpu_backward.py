@@ -529,3 +529,76 @@ def test_two_grad_forwards_on_one_plan_before_a_single_backward(gpu):
     g_w = grads()
     assert max(_rel(g_w[n], g_seq[n]) for n in g_seq) > 1e-2
     ad.engine.close()
+
+
+# ------------------------------------------------------------------------------------------------- weight gradients on row-major operands
+@pytest.mark.parametrize("M,N,K,split,strided", [(64, 128, 128, 1, False), (128, 128, 256, 2, False), (4096, 1536, 1536, 4, False), (8192, 1536, 1536, 7, True),
+                                                 (8192, 1536, 6144, 3, False), (2048, 4608, 1536, 2, True), (320, 256, 128, 5, False)])
+def test_weight_gradient_gemm_on_row_major_operands_is_bit_identical_to_the_transposed_copy_path(gpu, M, N, K, split, strided):
+    """Round 6 (csrc/gemm_tn.hip, mi355_op_wgrad): dW = dY^T X with dY [M][N] and X [M][K] read as they lie in HBM -- the MFMA fragments (8
+    consecutive m for one column) come out of the row-major LDS tiles through `ds_read_b64_tr_b16` -- against the path of rounds 2-5 (two
+    transposed copies + the K-contiguous GEMM): the fp32 partial sums of every split are BIT-IDENTICAL (same MFMA, operand order, m order,
+    split boundaries), and both agree with torch's fp32 product of the same bf16 values.  `strided`: dY is a column block of a wider buffer
+    (the q | k | v gradients lie side by side, engine_train.inc) and X a view with a larger row stride."""
+    from mi355_flow import engine
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    if strided:
+        dy_full = torch.randn(M, N + 256, device="cuda", generator=g).bfloat16()
+        x_full = torch.randn(M, K + 64, device="cuda", generator=g).bfloat16()
+        dy, x = dy_full[:, 128:128 + N], x_full[:, :K]
+    else:
+        dy = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+        x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    a = engine.op_wgrad(dy, x, split, variant=1)
+    b = engine.op_wgrad(dy, x, split, variant=0)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b), float((a - b).abs().max())
+    for _ in range(3):                                    # (a staging race would show as a run-to-run difference)
+        assert torch.equal(engine.op_wgrad(dy, x, split, variant=1), a)
+    ref = dy.float().t() @ x.float()
+    got = a.sum(0)
+    assert _rel(got, ref) < 2e-5, _rel(got, ref)
+    with pytest.raises(RuntimeError):
+        engine.op_wgrad(dy[:M - 1], x[:M - 1], 1, variant=1)          # M not a multiple of 64: refused, never padded silently
+
+
+@pytest.mark.parametrize("bf16_master", [False, True])
+def test_replay_gradients_with_row_major_weight_gradient_gemms_equal_the_transposed_copy_path(gpu, bf16_master):
+    """The same switch inside the engine (`mi355_tune_set(39, .)`): every WEIGHT gradient of the optimize() replay is bit-identical with and
+    without the transposed copies; the bias gradients (column sums, taken by the slab kernel instead of on the way through the transpose) agree
+    to fp32 reassociation."""
+    from mi355_flow import _lib
+    lib = _lib.load()
+    ad, mod, cfg_o = _build(lambda n: any(k in n for k in BLOCK_LINEARS))
+    B, h, w, Nt = 2, 16, 16, 13                           # 128 image rows: whole 64-row tiles; 26 text rows: the transposed-copy path either way
+    inp = _inputs(B, h, w, Nt, seed=11)
+    ad.scheduler.set_timesteps(4)
+    kw = dict(t=torch.full((B,), 900.0), t_next=torch.full((B,), 750.0), latents=inp["x"].cuda(), next_latents=inp["x1"].cuda(),
+              prompt_embeds=inp["pe"].cuda(), pooled_prompt_embeds=inp["pp"].cuda(), guidance_scale=1.0, noise_level=0.7, compute_log_prob=True,
+              return_kwargs=["log_prob", "noise_pred", "dt"])
+    if bf16_master:
+        mod.bfloat16()
+        live = getattr(ad, "_live_weights", None)
+        if live is not None:
+            live.reset()
+    try:
+        grads = {}
+        for tn in (1, 0):
+            _lib.check(lib.mi355_tune_set(39, tn))
+            for p in mod.parameters():
+                p.grad = None
+            out = ad.forward(**kw)
+            ((inp["wlp"].cuda() * out.log_prob).sum() + 3.0 * (inp["wnp"].cuda() * out.noise_pred).mean()).backward()
+            grads[tn] = {n: p.grad.detach().clone() for n, p in mod.named_parameters() if p.requires_grad}
+        n_w = 0
+        for n, g1 in grads[1].items():
+            g0 = grads[0][n]
+            if n.endswith(".weight"):
+                assert torch.equal(g1, g0), n
+                n_w += int(float(g1.float().norm()) > 0)
+            else:
+                assert _rel(g1, g0) < (1e-2 if bf16_master else 1e-5), (n, _rel(g1, g0))
+        assert n_w >= 20
+    finally:
+        lib.mi355_tune_set(39, 1)
+        ad.engine.close()
