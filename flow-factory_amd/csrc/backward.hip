@@ -494,7 +494,27 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* dy, l
     const long lo = blockIdx.y * per, hi = lo + per < M ? lo + per : M;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (n0 + 8 <= N && (ld & 7) == 0) {
-        for (long m = lo + rl; m < hi; m += 8) {
+        // four rows in flight per lane, added in row order (round 6: with the transposed copies gone this kernel takes the bias gradients of
+        // the image stream -- one dependent 16-byte load per iteration left it latency-bound at 1.8 TB/s; same sums in the same order)
+        long m = lo + rl;
+        for (; m + 24 < hi; m += 32) {
+            const uint4 u0 = *(const uint4*)(dy + m * ld + n0), u1 = *(const uint4*)(dy + (m + 8) * ld + n0);
+            const uint4 u2 = *(const uint4*)(dy + (m + 16) * ld + n0), u3 = *(const uint4*)(dy + (m + 24) * ld + n0);
+            float a[8];
+            unpack8(u0, a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += a[e];
+            unpack8(u1, a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += a[e];
+            unpack8(u2, a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += a[e];
+            unpack8(u3, a);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += a[e];
+        }
+        for (; m < hi; m += 8) {
             float a[8];
             unpack8(*(const uint4*)(dy + m * ld + n0), a);
 #pragma unroll
@@ -824,7 +844,12 @@ hipError_t launch_ln_mod_bwd(const LnModBwdParams& p, hipStream_t st) {
     if (p.D % 8 != 0 || p.D > (p.dmod ? 8 : 12) * 64 * 8 || p.M <= 0) return hipErrorInvalidValue;
     const int rpw = p.dmod ? 16 : 1;         // rows per wave: 16 with the modulation-gradient partials in registers
     const int grid = (p.M + 4 * rpw - 1) / (4 * rpw);
-    if (p.D <= 2048) hipLaunchKernelGGL(ln_mod_bwd_kernel<4>, dim3(grid), dim3(256), 0, st, p, rpw);
+    // Without modulation gradients (the reference's default target sets: no trainable tensor upstream of the modulation table) the
+    // DMOD = false instantiation: the 4 x LN_MAXC x 8 partial-sum registers of the other form cost it its occupancy even when unused
+    // (round 6: one wave per row, 8192 latency-bound waves per launch -- resident waves per SIMD are what hides their four reductions)
+    if (!p.dmod && p.D <= 2048) hipLaunchKernelGGL((ln_mod_bwd_kernel<4, false>), dim3(grid), dim3(256), 0, st, p, rpw);
+    else if (!p.dmod && p.D <= 4096) hipLaunchKernelGGL((ln_mod_bwd_kernel<8, false>), dim3(grid), dim3(256), 0, st, p, rpw);
+    else if (p.D <= 2048) hipLaunchKernelGGL(ln_mod_bwd_kernel<4>, dim3(grid), dim3(256), 0, st, p, rpw);
     else if (p.D <= 4096) hipLaunchKernelGGL(ln_mod_bwd_kernel<8>, dim3(grid), dim3(256), 0, st, p, rpw);
     else hipLaunchKernelGGL((ln_mod_bwd_kernel<12, false>), dim3(grid), dim3(256), 0, st, p, rpw);
     return hipGetLastError();

@@ -500,12 +500,14 @@ def op_wgrad(dy: torch.Tensor, x: torch.Tensor, k_split: int = 1, variant: int =
     row-major (rows may be strided views: the row stride is passed).  variant 1 = the row-major-operand kernel (csrc/gemm_tn.hip), 0 = the
     transposed-copy path; both return the same bits."""
     lib = _lib.load()
-    assert dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(1) == 1 and x.stride(1) == 1 and dy.shape[0] == x.shape[0]
+    assert dy.is_cuda and x.is_cuda and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(1) == 1 and x.stride(1) == 1
+    assert dy.shape[0] == x.shape[0]
     M, N = dy.shape
     K = x.shape[1]
     out = torch.empty((k_split, N, K), device=dy.device, dtype=torch.float32)
     scratch = torch.empty(((N + K) * M,), device=dy.device, dtype=torch.bfloat16) if variant == 0 else None
-    _lib.check(lib.mi355_op_wgrad(_stream(), _ptr(dy), dy.stride(0), _ptr(x), x.stride(0), _ptr(out), M, N, K, k_split, variant,
+    C = __import__("ctypes")
+    _lib.check(lib.mi355_op_wgrad(_stream(), C.c_void_p(dy.data_ptr()), dy.stride(0), C.c_void_p(x.data_ptr()), x.stride(0), _ptr(out), M, N, K, k_split, variant,
                                   _ptr(scratch) if scratch is not None else None), "op_wgrad")
     return out
 
