@@ -418,13 +418,12 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
                     gsum[e] += __shfl_xor(gsum[e], 16, 64); gsq[e] += __shfl_xor(gsq[e], 16, 64);
                     gsum[e] += __shfl_xor(gsum[e], 32, 64); gsq[e] += __shfl_xor(gsq[e], 32, 64);
                 }
-                // channel-major partials [b][channel][chunk]{sum, sumsq}: the finalize kernel reads one contiguous run per channel
-                if (lane < 8 && m_base < p.M && n_base + lane * 8 + 8 <= p.N) {
+                if (lane < 8 && m_base < p.M) {
                     const long b = m_base / p.gn_hw;
                     const long chunk = (m_base - b * p.gn_hw) / (NR * 16), nchunk = p.gn_hw / (NR * 16);
-                    float2* dst = (float2*)p.gn_part + (b * p.N + n_base + lane * 8) * nchunk + chunk;
+                    float2* dst = (float2*)(p.gn_part + ((b * nchunk + chunk) * p.N + n_base + lane * 8) * 2);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) dst[e * nchunk] = make_float2(gsum[e], gsq[e]);
+                    for (int e = 0; e < 8; ++e) dst[e] = make_float2(gsum[e], gsq[e]);
                 }
             }
         }

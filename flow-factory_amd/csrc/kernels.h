@@ -70,7 +70,7 @@ struct GemmParams {
     // [s*nt/k_split, (s+1)*nt/k_split) into out_f32 + s * split_stride (deterministic second-stage reduction by the caller)
     int k_split; long split_stride;
     // GroupNorm statistics of the OUTPUT taken in the epilogue (implicit-conv instantiations of gemm_kernel, EPI_BIAS / EPI_POSADD, round 6):
-    // gn_part[((b * N + n) * (gn_hw / 64) + chunk) * 2 + {0: sum, 1: sum of squares}] (channel-major) over the 64 output rows of chunk `chunk` of sample b
+    // gn_part[((b * (gn_hw / 64) + chunk) * N + n) * 2 + {0: sum, 1: sum of squares}] over the 64 output rows of chunk `chunk` of sample b
     // (gn_hw rows per sample), of the bf16 values as stored.  Whole tiles only: M % 64 == 0, N % 64 == 0, ldo % 8 == 0 (launcher's caller).
     float* gn_part; long gn_hw;
     int raster_gm;            // tile rows per raster band (set by launch_gemm from the global knob)

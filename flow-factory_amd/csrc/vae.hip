@@ -107,38 +107,6 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* part, int
     }
 }
 
-// pass 2 for CHANNEL-MAJOR partials part[b][c][chunk]{sum, sumsq} (left by a convolution epilogue, GemmParams::gn_part): one workgroup per
-// (sample, group) walks its cpg contiguous runs of nchunk float2 -- coalesced; same double-precision fixed-order reduction
-__global__ __launch_bounds__(256) void gn_finalize_cm_kernel(const float* part, int nchunk, int C, int groups, long HW, float eps,
-                                                             const float* gamma, const float* beta, float* ad /*[B][2][C]*/) {
-    __shared__ double red[2][4];
-    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cpg = C / groups;
-    double s = 0.0, ss = 0.0;
-    const float2* run = (const float2*)part + ((long)b * C + (long)g * cpg) * nchunk;      // cpg * nchunk consecutive float2
-    const long n = (long)cpg * nchunk;
-    for (long i = tid; i < n; i += 256) {
-        const float2 v = run[i];
-        s += (double)v.x; ss += (double)v.y;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
-    if (lane == 0) { red[0][wave] = s; red[1][wave] = ss; }
-    __syncthreads();
-    s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    ss = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-    const double cnt = (double)HW * cpg;
-    const double mean = s / cnt;
-    double var = ss / cnt - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    for (int c = g * cpg + tid; c < (g + 1) * cpg; c += 256) {
-        const float a = rstd * gamma[c];
-        ad[((long)b * 2 + 0) * C + c] = a;
-        ad[((long)b * 2 + 1) * C + c] = beta[c] - (float)mean * a;
-    }
-}
-
 // pass 3: y = x*a + d, optional SiLU, bf16
 template <bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* x, bf16_t* y, const float* ad, long HW, int C, long rows_per_chunk) {
@@ -378,7 +346,7 @@ hipError_t launch_group_norm(const bf16_t* x, bf16_t* y, const float* gamma, con
     rpc = (rpc + rpi - 1) / rpi * rpi;
     if (ready_part && ready_nchunk > 0) {
         // round 6: the convolution that produced x left the per-64-row channel partials in its epilogue: no statistics pass over x
-        hipLaunchKernelGGL(gn_finalize_cm_kernel, dim3(groups, B), dim3(256), 0, st, ready_part, ready_nchunk, C, groups, HW, eps, gamma, beta, ad);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, st, ready_part, ready_nchunk, C, groups, HW, eps, gamma, beta, ad);
     } else {
         hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, part, HW, C, rpc);
         hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, st, part, nchunk, C, groups, HW, eps, gamma, beta, ad);

@@ -205,11 +205,7 @@ def test_group_norm_statistics_taken_in_the_convolution_epilogue_match_the_stati
         d = (out[1] - out[0]).abs()
         scale = float(out[0].abs().mean())
         print(f"VAE decode, GroupNorm statistics fused vs statistics kernel: max |diff| {float(d.max()):.3e}, mean {float(d.mean()):.3e} (image mean-abs {scale:.3e})")
-        # two bf16 chains of ~20 layers whose GroupNorm statistics differ in the last fp32 bits: roundings flip here and there and the
-        # differences propagate (the engine-vs-oracle tests above allow 2e-2 for the same reason); a wrong statistic is O(1)
-        rel = float((out[1] - out[0]).norm() / out[0].norm())
-        print(f"  rel-L2 {rel:.3e}")
-        assert torch.isfinite(out[1]).all() and rel < 2e-2
+        assert torch.isfinite(out[1]).all() and float(d.mean()) < 2e-3 * scale and float(d.max()) < 0.1 * max(scale, 1e-3) + 2e-2
     finally:
         lib.mi355_tune_set(40, 1)
         dec.close()
