@@ -1085,7 +1085,6 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 36) { set_mid_mask(value); return 0; }          // launch classes it may take (1 gated residual K < 3072, 2 K >= 3072, 4 V^T, 8 the rest)
     if (key == 37) { set_mid_max_tiles(value); return 0; }     // largest grid of its tiles
     if (key == 35) { set_mid_stagger(value); return 0; }       // its per-wave staggered LDS-DMA issue slots: 1 on (default), 0 off
-    if (key == 40) { set_vae_gn_fused(value); return 0; }      // VAE decode: 1 (default) = GroupNorm statistics taken in the producing convolution's epilogue, 0 = the statistics kernel
     if (key == 39) { g_wgrad_tn = value; return 0; }           // optimize() backward: 1 (default) = weight-gradient GEMMs read dY / X row-major through transposed LDS reads, 0 = transposed copies
     if (key == 38) { g_fuse_colsum = value; return 0; }        // optimize() backward: 1 (default) = column-sum finish fused into the split-K reduction launch, 0 = two launches
     if (key == 22) { g_train_two_stream = value; return 0; }   // optimize() replay: the context-stream chain of the training forward / backward on a side stream (1 = default)

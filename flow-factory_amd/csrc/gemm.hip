@@ -111,9 +111,8 @@ __device__ __forceinline__ void unpatch_store(const GemmParams& p, int m, int n,
 // writes / read-modify-writes whole 128-byte lines, 16 bytes per lane.
 //   phase 1 (accumulator layout, fp32): + bias, per-head RMSNorm (q/k), SiLU / GELU  -> bf16 -> LDS
 //   phase 2 (row layout, 8 columns per lane): + pos-embed / + src, gated residual, scatter -> HBM
-// (returns the 8 bf16 values it stored -- meaningful on the 16-byte-vector paths only: the GroupNorm-statistics epilogue reads them back)
 template <int EPI, bool FULL>
-__device__ __forceinline__ uint4 store_row8(const GemmParams& p, int m, int n, int n_wave, uint4 val) {
+__device__ __forceinline__ void store_row8(const GemmParams& p, int m, int n, int n_wave, uint4 val) {
     const bool full = FULL || (n + 8 <= p.N);
     float y[8] = {bf_lo(val.x), bf_hi(val.x), bf_lo(val.y), bf_hi(val.y), bf_lo(val.z), bf_hi(val.z), bf_lo(val.w), bf_hi(val.w)};
     if constexpr (is_qk_epi(EPI)) {
@@ -124,7 +123,7 @@ __device__ __forceinline__ uint4 store_row8(const GemmParams& p, int m, int n, i
         const int s = m - bi * p.rows_per_sample + p.s_off;
         bf16_t* dst = (is_k ? p.k : p.q) + (((long)bi * p.H + h) * p.S_pad + s) * 64 + (n - n_wave);
         *(uint4*)dst = val;
-        return val;
+        return;
     } else if constexpr (EPI == EPI_VT) {
         // m = feature, n.. = 8 tokens; head_dim 64 (hd_shift 0) or 1 << hd_shift
         const int hs = p.hd_shift ? p.hd_shift : 6;
@@ -144,7 +143,7 @@ __device__ __forceinline__ uint4 store_row8(const GemmParams& p, int m, int n, i
                 }
             }
         }
-        return val;
+        return;
     } else {
         bf16_t* op = p.out + (long)m * p.ldo + n;
         const bool vec = FULL || (full && ((p.ldo & 7) == 0));
@@ -183,14 +182,12 @@ __device__ __forceinline__ uint4 store_row8(const GemmParams& p, int m, int n, i
             if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_SILU || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_ROW) o = val;
             else o = make_uint4(pack_bf16(y[0], y[1]), pack_bf16(y[2], y[3]), pack_bf16(y[4], y[5]), pack_bf16(y[6], y[7]));
             *(uint4*)op = o;
-            return o;
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e)
                 if (n + e < p.N) op[e] = f2bf(y[e]);
         }
     }
-    return val;
 }
 
 // acc: NR*16 rows x 64 columns of the wave's tile, acc[i][j][e] = C[m_base + 16 i + (lane&15)][n_base + 16 j + 4 (lane>>4) + e];
@@ -203,10 +200,7 @@ struct BiasPre { float4 v[4]; };      // by value: a pointer to a caller's array
 // NJ (round 6): 16-column blocks of the chunk (4 = the 64-column chunk every kernel used so far; 2 = the 32-column tail of the mid-size
 //       kernel's 96-column wave tile).  The staging rows stay 128 bytes; with NJ < 4 only the first 2 NJ 16-byte slots of a row carry data and
 //       the row-layout phase masks the lanes of the others (they would touch the NEIGHBOURING wave's columns).
-// GNS (round 6, the implicit-convolution instantiations of gemm_kernel only): when p.gn_part is set, the per-channel sum / sum of squares of
-//       the chunk's rows -- of the bf16 values as stored -- go to the GroupNorm partial buffer (GemmParams::gn_part): the next GroupNorm skips its
-//       statistics pass over the tensor.  Fixed order (8 rows per lane, then a 3-step butterfly over the 8 row lanes): deterministic.
-template <int EPI, int NR, bool FULL = false, bool PRE = false, int NJ = 4, bool GNS = false>
+template <int EPI, int NR, bool FULL = false, bool PRE = false, int NJ = 4>
 __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (&acc)[NR][NJ], int m_base, int n_base,
                                               char* stg, int lane, BiasPre bpre = BiasPre()) {
     static_assert(NJ == 4 || (NJ == 2 && !is_qk_epi(EPI)), "a q/k head is one whole 64-column chunk");
@@ -391,41 +385,12 @@ __device__ __forceinline__ void epilogue_part(const GemmParams& p, const f32x4 (
         for (int it = 0; it < NR * 2; ++it)
             if (cok) store_row8<EPI, FULL>(p, m_base + it * 8 + (lane >> 3), n_base + (lane & 7) * 8, n_base, val[it]);
     } else {
-        float gsum[8], gsq[8];
-        if constexpr (GNS) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { gsum[e] = 0.f; gsq[e] = 0.f; }
-        }
 #pragma unroll
         for (int it = 0; it < NR * 2; ++it) {
             const int r = it * 8 + (lane >> 3), c = lane & 7;
             const uint4 val = *(const uint4*)(stg + r * 128 + ((c ^ (r & 7)) << 4));
             const int m = m_base + r;
-            if (cok && (FULL || m < p.M)) {
-                const uint4 o = store_row8<EPI, FULL>(p, m, n_base + c * 8, n_base, val);
-                if constexpr (GNS) {
-                    const float f[8] = {bf_lo(o.x), bf_hi(o.x), bf_lo(o.y), bf_hi(o.y), bf_lo(o.z), bf_hi(o.z), bf_lo(o.w), bf_hi(o.w)};
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { gsum[e] += f[e]; gsq[e] = __builtin_fmaf(f[e], f[e], gsq[e]); }
-                }
-            }
-        }
-        if constexpr (GNS) {
-            if (p.gn_part) {                 // (wave-uniform)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    gsum[e] += __shfl_xor(gsum[e], 8, 64); gsq[e] += __shfl_xor(gsq[e], 8, 64);
-                    gsum[e] += __shfl_xor(gsum[e], 16, 64); gsq[e] += __shfl_xor(gsq[e], 16, 64);
-                    gsum[e] += __shfl_xor(gsum[e], 32, 64); gsq[e] += __shfl_xor(gsq[e], 32, 64);
-                }
-                if (lane < 8 && m_base < p.M) {
-                    const long b = m_base / p.gn_hw;
-                    const long chunk = (m_base - b * p.gn_hw) / (NR * 16), nchunk = p.gn_hw / (NR * 16);
-                    float2* dst = (float2*)(p.gn_part + ((b * nchunk + chunk) * p.N + n_base + lane * 8) * 2);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) dst[e] = make_float2(gsum[e], gsq[e]);
-                }
-            }
+            if (cok && (FULL || m < p.M)) store_row8<EPI, FULL>(p, m, n_base + c * 8, n_base, val);
         }
     }
 }
@@ -615,8 +580,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) a4[i][j] = acc[hh * 4 + i][j];
-            constexpr bool GNS = CONV && (EPI == EPI_BIAS || EPI == EPI_POSADD);
-            epilogue_part<EPI, 4, false, false, 4, GNS>(p, a4, m0 + wm * C::TM + hh * 64, n0 + wn * C::TN, stg, lane);
+            epilogue_part<EPI, 4>(p, a4, m0 + wm * C::TM + hh * 64, n0 + wn * C::TN, stg, lane);
         }
     }
 }

@@ -69,10 +69,6 @@ struct GemmParams {
     // split-K (EPI_F32 on the 2-stage kernel only: weight gradients, output tiles << CUs): split s of k_split accumulates K-tiles
     // [s*nt/k_split, (s+1)*nt/k_split) into out_f32 + s * split_stride (deterministic second-stage reduction by the caller)
     int k_split; long split_stride;
-    // GroupNorm statistics of the OUTPUT taken in the epilogue (implicit-conv instantiations of gemm_kernel, EPI_BIAS / EPI_POSADD, round 6):
-    // gn_part[((b * (gn_hw / 64) + chunk) * N + n) * 2 + {0: sum, 1: sum of squares}] over the 64 output rows of chunk `chunk` of sample b
-    // (gn_hw rows per sample), of the bf16 values as stored.  Whole tiles only: M % 64 == 0, N % 64 == 0, ldo % 8 == 0 (launcher's caller).
-    float* gn_part; long gn_hw;
     int raster_gm;            // tile rows per raster band (set by launch_gemm from the global knob)
     int mid_stagger;          // mid-size kernel: 1 = per-wave staggered LDS-DMA issue slots (set by launch_gemm from the global knob, key 35)
     // optional s_memtime trace (debug): per workgroup, per tile 4 stamps {tile start, main loop start, main loop end, epilogue end}
@@ -121,8 +117,7 @@ void set_mid_min_tiles(int v);
 void set_mid_stagger(int v);
 void set_mid_mask(int v);
 void set_mid_max_tiles(int v);
-void set_mid_plan_hint(int v);
-void set_vae_gn_fused(int v);     // vae_engine.hip (key 40)      // engine.hip forward_core: whether this plan takes the mid-size GEMM kernel at all
+void set_mid_plan_hint(int v);      // engine.hip forward_core: whether this plan takes the mid-size GEMM kernel at all
 void set_raster_gm(int v);      // GEMM tile raster: tile rows per band (0 = row-major)
 void set_conv_cfg(int v);       // VAE conv tile shape A/B knob (0 auto)
 void set_attn_variant(int v);  // 0 = plain online softmax, 1 = deferred-rescale (default)
@@ -260,9 +255,7 @@ hipError_t launch_vae_ingest(const void* lat, int dt, bf16_t* out, int B, int C,
 // ad: B*2*C floats of scratch (per-channel affine).  Deterministic (fixed-order partial sums).
 int gn_num_chunks(long HW, int C);
 hipError_t launch_group_norm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, float* part, float* ad, int B, long HW,
-                             int C, int groups, float eps, bool silu, hipStream_t st, const float* ready_part = nullptr, int ready_nchunk = 0);
-// (ready_part: per-chunk channel partials [B][ready_nchunk][C][2] already taken by the producing convolution's epilogue -- GemmParams::gn_part:
-//  the statistics pass over x is skipped)
+                             int C, int groups, float eps, bool silu, hipStream_t st);
 // p[r][:] = softmax(scale * s[r][:]) for `rows` rows of n fp32 scores (n % 4 == 0), bf16 out
 hipError_t launch_softmax_rows(const float* s, bf16_t* p, long rows, int n, float scale, hipStream_t st);
 // conv weight [Co][Ci][taps] (any dtype) -> bf16 [Co][taps][Cpad] (k = tap*Cpad + ci; ci >= Ci zero); taps = 1 for 1x1 / linear

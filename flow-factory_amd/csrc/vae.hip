@@ -338,19 +338,14 @@ int gn_num_chunks(long HW, int C) {
 }
 
 hipError_t launch_group_norm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, float* part, float* ad, int B, long HW,
-                             int C, int groups, float eps, bool silu, hipStream_t st, const float* ready_part, int ready_nchunk) {
+                             int C, int groups, float eps, bool silu, hipStream_t st) {
     if (C % 8 || C > 2048 || 256 % (C >> 3) || C % groups) return hipErrorInvalidValue;
     const int nchunk = gn_num_chunks(HW, C);
     const int rpi = 256 / (C >> 3);
     long rpc = (HW + nchunk - 1) / nchunk;
     rpc = (rpc + rpi - 1) / rpi * rpi;
-    if (ready_part && ready_nchunk > 0) {
-        // round 6: the convolution that produced x left the per-64-row channel partials in its epilogue: no statistics pass over x
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, st, ready_part, ready_nchunk, C, groups, HW, eps, gamma, beta, ad);
-    } else {
-        hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, part, HW, C, rpc);
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, st, part, nchunk, C, groups, HW, eps, gamma, beta, ad);
-    }
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, B), dim3(256), 0, st, x, part, HW, C, rpc);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, B), dim3(256), 0, st, part, nchunk, C, groups, HW, eps, gamma, beta, ad);
     if (silu) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(nchunk, B), dim3(256), 0, st, x, y, ad, HW, C, rpc);
     else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(nchunk, B), dim3(256), 0, st, x, y, ad, HW, C, rpc);
     return hipGetLastError();

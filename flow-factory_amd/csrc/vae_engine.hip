@@ -193,13 +193,9 @@ extern "C" int mi355_vae_weights_ready(mi355_vae* v) {
 }
 
 // -------------------------------------------------------------------------------------- plan
-static int g_vae_gn_fused = 1;       // GroupNorm statistics in the producing convolution's epilogue (mi355_tune_set(40, .): 0 = the statistics kernel)
-namespace mi355 { void set_vae_gn_fused(int v) { g_vae_gn_fused = v; } }
 struct mi355_vae_plan {
     mi355_vae* v;
     int B, h, w;
-    const bf16_t* part_of = nullptr;      // the tensor whose GroupNorm partials `part` holds (written by the last convolution's epilogue)
-    long part_hw = 0;
     char* ws = nullptr;
     size_t ws_bytes = 0;
     bf16_t *X, *Y, *T1, *T2, *P, *VT;
@@ -230,11 +226,7 @@ extern "C" int mi355_vae_plan_create(mi355_vae* v, int max_batch, int latent_h, 
     const size_t buf = ((size_t)max_batch * act * 2 + 255) & ~(size_t)255;
     const size_t sc = ((size_t)S * S * 4 + 255) & ~(size_t)255, pb = ((size_t)S * S * 2 + 255) & ~(size_t)255;
     const size_t vt = ((size_t)top * S * 2 + 255) & ~(size_t)255;
-    // GroupNorm partials: [B][chunks][C][2] floats -- up to 1024 chunks per image from the statistics kernel, or one chunk per 64 output rows
-    // when the producing convolution takes them in its epilogue (round 6: act / 64 chunk-channels per image)
-    size_t part = (size_t)max_batch * 1024 * cmax * 2 * 4;
-    if ((size_t)max_batch * (act / 64 + 1) * 2 * 4 > part) part = (size_t)max_batch * (act / 64 + 1) * 2 * 4;
-    part = (part + 255) & ~(size_t)255;
+    const size_t part = ((size_t)max_batch * 1024 * cmax * 2 * 4 + 255) & ~(size_t)255;
     const size_t ad = ((size_t)max_batch * 2 * cmax * 4 + 255) & ~(size_t)255;
     p->ws_bytes = 4 * buf + sc + pb + vt + part + ad;
     if (hipMalloc((void**)&p->ws, p->ws_bytes) != hipSuccess) {
@@ -272,23 +264,13 @@ int conv3(const Ctx& c, const ConvW& cw, const bf16_t* in, bf16_t* out, int H, i
     GemmParams g = make_gemm(in, cw.cipad, cw.w, 9L * cw.cipad, M, cw.co, 9 * cw.cipad, res ? EPI_POSADD : EPI_BIAS, cw.b, out, cw.co);
     g.conv_cin = cw.cipad; g.conv_h = H; g.conv_w = W; g.conv_up = up; g.zero_page = c.p->v->zero_page;
     g.aux = res; g.ld_aux = cw.co;
-    // Round 6: the GroupNorm that reads this output next finds its per-channel partial sums already taken (the convolution's epilogue holds
-    // the tile in registers; the statistics kernel was a full extra read of the tensor, 10 % of the decode).  Whole 64-row chunks and
-    // 64-column chunks only; `part_of` names the tensor the partial buffer currently describes (anything else that writes it resets it).
-    c.p->part_of = nullptr;
-    if (g_vae_gn_fused && (((long)H * W) % 64) == 0 && cw.co % 64 == 0) {
-        g.gn_part = c.p->part; g.gn_hw = (long)H * W;
-        c.p->part_of = out; c.p->part_hw = (long)H * W;
-    }
     HIPCHK(launch_gemm(g, c.st));
     return 0;
 }
 
 int group_norm(const Ctx& c, const NormW& n, const bf16_t* x, bf16_t* y, long HW, bool silu) {
     const mi355_vae_cfg& cfg = c.p->v->cfg;
-    const bool ready = c.p->part_of == x && c.p->part_hw == HW;
-    HIPCHK(launch_group_norm(x, y, n.g, n.b, c.p->part, c.p->ad, c.B, HW, n.c, cfg.norm_num_groups, cfg.eps, silu, c.st,
-                             ready ? c.p->part : nullptr, ready ? (int)(HW / 64) : 0));
+    HIPCHK(launch_group_norm(x, y, n.g, n.b, c.p->part, c.p->ad, c.B, HW, n.c, cfg.norm_num_groups, cfg.eps, silu, c.st));
     return 0;
 }
 
@@ -302,7 +284,6 @@ int resnet(const Ctx& c, const Resnet& r, int H, int W) {
     if (r.has_sc) {
         GemmParams g = make_gemm(p->X, r.ci, r.sc.w, r.ci, M, r.co, r.ci, EPI_BIAS, r.sc.b, p->T2, r.co);
         HIPCHK(launch_gemm(g, c.st));
-        p->part_of = nullptr;             // T2 was rewritten by a plain GEMM
         CHK(conv3(c, r.c2, p->T1, p->X, H, W, 0, p->T2));
     } else {
         CHK(conv3(c, r.c2, p->T1, p->X, H, W, 0, p->X));
@@ -336,7 +317,6 @@ int mid_attention(const Ctx& c, int H, int W) {
     GemmParams gout = make_gemm(p->Y, C, v->to_out.w, C, M, C, C, EPI_POSADD, v->to_out.b, p->X, C);
     gout.aux = p->X; gout.ld_aux = C;
     HIPCHK(launch_gemm(gout, c.st));
-    p->part_of = nullptr;                 // X was rewritten by a plain GEMM: no partials for it
     return 0;
 }
 
