@@ -13,7 +13,11 @@ stats_sub = sys.argv[2] if len(sys.argv) > 2 else None
 
 
 def short(name):
-    for key, tag in (("attn_bwd_dkv_tr_kernel", "attn_bwd_dkv_tr_kernel"), ("attn_bwd_dq_tr_kernel", "attn_bwd_dq_tr_kernel"), ("attn_kernel", "attn_kernel"),
+    for key, tag in (("gemm_tn_kernel", "gemm_tn<128x128,row-major wgrad>"), ("splitk_reduce_colsum_kernel", "splitk_reduce_colsum_kernel"),
+                     ("splitk_reduce_kernel", "splitk_reduce_kernel"), ("colsum_partial_kernel", "colsum_partial_kernel"),
+                     ("colsum_finish_kernel", "colsum_finish_kernel"), ("transpose_kernel", "transpose_kernel"), ("ln_mod_bwd_kernel", "ln_mod_bwd_kernel"),
+                     ("rms_bwd_gather", "rms_bwd_gather_kernel"), ("attn_bwd_prep", "attn_bwd_prep_kernel"), ("gate_mul_kernel", "gate_mul_kernel"),
+                     ("attn_bwd_dkv_tr_kernel", "attn_bwd_dkv_tr_kernel"), ("attn_bwd_dq_tr_kernel", "attn_bwd_dq_tr_kernel"), ("attn_kernel", "attn_kernel"),
                      ("gemm_mid_kernel", None), ("gemm_w4_kernel", None), ("gemm_pp_kernel", None), ("gemm_kernel", None), ("ln_mod_kernel", "ln_mod_kernel"),
                      ("sde_step_kernel", "sde_step_kernel"), ("patchify", "patchify_kernel"), ("time_proj", "time_proj_kernel"),
                      ("convert_kernel", "convert_kernel"), ("pos_crop", "pos_crop_kernel"), ("gn_partial", "gn_partial_kernel"),
