@@ -1082,9 +1082,8 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 32) { set_mid_mode(value); return 0; }          // mid-size GEMM kernel (128x192 / 192x128 tiles): 0 off, 1 cost rule (default), 2 wherever it applies
     if (key == 33) { set_mid_alpha_percent(value); return 0; } // margin of that rule in percent (default 100)
     if (key == 34) { set_mid_min_tiles(value); return 0; }     // smallest grid of its tiles (default 160)
-    if (key == 36) { set_mid_mask(value); return 0; }          // launch classes it may take (1 gated residual K < 3072, 2 K >= 3072, 4 V^T, 8 the rest)
     if (key == 37) { set_mid_max_tiles(value); return 0; }     // largest grid of its tiles
-    if (key == 35) { set_mid_stagger(value); return 0; }       // its per-wave staggered LDS-DMA issue slots: 1 on (default), 0 off
+    if (key == 35 || key == 36) return 0;                      // (round-6 measurement knobs of that kernel -- staggered LDS-DMA slots, launch-class mask -- measured and removed: accepted as no-ops)
     if (key == 39) { g_wgrad_tn = value; return 0; }           // optimize() backward: 1 (default) = weight-gradient GEMMs read dY / X row-major through transposed LDS reads, 0 = transposed copies
     if (key == 38) { g_fuse_colsum = value; return 0; }        // optimize() backward: 1 (default) = column-sum finish fused into the split-K reduction launch, 0 = two launches
     if (key == 22) { g_train_two_stream = value; return 0; }   // optimize() replay: the context-stream chain of the training forward / backward on a side stream (1 = default)

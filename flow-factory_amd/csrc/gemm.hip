@@ -16,7 +16,6 @@
 //   * workgroup -> tile mapping is XCD-aware (8 XCDs, private L2 each): consecutive tiles of one
 //     activation row-panel stay on one XCD.
 #include "kernels.h"
-#include <type_traits>
 
 namespace mi355 {
 
@@ -31,8 +30,6 @@ int g_pp_min_tiles = 128;     // smallest 256x256-tile grid for gemm_pp_kernel
 int g_w4_min_tiles = 512;     // smallest 256x256-tile grid the DEFAULT dispatch (key 0 = 1) gives to the 4-wave kernel; mi355_tune_set(31, v)
 int g_mid_mode = 1;           // mid-size kernel (128x192 / 192x128 tiles): 0 off, 1 by the cost rule of launch_epi, 2 wherever it applies; mi355_tune_set(32, v)
 double g_mid_alpha = 1.0;     // margin of that rule: the mid-size kernel's estimated cost is multiplied by it; mi355_tune_set(33, percent)
-int g_mid_stagger = 1;        // mid-size kernel: per-wave staggered LDS-DMA issue slots (0 = all four waves issue behind the same MFMAs); mi355_tune_set(35, v)
-int g_mid_mask = 15;          // which launch classes may take it: 1 gated residual K < 3072, 2 gated residual K >= 3072, 4 V^T, 8 the rest; mi355_tune_set(36, v)
 int g_mid_max_tiles = 256;    // largest grid of its tiles: ONE round, one workgroup per CU (measured in-model, profiles/r06b / r06d: two-round grids lose
                               // to the ping-pong kernel's 192 tiles + the CUs it leaves to the text chain: 1024^2 B = 2 -7 %); mi355_tune_set(37, v)
 int g_mid_plan_hint = 1;      // set by the SD3.5 engine around a forward (set_mid_plan_hint): 0 = the plan's text chain is too small for the kernel to pay
@@ -682,16 +679,15 @@ __global__ __launch_bounds__(256, 2) void gemm_mid_kernel(GemmParams p) {
     // crosses; hipcc's own scheduler bunches the loads in front of the MFMAs, and its sched_group_barrier pipeline did not hold for the
     // LDS-DMA half), one fragment read of the NEXT k-step behind every second MFMA and one LDS-DMA issue behind every fourth -- the wave is
     // alone on its SIMD, so whatever it issues between two MFMAs must fit the 16 cycles the first one occupies the matrix pipe.
-    // PH (0 .. 3, = the wave's index): the four waves of the workgroup run in lockstep between barriers; with the SAME slots their LDS-DMA
-    // issues would reach the CU's one texture-address unit in the same cycle and each wave would sit out the other three's 1 KiB requests.
-    // Wave w issues behind MFMA 4 q + w instead: four copies of the loop, one per wave (the interleave has to be static).
+    // (Measured and removed, profiles/r06c_*: per-wave STAGGERED LDS-DMA slots -- wave w issuing behind MFMA 4 q + w so that the four waves, which run
+    // in lockstep between barriers, do not reach the CU's one texture-address unit in the same cycle -- moved nothing, +-1 %: four copies of the loop.)
 #define MID_HALF(buf, rd_sb, rd_kk, ld_kt, ld_slot, ld_first)                                                    \
     do {                                                                                                         \
         _Pragma("unroll") for (int n = 0; n < MI * NJ; ++n) {                                                    \
             acc[n / NJ][n % NJ] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[buf][n % NJ], xf[buf][n / NJ], acc[n / NJ][n % NJ], 0, 0, 0); \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
             if ((n & 1) == 0 && n / 2 < MI + NJ) read_frag((buf) ^ 1, rd_sb, rd_kk, n / 2);                      \
-            if ((n & 3) == PH && n / 4 < GPW / 2) stage_one(ld_kt, ld_slot, (ld_first) + n / 4);                 \
+            if ((n & 3) == 1 && n / 4 < GPW / 2) stage_one(ld_kt, ld_slot, (ld_first) + n / 4);                   \
             __builtin_amdgcn_sched_barrier(0);                                                                   \
         }                                                                                                        \
     } while (0)
@@ -715,26 +711,18 @@ __global__ __launch_bounds__(256, 2) void gemm_mid_kernel(GemmParams p) {
     // from the MFMAs they are interleaved with, and peeled tail copies made the register allocator shuffle the accumulators between the
     // copies): the last K-tiles, which have nothing left to prefetch, re-load K-tile nt - 1 into the slots that became free and read
     // fragments nobody uses (as the ping-pong kernel's last prefetch does); <= 3 x 40 KiB of L2 hits per tile.
-    auto k_loop = [&](auto ph) {
-        constexpr int PH = decltype(ph)::value;
-        for (int t = 0; t < nt; ++t) {
-            const char* sb = smem + (t & 3) * STAGE;
-            // first half: k-step 0 of K-tile t; fragments of k-step 1; second half of the LDS-DMA of K-tile t + 2 (slot of K-tile t - 2:
-            // free since the barrier of the previous iteration)
-            MID_HALF(0, sb, 1, ktile(t + 2), (t + 2) & 3, GPW / 2);
-            // K-tile t + 1 has landed (this wave's share; the barrier makes it everybody's); K-tile t + 2 stays in flight
-            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            __builtin_amdgcn_s_barrier();          // ... and every wave is done with the slot of K-tile t - 1
-            __builtin_amdgcn_sched_barrier(0);
-            // second half: k-step 1; fragments of k-step 0 of K-tile t + 1; first half of the LDS-DMA of K-tile t + 3 into the slot K-tile t - 1 left
-            MID_HALF(1, smem + ((t + 1) & 3) * STAGE, 0, ktile(t + 3), (t + 3) & 3, 0);
-        }
-    };
-    if (p.mid_stagger == 0) k_loop(std::integral_constant<int, 1>{});
-    else if (wave == 0) k_loop(std::integral_constant<int, 0>{});
-    else if (wave == 1) k_loop(std::integral_constant<int, 1>{});
-    else if (wave == 2) k_loop(std::integral_constant<int, 2>{});
-    else k_loop(std::integral_constant<int, 3>{});
+    for (int t = 0; t < nt; ++t) {
+        const char* sb = smem + (t & 3) * STAGE;
+        // first half: k-step 0 of K-tile t; fragments of k-step 1; second half of the LDS-DMA of K-tile t + 2 (slot of K-tile t - 2: free
+        // since the barrier of the previous iteration)
+        MID_HALF(0, sb, 1, ktile(t + 2), (t + 2) & 3, GPW / 2);
+        // K-tile t + 1 has landed (this wave's share; the barrier makes it everybody's); K-tile t + 2 stays in flight
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // ... and every wave is done with the slot of K-tile t - 1
+        __builtin_amdgcn_sched_barrier(0);
+        // second half: k-step 1; fragments of k-step 0 of K-tile t + 1; first half of the LDS-DMA of K-tile t + 3 into the slot K-tile t - 1 left
+        MID_HALF(1, smem + ((t + 1) & 3) * STAGE, 0, ktile(t + 3), (t + 3) & 3, 0);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the surplus prefetches of the tail have landed before the ring becomes staging
 #undef MID_HALF
 
@@ -1235,8 +1223,7 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
         const long tmid = (long)((p.M + (vt ? 191 : 127)) / (vt ? 192 : 128)) * ((p.N + (vt ? 127 : 191)) / (vt ? 128 : 192));
         const double cost_mid = 1.5 * (double)((tmid + 255) / 256) * g_mid_alpha;
         const double cost_else = (big >= g_pp_min_tiles && fits32 && cost_pp <= cost_128) ? cost_pp : (t128 <= 256 ? 1.7 : cost_128);
-        const int cls = EPI == EPI_GATE_RES ? (p.K < 3072 ? 1 : 2) : vt ? 4 : 8;      // launch class for the A/B mask (key 36)
-        if (g_mid_mode != 0 && (g_mid_mode == 2 || g_mid_plan_hint) && (g_mid_mask & cls) && fits32 && g_gemm_variant != 0 && tmid >= g_mid_min_tiles && tmid <= g_mid_max_tiles &&
+        if (g_mid_mode != 0 && (g_mid_mode == 2 || g_mid_plan_hint) && fits32 && g_gemm_variant != 0 && tmid >= g_mid_min_tiles && tmid <= g_mid_max_tiles &&
             (g_mid_mode == 2 || cost_mid < cost_else))
             return vt ? launch_mid<6, 4, EPI>(p, stream) : launch_mid<4, 6, EPI>(p, stream);
     }
@@ -1309,8 +1296,6 @@ void set_w4_min_tiles(int v) { g_w4_min_tiles = v; }
 void set_mid_mode(int v) { g_mid_mode = v; }
 void set_mid_alpha_percent(int v) { g_mid_alpha = v / 100.0; }
 void set_mid_min_tiles(int v) { g_mid_min_tiles = v; }
-void set_mid_stagger(int v) { g_mid_stagger = v; }
-void set_mid_mask(int v) { g_mid_mask = v; }
 void set_mid_max_tiles(int v) { g_mid_max_tiles = v; }
 void set_mid_plan_hint(int v) { g_mid_plan_hint = v; }
 int get_gemm_variant() { return g_gemm_variant; }
@@ -1366,7 +1351,6 @@ static void trace_gemm(const GemmParams& p, hipStream_t stream) {
 hipError_t launch_gemm(const GemmParams& p_in, hipStream_t stream) {
     GemmParams p = p_in;
     p.raster_gm = g_raster_gm;
-    p.mid_stagger = g_mid_stagger;
     if (sched_trace_on()) trace_gemm(p, stream);
     if (p.K % BK != 0 || p.M <= 0 || p.N <= 0) return hipErrorInvalidValue;
     if (p.conv_cin > 0) {

@@ -70,7 +70,6 @@ struct GemmParams {
     // [s*nt/k_split, (s+1)*nt/k_split) into out_f32 + s * split_stride (deterministic second-stage reduction by the caller)
     int k_split; long split_stride;
     int raster_gm;            // tile rows per raster band (set by launch_gemm from the global knob)
-    int mid_stagger;          // mid-size kernel: 1 = per-wave staggered LDS-DMA issue slots (set by launch_gemm from the global knob, key 35)
     // optional s_memtime trace (debug): per workgroup, per tile 4 stamps {tile start, main loop start, main loop end, epilogue end}
     long long* trace;
     int dbg_skip_prefetch;    // debug ablation: the K-loop prefetches are not issued (results are garbage)
@@ -114,8 +113,6 @@ void set_w4_min_tiles(int v);
 void set_mid_mode(int v);
 void set_mid_alpha_percent(int v);
 void set_mid_min_tiles(int v);
-void set_mid_stagger(int v);
-void set_mid_mask(int v);
 void set_mid_max_tiles(int v);
 void set_mid_plan_hint(int v);      // engine.hip forward_core: whether this plan takes the mid-size GEMM kernel at all
 void set_raster_gm(int v);      // GEMM tile raster: tile rows per band (0 = row-major)
