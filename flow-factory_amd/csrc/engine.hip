@@ -120,7 +120,8 @@ static hipError_t sde_p(const SdeStepParams& s, hipStream_t st) { ProfScope ps(P
 
 // training-mode state (engine_train.inc, included at the end of this file)
 static int g_train_two_stream = 1;   // key 22, see engine_train.inc
-static int g_wgrad_tn = 1;           // key 39: weight gradients of whole-tile shapes on the row-major-operand kernel (gemm_tn.hip): no dY^T / X^T copies
+static int g_wgrad_tn = 1;           // key 39: weight gradients of whole-tile shapes on the row-major-operand kernels (gemm_tn.hip): no dY^T / X^T copies
+                                     // (1 = 256 x 256 tiles where they give a one-round grid, else 128 x 128; 2 = 128 x 128 only; 0 = transposed copies)
 static int g_fuse_colsum = 1;        // key 38: bias-gradient column-sum finish inside the weight gradient's split-K reduction launch (engine_train.inc: wgrad)
 struct mi355_engine;
 struct mi355_plan;
@@ -1117,11 +1118,13 @@ extern "C" int mi355_op_linear_gate_res(void* stream, const void* A, const void*
 // weight-gradient product as an operator (unit tests / A/B scripts): variant 1 = gemm_tn.hip on the row-major operands, variant 0 = the
 // transposed-copy path (launch_transpose x 2 + the K-contiguous EPI_F32 GEMM).  Output: k_split fp32 partial slabs [N][K].
 extern "C" int mi355_op_wgrad(void* stream, const void* dY, int64_t ld_dy, const void* X, int64_t ld_x, float* out, int M, int N, int K, int k_split,
-                              int variant, void* scratch) {
+                              int variant, void* scratch, float* colsum) {
     if (!dY || !X || !out || M <= 0 || N <= 0 || K <= 0 || k_split < 1) return fail("mi355_op_wgrad: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    if (variant == 1) {
-        GemmTnParams tp{(const bf16_t*)dY, (long)ld_dy, (const bf16_t*)X, (long)ld_x, M, N, K, out, (long)K, k_split, (long)N * K};
+    if (variant == 1 || variant == 2) {          // 2 = the 256 x 256-tile form (N, K multiples of 256; no column sums)
+        GemmTnParams tp{(const bf16_t*)dY, (long)ld_dy, (const bf16_t*)X, (long)ld_x, M, N, K, out, (long)K, k_split, (long)N * K, variant == 1 ? colsum : nullptr,
+                        variant == 2 ? 1 : 0};
+        if (variant == 2 && (N % 256 || K % 256)) return fail("mi355_op_wgrad: variant 2 needs N %% 256 == 0 and K %% 256 == 0");
         if (!gemm_tn_ok(tp)) return fail("mi355_op_wgrad: the row-major-operand kernel needs M %% 64 == 0, N %% 128 == 0, K %% 128 == 0, 16-byte aligned rows");
         HIPCHK(launch_gemm_tn(tp, st));
         return 0;

@@ -17,7 +17,9 @@
 //   * the transposed reads and their MFMAs are one inline-assembly block per k-step with the fragments in FIXED registers (a fragment is two
 //     64-bit reads into the halves of one 4-register operand; and hipcc guards every LDS read it recognises with `s_waitcnt vmcnt(0)` while an
 //     LDS-DMA is in flight, which would drain the prefetch of the next m-tile);
-//   * split over m (k_split) into fp32 partial buffers like gemm_kernel<.., EPI_F32>; the caller reduces in fixed order (backward.hip).
+//   * split over m (k_split) into fp32 partial buffers like gemm_kernel<.., EPI_F32>; the caller reduces in fixed order (backward.hip);
+//   * optional bias gradient (colsum != nullptr): the column sums of dY per split, taken from the fragments the k-tile-0 blocks hold
+//     (v_dot2c_f32_bf16 against a constant (1, 1): 16 VALU per k-step in 1 / (K / 128) of the blocks) -- no extra pass over dY.
 // Requirements (launcher): M % 64 == 0, N % 128 == 0, K % 128 == 0, lda / ldb multiples of 8, operands below 4 GiB.
 #include "kernels.h"
 
@@ -37,7 +39,17 @@ __device__ __forceinline__ int swz_row(int row) { return (row & 3) | (((row >> 3
 #define TN_MFMA(c, w, x) "v_mfma_f32_16x16x32_bf16 " c ", " w ", " x ", " c "\n\t"
 // one k-step (32 m): 16 transposed reads into v[224:255] (x fragments i = 0..3 at v[224 + 4 i ..], w fragments j = 0..3 at v[240 + 4 j ..]),
 // then the 16 MFMAs of the 64 x 64 wave tile.  KOFF = byte offset of the k-step inside the operand tile (32 rows x 256 B).
-#define TN_STEP(KOFF, KOFF4)                                                                                                     \
+// CS: "" or TN_CS -- the column sums of dY (the bias gradient) taken from the x fragments the step already holds: v_dot2c_f32_bf16 with a
+// constant (1, 1) operand adds both bf16 halves of a register to an fp32 accumulator; the four registers of fragment i are 8 consecutive m of
+// column 16 i + r.  Issued behind the last wait of the step, i.e. beside its last MFMAs.
+#define TN_CS                                                                                                                    \
+    "v_dot2c_f32_bf16 %[s0], %[one], v224\n\tv_dot2c_f32_bf16 %[s0], %[one], v225\n\tv_dot2c_f32_bf16 %[s0], %[one], v226\n\t"    \
+    "v_dot2c_f32_bf16 %[s0], %[one], v227\n\tv_dot2c_f32_bf16 %[s1], %[one], v228\n\tv_dot2c_f32_bf16 %[s1], %[one], v229\n\t"    \
+    "v_dot2c_f32_bf16 %[s1], %[one], v230\n\tv_dot2c_f32_bf16 %[s1], %[one], v231\n\tv_dot2c_f32_bf16 %[s2], %[one], v232\n\t"    \
+    "v_dot2c_f32_bf16 %[s2], %[one], v233\n\tv_dot2c_f32_bf16 %[s2], %[one], v234\n\tv_dot2c_f32_bf16 %[s2], %[one], v235\n\t"    \
+    "v_dot2c_f32_bf16 %[s3], %[one], v236\n\tv_dot2c_f32_bf16 %[s3], %[one], v237\n\tv_dot2c_f32_bf16 %[s3], %[one], v238\n\t"    \
+    "v_dot2c_f32_bf16 %[s3], %[one], v239\n\t"
+#define TN_STEP_G(KOFF, KOFF4, CS, A0)                                                                                               \
     asm volatile(                                                                                                                \
         TN_RD("v[224:225]", "%[xa0]", KOFF) TN_RD("v[226:227]", "%[xa0]", KOFF4)                                                  \
         TN_RD("v[240:241]", "%[wa0]", KOFF) TN_RD("v[242:243]", "%[wa0]", KOFF4)                                                  \
@@ -59,15 +71,51 @@ __device__ __forceinline__ int swz_row(int row) { return (row & 3) | (((row >> 3
         "s_waitcnt lgkmcnt(0)\n\t"                                                                                               \
         TN_MFMA("%[c30]", "v[240:243]", "v[236:239]") TN_MFMA("%[c31]", "v[244:247]", "v[236:239]")                               \
         TN_MFMA("%[c32]", "v[248:251]", "v[236:239]") TN_MFMA("%[c33]", "v[252:255]", "v[236:239]")                               \
-        : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c02] "+v"(acc[0][2]), [c03] "+v"(acc[0][3]), [c10] "+v"(acc[1][0]),       \
-          [c11] "+v"(acc[1][1]), [c12] "+v"(acc[1][2]), [c13] "+v"(acc[1][3]), [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]),       \
-          [c22] "+v"(acc[2][2]), [c23] "+v"(acc[2][3]), [c30] "+v"(acc[3][0]), [c31] "+v"(acc[3][1]), [c32] "+v"(acc[3][2]),       \
-          [c33] "+v"(acc[3][3])                                                                                                    \
-        : [xa0] "v"(xa[0]), [xa1] "v"(xa[1]), [xa2] "v"(xa[2]), [xa3] "v"(xa[3]), [wa0] "v"(wa[0]), [wa1] "v"(wa[1]), [wa2] "v"(wa[2]), \
-          [wa3] "v"(wa[3])                                                                                                         \
+        CS                                                                                                                       \
+        : [c00] "+v"(acc[A0 + 0][0]), [c01] "+v"(acc[A0 + 0][1]), [c02] "+v"(acc[A0 + 0][2]), [c03] "+v"(acc[A0 + 0][3]),             \
+          [c10] "+v"(acc[A0 + 1][0]), [c11] "+v"(acc[A0 + 1][1]), [c12] "+v"(acc[A0 + 1][2]), [c13] "+v"(acc[A0 + 1][3]),             \
+          [c20] "+v"(acc[A0 + 2][0]), [c21] "+v"(acc[A0 + 2][1]), [c22] "+v"(acc[A0 + 2][2]), [c23] "+v"(acc[A0 + 2][3]),             \
+          [c30] "+v"(acc[A0 + 3][0]), [c31] "+v"(acc[A0 + 3][1]), [c32] "+v"(acc[A0 + 3][2]), [c33] "+v"(acc[A0 + 3][3]),             \
+          [s0] "+v"(cs[A0 + 0]), [s1] "+v"(cs[A0 + 1]), [s2] "+v"(cs[A0 + 2]), [s3] "+v"(cs[A0 + 3])                                 \
+        : [one] "v"(ones), [xa0] "v"(xa[A0 + 0]), [xa1] "v"(xa[A0 + 1]), [xa2] "v"(xa[A0 + 2]), [xa3] "v"(xa[A0 + 3]), [wa0] "v"(wa[0]),   \
+          [wa1] "v"(wa[1]), [wa2] "v"(wa[2]), [wa3] "v"(wa[3])                                                                       \
         : "memory", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237",  \
           "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252",  \
           "v253", "v254", "v255")
+// (the same step without the column-sum operands: the 256 x 256 form has no registers to spare for them)
+#define TN_STEP_NC(KOFF, KOFF4, A0)                                                                                                      \
+    asm volatile(                                                                                                                \
+        TN_RD("v[224:225]", "%[xa0]", KOFF) TN_RD("v[226:227]", "%[xa0]", KOFF4)                                                  \
+        TN_RD("v[240:241]", "%[wa0]", KOFF) TN_RD("v[242:243]", "%[wa0]", KOFF4)                                                  \
+        TN_RD("v[244:245]", "%[wa1]", KOFF) TN_RD("v[246:247]", "%[wa1]", KOFF4)                                                  \
+        TN_RD("v[248:249]", "%[wa2]", KOFF) TN_RD("v[250:251]", "%[wa2]", KOFF4)                                                  \
+        TN_RD("v[252:253]", "%[wa3]", KOFF) TN_RD("v[254:255]", "%[wa3]", KOFF4)                                                  \
+        TN_RD("v[228:229]", "%[xa1]", KOFF) TN_RD("v[230:231]", "%[xa1]", KOFF4)                                                  \
+        TN_RD("v[232:233]", "%[xa2]", KOFF) TN_RD("v[234:235]", "%[xa2]", KOFF4)                                                  \
+        TN_RD("v[236:237]", "%[xa3]", KOFF) TN_RD("v[238:239]", "%[xa3]", KOFF4)                                                  \
+        "s_waitcnt lgkmcnt(6)\n\t"                                                                                               \
+        TN_MFMA("%[c00]", "v[240:243]", "v[224:227]") TN_MFMA("%[c01]", "v[244:247]", "v[224:227]")                               \
+        TN_MFMA("%[c02]", "v[248:251]", "v[224:227]") TN_MFMA("%[c03]", "v[252:255]", "v[224:227]")                               \
+        "s_waitcnt lgkmcnt(4)\n\t"                                                                                               \
+        TN_MFMA("%[c10]", "v[240:243]", "v[228:231]") TN_MFMA("%[c11]", "v[244:247]", "v[228:231]")                               \
+        TN_MFMA("%[c12]", "v[248:251]", "v[228:231]") TN_MFMA("%[c13]", "v[252:255]", "v[228:231]")                               \
+        "s_waitcnt lgkmcnt(2)\n\t"                                                                                               \
+        TN_MFMA("%[c20]", "v[240:243]", "v[232:235]") TN_MFMA("%[c21]", "v[244:247]", "v[232:235]")                               \
+        TN_MFMA("%[c22]", "v[248:251]", "v[232:235]") TN_MFMA("%[c23]", "v[252:255]", "v[232:235]")                               \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                               \
+        TN_MFMA("%[c30]", "v[240:243]", "v[236:239]") TN_MFMA("%[c31]", "v[244:247]", "v[236:239]")                               \
+        TN_MFMA("%[c32]", "v[248:251]", "v[236:239]") TN_MFMA("%[c33]", "v[252:255]", "v[236:239]")                               \
+        : [c00] "+v"(acc[A0 + 0][0]), [c01] "+v"(acc[A0 + 0][1]), [c02] "+v"(acc[A0 + 0][2]), [c03] "+v"(acc[A0 + 0][3]),             \
+          [c10] "+v"(acc[A0 + 1][0]), [c11] "+v"(acc[A0 + 1][1]), [c12] "+v"(acc[A0 + 1][2]), [c13] "+v"(acc[A0 + 1][3]),             \
+          [c20] "+v"(acc[A0 + 2][0]), [c21] "+v"(acc[A0 + 2][1]), [c22] "+v"(acc[A0 + 2][2]), [c23] "+v"(acc[A0 + 2][3]),             \
+          [c30] "+v"(acc[A0 + 3][0]), [c31] "+v"(acc[A0 + 3][1]), [c32] "+v"(acc[A0 + 3][2]), [c33] "+v"(acc[A0 + 3][3])              \
+        : [xa0] "v"(xa[A0 + 0]), [xa1] "v"(xa[A0 + 1]), [xa2] "v"(xa[A0 + 2]), [xa3] "v"(xa[A0 + 3]), [wa0] "v"(wa[0]),   \
+          [wa1] "v"(wa[1]), [wa2] "v"(wa[2]), [wa3] "v"(wa[3])                                                                       \
+        : "memory", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237",  \
+          "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252",  \
+          "v253", "v254", "v255")
+#define TN_STEP(KOFF, KOFF4, CS) TN_STEP_G(KOFF, KOFF4, CS, 0)
+
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -134,6 +182,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    const unsigned ones = 0x3f803f80u;                              // bf16 (1, 1)
+    const bool do_cs = p.colsum != nullptr && tk == 0 && wn == 0;     // (wave-uniform) the k-tile-0 blocks' left waves: every dY column once per split
 
     const int nt_all = p.M / TM;
     const int mt0 = (int)((long)nt_all * split / nsplit);
@@ -151,8 +202,24 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) { xa[b] = xa_s[0][b]; wa[b] = wa_s[0][b]; }
         }
-        TN_STEP(0, 1024);           // m rows  0 .. 31 of the tile (second read of a fragment: + 4 rows = 1024 B)
-        TN_STEP(8192, 9216);        // m rows 32 .. 63
+        if (do_cs) {
+            TN_STEP(0, 1024, TN_CS);        // m rows  0 .. 31 of the tile (second read of a fragment: + 4 rows = 1024 B)
+            TN_STEP(8192, 9216, TN_CS);     // m rows 32 .. 63
+        } else {
+            TN_STEP(0, 1024, "");
+            TN_STEP(8192, 9216, "");
+        }
+    }
+    // ---- bias gradient partials: cs[i] holds this lane's share (its kg's 8 of every 32 m) of column n0 + 64 wm + 16 i + r: combine the four
+    // kg lane groups in a fixed order, one slab per split (colsum[split][N]; the caller's finishing launch adds the slabs in order)
+    if (do_cs) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = cs[i];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (kg == 0) p.colsum[(long)split * p.N + n0 + wm * 64 + i * 16 + r] = v;
+        }
     }
 
     // ---- epilogue: fp32 partial sums straight from the accumulator layout: acc[i][j][e] = C[n0 + 64 wm + 16 i + r][k0 + 64 wn + 16 j + 4 kg + e]
@@ -162,6 +229,107 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wm * 64 + i * 16 + r, k = k0 + wn * 64 + j * 16 + 4 * kg;
+            *(float4*)(ob + (long)n * p.ldo + k) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+}
+
+
+// ---- 256 (n) x 256 (k) x 64 (m) tiles, 8 waves (2 x 4, wave tile 128 x 64), one workgroup per CU.  The 128 x 128 form stages 32 KiB per
+// 128 x 128 x 64 step: two co-resident workgroups ask the CU's L2 -> LDS path for ~140 GB/s where it delivers ~90 -- measured 54.7 us
+// for the N = K = 1536, M = 8192 weight gradient against a 17 us MFMA floor.  This form moves half the bytes per FLOP (64 KiB per 256 x 256 x 64
+// step, the ping-pong kernel's ratio).  LDS rows are 512 B (one LDS-DMA instruction = 2 rows); same chunk swizzle (the low 3 bits of the 32-byte
+// chunk index); a k-step is TWO assembly blocks of 16 MFMAs -- inline asm takes at most 30 operands -- each reading its own four x fragments
+// and the wave's four w fragments (re-read by the second block: nothing may be assumed to survive in registers between two asm statements).
+// Same MFMA, operand order and m order per output element as the 128 x 128 form: bit-identical for equal split boundaries.  No column sums
+// here (`colsum` must be null: the accumulators leave no registers for them; the caller takes the bias gradient with the slab kernel).
+constexpr int OP_BYTES_B = TM * 512;          // 64 rows x 256 columns bf16
+constexpr int STAGE_B = 2 * OP_BYTES_B;       // 64 KiB
+
+__global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;          // wave tile: output rows 128 wm .., output columns 64 wn ..
+
+    const int ntn = p.N / 256, ntk = p.K / 256;
+    const int nsplit = p.k_split > 1 ? p.k_split : 1;
+    const int nblk = ntn * ntk * nsplit;
+    int bid = blockIdx.x;
+    {
+        const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    }
+    const int split = bid / (ntn * ntk);
+    bid -= split * (ntn * ntk);
+    const int tn = bid / ntk, tk = bid - tn * ntk;
+    const int n0 = tn * 256, k0 = tk * 256;
+
+    // LDS-DMA: one instruction = 2 rows x 512 B; group g (32 per operand tile) belongs to wave g & 7; lane -> (row l >> 5, 16-byte chunk l & 31)
+    unsigned soffA[4], soffB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int g = wave + 8 * i;
+        const int row = g * 2 + (lane >> 5);
+        const int c32 = ((lane & 31) >> 1) ^ swz_row(row);
+        const int col = c32 * 16 + (lane & 1) * 8;
+        soffA[i] = ((unsigned)row * (unsigned)p.lda + (unsigned)(n0 + col)) * 2u;
+        soffB[i] = ((unsigned)row * (unsigned)p.ldb + (unsigned)(k0 + col)) * 2u;
+    }
+    auto stage = [&](int mt, int buf) {
+        char* base = smem + buf * STAGE_B;
+        const char* ga = (const char*)p.A + (long)mt * TM * p.lda * 2;
+        const char* gb = (const char*)p.B + (long)mt * TM * p.ldb * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = wave + 8 * i;
+            __builtin_amdgcn_global_load_lds((gptr_t)(ga + soffA[i]), (lptr_t)(base + g * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(gb + soffB[i]), (lptr_t)(base + OP_BYTES_B + g * 1024), 16, 0, 0);
+        }
+    };
+
+    const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem);
+    const int r = lane & 15, kg = lane >> 4;
+    const int rrow = kg * 8 + (r >> 2);
+    const int sw = swz_row(rrow);
+    const unsigned xbase = lds0 + rrow * 512 + (r & 3) * 8, wbase = xbase + OP_BYTES_B;
+    unsigned xa[8], wa[4];                            // stage 0 to start with
+#pragma unroll
+    for (int b = 0; b < 8; ++b) xa[b] = xbase + (((wm * 8 + b) ^ sw) << 5);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) wa[b] = wbase + (((wn * 4 + b) ^ sw) << 5);
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nt_all = p.M / TM;
+    const int mt0 = (int)((long)nt_all * split / nsplit);
+    const int nt = (int)((long)nt_all * (split + 1) / nsplit) - mt0;
+    if (nt > 0) stage(mt0, 0);
+    for (int t = 0; t < nt; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) stage(mt0 + t + 1, (t + 1) & 1);
+        // (xa / wa ARE the address registers: they flip between the two stages in place at the end of the iteration -- copies would not fit
+        //  beside the 128 accumulator registers)
+        // second read of a fragment: + 4 rows = 2048 B; second k-step: + 32 rows = 16384 B
+        TN_STEP_NC(0, 2048, 0); TN_STEP_NC(0, 2048, 4);
+        TN_STEP_NC(16384, 18432, 0); TN_STEP_NC(16384, 18432, 4);
+        const unsigned flip = (t & 1) ? (unsigned)-STAGE_B : (unsigned)STAGE_B;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) xa[b] += flip;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) wa[b] += flip;
+    }
+    float* ob = p.out + (long)split * p.split_stride;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wm * 128 + i * 16 + r, k = k0 + wn * 64 + j * 16 + 4 * kg;
             *(float4*)(ob + (long)n * p.ldo + k) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
         }
 }
@@ -178,7 +346,8 @@ hipError_t launch_gemm_tn(const GemmTnParams& p, hipStream_t stream) {
     if (!gemm_tn_ok(p) || !p.A || !p.B || !p.out) return hipErrorInvalidValue;
     if (sched_trace_on())
         sched_trace_launch("gemm_tn", stream, {treg(p.A, ((size_t)(p.M - 1) * p.lda + p.N) * 2), treg(p.B, ((size_t)(p.M - 1) * p.ldb + p.K) * 2)},
-                           {treg(p.out, (((size_t)(p.N - 1) * p.ldo + p.K) + (size_t)(p.k_split > 1 ? p.k_split - 1 : 0) * p.split_stride) * 4)});
+                           {treg(p.out, (((size_t)(p.N - 1) * p.ldo + p.K) + (size_t)(p.k_split > 1 ? p.k_split - 1 : 0) * p.split_stride) * 4),
+                            treg(p.colsum, p.colsum ? (size_t)(p.k_split > 1 ? p.k_split : 1) * p.N * 4 : 0)});
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE);
@@ -186,6 +355,17 @@ hipError_t launch_gemm_tn(const GemmTnParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const int nsplit = p.k_split > 1 ? p.k_split : 1;
+    if (p.tile256 && p.N % 256 == 0 && p.K % 256 == 0) {
+        if (p.colsum) return hipErrorInvalidValue;
+        static bool attr_b = false;
+        if (!attr_b) {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_B);
+            if (e != hipSuccess) return e;
+            attr_b = true;
+        }
+        hipLaunchKernelGGL(gemm_tn256_kernel, dim3((p.N / 256) * (p.K / 256) * nsplit), dim3(512), 2 * STAGE_B, stream, p);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(gemm_tn_kernel, dim3((p.N / 128) * (p.K / 128) * nsplit), dim3(256), 2 * STAGE, stream, p);
     return hipGetLastError();
 }

@@ -82,6 +82,8 @@ struct GemmTnParams {
     int M, N, K;
     float* out; long ldo;             // fp32 [N][ldo]
     int k_split; long split_stride;   // split over m, like GemmParams
+    float* colsum;                    // optional [k_split][N] fp32: per-split column sums of A (the bias gradient's partials); nullptr = not taken
+    int tile256;                      // 1 = the 256 x 256-tile form (8 waves, one workgroup per CU) where N and K are multiples of 256
 };
 bool gemm_tn_ok(const GemmTnParams& p);
 hipError_t launch_gemm_tn(const GemmTnParams& p, hipStream_t stream);

@@ -110,7 +110,7 @@ SIGNATURES = {
     "mi355_sched_trace_read": (C.c_longlong, [C.c_char_p, C.c_longlong]),
     "mi355_op_linear_trace": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "mi355_op_linear_gate_res": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
-    "mi355_op_wgrad": (_I, [_P, _P, C.c_int64, _P, C.c_int64, _P, _I, _I, _I, _I, _I, _P]),
+    "mi355_op_wgrad": (_I, [_P, _P, C.c_int64, _P, C.c_int64, _P, _I, _I, _I, _I, _I, _P, _P]),
     "mi355_clock_probe": (_I, [_P, _P, _I, _I]),
     "mi355_op_attention": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     "mi355_op_ln_modulate": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _F]),

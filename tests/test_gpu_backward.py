@@ -558,6 +558,21 @@ def test_weight_gradient_gemm_on_row_major_operands_is_bit_identical_to_the_tran
     ref = dy.float().t() @ x.float()
     got = a.sum(0)
     assert _rel(got, ref) < 2e-5, _rel(got, ref)
+    # the bias gradient's partials from the same launch: per-slice column sums of dY out of the operand fragments (v_dot2c against (1, 1))
+    a2, cs = engine.op_wgrad(dy, x, split, variant=1, want_colsum=True)
+    assert torch.equal(a2, a) and cs.shape == (split, N)
+    nt = M // 64
+    for sidx in range(split):
+        lo, hi = nt * sidx // split * 64, nt * (sidx + 1) // split * 64
+        want = dy[lo:hi].float().sum(0)
+        assert float((cs[sidx] - want).abs().max()) <= 1e-4 * float(want.abs().max() + 1.0), (sidx, float((cs[sidx] - want).abs().max()))
+    assert torch.equal(engine.op_wgrad(dy, x, split, variant=1, want_colsum=True)[1], cs)       # deterministic
+    if N % 256 == 0 and K % 256 == 0:
+        # the 256 x 256-tile form (8 waves, one workgroup per CU; what the engine takes for N = K = 1536): the same bits again
+        c = engine.op_wgrad(dy, x, split, variant=2)
+        assert torch.equal(c, a), float((c - a).abs().max())
+        for _ in range(3):
+            assert torch.equal(engine.op_wgrad(dy, x, split, variant=2), c)
     with pytest.raises(RuntimeError):
         engine.op_wgrad(dy[:M - 1], x[:M - 1], 1, variant=1)          # M not a multiple of 64: refused, never padded silently
 
@@ -594,7 +609,9 @@ def test_replay_gradients_with_row_major_weight_gradient_gemms_equal_the_transpo
         for n, g1 in grads[1].items():
             g0 = grads[0][n]
             if n.endswith(".weight"):
-                assert torch.equal(g1, g0), n
+                # same products; where the 256 x 256 form is taken the split over m differs from the transposed-copy path's (another
+                # association of the fp32 partial sums), elsewhere the gradients are bit-identical
+                assert torch.equal(g1, g0) or _rel(g1, g0) < (1e-2 if bf16_master else 2e-6), (n, _rel(g1, g0))
                 n_w += int(float(g1.float().norm()) > 0)
             else:
                 assert _rel(g1, g0) < (1e-2 if bf16_master else 1e-5), (n, _rel(g1, g0))
