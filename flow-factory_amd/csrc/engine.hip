@@ -121,7 +121,7 @@ static hipError_t sde_p(const SdeStepParams& s, hipStream_t st) { ProfScope ps(P
 // training-mode state (engine_train.inc, included at the end of this file)
 static int g_train_two_stream = 1;   // key 22, see engine_train.inc
 static int g_wgrad_tn = 1;           // key 39: weight gradients of whole-tile shapes on the row-major-operand kernels (gemm_tn.hip): no dY^T / X^T copies
-                                     // (1 = 256 x 256 tiles where they give a one-round grid, else 128 x 128; 2 = 128 x 128 only; 0 = transposed copies)
+                                     // (1 = 128 x 128 tiles; 2 = 256 x 256 tiles where they give a one-round grid, else 128 x 128: measured equal; 0 = transposed copies)
 static int g_fuse_colsum = 1;        // key 38: bias-gradient column-sum finish inside the weight gradient's split-K reduction launch (engine_train.inc: wgrad)
 struct mi355_engine;
 struct mi355_plan;
@@ -1085,7 +1085,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 34) { set_mid_min_tiles(value); return 0; }     // smallest grid of its tiles (default 160)
     if (key == 37) { set_mid_max_tiles(value); return 0; }     // largest grid of its tiles
     if (key == 35 || key == 36) return 0;                      // (round-6 measurement knobs of that kernel -- staggered LDS-DMA slots, launch-class mask -- measured and removed: accepted as no-ops)
-    if (key == 39) { g_wgrad_tn = value; return 0; }           // optimize() backward: 1 (default) = weight-gradient GEMMs read dY / X row-major through transposed LDS reads, 0 = transposed copies
+    if (key == 39) { g_wgrad_tn = value; return 0; }           // optimize() backward: 1 (default) = weight-gradient GEMMs read dY / X row-major through transposed LDS reads (2: 256 x 256 tiles where they fit), 0 = transposed copies
     if (key == 38) { g_fuse_colsum = value; return 0; }        // optimize() backward: 1 (default) = column-sum finish fused into the split-K reduction launch, 0 = two launches
     if (key == 22) { g_train_two_stream = value; return 0; }   // optimize() replay: the context-stream chain of the training forward / backward on a side stream (1 = default)
     if (key == 21) { set_attn128_op_bound(value); return 0; }  // mi355_op_attention128: the |score| bound the caller asserts (0 = none)          // default GEMM dispatch: largest K for the 4-wave hand-scheduled kernel
