@@ -33,6 +33,9 @@ double g_mid_alpha = 1.0;     // margin of that rule: the mid-size kernel's esti
 int g_mid_max_tiles = 256;    // largest grid of its tiles: ONE round, one workgroup per CU (measured in-model, profiles/r06b / r06d: two-round grids lose
                               // to the ping-pong kernel's 192 tiles + the CUs it leaves to the text chain: 1024^2 B = 2 -7 %); mi355_tune_set(37, v)
 int g_mid_plan_hint = 1;      // set by the SD3.5 engine around a forward (set_mid_plan_hint): 0 = the plan's text chain is too small for the kernel to pay
+int g_w6_mode = 1;            // 256x192 kernel: 0 off, 1 by the cost rule of launch_epi, 2 wherever it applies; mi355_tune_set(40, v)
+double g_w6_alpha = 1.05;     // its margin; mi355_tune_set(41, percent)
+int g_w6_min_tiles = 200;     // no launch below this many of its tiles; mi355_tune_set(42, v)
 int g_mid_min_tiles = 160;    // no mid-size launch below this many of its tiles (sub-chip grids: a lone 128x128 tile per CU is quicker); mi355_tune_set(34, v)
 
 // linear tile id -> (tm, tn).  Bands of `gm` tile rows are walked column by column, so the ~32 consecutive ids that the workgroups of one
@@ -1178,6 +1181,139 @@ inline bool w4_ok(const GemmParams& p) {      // whole tiles only (the kernel ha
            (EPI != EPI_VT || ((p.rows_per_sample | p.s_off) & 7) == 0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256x192x64 kernel (round 6): the hand-scheduled 4-wave loop on a 4 x 1 wave grid, each wave a 64 x 192 register tile (192 AGPR accumulators;
+// W6_LOOP_ASM of gemm_w4_asm.inc).  For grids that 256x256 tiles cut into 0.75 / 1.5 rounds of the 256 CUs -- 8192 rows x N = 1536 / 3072: the
+// image stream of SD3.5 at B = 2, 1024^2 (192 / 384 tiles) -- 256x192 tiles are whole rounds (256 / 512) with a quarter less work on every CU
+// than the 256x256 kernels' busy ones.  The wave tile spans the tile's whole width, so every 64-column chunk of the shared epilogues (a q/k head)
+// lies inside one wave.  Same MFMA, operand order and ascending-k accumulation as every kernel of this file: bit-identical outputs.
+// Requirements (launcher): M % 256 == 0, N % 192 == 0, K % 128 == 0.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_w6_kernel(GemmParams p) {
+    constexpr int BM = 256, BN = 192;
+    constexpr int STAGE = 57344, XW_OFF = 32768;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // persistent tile schedule (as gemm_pp_kernel)
+    const int ntm = p.M / BM, ntn = p.N / BN;
+    const int nblk = ntm * ntn;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per_xcd = (int)(gridDim.x >> 3);
+    const int q8 = nblk >> 3, r8 = nblk & 7;
+    const int chunk_lo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int chunk_n = q8 + (xcd < r8 ? 1 : 0);
+    if (slot >= chunk_n) return;
+    const int my_tiles = (chunk_n - slot + per_xcd - 1) / per_xcd;
+
+    // LDS-DMA: wave w fills X rows [64 w, 64 w + 64) and W rows [48 w, 48 w + 48), 8 rows (1 KiB) per instruction; lane -> (row = l >> 3, LDS
+    // chunk position l & 7); the position holds source chunk  pos ^ ((row >> 1) & 7)
+    unsigned ga[8], gw[6];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int row = wave * 64 + g * 8 + (lane >> 3);
+        ga[g] = ((unsigned)row * (unsigned)p.lda + (unsigned)((((lane & 7) ^ ((row >> 1) & 7))) * 8)) * 2u;
+    }
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {
+        const int row = wave * 48 + g * 8 + (lane >> 3);
+        gw[g] = ((unsigned)row * (unsigned)p.ldw + (unsigned)((((lane & 7) ^ ((row >> 1) & 7))) * 8)) * 2u;
+    }
+    // fragment reads: lane -> (row l & 15 of a 16-row block, k-chunk kk * 4 + (l >> 4)), position = chunk ^ ((row >> 1) & 7); X blocks of this
+    // wave's 64 rows, W blocks of the whole 192-row tile
+    const unsigned lds0 = (unsigned)(unsigned long)((__attribute__((address_space(3))) char*)smem);
+    unsigned lx[2][2], lw[2][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const unsigned in_blk = (unsigned)((lane & 15) * 128 + (((kk * 4 + (lane >> 4)) ^ ((lane & 15) >> 1)) << 4));
+            lx[st][kk] = lds0 + st * STAGE + wave * 8192 + in_blk;
+            lw[st][kk] = lds0 + st * STAGE + XW_OFF + in_blk;
+        }
+    const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + wave * 8192);                 // this wave's LDS-DMA destinations inside a stage
+    const unsigned ldsww = __builtin_amdgcn_readfirstlane(lds0 + XW_OFF + wave * 6144);
+
+    auto tile_bases = [&](int tile, unsigned long long& a, unsigned long long& w, int& m0, int& n0) {
+        int tm, tn;
+        tile_coords(tile, ntm, ntn, p.raster_gm, tm, tn);
+        m0 = tm * BM; n0 = tn * BN;
+        a = (unsigned long long)p.A + (unsigned long long)m0 * (unsigned long long)p.lda * 2ull;
+        w = (unsigned long long)p.W + (unsigned long long)n0 * (unsigned long long)p.ldw * 2ull;
+    };
+    unsigned long long cA, cW, nA, nW;
+    int m0, n0, m0n, n0n;
+    tile_bases(chunk_lo + slot, cA, cW, m0, n0);
+    {   // K-tile 0 of the first tile -> stage 0
+#pragma unroll
+        for (int g = 0; g < 8; ++g) glds16((const char*)cA + ga[g], smem + wave * 8192 + g * 1024);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) glds16((const char*)cW + gw[g], smem + XW_OFF + wave * 6144 + g * 1024);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const int pairs = p.K / 128 - 1;
+    char* stg = smem + 2 * STAGE + wave * 8192;
+    for (int ti = 0; ti < my_tiles; ++ti) {
+        if (ti + 1 < my_tiles) tile_bases(chunk_lo + slot + (ti + 1) * per_xcd, nA, nW, m0n, n0n);
+        else { nA = cA; nW = cW; m0n = m0; n0n = n0; }       // nothing follows: the last prefetch re-reads this tile's first K-tile (unused)
+        asm volatile(W6_LOOP_ASM
+                     : : [ga0] "v"(ga[0]), [ga1] "v"(ga[1]), [ga2] "v"(ga[2]), [ga3] "v"(ga[3]), [ga4] "v"(ga[4]), [ga5] "v"(ga[5]), [ga6] "v"(ga[6]),
+                         [ga7] "v"(ga[7]), [gw0] "v"(gw[0]), [gw1] "v"(gw[1]), [gw2] "v"(gw[2]), [gw3] "v"(gw[3]), [gw4] "v"(gw[4]), [gw5] "v"(gw[5]),
+                         [lx00] "v"(lx[0][0]), [lx01] "v"(lx[0][1]), [lx10] "v"(lx[1][0]), [lx11] "v"(lx[1][1]),
+                         [lw00] "v"(lw[0][0]), [lw01] "v"(lw[0][1]), [lw10] "v"(lw[1][0]), [lw11] "v"(lw[1][1]), [cA] "s"(cA), [cW] "s"(cW), [nA] "s"(nA),
+                         [nW] "s"(nW), [pairs] "s"(pairs), [ldsw] "s"(ldsw), [ldsww] "s"(ldsww)
+                     : W4_CLOBBERS);
+        // ---- epilogue: six 32x64 chunks of the wave's 64x192 tile through the shared fused epilogues (wave-private LDS staging); the lane id is
+        //      laundered per tile for the reason given in gemm_w4_kernel
+#define W6_CHUNK(Q, C)                                                                                         \
+        {                                                                                                      \
+            f32x4 a2[2][4];                                                                                    \
+            W6_READ_CHUNK_##Q##_##C(a2)                                                                        \
+            epilogue_part<EPI, 2, true, HAS_COLB>(p, a2, m0 + wave * 64 + Q * 32, n0 + C * 64, stg, lane_e, bpre); \
+        }
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        constexpr bool HAS_COLB = EPI != EPI_VT && EPI != EPI_BIAS_ROW;
+#define W6_COLUMN_PART(C)                                                                                                \
+        {                                                                                                            \
+            BiasPre bpre;                                                                                            \
+            if constexpr (HAS_COLB)                                                                                   \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                         \
+                    bpre.v[j] = *(const float4*)(p.bias + n0 + C * 64 + j * 16 + 4 * (lane_e >> 4));                  \
+            W6_CHUNK(0, C) W6_CHUNK(1, C)                                                                            \
+        }
+        W6_COLUMN_PART(0) W6_COLUMN_PART(1) W6_COLUMN_PART(2)
+#undef W6_COLUMN_PART
+#undef W6_CHUNK
+        cA = nA; cW = nW; m0 = m0n; n0 = n0n;
+    }
+}
+
+template <int EPI>
+hipError_t launch_w6(const GemmParams& p, hipStream_t stream) {
+    auto kern = gemm_w6_kernel<EPI>;
+    constexpr int smem = 2 * 57344 + 4 * 8192;            // operand stages + epilogue staging = 144 KiB
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    int grid = (p.M / 256) * (p.N / 192);
+    if (grid > 256) grid = 256;
+    grid = (grid + 7) / 8 * 8;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, stream, p);
+    return hipGetLastError();
+}
+template <int EPI>
+inline bool w6_ok(const GemmParams& p) {      // whole tiles only
+    return p.M % 256 == 0 && p.N % 192 == 0 && p.K % 128 == 0 && p.K >= 128 && ((p.ldo & 7) == 0 || is_qk_epi(EPI) || EPI == EPI_VT) &&
+           (EPI != EPI_VT || ((p.rows_per_sample | p.s_off) & 7) == 0);
+}
+
 template <int BM, int BN, int WM, int WN, int EPI, bool CONV = false>
 hipError_t launch_cfg(const GemmParams& p, hipStream_t stream) {
     using C = Cfg<BM, BN, WM, WN>;
@@ -1234,6 +1370,14 @@ hipError_t launch_epi(const GemmParams& p, hipStream_t stream) {
         // ... and only for grids of at least g_w4_min_tiles tiles (round 5, profiles/r05j_knob_sweep.txt): on the 192 / 384-tile grids of the
         // reference's 512^2 examples (forward batch 4: q|k, MLP projection) its single wave per SIMD has no second round to hide a tile's
         // epilogue behind -- the ping-pong kernel runs that rollout 2.5 % faster (154.5 vs 150.7 denoise-steps/s), +-0.3 % at 8192 rows
+        // 256x192 tiles (round 6) where they turn a fractional last round of 256x256 tiles into whole rounds: a round of them costs 3 units of
+        // 128x128 work against 4 (8192 rows x N = 1536: 192 tiles of 256x256 = 0.75 rounds -> 256 tiles of 256x192 = 1 round, 3 vs 4 units;
+        // N = 3072: 1.5 -> 2 rounds, 6 vs 8).  Only the grid decides (see the mid-size kernel above); g_w6_mode: mi355_tune_set(40, v).
+        if (g_w6_mode != 0 && g_gemm_variant != 0 && fits32 && w6_ok<EPI>(p)) {
+            const long t192 = (long)(p.M / 256) * (p.N / 192);
+            const double cost_w6 = 3.0 * (double)((t192 + 255) / 256) * g_w6_alpha;
+            if (g_w6_mode == 2 || (big >= g_pp_min_tiles && cost_pp <= cost_128 && cost_w6 < cost_pp && t192 >= g_w6_min_tiles)) return launch_w6<EPI>(p, stream);
+        }
         const bool w4_default = p.K <= g_w4_max_k && p.N >= 3072 && EPI != EPI_VT && EPI != EPI_GATE_RES && big >= g_w4_min_tiles;
         if ((g_gemm_variant == 2 || (g_gemm_variant == 1 && w4_default)) && big >= g_pp_min_tiles && w4_ok<EPI>(p) && cost_pp <= cost_128) {
             if constexpr (EPI == EPI_BIAS) {      // ablation builds of the hand-scheduled loop (scripts/gemm_ab.py): 33 no loads, 34 no fragment reads, 35 MFMA only
@@ -1293,6 +1437,9 @@ void set_gemm_variant(int v) { g_gemm_variant = v; }
 void set_w4_max_k(int v) { g_w4_max_k = v; }
 void set_pp_min_tiles(int v) { g_pp_min_tiles = v; }
 void set_w4_min_tiles(int v) { g_w4_min_tiles = v; }
+void set_w6_mode(int v) { g_w6_mode = v; }
+void set_w6_alpha_percent(int v) { g_w6_alpha = v / 100.0; }
+void set_w6_min_tiles(int v) { g_w6_min_tiles = v; }
 void set_mid_mode(int v) { g_mid_mode = v; }
 void set_mid_alpha_percent(int v) { g_mid_alpha = v / 100.0; }
 void set_mid_min_tiles(int v) { g_mid_min_tiles = v; }

@@ -20,16 +20,33 @@ Schedule per K-tile t ("interval" = barrier(t - 1) .. barrier(t), 128 MFMAs = 20
 Every load has >= 64 MFMAs (1024 cycles) of flight before its wait, every fragment read >= 32; one filler per MFMA gap at most.  The first
 K-tile of the NEXT output tile is prefetched by the last interval (stage 0), so an output tile's prologue never waits for HBM.
 
+Second instance (round 6), prefix W6: tile 256 x 192 x 64, 4 waves (4 x 1), each wave a 64 x 192 register tile (MI = 4 row blocks x NI = 12 column
+blocks = 192 accumulators, 48 MFMAs per k-step, 4 + 12 fragment reads per k-step, 8 + 6 LDS-DMA instructions per wave and K-tile; stage = 32 KiB
+of X rows + 24 KiB of W rows).  Why: grids that the 256 x 256 tile cuts into 0.75 / 1.5 rounds of 256 CUs (8192 rows x N = 1536 / 3072: SD3.5 at
+B = 2, 1024^2) are whole rounds of 256 x 192 tiles with a quarter less work on every CU.  The wave tile spans the whole tile width so that the
+64-column chunks of the shared epilogues (a q/k head) never straddle two waves.
+
 usage: python gen_gemm_w4.py > gemm_w4_asm.inc      (the Makefile does this; the .inc is committed so that a build needs no Python)
 """
 import sys
 
 FB = 120                      # first fragment VGPR; fragments occupy v[FB : FB + 128)
-STAGE = 65536
 XW = 32768                    # W rows start here inside a stage
+
+
+class Tile:
+    """MI x NI 16 x 16 blocks per wave; GX / GW LDS-DMA instructions (8 rows each) per wave, operand and K-tile."""
+    def __init__(self, prefix, mi, ni, gx, gw, stage, x_off, read_gaps, m0_gaps, ld_gaps, adv_gap0):
+        self.prefix, self.MI, self.NI, self.GX, self.GW, self.STAGE = prefix, mi, ni, gx, gw, stage
+        self.x_off = x_off                      # VGPR offset of the W fragments inside a k-step's 64 fragment registers
+        self.read_gaps, self.m0_gaps, self.ld_gaps, self.adv_gap0 = read_gaps, m0_gaps, ld_gaps, adv_gap0
+        assert mi * 4 <= x_off and x_off + ni * 4 <= 64 and mi * ni * 4 <= 256 and mi + ni <= 16
+
+
+T = None                      # the instance being emitted
 # fixed scalar registers of the loop (clobbered)
 S_A, S_W, S_NA, S_NW = 80, 82, 84, 86       # 64-bit bases: this tile's X / W operand (advance 128 B per K-tile), next tile's
-S_CNT, S_LDS, S_M0SAVE = 88, 89, 90
+S_CNT, S_LDS, S_M0SAVE, S_LDSW = 88, 89, 90, 91        # S_LDSW: this wave's LDS-DMA destination inside the W region (W6 only: 6 KiB per wave)
 
 
 def xf(kk, mi):
@@ -38,34 +55,30 @@ def xf(kk, mi):
 
 
 def wf(kk, ni):
-    b = FB + kk * 64 + 32 + ni * 4
+    b = FB + kk * 64 + T.x_off + ni * 4
     return f"v[{b}:{b + 3}]"
 
 
 def acc(mi, ni):
-    b = (mi * 8 + ni) * 4
+    b = (mi * T.NI + ni) * 4
     return f"a[{b}:{b + 3}]"
 
 
 def mfmas(kk, zero=False, ablate_mfma=False):
     """64 MFMAs of one k-step; column-block-major inside row-block pairs so that consecutive MFMAs never share an accumulator."""
     out = []
-    for mi in range(8):
-        for ni in range(8):
+    for mi in range(T.MI):
+        for ni in range(T.NI):
             c = "0" if zero else acc(mi, ni)
             out.append(f"v_mfma_f32_16x16x32_bf16 {acc(mi, ni)}, {wf(kk, ni)}, {xf(kk, mi)}, {c}")
     return out
 
 
 def reads(kk, stage):
-    """16 ds_read_b128: the fragments of k-step kk from `stage`; X first (the first MFMAs need X[0] and W[0..7])."""
+    """MI + NI ds_read_b128: the fragments of k-step kk from `stage`."""
     out = []
-    order = []
-    for i in range(8):
-        order.append(("w", i))
-        order.append(("x", i))
-    # W[0..7] are needed by the first 8 MFMAs, X[0] by all of them: lead with X[0], then the W fragments, then the other X
-    order = [("x", 0)] + [("w", i) for i in range(8)] + [("x", i) for i in range(1, 8)]
+    # W[0..NI) are needed by the first NI MFMAs, X[0] by all of them: lead with X[0], then the W fragments, then the other X
+    order = [("x", 0)] + [("w", i) for i in range(T.NI)] + [("x", i) for i in range(1, T.MI)]
     for kind, i in order:
         if kind == "x":
             out.append(f"ds_read_b128 {xf(kk, i)}, %[lx{stage}{kk}] offset:{i * 2048}")
@@ -75,13 +88,15 @@ def reads(kk, stage):
 
 
 def loads(stage, nxt=False):
-    """16 (M0 set-up, LDS-DMA) pairs: this wave's 64 X rows and 64 W rows of one K-tile into `stage`."""
+    """GX + GW (M0 set-up, LDS-DMA) pairs: this wave's X rows and W rows of one K-tile into `stage`."""
     sa, sw = (S_NA, S_NW) if nxt else (S_A, S_W)
     out = []
-    for g in range(8):
-        for (reg, region, s) in (("ga", 0, sa), ("gw", XW, sw)):
-            out.append((f"s_add_i32 m0, s{S_LDS}, {stage * STAGE + region + g * 1024}",
-                        f"global_load_lds_dwordx4 %[{reg}{g}], s[{s}:{s + 1}]"))
+    for g in range(max(T.GX, T.GW)):
+        for (reg, region, s, n, base) in (("ga", 0, sa, T.GX, S_LDS), ("gw", XW, sw, T.GW, S_LDS if T.GW == T.GX else S_LDSW)):
+            if g >= n:
+                continue
+            off = stage * T.STAGE + (region if base == S_LDS else 0) + g * 1024
+            out.append((f"s_add_i32 m0, s{base}, {off}", f"global_load_lds_dwordx4 %[{reg}{g}], s[{s}:{s + 1}]"))
     return out
 
 
@@ -110,9 +125,15 @@ SCHED = {
 }
 
 
+def sched(abl):
+    if "sched" in abl:
+        return SCHED[abl["sched"]]
+    return dict(read=T.read_gaps, m0=T.m0_gaps, ld=T.ld_gaps)
+
+
 def half1(stage_read, stage_load, do_load, nxt, abl):
     """H1: MFMAs on k-step 1 (fragments read during the previous interval) | reads of k-step 0 | the loads of the next K-tile."""
-    sc = SCHED[abl.get("sched", "s0")]
+    sc = sched(abl)
     f = {}
     if not abl.get("noread"):
         for j, r in enumerate(reads(0, stage_read)):
@@ -125,14 +146,14 @@ def half1(stage_read, stage_load, do_load, nxt, abl):
 
 
 def half2(stage_read, adv, abl, zero=False):
-    sc = SCHED[abl.get("sched", "s0")]
+    sc = sched(abl)
     f = {}
     if not abl.get("noread"):
         for j, r in enumerate(reads(1, stage_read)):
             f.setdefault(sc["read"][j], []).append(r)
     if adv:
         for j, a in enumerate(advance()):
-            f.setdefault(33 + 2 * j, []).append(a)
+            f.setdefault(T.adv_gap0 + 2 * j, []).append(a)
     return interleave(mfmas(0, zero=zero), f)
 
 
@@ -159,12 +180,14 @@ def main_loop(abl={}):
     L.append(f"s_mov_b64 s[{S_NW}:{S_NW + 1}], %[nW]")
     L.append(f"s_mov_b32 s{S_CNT}, %[pairs]")
     L.append(f"s_mov_b32 s{S_LDS}, %[ldsw]")
+    if T.GW != T.GX:
+        L.append(f"s_mov_b32 s{S_LDSW}, %[ldsww]")
     # the bases point at K-tile 0 (in stage 0 already, landed, barrier passed); K-tile 1 is the first one to load
     L += advance()
     # ---- I_0: fragments of K-tile 0, loads of K-tile 1 -> stage 1, k-step 0 with C = 0 (lgkmcnt is a 4-bit counter: never more than
     #      16 LDS reads in flight)
     L += reads(0, 0)
-    sc = SCHED[abl.get("sched", "s0")]
+    sc = sched(abl)
     f = {}
     for j, r in enumerate(reads(1, 0)):
         f.setdefault(sc["read"][j], []).append(r)
@@ -178,14 +201,14 @@ def main_loop(abl={}):
     L += sync()
     # ---- pairs of intervals (t odd, t even), `pairs` = K / 128 - 1 times
     L.append(f"s_cmp_eq_u32 s{S_CNT}, 0")
-    L.append("s_cbranch_scc1 L_w4_tail%=")
-    L.append("L_w4_loop%=:")
+    L.append(f"s_cbranch_scc1 L_{T.prefix}_tail%=")
+    L.append(f"L_{T.prefix}_loop%=:")
     L += interval(True, abl=abl)
     L += interval(False, abl=abl)
     L.append(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
     L.append(f"s_cmp_lg_u32 s{S_CNT}, 0")
-    L.append("s_cbranch_scc1 L_w4_loop%=")
-    L.append("L_w4_tail%=:")
+    L.append(f"s_cbranch_scc1 L_{T.prefix}_loop%=")
+    L.append(f"L_{T.prefix}_tail%=:")
     # ---- last interval (t = K / 64 - 1, odd): prefetches K-tile 0 of the NEXT output tile into stage 0
     L += interval(True, nxt=True, abl=abl)
     # ---- k-step 1 of the last K-tile
@@ -206,29 +229,40 @@ def emit(name, lines):
     print()
 
 
+W4 = Tile("w4", 8, 8, 8, 8, 65536, 32, SCHED["s0"]["read"], SCHED["s0"]["m0"], SCHED["s0"]["ld"], 33)
+# 48 MFMAs per half: 16 reads behind MFMAs 0, 2, ..., 30; the 14 (M0 set-up, LDS-DMA) pairs behind 3j + 1 / 3j + 2 (last: 41); base advance from 40
+W6 = Tile("w6", 4, 12, 8, 6, 57344, 16, [2 * j for j in range(16)], [3 * j + 1 for j in range(14)], [3 * j + 2 for j in range(14)], 40)
+
+
 def main():
-    print("// GENERATED by gen_gemm_w4.py -- do not edit.  Main loop of gemm_w4_kernel (gemm.hip); see the generator's docstring.")
+    global T
+    print("// GENERATED by gen_gemm_w4.py -- do not edit.  Main loops of gemm_w4_kernel / gemm_w6_kernel (gemm.hip); see the generator's docstring.")
     print(f"#define W4_FRAG_BASE {FB}")
+    T = W4
     emit("W4_LOOP_ASM", main_loop())
     emit("W4_LOOP_ASM_NOLOAD", main_loop({"noload": True}))
     emit("W4_LOOP_ASM_NOREAD", main_loop({"noread": True}))
     emit("W4_LOOP_ASM_MFMA_ONLY", main_loop({"noread": True, "noload": True}))
     emit("W4_LOOP_ASM_S1", main_loop({"sched": "s1"}))
     emit("W4_LOOP_ASM_S3", main_loop({"sched": "s3"}))
+    T = W6
+    emit("W6_LOOP_ASM", main_loop())
     cl = [f'"a{i}"' for i in range(256)] + [f'"v{i}"' for i in range(FB, FB + 128)] + [f'"s{i}"' for i in range(80, 92)] + ['"scc"', '"memory"']
     print("#define W4_CLOBBERS " + ", ".join(cl))
     print()
     # accumulator read-out: W4_READ_CHUNK_q_c(a2) fills f32x4 a2[2][4] with the 32 x 64 chunk (row quarter q, column half c) of the wave tile
     print("#define W4_READ_ACC_(d, r0, r1, r2, r3) { float t0_, t1_, t2_, t3_; asm volatile(\"v_accvgpr_read_b32 %0, a\" #r0 \"\\n v_accvgpr_read_b32 %1, a\" #r1 \"\\n"
           " v_accvgpr_read_b32 %2, a\" #r2 \"\\n v_accvgpr_read_b32 %3, a\" #r3 : \"=v\"(t0_), \"=v\"(t1_), \"=v\"(t2_), \"=v\"(t3_)); d = (f32x4){t0_, t1_, t2_, t3_}; }")
-    for q in range(4):              # 32-row quarter of the wave tile
-        for c in range(2):          # 64-column half
-            body = []
-            for i in range(2):
-                for j in range(4):
-                    b = ((q * 2 + i) * 8 + (c * 4 + j)) * 4
-                    body.append(f"W4_READ_ACC_(a2[{i}][{j}], {b}, {b + 1}, {b + 2}, {b + 3})")
-            print(f"#define W4_READ_CHUNK_{q}_{c}(a2) " + " ".join(body))
+    for tile, name, nq, nc in ((W4, "W4", 4, 2), (W6, "W6", 2, 3)):
+        T = tile
+        for q in range(nq):             # 32-row part of the wave tile
+            for c in range(nc):         # 64-column part
+                body = []
+                for i in range(2):
+                    for j in range(4):
+                        b = ((q * 2 + i) * T.NI + (c * 4 + j)) * 4
+                        body.append(f"W4_READ_ACC_(a2[{i}][{j}], {b}, {b + 1}, {b + 2}, {b + 3})")
+                print(f"#define {name}_READ_CHUNK_{q}_{c}(a2) " + " ".join(body))
 
 
 if __name__ == "__main__":
