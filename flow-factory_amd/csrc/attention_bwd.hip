@@ -17,6 +17,7 @@
 // `ds_read_b64_tr_b16` -- no transposed copies in HBM or LDS (see below).  v in [S_pad][64] comes from the forward's V^T by one HBM-bound
 // transpose (backward.hip); -L | -Delta per 64-query tile from the prep kernel.
 #include "kernels.h"
+#include <type_traits>
 
 namespace mi355 {
 namespace {
@@ -184,79 +185,93 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dkv_tr_kernel(AttnBwd
     stage(0, 0);
     if (nt > 1) stage(1, 1);
     if (nt > 2) stage(2, 2);
-    for (int t = 0; t < nt; ++t) {
-        wait_tiles_ahead(nt - 1 - t, 5);
-        if (t + 3 < nt) stage(t + 3, (t + 3) & (NST1 - 1));      // its buffer held tile t - 1: every wave is past it (the barrier above)
-        const char* sb = smem + (t & (NST1 - 1)) * ST1T;
-        // -L / -Delta reads as inline assembly: hipcc guards every C-level read of an LDS range that an in-flight LDS-DMA may alias with
-        // `s_waitcnt vmcnt(0)` (it cannot tell the ring stages apart) -- which would drain the two tiles just put in flight
+    // one half tile (32 queries): reads -> S / dP chains -> P, dZ -> second products.  Round 6: (1) ALL sixteen fragment / C-operand reads of the
+    // half are issued by one asm statement and waited for once -- hipcc had paired every ds_read_b128 with an `s_waitcnt lgkmcnt(0)` in front of
+    // its MFMA (eight exposed LDS round trips per half); (2) the query-tail mask is compiled into the LAST tile's copy of the body only (MASK) --
+    // inside the loop it was a uniform branch behind every pair of v_exp, which also cut the schedule into sixteen regions.
+    auto half = [&](int t, auto qb_c, auto mask_c) {
+        constexpr int qb = decltype(qb_c)::value;
+        constexpr bool MASK = decltype(mask_c)::value;
+        f32x16 (&dv_)[2] = dv;      // (named here: an asm operand inside a generic lambda does not capture by itself)
+        f32x16 (&dk_)[2] = dk;
         const unsigned stg = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + (t & (NST1 - 1)) * ST1T);
         const unsigned sLa = stg + 2 * TILE + 32 * lg;
+        const unsigned r0 = stg + offR[0], r1 = stg + offR[1], r2 = stg + offR[2], r3 = stg + offR[3];
+        f32x16 s, dp;
+        bf16x8 qa[4], oa[4];
+        {
+            f32x4 a[4], b[4];
+#define DKV_READS(L0, L1, L2, L3, D0, D1, D2, D3, QO, OO)                                                                                          \
+            asm volatile("ds_read_b128 %0, %16 offset:" #L0 "\n\tds_read_b128 %1, %16 offset:" #L1 "\n\tds_read_b128 %2, %16 offset:" #L2 "\n\t"     \
+                         "ds_read_b128 %3, %16 offset:" #L3 "\n\tds_read_b128 %4, %16 offset:" #D0 "\n\tds_read_b128 %5, %16 offset:" #D1 "\n\t"     \
+                         "ds_read_b128 %6, %16 offset:" #D2 "\n\tds_read_b128 %7, %16 offset:" #D3 "\n\t"                                          \
+                         "ds_read_b128 %8, %17 offset:" #QO "\n\tds_read_b128 %12, %17 offset:" #OO "\n\t"                                         \
+                         "ds_read_b128 %9, %18 offset:" #QO "\n\tds_read_b128 %13, %18 offset:" #OO "\n\t"                                         \
+                         "ds_read_b128 %10, %19 offset:" #QO "\n\tds_read_b128 %14, %19 offset:" #OO "\n\t"                                        \
+                         "ds_read_b128 %11, %20 offset:" #QO "\n\tds_read_b128 %15, %20 offset:" #OO "\n\t"                                        \
+                         "s_waitcnt lgkmcnt(0)"                                                                                                  \
+                         : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]),                 \
+                           "=&v"(qa[0]), "=&v"(qa[1]), "=&v"(qa[2]), "=&v"(qa[3]), "=&v"(oa[0]), "=&v"(oa[1]), "=&v"(oa[2]), "=&v"(oa[3])          \
+                         : "v"(sLa), "v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory")
+            if constexpr (qb == 0) DKV_READS(0, 16, 64, 80, 256, 272, 320, 336, 0, 8192);
+            else DKV_READS(128, 144, 192, 208, 384, 400, 448, 464, 4096, 12288);
+#undef DKV_READS
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) {
-            f32x16 s, dp;
-            {
-                f32x4 a[4], b[4];
-                if (qb == 0) {
-                    asm volatile("ds_read_b128 %0, %8\n\tds_read_b128 %1, %8 offset:16\n\tds_read_b128 %2, %8 offset:64\n\tds_read_b128 %3, %8 offset:80\n\t"
-                                 "ds_read_b128 %4, %8 offset:256\n\tds_read_b128 %5, %8 offset:272\n\tds_read_b128 %6, %8 offset:320\n\t"
-                                 "ds_read_b128 %7, %8 offset:336\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]) : "v"(sLa) : "memory");
-                } else {
-                    asm volatile("ds_read_b128 %0, %8 offset:128\n\tds_read_b128 %1, %8 offset:144\n\tds_read_b128 %2, %8 offset:192\n\tds_read_b128 %3, %8 offset:208\n\t"
-                                 "ds_read_b128 %4, %8 offset:384\n\tds_read_b128 %5, %8 offset:400\n\tds_read_b128 %6, %8 offset:448\n\t"
-                                 "ds_read_b128 %7, %8 offset:464\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]) : "v"(sLa) : "memory");
-                }
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { s[4 * j + e] = a[j][e]; dp[4 * j + e] = b[j][e]; }
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8 qa = *(const bf16x8*)(sb + offR[kk] + qb * 4096);
-                const bf16x8 oa = *(const bf16x8*)(sb + TILE + offR[kk] + qb * 4096);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa, vf[kk], dp, 0, 0, 0);
-            }
-            unsigned pk[8], zk[8];
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
-                if (t == nt - 1) {
-                    const int ql = 32 * qb + 16 * (r >> 3) + 8 * lg + (r & 7);
-                    if (t * TB + ql >= p.S) p0 = 0.f;
-                    if (t * TB + ql + 1 >= p.S) p1 = 0.f;
-                }
-                pk[r >> 1] = pack_bf16(p0, p1);
-                zk[r >> 1] = pack_bf16(p0 * dp[r], p1 * dp[r + 1]);
-            }
-            // dV^T += dO^T . P and dK^T += Q^T . dZ over this half tile's 32 queries (two k-steps hs of 16): A fragments = transposed reads of the
-            // dO tile (offset 8192) and the Q tile, v[224:239] for hs = 0, v[240:255] for hs = 1: [dO db0 | dO db1 | Q db0 | Q db1] x 4 registers
-            {
-                const bf16x8 pf0 = frag4(pk[0], pk[1], pk[2], pk[3]), pf1 = frag4(pk[4], pk[5], pk[6], pk[7]);
-                const bf16x8 zf0 = frag4(zk[0], zk[1], zk[2], zk[3]), zf1 = frag4(zk[4], zk[5], zk[6], zk[7]);
-                const unsigned a0 = stg + qb * 4096 + trb[0][0], a1 = stg + qb * 4096 + trb[0][1];
-                const unsigned a2 = stg + qb * 4096 + trb[1][0], a3 = stg + qb * 4096 + trb[1][1];
-                asm volatile(
-                    TR_RD("v[224:225]", "%[a0]", 8192) TR_RD("v[226:227]", "%[a1]", 8192) TR_RD("v[228:229]", "%[a2]", 8192) TR_RD("v[230:231]", "%[a3]", 8192)
-                    TR_RD("v[232:233]", "%[a0]", 0) TR_RD("v[234:235]", "%[a1]", 0) TR_RD("v[236:237]", "%[a2]", 0) TR_RD("v[238:239]", "%[a3]", 0)
-                    TR_RD("v[240:241]", "%[a0]", 10240) TR_RD("v[242:243]", "%[a1]", 10240) TR_RD("v[244:245]", "%[a2]", 10240) TR_RD("v[246:247]", "%[a3]", 10240)
-                    "s_waitcnt lgkmcnt(4)\n\t"
-                    MFMA32("%[dv0]", "v[224:227]", "%[pf0]") MFMA32("%[dk0]", "v[232:235]", "%[zf0]")
-                    TR_RD("v[248:249]", "%[a0]", 2048) TR_RD("v[250:251]", "%[a1]", 2048) TR_RD("v[252:253]", "%[a2]", 2048) TR_RD("v[254:255]", "%[a3]", 2048)
-                    MFMA32("%[dv1]", "v[228:231]", "%[pf0]") MFMA32("%[dk1]", "v[236:239]", "%[zf0]")
-                    "s_waitcnt lgkmcnt(0)\n\t"
-                    MFMA32("%[dv0]", "v[240:243]", "%[pf1]") MFMA32("%[dk0]", "v[248:251]", "%[zf1]")
-                    MFMA32("%[dv1]", "v[244:247]", "%[pf1]") MFMA32("%[dk1]", "v[252:255]", "%[zf1]")
-                    : [dv0] "+v"(dv[0]), [dv1] "+v"(dv[1]), [dk0] "+v"(dk[0]), [dk1] "+v"(dk[1])
-                    : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [pf0] "v"(pf0), [pf1] "v"(pf1), [zf0] "v"(zf0), [zf1] "v"(zf1)
-                    : "memory", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
-                      "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
-            }
+                for (int e = 0; e < 4; ++e) { s[4 * j + e] = a[j][e]; dp[4 * j + e] = b[j][e]; }
         }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[kk], kf[kk], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa[kk], vf[kk], dp, 0, 0, 0);
+        }
+        unsigned pk[8], zk[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
+            if constexpr (MASK) {
+                const int ql = 32 * qb + 16 * (r >> 3) + 8 * lg + (r & 7);
+                if (t * TB + ql >= p.S) p0 = 0.f;
+                if (t * TB + ql + 1 >= p.S) p1 = 0.f;
+            }
+            pk[r >> 1] = pack_bf16(p0, p1);
+            zk[r >> 1] = pack_bf16(p0 * dp[r], p1 * dp[r + 1]);
+        }
+        // dV^T += dO^T . P and dK^T += Q^T . dZ over this half tile's 32 queries (two k-steps hs of 16): A fragments = transposed reads of the
+        // dO tile (offset 8192) and the Q tile, v[224:239] for hs = 0, v[240:255] for hs = 1: [dO db0 | dO db1 | Q db0 | Q db1] x 4 registers
+        {
+            const bf16x8 pf0 = frag4(pk[0], pk[1], pk[2], pk[3]), pf1 = frag4(pk[4], pk[5], pk[6], pk[7]);
+            const bf16x8 zf0 = frag4(zk[0], zk[1], zk[2], zk[3]), zf1 = frag4(zk[4], zk[5], zk[6], zk[7]);
+            const unsigned a0 = stg + qb * 4096 + trb[0][0], a1 = stg + qb * 4096 + trb[0][1];
+            const unsigned a2 = stg + qb * 4096 + trb[1][0], a3 = stg + qb * 4096 + trb[1][1];
+            asm volatile(
+                TR_RD("v[224:225]", "%[a0]", 8192) TR_RD("v[226:227]", "%[a1]", 8192) TR_RD("v[228:229]", "%[a2]", 8192) TR_RD("v[230:231]", "%[a3]", 8192)
+                TR_RD("v[232:233]", "%[a0]", 0) TR_RD("v[234:235]", "%[a1]", 0) TR_RD("v[236:237]", "%[a2]", 0) TR_RD("v[238:239]", "%[a3]", 0)
+                TR_RD("v[240:241]", "%[a0]", 10240) TR_RD("v[242:243]", "%[a1]", 10240) TR_RD("v[244:245]", "%[a2]", 10240) TR_RD("v[246:247]", "%[a3]", 10240)
+                "s_waitcnt lgkmcnt(4)\n\t"
+                MFMA32("%[dv0]", "v[224:227]", "%[pf0]") MFMA32("%[dk0]", "v[232:235]", "%[zf0]")
+                TR_RD("v[248:249]", "%[a0]", 2048) TR_RD("v[250:251]", "%[a1]", 2048) TR_RD("v[252:253]", "%[a2]", 2048) TR_RD("v[254:255]", "%[a3]", 2048)
+                MFMA32("%[dv1]", "v[228:231]", "%[pf0]") MFMA32("%[dk1]", "v[236:239]", "%[zf0]")
+                "s_waitcnt lgkmcnt(0)\n\t"
+                MFMA32("%[dv0]", "v[240:243]", "%[pf1]") MFMA32("%[dk0]", "v[248:251]", "%[zf1]")
+                MFMA32("%[dv1]", "v[244:247]", "%[pf1]") MFMA32("%[dk1]", "v[252:255]", "%[zf1]")
+                : [dv0] "+v"(dv_[0]), [dv1] "+v"(dv_[1]), [dk0] "+v"(dk_[0]), [dk1] "+v"(dk_[1])
+                : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [pf0] "v"(pf0), [pf1] "v"(pf1), [zf0] "v"(zf0), [zf1] "v"(zf1)
+                : "memory", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239",
+                  "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255");
+        }
+    };
+    using std::integral_constant;
+    for (int t = 0; t < nt - 1; ++t) {
+        wait_tiles_ahead(nt - 1 - t, 5);
+        if (t + 3 < nt) stage(t + 3, (t + 3) & (NST1 - 1));      // its buffer held tile t - 1: every wave is past it (the barrier above)
+        half(t, integral_constant<int, 0>{}, integral_constant<bool, false>{});
+        half(t, integral_constant<int, 1>{}, integral_constant<bool, false>{});
     }
+    wait_tiles_ahead(0, 5);                                      // the last tile, behind the loop (no accumulator merge inside it)
+    half(nt - 1, integral_constant<int, 0>{}, integral_constant<bool, true>{});
+    half(nt - 1, integral_constant<int, 1>{}, integral_constant<bool, true>{});
     __syncthreads();     // every wave is done with the ring: reuse it for the output transposes (4 KiB per wave)
     char* ob = smem + wave * 4096;
     const int row0 = kblk * KB + wave * 32;
@@ -328,50 +343,67 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dq_tr_kernel(AttnBwdP
     stage(0, 0);
     if (nt > 1) stage(1, 1);
     if (nt > 2) stage(2, 2);
-    for (int t = 0; t < nt; ++t) {
+    // one half tile (32 keys); round 6: all eight fragment reads up front, one wait; the key-tail mask only in the last tile's copy (see pass 1)
+    auto half = [&](int t, auto kb_c, auto mask_c) {
+        constexpr int kb = decltype(kb_c)::value;
+        constexpr bool MASK = decltype(mask_c)::value;
+        f32x16 (&dq_)[2] = dq;      // (see pass 1)
+        const unsigned stg = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + (t % NST2) * ST2T);
+        const unsigned r0 = stg + offR[0], r1 = stg + offR[1], r2 = stg + offR[2], r3 = stg + offR[3];
+        bf16x8 ka[4], va[4];
+#define DQ_READS(KO, VO)                                                                                                                       \
+        asm volatile("ds_read_b128 %0, %8 offset:" #KO "\n\tds_read_b128 %4, %8 offset:" #VO "\n\tds_read_b128 %1, %9 offset:" #KO "\n\t"            \
+                     "ds_read_b128 %5, %9 offset:" #VO "\n\tds_read_b128 %2, %10 offset:" #KO "\n\tds_read_b128 %6, %10 offset:" #VO "\n\t"          \
+                     "ds_read_b128 %3, %11 offset:" #KO "\n\tds_read_b128 %7, %11 offset:" #VO "\n\ts_waitcnt lgkmcnt(0)"                          \
+                     : "=&v"(ka[0]), "=&v"(ka[1]), "=&v"(ka[2]), "=&v"(ka[3]), "=&v"(va[0]), "=&v"(va[1]), "=&v"(va[2]), "=&v"(va[3])              \
+                     : "v"(r0), "v"(r1), "v"(r2), "v"(r3) : "memory")
+        if constexpr (kb == 0) DQ_READS(0, 8192);
+        else DQ_READS(4096, 12288);
+#undef DQ_READS
+        f32x16 s, dp;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[kk], qf[kk], kk == 0 ? nL : s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[kk], of[kk], kk == 0 ? nD : dp, 0, 0, 0);
+        }
+        unsigned zk[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
+            if constexpr (MASK) {
+                const int kl = t * TB + 32 * kb + 16 * (r >> 3) + 8 * lg + (r & 7);
+                if (kl >= p.S) p0 = 0.f;
+                if (kl + 1 >= p.S) p1 = 0.f;
+            }
+            zk[r >> 1] = pack_bf16(p0 * dp[r], p1 * dp[r + 1]);
+        }
+        // dQ^T += K^T . dZ^T over this half tile's 32 keys: A fragments = transposed reads of the K tile, v[224:231] (hs = 0), v[232:239] (hs = 1)
+        {
+            const bf16x8 zf0 = frag4(zk[0], zk[1], zk[2], zk[3]), zf1 = frag4(zk[4], zk[5], zk[6], zk[7]);
+            const unsigned a0 = stg + kb * 4096 + trb[0][0], a1 = stg + kb * 4096 + trb[0][1];
+            const unsigned a2 = stg + kb * 4096 + trb[1][0], a3 = stg + kb * 4096 + trb[1][1];
+            asm volatile(
+                TR_RD("v[224:225]", "%[a0]", 0) TR_RD("v[226:227]", "%[a1]", 0) TR_RD("v[228:229]", "%[a2]", 0) TR_RD("v[230:231]", "%[a3]", 0)
+                TR_RD("v[232:233]", "%[a0]", 2048) TR_RD("v[234:235]", "%[a1]", 2048) TR_RD("v[236:237]", "%[a2]", 2048) TR_RD("v[238:239]", "%[a3]", 2048)
+                "s_waitcnt lgkmcnt(4)\n\t"
+                MFMA32("%[dq0]", "v[224:227]", "%[zf0]") MFMA32("%[dq1]", "v[228:231]", "%[zf0]")
+                "s_waitcnt lgkmcnt(0)\n\t"
+                MFMA32("%[dq0]", "v[232:235]", "%[zf1]") MFMA32("%[dq1]", "v[236:239]", "%[zf1]")
+                : [dq0] "+v"(dq_[0]), [dq1] "+v"(dq_[1])
+                : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [zf0] "v"(zf0), [zf1] "v"(zf1)
+                : "memory", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239");
+        }
+    };
+    using std::integral_constant;
+    for (int t = 0; t < nt - 1; ++t) {
         wait_tiles_ahead(nt - 1 - t, 4);
         if (t + 3 < nt) stage(t + 3, (t + 3) % NST2);
-        const char* sb = smem + (t % NST2) * ST2T;
-        const unsigned stg = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(smem + (t % NST2) * ST2T);
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            f32x16 s, dp;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8 ka = *(const bf16x8*)(sb + offR[kk] + kb * 4096);
-                const bf16x8 va = *(const bf16x8*)(sb + TILE + offR[kk] + kb * 4096);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[kk], kk == 0 ? nL : s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, of[kk], kk == 0 ? nD : dp, 0, 0, 0);
-            }
-            unsigned zk[8];
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                float p0 = __builtin_amdgcn_exp2f(s[r]), p1 = __builtin_amdgcn_exp2f(s[r + 1]);
-                if (t == nt - 1) {
-                    const int kl = t * TB + 32 * kb + 16 * (r >> 3) + 8 * lg + (r & 7);
-                    if (kl >= p.S) p0 = 0.f;
-                    if (kl + 1 >= p.S) p1 = 0.f;
-                }
-                zk[r >> 1] = pack_bf16(p0 * dp[r], p1 * dp[r + 1]);
-            }
-            // dQ^T += K^T . dZ^T over this half tile's 32 keys: A fragments = transposed reads of the K tile, v[224:231] (hs = 0), v[232:239] (hs = 1)
-            {
-                const bf16x8 zf0 = frag4(zk[0], zk[1], zk[2], zk[3]), zf1 = frag4(zk[4], zk[5], zk[6], zk[7]);
-                const unsigned a0 = stg + kb * 4096 + trb[0][0], a1 = stg + kb * 4096 + trb[0][1];
-                const unsigned a2 = stg + kb * 4096 + trb[1][0], a3 = stg + kb * 4096 + trb[1][1];
-                asm volatile(
-                    TR_RD("v[224:225]", "%[a0]", 0) TR_RD("v[226:227]", "%[a1]", 0) TR_RD("v[228:229]", "%[a2]", 0) TR_RD("v[230:231]", "%[a3]", 0)
-                    TR_RD("v[232:233]", "%[a0]", 2048) TR_RD("v[234:235]", "%[a1]", 2048) TR_RD("v[236:237]", "%[a2]", 2048) TR_RD("v[238:239]", "%[a3]", 2048)
-                    "s_waitcnt lgkmcnt(4)\n\t"
-                    MFMA32("%[dq0]", "v[224:227]", "%[zf0]") MFMA32("%[dq1]", "v[228:231]", "%[zf0]")
-                    "s_waitcnt lgkmcnt(0)\n\t"
-                    MFMA32("%[dq0]", "v[232:235]", "%[zf1]") MFMA32("%[dq1]", "v[236:239]", "%[zf1]")
-                    : [dq0] "+v"(dq[0]), [dq1] "+v"(dq[1])
-                    : [a0] "v"(a0), [a1] "v"(a1), [a2] "v"(a2), [a3] "v"(a3), [zf0] "v"(zf0), [zf1] "v"(zf1)
-                    : "memory", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239");
-            }
-        }
+        half(t, integral_constant<int, 0>{}, integral_constant<bool, false>{});
+        half(t, integral_constant<int, 1>{}, integral_constant<bool, false>{});
     }
+    wait_tiles_ahead(0, 4);
+    half(nt - 1, integral_constant<int, 0>{}, integral_constant<bool, true>{});
+    half(nt - 1, integral_constant<int, 1>{}, integral_constant<bool, true>{});
     __syncthreads();
     char* ob = smem + wave * 4096;
     store_rows(dq, LN2, ob, p.dq + bh * p.S_pad * 64, qblk * QB + wave * 32, p.S, lane);

@@ -33,7 +33,12 @@ double g_mid_alpha = 1.0;     // margin of that rule: the mid-size kernel's esti
 int g_mid_max_tiles = 256;    // largest grid of its tiles: ONE round, one workgroup per CU (measured in-model, profiles/r06b / r06d: two-round grids lose
                               // to the ping-pong kernel's 192 tiles + the CUs it leaves to the text chain: 1024^2 B = 2 -7 %); mi355_tune_set(37, v)
 int g_mid_plan_hint = 1;      // set by the SD3.5 engine around a forward (set_mid_plan_hint): 0 = the plan's text chain is too small for the kernel to pay
-int g_w6_mode = 1;            // 256x192 kernel: 0 off, 1 by the cost rule of launch_epi, 2 wherever it applies; mi355_tune_set(40, v)
+int g_w6_mode = 0;            // 256x192 kernel: 0 off (default), 1 by the cost rule of launch_epi, 2 wherever it applies; mi355_tune_set(40, v).
+                              // Measured (profiles/r06n_*): back to back it is 16-20 % faster than the 0.75- / 1.5-round 256x256 grids it replaces
+                              // (8192 x 1536 x 6144: 132 -> 106 us = 1.46 PFLOP/s), bit-identical -- and the SD3.5 forward gets 2.4 % SLOWER with
+                              // it (B = 2, 1024^2: 24.05 -> 24.63 ms; optimize() 83.1 -> 83.6 ms): the quarter of the CUs that a 192-tile grid
+                              // leaves free is where the text stream's GEMMs run (two-stream forward), and a 144 KiB workgroup on every CU
+                              // shuts them out.  Kept for single-stream callers and as a tested tile shape; off in the shipped dispatch.
 double g_w6_alpha = 1.05;     // its margin; mi355_tune_set(41, percent)
 int g_w6_min_tiles = 200;     // no launch below this many of its tiles; mi355_tune_set(42, v)
 int g_mid_min_tiles = 160;    // no mid-size launch below this many of its tiles (sub-chip grids: a lone 128x128 tile per CU is quicker); mi355_tune_set(34, v)

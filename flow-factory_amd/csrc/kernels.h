@@ -112,7 +112,7 @@ void set_w4_max_k(int k);      // largest K that the default dispatch gives to t
 int get_gemm_variant();
 void set_pp_min_tiles(int v);
 void set_w4_min_tiles(int v);
-void set_w6_mode(int v);            // 256x192 GEMM kernel: 0 off, 1 cost rule (default), 2 wherever it applies
+void set_w6_mode(int v);            // 256x192 GEMM kernel: 0 off (default), 1 cost rule, 2 wherever it applies
 void set_w6_alpha_percent(int v);
 void set_w6_min_tiles(int v);
 void set_mid_mode(int v);
