@@ -409,7 +409,157 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dq_tr_kernel(AttnBwdP
     store_rows(dq, LN2, ob, p.dq + bh * p.S_pad * 64, qblk * QB + wave * 32, p.S, lane);
 }
 
+// =============================================================================================== round 6: software-pipelined passes
+// The same two passes with their main loops as ONE hand-scheduled asm statement each (attn_bwd64_asm.inc, generated by gen_attn_bwd64.py: its
+// docstring has the schedule): the second products of half h - 1, the exp / scale / pack of half h and the S / dP chains of half h + 1 are
+// interleaved MFMA by MFMA, so a single wave keeps the matrix pipe fed.  Same arithmetic in the same order per output element: bit-identical to
+// the kernels above (kept: mi355_tune_set(43, 0), and the A/B of tests/test_gpu_backward.py).
+// CONTRACT (both pairs of kernels relied on it already -- a masked probability times a NaN is a NaN): rows [S, S_pad) of q, k, v and dO are
+// ZERO.  The engines' workspaces are zero-initialised and only rows < S are ever written; the pipelined loops carry no tail masks at all (a zero
+// query row adds exactly 0 to dK^T / dV^T, a zero key row exactly 0 to dQ^T).
+#include "attn_bwd64_asm.inc"
+
+__global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dkv_pipe_kernel(AttnBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane & 31, lg = lane >> 5;
+    constexpr int KB = 32 * NWAVES;
+    const int nkb = (p.S + KB - 1) / KB;
+    const int nwg = nkb * p.H * p.B;
+    int wid = blockIdx.x;
+    {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = wid & 7;
+        wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (wid >> 3);
+    }
+    const int kblk = wid % nkb;
+    const long bh = wid / nkb;
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();      // the asm addresses the ring from LDS byte 0
+    const bf16_t* Qg = p.q + bh * p.S_pad * 64;
+    const bf16_t* Og = p.doh + bh * p.S_pad * 64;
+    const float* NLt = p.nld + bh * p.S_pad * 2;
+    const int key = kblk * KB + wave * 32 + lk;
+    const int key_ld = key < p.S ? key : p.S - 1;
+    const int nt = (p.S + TB - 1) / TB;
+    // LDS-DMA: this lane's 16-byte piece of rows 8 w + (l >> 3) (and + 32) of a 64 x 64 tile; 16 bytes of the tile's -L | -Delta floats
+    const int srow = wave * 8 + (lane >> 3);
+    const unsigned g0 = (unsigned)(srow * 128 + (((lane & 7) ^ swz2(srow)) << 4));
+    const unsigned g2 = (unsigned)(wave * 128 + (lane & 7) * 16);
+    const unsigned grow = (unsigned)(key_ld * 128 + lg * 16);
+    auto stage = [&](int t, int buf) {                   // (tiles 0..2; the loop stages the rest)
+        const int tt = t < nt ? t : nt - 1;
+        char* base = smem + buf * ST1T;
+        stage_tile2<NWAVES>(Qg + (long)tt * TB * 64, 64, base, wave, lane);
+        stage_tile2<NWAVES>(Og + (long)tt * TB * 64, 64, base + TILE, wave, lane);
+        if (lane < 8) __builtin_amdgcn_global_load_lds((gptr_t)(NLt + (long)tt * 2 * TB + wave * 32 + (lane & 7) * 4), (lptr_t)(base + 2 * TILE + wave * 128), 16, 0, 0);
+    };
+    const int prow = row_perm(lk);
+    unsigned la = (unsigned)(2 * TILE + 32 * lg), r0, a0, a1;
+    {
+        r0 = (unsigned)(prow * 128 + ((lg ^ swz2(prow)) << 4));                  // fragment kk = 0 (pass 1's offR[0])
+        const int i = lane & 15, g1 = (lane >> 4) & 1;
+        unsigned a[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {                                         // pieces (db = 0, jj) (pass 1's trb[0][jj])
+            const int ql = 8 * lg + 4 * jj + (i >> 2);
+            const int ch = 2 * g1 + ((i & 3) >> 1);
+            a[jj] = (unsigned)(ql * 128 + ((ch ^ swz2(ql)) << 4) + (i & 1) * 8);
+        }
+        a0 = a[0]; a1 = a[1];
+    }
+    stage(0, 0); stage(1, 1); stage(2, 2);
+    const int lt = nt - 1 < 3 ? nt - 1 : 3;
+    const unsigned long long b0 = (unsigned long long)(Qg + (long)lt * TB * 64), b1 = (unsigned long long)(Og + (long)lt * TB * 64);
+    const unsigned long long b2 = (unsigned long long)(NLt + (long)lt * 2 * TB);
+    const unsigned long long p0 = (unsigned long long)(p.k + bh * p.S_pad * 64), p1 = (unsigned long long)(p.v + bh * p.S_pad * 64);
+    asm volatile(ABWD64_DKV_ASM
+                 : [la] "+v"(la), [r0] "+v"(r0), [a0] "+v"(a0), [a1] "+v"(a1)       // (r1..r3, a2, a3 are r0 ^ 32 kk, a0 / a1 ^ 64: formed at their use)
+                 : [g0] "v"(g0), [g2] "v"(g2), [grow] "v"(grow), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [p0] "s"(p0), [p1] "s"(p1), [nt] "s"(nt),
+                   [wv] "s"(wave)
+                 : ABWD64_DKV_CLOBBERS);
+    f32x16 dk[2], dv[2];
+    ABWD64_READ_ACC_0(dv[0]) ABWD64_READ_ACC_16(dk[0]) ABWD64_READ_ACC_32(dv[1]) ABWD64_READ_ACC_48(dk[1])
+    __syncthreads();     // every wave is done with the ring (and its LDS-DMA writes: the asm ends with vmcnt(0)): reuse it for the output transposes
+    // the epilogue's lane arithmetic hangs off an OPAQUE copy of the lane id: hipcc would otherwise form those addresses in front of the loop and
+    // keep them alive across it, where sixteen VGPRs are all there is (one more register and the kernel drops to one wave per SIMD)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    char* ob = smem + wave * 4096;
+    const int row0 = kblk * KB + wave * 32;
+    store_rows(dk, LN2, ob, p.dk + bh * p.S_pad * 64, row0, p.S, lane_e);
+    store_rows(dv, 1.0f, ob, p.dv + bh * p.S_pad * 64, row0, p.S, lane_e);
+}
+
+__global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dq_pipe_kernel(AttnBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, lg = lane >> 5;
+    constexpr int QB = 32 * NWAVES;
+    const int nqb = (p.S + QB - 1) / QB;
+    const int nwg = nqb * p.H * p.B;
+    int wid = blockIdx.x;
+    {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = wid & 7;
+        wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (wid >> 3);
+    }
+    const int qblk = wid % nqb;
+    const long bh = wid / nqb;
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
+    const bf16_t* Kg = p.k + bh * p.S_pad * 64;
+    const bf16_t* Vg = p.v + bh * p.S_pad * 64;
+    const int q_row = qblk * QB + wave * 32 + lq;
+    const int q_ld = q_row < p.S ? q_row : p.S - 1;
+    const int nt = (p.S + TB - 1) / TB;
+    const int srow = wave * 8 + (lane >> 3);
+    const unsigned g0 = (unsigned)(srow * 128 + (((lane & 7) ^ swz2(srow)) << 4));
+    const unsigned grow = (unsigned)(q_ld * 128 + lg * 16);
+    const float nl = -p.lse[bh * p.S_pad + q_ld], nd = -p.delta[bh * p.S_pad + q_ld];
+    auto stage = [&](int t, int buf) {
+        const int tt = t < nt ? t : nt - 1;
+        char* base = smem + buf * ST2T;
+        stage_tile2<NWAVES>(Kg + (long)tt * TB * 64, 64, base, wave, lane);
+        stage_tile2<NWAVES>(Vg + (long)tt * TB * 64, 64, base + TILE, wave, lane);
+    };
+    const int prow = row_perm(lq);
+    unsigned r0, r1, r2, r3, a0, a1, a2, a3;
+    {
+        unsigned r[4], a[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) r[kk] = (unsigned)(prow * 128 + (((2 * kk + lg) ^ swz2(prow)) << 4));
+        const int i = lane & 15, g1 = (lane >> 4) & 1;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int kl = 8 * lg + 4 * jj + (i >> 2);
+                const int ch = 4 * db + 2 * g1 + ((i & 3) >> 1);
+                a[db * 2 + jj] = (unsigned)(kl * 128 + ((ch ^ swz2(kl)) << 4) + (i & 1) * 8);
+            }
+        r0 = r[0]; r1 = r[1]; r2 = r[2]; r3 = r[3]; a0 = a[0]; a1 = a[1]; a2 = a[2]; a3 = a[3];
+    }
+    stage(0, 0); stage(1, 1); stage(2, 2);
+    const int lt = nt - 1 < 3 ? nt - 1 : 3;
+    const unsigned long long b0 = (unsigned long long)(Kg + (long)lt * TB * 64), b1 = (unsigned long long)(Vg + (long)lt * TB * 64);
+    const unsigned long long p0 = (unsigned long long)(p.q + bh * p.S_pad * 64), p1 = (unsigned long long)(p.doh + bh * p.S_pad * 64);
+    asm volatile(ABWD64_DQ_ASM
+                 : [r0] "+v"(r0), [r1] "+v"(r1), [r2] "+v"(r2), [r3] "+v"(r3), [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3)
+                 : [g0] "v"(g0), [grow] "v"(grow), [nl] "v"(nl), [nd] "v"(nd), [b0] "s"(b0), [b1] "s"(b1), [p0] "s"(p0), [p1] "s"(p1), [nt] "s"(nt),
+                   [wv] "s"(wave)
+                 : ABWD64_DQ_CLOBBERS);
+    f32x16 dq[2];
+    ABWD64_READ_ACC_0(dq[0]) ABWD64_READ_ACC_16(dq[1])
+    __syncthreads();
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    char* ob = smem + wave * 4096;
+    store_rows(dq, LN2, ob, p.dq + bh * p.S_pad * 64, qblk * QB + wave * 32, p.S, lane_e);
+}
+
 }  // namespace
+
+static int g_attn_bwd_pipe = 1;      // mi355_tune_set(43, .): 1 = the software-pipelined passes (round 6), 0 = the round-3 kernels
+void set_attn_bwd_pipe(int v) { g_attn_bwd_pipe = v; }
 
 hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream) {
     if (sched_trace_on()) {
@@ -426,6 +576,17 @@ hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const int nb = (p.S + 32 * NWAVES - 1) / (32 * NWAVES);
+    if (g_attn_bwd_pipe) {
+        static bool attr_set2 = false;
+        if (!attr_set2) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkv_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NST1 * ST1T);
+            if (e != hipSuccess) return e;
+            attr_set2 = true;
+        }
+        hipLaunchKernelGGL(attn_bwd_dkv_pipe_kernel, dim3(nb * p.H * p.B), dim3(NWAVES * 64), NST1 * ST1T, stream, p);
+        hipLaunchKernelGGL(attn_bwd_dq_pipe_kernel, dim3(nb * p.H * p.B), dim3(NWAVES * 64), NST2 * ST2T, stream, p);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(attn_bwd_dkv_tr_kernel, dim3(nb * p.H * p.B), dim3(NWAVES * 64), NST1 * ST1T, stream, p);
     hipLaunchKernelGGL(attn_bwd_dq_tr_kernel, dim3(nb * p.H * p.B), dim3(NWAVES * 64), NST2 * ST2T, stream, p);
     return hipGetLastError();

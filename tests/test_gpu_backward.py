@@ -43,7 +43,7 @@ def gpu():
 
 
 # ------------------------------------------------------------------------------------------------- attention backward
-@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (2, 3, 333 + 256), (1, 2, 1000), (1, 4, 4429)])
+@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (1, 1, 100), (1, 2, 192), (2, 1, 256), (1, 2, 300), (1, 1, 449), (2, 3, 333 + 256), (1, 2, 1000), (1, 4, 4429)])
 def test_attention_backward_matches_autograd(gpu, B, H, S):
     import ctypes as C
     from mi355_flow import _lib
@@ -63,6 +63,23 @@ def test_attention_backward_matches_autograd(gpu, B, H, S):
     dq, dk, dv = torch.zeros_like(q), torch.zeros_like(q), torch.zeros_like(q)
     _lib.check(lib.mi355_op_attention_fwd_bwd(_stream(), _ptr(q), _ptr(k), _ptr(vT), _ptr(do), _ptr(o), _ptr(dq), _ptr(dk), _ptr(dv),
                                               B, H, S, S_pad), "op_attention_fwd_bwd")
+    # round 6: the shipped passes are the software-pipelined ones (csrc/gen_attn_bwd64.py; 1 .. 70 tiles here: prologue-only, every ring-slot
+    # wrap, ragged last tiles).  Same MFMAs in the same order per output element as the round-3 kernels (mi355_tune_set(43, 0)): the same bits,
+    # run after run.
+    try:
+        _lib.check(lib.mi355_tune_set(43, 0))
+        dq0, dk0, dv0 = torch.zeros_like(q), torch.zeros_like(q), torch.zeros_like(q)
+        _lib.check(lib.mi355_op_attention_fwd_bwd(_stream(), _ptr(q), _ptr(k), _ptr(vT), _ptr(do), _ptr(o), _ptr(dq0), _ptr(dk0), _ptr(dv0),
+                                                  B, H, S, S_pad), "op_attention_fwd_bwd")
+    finally:
+        lib.mi355_tune_set(43, 1)
+    for name, a, b in (("dq", dq, dq0), ("dk", dk, dk0), ("dv", dv, dv0)):
+        assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
+    for _ in range(2):
+        dq1, dk1, dv1 = torch.zeros_like(q), torch.zeros_like(q), torch.zeros_like(q)
+        _lib.check(lib.mi355_op_attention_fwd_bwd(_stream(), _ptr(q), _ptr(k), _ptr(vT), _ptr(do), _ptr(o), _ptr(dq1), _ptr(dk1), _ptr(dv1),
+                                                  B, H, S, S_pad), "op_attention_fwd_bwd")
+        assert torch.equal(dq1, dq) and torch.equal(dk1, dk) and torch.equal(dv1, dv)
     # reference: softmax(ln2 * q~ k^T) v in fp32 with autograd, gradients w.r.t. the STORED (pre-scaled) q
     qr = q[:, :, :S].float().requires_grad_(True)
     kr = k[:, :, :S].float().requires_grad_(True)
