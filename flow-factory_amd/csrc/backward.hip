@@ -319,7 +319,9 @@ __device__ __forceinline__ float half8_sum_dpp(float v) {
 // token-major o / do (image rows, then context rows, as the forward wrote o) -> per (b, h):
 //   doh [B][H][S_pad][64] = do rows, delta [B][H][S_pad] = sum_d do * o (fp32), nld = -lse | -delta per 64-query tile (the dK/dV pass
 //   moves a tile's 128 floats into LDS with one LDS-DMA instruction per wave and feeds them to its MFMA chains as C operands)
-// one workgroup = 64 tokens of one (b, h); padded rows (s >= S) are left untouched (zero-initialised buffers)
+// one workgroup = 64 tokens of one (b, h); padded rows (S <= s < S_pad) are written as ZEROS (round 6: the scratch these three buffers live in is
+// shared by attentions of different lengths -- SD3.5's joint and dual attention -- so "zero-initialised" did not stay true for the padding, and
+// the software-pipelined backward passes carry no tail masks: attention_bwd.hip states the contract)
 __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnBwdPrepParams p) {
     const int s0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
     const int D = p.H * 64, n_ctx = p.S - p.n_img;
@@ -328,7 +330,17 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_kernel(AttnBwdPrepParams p)
     // 4 waves x 16 tokens: lane = d
     for (int r = w; r < 64; r += 4) {
         const int s = s0 + r;
-        if (s >= p.S) continue;
+        if (s >= p.S) {
+            if (s < p.S_pad) {
+                p.doh[(bh * p.S_pad + s) * 64 + lane] = 0;
+                if (lane == 0) {
+                    p.delta[bh * p.S_pad + s] = 0.f;
+                    float* nl = p.nld + (bh * p.S_pad + (s & ~63)) * 2 + (s & 63);
+                    nl[0] = 0.f; nl[64] = 0.f;
+                }
+            }
+            continue;
+        }
         const long row = (s < p.n_img) ? ((long)b * p.n_img + s) : ((long)b * n_ctx + (s - p.n_img));
         const bf16_t* dop = (s < p.n_img) ? p.do_img : p.do_ctx;
         const bf16_t* op = (s < p.n_img) ? p.o_img : p.o_ctx;
@@ -355,7 +367,17 @@ __global__ __launch_bounds__(256) void attn_bwd_prep_fast_kernel(AttnBwdPrepPara
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int s = s0 + pass * 32 + (threadIdx.x >> 3);
-        if (s >= p.S) continue;               // (uniform inside a half DPP row)
+        if (s >= p.S) {                       // (uniform inside a half DPP row)
+            if (s < p.S_pad) {
+                *(uint4*)(p.doh + (bh * p.S_pad + s) * 64 + c * 8) = make_uint4(0u, 0u, 0u, 0u);
+                if (c == 0) {
+                    p.delta[bh * p.S_pad + s] = 0.f;
+                    float* nl = p.nld + (bh * p.S_pad + (s & ~63)) * 2 + (s & 63);
+                    nl[0] = 0.f; nl[64] = 0.f;
+                }
+            }
+            continue;
+        }
         const long row = (s < p.n_img) ? ((long)b * p.n_img + s) : ((long)b * n_ctx + (s - p.n_img));
         const bf16_t* dop = (s < p.n_img) ? p.do_img : p.do_ctx;
         const bf16_t* op = (s < p.n_img) ? p.o_img : p.o_ctx;
