@@ -419,6 +419,9 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dq_tr_kernel(AttnBwdP
 // query row adds exactly 0 to dK^T / dV^T, a zero key row exactly 0 to dQ^T).
 #include "attn_bwd64_asm.inc"
 
+// ABL (timing only, results garbage; mi355_tune_set(43, 2..5) under MI355_ALLOW_ABLATION=1): 1 no exp / scale / pack, 2 no LDS reads, 3 no barrier /
+// waits / tile loads, 4 MFMAs only
+template <int ABL>
 __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dkv_pipe_kernel(AttnBwdParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -472,11 +475,17 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dkv_pipe_kernel(AttnB
     const unsigned long long b0 = (unsigned long long)(Qg + (long)lt * TB * 64), b1 = (unsigned long long)(Og + (long)lt * TB * 64);
     const unsigned long long b2 = (unsigned long long)(NLt + (long)lt * 2 * TB);
     const unsigned long long p0 = (unsigned long long)(p.k + bh * p.S_pad * 64), p1 = (unsigned long long)(p.v + bh * p.S_pad * 64);
-    asm volatile(ABWD64_DKV_ASM
-                 : [la] "+v"(la), [r0] "+v"(r0), [a0] "+v"(a0), [a1] "+v"(a1)       // (r1..r3, a2, a3 are r0 ^ 32 kk, a0 / a1 ^ 64: formed at their use)
-                 : [g0] "v"(g0), [g2] "v"(g2), [grow] "v"(grow), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [p0] "s"(p0), [p1] "s"(p1), [nt] "s"(nt),
-                   [wv] "s"(wave)
-                 : ABWD64_DKV_CLOBBERS);
+#define DKV_OPERANDS                                                                                                                          \
+                 : [la] "+v"(la), [r0] "+v"(r0), [a0] "+v"(a0), [a1] "+v"(a1)       /* (r1..r3, a2, a3 are r0 ^ 32 kk, a0 / a1 ^ 64: formed at their use) */ \
+                 : [g0] "v"(g0), [g2] "v"(g2), [grow] "v"(grow), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [p0] "s"(p0), [p1] "s"(p1), [nt] "s"(nt), \
+                   [wv] "s"(wave)                                                                                                                \
+                 : ABWD64_DKV_CLOBBERS
+    if constexpr (ABL == 0) asm volatile(ABWD64_DKV_ASM DKV_OPERANDS);
+    else if constexpr (ABL == 1) asm volatile(ABWD64_DKV_ASM_NOVALU DKV_OPERANDS);
+    else if constexpr (ABL == 2) asm volatile(ABWD64_DKV_ASM_NOLDS DKV_OPERANDS);
+    else if constexpr (ABL == 3) asm volatile(ABWD64_DKV_ASM_NOSYNC DKV_OPERANDS);
+    else asm volatile(ABWD64_DKV_ASM_MFMAONLY DKV_OPERANDS);
+#undef DKV_OPERANDS
     f32x16 dk[2], dv[2];
     ABWD64_READ_ACC_0(dv[0]) ABWD64_READ_ACC_16(dk[0]) ABWD64_READ_ACC_32(dv[1]) ABWD64_READ_ACC_48(dk[1])
     __syncthreads();     // every wave is done with the ring (and its LDS-DMA writes: the asm ends with vmcnt(0)): reuse it for the output transposes
@@ -577,13 +586,12 @@ hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream) {
     }
     const int nb = (p.S + 32 * NWAVES - 1) / (32 * NWAVES);
     if (g_attn_bwd_pipe) {
-        static bool attr_set2 = false;
-        if (!attr_set2) {
-            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkv_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NST1 * ST1T);
-            if (e != hipSuccess) return e;
-            attr_set2 = true;
-        }
-        hipLaunchKernelGGL(attn_bwd_dkv_pipe_kernel, dim3(nb * p.H * p.B), dim3(NWAVES * 64), NST1 * ST1T, stream, p);
+        void (*dkv)(AttnBwdParams) = g_attn_bwd_pipe == 2 ? attn_bwd_dkv_pipe_kernel<1> : g_attn_bwd_pipe == 3 ? attn_bwd_dkv_pipe_kernel<2>
+                                     : g_attn_bwd_pipe == 4 ? attn_bwd_dkv_pipe_kernel<3> : g_attn_bwd_pipe == 5 ? attn_bwd_dkv_pipe_kernel<4>
+                                                                                                                  : attn_bwd_dkv_pipe_kernel<0>;
+        hipError_t e = hipFuncSetAttribute((const void*)dkv, hipFuncAttributeMaxDynamicSharedMemorySize, NST1 * ST1T);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(dkv, dim3(nb * p.H * p.B), dim3(NWAVES * 64), NST1 * ST1T, stream, p);
         hipLaunchKernelGGL(attn_bwd_dq_pipe_kernel, dim3(nb * p.H * p.B), dim3(NWAVES * 64), NST2 * ST2T, stream, p);
         return hipGetLastError();
     }

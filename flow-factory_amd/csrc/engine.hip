@@ -1086,8 +1086,11 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 37) { set_mid_max_tiles(value); return 0; }     // largest grid of its tiles
     if (key == 35 || key == 36) return 0;                      // (round-6 measurement knobs of that kernel -- staggered LDS-DMA slots, launch-class mask -- measured and removed: accepted as no-ops)
     if (key == 39) { g_wgrad_tn = value; return 0; }           // optimize() backward: 1 (default) = weight-gradient GEMMs read dY / X row-major through transposed LDS reads (2: 256 x 256 tiles where they fit), 0 = transposed copies
-    if (key == 43) { set_attn_bwd_pipe(value); return 0; }     // head_dim-64 attention backward: 1 (default) = software-pipelined passes (gen_attn_bwd64.py), 0 = the round-3 kernels
-    if (key == 40) { set_w6_mode(value); return 0; }           // 256x192-tile GEMM kernel (round 6): 0 off (default: measured slower inside the two-stream forward), 1 cost rule, 2 wherever it applies
+    if (key == 43) {      // (values 2..5: ablation builds of the dK/dV loop -- no VALU / no LDS reads / no barrier + loads / MFMAs only; WRONG results, measurement only)
+        const char* ok = getenv("MI355_ALLOW_ABLATION");
+        if (value > 1 && !(ok && ok[0] == '1')) return fail("mi355_tune_set(43, %d): ablation builds produce wrong gradients; set MI355_ALLOW_ABLATION=1 for a timing measurement", value);
+        set_attn_bwd_pipe(value); return 0;
+    }         if (key == 40) { set_w6_mode(value); return 0; }           // 256x192-tile GEMM kernel (round 6): 0 off (default: measured slower inside the two-stream forward), 1 cost rule, 2 wherever it applies
     if (key == 41) { set_w6_alpha_percent(value); return 0; }  // margin of that rule in percent (default 105)
     if (key == 42) { set_w6_min_tiles(value); return 0; }      // smallest grid of its tiles (default 200)
     if (key == 38) { g_fuse_colsum = value; return 0; }        // optimize() backward: 1 (default) = column-sum finish fused into the split-K reduction launch, 0 = two launches

@@ -48,6 +48,9 @@ class Pass:
     pass
 
 
+ABL = set()       # ablation builds (timing only, results garbage): "novalu", "nolds", "nosync"
+
+
 def dkv():
     P = Pass()
     P.name, P.ST, P.nloads = "DKV", 16896, 5
@@ -126,7 +129,7 @@ def dkv():
     P.mf_A, P.mf_B, P.rd_A, P.rd_T, P.valu = mf_A, mf_B, rd_A, rd_T, valu
     P.nB, P.nA = 8, 8
     P.rdA_gaps = [0, 0, 0, 1, 1, 1, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5]      # C operands first (needed by m8 / m9), fragment kk3 last (read by m15 of the previous body)
-    P.rdT_gaps = [9, 9, 9, 10, 10, 10, 11, 11, 11, 12, 12, 12, 13, 13, 14, 14]
+    P.rdT_gaps = [8, 8, 8, 8, 9, 9, 9, 9, 10, 10, 10, 10, 11, 11, 12, 12]      # (from the gap behind B's last MFMA; three gaps of flight before the next body)
     P.a_addrs = ["la", "r0"]
     P.t_addrs = ["a0", "a1"]
 
@@ -225,7 +228,7 @@ def ring_step(P, idx_reg, addrs):
 
 def sync(P):
     """tile t + 1 landed for every wave; slot of tile t - 1 is free: load tile min(t + 3, nt - 1) into it; advance the load state"""
-    out = [f"s_waitcnt vmcnt({P.nloads})", "s_barrier"] + P.stage()
+    out = ([] if "nosync" in ABL else [f"s_waitcnt vmcnt({P.nloads})", "s_barrier"] + P.stage())
     out += [f"s_cmp_lt_u32 s{S_LT}, s{S_NT}", f"s_cselect_b32 s{S_INC}, 1, 0", f"s_add_u32 s{S_LT}, s{S_LT}, s{S_INC}"]     # S_NT holds nt - 1 here
     for (b, sh) in P.adv:
         out += [f"s_lshl_b32 s{S_T}, s{S_INC}, {sh}", f"s_add_u32 s{b}, s{b}, s{S_T}", f"s_addc_u32 s{b + 1}, s{b + 1}, 0"]
@@ -248,6 +251,10 @@ def body(P, cur, nxt, has_B, has_A, qb_A, qb_T, pre=()):
             put(gp, ins)
     for gp, ins in zip(P.rdT_gaps, P.rd_T(qb_T)):
         put(gp, ins)
+    if "novalu" in ABL:
+        fill = {g: [i for i in v if not i.startswith(("v_exp", "v_pk_mul", "v_cvt_pk"))] for g, v in fill.items()}
+    if "nolds" in ABL:
+        fill = {g: [i for i in v if "ds_read" not in i] for g, v in fill.items()}
     out = list(pre)
     out.append("s_waitcnt lgkmcnt(0)")                    # the transposed fragments of B(h-1) (read during the previous body)
     ngap = P.nB + P.nA
@@ -355,6 +362,11 @@ def main():
         lines = main_loop(P)
         check(P, lines)
         emit(f"ABWD64_{P.name}_ASM", lines)
+    # ablation builds of the dK/dV loop (scripts/attn_bwd_ablate.py; results are garbage): what bounds it?
+    for tag, abl in (("NOVALU", {"novalu"}), ("NOLDS", {"nolds"}), ("NOSYNC", {"nosync"}), ("MFMAONLY", {"novalu", "nolds", "nosync"})):
+        ABL.clear(); ABL.update(abl)
+        emit(f"ABWD64_DKV_ASM_{tag}", main_loop(dkv()))
+    ABL.clear()
     sregs = [f'"s{i}"' for i in range(70, 94)] + ['"scc"', '"memory"']
     print("#define ABWD64_DKV_CLOBBERS " + ", ".join([f'"v{i}"' for i in range(16, 160)] + [f'"a{i}"' for i in range(0, 96)] + sregs))
     print("#define ABWD64_DQ_CLOBBERS " + ", ".join([f'"v{i}"' for i in range(16, 176)] + [f'"a{i}"' for i in range(0, 64)] + sregs))
