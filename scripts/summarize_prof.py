@@ -13,12 +13,13 @@ stats_sub = sys.argv[2] if len(sys.argv) > 2 else None
 
 
 def short(name):
-    for key, tag in (("gemm_tn_kernel", "gemm_tn<128x128,row-major wgrad>"), ("splitk_reduce_colsum_kernel", "splitk_reduce_colsum_kernel"),
+    for key, tag in (("gemm_tn256_kernel", "gemm_tn<256x256,row-major wgrad>"), ("gemm_tn_kernel", "gemm_tn<128x128,row-major wgrad>"),
+                     ("attn_bwd_dkv_pipe_kernel", "attn_bwd_dkv_pipe_kernel"), ("attn_bwd_dq_pipe_kernel", "attn_bwd_dq_pipe_kernel"), ("splitk_reduce_colsum_kernel", "splitk_reduce_colsum_kernel"),
                      ("splitk_reduce_kernel", "splitk_reduce_kernel"), ("colsum_partial_kernel", "colsum_partial_kernel"),
                      ("colsum_finish_kernel", "colsum_finish_kernel"), ("transpose_kernel", "transpose_kernel"), ("ln_mod_bwd_kernel", "ln_mod_bwd_kernel"),
                      ("rms_bwd_gather", "rms_bwd_gather_kernel"), ("attn_bwd_prep", "attn_bwd_prep_kernel"), ("gate_mul_kernel", "gate_mul_kernel"),
                      ("attn_bwd_dkv_tr_kernel", "attn_bwd_dkv_tr_kernel"), ("attn_bwd_dq_tr_kernel", "attn_bwd_dq_tr_kernel"), ("attn_kernel", "attn_kernel"),
-                     ("gemm_mid_kernel", None), ("gemm_w4_kernel", None), ("gemm_pp_kernel", None), ("gemm_kernel", None), ("ln_mod_kernel", "ln_mod_kernel"),
+                     ("gemm_mid_kernel", None), ("gemm_w6_kernel", None), ("gemm_w4_kernel", None), ("gemm_pp_kernel", None), ("gemm_kernel", None), ("ln_mod_kernel", "ln_mod_kernel"),
                      ("sde_step_kernel", "sde_step_kernel"), ("patchify", "patchify_kernel"), ("time_proj", "time_proj_kernel"),
                      ("convert_kernel", "convert_kernel"), ("pos_crop", "pos_crop_kernel"), ("gn_partial", "gn_partial_kernel"),
                      ("gn_finalize", "gn_finalize_kernel"), ("gn_apply", "gn_apply_kernel"), ("softmax_rows", "softmax_rows_kernel"),
@@ -33,6 +34,9 @@ def short(name):
             mm = re.search(r"gemm_mid_kernel<(\d+), (\d+), (\d+)>", name)
             if mm:
                 return f"gemm_mid<{int(mm.group(1)) * 32}x{int(mm.group(2)) * 32},{epi[int(mm.group(3))]}>"
+            m6 = re.search(r"gemm_w6_kernel<(\d+)>", name)
+            if m6:
+                return f"gemm_w6<256x192,{epi[int(m6.group(1))]}>"
             m4 = re.search(r"gemm_w4_kernel<(\d+)(?:, \d+)?>", name)
             if m4:
                 return f"gemm_w4<256x256,{epi[int(m4.group(1))]}>"
