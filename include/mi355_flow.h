@@ -543,6 +543,16 @@ int mi355_profile_enable(int on);
  *  29     MEASUREMENT ONLY (scripts/gpu_r5_call2.sh): bit mask of launches the SD3.5 forward SKIPS -- 1 the text-stream chain, 2 every
  *         LayerNorm-modulate, 4 the V^T projections -- to put a measured ceiling on what fusing them away could buy.  Results
  *         are WRONG by construction; 0 (default) = nothing skipped.
+ *  32-37  mid-size GEMM kernel (128x192 / 192x128 tiles, round 6): 32 = 0 off, 1 by the cost rule (default), 2 wherever it applies; 33 margin of the
+ *         rule in percent (100); 34 / 37 smallest / largest grid of its tiles (160 / 256: one-round grids); 35, 36 accepted and ignored (measurement
+ *         knobs of round 6, removed).  Results are bit-identical for every value.
+ *  38     optimize() backward: 1 (default) = the bias gradient's column-sum finish rides in the weight gradient's split-K reduction launch.
+ *  39     optimize() backward: weight-gradient GEMMs of whole-tile shapes on ROW-MAJOR operands (csrc/gemm_tn.hip): 1 (default) 128x128 tiles,
+ *         2 = 256x256 tiles where they give a one-round grid (measured equal in the step), 0 = transposed copies.  Same products; 0 / 1 bit-identical.
+ *  40-42  256x192-tile GEMM kernel (gemm_w6_kernel): 40 = 0 off (default: 16-20 % faster back to back, 2.4 % slower inside the two-stream forward),
+ *         1 by its cost rule, 2 wherever it applies; 41 margin in percent (105); 42 smallest grid (200).  Bit-identical for every value.
+ *  43     head_dim-64 attention backward: 1 (default) = the software-pipelined passes (csrc/gen_attn_bwd64.py), 0 = the round-3 kernels
+ *         (bit-identical); 2..5 = ablation builds of the dK/dV loop (WRONG results; refused without MI355_ALLOW_ABLATION=1).
  * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);
