@@ -180,7 +180,10 @@ int mi355_unipc_convert(void* stream, const void* v_text, const void* v_uncond, 
                         float sigma, float* x0_out, int64_t n);
 int mi355_op_lincomb(void* stream, int n_terms, const void* const* tensors, const int* dtypes, const float* coefs, void* out, int out_dtype,
                      int64_t n);
-/* unit-test helper: attention forward (q pre-scaled by log2(e)/8) + flash backward; d_o / o token-major [B*S][H*64]; synchronises */
+/* unit-test helper: attention forward (q pre-scaled by log2(e)/8) + flash backward; d_o / o token-major [B*S][H*64]; synchronises.
+ * CONTRACT of the backward passes (round 6: the software-pipelined loops carry no tail masks): the padding -- rows [S, S_pad) of q and k,
+ * columns [S, S_pad) of vT -- must be ZERO (finite was required before: a masked probability times a NaN is a NaN).  The engines' stashes are
+ * zero-initialised and only written below S; a caller of this helper zero-fills its tensors. */
 int mi355_op_attention_fwd_bwd(void* stream, const void* q, const void* k, const void* vT, const void* d_o, void* o, void* dq, void* dk,
                                void* dv, int B, int H, int S, int S_pad);
 
