@@ -119,6 +119,9 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+DDP_LEG_DEADLINE_S = 420      # wall-clock budget of the optional `optimize_step_ddp` leg (normally ~30 s) before the headline line goes out without it
+
+
 def ddp_optimize_leg(ddp, microstep, params, world, rank, device, iters=3, backend="nccl (RCCL)"):
     """The policy-update collective of the north star, measured (world > 1 only): one `optimize()` micro-step -- grad-mode replay forward +
     backward -- under `DistributedDataParallel` (reference: the trainable component is DDP-wrapped by `accelerator.prepare`,
@@ -711,13 +714,41 @@ def main():
     if (world > 1 or args.ddp_step_world1) and not flux_mode and not args.no_ddp_step:
         # north star: "gradient all-reduce on RCCL over xGMI for the policy update" -- every rank takes part; a failure on any rank is
         # recorded (and keeps the headline line), never raised
+        # This leg is the only part of the file where a rank can wait for another rank that is not coming (one rank failing between two
+        # collectives).  Two guards keep the headline line safe: (1) everything local -- building the module -- happens first and the ranks
+        # agree (MIN of a success flag on the group they already used) before the first DDP collective; (2) a deadline: if the leg has not
+        # finished after DDP_LEG_DEADLINE_S seconds, rank 0 prints the line without it and every rank leaves.
+        import threading
+        print_lock, state = threading.Lock(), {"printed": False}
+
+        def abandon():
+            with print_lock:
+                if state["printed"]:
+                    return
+                state["printed"] = True
+                if rank == 0:
+                    out["optimize_step_ddp"] = {"error": f"the leg did not finish within {DDP_LEG_DEADLINE_S} s on some rank: abandoned"}
+                    print(json.dumps(out), flush=True)
+            os._exit(0)
+        timer = threading.Timer(DDP_LEG_DEADLINE_S, abandon)
+        timer.daemon = True
+        timer.start()
         leg = None
         try:
             from torch.nn.parallel import DistributedDataParallel as DDP
             from mi355_flow.weights import module_from_state_dict
             del samples
             torch.cuda.empty_cache()
-            mod = module_from_state_dict(synthetic_state_dict(cfg, device=dev, seed=1234))
+            ok_local, err_local = 1, None
+            try:
+                mod = module_from_state_dict(synthetic_state_dict(cfg, device=dev, seed=1234))
+            except Exception as e:  # noqa: BLE001
+                ok_local, err_local = 0, repr(e)
+            flag = torch.tensor([ok_local], device=dev, dtype=torch.int32)
+            if dist.is_initialized():
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                raise RuntimeError(f"module construction failed on some rank (this rank: {err_local}); leg skipped on every rank")
             targets = ("attn.add_q_proj", "attn.add_k_proj", "attn.add_v_proj", "attn.to_add_out",      # SD3_5Adapter.default_target_modules
                        "attn.to_q", "attn.to_k", "attn.to_v", "attn.to_out.0")                           # (reference sd3_5.py:75-80)
             for n_, q_ in mod.named_parameters():
@@ -742,6 +773,11 @@ def main():
             ad2.engine.close()
         except Exception as e:  # noqa: BLE001
             leg = {"error": repr(e)}
+        with print_lock:
+            if state["printed"]:          # (the deadline fired while this thread was finishing: the line is out, leave)
+                os._exit(0)
+            state["printed"] = True       # from here on the deadline thread does nothing; the line is printed below
+        timer.cancel()
         if rank == 0:
             out["optimize_step_ddp"] = leg
     if rank == 0:
@@ -749,8 +785,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1 or (args.ddp_step_world1 and dist.is_initialized()):
+        import threading
+        bye = threading.Timer(60, lambda: os._exit(0))      # the line is out: never sit in the farewell barrier for a rank that is gone
+        bye.daemon = True
+        bye.start()
         dist.barrier()
         dist.destroy_process_group()
+        bye.cancel()
 
 
 if __name__ == "__main__":

@@ -589,8 +589,13 @@ hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream) {
         void (*dkv)(AttnBwdParams) = g_attn_bwd_pipe == 2 ? attn_bwd_dkv_pipe_kernel<1> : g_attn_bwd_pipe == 3 ? attn_bwd_dkv_pipe_kernel<2>
                                      : g_attn_bwd_pipe == 4 ? attn_bwd_dkv_pipe_kernel<3> : g_attn_bwd_pipe == 5 ? attn_bwd_dkv_pipe_kernel<4>
                                                                                                                   : attn_bwd_dkv_pipe_kernel<0>;
-        hipError_t e = hipFuncSetAttribute((const void*)dkv, hipFuncAttributeMaxDynamicSharedMemorySize, NST1 * ST1T);
-        if (e != hipSuccess) return e;
+        static bool attr_set2[6] = {false, false, false, false, false, false};      // per instantiation (66 KiB of dynamic LDS)
+        const int vi = g_attn_bwd_pipe >= 1 && g_attn_bwd_pipe <= 5 ? g_attn_bwd_pipe : 1;
+        if (!attr_set2[vi]) {
+            hipError_t e = hipFuncSetAttribute((const void*)dkv, hipFuncAttributeMaxDynamicSharedMemorySize, NST1 * ST1T);
+            if (e != hipSuccess) return e;
+            attr_set2[vi] = true;
+        }
         hipLaunchKernelGGL(dkv, dim3(nb * p.H * p.B), dim3(NWAVES * 64), NST1 * ST1T, stream, p);
         hipLaunchKernelGGL(attn_bwd_dq_pipe_kernel, dim3(nb * p.H * p.B), dim3(NWAVES * 64), NST2 * ST2T, stream, p);
         return hipGetLastError();
