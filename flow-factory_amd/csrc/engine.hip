@@ -1085,7 +1085,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 34) { set_mid_min_tiles(value); return 0; }     // smallest grid of its tiles (default 160)
     if (key == 37) { set_mid_max_tiles(value); return 0; }     // largest grid of its tiles
     if (key == 35 || key == 36) return 0;                      // (round-6 measurement knobs of that kernel -- staggered LDS-DMA slots, launch-class mask -- measured and removed: accepted as no-ops)
-    if (key == 39) { g_wgrad_tn = value; return 0; }           // optimize() backward: 1 (default) = weight-gradient GEMMs read dY / X row-major through transposed LDS reads (2: 256 x 256 tiles where they fit), 0 = transposed copies
+    if (key == 39) { g_wgrad_tn = value; set_wgrad_tn_mode(value); return 0; }           // optimize() backward: 1 (default) = weight-gradient GEMMs read dY / X row-major through transposed LDS reads (2: 256 x 256 tiles where they fit), 0 = transposed copies
     if (key == 43) {      // (values 2..5: ablation builds of the dK/dV loop -- no VALU / no LDS reads / no barrier + loads / MFMAs only; WRONG results, measurement only)
         const char* ok = getenv("MI355_ALLOW_ABLATION");
         if (value > 1 && !(ok && ok[0] == '1')) return fail("mi355_tune_set(43, %d): ablation builds produce wrong gradients; set MI355_ALLOW_ABLATION=1 for a timing measurement", value);
@@ -1132,16 +1132,17 @@ extern "C" int mi355_op_wgrad(void* stream, const void* dY, int64_t ld_dy, const
         GemmTnParams tp{(const bf16_t*)dY, (long)ld_dy, (const bf16_t*)X, (long)ld_x, M, N, K, out, (long)K, k_split, (long)N * K, variant == 1 ? colsum : nullptr,
                         variant == 2 ? 1 : 0};
         if (variant == 2 && (N % 256 || K % 256)) return fail("mi355_op_wgrad: variant 2 needs N %% 256 == 0 and K %% 256 == 0");
-        if (!gemm_tn_ok(tp)) return fail("mi355_op_wgrad: the row-major-operand kernel needs M %% 64 == 0, N %% 128 == 0, K %% 128 == 0, 16-byte aligned rows");
+        if (!gemm_tn_ok(tp)) return fail("mi355_op_wgrad: the row-major-operand kernel needs N %% 128 == 0, K %% 128 == 0, 16-byte aligned rows");
         HIPCHK(launch_gemm_tn(tp, st));
         return 0;
     }
-    if (!scratch) return fail("mi355_op_wgrad: variant 0 needs (N + K) * M bf16 of scratch");
+    if (!scratch) return fail("mi355_op_wgrad: variant 0 needs (N + K) * M_pad bf16 of scratch (M_pad = M rounded up to 64)");
+    const int Mp = (M + 63) / 64 * 64;                  // the copies are zero-padded to whole 64-row tiles (what the engines' path does)
     bf16_t* aT = (bf16_t*)scratch;
-    bf16_t* xT = aT + (size_t)N * M;
-    HIPCHK(launch_transpose((const bf16_t*)dY, (long)ld_dy, 0, aT, M, 0, M, N, M, 1, st));
-    HIPCHK(launch_transpose((const bf16_t*)X, (long)ld_x, 0, xT, M, 0, M, K, M, 1, st));
-    GemmParams g = gp(aT, M, xT, M, N, K, M, EPI_F32, nullptr, nullptr, K);
+    bf16_t* xT = aT + (size_t)N * Mp;
+    HIPCHK(launch_transpose((const bf16_t*)dY, (long)ld_dy, 0, aT, Mp, 0, M, N, Mp, 1, st));
+    HIPCHK(launch_transpose((const bf16_t*)X, (long)ld_x, 0, xT, Mp, 0, M, K, Mp, 1, st));
+    GemmParams g = gp(aT, Mp, xT, Mp, N, K, Mp, EPI_F32, nullptr, nullptr, K);
     g.q_scale = 1.0f; g.out_f32 = out; g.k_split = k_split; g.split_stride = (long)N * K;
     HIPCHK(launch_gemm(g, st));
     return 0;

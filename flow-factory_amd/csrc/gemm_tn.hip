@@ -20,7 +20,7 @@
 //   * split over m (k_split) into fp32 partial buffers like gemm_kernel<.., EPI_F32>; the caller reduces in fixed order (backward.hip);
 //   * optional bias gradient (colsum != nullptr): the column sums of dY per split, taken from the fragments the k-tile-0 blocks hold
 //     (v_dot2c_f32_bf16 against a constant (1, 1): 16 VALU per k-step in 1 / (K / 128) of the blocks) -- no extra pass over dY.
-// Requirements (launcher): M % 64 == 0, N % 128 == 0, K % 128 == 0, lda / ldb multiples of 8, operands below 4 GiB.
+// Requirements (launcher): N % 128 == 0, K % 128 == 0, lda / ldb multiples of 8, operands below 4 GiB; any M (a ragged last m-tile reads zeros).
 #include "kernels.h"
 
 namespace mi355 {
@@ -150,15 +150,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
         soffA[i] = ((unsigned)row * (unsigned)p.lda + (unsigned)(n0 + col)) * 2u;
         soffB[i] = ((unsigned)row * (unsigned)p.ldb + (unsigned)(k0 + col)) * 2u;
     }
+    // ragged M (round 6b: the other engines' token counts -- 20 280, 6889 + text -- are not multiples of 64): the rows [M, M_pad) of the LAST m-tile
+    // are read from a 16-byte block of zeros instead (what the transposed-copy path's zero padding contributes: nothing)
     auto stage = [&](int mt, int buf) {
         char* base = smem + buf * STAGE;
         const char* ga = (const char*)p.A + (long)mt * TM * p.lda * 2;      // wave-uniform
         const char* gb = (const char*)p.B + (long)mt * TM * p.ldb * 2;
+        const bool ragged = (mt + 1) * TM > p.M;                            // wave-uniform
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int g = wave + 4 * i;
-            __builtin_amdgcn_global_load_lds((gptr_t)(ga + soffA[i]), (lptr_t)(base + g * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(gb + soffB[i]), (lptr_t)(base + OP_BYTES + g * 1024), 16, 0, 0);
+            const char* sa = ga + soffA[i];
+            const char* sb = gb + soffB[i];
+            if (ragged && mt * TM + g * 4 + (lane >> 4) >= p.M) { sa = (const char*)p.zeros; sb = (const char*)p.zeros; }
+            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(base + g * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(base + OP_BYTES + g * 1024), 16, 0, 0);
         }
     };
 
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmTnParams p) {
     const unsigned ones = 0x3f803f80u;                              // bf16 (1, 1)
     const bool do_cs = p.colsum != nullptr && tk == 0 && wn == 0;     // (wave-uniform) the k-tile-0 blocks' left waves: every dY column once per split
 
-    const int nt_all = p.M / TM;
+    const int nt_all = (p.M_pad > 0 ? p.M_pad : p.M + TM - 1) / TM;      // (M_pad: the transposed-copy path's padded length -- same split boundaries)
     const int mt0 = (int)((long)nt_all * split / nsplit);
     const int nt = (int)((long)nt_all * (split + 1) / nsplit) - mt0;
     if (nt > 0) stage(mt0, 0);
@@ -280,11 +286,15 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTnParams p) {
         char* base = smem + buf * STAGE_B;
         const char* ga = (const char*)p.A + (long)mt * TM * p.lda * 2;
         const char* gb = (const char*)p.B + (long)mt * TM * p.ldb * 2;
+        const bool ragged = (mt + 1) * TM > p.M;                            // (see gemm_tn_kernel)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int g = wave + 8 * i;
-            __builtin_amdgcn_global_load_lds((gptr_t)(ga + soffA[i]), (lptr_t)(base + g * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(gb + soffB[i]), (lptr_t)(base + OP_BYTES_B + g * 1024), 16, 0, 0);
+            const char* sa = ga + soffA[i];
+            const char* sb = gb + soffB[i];
+            if (ragged && mt * TM + g * 2 + (lane >> 5) >= p.M) { sa = (const char*)p.zeros; sb = (const char*)p.zeros; }
+            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)(base + g * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(base + OP_BYTES_B + g * 1024), 16, 0, 0);
         }
     };
 
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTnParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nt_all = p.M / TM;
+    const int nt_all = (p.M_pad > 0 ? p.M_pad : p.M + TM - 1) / TM;      // (M_pad: the transposed-copy path's padded length -- same split boundaries)
     const int mt0 = (int)((long)nt_all * split / nsplit);
     const int nt = (int)((long)nt_all * (split + 1) / nsplit) - mt0;
     if (nt > 0) stage(mt0, 0);
@@ -336,14 +346,33 @@ __global__ __launch_bounds__(512) void gemm_tn256_kernel(GemmTnParams p) {
 
 }  // namespace
 
+// the block of zeros a ragged last m-tile reads (one per process: allocated on first use, never freed)
+static const void* tn_zero_block() {
+    static void* z = nullptr;
+    if (!z) {
+        if (hipMalloc(&z, 256) != hipSuccess) { z = nullptr; return nullptr; }
+        if (hipMemset(z, 0, 256) != hipSuccess) { (void)hipFree(z); z = nullptr; return nullptr; }
+    }
+    return z;
+}
+
 bool gemm_tn_ok(const GemmTnParams& p) {
-    return p.M > 0 && p.M % TM == 0 && p.N % 128 == 0 && p.K % 128 == 0 && (p.lda & 7) == 0 && (p.ldb & 7) == 0 && (p.ldo & 3) == 0 &&
+    return p.M > 0 && (p.M_pad == 0 || (p.M_pad >= p.M && p.M_pad % TM == 0)) && p.N % 128 == 0 && p.K % 128 == 0 && (p.lda & 7) == 0 && (p.ldb & 7) == 0 && (p.ldo & 3) == 0 &&
            ((size_t)p.M * (size_t)p.lda) * 2 < (1ull << 32) && ((size_t)p.M * (size_t)p.ldb) * 2 < (1ull << 32) &&
            (((size_t)p.A | (size_t)p.B | (size_t)p.out) & 15) == 0;
 }
 
-hipError_t launch_gemm_tn(const GemmTnParams& p, hipStream_t stream) {
+static int g_wgrad_tn_mode = 1;
+void set_wgrad_tn_mode(int v) { g_wgrad_tn_mode = v; }
+int get_wgrad_tn_mode() { return g_wgrad_tn_mode; }
+
+hipError_t launch_gemm_tn(const GemmTnParams& p_in, hipStream_t stream) {
+    GemmTnParams p = p_in;
     if (!gemm_tn_ok(p) || !p.A || !p.B || !p.out) return hipErrorInvalidValue;
+    if (p.M % TM != 0 || (p.M_pad > 0 && p.M_pad != p.M)) {      // ragged: the kernels need the zero block
+        if (!p.zeros) p.zeros = tn_zero_block();
+        if (!p.zeros) return hipErrorOutOfMemory;
+    }
     if (sched_trace_on())
         sched_trace_launch("gemm_tn", stream, {treg(p.A, ((size_t)(p.M - 1) * p.lda + p.N) * 2), treg(p.B, ((size_t)(p.M - 1) * p.ldb + p.K) * 2)},
                            {treg(p.out, (((size_t)(p.N - 1) * p.ldo + p.K) + (size_t)(p.k_split > 1 ? p.k_split - 1 : 0) * p.split_stride) * 4),

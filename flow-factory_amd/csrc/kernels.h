@@ -84,8 +84,12 @@ struct GemmTnParams {
     int k_split; long split_stride;   // split over m, like GemmParams
     float* colsum;                    // optional [k_split][N] fp32: per-split column sums of A (the bias gradient's partials); nullptr = not taken
     int tile256;                      // 1 = the 256 x 256-tile form (8 waves, one workgroup per CU) where N and K are multiples of 256
+    int M_pad = 0;                    // 0 = M rounded up to 64; else the padded length (a multiple of 64, >= M) the split boundaries are taken on
+    const void* zeros = nullptr;      // >= 16 bytes of zeros, 16-byte aligned, for the rows [M, M_pad) (nullptr: the launcher's own block)
 };
 bool gemm_tn_ok(const GemmTnParams& p);
+void set_wgrad_tn_mode(int v);      // mi355_tune_set(39, .) for the head_dim-128 engines' shared weight-gradient path (train_common.h): 0 = transposed copies
+int get_wgrad_tn_mode();
 hipError_t launch_gemm_tn(const GemmTnParams& p, hipStream_t stream);
 
 // ---- launch-schedule trace (sched_trace.hip; off unless mi355_sched_trace(1)): every launch_* / event call reports (stream, regions)

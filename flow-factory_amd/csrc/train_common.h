@@ -106,6 +106,45 @@ static inline int t_wgrad_group(TrainScratch& t, hipStream_t st, const bf16_t* d
     float* csum = ctx_chain && t.csum_c ? t.csum_c : t.csum;          // (column-sum partials: one scratch per stream that takes them)
     int K = 0;
     for (int i = 0; i < nx; ++i) K += xs[i].K;
+    // Round 6: operands as they lie in HBM (csrc/gemm_tn.hip: dY [M][ldY], X [M][ldX] row-major, MFMA fragments through transposed LDS reads;
+    // a ragged last m-tile reads zeros) -- neither dY^T nor X^T is made, and the 256 x 256-tile form runs the large weights (N x K >= 160 tiles)
+    // at the ping-pong kernel's bytes per FLOP instead of the 2-stage kernel's.  Same products, same split boundaries over M_pad, same fixed-order
+    // reduction.  These GEMMs read dY itself, which the backward overwrites next: they run on `st`, not on the side stream that the copies made
+    // safe (the two big-GEMM streams shared the chip anyway).  mi355_tune_set(39, 0) = the transposed-copy path below.
+    if (get_wgrad_tn_mode() != 0 && nx == 1 && M_pad % 64 == 0) {
+        bool ok = true;
+        for (int i = 0; i < nseg && ok; ++i)
+            if (seg[i].gw) {
+                GemmTnParams tp{dY + seg[i].col0, ldY, xs[0].p, xs[0].ld, M, seg[i].N, K, t.part, (long)K, 1, (long)seg[i].N * K, nullptr, 0};
+                tp.M_pad = M_pad;
+                ok = gemm_tn_ok(tp) && (size_t)seg[i].N * K <= t.part_floats;
+            }
+        if (ok) {
+            CHK(t_wgrad_join(t, st));                  // earlier side-stream GEMMs may still be reading / writing t.part
+            for (int i = 0; i < nseg; ++i) {
+                const int N = seg[i].N;
+                if (seg[i].gb) HIPCHK(launch_colsum(dY + seg[i].col0, ldY, M, N, csum, seg[i].gb, 0, st));
+                if (!seg[i].gw) continue;
+                int split = wgrad_split(N, K, M_pad, t.part_floats, false);
+                int tile256 = 0;
+                if (N % 256 == 0 && K % 256 == 0) {
+                    const long t256 = (long)(N / 256) * (K / 256);
+                    int s256 = (int)(256 / t256 > 0 ? 256 / t256 : 1);
+                    const int cap = (M_pad / 64) / 2 > 0 ? (M_pad / 64) / 2 : 1;
+                    if (s256 > cap) s256 = cap;
+                    while (s256 > 1 && (size_t)s256 * N * K > t.part_floats) --s256;
+                    if (t256 * s256 >= 160) { tile256 = 1; split = s256; }
+                }
+                if (split < 1) split = 1;
+                const bool direct = split == 1 && grad_buf_dtype(seg[i].gw) == DT_F32;
+                GemmTnParams tp{dY + seg[i].col0, ldY, xs[0].p, xs[0].ld, M, N, K, direct ? seg[i].gw : t.part, (long)K, split, (long)N * K, nullptr, tile256};
+                tp.M_pad = M_pad;
+                HIPCHK(launch_gemm_tn(tp, st));
+                if (!direct) HIPCHK(launch_splitk_reduce(t.part, (long)N * K, split, seg[i].gw, (long)N * K, 0, st));
+            }
+            return 0;
+        }
+    }
     if (K > t.xT_rows) return errorf("wgrad: K = %d exceeds the transposed-input scratch (%ld rows)", K, t.xT_rows);
     int i = 0;
     while (i < nseg) {

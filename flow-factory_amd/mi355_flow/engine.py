@@ -497,8 +497,8 @@ def op_linear_gate_res(x: torch.Tensor, a: torch.Tensor, w: torch.Tensor, bias: 
 
 def op_wgrad(dy: torch.Tensor, x: torch.Tensor, k_split: int = 1, variant: int = 1, want_colsum: bool = False):
     """Weight-gradient partial sums [k_split, N, K] (fp32) of dW = dy^T @ x over `k_split` slices of the M rows; dy [M, N] and x [M, K] bf16
-    row-major (rows may be strided views: the row stride is passed).  variant 1 = the row-major-operand kernel (csrc/gemm_tn.hip), 0 = the
-    transposed-copy path; both return the same bits.  `want_colsum` (variant 1): also the per-slice column sums of dy [k_split, N] the kernel
+    row-major (rows may be strided views: the row stride is passed; any M: a ragged last 64-row tile reads zeros).  variant 1 = the
+    row-major-operand kernel (csrc/gemm_tn.hip), 2 = its 256 x 256-tile form, 0 = the transposed-copy path; all return the same bits.  `want_colsum` (variant 1): also the per-slice column sums of dy [k_split, N] the kernel
     takes from the fragments it holds (the bias gradient's partials)."""
     lib = _lib.load()
     assert dy.is_cuda and x.is_cuda and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.stride(1) == 1 and x.stride(1) == 1
@@ -506,7 +506,7 @@ def op_wgrad(dy: torch.Tensor, x: torch.Tensor, k_split: int = 1, variant: int =
     M, N = dy.shape
     K = x.shape[1]
     out = torch.empty((k_split, N, K), device=dy.device, dtype=torch.float32)
-    scratch = torch.empty(((N + K) * M,), device=dy.device, dtype=torch.bfloat16) if variant == 0 else None
+    scratch = torch.empty(((N + K) * ((M + 63) // 64 * 64),), device=dy.device, dtype=torch.bfloat16) if variant == 0 else None
     C = __import__("ctypes")
     colsum = torch.zeros((k_split, N), device=dy.device, dtype=torch.float32) if want_colsum else None
     _lib.check(lib.mi355_op_wgrad(_stream(), C.c_void_p(dy.data_ptr()), dy.stride(0), C.c_void_p(x.data_ptr()), x.stride(0), _ptr(out), M, N, K, k_split, variant,

@@ -198,8 +198,10 @@ int mi355_op_linear_gate_res(void* stream, const void* A, const void* W, const f
                              int rows_per_sample);
 /* Weight-gradient product on ROW-MAJOR operands (round 6, csrc/gemm_tn.hip): out[s][n][k] (fp32, [k_split][N][K]) = sum over the s-th slice of
  * the M rows of dY[m][n] * X[m][k]; dY [M][ld_dy] and X [M][ld_x] bf16 as the backward leaves them in HBM -- no transposed copies (reference: the
- * weight gradients `accelerator.backward(loss)` produces for the trainable linear layers, trainers/grpo.py:326-330).  M % 64, N % 128, K % 128
- * must be 0.  variant 1 = 128 x 128 tiles, 2 = 256 x 256 tiles (N % 256, K % 256 == 0), 0 = the transposed-copy path of rounds 2-5 (two transposes + the K-contiguous GEMM; scratch: (N + K) * M bf16) for A/B
+ * weight gradients `accelerator.backward(loss)` produces for the trainable linear layers, trainers/grpo.py:326-330).  N % 128, K % 128 must be
+ * 0; any M (a ragged last 64-row tile reads zeros for the missing rows; the slices are taken on M rounded up to 64).  variant 1 = 128 x 128 tiles,
+ * 2 = 256 x 256 tiles (N % 256, K % 256 == 0), 0 = the transposed-copy path of rounds 2-5 (two zero-padded transposes + the K-contiguous GEMM;
+ * scratch: (N + K) * M_pad bf16) for A/B
  * tests: both variants give the same bits. */
 int mi355_op_wgrad(void* stream, const void* dY, int64_t ld_dy, const void* X, int64_t ld_x, float* out, int M, int N, int K, int k_split,
                    int variant, void* scratch, float* colsum);

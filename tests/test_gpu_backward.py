@@ -550,13 +550,16 @@ def test_two_grad_forwards_on_one_plan_before_a_single_backward(gpu):
 
 # ------------------------------------------------------------------------------------------------- weight gradients on row-major operands
 @pytest.mark.parametrize("M,N,K,split,strided", [(64, 128, 128, 1, False), (128, 128, 256, 2, False), (4096, 1536, 1536, 4, False), (8192, 1536, 1536, 7, True),
-                                                 (8192, 1536, 6144, 3, False), (2048, 4608, 1536, 2, True), (320, 256, 128, 5, False)])
+                                                 (8192, 1536, 6144, 3, False), (2048, 4608, 1536, 2, True), (320, 256, 128, 5, False),
+                                                 # ragged M (the other engines' token counts are not multiples of 64: the last m-tile's missing rows read zeros)
+                                                 (666, 1536, 1536, 2, False), (333, 256, 256, 1, True), (40560, 1536, 1536, 7, False), (13978, 3072, 3072, 3, True), (1, 128, 128, 1, False)])
 def test_weight_gradient_gemm_on_row_major_operands_is_bit_identical_to_the_transposed_copy_path(gpu, M, N, K, split, strided):
     """Round 6 (csrc/gemm_tn.hip, mi355_op_wgrad): dW = dY^T X with dY [M][N] and X [M][K] read as they lie in HBM -- the MFMA fragments (8
     consecutive m for one column) come out of the row-major LDS tiles through `ds_read_b64_tr_b16` -- against the path of rounds 2-5 (two
     transposed copies + the K-contiguous GEMM): the fp32 partial sums of every split are BIT-IDENTICAL (same MFMA, operand order, m order,
     split boundaries), and both agree with torch's fp32 product of the same bf16 values.  `strided`: dY is a column block of a wider buffer
-    (the q | k | v gradients lie side by side, engine_train.inc) and X a view with a larger row stride."""
+    (the q | k | v gradients lie side by side, engine_train.inc) and X a view with a larger row stride.  Ragged M: the copies are zero-padded to
+    whole 64-row tiles, the row-major kernels read zeros for the missing rows of the last tile -- still the same bits."""
     from mi355_flow import engine
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     if strided:
