@@ -581,9 +581,9 @@ def test_weight_gradient_gemm_on_row_major_operands_is_bit_identical_to_the_tran
     # the bias gradient's partials from the same launch: per-slice column sums of dY out of the operand fragments (v_dot2c against (1, 1))
     a2, cs = engine.op_wgrad(dy, x, split, variant=1, want_colsum=True)
     assert torch.equal(a2, a) and cs.shape == (split, N)
-    nt = M // 64
+    nt = (M + 63) // 64                                   # slices are taken on whole 64-row tiles of M rounded up
     for sidx in range(split):
-        lo, hi = nt * sidx // split * 64, nt * (sidx + 1) // split * 64
+        lo, hi = nt * sidx // split * 64, min(M, nt * (sidx + 1) // split * 64)
         want = dy[lo:hi].float().sum(0)
         assert float((cs[sidx] - want).abs().max()) <= 1e-4 * float(want.abs().max() + 1.0), (sidx, float((cs[sidx] - want).abs().max()))
     assert torch.equal(engine.op_wgrad(dy, x, split, variant=1, want_colsum=True)[1], cs)       # deterministic
