@@ -351,7 +351,9 @@ static const void* tn_zero_block() {
     static void* z = nullptr;
     if (!z) {
         if (hipMalloc(&z, 256) != hipSuccess) { z = nullptr; return nullptr; }
-        if (hipMemset(z, 0, 256) != hipSuccess) { (void)hipFree(z); z = nullptr; return nullptr; }
+        // (hipMemset on device memory may return before the fill has run, and it runs on the NULL stream, which the engines' non-blocking streams
+        //  do not wait for: synchronise once -- the first model-level run read the block before it was zero)
+        if (hipMemset(z, 0, 256) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(z); z = nullptr; return nullptr; }
     }
     return z;
 }
