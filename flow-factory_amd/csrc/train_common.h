@@ -32,6 +32,7 @@ struct TrainScratch {
     int n_slots = 1, next_slot = 0;
     long aT_rows = 0, xT_rows = 0;
     hipStream_t wside = nullptr;
+    bool tn_default = false;                  // weight gradients on row-major operands by default (set per engine from measurements: Wan yes, FLUX.1 / Qwen-Image no)
 };
 
 struct AttnGeom {
@@ -110,8 +111,11 @@ static inline int t_wgrad_group(TrainScratch& t, hipStream_t st, const bf16_t* d
     // a ragged last m-tile reads zeros) -- neither dY^T nor X^T is made, and the 256 x 256-tile form runs the large weights (N x K >= 160 tiles)
     // at the ping-pong kernel's bytes per FLOP instead of the 2-stage kernel's.  Same products, same split boundaries over M_pad, same fixed-order
     // reduction.  These GEMMs read dY itself, which the backward overwrites next: they run on `st`, not on the side stream that the copies made
-    // safe (the two big-GEMM streams shared the chip anyway).  mi355_tune_set(39, 0) = the transposed-copy path below.
-    if (get_wgrad_tn_mode() != 0 && nx == 1 && M_pad % 64 == 0) {
+    // safe.  Measured per engine (profiles/r06w_*, optimize() step, row-major vs copies): Wan2.1 at 20 280 tokens 1033 vs 1053 ms (its 1536-wide
+    // weights need 7-way split-K on the copies' path and its ragged M a padded transpose of 40 560 rows) -- ON; FLUX.1 251 vs 239 ms and Qwen-Image
+    // 472 vs 468 ms (3072-wide weights: the 2-stage 256 x 256 kernel beside the dgrad chain on the side stream is the better schedule) -- OFF.
+    // mi355_tune_set(39, 2) = row-major wherever it applies, 0 = never, 1 (default) = the engine's measured default.
+    if ((get_wgrad_tn_mode() == 2 || (get_wgrad_tn_mode() == 1 && t.tn_default)) && nx == 1 && M_pad % 64 == 0) {
         bool ok = true;
         for (int i = 0; i < nseg && ok; ++i)
             if (seg[i].gw) {

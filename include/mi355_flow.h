@@ -552,8 +552,10 @@ int mi355_profile_enable(int on);
  *         rule in percent (100); 34 / 37 smallest / largest grid of its tiles (160 / 256: one-round grids); 35, 36 accepted and ignored (measurement
  *         knobs of round 6, removed).  Results are bit-identical for every value.
  *  38     optimize() backward: 1 (default) = the bias gradient's column-sum finish rides in the weight gradient's split-K reduction launch.
- *  39     optimize() backward: weight-gradient GEMMs of whole-tile shapes on ROW-MAJOR operands (csrc/gemm_tn.hip): 1 (default) 128x128 tiles,
- *         2 = 256x256 tiles where they give a one-round grid (measured equal in the step), 0 = transposed copies.  Same products; 0 / 1 bit-identical.
+ *  39     optimize() backward: weight-gradient GEMMs on ROW-MAJOR operands (csrc/gemm_tn.hip; N, K multiples of 128, any M): 0 = transposed copies
+ *         everywhere; 1 (default) = SD3.5: 128x128 tiles (image and text stream), the head_dim-128 engines: each engine's measured default
+ *         (Wan on, FLUX.1 / Qwen-Image off: train_common.h); 2 = SD3.5: 256x256 tiles where they give a one-round grid (measured equal in the
+ *         step), the other engines: row-major wherever it applies.  Same products; SD3.5 0 / 1 bit-identical.
  *  40-42  256x192-tile GEMM kernel (gemm_w6_kernel): 40 = 0 off (default: 16-20 % faster back to back, 2.4 % slower inside the two-stream forward),
  *         1 by its cost rule, 2 wherever it applies; 41 margin in percent (105); 42 smallest grid (200).  Bit-identical for every value.
  *  43     head_dim-64 attention backward: 1 (default) = the software-pipelined passes (csrc/gen_attn_bwd64.py), 0 = the round-3 kernels
