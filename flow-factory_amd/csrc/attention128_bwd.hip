@@ -234,8 +234,6 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dkv_kernel(AttnBwd
         constexpr bool MASK = decltype(mask_c)::value;
         f32x16 (&dk_)[4] = dk;        // (named here: an asm operand inside a generic lambda does not capture by itself)
         f32x16 (&dv_)[4] = dv;
-        const bf16x8 (&kf_)[8] = kf;
-        const bf16x8 (&vf_)[8] = vf;
         wait_tiles_ahead<9>(nt - 1 - t);
         if (t + 3 < nt) stage(t + 3, (t + 3) & (NST1 - 1));      // its buffer held tile t - 1: every wave is past it (the barrier above)
         const char* sb = smem + (t & (NST1 - 1)) * ST1;
@@ -281,7 +279,7 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dkv_kernel(AttnBwd
             for (int j = 0; j < 8; ++j) {
                 if (j + 1 < 8) rd(j + 1, (j + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
-                CHAIN4(s[0], dp[0], s[1], dp[1], fq[j & 1][0], fo[j & 1][0], fq[j & 1][1], fo[j & 1][1], kf_[j], vf_[j]);
+                CHAIN4(s[0], dp[0], s[1], dp[1], fq[j & 1][0], fo[j & 1][0], fq[j & 1][1], fo[j & 1][1], kf[j], vf[j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             MFMA_DRAIN();
@@ -400,8 +398,6 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dq_kernel(AttnBwdP
     auto tile = [&](int t, auto mask_c) {             // (MASK: the key-tail mask, needed by the last tile only -- see the dK / dV pass)
         constexpr bool MASK = decltype(mask_c)::value;
         f32x16 (&dq_)[4] = dq;
-        const bf16x8 (&qf_)[8] = qf;      // (asm INPUT operands too: unnamed, they compiled -- and fed the chains garbage)
-        const bf16x8 (&of_)[8] = of;
         wait_tiles_ahead<8>(nt - 1 - t);
         if (t + 3 < nt) stage(t + 3, (t + 3) % NST2);
         const char* sb = smem + (t % NST2) * ST2;
@@ -424,7 +420,7 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dq_kernel(AttnBwdP
                 if (j + 1 < 8) rd(j + 1, (j + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
                 if (j == 0) { s[0] = nL; s[1] = nL; dp[0] = nD; dp[1] = nD; }      // -L / -Delta of this lane's query: the chains' C operands
-                CHAIN4(s[0], dp[0], s[1], dp[1], fk[j & 1][0], fv[j & 1][0], fk[j & 1][1], fv[j & 1][1], qf_[j], of_[j]);
+                CHAIN4(s[0], dp[0], s[1], dp[1], fk[j & 1][0], fv[j & 1][0], fk[j & 1][1], fv[j & 1][1], qf[j], of[j]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             MFMA_DRAIN();
