@@ -20,7 +20,6 @@
 // blocks keep the attention output inside the [M][5D] concat buffer), and the backward of the q | k producer (per-head RMSNorm + RoPE,
 // flux_ops.hip rope_norm_kernel) gathered to token-major [dq_pre | dk_pre | dv] rows.
 #include "kernels.h"
-#include <type_traits>
 
 namespace mi355 {
 namespace {
@@ -228,12 +227,7 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dkv_kernel(AttnBwd
     stage(0, 0);
     if (nt > 1) stage(1, 1);
     if (nt > 2) stage(2, 2);
-    // Round 6: the query-tail / key mask lives in its own copy of the tile body (MASK): inside the loop the 64 extra v_cmp / v_cndmask per tile sat in
-    // the VALU phase that nothing hides at one wave per SIMD.  A wave whose 32 keys are all valid runs the unmasked copy for every tile but the last.
-    auto tile = [&](int t, auto mask_c) {
-        constexpr bool MASK = decltype(mask_c)::value;
-        f32x16 (&dk_)[4] = dk;        // (named here: an asm operand inside a generic lambda does not capture by itself)
-        f32x16 (&dv_)[4] = dv;
+    for (int t = 0; t < nt; ++t) {
         wait_tiles_ahead<9>(nt - 1 - t);
         if (t + 3 < nt) stage(t + 3, (t + 3) & (NST1 - 1));      // its buffer held tile t - 1: every wave is past it (the barrier above)
         const char* sb = smem + (t & (NST1 - 1)) * ST1;
@@ -291,11 +285,9 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dkv_kernel(AttnBwd
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 float p0 = __builtin_amdgcn_exp2f(s[qb][r]), p1 = __builtin_amdgcn_exp2f(s[qb][r + 1]);
-                if constexpr (MASK) {
-                    const int ql = 32 * qb + 16 * (r >> 3) + 8 * lg + (r & 7);      // branch-free tail mask: q_lim = valid queries of this tile (64 except the last)
-                    p0 = (ql < q_lim && key_ok) ? p0 : 0.f;
-                    p1 = (ql + 1 < q_lim && key_ok) ? p1 : 0.f;
-                }
+                const int ql = 32 * qb + 16 * (r >> 3) + 8 * lg + (r & 7);      // branch-free tail mask: q_lim = valid queries of this tile (64 except the last)
+                p0 = (ql < q_lim && key_ok) ? p0 : 0.f;
+                p1 = (ql + 1 < q_lim && key_ok) ? p1 : 0.f;
                 pk[r >> 1] = pack_bf16(p0, p1);
                 zk[r >> 1] = pack_bf16(p0 * dp[qb][r], p1 * dp[qb][r + 1]);
             }
@@ -305,18 +297,10 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dkv_kernel(AttnBwd
                 const unsigned a0 = stg + qb * 4096 + trb[0][0], a1 = stg + qb * 4096 + trb[0][1];
                 const unsigned a2 = stg + qb * 4096 + trb[1][0], a3 = stg + qb * 4096 + trb[1][1];
                 // d half 0: dO sub-tile at 16384, Q sub-tile at 0; d half 1: dO at 24576, Q at 8192; the second k-step is 16 rows (2048 B) on
-                DKV_BLOCK(16384, 0, 18432, 2048, dv_[0], dv_[1], dk_[0], dk_[1]);
-                DKV_BLOCK(24576, 8192, 26624, 10240, dv_[2], dv_[3], dk_[2], dk_[3]);
+                DKV_BLOCK(16384, 0, 18432, 2048, dv[0], dv[1], dk[0], dk[1]);
+                DKV_BLOCK(24576, 8192, 26624, 10240, dv[2], dv[3], dk[2], dk[3]);
             }
         }
-    };
-    using std::integral_constant;
-    const bool wave_keys_ok = kblk * KB + wave * 32 + 32 <= Skv;      // (wave-uniform) every lane of this wave holds a valid key
-    if (wave_keys_ok) {
-        for (int t = 0; t < nt - 1; ++t) tile(t, integral_constant<bool, false>{});
-        tile(nt - 1, integral_constant<bool, true>{});
-    } else {
-        for (int t = 0; t < nt; ++t) tile(t, integral_constant<bool, true>{});
     }
     __syncthreads();     // every wave is done with the ring: reuse it for the output transposes (8 KiB per wave)
     char* ob = smem + wave * 8192;
@@ -395,9 +379,7 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dq_kernel(AttnBwdP
     stage(0, 0);
     if (nt > 1) stage(1, 1);
     if (nt > 2) stage(2, 2);
-    auto tile = [&](int t, auto mask_c) {             // (MASK: the key-tail mask, needed by the last tile only -- see the dK / dV pass)
-        constexpr bool MASK = decltype(mask_c)::value;
-        f32x16 (&dq_)[4] = dq;
+    for (int t = 0; t < nt; ++t) {
         wait_tiles_ahead<8>(nt - 1 - t);
         if (t + 3 < nt) stage(t + 3, (t + 3) % NST2);
         const char* sb = smem + (t % NST2) * ST2;
@@ -432,25 +414,20 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dq_kernel(AttnBwdP
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 float p0 = __builtin_amdgcn_exp2f(s[kb][r]), p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
-                if constexpr (MASK) {
-                    const int kl = 32 * kb + 16 * (r >> 3) + 8 * lg + (r & 7);      // branch-free tail mask
-                    p0 = kl < k_lim ? p0 : 0.f;
-                    p1 = kl + 1 < k_lim ? p1 : 0.f;
-                }
+                const int kl = 32 * kb + 16 * (r >> 3) + 8 * lg + (r & 7);      // branch-free tail mask
+                p0 = kl < k_lim ? p0 : 0.f;
+                p1 = kl + 1 < k_lim ? p1 : 0.f;
                 zk[r >> 1] = pack_bf16(p0 * dp[kb][r], p1 * dp[kb][r + 1]);
             }
             {
                 const bf16x8 zf0 = frag4(zk[0], zk[1], zk[2], zk[3]), zf1 = frag4(zk[4], zk[5], zk[6], zk[7]);
                 const unsigned a0 = stg + kb * 4096 + trb[0][0], a1 = stg + kb * 4096 + trb[0][1];
                 const unsigned a2 = stg + kb * 4096 + trb[1][0], a3 = stg + kb * 4096 + trb[1][1];
-                DQ_BLOCK(0, 2048, dq_[0], dq_[1]);            // d half 0: K sub-tile at 0
-                DQ_BLOCK(8192, 10240, dq_[2], dq_[3]);        // d half 1: K sub-tile at 8192
+                DQ_BLOCK(0, 2048, dq[0], dq[1]);            // d half 0: K sub-tile at 0
+                DQ_BLOCK(8192, 10240, dq[2], dq[3]);        // d half 1: K sub-tile at 8192
             }
         }
-    };
-    using std::integral_constant;
-    for (int t = 0; t < nt - 1; ++t) tile(t, integral_constant<bool, false>{});
-    tile(nt - 1, integral_constant<bool, true>{});
+    }
     __syncthreads();
     char* ob = smem + wave * 8192;
     store_rows128(dq, LN2, ob, p.dq + bh * p.S_pad * HD, qblk * QB + wave * 32, p.S, lane);
