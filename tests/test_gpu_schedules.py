@@ -493,8 +493,10 @@ def test_wan_training_step_schedule_is_race_free():
         assert races == [], races[:5]
         nw = SC.n_waits(text)
         needed = [k for k in range(nw) if SC.parse(text, drop_waits=[k]).races(limit=1)]
-        print(f"wan optimize() step: {sum(1 for o in s.ops if o.regions)} launches on 2 streams, {nw} stream waits, {len(needed)} of them individually "
-              f"necessary, no race")
-        assert nw > 0 and len(needed) >= 0.5 * nw, (nw, len(needed))
+        print(f"wan optimize() step: {sum(1 for o in s.ops if o.regions)} launches on {len(s.streams())} stream(s), {nw} stream waits, {len(needed)} of them "
+              f"individually necessary, no race")
+        # (round 6b: the weight-gradient GEMMs read dY where it lies and therefore run on the backward's own stream -- the side stream and its
+        #  waits are gone from this step; where waits remain, at least half must be individually necessary)
+        assert (nw == 0 and len(s.streams()) == 1) or len(needed) >= 0.5 * nw, (nw, len(needed), s.streams())
     finally:
         ad.engine.close()

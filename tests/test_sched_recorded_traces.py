@@ -20,10 +20,13 @@ def test_recorded_schedule_is_race_free(path):
     text = open(path).read()
     s = SC.parse(text)
     n_launch = sum(1 for o in s.ops if o.regions)
-    assert n_launch >= 20 and len(s.streams()) >= 2, (n_launch, s.streams())
+    assert n_launch >= 20, n_launch
     races = s.races()
     assert races == [], races[:5]
     nw = SC.n_waits(text)
+    if len(s.streams()) == 1:          # (the Wan training step since round 6b: its weight-gradient GEMMs left the side stream -- nothing to order)
+        assert nw == 0, nw
+        return
     assert nw > 0
     needed = [k for k in range(nw) if SC.parse(text, drop_waits=[k]).races(limit=1)]
     assert len(needed) >= 0.6 * nw, (nw, len(needed))
