@@ -433,6 +433,163 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dq_kernel(AttnBwdP
     store_rows128(dq, LN2, ob, p.dq + bh * p.S_pad * HD, qblk * QB + wave * 32, p.S, lane);
 }
 
+// =============================================================================================== round 6: software-pipelined passes
+// The two passes with their main loops as ONE generated asm statement each (attn_bwd128_asm.inc <- gen_attn_bwd128.py; the schedule of
+// gen_attn_bwd64.py at head_dim 128): B(h - 1) || V(h) || A(h + 1) interleaved MFMA by MFMA -- with one wave per SIMD nothing else puts the
+// exp / mask / pack arithmetic under matrix work.  Same arithmetic and masks in the same order per output element as the kernels above
+// (kept: mi355_tune_set(44, 0), and the A/B of tests/test_gpu_flux_backward.py): bit-identical.
+#include "attn_bwd128_asm.inc"
+
+__global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dkv_pipe_kernel(AttnBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane & 31, lg = lane >> 5;
+    constexpr int KB = 32 * NWAVES;
+    const int Sk = p.S_kv > 0 ? p.S_kv : p.S;
+    const long Skp = p.S_kv > 0 ? p.S_kv_pad : p.S_pad;
+    const int nkb = (Sk + KB - 1) / KB;
+    const int nwg = nkb * p.H * p.B;
+    int wid = blockIdx.x;
+    {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = wid & 7;
+        wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (wid >> 3);
+    }
+    const int kblk = wid % nkb;
+    const long bh = wid / nkb;
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();      // the asm addresses the ring from LDS byte 0
+    const bf16_t* Qg = p.q + bh * p.S_pad * HD;
+    const bf16_t* Og = p.doh + bh * p.S_pad * HD;
+    const float* NLt = p.nld + bh * p.S_pad * 2;
+    const int key = kblk * KB + wave * 32 + lk;
+    const int key_ld = key < Sk ? key : Sk - 1;
+    int Skv = Sk;
+    if (p.kv_len) Skv = min(Skv, max(1, __builtin_amdgcn_readfirstlane(p.kv_len[bh / p.H])));
+    const int nt = (p.S + TB - 1) / TB;
+    const int srow = wave * 8 + (lane >> 3);
+    const unsigned g0 = (unsigned)(srow * 256 + (((lane & 7) ^ swz2(srow)) << 4));
+    const unsigned g2 = (unsigned)(wave * 128 + (lane & 7) * 16);
+    const unsigned grow = (unsigned)(key_ld * 256 + lg * 16);
+    auto stage = [&](int t, int buf) {                   // (tiles 0..2; the loop stages the rest)
+        const int tt = t < nt ? t : nt - 1;
+        char* base = smem + buf * ST1;
+        const bf16_t* qs = Qg + (long)tt * TB * HD;
+        const bf16_t* os = Og + (long)tt * TB * HD;
+        stage_sub(qs, base, wave, lane);
+        stage_sub(qs + 64, base + SUB, wave, lane);
+        stage_sub(os, base + TILE, wave, lane);
+        stage_sub(os + 64, base + TILE + SUB, wave, lane);
+        if (lane < 8) __builtin_amdgcn_global_load_lds((gptr_t)(NLt + (long)tt * 2 * TB + wave * 32 + (lane & 7) * 4), (lptr_t)(base + 2 * TILE + wave * 128), 16, 0, 0);
+    };
+    const int prow = row_perm(lk);
+    unsigned la = (unsigned)(2 * TILE + 32 * lg), r0, a0, a1;
+    {
+        r0 = (unsigned)(prow * 128 + ((lg ^ swz2(prow)) << 4));                  // fragment kk = 0 (offR[0]); kk = 1..3: r0 ^ 32 kk, formed by the asm
+        const int i = lane & 15, g1 = (lane >> 4) & 1;
+        unsigned a[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {                                         // pieces (db = 0, jj) (trb[0][jj]); db = 1: ^ 64
+            const int ql = 8 * lg + 4 * jj + (i >> 2);
+            const int ch = 2 * g1 + ((i & 3) >> 1);
+            a[jj] = (unsigned)(ql * 128 + ((ch ^ swz2(ql)) << 4) + (i & 1) * 8);
+        }
+        a0 = a[0]; a1 = a[1];
+    }
+    // valid queries of the current tile minus this half-wave's row offset; a lane whose key is masked (beyond the sample's keys) never has any
+    int vrem = key < Skv ? p.S - 8 * lg : -(1 << 30);
+    stage(0, 0); stage(1, 1); stage(2, 2);
+    const int lt = nt - 1 < 3 ? nt - 1 : 3;
+    const unsigned long long b0 = (unsigned long long)(Qg + (long)lt * TB * HD), b1 = (unsigned long long)(Og + (long)lt * TB * HD);
+    const unsigned long long b2 = (unsigned long long)(NLt + (long)lt * 2 * TB);
+    const unsigned long long p0 = (unsigned long long)(p.k + bh * Skp * HD), p1 = (unsigned long long)(p.v + bh * Skp * HD);
+    asm volatile(ABWD128_DKV_ASM
+                 : [la] "+v"(la), [r0] "+v"(r0), [a0] "+v"(a0), [a1] "+v"(a1), [vrem] "+v"(vrem)
+                 : [g0] "v"(g0), [g2] "v"(g2), [grow] "v"(grow), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [p0] "s"(p0), [p1] "s"(p1), [nt] "s"(nt),
+                   [wv] "s"(wave)
+                 : ABWD128_DKV_CLOBBERS);
+    f32x16 dk[4], dv[4];
+    ABWD128_READ_ACC_0(dv[0]) ABWD128_READ_ACC_16(dv[1]) ABWD128_READ_ACC_32(dv[2]) ABWD128_READ_ACC_48(dv[3])
+    ABWD128_READ_ACC_64(dk[0]) ABWD128_READ_ACC_80(dk[1]) ABWD128_READ_ACC_96(dk[2]) ABWD128_READ_ACC_112(dk[3])
+    __syncthreads();     // every wave is done with the ring (the asm ends with vmcnt(0)): reuse it for the output transposes (8 KiB per wave)
+    int lane_e = lane;   // (an opaque copy: the epilogue's lane arithmetic must not be formed in front of the loop -- see attention_bwd.hip)
+    asm volatile("" : "+v"(lane_e));
+    char* ob = smem + wave * 8192;
+    const int row0 = kblk * KB + wave * 32;
+    store_rows128(dk, LN2, ob, p.dk + bh * Skp * HD, row0, Sk, lane_e);
+    store_rows128(dv, 1.0f, ob, p.dv + bh * Skp * HD, row0, Sk, lane_e);
+}
+
+__global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dq_pipe_kernel(AttnBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, lg = lane >> 5;
+    constexpr int QB = 32 * NWAVES;
+    const int nqb = (p.S + QB - 1) / QB;
+    const int nwg = nqb * p.H * p.B;
+    int wid = blockIdx.x;
+    {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = wid & 7;
+        wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (wid >> 3);
+    }
+    const int qblk = wid % nqb;
+    const long bh = wid / nqb;
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
+    const long Skp = p.S_kv > 0 ? p.S_kv_pad : p.S_pad;
+    const bf16_t* Kg = p.k + bh * Skp * HD;
+    const bf16_t* Vg = p.v + bh * Skp * HD;
+    const int q_row = qblk * QB + wave * 32 + lq;
+    const int q_ld = q_row < p.S ? q_row : p.S - 1;
+    int Skv = p.S_kv > 0 ? p.S_kv : p.S;      // ragged text: this sample's keys end at kv_len[b]
+    if (p.kv_len) Skv = min(Skv, max(1, __builtin_amdgcn_readfirstlane(p.kv_len[bh / p.H])));
+    const int nt = (Skv + TB - 1) / TB;
+    const int srow = wave * 8 + (lane >> 3);
+    const unsigned g0 = (unsigned)(srow * 256 + (((lane & 7) ^ swz2(srow)) << 4));
+    const unsigned grow = (unsigned)(q_ld * 256 + lg * 16);
+    const float nl = -p.lse[bh * p.S_pad + q_ld], nd = -p.delta[bh * p.S_pad + q_ld];
+    auto stage = [&](int t, int buf) {
+        const int tt = t < nt ? t : nt - 1;
+        char* base = smem + buf * ST2;
+        const bf16_t* ks = Kg + (long)tt * TB * HD;
+        const bf16_t* vs = Vg + (long)tt * TB * HD;
+        stage_sub(ks, base, wave, lane);
+        stage_sub(ks + 64, base + SUB, wave, lane);
+        stage_sub(vs, base + TILE, wave, lane);
+        stage_sub(vs + 64, base + TILE + SUB, wave, lane);
+    };
+    const int prow = row_perm(lq);
+    unsigned r0, a0, a1;
+    {
+        r0 = (unsigned)(prow * 128 + ((lg ^ swz2(prow)) << 4));
+        const int i = lane & 15, g1 = (lane >> 4) & 1;
+        unsigned a[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int kl = 8 * lg + 4 * jj + (i >> 2);
+            const int ch = 2 * g1 + ((i & 3) >> 1);
+            a[jj] = (unsigned)(kl * 128 + ((ch ^ swz2(kl)) << 4) + (i & 1) * 8);
+        }
+        a0 = a[0]; a1 = a[1];
+    }
+    int vrem = Skv - 8 * lg;                  // valid keys of the current tile minus this half-wave's row offset
+    stage(0, 0); stage(1, 1); stage(2, 2);
+    const int lt = nt - 1 < 3 ? nt - 1 : 3;
+    const unsigned long long b0 = (unsigned long long)(Kg + (long)lt * TB * HD), b1 = (unsigned long long)(Vg + (long)lt * TB * HD);
+    const unsigned long long p0 = (unsigned long long)(p.q + bh * p.S_pad * HD), p1 = (unsigned long long)(p.doh + bh * p.S_pad * HD);
+    asm volatile(ABWD128_DQ_ASM
+                 : [r0] "+v"(r0), [a0] "+v"(a0), [a1] "+v"(a1), [vrem] "+v"(vrem)
+                 : [g0] "v"(g0), [grow] "v"(grow), [nl] "v"(nl), [nd] "v"(nd), [b0] "s"(b0), [b1] "s"(b1), [p0] "s"(p0), [p1] "s"(p1), [nt] "s"(nt),
+                   [wv] "s"(wave)
+                 : ABWD128_DQ_CLOBBERS);
+    f32x16 dq[4];
+    ABWD128_READ_ACC_0(dq[0]) ABWD128_READ_ACC_16(dq[1]) ABWD128_READ_ACC_32(dq[2]) ABWD128_READ_ACC_48(dq[3])
+    __syncthreads();
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    char* ob = smem + wave * 8192;
+    store_rows128(dq, LN2, ob, p.dq + bh * p.S_pad * HD, qblk * QB + wave * 32, p.S, lane_e);
+}
+
 __device__ __forceinline__ void unpack8(const uint4 u, float (&v)[8]) {
     v[0] = bf_lo(u.x); v[1] = bf_hi(u.x); v[2] = bf_lo(u.y); v[3] = bf_hi(u.y);
     v[4] = bf_lo(u.z); v[5] = bf_hi(u.z); v[6] = bf_lo(u.w); v[7] = bf_hi(u.w);
@@ -542,6 +699,9 @@ __global__ __launch_bounds__(256) void rope_rms_bwd128_kernel(RopeRmsBwdParams p
 
 }  // namespace
 
+static int g_attn128_bwd_pipe = 1;      // mi355_tune_set(44, .): 1 = the software-pipelined passes (round 6), 0 = the round-4 kernels
+void set_attn128_bwd_pipe(int v) { g_attn128_bwd_pipe = v; }
+
 hipError_t launch_attention128_bwd(const AttnBwdParams& p, hipStream_t stream) {
     const int Sk = p.S_kv > 0 ? p.S_kv : p.S;
     const long Skp = p.S_kv > 0 ? p.S_kv_pad : p.S_pad;
@@ -561,6 +721,19 @@ hipError_t launch_attention128_bwd(const AttnBwdParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const int nbq = (p.S + 32 * NWAVES - 1) / (32 * NWAVES), nbk = (Sk + 32 * NWAVES - 1) / (32 * NWAVES);
+    if (g_attn128_bwd_pipe) {
+        static bool attr_set2 = false;
+        if (!attr_set2) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn128_bwd_dkv_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NST1 * ST1);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)attn128_bwd_dq_pipe_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NST2 * ST2);
+            if (e != hipSuccess) return e;
+            attr_set2 = true;
+        }
+        hipLaunchKernelGGL(attn128_bwd_dkv_pipe_kernel, dim3(nbk * p.H * p.B), dim3(NWAVES * 64), NST1 * ST1, stream, p);
+        hipLaunchKernelGGL(attn128_bwd_dq_pipe_kernel, dim3(nbq * p.H * p.B), dim3(NWAVES * 64), NST2 * ST2, stream, p);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(attn128_bwd_dkv_kernel, dim3(nbk * p.H * p.B), dim3(NWAVES * 64), NST1 * ST1, stream, p);
     hipLaunchKernelGGL(attn128_bwd_dq_kernel, dim3(nbq * p.H * p.B), dim3(NWAVES * 64), NST2 * ST2, stream, p);
     return hipGetLastError();

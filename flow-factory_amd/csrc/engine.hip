@@ -1090,7 +1090,8 @@ extern "C" int mi355_tune_set(int key, int value) {
         const char* ok = getenv("MI355_ALLOW_ABLATION");
         if (value > 1 && !(ok && ok[0] == '1')) return fail("mi355_tune_set(43, %d): ablation builds produce wrong gradients; set MI355_ALLOW_ABLATION=1 for a timing measurement", value);
         set_attn_bwd_pipe(value); return 0;
-    }         if (key == 40) { set_w6_mode(value); return 0; }           // 256x192-tile GEMM kernel (round 6): 0 off (default: measured slower inside the two-stream forward), 1 cost rule, 2 wherever it applies
+    }         if (key == 44) { set_attn128_bwd_pipe(value); return 0; }  // head_dim-128 attention backward: 1 (default) = software-pipelined passes (gen_attn_bwd128.py), 0 = the round-4 kernels
+    if (key == 40) { set_w6_mode(value); return 0; }           // 256x192-tile GEMM kernel (round 6): 0 off (default: measured slower inside the two-stream forward), 1 cost rule, 2 wherever it applies
     if (key == 41) { set_w6_alpha_percent(value); return 0; }  // margin of that rule in percent (default 105)
     if (key == 42) { set_w6_min_tiles(value); return 0; }      // smallest grid of its tiles (default 200)
     if (key == 38) { g_fuse_colsum = value; return 0; }        // optimize() backward: 1 (default) = column-sum finish fused into the split-K reduction launch, 0 = two launches

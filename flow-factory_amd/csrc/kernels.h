@@ -370,7 +370,8 @@ struct AttnBwdParams {
     int S_kv = 0, S_kv_pad = 0;   // head_dim-128 kernels only: cross-attention -- k, v, dk, dv are [B][H][S_kv_pad][128] over S_kv keys (0 = self)
 };
 hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream);
-void set_attn_bwd_pipe(int v);      // head_dim-64 backward: 1 = software-pipelined passes (default), 0 = the round-3 kernels
+void set_attn_bwd_pipe(int v);
+void set_attn128_bwd_pipe(int v);   // head_dim-128 backward: 1 = software-pipelined passes (default), 0 = the round-4 kernels      // head_dim-64 backward: 1 = software-pipelined passes (default), 0 = the round-3 kernels
 // head_dim 128 (attention128_bwd.hip): the same contract with [B][H][S_pad][128] operands
 hipError_t launch_attention128_bwd(const AttnBwdParams& p, hipStream_t stream);
 struct Attn128BwdPrepParams {

@@ -41,7 +41,7 @@ def gpu():
 
 # ------------------------------------------------------------------------------------------------- attention backward, head_dim 128
 @pytest.mark.parametrize("static", [0, 1])
-@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (2, 3, 333 + 256), (1, 2, 1000), (1, 2, 4608)])
+@pytest.mark.parametrize("B,H,S", [(1, 2, 64), (1, 1, 100), (1, 2, 192), (2, 1, 256), (1, 1, 449), (2, 3, 333 + 256), (1, 2, 1000), (1, 2, 4608)])
 def test_attention128_backward_matches_autograd(gpu, B, H, S, static):
     from mi355_flow import _lib
     from mi355_flow.engine import _ptr, _stream
@@ -63,8 +63,22 @@ def test_attention128_backward_matches_autograd(gpu, B, H, S, static):
     try:
         _lib.check(lib.mi355_op_attention128_fwd_bwd(_stream(), _ptr(q), _ptr(k), _ptr(vT), _ptr(do), _ptr(o), _ptr(dq), _ptr(dk), _ptr(dv),
                                                      B, H, S, S_pad), "op_attention128_fwd_bwd")
+        # round 6: the shipped passes are the software-pipelined ones (csrc/gen_attn_bwd128.py; 1 .. 72 tiles here: prologue-only, every ring-slot
+        # wrap, ragged tails).  Same MFMAs / masks in the same order per output element as the round-4 kernels (mi355_tune_set(44, 0)): same bits.
+        _lib.check(lib.mi355_tune_set(44, 0))
+        dq0, dk0, dv0 = torch.zeros_like(q), torch.zeros_like(q), torch.zeros_like(q)
+        _lib.check(lib.mi355_op_attention128_fwd_bwd(_stream(), _ptr(q), _ptr(k), _ptr(vT), _ptr(do), _ptr(o), _ptr(dq0), _ptr(dk0), _ptr(dv0),
+                                                     B, H, S, S_pad), "op_attention128_fwd_bwd")
+        _lib.check(lib.mi355_tune_set(44, 1))
+        for name, a, b in (("dq", dq, dq0), ("dk", dk, dk0), ("dv", dv, dv0)):
+            assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
+        dq1, dk1, dv1 = torch.zeros_like(q), torch.zeros_like(q), torch.zeros_like(q)
+        _lib.check(lib.mi355_op_attention128_fwd_bwd(_stream(), _ptr(q), _ptr(k), _ptr(vT), _ptr(do), _ptr(o), _ptr(dq1), _ptr(dk1), _ptr(dv1),
+                                                     B, H, S, S_pad), "op_attention128_fwd_bwd")
+        assert torch.equal(dq1, dq) and torch.equal(dk1, dk) and torch.equal(dv1, dv)       # run to run
     finally:
         lib.mi355_tune_set(21, 0)
+        lib.mi355_tune_set(44, 1)
     qr = q[:, :, :S].float().requires_grad_(True)
     kr = k[:, :, :S].float().requires_grad_(True)
     vr = v[:, :, :S].float().requires_grad_(True)
