@@ -133,12 +133,14 @@ def dkv():
 
     def stage():
         out = []
-        first = True
+        first, prev = True, 0
         for (lo, hi) in ((S_B0, S_B0H), (S_B1, S_B1H)):
-            for (base, off) in ((lo, 0), (hi, 0), (lo, 128), (hi, 128)):       # sub-tile 0 rows w.., rows w + 32..; sub-tile 1 (d 64..127: + 128 bytes)
-                out += [f"s_add_i32 m0, s{S_W1K}, s{S_LDSL}" if first else "s_add_i32 m0, m0, 4096", "s_nop 0",
+            # sub-tile 0 rows w.., rows w + 32..; sub-tile 1 (d 64..127: + 128 bytes).  The instruction offset of an LDS-DMA load is added to the
+            # global AND to the LDS address: M0 carries the destination minus it
+            for (base, off) in ((lo, 0), (hi, 0), (lo, 128), (hi, 128)):
+                out += [f"s_add_i32 m0, s{S_W1K}, s{S_LDSL}" if first else f"s_add_i32 m0, m0, {4096 - off + prev}", "s_nop 0",
                         f"global_load_lds_dwordx4 %[g0], s[{base}:{base + 1}]" + (f" offset:{off}" if off else "")]
-                first = False
+                first, prev = False, off
         out += [f"s_add_i32 m0, s{S_WNL}, s{S_LDSL}", f"s_mov_b64 s[{S_EX}:{S_EX + 1}], exec", "s_mov_b64 exec, 0xff",
                 f"global_load_lds_dwordx4 %[g2], s[{S_B2}:{S_B2 + 1}]", f"s_mov_b64 exec, s[{S_EX}:{S_EX + 1}]"]
         return out
@@ -208,12 +210,12 @@ def dq():
 
     def stage():
         out = []
-        first = True
+        first, prev = True, 0
         for (lo, hi) in ((S_B0, S_B0H), (S_B1, S_B1H)):
-            for (base, off) in ((lo, 0), (hi, 0), (lo, 128), (hi, 128)):
-                out += [f"s_add_i32 m0, s{S_W1K}, s{S_LDSL}" if first else "s_add_i32 m0, m0, 4096", "s_nop 0",
+            for (base, off) in ((lo, 0), (hi, 0), (lo, 128), (hi, 128)):       # (M0 = destination - instruction offset: see the dK/dV pass)
+                out += [f"s_add_i32 m0, s{S_W1K}, s{S_LDSL}" if first else f"s_add_i32 m0, m0, {4096 - off + prev}", "s_nop 0",
                         f"global_load_lds_dwordx4 %[g0], s[{base}:{base + 1}]" + (f" offset:{off}" if off else "")]
-                first = False
+                first, prev = False, off
         return out
     P.stage = stage
     P.adv = [(S_B0, 14), (S_B1, 14), (S_B0H, 14), (S_B1H, 14)]
