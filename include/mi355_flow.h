@@ -560,6 +560,8 @@ int mi355_profile_enable(int on);
  *         1 by its cost rule, 2 wherever it applies; 41 margin in percent (105); 42 smallest grid (200).  Bit-identical for every value.
  *  43     head_dim-64 attention backward: 1 (default) = the software-pipelined passes (csrc/gen_attn_bwd64.py), 0 = the round-3 kernels
  *         (bit-identical); 2..5 = ablation builds of the dK/dV loop (WRONG results; refused without MI355_ALLOW_ABLATION=1).
+ *  44     head_dim-128 attention backward (FLUX.1 / Qwen-Image / Wan): 1 (default) = the software-pipelined passes (csrc/gen_attn_bwd128.py),
+ *         0 = the round-4 kernels (bit-identical).
  * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
 int mi355_tune_set(int key, int value);
 int mi355_profile_collect(double* ms_out, int64_t* count_out);
