@@ -565,6 +565,147 @@ __global__ __launch_bounds__(NWAVES * 64, 2) void attn_bwd_dq_pipe_kernel(AttnBw
     store_rows(dq, LN2, ob, p.dq + bh * p.S_pad * 64, qblk * QB + wave * 32, p.S, lane_e);
 }
 
+// ---- two 32-row blocks per wave, one wave per SIMD (attn_bwd64x2_asm.inc <- gen_attn_bwd64x2.py: its docstring has the why)
+#include "attn_bwd64x2_asm.inc"
+
+__global__ __launch_bounds__(NWAVES * 64, 1) void attn_bwd_dkv_pipe2_kernel(AttnBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lk = lane & 31, lg = lane >> 5;
+    constexpr int KB = 64 * NWAVES;
+    const int nkb = (p.S + KB - 1) / KB;
+    const int nwg = nkb * p.H * p.B;
+    int wid = blockIdx.x;
+    {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = wid & 7;
+        wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (wid >> 3);
+    }
+    const int kblk = wid % nkb;
+    const long bh = wid / nkb;
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
+    const bf16_t* Qg = p.q + bh * p.S_pad * 64;
+    const bf16_t* Og = p.doh + bh * p.S_pad * 64;
+    const float* NLt = p.nld + bh * p.S_pad * 2;
+    const int key0 = kblk * KB + wave * 64 + lk, key1 = key0 + 32;
+    const int kl0 = key0 < p.S ? key0 : p.S - 1, kl1 = key1 < p.S ? key1 : p.S - 1;
+    const int nt = (p.S + TB - 1) / TB;
+    const int srow = wave * 8 + (lane >> 3);
+    const unsigned g0 = (unsigned)(srow * 128 + (((lane & 7) ^ swz2(srow)) << 4));
+    const unsigned g2 = (unsigned)(wave * 128 + (lane & 7) * 16);
+    const unsigned grow0 = (unsigned)(kl0 * 128 + lg * 16), grow1 = (unsigned)(kl1 * 128 + lg * 16);
+    auto stage = [&](int t, int buf) {
+        const int tt = t < nt ? t : nt - 1;
+        char* base = smem + buf * ST1T;
+        stage_tile2<NWAVES>(Qg + (long)tt * TB * 64, 64, base, wave, lane);
+        stage_tile2<NWAVES>(Og + (long)tt * TB * 64, 64, base + TILE, wave, lane);
+        if (lane < 8) __builtin_amdgcn_global_load_lds((gptr_t)(NLt + (long)tt * 2 * TB + wave * 32 + (lane & 7) * 4), (lptr_t)(base + 2 * TILE + wave * 128), 16, 0, 0);
+    };
+    const int prow = row_perm(lk);
+    unsigned la = (unsigned)(2 * TILE + 32 * lg), r0, a0, a1;
+    {
+        r0 = (unsigned)(prow * 128 + ((lg ^ swz2(prow)) << 4));
+        const int i = lane & 15, g1 = (lane >> 4) & 1;
+        unsigned a[2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int ql = 8 * lg + 4 * jj + (i >> 2);
+            const int ch = 2 * g1 + ((i & 3) >> 1);
+            a[jj] = (unsigned)(ql * 128 + ((ch ^ swz2(ql)) << 4) + (i & 1) * 8);
+        }
+        a0 = a[0]; a1 = a[1];
+    }
+    stage(0, 0); stage(1, 1); stage(2, 2);
+    const int lt = nt - 1 < 3 ? nt - 1 : 3;
+    const unsigned long long b0 = (unsigned long long)(Qg + (long)lt * TB * 64), b1 = (unsigned long long)(Og + (long)lt * TB * 64);
+    const unsigned long long b2 = (unsigned long long)(NLt + (long)lt * 2 * TB);
+    const unsigned long long p0 = (unsigned long long)(p.k + bh * p.S_pad * 64), p1 = (unsigned long long)(p.v + bh * p.S_pad * 64);
+    asm volatile(ABWD64X2_DKV2_ASM
+                 : [la] "+v"(la), [r0] "+v"(r0), [a0] "+v"(a0), [a1] "+v"(a1)
+                 : [g0] "v"(g0), [g2] "v"(g2), [grow0] "v"(grow0), [grow1] "v"(grow1), [b0] "s"(b0), [b1] "s"(b1), [b2] "s"(b2), [p0] "s"(p0),
+                   [p1] "s"(p1), [nt] "s"(nt), [wv] "s"(wave)
+                 : ABWD64X2_DKV2_CLOBBERS);
+    f32x16 dk0[2], dv0[2], dk1[2], dv1[2];
+    ABWD64X2_READ_ACC_0(dv0[0]) ABWD64X2_READ_ACC_16(dv0[1]) ABWD64X2_READ_ACC_32(dk0[0]) ABWD64X2_READ_ACC_48(dk0[1])
+    ABWD64X2_READ_ACC_64(dv1[0]) ABWD64X2_READ_ACC_80(dv1[1]) ABWD64X2_READ_ACC_96(dk1[0]) ABWD64X2_READ_ACC_112(dk1[1])
+    __syncthreads();
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    char* ob = smem + wave * 4096;
+    const int row0 = kblk * KB + wave * 64;
+    store_rows(dk0, LN2, ob, p.dk + bh * p.S_pad * 64, row0, p.S, lane_e);
+    store_rows(dv0, 1.0f, ob, p.dv + bh * p.S_pad * 64, row0, p.S, lane_e);
+    store_rows(dk1, LN2, ob, p.dk + bh * p.S_pad * 64, row0 + 32, p.S, lane_e);
+    store_rows(dv1, 1.0f, ob, p.dv + bh * p.S_pad * 64, row0 + 32, p.S, lane_e);
+}
+
+__global__ __launch_bounds__(NWAVES * 64, 1) void attn_bwd_dq_pipe2_kernel(AttnBwdParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, lg = lane >> 5;
+    constexpr int QB = 64 * NWAVES;
+    const int nqb = (p.S + QB - 1) / QB;
+    const int nwg = nqb * p.H * p.B;
+    int wid = blockIdx.x;
+    {
+        const int q8 = nwg >> 3, r8 = nwg & 7, xcd = wid & 7;
+        wid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (wid >> 3);
+    }
+    const int qblk = wid % nqb;
+    const long bh = wid / nqb;
+    if ((unsigned)(size_t)(__attribute__((address_space(3))) char*)smem != 0u) __builtin_trap();
+    const bf16_t* Kg = p.k + bh * p.S_pad * 64;
+    const bf16_t* Vg = p.v + bh * p.S_pad * 64;
+    const int q0 = qblk * QB + wave * 64 + lq, q1 = q0 + 32;
+    const int ql0 = q0 < p.S ? q0 : p.S - 1, ql1 = q1 < p.S ? q1 : p.S - 1;
+    const int nt = (p.S + TB - 1) / TB;
+    const int srow = wave * 8 + (lane >> 3);
+    const unsigned g0 = (unsigned)(srow * 128 + (((lane & 7) ^ swz2(srow)) << 4));
+    const unsigned grow0 = (unsigned)(ql0 * 128 + lg * 16), grow1 = (unsigned)(ql1 * 128 + lg * 16);
+    const float nl0 = -p.lse[bh * p.S_pad + ql0], nd0 = -p.delta[bh * p.S_pad + ql0];
+    const float nl1 = -p.lse[bh * p.S_pad + ql1], nd1 = -p.delta[bh * p.S_pad + ql1];
+    auto stage = [&](int t, int buf) {
+        const int tt = t < nt ? t : nt - 1;
+        char* base = smem + buf * ST2T;
+        stage_tile2<NWAVES>(Kg + (long)tt * TB * 64, 64, base, wave, lane);
+        stage_tile2<NWAVES>(Vg + (long)tt * TB * 64, 64, base + TILE, wave, lane);
+    };
+    const int prow = row_perm(lq);
+    unsigned r0, a0, a1, a2, a3;
+    {
+        r0 = (unsigned)(prow * 128 + ((lg ^ swz2(prow)) << 4));
+        const int i = lane & 15, g1 = (lane >> 4) & 1;
+        unsigned a[4];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int kl = 8 * lg + 4 * jj + (i >> 2);
+                const int ch = 4 * db + 2 * g1 + ((i & 3) >> 1);
+                a[db * 2 + jj] = (unsigned)(kl * 128 + ((ch ^ swz2(kl)) << 4) + (i & 1) * 8);
+            }
+        a0 = a[0]; a1 = a[1]; a2 = a[2]; a3 = a[3];
+    }
+    stage(0, 0); stage(1, 1); stage(2, 2);
+    const int lt = nt - 1 < 3 ? nt - 1 : 3;
+    const unsigned long long b0 = (unsigned long long)(Kg + (long)lt * TB * 64), b1 = (unsigned long long)(Vg + (long)lt * TB * 64);
+    const unsigned long long p0 = (unsigned long long)(p.q + bh * p.S_pad * 64), p1 = (unsigned long long)(p.doh + bh * p.S_pad * 64);
+    asm volatile(ABWD64X2_DQ2_ASM
+                 : [r0] "+v"(r0), [a0] "+v"(a0), [a1] "+v"(a1), [a2] "+v"(a2), [a3] "+v"(a3)
+                 : [g0] "v"(g0), [grow0] "v"(grow0), [grow1] "v"(grow1), [nl0] "v"(nl0), [nd0] "v"(nd0), [nl1] "v"(nl1), [nd1] "v"(nd1), [b0] "s"(b0),
+                   [b1] "s"(b1), [p0] "s"(p0), [p1] "s"(p1), [nt] "s"(nt), [wv] "s"(wave)
+                 : ABWD64X2_DQ2_CLOBBERS);
+    f32x16 dqa[2], dqb[2];
+    ABWD64X2_READ_ACC_0(dqa[0]) ABWD64X2_READ_ACC_16(dqa[1]) ABWD64X2_READ_ACC_32(dqb[0]) ABWD64X2_READ_ACC_48(dqb[1])
+    __syncthreads();
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    char* ob = smem + wave * 4096;
+    store_rows(dqa, LN2, ob, p.dq + bh * p.S_pad * 64, qblk * QB + wave * 64, p.S, lane_e);
+    store_rows(dqb, LN2, ob, p.dq + bh * p.S_pad * 64, qblk * QB + wave * 64 + 32, p.S, lane_e);
+}
+
 }  // namespace
 
 static int g_attn_bwd_pipe = 1;      // mi355_tune_set(43, .): 1 = the software-pipelined passes (round 6), 0 = the round-3 kernels
@@ -585,6 +726,18 @@ hipError_t launch_attention_bwd(const AttnBwdParams& p, hipStream_t stream) {
         attr_set = true;
     }
     const int nb = (p.S + 32 * NWAVES - 1) / (32 * NWAVES);
+    if (g_attn_bwd_pipe == 6) {      // two 32-row blocks per wave, one workgroup per CU
+        static bool attr_set3 = false;
+        if (!attr_set3) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_dkv_pipe2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NST1 * ST1T);
+            if (e != hipSuccess) return e;
+            attr_set3 = true;
+        }
+        const int nb2 = (p.S + 64 * NWAVES - 1) / (64 * NWAVES);
+        hipLaunchKernelGGL(attn_bwd_dkv_pipe2_kernel, dim3(nb2 * p.H * p.B), dim3(NWAVES * 64), NST1 * ST1T, stream, p);
+        hipLaunchKernelGGL(attn_bwd_dq_pipe2_kernel, dim3(nb2 * p.H * p.B), dim3(NWAVES * 64), NST2 * ST2T, stream, p);
+        return hipGetLastError();
+    }
     if (g_attn_bwd_pipe) {
         void (*dkv)(AttnBwdParams) = g_attn_bwd_pipe == 2 ? attn_bwd_dkv_pipe_kernel<1> : g_attn_bwd_pipe == 3 ? attn_bwd_dkv_pipe_kernel<2>
                                      : g_attn_bwd_pipe == 4 ? attn_bwd_dkv_pipe_kernel<3> : g_attn_bwd_pipe == 5 ? attn_bwd_dkv_pipe_kernel<4>

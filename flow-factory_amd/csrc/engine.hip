@@ -1088,7 +1088,7 @@ extern "C" int mi355_tune_set(int key, int value) {
     if (key == 39) { g_wgrad_tn = value; set_wgrad_tn_mode(value); return 0; }           // optimize() backward: 1 (default) = weight-gradient GEMMs read dY / X row-major through transposed LDS reads (2: 256 x 256 tiles where they fit), 0 = transposed copies
     if (key == 43) {      // (values 2..5: ablation builds of the dK/dV loop -- no VALU / no LDS reads / no barrier + loads / MFMAs only; WRONG results, measurement only)
         const char* ok = getenv("MI355_ALLOW_ABLATION");
-        if (value > 1 && !(ok && ok[0] == '1')) return fail("mi355_tune_set(43, %d): ablation builds produce wrong gradients; set MI355_ALLOW_ABLATION=1 for a timing measurement", value);
+        if (value > 1 && value < 6 && !(ok && ok[0] == '1')) return fail("mi355_tune_set(43, %d): ablation builds produce wrong gradients; set MI355_ALLOW_ABLATION=1 for a timing measurement", value);
         set_attn_bwd_pipe(value); return 0;
     }         if (key == 44) { set_attn128_bwd_pipe(value); return 0; }  // head_dim-128 attention backward: 1 (default) = software-pipelined passes (gen_attn_bwd128.py), 0 = the round-4 kernels
     if (key == 40) { set_w6_mode(value); return 0; }           // 256x192-tile GEMM kernel (round 6): 0 off (default: measured slower inside the two-stream forward), 1 cost rule, 2 wherever it applies

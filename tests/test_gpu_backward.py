@@ -75,6 +75,16 @@ def test_attention_backward_matches_autograd(gpu, B, H, S):
         lib.mi355_tune_set(43, 1)
     for name, a, b in (("dq", dq, dq0), ("dk", dk, dk0), ("dv", dv, dv0)):
         assert torch.equal(a, b), (name, float((a.float() - b.float()).abs().max()))
+    # the two-row-block form (csrc/gen_attn_bwd64x2.py: 64 keys / queries per wave, one wave per SIMD; mi355_tune_set(43, 6)): the same bits again
+    try:
+        _lib.check(lib.mi355_tune_set(43, 6))
+        dq2, dk2, dv2 = torch.zeros_like(q), torch.zeros_like(q), torch.zeros_like(q)
+        _lib.check(lib.mi355_op_attention_fwd_bwd(_stream(), _ptr(q), _ptr(k), _ptr(vT), _ptr(do), _ptr(o), _ptr(dq2), _ptr(dk2), _ptr(dv2),
+                                                  B, H, S, S_pad), "op_attention_fwd_bwd")
+    finally:
+        lib.mi355_tune_set(43, 1)
+    for name, a, b in (("dq", dq2, dq0), ("dk", dk2, dk0), ("dv", dv2, dv0)):
+        assert torch.equal(a, b), (name + " (two-row-block form)", float((a.float() - b.float()).abs().max()))
     for _ in range(2):
         dq1, dk1, dv1 = torch.zeros_like(q), torch.zeros_like(q), torch.zeros_like(q)
         _lib.check(lib.mi355_op_attention_fwd_bwd(_stream(), _ptr(q), _ptr(k), _ptr(vT), _ptr(do), _ptr(o), _ptr(dq1), _ptr(dk1), _ptr(dv1),
