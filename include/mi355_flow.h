@@ -559,7 +559,8 @@ int mi355_profile_enable(int on);
  *  40-42  256x192-tile GEMM kernel (gemm_w6_kernel): 40 = 0 off (default: 16-20 % faster back to back, 2.4 % slower inside the two-stream forward),
  *         1 by its cost rule, 2 wherever it applies; 41 margin in percent (105); 42 smallest grid (200).  Bit-identical for every value.
  *  43     head_dim-64 attention backward: 1 (default) = the software-pipelined passes (csrc/gen_attn_bwd64.py), 0 = the round-3 kernels
- *         (bit-identical); 2..5 = ablation builds of the dK/dV loop (WRONG results; refused without MI355_ALLOW_ABLATION=1).
+ *         (bit-identical); 2..5 = ablation builds of the dK/dV loop (WRONG results; refused without MI355_ALLOW_ABLATION=1); 6 = the two-row-block
+ *         form (64 keys / queries per wave, one wave per SIMD: bit-identical, measured equal -- csrc/gen_attn_bwd64x2.py).
  *  44     head_dim-128 attention backward (FLUX.1 / Qwen-Image / Wan): 1 (default) = the software-pipelined passes (csrc/gen_attn_bwd128.py),
  *         0 = the round-4 kernels (bit-identical).
  * The environment variable MI355_TUNE="key=value,..." applies these settings when the Python binding loads the library. */
