@@ -510,6 +510,12 @@ __global__ __launch_bounds__(NWAVES * 64, 1) void attn128_bwd_dkv_pipe_kernel(At
     f32x16 dk[4], dv[4];
     ABWD128_READ_ACC_0(dv[0]) ABWD128_READ_ACC_16(dv[1]) ABWD128_READ_ACC_32(dv[2]) ABWD128_READ_ACC_48(dv[3])
     ABWD128_READ_ACC_64(dk[0]) ABWD128_READ_ACC_80(dk[1]) ABWD128_READ_ACC_96(dk[2]) ABWD128_READ_ACC_112(dk[3])
+    // a key beyond its sample's key count (ragged text): its P column is zero in every tile -- the loop masks the last tile only, so the lane's
+    // sums are dropped here instead (the round-4 kernel's rows for such keys are exact zeros too)
+    if (key >= Skv) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dk[j] = (f32x16){0}; dv[j] = (f32x16){0}; }
+    }
     __syncthreads();     // every wave is done with the ring (the asm ends with vmcnt(0)): reuse it for the output transposes (8 KiB per wave)
     int lane_e = lane;   // (an opaque copy: the epilogue's lane arithmetic must not be formed in front of the loop -- see attention_bwd.hip)
     asm volatile("" : "+v"(lane_e));

@@ -9,7 +9,8 @@ per 32-row half h:  A = the S and dP chains (8 k-steps each: 16 MFMAs),  V = 16 
 products (dV^T, dK^T: 16 MFMAs; dQ^T: 8).  These kernels run ONE wave per SIMD (512 registers: 128 / 64 accumulator registers), so nothing
 but the wave's own instruction order can put VALU work under MFMAs: the round-4 kernels issue both halves' chains back to back and overlap
 half of the exp / pack arithmetic; here every MFMA gap of a body carries fillers of another half.  Same MFMAs, operand order and accumulation
-order per output element as the round-4 kernels, same masks (queries >= S / keys >= the sample's key count get P = 0): BIT-IDENTICAL
+order per output element as the round-4 kernels, same masks where they can act (the last tile: queries >= S / keys >= the sample's key count
+get P = 0; the loop's other tiles run a copy of the body without the 32 mask instructions per half): BIT-IDENTICAL
 (tests/test_gpu_flux_backward.py compares the two).
 
 Registers (fixed).  S / dP of consecutive halves alternate between X and Y:
@@ -109,15 +110,17 @@ def dkv():
                         out.append(f"ds_read_b64_tr_b16 {vr(TR + 32 * dh + 16 * hs + blk + 2 * i, 2)}, {taddr(i)} offset:{off + 2048 * hs + 4096 * qb}")
         return out
 
-    def valu(c, qb):
+    def valu(c, qb, masked=True):
         g = {}
         def put(gap, ins):
             g.setdefault(gap, []).append(ins)
-        for r, lst in masks(qb).items():
-            put(r, lst[0])
+        if masked:
+            for r, lst in masks(qb).items():
+                put(r, lst[0])
         for r in range(16):
             put(r + 1, f"v_exp_f32 {vr(c + r)}, {vr(c + r)}")
-            put(r + 3, f"v_cndmask_b32_e64 {vr(c + r)}, 0, {vr(c + r)}, {sr(MK + 2 * r)}")
+            if masked:
+                put(r + 3, f"v_cndmask_b32_e64 {vr(c + r)}, 0, {vr(c + r)}, {sr(MK + 2 * r)}")
         for j in range(8):
             put(2 * j + 6, f"v_pk_mul_f32 {vr(c + 16 + 2 * j, 2)}, {vr(c + 16 + 2 * j, 2)}, {vr(c + 2 * j, 2)}")
             lo = 9 if j < 4 else 17                      # behind the MFMAs of B that read the old packed values (m0..m7 / m8..m15)
@@ -188,15 +191,17 @@ def dq():
                     out.append(f"ds_read_b64_tr_b16 {vr(TR + 16 * dh + 8 * hs + 2 * i, 2)}, {taddr(i)} offset:{dh * SUB + 2048 * hs + 4096 * kb}")
         return out
 
-    def valu(c, kb):
+    def valu(c, kb, masked=True):
         g = {}
         def put(gap, ins):
             g.setdefault(gap, []).append(ins)
-        for r, lst in masks(kb).items():
-            put(r, lst[0])
+        if masked:
+            for r, lst in masks(kb).items():
+                put(r, lst[0])
         for r in range(16):
             put(r + 1, f"v_exp_f32 {vr(c + r)}, {vr(c + r)}")
-            put(r + 3, f"v_cndmask_b32_e64 {vr(c + r)}, 0, {vr(c + r)}, {sr(MK + 2 * r)}")
+            if masked:
+                put(r + 3, f"v_cndmask_b32_e64 {vr(c + r)}, 0, {vr(c + r)}, {sr(MK + 2 * r)}")
         for j in range(8):
             put(2 * j + 6, f"v_pk_mul_f32 {vr(c + 16 + 2 * j, 2)}, {vr(c + 16 + 2 * j, 2)}, {vr(c + 2 * j, 2)}")
             put(max(2 * j + 7, 5 if j < 4 else 9), f"v_cvt_pk_bf16_f32 {vr(PZ + j)}, {vr(c + 16 + 2 * j)}, {vr(c + 16 + 2 * j + 1)}")
@@ -246,7 +251,7 @@ def sync(P):
     return out
 
 
-def body(P, cur, nxt, has_B, has_A, qb_cur, qb_A, qb_T, pre=()):
+def body(P, cur, nxt, has_B, has_A, qb_cur, qb_A, qb_T, pre=(), masked=True):
     """B(h-1) || V(h) on buffer cur (half qb_cur of its tile: the mask constants) || A(h+1) into nxt (reads: half qb_A of the A-side tile);
     transposed reads of half h (qb_T = qb_cur)."""
     fill = {}
@@ -255,7 +260,7 @@ def body(P, cur, nxt, has_B, has_A, qb_cur, qb_A, qb_T, pre=()):
     if has_A:
         for gp, ins in zip(P.rdA_gaps, P.rd_A(nxt, qb_A)):
             put(gp, ins)
-    for gp, lst in sorted(P.valu(cur, qb_cur).items()):
+    for gp, lst in sorted(P.valu(cur, qb_cur, masked).items()):
         for ins in lst:
             put(gp, ins)
     for gp, ins in zip(P.rdT_gaps, P.rd_T(qb_T)):
@@ -309,12 +314,20 @@ def main_loop(P):
     L += ["s_nop 15", "s_nop 15"]
     L += body(P, X, Y, False, True, 0, 1, 0)
     # nt - 1 iterations: sync(t + 1) | body(2t + 1) on Y (A-side addresses -> tile t + 1) | body(2t + 2) on X (transposed side, masks -> tile t + 1)
+    # The masks (32 VALU instructions per half) only matter in the LAST tile -- rows beyond S / keys beyond the sample's key count -- (a lane whose
+    # own key is masked in the dK/dV pass is zeroed by the shell at the end): nt - 2 unmasked iterations, then one whose second body is masked.
     L.append(f"s_cmp_eq_u32 s{S_CNT}, 0")
     L.append(f"s_cbranch_scc1 L_{P.name}128_tail%=")
+    L.append(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    L.append(f"s_cmp_eq_u32 s{S_CNT}, 0")
+    L.append(f"s_cbranch_scc1 L_{P.name}128_last%=")
     L.append(f"L_{P.name}128_loop%=:")
-    L += body(P, Y, X, True, True, 1, 0, 1, pre=sync(P) + ring_step(P, S_STA, P.a_addrs, derive_A()))
-    L += body(P, X, Y, True, True, 0, 1, 0, pre=ring_step(P, S_STT, P.t_addrs, derive_T(), extra=["v_subrev_u32 %[vrem], 64, %[vrem]"]))
+    L += body(P, Y, X, True, True, 1, 0, 1, pre=sync(P) + ring_step(P, S_STA, P.a_addrs, derive_A()), masked=False)
+    L += body(P, X, Y, True, True, 0, 1, 0, pre=ring_step(P, S_STT, P.t_addrs, derive_T(), extra=["v_subrev_u32 %[vrem], 64, %[vrem]"]), masked=False)
     L += [f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1", f"s_cmp_lg_u32 s{S_CNT}, 0", f"s_cbranch_scc1 L_{P.name}128_loop%="]
+    L.append(f"L_{P.name}128_last%=:")
+    L += body(P, Y, X, True, True, 1, 0, 1, pre=sync(P) + ring_step(P, S_STA, P.a_addrs, derive_A()), masked=False)
+    L += body(P, X, Y, True, True, 0, 1, 0, pre=ring_step(P, S_STT, P.t_addrs, derive_T(), extra=["v_subrev_u32 %[vrem], 64, %[vrem]"]))
     L.append(f"L_{P.name}128_tail%=:")
     L += body(P, Y, X, True, False, 1, 0, 1)
     L += ["s_waitcnt lgkmcnt(0)", "s_nop 7"]
